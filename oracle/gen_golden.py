@@ -1,0 +1,298 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz by importing the REAL reference
+(/root/reference) in this container through oracle/ref_shim.py.  Run:
+
+    PYTHONDONTWRITEBYTECODE=1 OMP_NUM_THREADS=1 python oracle/gen_golden.py [case ...]
+
+The .npz files hold only data (inputs + the reference's outputs); the reference itself never
+travels. Every array is float64. Per-iteration detail is stored under keys "it{n}/<name>".
+"""
+import os
+import sys
+import json
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+
+import numpy as np  # noqa: E402
+from i2c.i2c import I2cGraph  # noqa: E402  (the reference)
+from i2c.model import make_env_model  # noqa: E402
+from i2c.exp_types import CubatureQuadrature, GaussHermiteQuadrature  # noqa: E402
+from i2c.inference.quadrature import QuadratureInference  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+FWD_KEYS = ["mu_xu0_f", "sig_xu0_f", "mu_xu1_f", "sig_xu1_f", "mu_x3_f", "sig_x3_f", "J_dyn", "mu_z0_f", "sig_z0_f"]
+BWD_KEYS = ["mu_xu0_m", "sig_xu0_m", "K", "k", "sigK", "mu_z0_m", "sig_z0_m", "mu_x3_m", "sig_x3_m"]
+PF_KEYS = ["mu_xu0_pf", "sig_xu0_pf", "mu_x3_pf", "sig_x3_pf", "mu_z0_pf", "sig_z0_pf"]
+
+
+def _stack(cells, key):
+    arrs = [np.asarray(getattr(c, key), dtype=float) for c in cells]
+    a = np.stack(arrs)
+    if a.ndim == 3 and a.shape[-1] == 1 and key.startswith(("mu_", "k")):
+        a = a[..., 0]  # (T, n, 1) column means -> (T, n)
+    if key in ("mu_z0_f", "mu_z0_m", "mu_z0_pf") and a.ndim == 3:
+        a = a.reshape(a.shape[0], -1)
+    return a
+
+
+def capture(g, keys):
+    return {k: _stack(g.cells, k) for k in keys}
+
+
+def run_em(g, n_detail, n_total, out, pre_propagate=False):
+    """Replicates I2cGraph.learn_msgs (i2c.py:1238-1245) with capture points in between."""
+    if pre_propagate:
+        g.propagate()
+    for it in range(1, n_total + 1):
+        g.em_iter += 1
+        g._forward_msgs()
+        if it <= n_detail:
+            for k, v in capture(g, FWD_KEYS).items():
+                out[f"it{it}/{k}"] = v
+        g._backward_msgs()
+        if it <= n_detail:
+            for k, v in capture(g, BWD_KEYS).items():
+                out[f"it{it}/{k}"] = v
+            c = g.cells[-1]
+            if c.mu_z3_m is not None:
+                out[f"it{it}/mu_z3_m"] = np.asarray(c.mu_z3_m, dtype=float).reshape(-1)
+                out[f"it{it}/sig_z3_m"] = np.asarray(c.sig_z3_m, dtype=float)
+        if g._propagate:
+            g.propagate()
+            if it <= n_detail:
+                for k, v in capture(g, PF_KEYS).items():
+                    out[f"it{it}/{k}"] = v
+        g._maximize()
+    out["alphas"] = np.asarray(g.alphas, dtype=float)
+    out["alphas_desired"] = np.asarray(g.alphas_desired, dtype=float)
+    out["costs_m"] = np.asarray(g.costs_m, dtype=float)
+    out["costs_m_var"] = np.asarray(g.costs_m_var, dtype=float)
+    out["costs_pf"] = np.asarray(g.costs_pf, dtype=float)
+    if g._propagate:
+        out["alphas_pf"] = np.asarray(g.alphas_pf, dtype=float)
+        out["costs_pf_var"] = np.asarray(g.costs_pf_var, dtype=float)
+    if len(g.kl_terms):
+        out["kl_terms"] = np.asarray(g.kl_terms, dtype=float)
+    K, k, sigK = g.get_local_linear_policy()
+    out["final/K"], out["final/k"], out["final/sigK"] = K, k, sigK
+    mu, sig = g.get_marginal_state_action_distribution()
+    out["final/mu_xu0_m"], out["final/sig_xu0_m"] = mu, sig
+    out["final/mu_z0_m"] = g.get_marginal_observed_trajectory()[0]
+
+
+def problem_inputs(model_name, model, T, Q, R, Qf, alpha, tol, mu_u, sig_u, mu_x_term, sig_x_term, quad, **extra):
+    meta = dict(model=model_name, T=int(T), alpha=float(alpha), tol=float(tol), quad=list(map(float, quad)))
+    meta.update(extra)
+    d = {
+        "meta": np.array(json.dumps(meta)),
+        "R": np.asarray(R, float),
+        "mu_u": np.asarray(mu_u, float),
+        "sig_u": np.asarray(sig_u, float),
+        "x0": np.asarray(model.x0, float).reshape(-1),
+        "sig_x0": np.asarray(model.sig_x0, float),
+        "sig_eta": np.asarray(model.sig_eta, float),
+    }
+    if Q is not None:
+        d["Q"] = np.asarray(Q, float)
+    if Qf is not None:
+        d["Qf"] = np.asarray(Qf, float)
+    if mu_x_term is not None:
+        d["mu_x_term"] = np.asarray(mu_x_term, float)
+        d["sig_x_term"] = np.asarray(sig_x_term, float)
+    return d
+
+
+def save(name, out):
+    os.makedirs(GOLDEN, exist_ok=True)
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KiB, {len(out)} arrays")
+
+
+# --------------------------------------------------------------------------------------
+def case_pendulum(T=200, n_detail=3, n_total=30, seed=0, quad=(1, 0, 0), name="em_pendulum_T200"):
+    """scripts/experiments/pendulum_known_quad.py:22-33 hyper-parameters at horizon T."""
+    np.random.seed(seed)
+    mu_u = 1e-2 * np.random.randn(T, 1)
+    Q, R, Qf = np.diag([1, 100.0, 1]), np.diag([2.0]), np.diag([1, 100.0, 1])
+    model = make_env_model("PendulumKnown", None)
+    g = I2cGraph(model, T, Q, R, Qf, 100.0, 0.0, mu_u, 2.0 * np.eye(1), None, None, CubatureQuadrature(*quad))
+    out = problem_inputs("PendulumKnown", model, T, Q, R, Qf, 100.0, 0.0, mu_u, 2.0 * np.eye(1), None, None, quad, seed=seed)
+    run_em(g, n_detail, n_total, out)
+    save(name, out)
+
+
+def case_pendulum_long():
+    case_pendulum(T=200, n_detail=0, n_total=200, seed=0, name="em_pendulum_T200_run200")
+
+
+def case_pendulum_general_weights():
+    case_pendulum(T=40, n_detail=2, n_total=6, seed=3, quad=(1.2, 0.44, 0.5), name="em_pendulum_T40_quad_general")
+
+
+def case_double_cartpole(T=60, n_detail=2, n_total=10, name="em_dcp_T60"):
+    """scripts/experiments/double_cartpole_known_cq.py:23-39 hyper-parameters."""
+    np.random.seed(0)
+    mu_u = 1e-2 * np.random.randn(T, 1)
+    sf = 1e-3
+    Q = sf * np.diag([1.0, 1.0, 100.0, 1.0, 100.0, 10.0, 1.0, 1.0])
+    R = sf * np.diag([0.1])
+    model = make_env_model("DoubleCartpoleKnown", None)
+    g = I2cGraph(model, T, Q, R, Q, 0.05, 0.99, mu_u, np.eye(1), None, None, CubatureQuadrature(1, 0, 0))
+    out = problem_inputs("DoubleCartpoleKnown", model, T, Q, R, Q, 0.05, 0.99, mu_u, np.eye(1), None, None, (1, 0, 0), seed=0)
+    run_em(g, n_detail, n_total, out)
+    save(name, out)
+
+
+def case_double_cartpole_T300():
+    case_double_cartpole(T=300, n_detail=0, n_total=20, name="em_dcp_T300_run20")
+
+
+def case_cartpole(T=100, n_detail=2, n_total=10):
+    """scripts/experiments/cartpole_known_quad.py:24-35."""
+    np.random.seed(0)
+    mu_u = 1e-3 * np.random.randn(T, 1)
+    Q = np.diag([1.0, 1.0, 100.0, 10.0, 1.0])
+    R = np.diag([1.0])
+    model = make_env_model("CartpoleKnown", None)
+    g = I2cGraph(model, T, Q, R, Q, 80.0, 0.0, mu_u, np.eye(1), None, None, CubatureQuadrature(1, 0, 0))
+    out = problem_inputs("CartpoleKnown", model, T, Q, R, Q, 80.0, 0.0, mu_u, np.eye(1), None, None, (1, 0, 0), seed=0)
+    run_em(g, n_detail, n_total, out)
+    save("em_cartpole_T100", out)
+
+
+def case_linear(T=60, n_detail=2, n_total=10, noise=1e-4):
+    """scripts/experiments/linear_known_quad.py:21-33 with non-degenerate noise."""
+    mu_u = np.zeros((T, 1))
+    Q, R = np.diag([10.0, 10.0]), np.diag([1.0])
+    model = make_env_model("LinearKnown", None)
+    model.sig_x0 = noise * np.eye(2)
+    model.sig_eta = noise * np.eye(2)
+    g = I2cGraph(model, T, Q, R, Q, 800.0, 0.0, mu_u, np.eye(1), None, None, CubatureQuadrature(1, 0, 0))
+    out = problem_inputs("LinearKnown", model, T, Q, R, Q, 800.0, 0.0, mu_u, np.eye(1), None, None, (1, 0, 0), noise=noise)
+    run_em(g, n_detail, n_total, out)
+    save("em_linear_T60", out)
+
+
+def case_covariance_control(T=100, n_detail=3, n_total=30):
+    """scripts/nonlinear_covariance_control.py:81-124 + experiments/pendulum_known_act_reg_quad.py."""
+    mu_u = np.zeros((T, 1))
+    R = np.diag([1.0])
+    mu_xt, sig_xt = np.array([0.0, 0.0]), np.diag([1e-3, 1e-3])
+    model = make_env_model("PendulumKnownActReg", None)
+    g = I2cGraph(model, T, None, R, None, 300.0, 1.0, mu_u, 0.5 * np.eye(1), mu_xt, sig_xt, CubatureQuadrature(1, 0, 0))
+    for c in g.cells:
+        c.use_expert_controller = False
+    g._propagate = True
+    out = problem_inputs(
+        "PendulumKnownActReg", model, T, None, R, None, 300.0, 1.0, mu_u, 0.5 * np.eye(1), mu_xt, sig_xt, (1, 0, 0),
+        propagate=True, use_expert_controller=False,
+    )
+    run_em(g, n_detail, n_total, out, pre_propagate=True)
+    save("em_covctrl_T100", out)
+
+
+def case_propagate_expert(T=50, n_detail=3, n_total=5):
+    """Closed-loop propagation with the expert (pdf-ratio scaled) controller, i2c.py:160-165,
+    plus calibrate_alpha (i2c.py:895-911) before the EM loop, as mpc_quad.py:624-630 does."""
+    np.random.seed(1)
+    mu_u = 1e-2 * np.random.randn(T, 1)
+    Q, R, Qf = np.diag([1, 100.0, 1]), np.diag([2.0]), np.diag([1, 100.0, 1])
+    model = make_env_model("PendulumKnown", None)
+    g = I2cGraph(model, T, Q, R, Qf, 100.0, 0.5, mu_u, 2.0 * np.eye(1), None, None, CubatureQuadrature(1, 0, 0))
+    g._propagate = True
+    out = problem_inputs(
+        "PendulumKnown", model, T, Q, R, Qf, 100.0, 0.5, mu_u, 2.0 * np.eye(1), None, None, (1, 0, 0),
+        propagate=True, use_expert_controller=True, calibrate_first=True, seed=1,
+    )
+    g.calibrate_alpha()
+    out["alpha_calibrated"] = np.asarray(g.alpha, float)
+    run_em(g, n_detail, n_total, out)
+    save("em_pendulum_T50_propagate", out)
+
+
+def case_quadrature():
+    """QuadratureInference.forward / forward_gaussian unit vectors (quadrature.py:15-58)."""
+    rng = np.random.default_rng(7)
+    out = {}
+    model = make_env_model("PendulumKnown", None)
+    n = 0
+    for quad in [(1, 0, 0), (0.7, 2.0, 0.5), (1.3, 0.0, 1.0)]:
+        for _ in range(4):
+            A = rng.normal(size=(3, 3))
+            S = A @ A.T * 10 ** rng.uniform(-4, 0) + 1e-6 * np.eye(3)
+            m = rng.normal(size=(3, 1)) * np.array([[3.0], [2.0], [1.0]])
+            qi = QuadratureInference(CubatureQuadrature(*quad), 3)
+            m_z, S_z = qi.forward(model.observe, m, S)
+            pre = f"q{n}/"
+            out[pre + "quad"] = np.array(quad, float)
+            out[pre + "m"], out[pre + "S"] = m[:, 0], S
+            out[pre + "x_pts"] = qi.x_pts
+            out[pre + "obs_m"], out[pre + "obs_S"], out[pre + "obs_Sxy"] = m_z[:, 0], S_z, qi.sig_xy
+            m_y, S_y, S_n = qi.forward_gaussian(model.forward, m, S)
+            out[pre + "dyn_m"], out[pre + "dyn_S"], out[pre + "dyn_Sxy"], out[pre + "dyn_noise"] = (
+                m_y[:, 0], S_y, qi.sig_xy, S_n,
+            )
+            n += 1
+    out["n"] = np.array(n)
+    # Gauss-Hermite rule parameters (exp_types.py:52-68)
+    for deg in (2, 3, 4):
+        gh = GaussHermiteQuadrature(deg)
+        out[f"gh{deg}/pts"] = gh.pts(3)
+        sf, w, _ = gh.weights(3)
+        out[f"gh{deg}/sf"], out[f"gh{deg}/w"] = np.array(sf), w
+    qi = QuadratureInference(GaussHermiteQuadrature(3), 3)
+    m = np.array([[0.3], [-0.2], [0.1]])
+    S = np.array([[0.2, 0.05, 0.0], [0.05, 0.1, 0.01], [0.0, 0.01, 0.3]])
+    m_z, S_z = qi.forward(model.observe, m, S)
+    out["gh3/m"], out["gh3/S"], out["gh3/obs_m"], out["gh3/obs_S"], out["gh3/obs_Sxy"] = m[:, 0], S, m_z[:, 0], S_z, qi.sig_xy
+    save("quadrature_vectors", out)
+
+
+def case_models():
+    """Known-model plugins: dynamics / observe / observe_terminal on random inputs."""
+    rng = np.random.default_rng(11)
+    out = {}
+    for name in ["PendulumKnown", "PendulumKnownActReg", "CartpoleKnown", "DoubleCartpoleKnown", "LinearKnown",
+                 "LinearKnownMinimumEnergy"]:
+        m = make_env_model(name, None)
+        xu = rng.normal(size=(32, m.dim_xu)) * 3.0
+        xu[:4, -1] *= 10  # exercise the action clip
+        out[name + "/xu"] = xu
+        dyn, noise = m.forward(xu)
+        out[name + "/dyn"] = dyn
+        out[name + "/noise0"] = noise[0]
+        out[name + "/obs"] = m.observe(xu)
+        zt = m.observe_terminal_x(xu[:, : m.dim_x])
+        if zt is not None:
+            out[name + "/obs_term"] = zt
+        out[name + "/x0"] = np.asarray(m.x0, float).reshape(-1)
+        out[name + "/sig_x0"] = np.asarray(m.sig_x0, float)
+        out[name + "/sig_eta"] = np.asarray(m.sig_eta, float)
+        out[name + "/zg"] = np.asarray(m.zg, float).reshape(-1)
+        out[name + "/zg_term"] = np.asarray(m.zg_term, float).reshape(-1)
+    save("models_vectors", out)
+
+
+CASES = {
+    "pendulum": case_pendulum,
+    "pendulum_long": case_pendulum_long,
+    "pendulum_general": case_pendulum_general_weights,
+    "dcp": case_double_cartpole,
+    "dcp300": case_double_cartpole_T300,
+    "cartpole": case_cartpole,
+    "linear": case_linear,
+    "covctrl": case_covariance_control,
+    "propagate": case_propagate_expert,
+    "quadrature": case_quadrature,
+    "models": case_models,
+}
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or list(CASES)
+    for c in which:
+        CASES[c]()

@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_DIR = os.path.join(ROOT, "input-inference-for-control_amd")
+for p in (ROOT, PKG_DIR, os.path.dirname(os.path.abspath(__file__))):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests are skipped (not failed) when no GPU is visible and -m gpu was not requested."""
+    try:
+        import torch
+
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

@@ -1,0 +1,151 @@
+"""Pins the CPU oracle (oracle/i2c_numpy.py, oracle/models_numpy.py) against vectors captured
+from the REAL reference (oracle/gen_golden.py -> tests/golden). CPU only."""
+import numpy as np
+import pytest
+
+from golden_util import assert_close, load_case, oracle_from_case
+from oracle.i2c_numpy import CubatureRule, GaussHermiteRule, SigmaPointTransform
+from oracle.models_numpy import make_model
+
+FWD = ["mu_xu0_f", "sig_xu0_f", "mu_xu1_f", "sig_xu1_f", "mu_x3_f", "sig_x3_f", "J_dyn", "mu_z0_f", "sig_z0_f"]
+BWD = ["mu_xu0_m", "sig_xu0_m", "K", "k", "sigK", "mu_z0_m", "sig_z0_m", "mu_x3_m", "sig_x3_m"]
+PF = ["mu_xu0_pf", "sig_xu0_pf", "mu_x3_pf", "sig_x3_pf", "mu_z0_pf", "sig_z0_pf"]
+
+
+def test_models_match_reference():
+    g = load_case("models_vectors")
+    for name in ["PendulumKnown", "PendulumKnownActReg", "CartpoleKnown", "DoubleCartpoleKnown", "LinearKnown",
+                 "LinearKnownMinimumEnergy"]:
+        m = make_model(name)
+        xu = g[name + "/xu"]
+        assert_close(m.dynamics(xu), g[name + "/dyn"], 1e-13, name + " dynamics")
+        assert_close(m.observe(xu), g[name + "/obs"], 1e-15, name + " observe")
+        if name + "/obs_term" in g:
+            assert_close(m.observe_terminal(xu[:, : m.dim_x]), g[name + "/obs_term"], 1e-15, name + " obs_term")
+        else:
+            assert m.observe_terminal(xu[:, : m.dim_x]) is None
+        assert_close(m.x0, g[name + "/x0"], 0, name + " x0")
+        assert_close(m.sig_x0, g[name + "/sig_x0"], 0, name + " sig_x0")
+        assert_close(m.sig_eta, g[name + "/sig_eta"], 0, name + " sig_eta")
+        assert_close(m.sig_eta, g[name + "/noise0"], 0, name + " forward noise")
+        assert_close(m.zg, g[name + "/zg"], 0, name + " zg")
+        if name != "PendulumKnownActReg":  # reference zg_term there is the (unused) parent value
+            assert_close(m.zg_term, g[name + "/zg_term"], 0, name + " zg_term")
+
+
+def test_sigma_point_transform_matches_reference():
+    g = load_case("quadrature_vectors")
+    model = make_model("PendulumKnown")
+    for n in range(int(g["n"])):
+        pre = f"q{n}/"
+        tf = SigmaPointTransform(CubatureRule(*g[pre + "quad"]), 3)
+        m, S = g[pre + "m"], g[pre + "S"]
+        assert_close(tf.points(m, S), g[pre + "x_pts"], 1e-14, pre + "x_pts")
+        m_z, S_z, S_xz, _, _ = tf.forward(model.observe, m, S)
+        assert_close(m_z, g[pre + "obs_m"], 1e-13, pre + "obs_m")
+        assert_close(S_z, g[pre + "obs_S"], 1e-12, pre + "obs_S")
+        assert_close(S_xz, g[pre + "obs_Sxy"], 1e-12, pre + "obs_Sxy")
+        m_y, S_y, S_xy, _, _ = tf.forward(model.dynamics, m, S)
+        assert_close(m_y, g[pre + "dyn_m"], 1e-13, pre + "dyn_m")
+        assert_close(S_y, g[pre + "dyn_S"], 1e-11, pre + "dyn_S")
+        assert_close(S_xy, g[pre + "dyn_Sxy"], 1e-11, pre + "dyn_Sxy")
+        assert_close(tf.w.sum() * model.sig_eta, g[pre + "dyn_noise"], 1e-15, pre + "dyn_noise")
+
+
+def test_gauss_hermite_rule_matches_reference():
+    g = load_case("quadrature_vectors")
+    for deg in (2, 3, 4):
+        r = GaussHermiteRule(deg)
+        assert_close(r.points(3), g[f"gh{deg}/pts"], 1e-15)
+        sf, _, w = r.weights(3)
+        assert_close(sf, g[f"gh{deg}/sf"], 1e-15)
+        assert_close(w, g[f"gh{deg}/w"], 1e-14)
+    tf = SigmaPointTransform(GaussHermiteRule(3), 3)
+    m_z, S_z, S_xz, _, _ = tf.forward(make_model("PendulumKnown").observe, g["gh3/m"], g["gh3/S"])
+    assert_close(m_z, g["gh3/obs_m"], 1e-13)
+    assert_close(S_z, g["gh3/obs_S"], 1e-12)
+    assert_close(S_xz, g["gh3/obs_Sxy"], 1e-12)
+
+
+def _run_and_check(name, tol_detail, tol_summary, n_iters=None):
+    g = load_case(name)
+    o = oracle_from_case(g)
+    meta = g.meta
+    if meta.get("calibrate_first"):
+        o.calibrate_alpha()
+        assert_close(o.alpha[0], g["alpha_calibrated"], 1e-10, "calibrated alpha")
+    elif meta.get("propagate"):
+        o.propagate()  # nonlinear_covariance_control.py:113 runs propagate() once before the loop
+    detail = set(g.iters())
+    n_total = len(g["costs_m"]) if n_iters is None else n_iters
+    for it in range(1, n_total + 1):
+        o.em_iter += 1
+        o.forward_sweep()
+        if it in detail:
+            for k in FWD:
+                assert_close(getattr(o, k)[0], g.at(it, k), tol_detail, f"{name} it{it} {k}")
+        o.backward_sweep()
+        if it in detail:
+            for k in BWD:
+                assert_close(getattr(o, k)[0], g.at(it, k), tol_detail, f"{name} it{it} {k}")
+            if g.has(it, "mu_z3_m"):
+                assert_close(o.mu_z3_m[0], g.at(it, "mu_z3_m"), tol_detail, f"{name} it{it} mu_z3_m")
+                assert_close(o.sig_z3_m[0], g.at(it, "sig_z3_m"), tol_detail, f"{name} it{it} sig_z3_m")
+        if o._propagate:
+            o.propagate()
+            if it in detail:
+                for k in PF:
+                    assert_close(getattr(o, k)[0], g.at(it, k), tol_detail, f"{name} it{it} {k}")
+        o.maximize()
+    n = n_total
+    assert_close(np.array(o.alphas)[: n + 1, 0], g["alphas"][: n + 1], tol_summary, name + " alphas")
+    assert_close(np.array(o.alphas_desired)[: n + 1, 0], g["alphas_desired"][: n + 1], tol_summary, name + " alphas_desired")
+    assert_close(np.array(o.costs_m)[:n, 0], g["costs_m"][:n], tol_summary, name + " costs_m")
+    assert_close(np.array(o.costs_m_var)[:n, 0], g["costs_m_var"][:n], tol_summary, name + " costs_m_var")
+    assert_close(np.array(o.costs_pf)[:n, 0], g["costs_pf"][:n], tol_summary, name + " costs_pf")
+    if "kl_terms" in g:
+        assert_close(np.array(o.kl_terms)[:n, 0], g["kl_terms"][:n], tol_summary * 10, name + " kl_terms")
+    if "alphas_pf" in g:
+        assert_close(np.array(o.alphas_pf)[: n + 1, 0], g["alphas_pf"][: n + 1], tol_summary, name + " alphas_pf")
+    if n == len(g["costs_m"]):
+        assert_close(o.K[0], g["final/K"], tol_summary, name + " final K")
+        assert_close(o.k[0], g["final/k"], tol_summary, name + " final k")
+        assert_close(o.sigK[0], g["final/sigK"], tol_summary, name + " final sigK")
+        assert_close(o.mu_xu0_m[0], g["final/mu_xu0_m"], tol_summary, name + " final mu_xu0_m")
+        assert_close(o.sig_xu0_m[0], g["final/sig_xu0_m"], tol_summary, name + " final sig_xu0_m")
+    return o, g
+
+
+def test_em_pendulum_T200():
+    _run_and_check("em_pendulum_T200", 1e-9, 1e-8)
+
+
+def test_em_pendulum_general_weights():
+    _run_and_check("em_pendulum_T40_quad_general", 1e-9, 1e-8)
+
+
+def test_em_double_cartpole_T60():
+    _run_and_check("em_dcp_T60", 1e-8, 1e-7)
+
+
+def test_em_cartpole_T100():
+    _run_and_check("em_cartpole_T100", 1e-8, 1e-7)
+
+
+def test_em_linear_T60():
+    _run_and_check("em_linear_T60", 1e-9, 1e-8)
+
+
+def test_em_covariance_control_T100():
+    _run_and_check("em_covctrl_T100", 1e-8, 1e-7)
+
+
+def test_em_propagate_expert_T50():
+    _run_and_check("em_pendulum_T50_propagate", 1e-9, 1e-8)
+
+
+@pytest.mark.parametrize("name,n", [("em_pendulum_T200_run200", 200), ("em_dcp_T300_run20", 20)])
+def test_em_long_runs(name, n):
+    """Free-running EM against the reference: no teacher forcing (perturbations
+    stay ~1e-11 over 100 iterations)."""
+    _run_and_check(name, 1e-8, 1e-6)
