@@ -1,0 +1,211 @@
+/*
+ * i2c_hip.h -- C ABI of the MI355X (gfx950) batched Gaussian i2c solver.
+ *
+ * The reference (JoeMWatson/input-inference-for-control) is pure Python and has no FFI;
+ * its boundary for this path is the object protocol of I2cGraph / I2cCell (i2c/i2c.py).
+ * Each entry point below replaces the reference method named in its comment for B
+ * independent trajectories at once. All citations are relative to the reference root.
+ *
+ * Conventions
+ *  - No torch / C++ types: plain pointers and sizes. `stream` is a hipStream_t passed as void*.
+ *  - DEVICE buffers are struct-of-arrays with the trajectory index innermost:
+ *      buf[t][e][b]  at element offset (t*E + e)*B + b,
+ *    so that lane b of a wavefront reads element e of step t with one coalesced transaction.
+ *    Element type = I2cProblem.dtype (I2C_F64: double, I2C_F32: float).
+ *  - Symmetric n x n matrices are stored packed, lower triangle, row-major:
+ *      (i,j), i>=j  ->  i*(i+1)/2 + j ;  I2C_SYM(n) = n(n+1)/2 elements.
+ *  - Problem constants shared by the whole batch are small HOST arrays of double inside
+ *    I2cProblem (they travel in the kernel-argument segment).
+ *  - Every function returns 0 on success or a negative I2C_E* code for argument / launch errors.
+ *    Per-trajectory numerical failures (a covariance that is not positive definite -- the
+ *    reference raises LinAlgError from quadrature.py:17-24 or scipy) never abort the batch:
+ *    they are recorded in status[b] = (reason << 16) | (t + 1) for the FIRST failing step.
+ *  - The library keeps no global mutable state; calls on different streams are independent.
+ *    Nothing is allocated or freed by the library: every buffer is owned by the caller.
+ */
+#ifndef I2C_HIP_H
+#define I2C_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define I2C_ABI_VERSION 1
+
+#define I2C_MAX_NX 8
+#define I2C_MAX_NU 4
+#define I2C_MAX_NZ 12
+#define I2C_MAX_PARAMS 16
+#define I2C_SYM(n) ((n) * ((n) + 1) / 2)
+
+/* model plugins (the reference's `sys` objects, i2c/model.py:19-44) */
+enum {
+  I2C_MODEL_PENDULUM = 0,         /* PendulumKnown         env_def.py:233-309, env_autograd.py:5-19   */
+  I2C_MODEL_PENDULUM_ACTREG = 1,  /* PendulumKnownActReg   env_def.py:312-346                          */
+  I2C_MODEL_CARTPOLE = 2,         /* CartpoleKnown         env_def.py:491-612, env_autograd.py:25-54  */
+  I2C_MODEL_DOUBLE_CARTPOLE = 3,  /* DoubleCartpoleKnown   env_def.py:615-761, env_autograd.py:60-167 */
+  I2C_MODEL_LINEAR = 4,           /* LinearKnown           env_def.py:139-191, model.py:226-246       */
+  I2C_MODEL_LINEAR_MINENERGY = 5, /* LinearKnownMinimumEnergy env_def.py:194-230                      */
+  I2C_MODEL_QUADROTOR = 6,        /* build-defined planar quadrotor (Box2D physics is not reproducible) */
+  I2C_NUM_MODELS = 7
+};
+
+enum { I2C_F64 = 0, I2C_F32 = 1 };
+
+enum {
+  I2C_OK = 0,
+  I2C_EINVAL = -1,   /* bad argument (null pointer, unknown model / dtype, B or T < 1) */
+  I2C_ENOTSUP = -2,  /* combination not compiled in */
+  I2C_ELAUNCH = -3   /* HIP launch error (hipGetLastError != hipSuccess) */
+};
+
+/* status[b] reason codes (upper 16 bits) */
+enum {
+  I2C_FAIL_PRIOR_JOINT = 1,   /* chol(sig_xu0_f) failed       (quadrature.py:17-24 via i2c.py:391)   */
+  I2C_FAIL_PDF_RATIO = 2,     /* chol(sig_xx + sig_x0_f)      (scipy mvn, i2c.py:369-374)            */
+  I2C_FAIL_OBS_COV = 3,       /* chol(sig_z0_f + sig_xi)      (la.solve assume_a='pos', i2c.py:398)  */
+  I2C_FAIL_UPDATED_JOINT = 4, /* chol(sig_xu1_f)              (quadrature.py:17-24 via i2c.py:415)   */
+  I2C_FAIL_PRED_COV = 5,      /* chol(sig_x3_f)               (i2c.py:423)                           */
+  I2C_FAIL_TERMINAL = 6,      /* terminal observation update  (i2c.py:430-443, 548-570)              */
+  I2C_FAIL_POSTERIOR = 7,     /* chol(sig_xu0_m)              (quadrature.py:17-24 via i2c.py:594)   */
+  I2C_FAIL_PROPAGATE = 8      /* closed-loop propagation      (i2c.py:196-197)                       */
+};
+
+typedef struct I2cDims {
+  int32_t nx, nu, nz, nzt; /* dim_x, dim_u, dim_z, dim_z_term (nzt = 0: no terminal observation) */
+  int32_t e_post;          /* elements per cell of the posterior buffer  (see I2cPosterior) */
+  int32_t e_fwd;           /* elements per cell of the forward buffer    (see I2cFwdState)  */
+  int32_t e_xm;            /* elements per cell of the smoothed-state buffer: nx + SYM(nx)  */
+  int32_t e_zpost;         /* elements per cell of the optional z-moment buffer: nz + SYM(nz) */
+  int32_t e_prop;          /* elements per cell of the propagation buffer (see I2cProp)     */
+  int32_t n_params;        /* number of doubles the model reads from I2cProblem.model_params */
+} I2cDims;
+
+/*
+ * One optimisation problem = B independent trajectories of the same model and horizon.
+ * Mirrors the constructor of I2cGraph (i2c/i2c.py:735-848) plus the per-cell state that the
+ * reference keeps on I2cCell objects (i2c/i2c.py:81-148).
+ */
+typedef struct I2cProblem {
+  int32_t abi_version; /* = I2C_ABI_VERSION */
+  int32_t model_id;
+  int32_t dtype;
+  int32_t B, T;
+  int32_t has_Qf;          /* terminal cost observation (Qf given, i2c.py:787-793)             */
+  int32_t has_x_terminal;  /* covariance control: terminal state prior (i2c.py:548-559)        */
+  int32_t z_per_cell;      /* 0: target = zg for every cell; 1: device targets `z` [T][nz][B]  */
+  /* CubatureQuadrature(alpha, beta, kappa): i2c/exp_types.py:31-49 */
+  double quad_alpha, quad_beta, quad_kappa;
+  double dtemp;            /* terminal-prior annealing rate (i2c.py:66,552)                    */
+  /* HOST constants (double, packed lower where symmetric) */
+  double sig_eta[I2C_SYM(I2C_MAX_NX)];   /* sys.sig_eta                                          */
+  double sig_xi0[I2C_SYM(I2C_MAX_NZ)];   /* inv(QR)   (i2c.py:786)  -> sig_xi = alpha * sig_xi0  */
+  double QR[I2C_SYM(I2C_MAX_NZ)];        /* blkdiag(Q, R) (i2c.py:781-784)                       */
+  double sig_xiT0[I2C_SYM(I2C_MAX_NZ)];  /* inv(Qf)   (i2c.py:789)                               */
+  double Qf[I2C_SYM(I2C_MAX_NZ)];
+  double zg[I2C_MAX_NZ];                 /* sys.zg      (i2c.py:84)                              */
+  double zg_term[I2C_MAX_NZ];            /* sys.zg_term (i2c.py:85)                              */
+  double mu_x_term[I2C_MAX_NX];          /* mu_x_terminal (i2c.py:797-801)                       */
+  double sig_x_term[I2C_SYM(I2C_MAX_NX)];
+  double model_params[I2C_MAX_PARAMS];   /* model-specific (Linear*: A row-major, B, a)          */
+  /* DEVICE per-trajectory data */
+  const void* x0;       /* [nx][B]        sys.x0       (i2c.py:877)                              */
+  const void* sig_x0;   /* [SYM(nx)][B]   sys.sig_x0   (i2c.py:878)                              */
+  const void* z;        /* [T][nz][B] per-cell targets (mpc.py:29-31) or NULL when !z_per_cell   */
+  void* alpha;          /* [B] temperature; read by the sweeps, updated in place by i2c_mstep    */
+  void* temp;           /* [B] terminal-prior temperature (i2c.py:147,552) or NULL               */
+  const uint8_t* feedforward; /* [T] bytes: 1 = cell in feed-forward mode
+                                 (state_action_independence, i2c.py:132,355,1212-1213)            */
+} I2cProblem;
+
+/*
+ * Posterior + controller buffer, [T][e_post][B]; per cell, in this order:
+ *   mu_xu0_m[d] | sig_xu0_m[SYM(d)] | K[nu*nx] (row-major) | k[nu] | sigK[SYM(nu)]
+ * Written by i2c_backward_sweep (i2c.py:586-608). The forward sweep READS the first
+ * d + SYM(d) + nu*nx elements of `prior` as the previous iteration's posterior and controller
+ * (i2c.py:361-387; after _update_priors, i2c.py:1210-1221, prior joint == posterior, and the
+ * feed-forward action prior mu_u0_f/sig_u0_f is always the u-block of that joint).
+ * Before the first iteration the caller fills it with [x0; mu_u], blkdiag(sig_x0, sig_u), K = 0
+ * (I2cCell.__init__, i2c.py:95-100,135).
+ */
+
+/*
+ * Forward-message buffer, [T][e_fwd][B]; per cell:
+ *   mu_xu1_f[d] | sig_xu1_f[SYM(d)] | mu_x3_f[nx] | sig_x3_f[SYM(nx)] | J_dyn[d*nx] (row-major)
+ * (the quantities I2cCell keeps for the backward pass, i2c.py:402-428).
+ */
+
+/* Smoothed next-state buffer [T][e_xm][B]: mu_x3_m[nx] | sig_x3_m[SYM(nx)] (i2c.py:546-576). */
+
+/* Optional posterior cost-observation moments [T][e_zpost][B]: mu_z0_m[nz] | sig_z0_m[SYM(nz)]. */
+
+/* Query compile-time dimensions of a model. Replaces reading sys.dim_* (env_def.py:34-82). */
+int i2c_query(int model_id, I2cDims* out);
+
+/* Library self-description: ABI version, and the gfx target it was compiled for. */
+int i2c_abi_version(void);
+const char* i2c_build_info(void);
+
+/*
+ * Forward filter over all T cells: replaces I2cGraph._forward_msgs (i2c.py:876-880) calling
+ * I2cCell._forward_msgs_quadrature (i2c.py:350-447) for every cell.
+ *   prior      [T][e_post][B]  in   (see above; only the first d+SYM(d)+nu*nx rows are read)
+ *   fwd        [T][e_fwd][B]   out
+ *   prior_out  [T][d+SYM(d)][B] out, optional (NULL to skip): the joint prior mu_xu0_f,
+ *              sig_xu0_f built in each cell (i2c.py:360,381-387; get_state_action_prior :1191)
+ *   status     [B] int32       in/out (only overwritten where it is 0)
+ */
+int i2c_forward_sweep(const I2cProblem* p, const void* prior, void* fwd, void* prior_out,
+                      int32_t* status, void* stream);
+
+/*
+ * Backward smoother + controller extraction + M-step statistics: replaces
+ * I2cGraph._backward_msgs (i2c.py:882-886) calling I2cCell._backward_msgs_quadrature
+ * (i2c.py:544-610) and the per-cell parts of calc_cost / get_z_covar (i2c.py:1034-1053,
+ * 680-683, 983-992). Two launches: a light sequential scan of the x-marginal recursion (one
+ * lane per trajectory) and a fully parallel per-cell pass (one lane per (t, b)).
+ *   fwd        [T][e_fwd][B]   in
+ *   xm         [T][e_xm][B]    out (workspace that is also a result: mu_x3_m, sig_x3_m)
+ *   post       [T][e_post][B]  out (may alias the `prior` given to the forward sweep)
+ *   zpost      [T][e_zpost][B] out, optional (NULL to skip)
+ *   cell_stats [T][2][B]       out: per-cell expected cost mean m_t and variance v_t
+ *                              (compute_cost_gaussian, i2c.py:1034-1043); m_t is also the cell's
+ *                              contribution tr(QR (err err^T + sig_z0_m)) to alpha (i2c.py:913-919)
+ *   term_stats [3 + nzt + SYM(nzt)][B] out: tr(Qf (errT errT^T + sig_z3_m)) (i2c.py:989-992), two
+ *                              reserved rows, then mu_z3_m, sig_z3_m; zero when !has_Qf
+ */
+int i2c_backward_sweep(const I2cProblem* p, const void* fwd, void* xm, void* post, void* zpost,
+                       void* cell_stats, void* term_stats, int32_t* status, void* stream);
+
+/*
+ * M-step on the temperature: replaces calc_cost's sums, calculate_alpha, update_alpha and
+ * update_xi (i2c.py:913-981, 1045-1053).
+ *   alpha_update_tol  as I2cGraph.alpha_update_tol (>= 0: clamp ratio to [tol, 2 - tol];
+ *                     < 0: keep alpha)
+ *   update            0: only report alpha_hat (compute_update_alpha(False))
+ *   stats_out [4][B]  out: alpha_hat (alphas_desired), alpha after the clamp (alphas),
+ *                     cost mean (costs_m), cost variance (costs_m_var)
+ * p->alpha is updated in place when update != 0.
+ */
+int i2c_mstep(const I2cProblem* p, const void* cell_stats, const void* term_stats,
+              double alpha_update_tol, int update, void* stats_out, void* stream);
+
+/*
+ * Closed-loop propagation of the controller distribution: replaces I2cGraph.propagate
+ * (i2c.py:1247-1251) calling I2cCell._propagate_forward_quadrature (i2c.py:150-199), plus the
+ * per-cell propagated cost statistics (i2c.py:685-688, 1055-1063).
+ *   post       [T][e_post][B]  in  (posterior + controller from i2c_backward_sweep)
+ *   prop       [T][e_prop][B]  out: mu_xu0_pf[d] | sig_xu0_pf[SYM(d)] | mu_x3_pf[nx] | sig_x3_pf[SYM(nx)]
+ *   cell_stats_pf [T][2][B]    out: propagated cost mean / variance per cell
+ *   use_expert_controller      cells' use_expert_controller flag (i2c.py:143,160)
+ */
+int i2c_propagate(const I2cProblem* p, const void* post, void* prop, void* cell_stats_pf,
+                  int use_expert_controller, int32_t* status, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* I2C_HIP_H */

@@ -1,0 +1,141 @@
+"""ctypes binding of the C ABI in include/i2c_hip.h.
+
+The product path loads exactly one library: ``lib/libi2c_hip.so`` (hipcc, gfx950), built
+in-tree by ``__graft_entry__.build()`` / ``build.py``. If it is missing or does not export the
+whole ABI, loading fails loudly -- there is no CPU fallback. (tests/ may hand an explicitly
+built host-simulation library to :func:`load_library` to check kernel numerics on a box
+without a GPU; nothing in the package ever looks for it.)
+"""
+import ctypes as C
+import os
+
+ABI_VERSION = 1
+MAX_NX, MAX_NU, MAX_NZ, MAX_PARAMS = 8, 4, 12, 16
+
+
+def _sym(n):
+    return n * (n + 1) // 2
+
+
+F64, F32 = 0, 1
+
+MODEL_IDS = {
+    "PendulumKnown": 0,
+    "PendulumKnownActReg": 1,
+    "CartpoleKnown": 2,
+    "DoubleCartpoleKnown": 3,
+    "LinearKnown": 4,
+    "LinearKnownMinimumEnergy": 5,
+    "PlanarQuadrotor": 6,
+}
+
+FAIL_REASONS = {
+    1: "prior joint covariance sig_xu0_f is not positive definite",
+    2: "pdf-ratio covariance sig_xx + sig_x0_f is not positive definite",
+    3: "cost-observation covariance sig_z0_f + sig_xi is not positive definite",
+    4: "updated joint covariance sig_xu1_f is not positive definite",
+    5: "predicted state covariance sig_x3_f is not positive definite",
+    6: "terminal observation / terminal prior update failed",
+    7: "posterior joint covariance sig_xu0_m is not positive definite",
+    8: "closed-loop propagation covariance is not positive definite",
+}
+
+
+class I2cDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("nx", "nu", "nz", "nzt", "e_post", "e_fwd", "e_xm", "e_zpost", "e_prop", "n_params")]
+
+
+class I2cProblem(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("model_id", C.c_int32),
+        ("dtype", C.c_int32),
+        ("B", C.c_int32),
+        ("T", C.c_int32),
+        ("has_Qf", C.c_int32),
+        ("has_x_terminal", C.c_int32),
+        ("z_per_cell", C.c_int32),
+        ("quad_alpha", C.c_double),
+        ("quad_beta", C.c_double),
+        ("quad_kappa", C.c_double),
+        ("dtemp", C.c_double),
+        ("sig_eta", C.c_double * _sym(MAX_NX)),
+        ("sig_xi0", C.c_double * _sym(MAX_NZ)),
+        ("QR", C.c_double * _sym(MAX_NZ)),
+        ("sig_xiT0", C.c_double * _sym(MAX_NZ)),
+        ("Qf", C.c_double * _sym(MAX_NZ)),
+        ("zg", C.c_double * MAX_NZ),
+        ("zg_term", C.c_double * MAX_NZ),
+        ("mu_x_term", C.c_double * MAX_NX),
+        ("sig_x_term", C.c_double * _sym(MAX_NX)),
+        ("model_params", C.c_double * MAX_PARAMS),
+        ("x0", C.c_void_p),
+        ("sig_x0", C.c_void_p),
+        ("z", C.c_void_p),
+        ("alpha", C.c_void_p),
+        ("temp", C.c_void_p),
+        ("feedforward", C.c_void_p),
+    ]
+
+
+_SIGNATURES = {
+    "i2c_abi_version": (C.c_int, []),
+    "i2c_build_info": (C.c_char_p, []),
+    "i2c_query": (C.c_int, [C.c_int, C.POINTER(I2cDims)]),
+    "i2c_forward_sweep": (C.c_int, [C.POINTER(I2cProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "i2c_backward_sweep": (
+        C.c_int,
+        [C.POINTER(I2cProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "i2c_mstep": (C.c_int, [C.POINTER(I2cProblem), C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
+    "i2c_propagate": (C.c_int, [C.POINTER(I2cProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(PKG_DIR, "lib", "libi2c_hip.so")
+
+
+class NativeLibrary:
+    """A loaded i2c C-ABI library with typed entry points."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise ImportError(
+                f"i2c HIP library not found at {path}; build it with `python __graft_entry__.py` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+            )
+        self.path = path
+        self._dll = C.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError as e:
+                raise ImportError(f"{path} does not export {name} (include/i2c_hip.h)") from e
+            fn.restype, fn.argtypes = res, args
+            setattr(self, name, fn)
+        if self.i2c_abi_version() != ABI_VERSION:
+            raise ImportError(f"{path}: ABI version {self.i2c_abi_version()} != {ABI_VERSION}")
+        self.build_info = self.i2c_build_info().decode()
+        self.is_host_sim = "host-simulation" in self.build_info
+
+    def query(self, model_id):
+        d = I2cDims()
+        rc = self.i2c_query(int(model_id), C.byref(d))
+        if rc != 0:
+            raise ValueError(f"i2c_query({model_id}) failed with {rc}")
+        return d
+
+
+_default = None
+
+
+def load_library(path=None):
+    """Load (once) the gfx950 library; `path` is only for tests that pass an explicit build."""
+    global _default
+    if path is not None:
+        return NativeLibrary(path)
+    if _default is None:
+        _default = NativeLibrary(DEFAULT_LIB)
+    return _default

@@ -1,0 +1,268 @@
+// C ABI (include/i2c_hip.h) over the gfx950 kernels.
+//
+// Built two ways from this one file:
+//   hipcc --offload-arch=gfx950            -> libi2c_hip.so      (THE product; the only library
+//                                                                 the Python package ever loads)
+//   g++ -x c++ -DI2C_HOST_SIM              -> libi2c_hostsim.so  (tests only: the same cell math
+//                                                                 looped on the CPU so that kernel
+//                                                                 numerics can be checked against the
+//                                                                 oracle on a box without a GPU)
+#include "../../include/i2c_hip.h"
+#include "i2c_cell.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace i2c {
+
+#ifndef I2C_HOST_SIM
+// One wavefront per workgroup for the sequential sweeps: at B = 4096 that is 64 workgroups on
+// 64 different CUs, each wave with a CU's issue ports, L1 and scalar cache to itself.
+constexpr int SWEEP_BLOCK = 64;
+constexpr int CELL_BLOCK = 256;
+
+template <class M, typename R>
+__global__ __launch_bounds__(SWEEP_BLOCK) void k_forward(const Consts<M, R> c, const FwdArgs<R> a) {
+  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
+  if (b < c.B) forward_sweep_body<M, R>(c, a, b);
+}
+template <class M, typename R>
+__global__ __launch_bounds__(SWEEP_BLOCK) void k_scan(const Consts<M, R> c, const ScanArgs<R> a) {
+  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
+  if (b < c.B) backward_scan_body<M, R>(c, a, b);
+}
+template <class M, typename R>
+__global__ __launch_bounds__(CELL_BLOCK) void k_cell(const Consts<M, R> c, const CellArgs<R> a) {
+  const int b = blockIdx.x * CELL_BLOCK + threadIdx.x;
+  const int t = blockIdx.y;
+  if (b < c.B) backward_cell_body<M, R>(c, a, t, b);
+}
+template <class M, typename R>
+__global__ __launch_bounds__(SWEEP_BLOCK) void k_mstep(const Consts<M, R> c, const MstepArgs<R> a) {
+  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
+  if (b < c.B) mstep_body<M, R>(c, a, b);
+}
+template <class M, typename R>
+__global__ __launch_bounds__(SWEEP_BLOCK) void k_propagate(const Consts<M, R> c, const PropArgs<R> a) {
+  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
+  if (b < c.B) propagate_body<M, R>(c, a, b);
+}
+static int launch_status() { return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH; }
+#endif
+
+template <typename R> static Rule<R> make_rule(const I2cProblem* p, int dim) {
+  // CubatureQuadrature.weights, i2c/exp_types.py:40-49
+  const double a = p->quad_alpha, lam = a * a * (dim + p->quad_kappa) - dim;
+  const double wi = 1.0 / (2.0 * (dim + lam));
+  const double w0 = 2.0 * lam * wi + (1.0 - a * a + p->quad_beta);
+  const double W = w0 + 2.0 * dim * wi;
+  Rule<R> r;
+  r.sf = (R)std::sqrt(dim + lam);
+  r.w0 = (R)w0;
+  r.wi = (R)wi;
+  r.unit = std::fabs(W - 1.0) < 1e-14;
+  r.W = r.unit ? (R)1 : (R)W;
+  return r;
+}
+
+template <class M, typename R> static Consts<M, R> make_consts(const I2cProblem* p, double tol, int use_expert) {
+  using C = Consts<M, R>;
+  C c;
+  std::memset(&c, 0, sizeof(c));
+  c.B = p->B;
+  c.T = p->T;
+  c.has_Qf = p->has_Qf && M::NZT > 0;
+  c.has_x_terminal = p->has_x_terminal;
+  c.z_per_cell = p->z_per_cell && p->z != nullptr;
+  c.use_expert = use_expert;
+  c.rule_xu = make_rule<R>(p, C::D);
+  c.rule_x = make_rule<R>(p, C::NX);
+  c.dtemp = (R)p->dtemp;
+  c.tol = (R)tol;
+  for (int i = 0; i < sym(C::NX); ++i) c.sig_eta[i] = (R)p->sig_eta[i];
+  for (int i = 0; i < sym(C::NZ); ++i) c.sig_xi0[i] = (R)p->sig_xi0[i];
+  for (int i = 0; i < sym(C::NZ); ++i) c.QR[i] = (R)p->QR[i];
+  for (int i = 0; i < sym(C::NZT); ++i) c.sig_xiT0[i] = (R)p->sig_xiT0[i];
+  for (int i = 0; i < sym(C::NZT); ++i) c.Qf[i] = (R)p->Qf[i];
+  for (int i = 0; i < C::NZ; ++i) c.zg[i] = (R)p->zg[i];
+  for (int i = 0; i < C::NZT; ++i) c.zg_term[i] = (R)p->zg_term[i];
+  for (int i = 0; i < C::NX; ++i) c.mu_x_term[i] = (R)p->mu_x_term[i];
+  for (int i = 0; i < sym(C::NX); ++i) c.sig_x_term[i] = (R)p->sig_x_term[i];
+  for (int i = 0; i < M::NP; ++i) c.params[i] = (R)p->model_params[i];
+  return c;
+}
+
+static int check_problem(const I2cProblem* p) {
+  if (!p || p->abi_version != I2C_ABI_VERSION) return I2C_EINVAL;
+  if (p->B < 1 || p->T < 1) return I2C_EINVAL;
+  if (!p->x0 || !p->sig_x0 || !p->alpha || !p->feedforward) return I2C_EINVAL;
+  if (p->has_x_terminal && !p->temp) return I2C_EINVAL;
+  return I2C_OK;
+}
+
+// ---- per-(model, dtype) entry points ------------------------------------------------------
+template <class M, typename R> struct Impl {
+  using C = Consts<M, R>;
+
+  static int forward(const I2cProblem* p, const void* prior, void* fwd, void* prior_out, int32_t* status,
+                     void* stream) {
+    const C c = make_consts<M, R>(p, 0.0, 0);
+    FwdArgs<R> a{(const R*)prior, (R*)fwd, (R*)prior_out, (const R*)p->x0, (const R*)p->sig_x0,
+                 (const R*)p->z,  (const R*)p->alpha, p->feedforward, status};
+#ifdef I2C_HOST_SIM
+    (void)stream;
+    for (int b = 0; b < p->B; ++b) forward_sweep_body<M, R>(c, a, b);
+    return I2C_OK;
+#else
+    const int grid = (p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+    hipLaunchKernelGGL((k_forward<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, a);
+    return launch_status();
+#endif
+  }
+
+  static int backward(const I2cProblem* p, const void* fwd, void* xm, void* post, void* zpost, void* cell_stats,
+                      void* term_stats, int32_t* status, void* stream) {
+    const C c = make_consts<M, R>(p, 0.0, 0);
+    ScanArgs<R> s{(const R*)fwd, (R*)xm, (R*)p->temp, status};
+    CellArgs<R> a{(const R*)fwd, (const R*)xm, (const R*)p->z, (R*)post,
+                  (R*)zpost,     (R*)cell_stats, (R*)term_stats, status};
+#ifdef I2C_HOST_SIM
+    (void)stream;
+    for (int b = 0; b < p->B; ++b) backward_scan_body<M, R>(c, s, b);
+    for (int t = 0; t < p->T; ++t)
+      for (int b = 0; b < p->B; ++b) backward_cell_body<M, R>(c, a, t, b);
+    return I2C_OK;
+#else
+    const int grid = (p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+    hipLaunchKernelGGL((k_scan<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, s);
+    if (launch_status() != I2C_OK) return I2C_ELAUNCH;
+    const dim3 cgrid((p->B + CELL_BLOCK - 1) / CELL_BLOCK, p->T);
+    hipLaunchKernelGGL((k_cell<M, R>), cgrid, dim3(CELL_BLOCK), 0, (hipStream_t)stream, c, a);
+    return launch_status();
+#endif
+  }
+
+  static int mstep(const I2cProblem* p, const void* cell_stats, const void* term_stats, double tol, int update,
+                   void* stats_out, void* stream) {
+    const C c = make_consts<M, R>(p, tol, 0);
+    MstepArgs<R> a{(const R*)cell_stats, (const R*)term_stats, (R*)p->alpha, (R*)stats_out, update};
+#ifdef I2C_HOST_SIM
+    (void)stream;
+    for (int b = 0; b < p->B; ++b) mstep_body<M, R>(c, a, b);
+    return I2C_OK;
+#else
+    const int grid = (p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+    hipLaunchKernelGGL((k_mstep<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, a);
+    return launch_status();
+#endif
+  }
+
+  static int propagate(const I2cProblem* p, const void* post, void* prop, void* cell_stats, int use_expert,
+                       int32_t* status, void* stream) {
+    const C c = make_consts<M, R>(p, 0.0, use_expert);
+    PropArgs<R> a{(const R*)post, (R*)prop, (R*)cell_stats, (const R*)p->x0, (const R*)p->sig_x0,
+                  (const R*)p->z, p->feedforward, status};
+#ifdef I2C_HOST_SIM
+    (void)stream;
+    for (int b = 0; b < p->B; ++b) propagate_body<M, R>(c, a, b);
+    return I2C_OK;
+#else
+    const int grid = (p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+    hipLaunchKernelGGL((k_propagate<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, a);
+    return launch_status();
+#endif
+  }
+};
+
+template <class M> static void fill_dims(I2cDims* d) {
+  using C = Consts<M, double>;
+  d->nx = M::NX;
+  d->nu = M::NU;
+  d->nz = M::NZ;
+  d->nzt = M::NZT;
+  d->e_post = C::E_POST;
+  d->e_fwd = C::E_FWD;
+  d->e_xm = C::E_XM;
+  d->e_zpost = C::E_ZPOST;
+  d->e_prop = C::E_PROP;
+  d->n_params = M::NP;
+}
+
+}  // namespace i2c
+
+// Dispatch a call over (model_id, dtype). fp32 instantiations exist for every model.
+#define I2C_DISPATCH(p, CALL)                                                        \
+  do {                                                                               \
+    const int rc_ = i2c::check_problem(p);                                           \
+    if (rc_ != I2C_OK) return rc_;                                                   \
+    switch ((p)->model_id) {                                                         \
+      case I2C_MODEL_PENDULUM: I2C_DISPATCH_T(i2c::Pendulum, p, CALL);               \
+      case I2C_MODEL_PENDULUM_ACTREG: I2C_DISPATCH_T(i2c::PendulumActReg, p, CALL);  \
+      case I2C_MODEL_CARTPOLE: I2C_DISPATCH_T(i2c::Cartpole, p, CALL);               \
+      case I2C_MODEL_DOUBLE_CARTPOLE: I2C_DISPATCH_T(i2c::DoubleCartpole, p, CALL);  \
+      case I2C_MODEL_LINEAR: I2C_DISPATCH_T(i2c::Linear, p, CALL);                   \
+      case I2C_MODEL_LINEAR_MINENERGY: I2C_DISPATCH_T(i2c::LinearMinEnergy, p, CALL);\
+      case I2C_MODEL_QUADROTOR: I2C_DISPATCH_T(i2c::Quadrotor, p, CALL);             \
+      default: return I2C_EINVAL;                                                    \
+    }                                                                                \
+  } while (0)
+
+#define I2C_DISPATCH_T(MODEL, p, CALL)                                     \
+  do {                                                                     \
+    if ((p)->dtype == I2C_F64) return i2c::Impl<MODEL, double>::CALL;      \
+    if ((p)->dtype == I2C_F32) return i2c::Impl<MODEL, float>::CALL;       \
+    return I2C_EINVAL;                                                     \
+  } while (0)
+
+extern "C" {
+
+int i2c_abi_version(void) { return I2C_ABI_VERSION; }
+
+const char* i2c_build_info(void) {
+#ifdef I2C_HOST_SIM
+  return "i2c host-simulation build (CPU, tests only)";
+#else
+  return "i2c hip build: gfx950 (MI355X), wave64, one trajectory per lane";
+#endif
+}
+
+int i2c_query(int model_id, I2cDims* out) {
+  if (!out) return I2C_EINVAL;
+  switch (model_id) {
+    case I2C_MODEL_PENDULUM: i2c::fill_dims<i2c::Pendulum>(out); break;
+    case I2C_MODEL_PENDULUM_ACTREG: i2c::fill_dims<i2c::PendulumActReg>(out); break;
+    case I2C_MODEL_CARTPOLE: i2c::fill_dims<i2c::Cartpole>(out); break;
+    case I2C_MODEL_DOUBLE_CARTPOLE: i2c::fill_dims<i2c::DoubleCartpole>(out); break;
+    case I2C_MODEL_LINEAR: i2c::fill_dims<i2c::Linear>(out); break;
+    case I2C_MODEL_LINEAR_MINENERGY: i2c::fill_dims<i2c::LinearMinEnergy>(out); break;
+    case I2C_MODEL_QUADROTOR: i2c::fill_dims<i2c::Quadrotor>(out); break;
+    default: return I2C_EINVAL;
+  }
+  return I2C_OK;
+}
+
+int i2c_forward_sweep(const I2cProblem* p, const void* prior, void* fwd, void* prior_out, int32_t* status,
+                      void* stream) {
+  if (!prior || !fwd || !status) return I2C_EINVAL;
+  I2C_DISPATCH(p, forward(p, prior, fwd, prior_out, status, stream));
+}
+
+int i2c_backward_sweep(const I2cProblem* p, const void* fwd, void* xm, void* post, void* zpost, void* cell_stats,
+                       void* term_stats, int32_t* status, void* stream) {
+  if (!fwd || !xm || !post || !cell_stats || !term_stats || !status) return I2C_EINVAL;
+  I2C_DISPATCH(p, backward(p, fwd, xm, post, zpost, cell_stats, term_stats, status, stream));
+}
+
+int i2c_mstep(const I2cProblem* p, const void* cell_stats, const void* term_stats, double alpha_update_tol,
+              int update, void* stats_out, void* stream) {
+  if (!cell_stats || !term_stats || !stats_out) return I2C_EINVAL;
+  I2C_DISPATCH(p, mstep(p, cell_stats, term_stats, alpha_update_tol, update, stats_out, stream));
+}
+
+int i2c_propagate(const I2cProblem* p, const void* post, void* prop, void* cell_stats_pf, int use_expert_controller,
+                  int32_t* status, void* stream) {
+  if (!post || !prop || !cell_stats_pf || !status) return I2C_EINVAL;
+  I2C_DISPATCH(p, propagate(p, post, prop, cell_stats_pf, use_expert_controller, status, stream));
+}
+
+}  // extern "C"

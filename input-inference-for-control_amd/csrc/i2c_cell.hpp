@@ -1,0 +1,837 @@
+// Per-trajectory cell math of the Gaussian i2c cubature path, one trajectory per lane.
+//
+// Mathematically identical to the reference's I2cCell (i2c/i2c.py:350-447, 544-610, 150-199)
+// and QuadratureInference (i2c/inference/quadrature.py:15-58), but arranged for registers:
+//   * sigma points are generated column by column from the Cholesky factor and consumed
+//     immediately (pairwise +/- differences), so only O(d * ny) accumulators are live;
+//   * covariances are accumulated in the centred, shift-by-centre-point form (no
+//     sum w y y^T - m m^T cancellation); the general-weight correction terms
+//     reproduce the reference's formula exactly, including its use of w_sig for the mean;
+//   * the Kalman-style update uses only forward substitutions with chol(sig_z):
+//        V = C^{-1} sig_xz^T,  mu += V^T C^{-1} r,  sig -= V^T V   (symmetric by construction);
+//   * the controller (K, k, sigK) falls out of the Cholesky factor of the posterior joint.
+#pragma once
+#include <stdint.h>
+#include "i2c_linalg.hpp"
+#include "i2c_models.hpp"
+
+namespace i2c {
+
+// Sigma-point rule for one input dimension (i2c/exp_types.py:36-49), precomputed on the host.
+template <typename R> struct Rule {
+  R sf;   // sqrt(dim + lam)
+  R w0;   // weights_sig[0]
+  R wi;   // weights_sig[1:]
+  R W;    // sum of weights_sig (= 1 unless 1 - alpha^2 + beta != 0)
+  int unit;  // W == 1 exactly: skip the correction terms
+};
+
+template <class M, typename R> struct Consts {
+  static constexpr int NX = M::NX, NU = M::NU, NZ = M::NZ, NZT = M::NZT, D = NX + NU;
+  static constexpr int NZT1 = NZT > 0 ? NZT : 1, NP1 = M::NP > 0 ? M::NP : 1;
+  static constexpr int E_PRI = D + sym(D) + NU * NX;                        // rows the forward reads
+  static constexpr int E_POST = E_PRI + NU + sym(NU);
+  static constexpr int E_FWD = D + sym(D) + NX + sym(NX) + D * NX;
+  static constexpr int E_XM = NX + sym(NX);
+  static constexpr int E_ZPOST = NZ + sym(NZ);
+  static constexpr int E_PROP = D + sym(D) + NX + sym(NX);
+  static constexpr int E_TERM = 3 + NZT + sym(NZT);
+  int B, T;
+  int has_Qf, has_x_terminal, z_per_cell, use_expert;
+  Rule<R> rule_xu, rule_x;
+  R dtemp, tol;
+  R sig_eta[sym(NX)], sig_xi0[sym(NZ)], QR[sym(NZ)], sig_xiT0[sym(NZT1)], Qf[sym(NZT1)];
+  R zg[NZ], zg_term[NZT1], mu_x_term[NX], sig_x_term[sym(NX)], params[NP1];
+};
+
+template <class M, typename R> struct ObserveF {
+  const R* p;
+  I2C_HD inline void operator()(const R* x, R* y) const { M::observe(p, x, y); }
+};
+template <class M, typename R> struct DynamicsF {
+  const R* p;
+  I2C_HD inline void operator()(const R* x, R* y) const { M::dynamics(p, x, y); }
+};
+template <class M, typename R> struct ObserveTermF {
+  const R* p;
+  I2C_HD inline void operator()(const R* x, R* y) const { M::observe_terminal(p, x, y); }
+};
+
+// Gaussian push-through  N(m, L L^T) -> (my, Sy [, Sxy])   (quadrature.py:27-58).
+//   L     packed lower Cholesky factor of the input covariance (DIN)
+//   my    [DOUT]   weighted mean (uses weights_sig, as the reference does)
+//   Sy    [sym DOUT] covariance, equal to  sum_p w_p y_p y_p^T - my my^T
+//   Sxy   [DIN * DOUT] row-major cross-covariance = sum_p w_p x_p y_p^T - m my^T  (only if CROSS)
+template <int DIN, int DOUT, bool CROSS, typename R, class F>
+I2C_FN void sp_transform(const Rule<R>& rule, const R* m, const R* L, const F& f, R* my, R* Sy, R* Sxy) {
+  R y0[DOUT];
+  f(m, y0);
+  R A[DOUT];
+#pragma unroll
+  for (int k = 0; k < DOUT; ++k) A[k] = R(0);
+#pragma unroll
+  for (int k = 0; k < sym(DOUT); ++k) Sy[k] = R(0);
+  if (CROSS) {
+#pragma unroll
+    for (int k = 0; k < DIN * DOUT; ++k) Sxy[k] = R(0);
+  }
+#pragma unroll
+  for (int j = 0; j < DIN; ++j) {
+    // points m +/- sf L[:, j]; rows above the diagonal of L are structurally zero
+    R xp[DIN], xm[DIN];
+#pragma unroll
+    for (int i = 0; i < DIN; ++i) {
+      if (i < j) {
+        xp[i] = m[i];
+        xm[i] = m[i];
+      } else {
+        const R dl = rule.sf * L[tri(i, j)];
+        xp[i] = m[i] + dl;
+        xm[i] = m[i] - dl;
+      }
+    }
+    R yp[DOUT], ym[DOUT];
+    f(xp, yp);
+    f(xm, ym);
+    R a[DOUT], dl[DOUT];
+#pragma unroll
+    for (int k = 0; k < DOUT; ++k) {
+      a[k] = (yp[k] - y0[k]) + (ym[k] - y0[k]);
+      dl[k] = yp[k] - ym[k];
+      A[k] += a[k];
+    }
+#pragma unroll
+    for (int k = 0; k < DOUT; ++k)
+#pragma unroll
+      for (int l = 0; l <= k; ++l) Sy[tri(k, l)] += a[k] * a[l] + dl[k] * dl[l];
+    if (CROSS) {
+#pragma unroll
+      for (int i = j; i < DIN; ++i)
+#pragma unroll
+        for (int k = 0; k < DOUT; ++k) Sxy[i * DOUT + k] += L[tri(i, j)] * dl[k];
+    }
+  }
+  const R hw = R(0.5) * rule.wi, w2 = rule.wi * rule.wi;
+#pragma unroll
+  for (int k = 0; k < DOUT; ++k) my[k] = rule.W * y0[k] + rule.wi * A[k];
+#pragma unroll
+  for (int k = 0; k < DOUT; ++k)
+#pragma unroll
+    for (int l = 0; l <= k; ++l) Sy[tri(k, l)] = hw * Sy[tri(k, l)] - w2 * A[k] * A[l];
+  if (!rule.unit) {  // sum of weights != 1: the reference's m m^T term no longer cancels
+    const R omw = R(1) - rule.W;
+#pragma unroll
+    for (int k = 0; k < DOUT; ++k)
+#pragma unroll
+      for (int l = 0; l <= k; ++l)
+        Sy[tri(k, l)] += omw * (rule.W * y0[k] * y0[l] + rule.wi * (A[k] * y0[l] + y0[k] * A[l]));
+  }
+  if (CROSS) {
+    const R cs = rule.wi * rule.sf;
+#pragma unroll
+    for (int k = 0; k < DIN * DOUT; ++k) Sxy[k] *= cs;
+  }
+}
+
+// Kalman-style update of N(mu, S) (dimension DX) on an observation with moments
+// (mz, Sz + noise, Sxz) and target zt:  i2c.py:394-403 / 435-443.
+// On entry Sz already includes the observation noise. Returns false if Sz is not PD.
+template <int DX, int DZ, typename R>
+I2C_FN bool kalman_update(R* mu, R* S, const R* mz, R* Sz, R* Sxz, const R* zt) {
+  R rinv[DZ];
+  const bool ok = chol<DZ>(Sz, rinv);
+  R q[DZ];
+#pragma unroll
+  for (int k = 0; k < DZ; ++k) q[k] = zt[k] - mz[k];
+  fsub<DZ>(Sz, rinv, q);
+#pragma unroll
+  for (int i = 0; i < DX; ++i) {
+    fsub<DZ>(Sz, rinv, &Sxz[i * DZ]);  // row i of V^T
+    R v = mu[i];
+#pragma unroll
+    for (int k = 0; k < DZ; ++k) v += Sxz[i * DZ + k] * q[k];
+    mu[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < DX; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      R v = S[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < DZ; ++k) v -= Sxz[i * DZ + k] * Sxz[j * DZ + k];
+      S[tri(i, j)] = v;
+    }
+  return ok;
+}
+
+// exp(-1/2 delta^T S^{-1} delta): the ratio N(x; m, S) / N(m; m, S) of i2c.py:369-374, 162-165.
+template <int N, typename R> I2C_FN R pdf_ratio(R* S, const R* delta, bool* ok) {
+  R rinv[N], q[N];
+  *ok = chol<N>(S, rinv);
+#pragma unroll
+  for (int i = 0; i < N; ++i) q[i] = delta[i];
+  fsub<N>(S, rinv, q);
+  R maha = R(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) maha += q[i] * q[i];
+  return r_exp(R(-0.5) * maha);
+}
+
+// Joint prior over (x, u) from the incoming state message and the previous controller
+// (feedback mode: i2c.py:361-387; propagation: i2c.py:158-179). Kt = scaled gain (nu x nx).
+//   mu_u = qmu_u + Kt (mu_x - qmu_x);  cross = Kt sig_x;  sig_u given by the caller.
+template <int NX, int NU, typename R>
+I2C_FN void joint_from_gain(const R* mu_x, const R* sig_x, const R* Kt, const R* qmu_x, const R* qmu_u,
+                            const R* sig_u, R* mu0, R* S0) {
+  constexpr int D = NX + NU;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) mu0[i] = mu_x[i];
+#pragma unroll
+  for (int a = 0; a < NU; ++a) {
+    R v = qmu_u[a];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) v += Kt[a * NX + k] * (mu_x[k] - qmu_x[k]);
+    mu0[NX + a] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) S0[tri(i, j)] = sig_x[tri(i, j)];
+#pragma unroll
+  for (int a = 0; a < NU; ++a) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      R v = R(0);
+#pragma unroll
+      for (int k = 0; k < NX; ++k) v += Kt[a * NX + k] * sig_x[tri_any(k, j)];
+      S0[tri(NX + a, j)] = v;
+    }
+#pragma unroll
+    for (int c = 0; c <= a; ++c) S0[tri(NX + a, NX + c)] = sig_u[tri(a, c)];
+  }
+  (void)D;
+}
+
+// Kt sig Kt^T (packed sym NU) for packed sym sig (NX)
+template <int NX, int NU, typename R> I2C_FN void gain_quad(const R* Kt, const R* sig, R* out) {
+  R KS[NU * NX];
+#pragma unroll
+  for (int a = 0; a < NU; ++a)
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      R v = R(0);
+#pragma unroll
+      for (int k = 0; k < NX; ++k) v += Kt[a * NX + k] * sig[tri_any(k, j)];
+      KS[a * NX + j] = v;
+    }
+#pragma unroll
+  for (int a = 0; a < NU; ++a)
+#pragma unroll
+    for (int c = 0; c <= a; ++c) {
+      R v = R(0);
+#pragma unroll
+      for (int j = 0; j < NX; ++j) v += KS[a * NX + j] * Kt[c * NX + j];
+      out[tri(a, c)] = v;
+    }
+}
+
+I2C_FN void set_status(int32_t* status, int b, int reason, int t) {
+  if (status[b] == 0) status[b] = (reason << 16) | (t + 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward sweep: one lane walks one trajectory through all T cells (i2c.py:876-880, 350-447).
+// ------------------------------------------------------------------------------------------
+template <typename R> struct FwdArgs {
+  const R* prior;   // [T][E_POST][B]
+  R* fwd;           // [T][E_FWD][B]
+  R* prior_out;     // [T][D + sym(D)][B] or null
+  const R* x0;      // [NX][B]
+  const R* sig_x0;  // [sym NX][B]
+  const R* z;       // [T][NZ][B] or null
+  const R* alpha;   // [B]
+  const uint8_t* ff;  // [T]
+  int32_t* status;  // [B]
+};
+
+template <class M, typename R>
+I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a, const int b) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D;
+  const long B = c.B;
+  const int T = c.T;
+  const R alpha = a.alpha[b];
+
+  R mu_x[NX], sig_x[sym(NX)];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) mu_x[i] = a.x0[i * B + b];
+#pragma unroll
+  for (int i = 0; i < sym(NX); ++i) sig_x[i] = a.sig_x0[i * B + b];
+
+  // software prefetch of the next cell's prior rows: the loads do not depend on the recursion
+  R pri[C::E_PRI], zt[NZ];
+#pragma unroll
+  for (int e = 0; e < C::E_PRI; ++e) pri[e] = a.prior[(long)e * B + b];
+#pragma unroll
+  for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[(long)k * B + b] : c.zg[k];
+
+  for (int t = 0; t < T; ++t) {
+    R nxt[C::E_PRI], zn[NZ];
+    const int tn = t + 1 < T ? t + 1 : t;
+#pragma unroll
+    for (int e = 0; e < C::E_PRI; ++e) nxt[e] = a.prior[((long)tn * C::E_POST + e) * B + b];
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) zn[k] = c.z_per_cell ? a.z[((long)tn * NZ + k) * B + b] : c.zg[k];
+
+    const R* pmu = pri;               // prior joint mean  (== previous posterior, see i2c_hip.h)
+    const R* psig = pri + D;          // prior joint covariance
+    const R* Kprev = pri + D + sym(D);
+
+    // ---- 1. joint prior over (x, u) ---------------------------------------------------
+    R mu0[D], S0[sym(D)];
+    if (a.ff[t]) {  // feed-forward: independent action prior (i2c.py:355-360)
+#pragma unroll
+      for (int i = 0; i < NX; ++i) mu0[i] = mu_x[i];
+#pragma unroll
+      for (int i = NX; i < D; ++i) mu0[i] = pmu[i];
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j)
+          S0[tri(i, j)] = (i < NX) ? sig_x[tri(i, j)] : (j >= NX ? psig[tri(i, j)] : R(0));
+    } else {  // feedback: condition the previous controller on the new state message (i2c.py:361-387)
+      R S[sym(NX)], delta[NX];
+#pragma unroll
+      for (int i = 0; i < sym(NX); ++i) S[i] = psig[i] + sig_x[i];  // xx block is the packed prefix
+#pragma unroll
+      for (int i = 0; i < NX; ++i) delta[i] = mu_x[i] - pmu[i];
+      bool ok;
+      const R rho = pdf_ratio<NX>(S, delta, &ok);
+      if (!ok) set_status(a.status, b, 2, t);
+      R Kt[NU * NX];
+#pragma unroll
+      for (int i = 0; i < NU * NX; ++i) Kt[i] = rho * Kprev[i];
+      // sig_u0_f = sig_u0_m - Kt sig_ux^T + Kt sig_x0_f Kt^T
+      R sig_u[sym(NU)];
+      gain_quad<NX, NU>(Kt, sig_x, sig_u);
+#pragma unroll
+      for (int p = 0; p < NU; ++p)
+#pragma unroll
+        for (int q = 0; q <= p; ++q) {
+          R v = psig[tri(NX + p, NX + q)] + sig_u[tri(p, q)];
+#pragma unroll
+          for (int k = 0; k < NX; ++k) v -= Kt[p * NX + k] * psig[tri(NX + q, k)];
+          sig_u[tri(p, q)] = v;
+        }
+      joint_from_gain<NX, NU>(mu_x, sig_x, Kt, pmu, pmu + NX, sig_u, mu0, S0);
+    }
+    if (a.prior_out) {
+#pragma unroll
+      for (int e = 0; e < D; ++e) a.prior_out[((long)t * (D + sym(D)) + e) * B + b] = mu0[e];
+#pragma unroll
+      for (int e = 0; e < sym(D); ++e) a.prior_out[((long)t * (D + sym(D)) + D + e) * B + b] = S0[e];
+    }
+
+    // ---- 2. cost "observation": measurement update on z (i2c.py:390-407) --------------
+    {
+      R L[sym(D)], rinv[D];
+#pragma unroll
+      for (int i = 0; i < sym(D); ++i) L[i] = S0[i];
+      if (!chol<D>(L, rinv)) set_status(a.status, b, 1, t);
+      R mz[NZ], Sz[sym(NZ)], Sxz[D * NZ];
+      sp_transform<D, NZ, true>(c.rule_xu, mu0, L, ObserveF<M, R>{c.params}, mz, Sz, Sxz);
+#pragma unroll
+      for (int i = 0; i < sym(NZ); ++i) Sz[i] += alpha * c.sig_xi0[i];
+      if (!kalman_update<D, NZ>(mu0, S0, mz, Sz, Sxz, zt)) set_status(a.status, b, 3, t);
+    }
+    // mu0 / S0 now hold mu_xu1_f / sig_xu1_f
+    R* out = a.fwd + ((long)t * C::E_FWD) * B + b;
+#pragma unroll
+    for (int e = 0; e < D; ++e) out[(long)e * B] = mu0[e];
+#pragma unroll
+    for (int e = 0; e < sym(D); ++e) out[(long)(D + e) * B] = S0[e];
+
+    // ---- 3. dynamics push-through (i2c.py:415-421) and smoother gain (i2c.py:423-425) --
+    R Sxy[D * NX];
+    {
+      R L[sym(D)], rinv[D];
+#pragma unroll
+      for (int i = 0; i < sym(D); ++i) L[i] = S0[i];
+      if (!chol<D>(L, rinv)) set_status(a.status, b, 4, t);
+      sp_transform<D, NX, true>(c.rule_xu, mu0, L, DynamicsF<M, R>{c.params}, mu_x, sig_x, Sxy);
+    }
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) sig_x[i] += c.rule_xu.W * c.sig_eta[i];
+    R L3[sym(NX)], rinv3[NX];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) L3[i] = sig_x[i];
+    if (!chol<NX>(L3, rinv3)) set_status(a.status, b, 5, t);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {  // J = sig_xy sig_x3^{-1}, row by row
+      fsub<NX>(L3, rinv3, &Sxy[i * NX]);
+      bsub<NX>(L3, rinv3, &Sxy[i * NX]);
+    }
+
+    // ---- 4. terminal cost observation on the last cell, after J (i2c.py:430-443) -------
+    if (NZT > 0 && t == T - 1 && c.has_Qf) {
+      constexpr int NT = C::NZT1;
+      R mzt[NT], Szt[sym(NT)], Sxzt[NX * NT];
+      sp_transform<NX, NT, true>(c.rule_x, mu_x, L3, ObserveTermF<M, R>{c.params}, mzt, Szt, Sxzt);
+#pragma unroll
+      for (int i = 0; i < sym(NT); ++i) Szt[i] += alpha * c.sig_xiT0[i];
+      if (!kalman_update<NX, NT>(mu_x, sig_x, mzt, Szt, Sxzt, c.zg_term)) set_status(a.status, b, 6, t);
+    }
+#pragma unroll
+    for (int e = 0; e < NX; ++e) out[(long)(D + sym(D) + e) * B] = mu_x[e];
+#pragma unroll
+    for (int e = 0; e < sym(NX); ++e) out[(long)(D + sym(D) + NX + e) * B] = sig_x[e];
+#pragma unroll
+    for (int e = 0; e < D * NX; ++e) out[(long)(D + sym(D) + NX + sym(NX) + e) * B] = Sxy[e];
+
+#pragma unroll
+    for (int e = 0; e < C::E_PRI; ++e) pri[e] = nxt[e];
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) zt[k] = zn[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward pass, part 1: the x-marginal recursion (i2c.py:544-583 restricted to the xx block).
+//   mu_x0_m = mu_x1_f + Jx (mu_x3_m - mu_x3_f);  sig_x0_m = sig_x1_f + Jx (sig_x3_m - sig_x3_f) Jx^T
+// It is affine in (mu_x3_m, sig_x3_m), touches only nx x nx blocks, and is the ONLY sequential
+// part of the backward pass; everything else is independent per cell (part 2).
+// ------------------------------------------------------------------------------------------
+template <typename R> struct ScanArgs {
+  const R* fwd;  // [T][E_FWD][B]
+  R* xm;         // [T][E_XM][B]
+  R* temp;       // [B] or null
+  int32_t* status;
+};
+
+template <class M, typename R>
+I2C_HD inline void backward_scan_body(const Consts<M, R>& c, const ScanArgs<R>& a, const int b) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, D = C::D;
+  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  const long B = c.B;
+  const int T = c.T;
+  R m3m[NX], S3m[sym(NX)];
+
+  // rows of one cell the scan needs: mu_x1_f, sig_x1_f (xx prefix), mu_x3_f, sig_x3_f, Jx
+  R mu1[NX], S1[sym(NX)], m3f[NX], S3f[sym(NX)], Jx[NX * NX];
+  auto load = [&](int t, R* lmu1, R* lS1, R* lm3f, R* lS3f, R* lJx) {
+    const R* in = a.fwd + ((long)t * C::E_FWD) * B + b;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) lmu1[i] = in[(long)i * B];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) lS1[i] = in[(long)(D + i) * B];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) lm3f[i] = in[(long)(O_MU3 + i) * B];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) lS3f[i] = in[(long)(O_S3 + i) * B];
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) lJx[i] = in[(long)(O_J + i) * B];
+  };
+  load(T - 1, mu1, S1, m3f, S3f, Jx);
+
+  // end of chain (i2c.py:546-564)
+  if (c.has_x_terminal) {  // covariance control with a tempered terminal prior (i2c.py:548-559)
+    const R temp = a.temp[b];
+    a.temp[b] = temp + c.dtemp;
+    R St[sym(NX)], Ssum[sym(NX)], rinv[NX];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) {
+      St[i] = temp * S3f[i];
+      Ssum[i] = c.sig_x_term[i] + St[i];
+    }
+    bool ok = chol<NX>(Ssum, rinv);
+    // sig_x3_m = St - St (sig_T + St)^{-1} St  = St - W^T W,  W = chol(sum)^{-1} St
+    R Wm[NX * NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      R col[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) col[i] = St[tri_any(i, j)];
+      fsub<NX>(Ssum, rinv, col);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Wm[i * NX + j] = col[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        R v = St[tri(i, j)];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) v -= Wm[k * NX + i] * Wm[k * NX + j];
+        S3m[tri(i, j)] = v;
+      }
+    // mu_x3_m = sig_x3_m (St^{-1} mu_x3_f + sig_T^{-1} mu_T)
+    R r1[NX], r2[NX], Lt[sym(NX)], LT[sym(NX)];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) {
+      Lt[i] = St[i];
+      LT[i] = c.sig_x_term[i];
+    }
+    ok = chol<NX>(Lt, rinv) && ok;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) r1[i] = m3f[i];
+    fsub<NX>(Lt, rinv, r1);
+    bsub<NX>(Lt, rinv, r1);
+    ok = chol<NX>(LT, rinv) && ok;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) r2[i] = c.mu_x_term[i];
+    fsub<NX>(LT, rinv, r2);
+    bsub<NX>(LT, rinv, r2);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) r1[i] += r2[i];
+    symv<NX>(S3m, r1, m3m);
+    if (!ok) set_status(a.status, b, 6, T - 1);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) m3m[i] = m3f[i];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) S3m[i] = S3f[i];
+  }
+
+  for (int t = T - 1; t >= 0; --t) {
+    R nmu1[NX], nS1[sym(NX)], nm3f[NX], nS3f[sym(NX)], nJx[NX * NX];
+    load(t > 0 ? t - 1 : 0, nmu1, nS1, nm3f, nS3f, nJx);  // prefetch
+
+    R* out = a.xm + ((long)t * C::E_XM) * B + b;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) out[(long)i * B] = m3m[i];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) out[(long)(NX + i) * B] = S3m[i];
+
+    R dm[NX], dS[sym(NX)];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dm[i] = m3m[i] - m3f[i];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) dS[i] = S3m[i] - S3f[i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      R v = mu1[i];
+#pragma unroll
+      for (int k = 0; k < NX; ++k) v += Jx[i * NX + k] * dm[k];
+      m3m[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) S3m[i] = S1[i];
+    add_JDJt<NX, NX>(Jx, dS, S3m);
+
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { mu1[i] = nmu1[i]; m3f[i] = nm3f[i]; }
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) { S1[i] = nS1[i]; S3f[i] = nS3f[i]; }
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) Jx[i] = nJx[i];
+  }
+}
+
+// Expected quadratic cost of N(mz, Sz) against target zt under weight W (packed sym):
+//   m = err^T W err + tr(Sz W),  v = 2 tr((Sz W)^2) + 4 err^T W Sz W err   (i2c.py:1034-1043)
+template <int N, typename R> I2C_FN void gaussian_cost(const R* W, const R* mz, const R* Sz, const R* zt, R* m, R* v) {
+  R err[N], We[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) err[i] = mz[i] - zt[i];
+  symv<N>(W, err, We);
+  R SW[N * N];  // Sz W (not symmetric)
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      R s = R(0);
+#pragma unroll
+      for (int k = 0; k < N; ++k) s += Sz[tri_any(i, k)] * W[tri_any(k, j)];
+      SW[i * N + j] = s;
+    }
+  R mm = R(0), tr2 = R(0), quad = R(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    mm += err[i] * We[i] + SW[i * N + i];
+    R SWe = R(0);  // (Sz W err)_i = sum_j Sz[i][j] We[j]
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      tr2 += SW[i * N + j] * SW[j * N + i];
+      SWe += Sz[tri_any(i, j)] * We[j];
+    }
+    quad += We[i] * SWe;
+  }
+  *m = mm;
+  *v = R(2) * tr2 + R(4) * quad;
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward pass, part 2: independent per cell (t, b): RTS update of the joint, posterior
+// observation statistics, controller, and the M-step / cost statistics (i2c.py:578-608,
+// 680-683, 1034-1043). One lane per (t, b).
+// ------------------------------------------------------------------------------------------
+template <typename R> struct CellArgs {
+  const R* fwd;      // [T][E_FWD][B]
+  const R* xm;       // [T][E_XM][B]
+  const R* z;        // [T][NZ][B] or null
+  R* post;           // [T][E_POST][B]
+  R* zpost;          // [T][E_ZPOST][B] or null
+  R* cell_stats;     // [T][2][B]
+  R* term_stats;     // [E_TERM][B]
+  int32_t* status;
+};
+
+template <class M, typename R>
+I2C_HD inline void backward_cell_body(const Consts<M, R>& c, const CellArgs<R>& a, const int t, const int b) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D;
+  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  const long B = c.B;
+  const R* in = a.fwd + ((long)t * C::E_FWD) * B + b;
+  const R* xin = a.xm + ((long)t * C::E_XM) * B + b;
+
+  R mu[D], S[sym(D)], J[D * NX], dm[NX], dS[sym(NX)], m3m[NX], S3m[sym(NX)];
+#pragma unroll
+  for (int e = 0; e < D; ++e) mu[e] = in[(long)e * B];
+#pragma unroll
+  for (int e = 0; e < sym(D); ++e) S[e] = in[(long)(D + e) * B];
+#pragma unroll
+  for (int e = 0; e < NX; ++e) {
+    m3m[e] = xin[(long)e * B];
+    dm[e] = m3m[e] - in[(long)(O_MU3 + e) * B];
+  }
+#pragma unroll
+  for (int e = 0; e < sym(NX); ++e) {
+    S3m[e] = xin[(long)(NX + e) * B];
+    dS[e] = S3m[e] - in[(long)(O_S3 + e) * B];
+  }
+#pragma unroll
+  for (int e = 0; e < D * NX; ++e) J[e] = in[(long)(O_J + e) * B];
+
+  // RTS update of the joint (i2c.py:580-583)
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    R v = mu[i];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) v += J[i * NX + k] * dm[k];
+    mu[i] = v;
+  }
+  add_JDJt<D, NX>(J, dS, S);
+
+  R* out = a.post + ((long)t * C::E_POST) * B + b;
+#pragma unroll
+  for (int e = 0; e < D; ++e) out[(long)e * B] = mu[e];
+#pragma unroll
+  for (int e = 0; e < sym(D); ++e) out[(long)(D + e) * B] = S[e];
+
+  // posterior observation moments (i2c.py:594-596) from chol(sig_xu0_m)
+  R rinv[D];
+  if (!chol<D>(S, rinv)) set_status(a.status, b, 7, t);  // S <- L
+  R zt[NZ], mz[NZ], Sz[sym(NZ)];
+#pragma unroll
+  for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
+  sp_transform<D, NZ, false>(c.rule_xu, mu, S, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
+  if (a.zpost) {
+    R* zo = a.zpost + ((long)t * C::E_ZPOST) * B + b;
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) zo[(long)k * B] = mz[k];
+#pragma unroll
+    for (int k = 0; k < sym(NZ); ++k) zo[(long)(NZ + k) * B] = Sz[k];
+  }
+  R cm, cv;
+  gaussian_cost<NZ>(c.QR, mz, Sz, zt, &cm, &cv);
+  a.cell_stats[((long)t * 2 + 0) * B + b] = cm;
+  a.cell_stats[((long)t * 2 + 1) * B + b] = cv;
+
+  // controller p(u | x) from the Cholesky factor L of the posterior joint (i2c.py:600-608):
+  //   K L_xx = L_ux  ->  K^T = L_xx^{-T} L_ux^T ;  sigK = L_uu L_uu^T ;  k = mu_u - K mu_x
+  R Kc[NU * NX];
+#pragma unroll
+  for (int p = 0; p < NU; ++p) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) Kc[p * NX + k] = S[tri(NX + p, k)];
+    bsub<NX>(S, rinv, &Kc[p * NX]);  // leading NX x NX block of L is chol(sig_xx)
+  }
+#pragma unroll
+  for (int e = 0; e < NU * NX; ++e) out[(long)(D + sym(D) + e) * B] = Kc[e];
+#pragma unroll
+  for (int p = 0; p < NU; ++p) {
+    R v = mu[NX + p];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) v -= Kc[p * NX + k] * mu[k];
+    out[(long)(C::E_PRI + p) * B] = v;
+  }
+#pragma unroll
+  for (int p = 0; p < NU; ++p)
+#pragma unroll
+    for (int q = 0; q <= p; ++q) {
+      R v = R(0);
+#pragma unroll
+      for (int k = 0; k <= q; ++k) v += S[tri(NX + p, NX + k)] * S[tri(NX + q, NX + k)];
+      out[(long)(C::E_PRI + NU + tri(p, q)) * B] = v;
+    }
+
+  // terminal observation statistics on the last cell (i2c.py:567-570, 989-992)
+  if (t == c.T - 1) {
+    R trT = R(0);
+    if (NZT > 0 && c.has_Qf) {
+      constexpr int NT = C::NZT1;
+      R L3[sym(NX)], rinv3[NX], mzt[NT], Szt[sym(NT)];
+#pragma unroll
+      for (int i = 0; i < sym(NX); ++i) L3[i] = S3m[i];
+      if (!chol<NX>(L3, rinv3)) set_status(a.status, b, 6, t);
+      sp_transform<NX, NT, false>(c.rule_x, m3m, L3, ObserveTermF<M, R>{c.params}, mzt, Szt, (R*)nullptr);
+      R tv;
+      gaussian_cost<NT>(c.Qf, mzt, Szt, c.zg_term, &trT, &tv);
+#pragma unroll
+      for (int k = 0; k < NT; ++k) a.term_stats[(long)(3 + k) * B + b] = mzt[k];
+#pragma unroll
+      for (int k = 0; k < sym(NT); ++k) a.term_stats[(long)(3 + NT + k) * B + b] = Szt[k];
+    }
+    a.term_stats[b] = trT;
+    a.term_stats[B + b] = R(0);
+    a.term_stats[2 * B + b] = R(0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// M-step on the temperature (i2c.py:913-963, 1045-1053). One lane per trajectory.
+// ------------------------------------------------------------------------------------------
+template <typename R> struct MstepArgs {
+  const R* cell_stats;  // [T][2][B]
+  const R* term_stats;  // [E_TERM][B]
+  R* alpha;             // [B]
+  R* stats_out;         // [4][B]
+  int update;
+};
+
+template <class M, typename R>
+I2C_HD inline void mstep_body(const Consts<M, R>& c, const MstepArgs<R>& a, const int b) {
+  using C = Consts<M, R>;
+  const long B = c.B;
+  R m = R(0), v = R(0);
+  for (int t = 0; t < c.T; ++t) {
+    m += a.cell_stats[((long)t * 2 + 0) * B + b];
+    v += a.cell_stats[((long)t * 2 + 1) * B + b];
+  }
+  R tr = m, sf = R(C::NZ) * R(c.T);
+  if (C::NZT > 0 && c.has_Qf) {
+    tr += a.term_stats[b];
+    sf += R(C::NZT);
+  }
+  const R alpha_hat = tr / sf;
+  const R alpha = a.alpha[b];
+  R alpha_new = alpha;
+  if (a.update) {
+    if (c.tol >= R(0)) {  // i2c.py:953-959
+      const R ratio = alpha_hat / alpha;
+      alpha_new = alpha_hat;
+      if (ratio < c.tol) alpha_new = c.tol * alpha;
+      if (ratio > R(2) - c.tol) alpha_new = (R(2) - c.tol) * alpha;
+    }
+    a.alpha[b] = alpha_new;
+  }
+  a.stats_out[b] = alpha_hat;
+  a.stats_out[B + b] = alpha_new;
+  a.stats_out[2 * B + b] = m;
+  a.stats_out[3 * B + b] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Closed-loop propagation (i2c.py:150-199, 1247-1251): forward-only rollout of the controller
+// distribution through the model. One lane per trajectory.
+// ------------------------------------------------------------------------------------------
+template <typename R> struct PropArgs {
+  const R* post;   // [T][E_POST][B]
+  R* prop;         // [T][E_PROP][B]
+  R* cell_stats;   // [T][2][B]
+  const R* x0;
+  const R* sig_x0;
+  const R* z;
+  const uint8_t* ff;
+  int32_t* status;
+};
+
+template <class M, typename R>
+I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, const int b) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, D = C::D;
+  const long B = c.B;
+  const int T = c.T;
+  R mu_x[NX], sig_x[sym(NX)];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) mu_x[i] = a.x0[i * B + b];
+#pragma unroll
+  for (int i = 0; i < sym(NX); ++i) sig_x[i] = a.sig_x0[i * B + b];
+  R pri[C::E_PRI];
+#pragma unroll
+  for (int e = 0; e < C::E_PRI; ++e) pri[e] = a.post[(long)e * B + b];
+
+  for (int t = 0; t < T; ++t) {
+    R nxt[C::E_PRI];
+    const int tn = t + 1 < T ? t + 1 : t;
+#pragma unroll
+    for (int e = 0; e < C::E_PRI; ++e) nxt[e] = a.post[((long)tn * C::E_POST + e) * B + b];
+    const R* qmu = pri;
+    const R* qsig = pri + D;
+    const R* Kpost = pri + D + sym(D);
+
+    R mu0[D], S0[sym(D)], Kt[NU * NX], sig_u[sym(NU)];
+#pragma unroll
+    for (int i = 0; i < NU * NX; ++i) Kt[i] = Kpost[i];
+    if (a.ff[t]) {  // i2c.py:155-157: action marginal, but the joint still carries K sig_x (i2c.py:173-179)
+#pragma unroll
+      for (int p = 0; p < NU; ++p)
+#pragma unroll
+        for (int q = 0; q <= p; ++q) sig_u[tri(p, q)] = qsig[tri(NX + p, NX + q)];
+      joint_from_gain<NX, NU>(mu_x, sig_x, Kt, mu_x, qmu + NX, sig_u, mu0, S0);
+    } else {
+      if (c.use_expert) {  // i2c.py:160-167
+        R S[sym(NX)], delta[NX];
+#pragma unroll
+        for (int i = 0; i < sym(NX); ++i) S[i] = qsig[i] + sig_x[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) delta[i] = mu_x[i] - qmu[i];
+        bool ok;
+        const R rho = pdf_ratio<NX>(S, delta, &ok);
+        if (ok) {  // the reference logs the exception and keeps K unscaled (i2c.py:166-167)
+#pragma unroll
+          for (int i = 0; i < NU * NX; ++i) Kt[i] *= rho;
+        }
+      }
+      // sig_u0_pf = K sig_x0_pf K^T + sig_u0_m - K sig_x0_m K^T  (i2c.py:169-171)
+      R q1[sym(NU)], q2[sym(NU)];
+      gain_quad<NX, NU>(Kt, sig_x, q1);
+      gain_quad<NX, NU>(Kt, qsig, q2);
+#pragma unroll
+      for (int p = 0; p < NU; ++p)
+#pragma unroll
+        for (int q = 0; q <= p; ++q) sig_u[tri(p, q)] = q1[tri(p, q)] + qsig[tri(NX + p, NX + q)] - q2[tri(p, q)];
+      joint_from_gain<NX, NU>(mu_x, sig_x, Kt, qmu, qmu + NX, sig_u, mu0, S0);
+    }
+    R* out = a.prop + ((long)t * C::E_PROP) * B + b;
+#pragma unroll
+    for (int e = 0; e < D; ++e) out[(long)e * B] = mu0[e];
+#pragma unroll
+    for (int e = 0; e < sym(D); ++e) out[(long)(D + e) * B] = S0[e];
+
+    R rinv[D];
+    if (!chol<D>(S0, rinv)) set_status(a.status, b, 8, t);  // S0 <- L
+    R zt[NZ], mz[NZ], Sz[sym(NZ)];
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
+    sp_transform<D, NZ, false>(c.rule_xu, mu0, S0, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
+    R cm, cv;
+    gaussian_cost<NZ>(c.QR, mz, Sz, zt, &cm, &cv);
+    a.cell_stats[((long)t * 2 + 0) * B + b] = cm;
+    a.cell_stats[((long)t * 2 + 1) * B + b] = cv;
+
+    sp_transform<D, NX, false>(c.rule_xu, mu0, S0, DynamicsF<M, R>{c.params}, mu_x, sig_x, (R*)nullptr);
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) sig_x[i] += c.rule_xu.W * c.sig_eta[i];
+#pragma unroll
+    for (int e = 0; e < NX; ++e) out[(long)(D + sym(D) + e) * B] = mu_x[e];
+#pragma unroll
+    for (int e = 0; e < sym(NX); ++e) out[(long)(D + sym(D) + NX + e) * B] = sig_x[e];
+#pragma unroll
+    for (int e = 0; e < C::E_PRI; ++e) pri[e] = nxt[e];
+  }
+}
+
+}  // namespace i2c

@@ -1,0 +1,199 @@
+// Device functors for the reference's known-model plugins (the `sys` protocol of
+// SURVEY.md section 8b): dynamics / observe / observe_terminal evaluated at one sigma point.
+// Citations are relative to the reference root.
+#pragma once
+#include "i2c_linalg.hpp"
+
+namespace i2c {
+
+// PendulumKnown: i2c/env_def.py:233-309, step i2c/env_autograd.py:5-19
+struct Pendulum {
+  static constexpr int ID = 0, NX = 2, NU = 1, NZ = 4, NZT = 3, NP = 0;
+  template <typename R> I2C_FN void dynamics(const R*, const R* xu, R* xn) {
+    const R dt = R(0.05), damp = R(1e-2), u_max = R(2.0);
+    const R c_grav = R(-3.0 * 9.80665 / (2 * 1.0));  // -3 g / (2 l)
+    const R c_torque = R(3.0 / (1.0 * 1.0 * 1.0));    // 3 / (m l^2)
+    const R u = r_clip(xu[2], -u_max, u_max);
+    R acc = c_grav * r_sin(xu[0] + R(3.14159265358979323846)) - damp * xu[1];
+    acc += c_torque * u;
+    const R om = xu[1] + acc * dt;
+    xn[0] = xu[0] + om * dt;
+    xn[1] = om;
+  }
+  template <typename R> I2C_FN void observe(const R*, const R* xu, R* z) {  // env_def.py:273-276
+    r_sincos(xu[0], &z[0], &z[1]);
+    z[2] = xu[1];
+    z[3] = xu[2];
+  }
+  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, R* z) {  // env_def.py:288-291
+    r_sincos(x[0], &z[0], &z[1]);
+    z[2] = x[1];
+  }
+};
+
+// PendulumKnownActReg: i2c/env_def.py:312-346 (only the action is observed; no terminal observation)
+struct PendulumActReg {
+  static constexpr int ID = 1, NX = 2, NU = 1, NZ = 1, NZT = 0, NP = 0;
+  template <typename R> I2C_FN void dynamics(const R* p, const R* xu, R* xn) { Pendulum::dynamics(p, xu, xn); }
+  template <typename R> I2C_FN void observe(const R*, const R* xu, R* z) { z[0] = xu[2]; }
+  template <typename R> I2C_FN void observe_terminal(const R*, const R*, R*) {}
+};
+
+// CartpoleKnown: i2c/env_def.py:491-612, step i2c/env_autograd.py:25-54
+struct Cartpole {
+  static constexpr int ID = 2, NX = 4, NU = 1, NZ = 6, NZT = 5, NP = 0;
+  template <typename R> I2C_FN void dynamics(const R*, const R* xu, R* xn) {
+    const R grav = R(9.81), m_cart = R(0.37), m_pole = R(0.127), len = R(0.3365);
+    const R dt = R(1.0 / 250.0), u_max = R(5.0);
+    const R m_tot = m_cart + m_pole;
+    const R u = r_clip(xu[4], -u_max, u_max);
+    const R om2 = xu[3] * xu[3];
+    R s, c;
+    r_sincos(xu[1], &s, &c);
+    const R num = -m_pole * len * s * c * om2 + m_tot * grav * s - u * c;
+    const R den = len * (R(4.0 / 3.0) * m_tot - m_pole * (c * c));
+    const R th_acc = num / den;
+    const R x_acc = (m_pole * len * s * om2 - m_pole * len * th_acc * c + u) / m_tot;
+    xn[0] = xu[0] + dt * xu[2];
+    xn[1] = xu[1] + dt * xu[3];
+    xn[2] = xu[2] + dt * x_acc;
+    xn[3] = xu[3] + dt * th_acc;
+  }
+  template <typename R> I2C_FN void observe(const R*, const R* xu, R* z) {  // env_def.py:537-549
+    z[0] = xu[0];
+    r_sincos(xu[1], &z[1], &z[2]);
+    z[3] = xu[2];
+    z[4] = xu[3];
+    z[5] = xu[4];
+  }
+  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, R* z) {  // env_def.py:567-570
+    z[0] = x[0];
+    r_sincos(x[1], &z[1], &z[2]);
+    z[3] = x[2];
+    z[4] = x[3];
+  }
+};
+
+// DoubleCartpoleKnown: i2c/env_def.py:615-761, step i2c/env_autograd.py:60-167
+struct DoubleCartpole {
+  static constexpr int ID = 3, NX = 6, NU = 1, NZ = 9, NZT = 8, NP = 0;
+  template <typename R> I2C_FN void dynamics(const R*, const R* xu, R* xn) {
+    const R dt = R(1.0 / 125.0), grav = R(9.81);
+    const R m_c = R(0.37), m1 = R(0.127), m2 = R(0.127);
+    const R L1 = R(0.3365), L2 = R(0.3365);
+    const R l1 = L1 / 2, l2 = L2 / 2;
+    const R J1 = m1 * L1 / 12, J2 = m2 * L2 / 12;
+    const R u_max = R(10.0), gear = R(3.0);
+    const R m_tot = m_c + m1 + m2;
+    const R h1 = m1 * l1 + m2 * L2, h2 = m2 * l2, h3 = L1 * l2 * m2;
+
+    R s1, c1, s2, c2, sd, cd;
+    r_sincos(xu[1], &s1, &c1);
+    r_sincos(xu[2], &s2, &c2);
+    r_sincos(xu[1] - xu[2], &sd, &cd);
+    const R qd0 = xu[3], qd1 = xu[4], qd2 = xu[5];
+    // symmetric mass matrix M(q)
+    const R M00 = m_tot, M01 = h1 * c1, M02 = h2 * c2;
+    const R M11 = l1 * l1 * m1 + L1 * L1 * m2 + J1, M12 = h3 * cd;
+    const R M22 = l2 * l2 * m2 + J2;
+    // rhs = B u - C(q, qd) qd - G(q)
+    const R u = gear * r_clip(xu[6], -u_max, u_max);
+    const R r0 = u - ((-h1 * qd1 * s1) * qd1 + (-h2 * qd2 * s2) * qd2);
+    const R r1 = -((h3 * qd2 * sd) * qd2) - (-(m1 * l1 + m2 * L1) * grav * s1);
+    const R r2 = -((-h3 * qd1 * sd) * qd1) - (-m2 * l2 * grav * s2);
+    // qdd = M^{-1} rhs through the adjugate (M is symmetric 3x3)
+    const R A00 = M11 * M22 - M12 * M12, A01 = M02 * M12 - M01 * M22, A02 = M01 * M12 - M02 * M11;
+    const R A11 = M00 * M22 - M02 * M02, A12 = M01 * M02 - M00 * M12, A22 = M00 * M11 - M01 * M01;
+    const R idet = R(1) / (M00 * A00 + M01 * A01 + M02 * A02);
+    const R a0 = (A00 * r0 + A01 * r1 + A02 * r2) * idet;
+    const R a1 = (A01 * r0 + A11 * r1 + A12 * r2) * idet;
+    const R a2 = (A02 * r0 + A12 * r1 + A22 * r2) * idet;
+    xn[3] = qd0 + a0 * dt;
+    xn[4] = qd1 + a1 * dt;
+    xn[5] = qd2 + a2 * dt;
+    xn[0] = xu[0] + xn[3] * dt;
+    xn[1] = xu[1] + xn[4] * dt;
+    xn[2] = xu[2] + xn[5] * dt;
+  }
+  template <typename R> I2C_FN void observe(const R*, const R* xu, R* z) {  // env_def.py:682-695
+    z[0] = xu[0];
+    r_sincos(xu[1], &z[1], &z[2]);
+    r_sincos(xu[2], &z[3], &z[4]);
+    z[5] = xu[3];
+    z[6] = xu[4];
+    z[7] = xu[5];
+    z[8] = xu[6];
+  }
+  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, R* z) {  // env_def.py:719-732
+    z[0] = x[0];
+    r_sincos(x[1], &z[1], &z[2]);
+    r_sincos(x[2], &z[3], &z[4]);
+    z[5] = x[3];
+    z[6] = x[4];
+    z[7] = x[5];
+  }
+};
+
+// LinearKnown: i2c/env_def.py:139-191, i2c/model.py:226-246.  params = A (2x2 row-major), B (2), a (2)
+struct Linear {
+  static constexpr int ID = 4, NX = 2, NU = 1, NZ = 3, NZT = 2, NP = 8;
+  template <typename R> I2C_FN void dynamics(const R* p, const R* xu, R* xn) {
+    xn[0] = xu[0] * p[0] + xu[1] * p[1] + xu[2] * p[4] + p[6];
+    xn[1] = xu[0] * p[2] + xu[1] * p[3] + xu[2] * p[5] + p[7];
+  }
+  template <typename R> I2C_FN void observe(const R*, const R* xu, R* z) {
+    z[0] = xu[0];
+    z[1] = xu[1];
+    z[2] = xu[2];
+  }
+  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, R* z) {
+    z[0] = x[0];
+    z[1] = x[1];
+  }
+};
+
+// LinearKnownMinimumEnergy: i2c/env_def.py:194-230 (only the action is observed; terminal = state)
+struct LinearMinEnergy {
+  static constexpr int ID = 5, NX = 2, NU = 1, NZ = 1, NZT = 2, NP = 8;
+  template <typename R> I2C_FN void dynamics(const R* p, const R* xu, R* xn) { Linear::dynamics(p, xu, xn); }
+  template <typename R> I2C_FN void observe(const R*, const R* xu, R* z) { z[0] = xu[2]; }
+  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, R* z) {
+    z[0] = x[0];
+    z[1] = x[1];
+  }
+};
+
+// Build-defined analytic planar quadrotor with the reference's interface and dimensions
+// (scripts/mpc_state_est/mpc_quad.py:219-383: dim_x 6, dim_u 2, dim_z 8, observe = identity).
+// The reference steps a Box2D body, which cannot be reproduced (not vendored / pinned); this is
+// a semi-implicit Euler rigid-body step with the same constants. params = {mass, inertia, u_max}.
+struct Quadrotor {
+  static constexpr int ID = 6, NX = 6, NU = 2, NZ = 8, NZT = 6, NP = 3;
+  template <typename R> I2C_FN void dynamics(const R* p, const R* xu, R* xn) {
+    const R dt = R(0.1), arm = R(0.8), ang_damp = R(0.5), grav = R(9.81);
+    const R mass = p[0], inertia = p[1], u_max = p[2];
+    const R f1 = r_clip(xu[6], R(0), u_max), f2 = r_clip(xu[7], R(0), u_max);
+    const R thrust = f1 + f2;
+    R s, c;
+    r_sincos(xu[2], &s, &c);
+    const R ax = -thrust * s / mass;
+    const R ay = thrust * c / mass - grav;
+    const R al = arm * (f2 - f1) / inertia;
+    xn[3] = xu[3] + dt * ax;
+    xn[4] = xu[4] + dt * ay;
+    xn[5] = (xu[5] + dt * al) / (R(1) + dt * ang_damp);
+    xn[0] = xu[0] + dt * xn[3];
+    xn[1] = xu[1] + dt * xn[4];
+    xn[2] = xu[2] + dt * xn[5];
+  }
+  template <typename R> I2C_FN void observe(const R*, const R* xu, R* z) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = xu[i];
+  }
+  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, R* z) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) z[i] = x[i];
+  }
+};
+
+}  // namespace i2c

@@ -1,0 +1,411 @@
+"""Batched i2c engine: device state as PyTorch tensors, sweeps as HIP kernels through the C ABI.
+
+`BatchedI2c` is the batched counterpart of the reference's I2cGraph (i2c/i2c.py:732-1314): B
+independent trajectories of one model and horizon, optimised by the same EM iteration
+(learn_msgs, i2c.py:1238-1245). The EM loop lives here in Python; every sweep is one call into
+``libi2c_hip.so``. PyTorch is plumbing only: it owns the HBM buffers and the stream.
+
+Device layout (see include/i2c_hip.h): every per-cell buffer is ``[T][E][B]`` with the
+trajectory index innermost, symmetric matrices packed (lower, row-major).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native
+from ._native import F32, F64, I2cProblem
+
+
+def sym_size(n):
+    return n * (n + 1) // 2
+
+
+def tril_index(n):
+    r, c = np.tril_indices(n)
+    return r, c  # row-major order of the lower triangle == packed order
+
+
+def pack_sym_np(mat):
+    """(..., n, n) -> (..., n(n+1)/2) packed lower, row-major."""
+    mat = np.asarray(mat, dtype=np.float64)
+    r, c = tril_index(mat.shape[-1])
+    return mat[..., r, c]
+
+
+def unpack_sym(packed, n):
+    """torch (..., n(n+1)/2) -> (..., n, n) full symmetric."""
+    r, c = tril_index(n)
+    r_t = torch.as_tensor(r, device=packed.device)
+    c_t = torch.as_tensor(c, device=packed.device)
+    out = packed.new_zeros(packed.shape[:-1] + (n, n))
+    out[..., r_t, c_t] = packed
+    out[..., c_t, r_t] = packed
+    return out
+
+
+class I2cNumericalError(np.linalg.LinAlgError):
+    """A covariance lost positive definiteness (the reference raises LinAlgError from
+    np.linalg.cholesky / scipy, i2c/inference/quadrature.py:17-24)."""
+
+
+class BatchedI2c:
+    def __init__(self, model, horizon, Q, R, Qf, alpha, alpha_update_tol, mu_u, sig_u,
+                 mu_x_terminal=None, sig_x_terminal=None, quad=(1.0, 0.0, 0.0), x0=None, sig_x0=None,
+                 z_traj=None, batch=None, dtype=torch.float64, device=None, lib=None, dtemp=1.0,
+                 keep_zpost=True, keep_prior=False):
+        self.lib = lib if lib is not None else _native.load_library()
+        if device is None:
+            device = "cpu" if self.lib.is_host_sim else "cuda"
+        self.device = torch.device(device)
+        if self.lib.is_host_sim != (self.device.type == "cpu"):
+            raise RuntimeError(
+                f"library '{self.lib.build_info}' cannot run on device {self.device}: the HIP build needs a "
+                "GPU tensor device (there is no CPU fallback)"
+            )
+        assert dtype in (torch.float64, torch.float32)
+        self.dtype = dtype
+        self.sys = model
+        self.model_id = int(model.model_id)
+        dims = self.lib.query(self.model_id)
+        self.dims = dims
+        nx, nu, nz, nzt = dims.nx, dims.nu, dims.nz, dims.nzt
+        assert (nx, nu, nz) == (model.dim_x, model.dim_u, model.dim_z), "model plugin / library dimension mismatch"
+        self.nx, self.nu, self.nz, self.nzt, self.d = nx, nu, nz, nzt, nx + nu
+        self.H = T = int(horizon)
+
+        mu_u = np.asarray(mu_u, dtype=np.float64)
+        if mu_u.ndim == 2:
+            mu_u = mu_u[None]
+        assert mu_u.shape[1:] == (T, nu), f"mu_u must be (T, nu) or (B, T, nu), got {mu_u.shape}"
+        B = mu_u.shape[0]
+        if x0 is not None:
+            x0 = np.asarray(x0, dtype=np.float64).reshape(-1, nx)
+            B = max(B, x0.shape[0])
+        if batch is not None:
+            B = max(B, int(batch))
+        self.B = B
+        mu_u = np.broadcast_to(mu_u, (B, T, nu))
+        x0 = np.broadcast_to(np.asarray(model.x0, np.float64).reshape(nx) if x0 is None else x0, (B, nx))
+        sig_x0 = np.asarray(model.sig_x0 if sig_x0 is None else sig_x0, dtype=np.float64)
+        sig_x0 = np.broadcast_to(sig_x0, (B, nx, nx))
+        sig_u = np.atleast_2d(np.asarray(sig_u, dtype=np.float64))
+
+        # cost model (i2c.py:778-793)
+        R = np.atleast_2d(np.asarray(R, dtype=np.float64))
+        if Q is not None:
+            Q = np.atleast_2d(np.asarray(Q, dtype=np.float64))
+            QR = np.zeros((nz, nz))
+            QR[: Q.shape[0], : Q.shape[0]] = Q
+            QR[Q.shape[0]:, Q.shape[0]:] = R
+        else:
+            QR = R
+        assert QR.shape == (nz, nz), f"blkdiag(Q, R) must be ({nz},{nz}), got {QR.shape}"
+        assert np.allclose(QR, QR.T), "Q and R must be symmetric"
+        self.Q, self.R, self.QR = Q, R, QR
+        self.sig_xi0 = np.linalg.inv(QR)
+        assert np.linalg.det(self.sig_xi0) > 0.0  # i2c.py:803-804
+        self.has_Qf = Qf is not None and nzt > 0
+        if Qf is not None:
+            self.Qf = np.atleast_2d(np.asarray(Qf, dtype=np.float64))
+            self.sig_xi_terminal_base = np.linalg.inv(self.Qf)
+        else:
+            self.Qf = np.zeros((nx, nx))  # i2c.py:792
+            self.sig_xi_terminal_base = None
+        self.alpha_update_tol = float(alpha_update_tol)
+        self.quad = tuple(float(q) for q in quad)
+        self.mu_x_terminal = None if mu_x_terminal is None else np.asarray(mu_x_terminal, np.float64).reshape(nx)
+        self.sig_x_terminal = None if sig_x_terminal is None else np.asarray(sig_x_terminal, np.float64)
+        self.has_x_terminal = self.sig_x_terminal is not None
+        if self.has_x_terminal and self.mu_x_terminal is None:
+            raise TypeError("sig_x_terminal given without mu_x_terminal (the reference crashes at i2c.py:558)")
+        self.dtemp = float(dtemp)
+
+        dev, dt = self.device, self.dtype
+        to = lambda a: torch.as_tensor(np.array(a, dtype=np.float64), dtype=dt, device=dev)  # noqa: E731
+        zeros = lambda *s: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+        d = self.d
+        # initial "posterior" = cell constructor state (i2c.py:95-100, 135-136)
+        post = np.zeros((T, dims.e_post, B))
+        post[:, :nx, :] = x0.T[None]
+        post[:, nx:d, :] = np.transpose(mu_u, (1, 2, 0))
+        S0 = np.zeros((B, d, d))
+        S0[:, :nx, :nx] = sig_x0
+        S0[:, nx:, nx:] = sig_u
+        post[:, d: d + sym_size(d), :] = pack_sym_np(S0).T[None]
+        o_k = d + sym_size(d) + nu * nx
+        post[:, o_k: o_k + nu, :] = np.transpose(mu_u, (1, 2, 0))  # k = mu_u (i2c.py:136)
+        post[:, o_k + nu:, :] = pack_sym_np(sig_u)[None, :, None]
+        self.post = to(post)
+        self.fwd = zeros(T, dims.e_fwd, B)
+        self.xm = zeros(T, dims.e_xm, B)
+        self.zpost = zeros(T, dims.e_zpost, B) if keep_zpost else None
+        self.prior_out = zeros(T, d + sym_size(d), B) if keep_prior else None
+        self.cell_stats = zeros(T, 2, B)
+        self.e_term = 3 + nzt + sym_size(nzt)
+        self.term_stats = zeros(self.e_term, B)
+        self.stats_out = zeros(4, B)
+        self.prop = None
+        self.cell_stats_pf = None
+        self.x0 = to(x0.T)
+        self.sig_x0 = to(pack_sym_np(sig_x0).T)
+        self.alpha = to(np.broadcast_to(np.asarray(alpha, np.float64), (B,)))
+        self.temp = torch.ones(B, dtype=dt, device=dev)
+        self.status = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.feedforward = torch.ones(T, dtype=torch.uint8, device=dev)  # i2c.py:132
+        if z_traj is not None:
+            z = np.broadcast_to(np.asarray(z_traj, np.float64), (B, T, nz))
+            self.z = to(np.transpose(z, (1, 2, 0)))
+        else:
+            self.z = None
+        self.zg = np.asarray(model.zg, np.float64).reshape(nz)
+        self.zg_term = None if model.zg_term is None else np.asarray(model.zg_term, np.float64).reshape(-1)
+
+        self.tau = T - 1  # i2c.py:833
+        self._propagate = False
+        self.use_expert_controller = True
+        self.em_iter = 0
+        # per-iteration metrics as device tensors (B,): no host sync inside the EM loop
+        self.alphas = [self.alpha.clone()]
+        self.alphas_desired = [self.alpha.clone()]
+        self.alphas_pf = [self.alpha.clone()]
+        self.costs_m, self.costs_m_var, self.costs_pf, self.costs_pf_var, self.kl_terms = [], [], [], [], []
+        self._problem = self._make_problem()
+
+    # ------------------------------------------------------------------ C-ABI plumbing
+    def _make_problem(self):
+        p = I2cProblem()
+        p.abi_version = _native.ABI_VERSION
+        p.model_id = self.model_id
+        p.dtype = F64 if self.dtype == torch.float64 else F32
+        p.B, p.T = self.B, self.H
+        p.has_Qf = int(self.has_Qf)
+        p.has_x_terminal = int(self.has_x_terminal)
+        p.z_per_cell = int(self.z is not None)
+        p.quad_alpha, p.quad_beta, p.quad_kappa = self.quad
+        p.dtemp = self.dtemp
+
+        def put(dst, arr):
+            arr = np.asarray(arr, np.float64).reshape(-1)
+            for i, v in enumerate(arr):
+                dst[i] = float(v)
+
+        put(p.sig_eta, pack_sym_np(np.asarray(self.sys.sig_eta, np.float64)))
+        put(p.sig_xi0, pack_sym_np(self.sig_xi0))
+        put(p.QR, pack_sym_np(self.QR))
+        if self.has_Qf:
+            assert self.Qf.shape == (self.nzt, self.nzt)
+            put(p.sig_xiT0, pack_sym_np(self.sig_xi_terminal_base))
+            put(p.Qf, pack_sym_np(self.Qf))
+            put(p.zg_term, self.zg_term)
+        put(p.zg, self.zg)
+        if self.has_x_terminal:
+            put(p.mu_x_term, self.mu_x_terminal)
+            put(p.sig_x_term, pack_sym_np(self.sig_x_terminal))
+        params = list(self.sys.device_params()) if hasattr(self.sys, "device_params") else []
+        assert len(params) == self.dims.n_params, "model plugin / library parameter-count mismatch"
+        put(p.model_params, params)
+        p.x0 = self.x0.data_ptr()
+        p.sig_x0 = self.sig_x0.data_ptr()
+        p.z = self.z.data_ptr() if self.z is not None else None
+        p.alpha = self.alpha.data_ptr()
+        p.temp = self.temp.data_ptr()
+        p.feedforward = self.feedforward.data_ptr()
+        return p
+
+    def refresh_problem(self):
+        """Rebuild the C problem descriptor after changing host-side constants / tensors."""
+        self._problem = self._make_problem()
+
+    def _stream(self):
+        if self.device.type == "cuda":
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return None
+
+    @staticmethod
+    def _ptr(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    @staticmethod
+    def _check(rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed with code {rc} (see include/i2c_hip.h)")
+
+    # ------------------------------------------------------------------ sweeps
+    def forward_sweep(self):
+        """I2cGraph._forward_msgs (i2c.py:876-880)."""
+        rc = self.lib.i2c_forward_sweep(C.byref(self._problem), self._ptr(self.post), self._ptr(self.fwd),
+                                        self._ptr(self.prior_out), self._ptr(self.status), self._stream())
+        self._check(rc, "i2c_forward_sweep")
+
+    def backward_sweep(self):
+        """I2cGraph._backward_msgs (i2c.py:882-886) + per-cell M-step statistics."""
+        rc = self.lib.i2c_backward_sweep(C.byref(self._problem), self._ptr(self.fwd), self._ptr(self.xm),
+                                         self._ptr(self.post), self._ptr(self.zpost), self._ptr(self.cell_stats),
+                                         self._ptr(self.term_stats), self._ptr(self.status), self._stream())
+        self._check(rc, "i2c_backward_sweep")
+
+    def forward_backward(self):
+        """I2cGraph._forward_backward_msgs (i2c.py:1231-1236)."""
+        self.forward_sweep()
+        self.backward_sweep()
+
+    def propagate(self):
+        """I2cGraph.propagate (i2c.py:1247-1251)."""
+        if self.prop is None:
+            self.prop = torch.zeros(self.H, self.dims.e_prop, self.B, dtype=self.dtype, device=self.device)
+            self.cell_stats_pf = torch.zeros(self.H, 2, self.B, dtype=self.dtype, device=self.device)
+        rc = self.lib.i2c_propagate(C.byref(self._problem), self._ptr(self.post), self._ptr(self.prop),
+                                    self._ptr(self.cell_stats_pf), int(self.use_expert_controller),
+                                    self._ptr(self.status), self._stream())
+        self._check(rc, "i2c_propagate")
+
+    def update_priors(self):
+        """I2cGraph._update_priors (i2c.py:1210-1221). The data copy is free: the forward sweep reads
+        the posterior buffer as its prior; only the feed-forward -> feedback flags change."""
+        if self.tau > 0:
+            self.feedforward[: self.tau + 1] = 0
+
+    def _alpha_from_stats(self, cell_stats, with_terminal):
+        m = cell_stats[:, 0, :].sum(dim=0)
+        sf = float(self.nz * self.H)
+        if with_terminal and self.has_Qf:
+            m = m + self.term_stats[0]
+            sf += float(self.nzt)
+        return m / sf
+
+    def maximize(self, update_alpha=True):
+        """I2cGraph._maximize (i2c.py:1004-1019): cost, prior update, temperature M-step."""
+        rc = self.lib.i2c_mstep(C.byref(self._problem), self._ptr(self.cell_stats), self._ptr(self.term_stats),
+                                self.alpha_update_tol, int(bool(update_alpha)), self._ptr(self.stats_out),
+                                self._stream())
+        self._check(rc, "i2c_mstep")
+        out = self.stats_out.clone()
+        self.costs_m.append(out[2])
+        self.costs_m_var.append(out[3])
+        if self._propagate:
+            self.costs_pf.append(self.cell_stats_pf[:, 0, :].sum(dim=0))
+            self.costs_pf_var.append(self.cell_stats_pf[:, 1, :].sum(dim=0))
+            self.alphas_pf.append(self._alpha_from_stats(self.cell_stats_pf, False))
+        else:
+            self.costs_pf.append(torch.full_like(out[2], -1.0))  # i2c.py:1065
+        self.update_priors()
+        self.alphas_desired.append(out[0])
+        self.alphas.append(out[1])
+        if self.has_x_terminal:
+            self.kl_terms.append(self._terminal_kl())
+
+    def learn_msgs(self):
+        """One EM iteration (I2cGraph.learn_msgs, i2c.py:1238-1245)."""
+        self.em_iter += 1
+        self.forward_backward()
+        if self._propagate:
+            self.propagate()
+        self.maximize()
+
+    def calibrate_alpha(self, only_decrease=False):
+        """I2cGraph.calibrate_alpha (i2c.py:895-911)."""
+        assert self._propagate
+        self.propagate()
+        a = self._alpha_from_stats(self.cell_stats_pf, False)
+        if only_decrease:
+            a = torch.where(a < self.alpha, a, self.alpha)
+        self.alpha.copy_(a)
+        self.alphas[-1] = self.alpha.clone()
+
+    def _terminal_kl(self):
+        """mvn_kl_divergence(x3_pf[T-1] || terminal prior) (i2c.py:1012-1019, 1223-1229)."""
+        nx = self.nx
+        if self.prop is None:
+            mu1 = self.x0.T.to(torch.float64)
+            sig1 = unpack_sym(self.sig_x0.T.to(torch.float64), nx)
+        else:
+            o = self.d + sym_size(self.d)
+            mu1 = self.prop[-1, o: o + nx, :].T.to(torch.float64)
+            sig1 = unpack_sym(self.prop[-1, o + nx: o + nx + sym_size(nx), :].T.to(torch.float64), nx)
+        mu2 = torch.as_tensor(self.mu_x_terminal, dtype=torch.float64, device=self.device)
+        sig2 = torch.as_tensor(self.sig_x_terminal, dtype=torch.float64, device=self.device)
+        diff = mu2 - mu1
+        dist = (diff * torch.linalg.solve(sig2, diff.T).T).sum(-1)
+        log_det_ratio = torch.log(torch.linalg.det(sig2) / torch.linalg.det(sig1))
+        trace_ratio = torch.diagonal(torch.linalg.solve(sig2, sig1), dim1=-2, dim2=-1).sum(-1)
+        return 0.5 * (log_det_ratio + trace_ratio + dist - nx)
+
+    # ------------------------------------------------------------------ failure reporting
+    def failures(self):
+        """Per-trajectory status words -> list of (b, reason, t) for failed trajectories."""
+        st = self.status.cpu().numpy()
+        return [(int(b), int(s) >> 16, (int(s) & 0xFFFF) - 1) for b, s in enumerate(st) if s != 0]
+
+    def raise_on_failure(self):
+        """With B == 1 behave like the reference: raise; batched callers read `failures()`."""
+        f = self.failures()
+        if f:
+            b, reason, t = f[0]
+            raise I2cNumericalError(f"trajectory {b}, cell {t}: {_native.FAIL_REASONS.get(reason, reason)}")
+
+    # ------------------------------------------------------------------ getters: (B, T, ...) tensors
+    def _rows(self, buf, lo, n):
+        return buf[:, lo: lo + n, :].permute(2, 0, 1)  # (B, T, n)
+
+    def _sym_rows(self, buf, lo, n):
+        return unpack_sym(self._rows(buf, lo, sym_size(n)), n)
+
+    def marginal_state_action(self):
+        """(mu_xu0_m (B,T,d), sig_xu0_m (B,T,d,d)): i2c.py:1300-1304."""
+        return self._rows(self.post, 0, self.d), self._sym_rows(self.post, self.d, self.d)
+
+    def local_linear_policy(self):
+        """(K (B,T,nu,nx), k (B,T,nu), sigK (B,T,nu,nu)): i2c.py:1253-1264."""
+        o = self.d + sym_size(self.d)
+        K = self._rows(self.post, o, self.nu * self.nx).reshape(self.B, self.H, self.nu, self.nx)
+        k = self._rows(self.post, o + self.nu * self.nx, self.nu)
+        sigK = self._sym_rows(self.post, o + self.nu * self.nx + self.nu, self.nu)
+        return K, k, sigK
+
+    def forward_messages(self):
+        d, nx = self.d, self.nx
+        o = d + sym_size(d)
+        return dict(
+            mu_xu1_f=self._rows(self.fwd, 0, d),
+            sig_xu1_f=self._sym_rows(self.fwd, d, d),
+            mu_x3_f=self._rows(self.fwd, o, nx),
+            sig_x3_f=self._sym_rows(self.fwd, o + nx, nx),
+            J_dyn=self._rows(self.fwd, o + nx + sym_size(nx), d * nx).reshape(self.B, self.H, d, nx),
+        )
+
+    def smoothed_next_state(self):
+        return self._rows(self.xm, 0, self.nx), self._sym_rows(self.xm, self.nx, self.nx)
+
+    def observed_marginal(self):
+        """(mu_z0_m (B,T,nz), sig_z0_m (B,T,nz,nz)) (i2c.py:594-596, 1312-1314)."""
+        assert self.zpost is not None, "constructed with keep_zpost=False"
+        return self._rows(self.zpost, 0, self.nz), self._sym_rows(self.zpost, self.nz, self.nz)
+
+    def terminal_observed_marginal(self):
+        if not self.has_Qf:
+            return None, None
+        nzt = self.nzt
+        return self.term_stats[3: 3 + nzt].T, unpack_sym(self.term_stats[3 + nzt:].T, nzt)
+
+    def prior_state_action(self):
+        assert self.prior_out is not None, "constructed with keep_prior=False"
+        return self._rows(self.prior_out, 0, self.d), self._sym_rows(self.prior_out, self.d, self.d)
+
+    def propagated(self):
+        d, nx = self.d, self.nx
+        o = d + sym_size(d)
+        return dict(
+            mu_xu0_pf=self._rows(self.prop, 0, d),
+            sig_xu0_pf=self._sym_rows(self.prop, d, d),
+            mu_x3_pf=self._rows(self.prop, o, nx),
+            sig_x3_pf=self._sym_rows(self.prop, o + nx, nx),
+        )
+
+    # ------------------------------------------------------------------ history helpers
+    @staticmethod
+    def history(lst):
+        """list of (B,) device tensors -> (n, B) float64 numpy (one host sync)."""
+        if not lst:
+            return np.zeros((0, 0))
+        return torch.stack([x.to(torch.float64) for x in lst]).cpu().numpy()

@@ -1,0 +1,413 @@
+"""Known-model plugins (`sys` objects) for the MI355X build.
+
+Each class carries (a) the attribute protocol the reference's callers read (dim_x, dim_u,
+dim_xu, dim_z, dim_z_term, x0 (nx,1), sig_x0, sig_eta, zg (nz,1), zg_term, xu_lim ...;
+reference i2c/env_def.py:34-82) and (b) ``model_id`` / ``device_params()`` selecting the
+compile-time device functor in csrc/i2c_models.hpp that the solver actually evaluates.
+
+The NumPy methods (``dynamics``, ``observe``, ``observe_terminal``, ``forward`` ...) exist for
+the host-side callers of the same protocol (simulators, the MPC state estimator, scripts that
+poke ``sys.forward`` directly): they are NOT used by I2cGraph, whose sweeps run on the GPU.
+"""
+import numpy as np
+
+
+class KnownModel:
+    """Base of all known models (reference: BaseDef env_def.py:12-137 + BaseModelKnown model.py:144-183)."""
+
+    name = "Template"
+    model_name = None
+    model_id = None
+    data_driven = False
+    deterministic = False
+    model = None
+    dim_x = dim_u = dim_z = dim_z_term = None
+    xag = None
+    x0_dist = None
+    xu_lim = None
+
+    def __init__(self, model=None, model_def=None):
+        assert model is None and model_def is None, "only known models exist in the MI355X build"
+
+    # ---- dimensions -----------------------------------------------------------------
+    @property
+    def dim_xu(self):
+        return self.dim_x + self.dim_u
+
+    dim_s = dim_xat = dim_xu
+
+    @property
+    def dim_yt(self):
+        return self.dim_x
+
+    @property
+    def random_starting_state(self):
+        return self.x0_dist is not None
+
+    # ---- targets ----------------------------------------------------------------------
+    @property
+    def zg(self):
+        zeros_u = np.zeros((self.dim_u, 1))
+        return zeros_u if self.xag is None else np.vstack((self.xag, zeros_u))
+
+    @property
+    def zg_term(self):
+        return self.zg
+
+    # ---- device side ------------------------------------------------------------------
+    def device_params(self):
+        return []
+
+    # ---- host-side protocol -----------------------------------------------------------
+    def dynamics(self, xu):
+        raise NotImplementedError
+
+    def observe(self, xu):
+        raise NotImplementedError
+
+    def observe_terminal(self, x):
+        raise NotImplementedError
+
+    def observe_terminal_x(self, x):
+        return self.observe_terminal(x)
+
+    def forward(self, xu):
+        xn = self.dynamics(xu)
+        return xn, np.broadcast_to(self.sig_eta, (xu.shape[0],) + self.sig_eta.shape).copy()
+
+    def __call__(self, xu):
+        return self.forward(xu)
+
+    def predict(self, xu):
+        return self.dynamics(xu)
+
+    def init(self):
+        return self.x0.squeeze(), self.sig_x0
+
+    def sample(self, xu):
+        mean, cov = self.forward(xu)
+        noise = np.random.randn(xu.shape[0], self.dim_x)
+        return mean + np.einsum("bij,bj->bi", np.linalg.cholesky(cov), noise)
+
+    def clip_u(self, u):
+        return np.clip(u, self.xu_lim[0, self.dim_x:], self.xu_lim[1, self.dim_x:])
+
+    def run(self, horizon, policy, deterministic=False):
+        """Roll a policy through the model (reference BaseModel.run, model.py:65-77)."""
+        XU = np.zeros((horizon, self.dim_xu))
+        Z = np.zeros((horizon, self.dim_z))
+        x = np.array(self.x0, dtype=float).reshape(1, self.dim_x)
+        for t in range(horizon):
+            u = policy(t, x.T, deterministic=deterministic).T
+            xu = np.hstack((x, u))
+            XU[t], Z[t] = xu, self.observe(xu)[0]
+            x = self.sample(xu)
+        return XU, Z, np.squeeze(self.observe_terminal(x))
+
+    def train(self, *a, **k):
+        pass
+
+    def save(self, path):
+        print("Known model, no saving")
+
+
+_INF = np.inf
+
+
+class PendulumKnown(KnownModel):
+    """Torque-limited pendulum swing-up (reference env_def.py:233-309, env_autograd.py:5-19)."""
+
+    name = "Pendulum"
+    model_name = "PendulumKnown"
+    model_id = 0
+    key = ["$\\theta$", "$\\dot{\\theta}$", "$u$"]
+    z_key = ["$\\sin(\\theta)$", "$\\cos(\\theta)$", "$\\dot{\\theta}$", "$u$"]
+    unit = ["rad", "rad/s", "Nm"]
+    dim_x, dim_u, dim_z, dim_z_term, dim_xuf = 2, 1, 4, 3, 4
+
+    def __init__(self, model=None, model_def=None):
+        super().__init__(model, model_def)
+        self.x0 = np.array([[np.pi], [0.0]])
+        self.xg = np.zeros((2, 1))
+        self.xag = np.array([[0.0], [1.0], [0.0]])
+        self._zg_term = np.array([[0.0], [1.0], [0.0]])
+        self.sig_x0 = 1e-5 * np.eye(2)
+        self.sig_eta = np.diag([1e-5, 1e-5])
+        self.xu_lim = np.array([[-_INF, -_INF, -2.0], [_INF, _INF, 2.0]])
+
+    @property
+    def zg_term(self):
+        return self._zg_term
+
+    def dynamics(self, xu):
+        xu = np.asarray(xu, dtype=float)
+        th, om = xu[:, 0], xu[:, 1]
+        torque = np.clip(xu[:, 2], -2.0, 2.0)
+        acc = (-3.0 * 9.80665 / 2.0) * np.sin(th + np.pi) - 1e-2 * om + 3.0 * torque
+        om2 = om + 0.05 * acc
+        return np.column_stack((th + 0.05 * om2, om2))
+
+    def observe(self, xu):
+        return np.column_stack((np.sin(xu[:, 0]), np.cos(xu[:, 0]), xu[:, 1], xu[:, 2]))
+
+    def observe_terminal(self, x):
+        return np.column_stack((np.sin(x[:, 0]), np.cos(x[:, 0]), x[:, 1]))
+
+
+class PendulumKnownActReg(PendulumKnown):
+    """Pendulum with only the action in the cost (covariance control; env_def.py:312-346)."""
+
+    model_name = "PendulumKnownActReg"
+    model_id = 1
+    z_key = ["$u$"]
+    dim_z, dim_z_term = 1, 1
+
+    def __init__(self, model=None, model_def=None):
+        super().__init__(model, model_def)
+        self.xag = None
+        self.xg = np.array([[None], [None]])
+
+    def observe(self, xu):
+        return xu[:, self.dim_x:]
+
+    def observe_terminal(self, x):
+        return None
+
+
+class CartpoleKnown(KnownModel):
+    """Cart-pole swing-up (env_def.py:491-612, env_autograd.py:25-54)."""
+
+    name = "Cartpole"
+    model_name = "CartpoleKnown"
+    model_id = 2
+    dim_x, dim_u, dim_z, dim_z_term, dim_xuf = 4, 1, 6, 5, 6
+
+    def __init__(self, model=None, model_def=None):
+        super().__init__(model, model_def)
+        self.x0 = np.array([[0.0], [np.pi], [0.0], [0.0]])
+        self.xg = np.zeros((4, 1))
+        self.xag = np.array([[0.0], [0.0], [1.0], [0.0], [0.0]])
+        self._zg_term = self.xag.copy()
+        self.sig_x0 = 1e-5 * np.eye(4)
+        self.sig_eta = 1e-8 * np.eye(4)
+        self.xu_lim = np.array([[-_INF] * 4 + [-5.0], [_INF] * 4 + [5.0]])
+
+    @property
+    def zg_term(self):
+        return self._zg_term
+
+    def dynamics(self, xu):
+        xu = np.asarray(xu, dtype=float)
+        g, m_p, ln, dt = 9.81, 0.127, 0.3365, 1.0 / 250.0
+        m_t = 0.37 + m_p
+        u = np.clip(xu[:, 4], -5.0, 5.0)
+        s, c, w2 = np.sin(xu[:, 1]), np.cos(xu[:, 1]), xu[:, 3] ** 2
+        th_acc = (-m_p * ln * s * c * w2 + m_t * g * s - u * c) / (ln * (4.0 / 3.0 * m_t - m_p * c ** 2))
+        x_acc = (m_p * ln * s * w2 - m_p * ln * th_acc * c + u) / m_t
+        return np.column_stack((xu[:, 0] + dt * xu[:, 2], xu[:, 1] + dt * xu[:, 3], xu[:, 2] + dt * x_acc,
+                                xu[:, 3] + dt * th_acc))
+
+    def observe(self, xu):
+        return np.column_stack((xu[:, 0], np.sin(xu[:, 1]), np.cos(xu[:, 1]), xu[:, 2], xu[:, 3], xu[:, 4]))
+
+    def observe_terminal(self, x):
+        return np.column_stack((x[:, 0], np.sin(x[:, 1]), np.cos(x[:, 1]), x[:, 2], x[:, 3]))
+
+
+class DoubleCartpoleKnown(KnownModel):
+    """Double cart-pole swing-up (env_def.py:615-761, env_autograd.py:60-167)."""
+
+    name = "Double Cartpole"
+    model_name = "DoubleCartpoleKnown"
+    model_id = 3
+    dim_x, dim_u, dim_z, dim_z_term, dim_xuf = 6, 1, 9, 8, 9
+
+    def __init__(self, model=None, model_def=None):
+        super().__init__(model, model_def)
+        self.x0 = np.array([[0.0], [np.pi], [np.pi], [0.0], [0.0], [0.0]])
+        self.xg = np.zeros((6, 1))
+        self.xag = np.array([[0.0, 0.0, 1.0, 0.0, 1.0, 0.0, 0.0, 0.0]]).T
+        self._zg_term = self.xag.copy()
+        self.sig_x0 = 1e-6 * np.eye(6)
+        self.sig_eta = 1e-6 * np.eye(6)
+        self.xu_lim = np.array([[-_INF] * 6 + [-10.0], [_INF] * 6 + [10.0]])
+
+    @property
+    def zg_term(self):
+        return self._zg_term
+
+    def dynamics(self, xu):
+        xu = np.asarray(xu, dtype=float)
+        dt, g, m1, m2, L1 = 1 / 125, 9.81, 0.127, 0.127, 0.3365
+        l1 = l2 = L1 / 2
+        m_t = 0.37 + m1 + m2
+        h1, h2, h3 = m1 * l1 + m2 * L1, m2 * l2, L1 * l2 * m2
+        s1, c1, s2, c2 = np.sin(xu[:, 1]), np.cos(xu[:, 1]), np.sin(xu[:, 2]), np.cos(xu[:, 2])
+        sd, cd = np.sin(xu[:, 1] - xu[:, 2]), np.cos(xu[:, 1] - xu[:, 2])
+        n = xu.shape[0]
+        M = np.empty((n, 3, 3))
+        M[:, 0, 0] = m_t
+        M[:, 0, 1] = M[:, 1, 0] = h1 * c1
+        M[:, 0, 2] = M[:, 2, 0] = h2 * c2
+        M[:, 1, 1] = l1 ** 2 * m1 + L1 ** 2 * m2 + m1 * L1 / 12
+        M[:, 1, 2] = M[:, 2, 1] = h3 * cd
+        M[:, 2, 2] = l2 ** 2 * m2 + m2 * L1 / 12
+        w1, w2 = xu[:, 4], xu[:, 5]
+        rhs = np.column_stack((
+            3.0 * np.clip(xu[:, 6], -10.0, 10.0) + h1 * w1 * w1 * s1 + h2 * w2 * w2 * s2,
+            -h3 * w2 * w2 * sd + h1 * g * s1,
+            h3 * w1 * w1 * sd + h2 * g * s2,
+        ))
+        acc = np.linalg.solve(M, rhs[:, :, None])[:, :, 0]
+        vel = xu[:, 3:6] + dt * acc
+        return np.hstack((xu[:, 0:3] + dt * vel, vel))
+
+    def observe(self, xu):
+        return np.column_stack((xu[:, 0], np.sin(xu[:, 1]), np.cos(xu[:, 1]), np.sin(xu[:, 2]), np.cos(xu[:, 2]),
+                                xu[:, 3], xu[:, 4], xu[:, 5], xu[:, 6]))
+
+    def observe_terminal(self, x):
+        return np.column_stack((x[:, 0], np.sin(x[:, 1]), np.cos(x[:, 1]), np.sin(x[:, 2]), np.cos(x[:, 2]),
+                                x[:, 3], x[:, 4], x[:, 5]))
+
+
+class LinearExact(KnownModel):
+    """Linear dynamical system used for the LQR equivalence (env_def.py:139-191, model.py:226-246)."""
+
+    name = "Linear"
+    model_name = "LinearKnown"
+    model_id = 4
+    key = ["$x_1$", "$x_2$", "$u$"]
+    dim_x, dim_u, dim_z, dim_z_term = 2, 1, 3, 2
+
+    def __init__(self, model=None, model_def=None):
+        super().__init__(model, model_def)
+        self.x0 = np.array([[5.0], [5.0]])
+        self.xg = np.array([[1.0], [-1.0]])
+        self.xag = self.xg
+        self.zg_term_ = self.xg
+        self.sig_x0 = 1e-20 * np.eye(2)
+        self.sig_eta = 1e-20 * np.eye(2)
+        self.A = np.array([[1.1, 0.0], [0.1, 1.1]])
+        self.B = np.array([[0.1], [0.0]])
+        self.a = self.xg - self.A @ self.xg
+        self.xu_lim = np.array([[-_INF] * 3, [_INF] * 3])
+
+    @property
+    def zg_term(self):
+        return self.zg_term_
+
+    @zg_term.setter
+    def zg_term(self, v):
+        self.zg_term_ = v
+
+    @property
+    def AB(self):
+        return np.concatenate((self.A, self.B), axis=1)
+
+    def device_params(self):
+        return list(self.A.reshape(-1)) + list(self.B.reshape(-1)) + list(np.asarray(self.a).reshape(-1))
+
+    def dynamics(self, xu):
+        return xu @ self.AB.T + np.asarray(self.a).reshape(1, -1)
+
+    def observe(self, xu):
+        return np.array(xu, dtype=float)
+
+    def observe_terminal(self, x):
+        return np.array(x, dtype=float)
+
+
+class LinearMinimumEnergy(LinearExact):
+    """LDS with action-only cost for covariance control (env_def.py:194-230)."""
+
+    model_name = "LinearKnownMinimumEnergy"
+    model_id = 5
+    dim_z = 1
+
+    def __init__(self, model=None, model_def=None):
+        super().__init__(model, model_def)
+        self.sig_x0 = np.diag([1e-1, 5e0])
+        self.xag = None
+        self.zg_term_ = np.array([[-5.0], [-5.0]])
+        self.A = np.array([[1.05, 0.0], [0.05, 1.01]])
+        self.B = np.array([[0.1], [0.0]])
+        self.a = self.zg_term_ - self.A @ self.zg_term_
+        self.sig_eta = np.diag([1e-1, 1e-2])
+
+    def observe(self, xu):
+        return xu[:, self.dim_x:]
+
+
+class PlanarQuadrotor(KnownModel):
+    """Build-defined analytic planar quadrotor with the interface of the reference's Box2D
+    QuadrotorDef (scripts/mpc_state_est/mpc_quad.py:219-383); see csrc/i2c_models.hpp."""
+
+    name = "2D Quadrotor"
+    model_name = "PlanarQuadrotor"
+    model_id = 6
+    dim_x, dim_u, dim_z, dim_y = 6, 2, 8, 8
+    dim_z_term = 6
+    dt, arm, half_h, density, ang_damp, grav = 0.1, 0.8, 0.8 / 6.0, 5.0, 0.5, 9.81
+
+    def __init__(self, model=None, model_def=None):
+        super().__init__(model, model_def)
+        w, h = 2 * self.arm, 2 * self.half_h
+        self.mass = self.density * w * h
+        self.inertia = self.mass * (w * w + h * h) / 12.0
+        hover = 0.5 * self.mass * self.grav
+        self.u_max = 4.0 * hover
+        self.x0 = np.zeros((6, 1))
+        self.sig_x0 = 1e-4 * np.eye(6)
+        self.sig_eta = 1e-6 * np.eye(6)
+        self.xag = np.array([[2.0, 2.0, 0.0, 0.0, 0.0, 0.0]]).T
+        self._zg = np.vstack((self.xag, np.full((2, 1), hover)))
+        self.sig_zeta = None
+        self.xu_lim = np.array([[-_INF] * 6 + [0.0, 0.0], [_INF] * 6 + [self.u_max] * 2])
+
+    @property
+    def zg(self):
+        return self._zg
+
+    @property
+    def zg_term(self):
+        return self.xag
+
+    def device_params(self):
+        return [self.mass, self.inertia, self.u_max]
+
+    def dynamics(self, xu):
+        xu = np.asarray(xu, dtype=float)
+        f1, f2 = np.clip(xu[:, 6], 0.0, self.u_max), np.clip(xu[:, 7], 0.0, self.u_max)
+        thrust = f1 + f2
+        vx = xu[:, 3] - self.dt * thrust * np.sin(xu[:, 2]) / self.mass
+        vy = xu[:, 4] + self.dt * (thrust * np.cos(xu[:, 2]) / self.mass - self.grav)
+        om = (xu[:, 5] + self.dt * self.arm * (f2 - f1) / self.inertia) / (1.0 + self.dt * self.ang_damp)
+        return np.column_stack((xu[:, 0] + self.dt * vx, xu[:, 1] + self.dt * vy, xu[:, 2] + self.dt * om, vx, vy, om))
+
+    def observe(self, xu):
+        return np.array(xu, dtype=float)
+
+    def observe_terminal(self, x):
+        return np.array(x, dtype=float)
+
+
+ENVIRONMENTS = {
+    "LinearKnown": LinearExact,
+    "LinearKnownMinimumEnergy": LinearMinimumEnergy,
+    "PendulumKnown": PendulumKnown,
+    "PendulumKnownActReg": PendulumKnownActReg,
+    "CartpoleKnown": CartpoleKnown,
+    "DoubleCartpoleKnown": DoubleCartpoleKnown,
+    "PlanarQuadrotor": PlanarQuadrotor,
+}
+
+
+def make_env_model(env_def, model_def=None):
+    """Same call as the reference's i2c.model.make_env_model (model.py:19-44); known models only."""
+    if model_def is not None:
+        raise ValueError("learned models are not part of the MI355X build (none exists in the reference either)")
+    try:
+        return ENVIRONMENTS[env_def]()
+    except KeyError:
+        raise KeyError(f"unknown or unsupported environment '{env_def}'; available: {sorted(ENVIRONMENTS)}")

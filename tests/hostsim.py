@@ -1,0 +1,39 @@
+"""Builds (once) and loads the HOST SIMULATION of the kernel math: csrc/i2c_capi.hip compiled
+by g++ with -DI2C_HOST_SIM, i.e. the very same templated cell code looped on the CPU.
+
+Test infrastructure only: it lets `-m "not gpu"` tests check the kernels' arithmetic against
+the oracle in a container without a GPU. The product package never builds, looks for, or
+loads this library.
+"""
+import importlib
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "input-inference-for-control_amd", "csrc")
+OUT_DIR = os.path.join(ROOT, "tests", "_hostsim")
+OUT = os.path.join(OUT_DIR, "libi2c_hostsim.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "i2c_hip.h")]
+    newest = max(os.path.getmtime(s) for s in srcs)
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
+        return OUT
+    os.makedirs(OUT_DIR, exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-x", "c++", "-DI2C_HOST_SIM",
+           os.path.join(CSRC, "i2c_capi.hip"), "-o", OUT]
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        pkg = importlib.import_module("input-inference-for-control_amd")
+        _lib = pkg.load_library(build())
+        assert _lib.is_host_sim
+    return _lib

@@ -1,0 +1,104 @@
+"""GPU parity tests proper: the HIP kernels, through the C ABI, against the golden vectors of
+the real reference and against the CPU oracle on the same seeded inputs. fp64 tolerances are
+far inside the north star's 1e-5 (means) / 1e-4 (covariances)."""
+import numpy as np
+import pytest
+import torch
+
+import parity
+from golden_util import assert_close, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    l = parity.pkg.load_library()
+    assert not l.is_host_sim, "GPU tests must run the HIP build"
+    return l
+
+
+GOLDEN = [
+    ("em_pendulum_T200", 1e-8, 1e-7),
+    ("em_pendulum_T40_quad_general", 1e-8, 1e-7),
+    ("em_dcp_T60", 1e-6, 1e-5),
+    ("em_cartpole_T100", 1e-6, 1e-5),
+    ("em_linear_T60", 1e-8, 1e-7),
+    ("em_covctrl_T100", 1e-7, 1e-6),
+    ("em_pendulum_T50_propagate", 1e-8, 1e-7),
+]
+
+
+@pytest.mark.parametrize("name,tol_d,tol_s", GOLDEN)
+def test_hip_vs_reference_golden(lib, name, tol_d, tol_s):
+    parity.check_against_golden(name, lib, "cuda", tol_d, tol_s)
+
+
+def test_hip_pendulum_200_iterations_vs_reference(lib):
+    """Free-running 200 EM iterations (the shipped N_INFERENCE) against the reference's run."""
+    parity.check_against_golden("em_pendulum_T200_run200", lib, "cuda", 1e-7, 1e-5)
+
+
+def test_hip_double_cartpole_T300_vs_reference(lib):
+    parity.check_against_golden("em_dcp_T300_run20", lib, "cuda", 1e-6, 1e-5)
+
+
+@pytest.mark.parametrize("name,B,iters", [("em_pendulum_T200", 256, 4), ("em_dcp_T60", 64, 3), ("em_covctrl_T100", 64, 4),
+                                          ("em_cartpole_T100", 64, 3)])
+def test_hip_batch_vs_oracle(lib, name, B, iters):
+    parity.check_batch_against_oracle(name, lib, "cuda", B, iters, tol=1e-6)
+
+
+def test_hip_full_size_pendulum_B4096_T200_vs_oracle(lib):
+    """BASELINE.json's headline shape, every trajectory and every cell against the oracle."""
+    parity.check_batch_against_oracle("em_pendulum_T200", lib, "cuda", 4096, 2, tol=1e-6)
+
+
+def test_hip_batch_position_invariance(lib):
+    """A trajectory's result must not depend on where it sits in the batch (no cross-lane leaks):
+    the reference problem placed at b = 0, 77 and B-1 gives bit-identical outputs."""
+    g = load_case("em_pendulum_T200")
+    B = 1000  # not a multiple of 64: exercises the ragged last wavefront
+    x0, mu_u = parity.batched_inputs(g, B)
+    for b in (77, B - 1):
+        x0[b], mu_u[b] = x0[0], mu_u[0]
+    eng = parity.engine_from_case(g, lib, "cuda", x0=x0, mu_u=mu_u)
+    for _ in range(3):
+        eng.learn_msgs()
+    mu, sig = eng.marginal_state_action()
+    K, k, sigK = eng.local_linear_policy()
+    for t in (mu, sig, K, k, sigK):
+        t = t.cpu().numpy()
+        assert np.array_equal(t[0], t[77]) and np.array_equal(t[0], t[B - 1])
+    assert np.array_equal(eng.alpha.cpu().numpy()[[77, B - 1]], eng.alpha.cpu().numpy()[[0, 0]])
+
+
+def test_hip_failure_is_per_trajectory(lib):
+    """One non-PD trajectory must not kill the batch: poison sig_x0 of b = 3."""
+    g = load_case("em_pendulum_T40_quad_general")
+    B = 8
+    x0, mu_u = parity.batched_inputs(g, B)
+    eng = parity.engine_from_case(g, lib, "cuda", x0=x0, mu_u=mu_u)
+    eng.sig_x0[:, 3] = torch.tensor([1e-5, 1.0, 1e-5], dtype=eng.dtype, device=eng.device)  # not PD
+    eng.learn_msgs()
+    fails = eng.failures()
+    assert [f[0] for f in fails] == [3] and fails[0][2] == 0
+    mu, _ = eng.marginal_state_action()
+    ok = [b for b in range(B) if b != 3]
+    assert torch.isfinite(mu[ok]).all()
+    with pytest.raises(np.linalg.LinAlgError):
+        eng.raise_on_failure()
+
+
+def test_hip_fp32_runs_and_tracks_fp64(lib):
+    """fp32 variant (config 3's tolerance sweep): same problem in both precisions."""
+    g = load_case("em_pendulum_T200")
+    e64 = parity.engine_from_case(g, lib, "cuda", dtype=torch.float64)
+    e32 = parity.engine_from_case(g, lib, "cuda", dtype=torch.float32)
+    for _ in range(3):
+        e64.learn_msgs()
+        e32.learn_msgs()
+    m64, _ = e64.marginal_state_action()
+    m32, _ = e32.marginal_state_action()
+    assert e32.failures() == []
+    assert_close(m32.double().cpu().numpy(), m64.cpu().numpy(), 5e-3, "fp32 vs fp64 posterior mean")
