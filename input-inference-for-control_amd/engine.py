@@ -122,7 +122,7 @@ class BatchedI2c:
         self.dtemp = float(dtemp)
 
         dev, dt = self.device, self.dtype
-        to = lambda a: torch.as_tensor(np.array(a, dtype=np.float64), dtype=dt, device=dev)  # noqa: E731
+        to = lambda a: torch.as_tensor(np.array(a, dtype=np.float64, order="C"), dtype=dt, device=dev)  # noqa: E731
         zeros = lambda *s: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
         d = self.d
         # initial "posterior" = cell constructor state (i2c.py:95-100, 135-136)
