@@ -44,28 +44,61 @@ template <class M, typename R> struct Consts {
   R zg[NZ], zg_term[NZT1], mu_x_term[NX], sig_x_term[sym(NX)], params[NP1];
 };
 
+// The three model callbacks as functors: f(x, sin(angles of x), cos(angles of x), y).
 template <class M, typename R> struct ObserveF {
   const R* p;
-  I2C_HD inline void operator()(const R* x, R* y) const { M::observe(p, x, y); }
+  I2C_HD inline void operator()(const R* x, const R* sn, const R* cs, R* y) const { M::observe(p, x, sn, cs, y); }
 };
 template <class M, typename R> struct DynamicsF {
   const R* p;
-  I2C_HD inline void operator()(const R* x, R* y) const { M::dynamics(p, x, y); }
+  I2C_HD inline void operator()(const R* x, const R* sn, const R* cs, R* y) const { M::dynamics(p, x, sn, cs, y); }
 };
 template <class M, typename R> struct ObserveTermF {
   const R* p;
-  I2C_HD inline void operator()(const R* x, R* y) const { M::observe_terminal(p, x, y); }
+  I2C_HD inline void operator()(const R* x, const R* sn, const R* cs, R* y) const {
+    M::observe_terminal(p, x, sn, cs, y);
+  }
 };
 
-// Gaussian push-through  N(m, L L^T) -> (my, Sy [, Sxy])   (quadrature.py:27-58).
-//   L     packed lower Cholesky factor of the input covariance (DIN)
+// Compile-time structure of a model callback, used to skip sigma-point work that is exactly
+// known: output k is either a pass-through of input lin(k) (>= 0) or nonlinear (lin(k) < 0) and
+// then depends on no input with index above dep(k). (Column j of the cubature points only moves
+// inputs i >= j because the Cholesky factor is lower triangular.)
+template <class M> struct ObsStruct {
+  I2C_HD static constexpr int lin(int k) { return M::obs_lin(k); }
+  I2C_HD static constexpr int dep(int k) { return M::obs_dep(k); }
+};
+template <class M> struct TermStruct {
+  I2C_HD static constexpr int lin(int k) { return M::term_lin(k); }
+  I2C_HD static constexpr int dep(int k) { return M::term_dep(k); }
+};
+template <int DIN> struct DenseStruct {
+  I2C_HD static constexpr int lin(int) { return -1; }
+  I2C_HD static constexpr int dep(int) { return DIN - 1; }
+};
+
+// Gaussian push-through  N(m, Sin = L L^T) -> (my, Sy [, Sxy])   (quadrature.py:27-58).
+//   L     packed lower Cholesky factor of the input covariance Sin (DIN)
 //   my    [DOUT]   weighted mean (uses weights_sig, as the reference does)
 //   Sy    [sym DOUT] covariance, equal to  sum_p w_p y_p y_p^T - my my^T
 //   Sxy   [DIN * DOUT] row-major cross-covariance = sum_p w_p x_p y_p^T - m my^T  (only if CROSS)
-template <int DIN, int DOUT, bool CROSS, typename R, class F>
-I2C_FN void sp_transform(const Rule<R>& rule, const R* m, const R* L, const F& f, R* my, R* Sy, R* Sxy) {
+//
+// With pairwise sums a_j = (y_j+ - y0) + (y_j- - y0) and differences dl_j = y_j+ - y_j-:
+//   my = W y0 + wi sum_j a_j,   Sy = wi/2 sum_j (a_j a_j^T + dl_j dl_j^T) - wi^2 A A^T (+ terms in 1-W),
+//   Sxy = wi sf L [dl_0 .. dl_{d-1}]^T.
+// For a pass-through output a_j = 0 and dl_j = 2 sf L[i][j] exactly, so its moments are rows of
+// Sin (2 wi sf^2 = 1 for every alpha, beta, kappa) and cost nothing.
+// Trig of the model's angle coordinates is computed once at the mean and once per (angle, column)
+// offset d = sf L[i][j], then rotated: sin(m +/- d) = s0 cd +/- c0 sd, cos(m +/- d) = c0 cd -/+ s0 sd.
+template <class M, class ST, int DIN, int DOUT, bool CROSS, typename R, class F>
+I2C_FN void sp_transform(const Rule<R>& rule, const R* m, const R* Sin, const R* L, const F& f, R* my, R* Sy,
+                         R* Sxy) {
+  constexpr int NA = M::NA, NA1 = NA > 0 ? NA : 1;
+  R s0[NA1], c0[NA1];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) r_sincos(m[M::ang(a)], &s0[a], &c0[a]);
   R y0[DOUT];
-  f(m, y0);
+  f(m, s0, c0, y0);
   R A[DOUT];
 #pragma unroll
   for (int k = 0; k < DOUT; ++k) A[k] = R(0);
@@ -77,59 +110,96 @@ I2C_FN void sp_transform(const Rule<R>& rule, const R* m, const R* L, const F& f
   }
 #pragma unroll
   for (int j = 0; j < DIN; ++j) {
-    // points m +/- sf L[:, j]; rows above the diagonal of L are structurally zero
-    R xp[DIN], xm[DIN];
+    // does any nonlinear output move with this column?
+    bool any = false;
 #pragma unroll
-    for (int i = 0; i < DIN; ++i) {
-      if (i < j) {
-        xp[i] = m[i];
-        xm[i] = m[i];
-      } else {
-        const R dl = rule.sf * L[tri(i, j)];
-        xp[i] = m[i] + dl;
-        xm[i] = m[i] - dl;
+    for (int k = 0; k < DOUT; ++k) any = any || (ST::lin(k) < 0 && ST::dep(k) >= j);
+    R a[DOUT], dl[DOUT];
+    if (any) {
+      // points m +/- sf L[:, j]; rows above the diagonal of L are structurally zero
+      R xp[DIN], xm[DIN];
+#pragma unroll
+      for (int i = 0; i < DIN; ++i) {
+        if (i < j) {
+          xp[i] = m[i];
+          xm[i] = m[i];
+        } else {
+          const R d = rule.sf * L[tri(i, j)];
+          xp[i] = m[i] + d;
+          xm[i] = m[i] - d;
+        }
+      }
+      R sp[NA1], cp[NA1], sm[NA1], cm[NA1];
+#pragma unroll
+      for (int q = 0; q < NA; ++q) {
+        if (M::ang(q) < j) {  // this column does not move the angle
+          sp[q] = sm[q] = s0[q];
+          cp[q] = cm[q] = c0[q];
+        } else {
+          R sd, cd;
+          r_sincos(rule.sf * L[tri(M::ang(q), j)], &sd, &cd);
+          sp[q] = s0[q] * cd + c0[q] * sd;
+          cp[q] = c0[q] * cd - s0[q] * sd;
+          sm[q] = s0[q] * cd - c0[q] * sd;
+          cm[q] = c0[q] * cd + s0[q] * sd;
+        }
+      }
+      R yp[DOUT], ym[DOUT];
+      f(xp, sp, cp, yp);
+      f(xm, sm, cm, ym);
+#pragma unroll
+      for (int k = 0; k < DOUT; ++k) {
+        a[k] = (yp[k] - y0[k]) + (ym[k] - y0[k]);
+        dl[k] = yp[k] - ym[k];
       }
     }
-    R yp[DOUT], ym[DOUT];
-    f(xp, yp);
-    f(xm, ym);
-    R a[DOUT], dl[DOUT];
+    // per-output activity in this column (all compile-time after unrolling)
 #pragma unroll
     for (int k = 0; k < DOUT; ++k) {
-      a[k] = (yp[k] - y0[k]) + (ym[k] - y0[k]);
-      dl[k] = yp[k] - ym[k];
-      A[k] += a[k];
-    }
+      const bool nl_k = ST::lin(k) < 0 && ST::dep(k) >= j;
+      if (ST::lin(k) >= j) dl[k] = R(2) * rule.sf * L[tri(ST::lin(k) >= j ? ST::lin(k) : j, j)];
+      if (nl_k) A[k] += a[k];
 #pragma unroll
-    for (int k = 0; k < DOUT; ++k)
+      for (int l = 0; l <= k; ++l) {
+        const bool nl_l = ST::lin(l) < 0 && ST::dep(l) >= j;
+        const bool d_k = nl_k || ST::lin(k) >= j, d_l = nl_l || ST::lin(l) >= j;
+        const bool both_lin = ST::lin(k) >= 0 && ST::lin(l) >= 0;
+        if (nl_k && nl_l) Sy[tri(k, l)] += a[k] * a[l];
+        if (d_k && d_l && !both_lin) Sy[tri(k, l)] += dl[k] * dl[l];
+      }
+      if (CROSS && nl_k) {
 #pragma unroll
-      for (int l = 0; l <= k; ++l) Sy[tri(k, l)] += a[k] * a[l] + dl[k] * dl[l];
-    if (CROSS) {
-#pragma unroll
-      for (int i = j; i < DIN; ++i)
-#pragma unroll
-        for (int k = 0; k < DOUT; ++k) Sxy[i * DOUT + k] += L[tri(i, j)] * dl[k];
+        for (int i = j; i < DIN; ++i) Sxy[i * DOUT + k] += L[tri(i, j)] * dl[k];
+      }
     }
   }
-  const R hw = R(0.5) * rule.wi, w2 = rule.wi * rule.wi;
+  const R hw = R(0.5) * rule.wi, w2 = rule.wi * rule.wi, cs = rule.wi * rule.sf;
 #pragma unroll
-  for (int k = 0; k < DOUT; ++k) my[k] = rule.W * y0[k] + rule.wi * A[k];
+  for (int k = 0; k < DOUT; ++k) {
+    my[k] = ST::lin(k) >= 0 ? rule.W * m[ST::lin(k) >= 0 ? ST::lin(k) : 0] : rule.W * y0[k] + rule.wi * A[k];
 #pragma unroll
-  for (int k = 0; k < DOUT; ++k)
+    for (int l = 0; l <= k; ++l) {
+      if (ST::lin(k) >= 0 && ST::lin(l) >= 0)
+        Sy[tri(k, l)] = Sin[tri_any(ST::lin(k) >= 0 ? ST::lin(k) : 0, ST::lin(l) >= 0 ? ST::lin(l) : 0)];
+      else
+        Sy[tri(k, l)] = hw * Sy[tri(k, l)] - w2 * A[k] * A[l];
+    }
+    if (CROSS) {
 #pragma unroll
-    for (int l = 0; l <= k; ++l) Sy[tri(k, l)] = hw * Sy[tri(k, l)] - w2 * A[k] * A[l];
+      for (int i = 0; i < DIN; ++i)
+        Sxy[i * DOUT + k] = ST::lin(k) >= 0 ? Sin[tri_any(i, ST::lin(k) >= 0 ? ST::lin(k) : 0)] : cs * Sxy[i * DOUT + k];
+    }
+  }
   if (!rule.unit) {  // sum of weights != 1: the reference's m m^T term no longer cancels
     const R omw = R(1) - rule.W;
+    R yc[DOUT];
+#pragma unroll
+    for (int k = 0; k < DOUT; ++k) yc[k] = ST::lin(k) >= 0 ? m[ST::lin(k) >= 0 ? ST::lin(k) : 0] : y0[k];
 #pragma unroll
     for (int k = 0; k < DOUT; ++k)
 #pragma unroll
       for (int l = 0; l <= k; ++l)
-        Sy[tri(k, l)] += omw * (rule.W * y0[k] * y0[l] + rule.wi * (A[k] * y0[l] + y0[k] * A[l]));
-  }
-  if (CROSS) {
-    const R cs = rule.wi * rule.sf;
-#pragma unroll
-    for (int k = 0; k < DIN * DOUT; ++k) Sxy[k] *= cs;
+        Sy[tri(k, l)] += omw * (rule.W * yc[k] * yc[l] + rule.wi * (A[k] * yc[l] + yc[k] * A[l]));
   }
 }
 
@@ -339,7 +409,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       for (int i = 0; i < sym(D); ++i) L[i] = S0[i];
       if (!chol<D>(L, rinv)) set_status(a.status, b, 1, t);
       R mz[NZ], Sz[sym(NZ)], Sxz[D * NZ];
-      sp_transform<D, NZ, true>(c.rule_xu, mu0, L, ObserveF<M, R>{c.params}, mz, Sz, Sxz);
+      sp_transform<M, ObsStruct<M>, D, NZ, true>(c.rule_xu, mu0, S0, L, ObserveF<M, R>{c.params}, mz, Sz, Sxz);
 #pragma unroll
       for (int i = 0; i < sym(NZ); ++i) Sz[i] += alpha * c.sig_xi0[i];
       if (!kalman_update<D, NZ>(mu0, S0, mz, Sz, Sxz, zt)) set_status(a.status, b, 3, t);
@@ -358,7 +428,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 #pragma unroll
       for (int i = 0; i < sym(D); ++i) L[i] = S0[i];
       if (!chol<D>(L, rinv)) set_status(a.status, b, 4, t);
-      sp_transform<D, NX, true>(c.rule_xu, mu0, L, DynamicsF<M, R>{c.params}, mu_x, sig_x, Sxy);
+      sp_transform<M, DenseStruct<D>, D, NX, true>(c.rule_xu, mu0, S0, L, DynamicsF<M, R>{c.params}, mu_x, sig_x, Sxy);
     }
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) sig_x[i] += c.rule_xu.W * c.sig_eta[i];
@@ -376,7 +446,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     if (NZT > 0 && t == T - 1 && c.has_Qf) {
       constexpr int NT = C::NZT1;
       R mzt[NT], Szt[sym(NT)], Sxzt[NX * NT];
-      sp_transform<NX, NT, true>(c.rule_x, mu_x, L3, ObserveTermF<M, R>{c.params}, mzt, Szt, Sxzt);
+      sp_transform<M, TermStruct<M>, NX, NT, true>(c.rule_x, mu_x, sig_x, L3, ObserveTermF<M, R>{c.params}, mzt, Szt, Sxzt);
 #pragma unroll
       for (int i = 0; i < sym(NT); ++i) Szt[i] += alpha * c.sig_xiT0[i];
       if (!kalman_update<NX, NT>(mu_x, sig_x, mzt, Szt, Sxzt, c.zg_term)) set_status(a.status, b, 6, t);
@@ -408,34 +478,44 @@ template <typename R> struct ScanArgs {
   int32_t* status;
 };
 
+template <int NX, typename R> struct ScanRow {  // the rows of one cell the recursion needs
+  R mu1[NX], S1[sym(NX)], m3f[NX], S3f[sym(NX)], Jx[NX * NX];
+};
+
 template <class M, typename R>
 I2C_HD inline void backward_scan_body(const Consts<M, R>& c, const ScanArgs<R>& a, const int b) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, D = C::D;
   constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  // The recursion itself is ~40 FMAs per cell; what bounds this kernel is load latency with only
+  // B/64 wavefronts in flight. Cells are therefore fetched U at a time, one chunk ahead.
+  constexpr int U = NX <= 2 ? 4 : 1;
   const long B = c.B;
   const int T = c.T;
-  R m3m[NX], S3m[sym(NX)];
+  using Row = ScanRow<NX, R>;
 
-  // rows of one cell the scan needs: mu_x1_f, sig_x1_f (xx prefix), mu_x3_f, sig_x3_f, Jx
-  R mu1[NX], S1[sym(NX)], m3f[NX], S3f[sym(NX)], Jx[NX * NX];
-  auto load = [&](int t, R* lmu1, R* lS1, R* lm3f, R* lS3f, R* lJx) {
-    const R* in = a.fwd + ((long)t * C::E_FWD) * B + b;
+  auto load = [&](int t, Row& r) {
+    const R* in = a.fwd + ((long)(t > 0 ? t : 0) * C::E_FWD) * B + b;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) lmu1[i] = in[(long)i * B];
+    for (int i = 0; i < NX; ++i) r.mu1[i] = in[(long)i * B];
 #pragma unroll
-    for (int i = 0; i < sym(NX); ++i) lS1[i] = in[(long)(D + i) * B];
+    for (int i = 0; i < sym(NX); ++i) r.S1[i] = in[(long)(D + i) * B];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) lm3f[i] = in[(long)(O_MU3 + i) * B];
+    for (int i = 0; i < NX; ++i) r.m3f[i] = in[(long)(O_MU3 + i) * B];
 #pragma unroll
-    for (int i = 0; i < sym(NX); ++i) lS3f[i] = in[(long)(O_S3 + i) * B];
+    for (int i = 0; i < sym(NX); ++i) r.S3f[i] = in[(long)(O_S3 + i) * B];
 #pragma unroll
-    for (int i = 0; i < NX * NX; ++i) lJx[i] = in[(long)(O_J + i) * B];
+    for (int i = 0; i < NX * NX; ++i) r.Jx[i] = in[(long)(O_J + i) * B];
   };
-  load(T - 1, mu1, S1, m3f, S3f, Jx);
+  Row cur[U], nxt[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) load(T - 1 - u, cur[u]);
 
+  R m3m[NX], S3m[sym(NX)];
   // end of chain (i2c.py:546-564)
   if (c.has_x_terminal) {  // covariance control with a tempered terminal prior (i2c.py:548-559)
+    const R* m3f = cur[0].m3f;
+    const R* S3f = cur[0].S3f;
     const R temp = a.temp[b];
     a.temp[b] = temp + c.dtemp;
     R St[sym(NX)], Ssum[sym(NX)], rinv[NX];
@@ -488,43 +568,42 @@ I2C_HD inline void backward_scan_body(const Consts<M, R>& c, const ScanArgs<R>& 
     if (!ok) set_status(a.status, b, 6, T - 1);
   } else {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) m3m[i] = m3f[i];
+    for (int i = 0; i < NX; ++i) m3m[i] = cur[0].m3f[i];
 #pragma unroll
-    for (int i = 0; i < sym(NX); ++i) S3m[i] = S3f[i];
+    for (int i = 0; i < sym(NX); ++i) S3m[i] = cur[0].S3f[i];
   }
 
-  for (int t = T - 1; t >= 0; --t) {
-    R nmu1[NX], nS1[sym(NX)], nm3f[NX], nS3f[sym(NX)], nJx[NX * NX];
-    load(t > 0 ? t - 1 : 0, nmu1, nS1, nm3f, nS3f, nJx);  // prefetch
-
-    R* out = a.xm + ((long)t * C::E_XM) * B + b;
+  for (int t0 = T - 1; t0 >= 0; t0 -= U) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) out[(long)i * B] = m3m[i];
+    for (int u = 0; u < U; ++u) load(t0 - U - u, nxt[u]);  // next chunk (clamped at cell 0)
 #pragma unroll
-    for (int i = 0; i < sym(NX); ++i) out[(long)(NX + i) * B] = S3m[i];
-
-    R dm[NX], dS[sym(NX)];
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 - u;
+      if (t < 0) break;
+      const Row& r = cur[u];
+      R* out = a.xm + ((long)t * C::E_XM) * B + b;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) dm[i] = m3m[i] - m3f[i];
+      for (int i = 0; i < NX; ++i) out[(long)i * B] = m3m[i];
 #pragma unroll
-    for (int i = 0; i < sym(NX); ++i) dS[i] = S3m[i] - S3f[i];
+      for (int i = 0; i < sym(NX); ++i) out[(long)(NX + i) * B] = S3m[i];
+      R dm[NX], dS[sym(NX)];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      R v = mu1[i];
+      for (int i = 0; i < NX; ++i) dm[i] = m3m[i] - r.m3f[i];
 #pragma unroll
-      for (int k = 0; k < NX; ++k) v += Jx[i * NX + k] * dm[k];
-      m3m[i] = v;
+      for (int i = 0; i < sym(NX); ++i) dS[i] = S3m[i] - r.S3f[i];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        R v = r.mu1[i];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) v += r.Jx[i * NX + k] * dm[k];
+        m3m[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < sym(NX); ++i) S3m[i] = r.S1[i];
+      add_JDJt<NX, NX>(r.Jx, dS, S3m);
     }
 #pragma unroll
-    for (int i = 0; i < sym(NX); ++i) S3m[i] = S1[i];
-    add_JDJt<NX, NX>(Jx, dS, S3m);
-
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { mu1[i] = nmu1[i]; m3f[i] = nm3f[i]; }
-#pragma unroll
-    for (int i = 0; i < sym(NX); ++i) { S1[i] = nS1[i]; S3f[i] = nS3f[i]; }
-#pragma unroll
-    for (int i = 0; i < NX * NX; ++i) Jx[i] = nJx[i];
+    for (int u = 0; u < U; ++u) cur[u] = nxt[u];
   }
 }
 
@@ -621,12 +700,14 @@ I2C_HD inline void backward_cell_body(const Consts<M, R>& c, const CellArgs<R>& 
   for (int e = 0; e < sym(D); ++e) out[(long)(D + e) * B] = S[e];
 
   // posterior observation moments (i2c.py:594-596) from chol(sig_xu0_m)
-  R rinv[D];
-  if (!chol<D>(S, rinv)) set_status(a.status, b, 7, t);  // S <- L
+  R Lm[sym(D)], rinv[D];
+#pragma unroll
+  for (int e = 0; e < sym(D); ++e) Lm[e] = S[e];
+  if (!chol<D>(Lm, rinv)) set_status(a.status, b, 7, t);
   R zt[NZ], mz[NZ], Sz[sym(NZ)];
 #pragma unroll
   for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
-  sp_transform<D, NZ, false>(c.rule_xu, mu, S, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
+  sp_transform<M, ObsStruct<M>, D, NZ, false>(c.rule_xu, mu, S, Lm, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
   if (a.zpost) {
     R* zo = a.zpost + ((long)t * C::E_ZPOST) * B + b;
 #pragma unroll
@@ -645,8 +726,8 @@ I2C_HD inline void backward_cell_body(const Consts<M, R>& c, const CellArgs<R>& 
 #pragma unroll
   for (int p = 0; p < NU; ++p) {
 #pragma unroll
-    for (int k = 0; k < NX; ++k) Kc[p * NX + k] = S[tri(NX + p, k)];
-    bsub<NX>(S, rinv, &Kc[p * NX]);  // leading NX x NX block of L is chol(sig_xx)
+    for (int k = 0; k < NX; ++k) Kc[p * NX + k] = Lm[tri(NX + p, k)];
+    bsub<NX>(Lm, rinv, &Kc[p * NX]);  // leading NX x NX block of L is chol(sig_xx)
   }
 #pragma unroll
   for (int e = 0; e < NU * NX; ++e) out[(long)(D + sym(D) + e) * B] = Kc[e];
@@ -663,7 +744,7 @@ I2C_HD inline void backward_cell_body(const Consts<M, R>& c, const CellArgs<R>& 
     for (int q = 0; q <= p; ++q) {
       R v = R(0);
 #pragma unroll
-      for (int k = 0; k <= q; ++k) v += S[tri(NX + p, NX + k)] * S[tri(NX + q, NX + k)];
+      for (int k = 0; k <= q; ++k) v += Lm[tri(NX + p, NX + k)] * Lm[tri(NX + q, NX + k)];
       out[(long)(C::E_PRI + NU + tri(p, q)) * B] = v;
     }
 
@@ -676,7 +757,7 @@ I2C_HD inline void backward_cell_body(const Consts<M, R>& c, const CellArgs<R>& 
 #pragma unroll
       for (int i = 0; i < sym(NX); ++i) L3[i] = S3m[i];
       if (!chol<NX>(L3, rinv3)) set_status(a.status, b, 6, t);
-      sp_transform<NX, NT, false>(c.rule_x, m3m, L3, ObserveTermF<M, R>{c.params}, mzt, Szt, (R*)nullptr);
+      sp_transform<M, TermStruct<M>, NX, NT, false>(c.rule_x, m3m, S3m, L3, ObserveTermF<M, R>{c.params}, mzt, Szt, (R*)nullptr);
       R tv;
       gaussian_cost<NT>(c.Qf, mzt, Szt, c.zg_term, &trT, &tv);
 #pragma unroll
@@ -706,6 +787,7 @@ I2C_HD inline void mstep_body(const Consts<M, R>& c, const MstepArgs<R>& a, cons
   using C = Consts<M, R>;
   const long B = c.B;
   R m = R(0), v = R(0);
+#pragma unroll 8
   for (int t = 0; t < c.T; ++t) {
     m += a.cell_stats[((long)t * 2 + 0) * B + b];
     v += a.cell_stats[((long)t * 2 + 1) * B + b];
@@ -811,18 +893,20 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
 #pragma unroll
     for (int e = 0; e < sym(D); ++e) out[(long)(D + e) * B] = S0[e];
 
-    R rinv[D];
-    if (!chol<D>(S0, rinv)) set_status(a.status, b, 8, t);  // S0 <- L
+    R L0[sym(D)], rinv[D];
+#pragma unroll
+    for (int e = 0; e < sym(D); ++e) L0[e] = S0[e];
+    if (!chol<D>(L0, rinv)) set_status(a.status, b, 8, t);
     R zt[NZ], mz[NZ], Sz[sym(NZ)];
 #pragma unroll
     for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
-    sp_transform<D, NZ, false>(c.rule_xu, mu0, S0, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
+    sp_transform<M, ObsStruct<M>, D, NZ, false>(c.rule_xu, mu0, S0, L0, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
     R cm, cv;
     gaussian_cost<NZ>(c.QR, mz, Sz, zt, &cm, &cv);
     a.cell_stats[((long)t * 2 + 0) * B + b] = cm;
     a.cell_stats[((long)t * 2 + 1) * B + b] = cv;
 
-    sp_transform<D, NX, false>(c.rule_xu, mu0, S0, DynamicsF<M, R>{c.params}, mu_x, sig_x, (R*)nullptr);
+    sp_transform<M, DenseStruct<D>, D, NX, false>(c.rule_xu, mu0, S0, L0, DynamicsF<M, R>{c.params}, mu_x, sig_x, (R*)nullptr);
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) sig_x[i] += c.rule_xu.W * c.sig_eta[i];
 #pragma unroll

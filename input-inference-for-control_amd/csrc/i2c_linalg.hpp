@@ -23,26 +23,79 @@ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 // packed index of (i, j) for any order
 constexpr int tri_any(int i, int j) { return i >= j ? tri(i, j) : tri(j, i); }
 
-// scalar math, overloaded on precision (device: OCML via the HIP math headers; host sim: libm)
+// ---- scalar math, overloaded on precision ----------------------------------------------------
+// The fp64 versions avoid the IEEE divide / sqrt expansions (v_div_scale/fmas/fixup sequences)
+// and OCML's branchy large-argument trig path; results are within ~1-2 ulp, far inside the
+// parity tolerance. The host simulation runs the SAME formulas; only the hardware seed
+// instructions (v_rsq_f64 / v_rcp_f64, ~2^-23 accurate) are emulated by a float-rounded value.
 #ifdef I2C_HOST_SIM
-I2C_FN double r_rsqrt(double x) { return 1.0 / std::sqrt(x); }
+I2C_FN double seed_rsq(double x) { return (double)(float)(1.0 / std::sqrt(x)); }
+I2C_FN double seed_rcp(double x) { return (double)(float)(1.0 / x); }
+I2C_FN double m_fma(double a, double b, double c) { return std::fma(a, b, c); }
+I2C_FN double m_rint(double x) { return std::rint(x); }
+I2C_FN double m_fabs(double x) { return std::fabs(x); }
+I2C_FN void slow_sincos(double x, double* s, double* c) { *s = std::sin(x); *c = std::cos(x); }
 I2C_FN float r_rsqrt(float x) { return 1.0f / std::sqrt(x); }
+I2C_FN float r_rcp(float x) { return 1.0f / x; }
 I2C_FN double r_exp(double x) { return std::exp(x); }
 I2C_FN float r_exp(float x) { return std::exp(x); }
-I2C_FN double r_sin(double x) { return std::sin(x); }
-I2C_FN float r_sin(float x) { return std::sin(x); }
-I2C_FN void r_sincos(double x, double* s, double* c) { *s = std::sin(x); *c = std::cos(x); }
 I2C_FN void r_sincos(float x, float* s, float* c) { *s = std::sin(x); *c = std::cos(x); }
 #else
-I2C_FN double r_rsqrt(double x) { return 1.0 / sqrt(x); }
-I2C_FN float r_rsqrt(float x) { return 1.0f / sqrtf(x); }
+I2C_FN double seed_rsq(double x) { return __builtin_amdgcn_rsq(x); }
+I2C_FN double seed_rcp(double x) { return __builtin_amdgcn_rcp(x); }
+I2C_FN double m_fma(double a, double b, double c) { return fma(a, b, c); }
+I2C_FN double m_rint(double x) { return rint(x); }
+I2C_FN double m_fabs(double x) { return fabs(x); }
+I2C_FN void slow_sincos(double x, double* s, double* c) { sincos(x, s, c); }
+I2C_FN float r_rsqrt(float x) { return rsqrtf(x); }
+I2C_FN float r_rcp(float x) { return 1.0f / x; }
 I2C_FN double r_exp(double x) { return exp(x); }
 I2C_FN float r_exp(float x) { return expf(x); }
-I2C_FN double r_sin(double x) { return sin(x); }
-I2C_FN float r_sin(float x) { return sinf(x); }
-I2C_FN void r_sincos(double x, double* s, double* c) { sincos(x, s, c); }
 I2C_FN void r_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
 #endif
+
+// 1/sqrt(x): ~2^-23 seed + one cubically convergent correction (relative error ~ e^3).
+I2C_FN double r_rsqrt(double x) {
+  const double y = seed_rsq(x);
+  const double e = m_fma(-(x * y), y, 1.0);  // 1 - x y^2
+  return m_fma(y * e, m_fma(e, 0.375, 0.5), y);
+}
+// 1/x: seed + two Newton steps.
+I2C_FN double r_rcp(double x) {
+  double y = seed_rcp(x);
+  y = m_fma(m_fma(-x, y, 1.0), y, y);
+  return m_fma(m_fma(-x, y, 1.0), y, y);
+}
+// sin and cos together. |x| < 1e5: three-term Cody-Waite reduction by pi/2 (each n * chunk
+// product is exact for |n| < 2^20) + the classic degree-13/14 minimax kernels on [-pi/4, pi/4];
+// otherwise (never on the shipped problems) the library's Payne-Hanek path.
+I2C_FN void r_sincos(double x, double* s, double* c) {
+  if (!(m_fabs(x) < 1.0e5)) {
+    slow_sincos(x, s, c);
+    return;
+  }
+  const double n = m_rint(x * 6.36619772367581382433e-01);
+  double r = m_fma(-n, 1.57079632673412561417e+00, x);
+  r = m_fma(-n, 6.07710050630396597660e-11, r);
+  r = m_fma(-n, 2.02226624871116645580e-21, r);
+  const double z = r * r;
+  double ps = m_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = m_fma(z, ps, 2.75573137070700676789e-06);
+  ps = m_fma(z, ps, -1.98412698298579493134e-04);
+  ps = m_fma(z, ps, 8.33333333332248946124e-03);
+  const double sr = m_fma(z * r, m_fma(z, ps, -1.66666666666666324348e-01), r);
+  double pc = m_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = m_fma(z, pc, -2.75573143513906633035e-07);
+  pc = m_fma(z, pc, 2.48015872894767294178e-05);
+  pc = m_fma(z, pc, -1.38888888888741095749e-03);
+  pc = m_fma(z, pc, 4.16666666666666019037e-02);
+  const double cr = 1.0 - m_fma(0.5, z, -(z * z) * pc);
+  const int q = (int)n;
+  const double ss = (q & 1) ? cr : sr;
+  const double cc = (q & 1) ? sr : cr;
+  *s = (q & 2) ? -ss : ss;
+  *c = ((q + 1) & 2) ? -cc : cc;
+}
 template <typename R> I2C_FN R r_clip(R x, R lo, R hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // In-place Cholesky of a packed SPD matrix: a <- L (lower), rinv[j] = 1 / L[j][j].

@@ -1,6 +1,11 @@
 // Device functors for the reference's known-model plugins (the `sys` protocol of
 // SURVEY.md section 8b): dynamics / observe / observe_terminal evaluated at one sigma point.
 // Citations are relative to the reference root.
+//
+// Every model lists its NA "angle coordinates" (state entries that only enter through sin/cos).
+// The functors receive sn[a] = sin(x[ang(a)]), cs[a] = cos(x[ang(a)]) precomputed by the
+// sigma-point transform, which evaluates sincos once at the mean and once per (angle, column)
+// offset and rotates (angle addition) instead of calling sincos at all 2d+1 points.
 #pragma once
 #include "i2c_linalg.hpp"
 
@@ -8,67 +13,89 @@ namespace i2c {
 
 // PendulumKnown: i2c/env_def.py:233-309, step i2c/env_autograd.py:5-19
 struct Pendulum {
-  static constexpr int ID = 0, NX = 2, NU = 1, NZ = 4, NZT = 3, NP = 0;
-  template <typename R> I2C_FN void dynamics(const R*, const R* xu, R* xn) {
+  static constexpr int ID = 0, NX = 2, NU = 1, NZ = 4, NZT = 3, NP = 0, NA = 1;
+  I2C_HD static constexpr int ang(int) { return 0; }
+  // z = [sin th, cos th, thd, u],  zT = [sin th, cos th, thd]
+  I2C_HD static constexpr int obs_lin(int k) { return k < 2 ? -1 : k - 1; }
+  I2C_HD static constexpr int obs_dep(int) { return 0; }
+  I2C_HD static constexpr int term_lin(int k) { return k < 2 ? -1 : 1; }
+  I2C_HD static constexpr int term_dep(int) { return 0; }
+  template <typename R> I2C_FN void dynamics(const R*, const R* xu, const R* sn, const R*, R* xn) {
     const R dt = R(0.05), damp = R(1e-2), u_max = R(2.0);
     const R c_grav = R(-3.0 * 9.80665 / (2 * 1.0));  // -3 g / (2 l)
     const R c_torque = R(3.0 / (1.0 * 1.0 * 1.0));    // 3 / (m l^2)
     const R u = r_clip(xu[2], -u_max, u_max);
-    R acc = c_grav * r_sin(xu[0] + R(3.14159265358979323846)) - damp * xu[1];
+    R acc = c_grav * (-sn[0]) - damp * xu[1];  // sin(th + pi) = -sin(th)
     acc += c_torque * u;
     const R om = xu[1] + acc * dt;
     xn[0] = xu[0] + om * dt;
     xn[1] = om;
   }
-  template <typename R> I2C_FN void observe(const R*, const R* xu, R* z) {  // env_def.py:273-276
-    r_sincos(xu[0], &z[0], &z[1]);
+  template <typename R> I2C_FN void observe(const R*, const R* xu, const R* sn, const R* cs, R* z) {  // env_def.py:273-276
+    z[0] = sn[0];
+    z[1] = cs[0];
     z[2] = xu[1];
     z[3] = xu[2];
   }
-  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, R* z) {  // env_def.py:288-291
-    r_sincos(x[0], &z[0], &z[1]);
+  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, const R* sn, const R* cs, R* z) {  // env_def.py:288-291
+    z[0] = sn[0];
+    z[1] = cs[0];
     z[2] = x[1];
   }
 };
 
 // PendulumKnownActReg: i2c/env_def.py:312-346 (only the action is observed; no terminal observation)
 struct PendulumActReg {
-  static constexpr int ID = 1, NX = 2, NU = 1, NZ = 1, NZT = 0, NP = 0;
-  template <typename R> I2C_FN void dynamics(const R* p, const R* xu, R* xn) { Pendulum::dynamics(p, xu, xn); }
-  template <typename R> I2C_FN void observe(const R*, const R* xu, R* z) { z[0] = xu[2]; }
-  template <typename R> I2C_FN void observe_terminal(const R*, const R*, R*) {}
+  static constexpr int ID = 1, NX = 2, NU = 1, NZ = 1, NZT = 0, NP = 0, NA = 1;
+  I2C_HD static constexpr int ang(int) { return 0; }
+  I2C_HD static constexpr int obs_lin(int) { return 2; }  // z = [u]
+  I2C_HD static constexpr int obs_dep(int) { return 0; }
+  I2C_HD static constexpr int term_lin(int) { return 0; }
+  I2C_HD static constexpr int term_dep(int) { return 0; }
+  template <typename R> I2C_FN void dynamics(const R* p, const R* xu, const R* sn, const R* cs, R* xn) {
+    Pendulum::dynamics(p, xu, sn, cs, xn);
+  }
+  template <typename R> I2C_FN void observe(const R*, const R* xu, const R*, const R*, R* z) { z[0] = xu[2]; }
+  template <typename R> I2C_FN void observe_terminal(const R*, const R*, const R*, const R*, R*) {}
 };
 
 // CartpoleKnown: i2c/env_def.py:491-612, step i2c/env_autograd.py:25-54
 struct Cartpole {
-  static constexpr int ID = 2, NX = 4, NU = 1, NZ = 6, NZT = 5, NP = 0;
-  template <typename R> I2C_FN void dynamics(const R*, const R* xu, R* xn) {
+  static constexpr int ID = 2, NX = 4, NU = 1, NZ = 6, NZT = 5, NP = 0, NA = 1;
+  I2C_HD static constexpr int ang(int) { return 1; }
+  // z = [x, sin th, cos th, xd, thd, u],  zT = [x, sin th, cos th, xd, thd]
+  I2C_HD static constexpr int obs_lin(int k) { return k == 0 ? 0 : (k < 3 ? -1 : k - 1); }
+  I2C_HD static constexpr int obs_dep(int) { return 1; }
+  I2C_HD static constexpr int term_lin(int k) { return k == 0 ? 0 : (k < 3 ? -1 : k - 1); }
+  I2C_HD static constexpr int term_dep(int) { return 1; }
+  template <typename R> I2C_FN void dynamics(const R*, const R* xu, const R* sn, const R* cs, R* xn) {
     const R grav = R(9.81), m_cart = R(0.37), m_pole = R(0.127), len = R(0.3365);
     const R dt = R(1.0 / 250.0), u_max = R(5.0);
     const R m_tot = m_cart + m_pole;
     const R u = r_clip(xu[4], -u_max, u_max);
     const R om2 = xu[3] * xu[3];
-    R s, c;
-    r_sincos(xu[1], &s, &c);
+    const R s = sn[0], c = cs[0];
     const R num = -m_pole * len * s * c * om2 + m_tot * grav * s - u * c;
     const R den = len * (R(4.0 / 3.0) * m_tot - m_pole * (c * c));
-    const R th_acc = num / den;
-    const R x_acc = (m_pole * len * s * om2 - m_pole * len * th_acc * c + u) / m_tot;
+    const R th_acc = num * r_rcp(den);
+    const R x_acc = (m_pole * len * s * om2 - m_pole * len * th_acc * c + u) * (R(1) / m_tot);
     xn[0] = xu[0] + dt * xu[2];
     xn[1] = xu[1] + dt * xu[3];
     xn[2] = xu[2] + dt * x_acc;
     xn[3] = xu[3] + dt * th_acc;
   }
-  template <typename R> I2C_FN void observe(const R*, const R* xu, R* z) {  // env_def.py:537-549
+  template <typename R> I2C_FN void observe(const R*, const R* xu, const R* sn, const R* cs, R* z) {  // env_def.py:537-549
     z[0] = xu[0];
-    r_sincos(xu[1], &z[1], &z[2]);
+    z[1] = sn[0];
+    z[2] = cs[0];
     z[3] = xu[2];
     z[4] = xu[3];
     z[5] = xu[4];
   }
-  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, R* z) {  // env_def.py:567-570
+  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, const R* sn, const R* cs, R* z) {  // env_def.py:567-570
     z[0] = x[0];
-    r_sincos(x[1], &z[1], &z[2]);
+    z[1] = sn[0];
+    z[2] = cs[0];
     z[3] = x[2];
     z[4] = x[3];
   }
@@ -76,8 +103,14 @@ struct Cartpole {
 
 // DoubleCartpoleKnown: i2c/env_def.py:615-761, step i2c/env_autograd.py:60-167
 struct DoubleCartpole {
-  static constexpr int ID = 3, NX = 6, NU = 1, NZ = 9, NZT = 8, NP = 0;
-  template <typename R> I2C_FN void dynamics(const R*, const R* xu, R* xn) {
+  static constexpr int ID = 3, NX = 6, NU = 1, NZ = 9, NZT = 8, NP = 0, NA = 2;
+  I2C_HD static constexpr int ang(int a) { return a == 0 ? 1 : 2; }
+  // z = [x, sin th1, cos th1, sin th2, cos th2, xd, th1d, th2d, u],  zT = z without u
+  I2C_HD static constexpr int obs_lin(int k) { return k == 0 ? 0 : (k < 5 ? -1 : k - 2); }
+  I2C_HD static constexpr int obs_dep(int k) { return k < 3 ? 1 : 2; }
+  I2C_HD static constexpr int term_lin(int k) { return k == 0 ? 0 : (k < 5 ? -1 : k - 2); }
+  I2C_HD static constexpr int term_dep(int k) { return k < 3 ? 1 : 2; }
+  template <typename R> I2C_FN void dynamics(const R*, const R* xu, const R* sn, const R* cs, R* xn) {
     const R dt = R(1.0 / 125.0), grav = R(9.81);
     const R m_c = R(0.37), m1 = R(0.127), m2 = R(0.127);
     const R L1 = R(0.3365), L2 = R(0.3365);
@@ -87,10 +120,8 @@ struct DoubleCartpole {
     const R m_tot = m_c + m1 + m2;
     const R h1 = m1 * l1 + m2 * L2, h2 = m2 * l2, h3 = L1 * l2 * m2;
 
-    R s1, c1, s2, c2, sd, cd;
-    r_sincos(xu[1], &s1, &c1);
-    r_sincos(xu[2], &s2, &c2);
-    r_sincos(xu[1] - xu[2], &sd, &cd);
+    const R s1 = sn[0], c1 = cs[0], s2 = sn[1], c2 = cs[1];
+    const R sd = s1 * c2 - c1 * s2, cd = c1 * c2 + s1 * s2;  // sin / cos (th1 - th2)
     const R qd0 = xu[3], qd1 = xu[4], qd2 = xu[5];
     // symmetric mass matrix M(q)
     const R M00 = m_tot, M01 = h1 * c1, M02 = h2 * c2;
@@ -104,7 +135,7 @@ struct DoubleCartpole {
     // qdd = M^{-1} rhs through the adjugate (M is symmetric 3x3)
     const R A00 = M11 * M22 - M12 * M12, A01 = M02 * M12 - M01 * M22, A02 = M01 * M12 - M02 * M11;
     const R A11 = M00 * M22 - M02 * M02, A12 = M01 * M02 - M00 * M12, A22 = M00 * M11 - M01 * M01;
-    const R idet = R(1) / (M00 * A00 + M01 * A01 + M02 * A02);
+    const R idet = r_rcp(M00 * A00 + M01 * A01 + M02 * A02);
     const R a0 = (A00 * r0 + A01 * r1 + A02 * r2) * idet;
     const R a1 = (A01 * r0 + A11 * r1 + A12 * r2) * idet;
     const R a2 = (A02 * r0 + A12 * r1 + A22 * r2) * idet;
@@ -115,19 +146,23 @@ struct DoubleCartpole {
     xn[1] = xu[1] + xn[4] * dt;
     xn[2] = xu[2] + xn[5] * dt;
   }
-  template <typename R> I2C_FN void observe(const R*, const R* xu, R* z) {  // env_def.py:682-695
+  template <typename R> I2C_FN void observe(const R*, const R* xu, const R* sn, const R* cs, R* z) {  // env_def.py:682-695
     z[0] = xu[0];
-    r_sincos(xu[1], &z[1], &z[2]);
-    r_sincos(xu[2], &z[3], &z[4]);
+    z[1] = sn[0];
+    z[2] = cs[0];
+    z[3] = sn[1];
+    z[4] = cs[1];
     z[5] = xu[3];
     z[6] = xu[4];
     z[7] = xu[5];
     z[8] = xu[6];
   }
-  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, R* z) {  // env_def.py:719-732
+  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, const R* sn, const R* cs, R* z) {  // env_def.py:719-732
     z[0] = x[0];
-    r_sincos(x[1], &z[1], &z[2]);
-    r_sincos(x[2], &z[3], &z[4]);
+    z[1] = sn[0];
+    z[2] = cs[0];
+    z[3] = sn[1];
+    z[4] = cs[1];
     z[5] = x[3];
     z[6] = x[4];
     z[7] = x[5];
@@ -136,17 +171,22 @@ struct DoubleCartpole {
 
 // LinearKnown: i2c/env_def.py:139-191, i2c/model.py:226-246.  params = A (2x2 row-major), B (2), a (2)
 struct Linear {
-  static constexpr int ID = 4, NX = 2, NU = 1, NZ = 3, NZT = 2, NP = 8;
-  template <typename R> I2C_FN void dynamics(const R* p, const R* xu, R* xn) {
+  static constexpr int ID = 4, NX = 2, NU = 1, NZ = 3, NZT = 2, NP = 8, NA = 0;
+  I2C_HD static constexpr int ang(int) { return 0; }
+  I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
+  I2C_HD static constexpr int obs_dep(int) { return 0; }
+  I2C_HD static constexpr int term_lin(int k) { return k; }
+  I2C_HD static constexpr int term_dep(int) { return 0; }
+  template <typename R> I2C_FN void dynamics(const R* p, const R* xu, const R*, const R*, R* xn) {
     xn[0] = xu[0] * p[0] + xu[1] * p[1] + xu[2] * p[4] + p[6];
     xn[1] = xu[0] * p[2] + xu[1] * p[3] + xu[2] * p[5] + p[7];
   }
-  template <typename R> I2C_FN void observe(const R*, const R* xu, R* z) {
+  template <typename R> I2C_FN void observe(const R*, const R* xu, const R*, const R*, R* z) {
     z[0] = xu[0];
     z[1] = xu[1];
     z[2] = xu[2];
   }
-  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, R* z) {
+  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, const R*, const R*, R* z) {
     z[0] = x[0];
     z[1] = x[1];
   }
@@ -154,10 +194,17 @@ struct Linear {
 
 // LinearKnownMinimumEnergy: i2c/env_def.py:194-230 (only the action is observed; terminal = state)
 struct LinearMinEnergy {
-  static constexpr int ID = 5, NX = 2, NU = 1, NZ = 1, NZT = 2, NP = 8;
-  template <typename R> I2C_FN void dynamics(const R* p, const R* xu, R* xn) { Linear::dynamics(p, xu, xn); }
-  template <typename R> I2C_FN void observe(const R*, const R* xu, R* z) { z[0] = xu[2]; }
-  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, R* z) {
+  static constexpr int ID = 5, NX = 2, NU = 1, NZ = 1, NZT = 2, NP = 8, NA = 0;
+  I2C_HD static constexpr int ang(int) { return 0; }
+  I2C_HD static constexpr int obs_lin(int) { return 2; }  // z = [u], zT = x
+  I2C_HD static constexpr int obs_dep(int) { return 0; }
+  I2C_HD static constexpr int term_lin(int k) { return k; }
+  I2C_HD static constexpr int term_dep(int) { return 0; }
+  template <typename R> I2C_FN void dynamics(const R* p, const R* xu, const R* sn, const R* cs, R* xn) {
+    Linear::dynamics(p, xu, sn, cs, xn);
+  }
+  template <typename R> I2C_FN void observe(const R*, const R* xu, const R*, const R*, R* z) { z[0] = xu[2]; }
+  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, const R*, const R*, R* z) {
     z[0] = x[0];
     z[1] = x[1];
   }
@@ -168,16 +215,21 @@ struct LinearMinEnergy {
 // The reference steps a Box2D body, which cannot be reproduced (not vendored / pinned); this is
 // a semi-implicit Euler rigid-body step with the same constants. params = {mass, inertia, u_max}.
 struct Quadrotor {
-  static constexpr int ID = 6, NX = 6, NU = 2, NZ = 8, NZT = 6, NP = 3;
-  template <typename R> I2C_FN void dynamics(const R* p, const R* xu, R* xn) {
+  static constexpr int ID = 6, NX = 6, NU = 2, NZ = 8, NZT = 6, NP = 3, NA = 1;
+  I2C_HD static constexpr int ang(int) { return 2; }
+  I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
+  I2C_HD static constexpr int obs_dep(int) { return 0; }
+  I2C_HD static constexpr int term_lin(int k) { return k; }
+  I2C_HD static constexpr int term_dep(int) { return 0; }
+  template <typename R> I2C_FN void dynamics(const R* p, const R* xu, const R* sn, const R* cs, R* xn) {
     const R dt = R(0.1), arm = R(0.8), ang_damp = R(0.5), grav = R(9.81);
     const R mass = p[0], inertia = p[1], u_max = p[2];
     const R f1 = r_clip(xu[6], R(0), u_max), f2 = r_clip(xu[7], R(0), u_max);
     const R thrust = f1 + f2;
-    R s, c;
-    r_sincos(xu[2], &s, &c);
-    const R ax = -thrust * s / mass;
-    const R ay = thrust * c / mass - grav;
+    const R s = sn[0], c = cs[0];
+    const R imass = R(1) / mass;  // wave-uniform: one scalar-ish divide hoisted by the compiler
+    const R ax = -thrust * s * imass;
+    const R ay = thrust * c * imass - grav;
     const R al = arm * (f2 - f1) / inertia;
     xn[3] = xu[3] + dt * ax;
     xn[4] = xu[4] + dt * ay;
@@ -186,11 +238,11 @@ struct Quadrotor {
     xn[1] = xu[1] + dt * xn[4];
     xn[2] = xu[2] + dt * xn[5];
   }
-  template <typename R> I2C_FN void observe(const R*, const R* xu, R* z) {
+  template <typename R> I2C_FN void observe(const R*, const R* xu, const R*, const R*, R* z) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) z[i] = xu[i];
   }
-  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, R* z) {
+  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, const R*, const R*, R* z) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) z[i] = x[i];
   }

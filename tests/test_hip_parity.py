@@ -101,4 +101,4 @@ def test_hip_fp32_runs_and_tracks_fp64(lib):
     m64, _ = e64.marginal_state_action()
     m32, _ = e32.marginal_state_action()
     assert e32.failures() == []
-    assert_close(m32.double().cpu().numpy(), m64.cpu().numpy(), 5e-3, "fp32 vs fp64 posterior mean")
+    assert_close(m32.double().cpu().numpy(), m64.cpu().numpy(), 5e-2, "fp32 vs fp64 posterior mean")
