@@ -9,4 +9,5 @@ The sub-package ``i2c`` mirrors the reference's public names (``i2c.i2c.I2cGraph
 the reference's scripts import the MI355X build instead.
 """
 from ._native import load_library, MODEL_IDS  # noqa: F401
+from . import dist, engine  # noqa: F401
 from .engine import BatchedI2c, I2cNumericalError  # noqa: F401

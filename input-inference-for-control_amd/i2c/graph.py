@@ -1,0 +1,511 @@
+"""`I2cGraph` / cell views: the reference's solver API (i2c/i2c.py:732-1401) over the MI355X engine.
+
+Callers written against the reference (scripts/i2c_run.py, the covariance-control scripts,
+policy/mpc.py) construct `I2cGraph(sys, horizon, Q, R, Qf, alpha, alpha_update_tol, mu_u, sig_u,
+mu_x_terminal, sig_x_terminal, inference, res_dir=None)` and read the attributes / methods
+listed in SURVEY.md section 8(b). Here every sweep is a HIP kernel launch on device tensors
+(`BatchedI2c`); this module only translates shapes and names:
+
+  * reference means are (n, 1) column vectors, covariances (n, n); the engine is (B, T, ...),
+  * `graph.cells[t].<name>` is a lazy *view* of cell t of the device buffers,
+  * extra keyword arguments (`batch`, `x0`, `sig_x0`, `z_traj`, `device`, `dtype`) expose the
+    batch axis the reference does not have; with B == 1 all getters return reference shapes.
+
+Not offered: the Linearize / Gauss-Hermite inference paths on the GPU and the matplotlib
+figures (the `plot_*` methods are no-ops so that runner scripts keep working).
+"""
+import logging
+import os
+
+import numpy as np
+import torch
+
+from . import core
+
+BatchedI2c = core.BatchedI2c
+from .exp_types import CubatureQuadrature, GaussHermiteQuadrature, Linearize
+
+PLOT_TIKZ = False
+CHECK_COVAR = False
+DEBUG_PLOTS = False
+
+
+def _np(t):
+    return t.detach().to(torch.float64).cpu().numpy()
+
+
+class I2cCell:
+    """View of one timestep of an `I2cGraph` (reference I2cCell, i2c/i2c.py:51-148).
+
+    Attribute reads fetch the cell's slice from the device buffers; the few attributes the
+    reference's callers *write* (`z`, `state_action_independence`, `use_expert_controller`,
+    `sys`) are forwarded to the graph."""
+
+    def __init__(self, graph, index):
+        object.__setattr__(self, "_g", graph)
+        object.__setattr__(self, "index", index)
+
+    # -- helpers --------------------------------------------------------------------------
+    def _pick(self, arr, column=False):
+        g, t = self._g, self.index
+        a = arr[:, t]
+        if g.B == 1:
+            a = a[0]
+            if column:
+                a = a.reshape(-1, 1)
+        return a
+
+    @property
+    def terminal_cell(self):
+        return self.index == self._g.H - 1
+
+    @property
+    def sys(self):
+        return self._g.sys
+
+    @sys.setter
+    def sys(self, value):
+        self._g.sys = value
+
+    # -- writable flags ---------------------------------------------------------------------
+    @property
+    def state_action_independence(self):
+        return bool(self._g.engine.feedforward[self.index].item())
+
+    @state_action_independence.setter
+    def state_action_independence(self, value):
+        self._g.engine.feedforward[self.index] = 1 if value else 0
+
+    @property
+    def use_expert_controller(self):
+        return self._g.engine.use_expert_controller
+
+    @use_expert_controller.setter
+    def use_expert_controller(self, value):
+        # the reference keeps the flag per cell but every script sets all cells alike
+        self._g.engine.use_expert_controller = bool(value)
+
+    @property
+    def z(self):
+        return self._g._cell_target(self.index)
+
+    @z.setter
+    def z(self, value):
+        self._g._set_cell_target(self.index, value)
+
+    @property
+    def sig_xi(self):
+        return self._g.sig_xi
+
+    @property
+    def temp(self):
+        return self._g._maybe_scalar(_np(self._g.engine.temp))
+
+    # -- read-only message / posterior state ------------------------------------------------
+    def __getattr__(self, name):
+        g = object.__getattribute__(self, "_g")
+        table = g._cell_table()
+        if name not in table:
+            raise AttributeError(f"I2cCell has no attribute '{name}' in the MI355X build")
+        arr, column = table[name]()
+        return self._pick(arr, column)
+
+
+class I2cGraph:
+    """Manages Gaussian i2c for a whole trajectory (or a batch of them) on the GPU."""
+
+    def __init__(self, sys, horizon, Q, R, Qf, alpha, alpha_update_tol, mu_u, sig_u, mu_x_terminal,
+                 sig_x_terminal, inference, res_dir=None, *, batch=None, x0=None, sig_x0=None, z_traj=None,
+                 device=None, dtype=torch.float64, lib=None):
+        if isinstance(inference, (Linearize, GaussHermiteQuadrature)):
+            raise NotImplementedError(
+                f"{type(inference).__name__} inference is not part of the MI355X hot path; "
+                "only CubatureQuadrature(alpha, beta, kappa) runs on the GPU"
+            )
+        if not isinstance(inference, CubatureQuadrature):
+            raise ValueError("Unknown inference method")
+        if not hasattr(sys, "model_id") or sys.model_id is None:
+            raise TypeError(
+                "the MI355X build evaluates models as compiled device functors: `sys` must come from "
+                "i2c.model.make_env_model (arbitrary Python callables cannot run inside the kernels)"
+            )
+        self.sys = sys
+        self.H = int(horizon)
+        self.inference = inference
+        self.res_dir = res_dir
+        self.engine = BatchedI2c(
+            sys, horizon, Q, R, Qf, alpha, alpha_update_tol, mu_u, sig_u, mu_x_terminal, sig_x_terminal,
+            quad=inference.as_tuple(), x0=x0, sig_x0=sig_x0, z_traj=z_traj, batch=batch, dtype=dtype,
+            device=device, lib=lib, keep_zpost=True, keep_prior=True,
+        )
+        e = self.engine
+        self.B = e.B
+        self.z = np.copy(np.asarray(sys.zg, dtype=float))
+        self.z_term = None if sys.zg_term is None else np.copy(np.asarray(sys.zg_term, dtype=float))
+        self.alpha_base = alpha
+        self.alpha_update_tol = alpha_update_tol
+        self.Q, self.R, self.QR, self.Qf = e.Q, e.R, e.QR, e.Qf
+        self.lam_xi0 = np.copy(e.QR)
+        self.sig_xi0 = e.sig_xi0
+        self.sig_xi_terminal_base = e.sig_xi_terminal_base
+        self.mu_x_terminal = None if mu_x_terminal is None else np.asarray(mu_x_terminal, float).reshape(sys.dim_x, 1)
+        self.sig_x_terminal = sig_x_terminal
+        self.cells = [I2cCell(self, t) for t in range(self.H)]
+        self.alpha_risk = []
+        self.alpha_sigma = 0
+        self.policy_valid = False
+        self._x0_seen = None
+        self.reset_metrics(False)
+        self.costs_m_all, self.costs_p_all, self.costs_pf_all = [], [], []
+        self._cache = {}
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        pass
+
+    def _maybe_scalar(self, arr):
+        arr = np.asarray(arr)
+        return float(arr.reshape(-1)[0]) if self.B == 1 else arr
+
+    def _sync_initial_state(self):
+        """MPC callers overwrite sys.x0 / sys.sig_x0 between sweeps (mpc.py:149-150)."""
+        if self.B != 1:
+            return
+        x0 = np.asarray(self.sys.x0, dtype=float).reshape(-1)
+        s0 = np.asarray(self.sys.sig_x0, dtype=float)
+        key = (x0.tobytes(), s0.tobytes())
+        if key != self._x0_seen:
+            pack_sym_np = core.engine.pack_sym_np
+            e = self.engine
+            e.x0.copy_(torch.as_tensor(x0.reshape(-1, 1), dtype=e.dtype))
+            e.sig_x0.copy_(torch.as_tensor(pack_sym_np(s0).reshape(-1, 1), dtype=e.dtype))
+            self._x0_seen = key
+
+    def _invalidate(self):
+        self._cache = {}
+
+    def _cached(self, key, fn):
+        if key not in self._cache:
+            self._cache[key] = fn()
+        return self._cache[key]
+
+    def _cell_table(self):
+        """name -> thunk returning ((B, T, ...) numpy array, is_column_vector)."""
+        e, nx = self.engine, self.engine.nx
+        c = self._cached
+
+        def post():
+            mu, sig = e.marginal_state_action()
+            return _np(mu), _np(sig)
+
+        def pol():
+            return tuple(_np(x) for x in e.local_linear_policy())
+
+        def fwd():
+            return {k: _np(v) for k, v in e.forward_messages().items()}
+
+        def zp():
+            return tuple(_np(x) for x in e.observed_marginal())
+
+        def xm():
+            return tuple(_np(x) for x in e.smoothed_next_state())
+
+        def pri():
+            return tuple(_np(x) for x in e.prior_state_action())
+
+        def prop():
+            return {k: _np(v) for k, v in e.propagated().items()}
+
+        P = lambda: c("post", post)  # noqa: E731
+        L = lambda: c("pol", pol)  # noqa: E731
+        F = lambda: c("fwd", fwd)  # noqa: E731
+        Z = lambda: c("zp", zp)  # noqa: E731
+        X = lambda: c("xm", xm)  # noqa: E731
+        R_ = lambda: c("pri", pri)  # noqa: E731
+        G = lambda: c("prop", prop)  # noqa: E731
+        return {
+            "mu_xu0_m": lambda: (P()[0], True), "sig_xu0_m": lambda: (P()[1], False),
+            "mu_xu1_m": lambda: (P()[0], True), "sig_xu1_m": lambda: (P()[1], False),
+            "mu_x0_m": lambda: (P()[0][..., :nx], True), "sig_x0_m": lambda: (P()[1][..., :nx, :nx], False),
+            "mu_u0_m": lambda: (P()[0][..., nx:], True), "sig_u0_m": lambda: (P()[1][..., nx:, nx:], False),
+            "K": lambda: (L()[0], False), "k": lambda: (L()[1], True), "sigK": lambda: (L()[2], False),
+            "mu_xu1_f": lambda: (F()["mu_xu1_f"], True), "sig_xu1_f": lambda: (F()["sig_xu1_f"], False),
+            "mu_x3_f": lambda: (F()["mu_x3_f"], True), "sig_x3_f": lambda: (F()["sig_x3_f"], False),
+            "J_dyn": lambda: (F()["J_dyn"], False), "Jx_dyn": lambda: (F()["J_dyn"][..., :nx, :], False),
+            "mu_z0_m": lambda: (Z()[0], True), "sig_z0_m": lambda: (Z()[1], False),
+            "mu_x3_m": lambda: (X()[0], True), "sig_x3_m": lambda: (X()[1], False),
+            "mu_xu0_f": lambda: (R_()[0], True), "sig_xu0_f": lambda: (R_()[1], False),
+            "mu_u0_f": lambda: (R_()[0][..., nx:], True), "sig_u0_f": lambda: (R_()[1][..., nx:, nx:], False),
+            "mu_xu0_pf": lambda: (G()["mu_xu0_pf"], True), "sig_xu0_pf": lambda: (G()["sig_xu0_pf"], False),
+            "mu_x0_pf": lambda: (G()["mu_xu0_pf"][..., :nx], True),
+            "sig_x0_pf": lambda: (G()["sig_xu0_pf"][..., :nx, :nx], False),
+            "mu_u0_pf": lambda: (G()["mu_xu0_pf"][..., nx:], True),
+            "sig_u0_pf": lambda: (G()["sig_xu0_pf"][..., nx:, nx:], False),
+            "mu_x3_pf": lambda: (G()["mu_x3_pf"], True), "sig_x3_pf": lambda: (G()["sig_x3_pf"], False),
+        }
+
+    def _cell_target(self, t):
+        e = self.engine
+        if e.z is None:
+            return np.copy(self.z)
+        z = _np(e.z[t]).T  # (B, nz)
+        return z[0].reshape(-1, 1) if self.B == 1 else z
+
+    def _set_cell_target(self, t, value):
+        """Per-cell targets (MPC reference trajectories, mpc.py:29-31)."""
+        e = self.engine
+        if e.z is None:
+            zg = torch.as_tensor(e.zg, dtype=e.dtype, device=e.device)
+            e.z = zg.reshape(1, -1, 1).repeat(self.H, 1, self.B).contiguous()
+            e.refresh_problem()
+        v = torch.as_tensor(np.asarray(value, dtype=float).reshape(-1, e.nz).T, dtype=e.dtype, device=e.device)
+        e.z[t] = v.expand(e.nz, self.B)
+
+    # ------------------------------------------------------------------ temperature
+    @property
+    def alpha(self):
+        return self._maybe_scalar(_np(self.engine.alpha))
+
+    @alpha.setter
+    def alpha(self, value):
+        self.engine.alpha.copy_(torch.as_tensor(np.broadcast_to(np.asarray(value, float), (self.B,)).copy(),
+                                                dtype=self.engine.dtype))
+
+    @property
+    def sig_xi(self):
+        a = _np(self.engine.alpha)
+        return a[0] * self.sig_xi0 if self.B == 1 else a[:, None, None] * self.sig_xi0
+
+    @property
+    def sig_xi_terminal(self):
+        if self.sig_xi_terminal_base is None:
+            return None
+        a = _np(self.engine.alpha)
+        return a[0] * self.sig_xi_terminal_base if self.B == 1 else a[:, None, None] * self.sig_xi_terminal_base
+
+    @property
+    def tau(self):
+        return self.engine.tau
+
+    @tau.setter
+    def tau(self, value):
+        self.engine.tau = int(value)
+
+    @property
+    def _propagate(self):
+        return self.engine._propagate
+
+    @_propagate.setter
+    def _propagate(self, value):
+        self.engine._propagate = bool(value)
+
+    @property
+    def state_action_independence(self):
+        return bool(self.engine.feedforward.all().item())
+
+    @state_action_independence.setter
+    def state_action_independence(self, value):  # mpc.py:21,37,40 set this graph-level attribute
+        pass
+
+    def _hist(self, lst):
+        h = BatchedI2c.history(lst)
+        return [self._maybe_scalar(row) for row in h]
+
+    alphas = property(lambda self: self._hist(self.engine.alphas))
+    alphas_desired = property(lambda self: self._hist(self.engine.alphas_desired))
+    alphas_pf = property(lambda self: self._hist(self.engine.alphas_pf))
+    costs_m = property(lambda self: self._hist(self.engine.costs_m))
+    costs_m_var = property(lambda self: self._hist(self.engine.costs_m_var))
+    costs_pf = property(lambda self: self._hist(self.engine.costs_pf))
+    costs_pf_var = property(lambda self: self._hist(self.engine.costs_pf_var))
+    kl_terms = property(lambda self: self._hist(self.engine.kl_terms))
+
+    @property
+    def em_iter(self):
+        return self.engine.em_iter
+
+    @em_iter.setter
+    def em_iter(self, v):
+        self.engine.em_iter = int(v)
+
+    # ------------------------------------------------------------------ sweeps / EM
+    def _check(self):
+        if self.B == 1:
+            self.engine.raise_on_failure()
+
+    def _forward_msgs(self):
+        self._sync_initial_state()
+        self._invalidate()
+        self.engine.forward_sweep()
+        self._check()
+
+    def _backward_msgs(self):
+        self._invalidate()
+        self.engine.backward_sweep()
+        self._check()
+
+    def _forward_backward_msgs(self):
+        self._forward_msgs()
+        self._backward_msgs()
+
+    def _update_priors(self):
+        self.engine.update_priors()
+
+    def propagate(self):
+        self._sync_initial_state()
+        self._invalidate()
+        self.engine.propagate()
+        self._check()
+
+    def calibrate_alpha(self, only_decrease=False):
+        self._sync_initial_state()
+        self._invalidate()
+        before = self.alpha
+        self.engine.calibrate_alpha(only_decrease)
+        logging.info(f"calibrating alpha from propagation {before}->{self.alpha}")
+
+    def _maximize(self):
+        self.engine.maximize(update_alpha=True)
+        if self.B == 1 and np.isnan(_np(self.engine.alphas_desired[-1])).any():
+            raise ValueError("Alpha is NaN")
+
+    def compute_update_alpha(self, update_alpha):
+        """i2c.py:921-946 without the cost bookkeeping of _maximize."""
+        e = self.engine
+        n_cost, n_pf = len(e.costs_m), len(e.costs_pf)
+        e.maximize(update_alpha=bool(update_alpha))
+        del e.costs_m[n_cost:], e.costs_m_var[n_cost:], e.costs_pf[n_pf:]
+
+    def learn_msgs(self):
+        self._sync_initial_state()
+        self._invalidate()
+        self.engine.learn_msgs()
+        self._check()
+        if self.B == 1 and np.isnan(_np(self.engine.alphas_desired[-1])).any():
+            raise ValueError("Alpha is NaN")
+
+    def update_models(self):
+        pass
+
+    # ------------------------------------------------------------------ getters (i2c.py:1191-1314)
+    def _squeeze(self, a):
+        return a[0] if self.B == 1 else a
+
+    def get_local_linear_policy(self):
+        K, k, sigK = (_np(x) for x in self.engine.local_linear_policy())
+        return self._squeeze(K), self._squeeze(k), self._squeeze(sigK)
+
+    def get_local_expert_linear_policy(self):
+        K, _, sigK = (_np(x) for x in self.engine.local_linear_policy())
+        mu, sig = (_np(x) for x in self.engine.marginal_state_action())
+        nx = self.engine.nx
+        lam = np.linalg.inv(sig[..., :nx, :nx])
+        return tuple(self._squeeze(a) for a in (K, mu[..., nx:], sigK, mu[..., :nx], lam))
+
+    def get_marginal_input(self):
+        mu = _np(self.engine.marginal_state_action()[0])[..., self.engine.nx:]
+        return mu[0][:, :, None] if self.B == 1 else mu
+
+    def get_marginal_state_action(self):
+        mu = _np(self.engine.marginal_state_action()[0])
+        return mu[0][:, :, None] if self.B == 1 else mu
+
+    def get_marginal_state_action_distribution(self):
+        mu, sig = (_np(x) for x in self.engine.marginal_state_action())
+        return self._squeeze(mu), self._squeeze(sig)
+
+    def get_marginal_trajectory(self):
+        return self._squeeze(_np(self.engine.marginal_state_action()[0]))
+
+    def get_marginal_observed_trajectory(self):
+        mz = self._squeeze(_np(self.engine.observed_marginal()[0]))
+        mzt, _ = self.engine.terminal_observed_marginal()
+        if mzt is None:
+            return mz, None
+        mzt = _np(mzt)
+        return mz, (mzt[0].reshape(1, -1) if self.B == 1 else mzt)
+
+    def get_state_action_prior(self):
+        mu = _np(self.engine.prior_state_action()[0])
+        return mu[0][:, :, None] if self.B == 1 else mu
+
+    def get_state_and_action(self):
+        mu = _np(self.engine.marginal_state_action()[0])
+        nx = self.engine.nx
+        if self.B == 1:
+            return mu[0][:, :nx, None], mu[0][:, nx:, None]
+        return mu[..., :nx], mu[..., nx:]
+
+    def get_propagated_state_action(self):
+        p = self.engine.propagated()
+        return self._squeeze(_np(p["mu_xu0_pf"])), self._squeeze(_np(p["sig_xu0_pf"]))
+
+    def get_propagated_state(self):
+        p = self.engine.propagated()
+        nx = self.engine.nx
+        mu, sig = _np(p["mu_xu0_pf"])[..., :nx], _np(p["sig_xu0_pf"])[..., :nx, :nx]
+        if self.B == 1:
+            return mu[0][:, :, None], sig[0]
+        return mu, sig
+
+    def get_z_covar(self):
+        mz, sz = (_np(x) for x in self.engine.observed_marginal())
+        zt = np.stack([np.asarray(self._cell_target(t)).reshape(self.B, -1) for t in range(self.H)], axis=1)
+        err = zt - mz
+        return self._squeeze((err[..., :, None] * err[..., None, :] + sz).sum(axis=1))
+
+    def converged(self):
+        c = self.costs_m
+        if len(c) > 2 and self.B == 1:
+            return abs(c[-1] - c[-2]) / c[-1] < 0.005
+        return False
+
+    # ------------------------------------------------------------------ metrics / persistence
+    def reset_metrics(self, extend=True):
+        e = self.engine
+        if extend:
+            self.costs_m_all.extend(self.costs_m)
+            self.costs_pf_all.extend(self.costs_pf)
+        e.costs_m, e.costs_m_var, e.costs_pf, e.costs_pf_var, e.kl_terms = [], [], [], [], []
+        e.em_iter = 0
+        for name in ("likelihoods", "likelihoods_xu", "likelihoods_z", "policy_entropy", "sig_eta_entropy",
+                     "sig_eta_pf_entropy", "x_prior_entropy", "x_prior_neg_entropy", "propagate_entropy",
+                     "costs_p", "costs_s", "risk"):
+            setattr(self, name, [])
+
+    def reset_priors(self):
+        raise NotImplementedError("reset_priors: construct a new I2cGraph instead")
+
+    def save_traj(self, res_dir):
+        """Same four .npy files as the reference (i2c.py:1374-1382)."""
+        mu = _np(self.engine.marginal_state_action()[0])
+        mz = _np(self.engine.observed_marginal()[0])
+        nx = self.engine.nx
+        sq = (lambda a: a[0][:, :, None]) if self.B == 1 else (lambda a: a)
+        np.save(os.path.join(res_dir, "xu_plan.npy"), np.hstack((sq(mu[..., :nx]), sq(mu[..., nx:]))) if self.B == 1 else mu)
+        np.save(os.path.join(res_dir, "x_plan.npy"), sq(mu[..., :nx]))
+        np.save(os.path.join(res_dir, "u_plan.npy"), sq(mu[..., nx:]))
+        np.save(os.path.join(res_dir, "z_plan.npy"), self._squeeze(mz))
+
+    def state_dict(self):
+        """Tensors that define the solver state (replaces the reference's whole-object dill pickle)."""
+        e = self.engine
+        return {"post": e.post.cpu(), "alpha": e.alpha.cpu(), "temp": e.temp.cpu(), "feedforward": e.feedforward.cpu(),
+                "status": e.status.cpu(), "em_iter": e.em_iter}
+
+    def load_state_dict(self, sd):
+        e = self.engine
+        for k in ("post", "alpha", "temp", "feedforward", "status"):
+            getattr(e, k).copy_(sd[k])
+        e.em_iter = int(sd["em_iter"])
+        self._invalidate()
+
+    def save(self, path, name):
+        torch.save(self.state_dict(), os.path.join(path, f"i2c_{name}.pt"))
+
+    # figures are presentation, not part of the solver: keep runner scripts working
+    def _no_plot(self, *args, **kwargs):
+        return None
+
+    plot_traj = plot_metrics = plot_alphas = plot_cost = plot_controller = plot_observed_traj = _no_plot
+    plot_propagate = plot_uncertainty = plot_cost_all = plot_system_dynamics = _no_plot

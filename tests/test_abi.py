@@ -1,0 +1,59 @@
+"""The C-ABI shared library loads (no GPU needed) and exports every function that
+include/i2c_hip.h declares; i2c_query reports the compile-time layout of every model."""
+import ctypes
+import importlib
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pkg = importlib.import_module("input-inference-for-control_amd")
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "i2c_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(i2c_[a-z_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_functions() == sorted(pkg._native.EXPORTED_SYMBOLS)
+
+
+def test_hip_library_exports_the_whole_abi():
+    lib = pkg.load_library()  # in-tree gfx950 build (built by __graft_entry__.build())
+    assert os.path.basename(lib.path) == "libi2c_hip.so" and not lib.is_host_sim
+    raw = ctypes.CDLL(lib.path)
+    for name in _declared_functions():
+        assert hasattr(raw, name), name
+    assert lib.i2c_abi_version() == pkg._native.ABI_VERSION
+    assert "gfx950" in lib.build_info
+
+
+def test_query_layouts():
+    lib = pkg.load_library()
+    sym = lambda n: n * (n + 1) // 2  # noqa: E731
+    expect = {0: (2, 1, 4, 3), 1: (2, 1, 1, 0), 2: (4, 1, 6, 5), 3: (6, 1, 9, 8), 4: (2, 1, 3, 2), 5: (2, 1, 1, 2),
+              6: (6, 2, 8, 6)}
+    for mid, (nx, nu, nz, nzt) in expect.items():
+        d = lib.query(mid)
+        assert (d.nx, d.nu, d.nz, d.nzt) == (nx, nu, nz, nzt)
+        dd = nx + nu
+        assert d.e_post == dd + sym(dd) + nu * nx + nu + sym(nu)
+        assert d.e_fwd == dd + sym(dd) + nx + sym(nx) + dd * nx
+        assert d.e_xm == nx + sym(nx) and d.e_zpost == nz + sym(nz)
+    # 64 elements (512 B fp64) per pendulum cell-iteration, 292 for the double cartpole
+    for mid, total in ((0, 64), (3, 292)):
+        d = lib.query(mid)
+        pri = d.e_post - d.nu - sym(d.nu)
+        assert pri + 2 * d.e_fwd + d.e_post == total
+    import pytest
+
+    with pytest.raises(ValueError):
+        lib.query(99)
+
+
+def test_bad_arguments_are_rejected_without_touching_the_gpu():
+    lib = pkg.load_library()
+    p = pkg._native.I2cProblem()
+    assert lib.i2c_forward_sweep(ctypes.byref(p), None, None, None, None, None) == -1  # I2C_EINVAL
+    assert lib.i2c_mstep(ctypes.byref(p), None, None, 0.0, 1, None, None) == -1

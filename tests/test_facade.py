@@ -1,0 +1,150 @@
+"""The drop-in boundary: code written against the reference's I2cGraph API (constructor,
+learn_msgs, getters, cells[t].<attr>) runs on the MI355X build and reproduces the reference's
+captured outputs. CPU: host simulation of the kernels; GPU: the HIP library."""
+import numpy as np
+import pytest
+import torch
+
+import hostsim
+from golden_util import assert_close, load_case
+from i2c.exp_types import CubatureQuadrature, GaussHermiteQuadrature, GaussianI2c, Linearize
+from i2c.i2c import I2cGraph
+from i2c.model import make_env_model
+
+
+def _graph(g, lib, device):
+    meta = g.meta
+    model = make_env_model(meta["model"], None)
+    return I2cGraph(model, meta["T"], g.get("Q"), g["R"], g.get("Qf"), meta["alpha"], meta["tol"], g["mu_u"], g["sig_u"],
+                    g.get("mu_x_term"), g.get("sig_x_term"), CubatureQuadrature(*meta["quad"]), res_dir=None, lib=lib,
+                    device=device)
+
+
+def _run_reference_style(lib, device, tol):
+    g = load_case("em_pendulum_T200")
+    i2c = _graph(g, lib, device)
+    i2c.reset_metrics()
+    n = 5
+    for _ in range(n):
+        i2c.learn_msgs()
+    # what scripts/i2c_run.py reads every iteration (i2c_run.py:98-114)
+    K, k, sigK = i2c.get_local_linear_policy()
+    assert K.shape == (200, 1, 2) and k.shape == (200, 1) and sigK.shape == (200, 1, 1)
+    Ke, ke, sKe, mu, lam = i2c.get_local_expert_linear_policy()
+    assert ke.shape == (200, 1) and mu.shape == (200, 2) and lam.shape == (200, 2, 2)
+    z_est, z_term_est = i2c.get_marginal_observed_trajectory()
+    assert z_est.shape == (200, 4) and z_term_est.shape == (1, 3)
+    assert i2c.get_marginal_trajectory().shape == (200, 3)
+    assert i2c.get_marginal_input().shape == (200, 1, 1)
+    assert_close(np.array(i2c.costs_m), g["costs_m"][:n], tol, "costs_m")
+    assert_close(np.array(i2c.alphas), g["alphas"][: n + 1], tol, "alphas")
+    assert_close(np.array(i2c.alphas_desired), g["alphas_desired"][: n + 1], tol, "alphas_desired")
+    assert i2c.costs_pf[-1] == -1.0
+    assert isinstance(i2c.alpha, float)
+    # cell views, reference shapes (column vectors)
+    c = i2c.cells[17]
+    assert c.mu_xu0_m.shape == (3, 1) and c.sig_xu0_m.shape == (3, 3) and c.K.shape == (1, 2)
+    assert c.mu_u0_m.shape == (1, 1) and c.sig_u0_m.shape == (1, 1) and c.mu_x0_m.shape == (2, 1)
+    assert not c.state_action_independence and i2c.cells[-1].terminal_cell
+    # three more iterations, then compare cell state with the reference's iteration-3 capture of a fresh run
+    j = _graph(g, lib, device)
+    for _ in range(3):
+        j.learn_msgs()
+    for t in (0, 57, 198):
+        cell = j.cells[t]
+        assert_close(cell.mu_xu0_m[:, 0], g.at(3, "mu_xu0_m")[t], tol, "cell mu_xu0_m")
+        assert_close(cell.sig_xu0_m, g.at(3, "sig_xu0_m")[t], tol, "cell sig_xu0_m")
+        assert_close(cell.K, g.at(3, "K")[t], tol * 10, "cell K")
+        assert_close(cell.mu_x3_f[:, 0], g.at(3, "mu_x3_f")[t], tol, "cell mu_x3_f")
+        assert_close(cell.J_dyn, g.at(3, "J_dyn")[t], tol, "cell J_dyn")
+    return i2c
+
+
+def test_facade_reference_style_cpu():
+    _run_reference_style(hostsim.load(), "cpu", 1e-8)
+
+
+@pytest.mark.gpu
+def test_facade_reference_style_gpu():
+    _run_reference_style(None, "cuda", 1e-7)
+
+
+def test_facade_mpc_style_calls_cpu():
+    """The calls PartiallyObservedMpcPolicy makes (mpc.py:147-167): overwrite sys.x0/sig_x0, run
+    _forward_backward_msgs + _update_priors, read cells[0].mu_u0_m / sig_u0_m."""
+    g = load_case("em_pendulum_T200")
+    meta = g.meta
+    model = make_env_model(meta["model"], None)
+    T = 10
+    i2c = I2cGraph(model, T, g["Q"], g["R"], g["Qf"], 10.0, 1.0, np.zeros((T, 1)), g["sig_u"], None, None,
+                   CubatureQuadrature(1, 0, 0), lib=hostsim.load(), device="cpu")
+    i2c.tau = 0  # feed-forward MPC (mpc.py:21-22)
+    u_first = []
+    for x in (np.array([[np.pi], [0.0]]), np.array([[np.pi - 0.3], [0.5]])):
+        i2c.sys.x0 = x
+        i2c.sys.sig_x0 = 1e-4 * np.eye(2)
+        for _ in range(2):
+            i2c._forward_backward_msgs()
+            i2c._update_priors()
+        assert i2c.cells[0].state_action_independence  # tau = 0: cells stay feed-forward
+        u_first.append(np.copy(i2c.cells[0].mu_u0_m))
+        assert i2c.cells[0].sig_u0_m.shape == (1, 1)
+        xu = i2c.get_marginal_state_action()
+        assert xu.shape == (T, 3, 1)
+        assert_close(xu[0, :2, 0], x[:, 0], 5e-2, "first marginal state follows the new x0")
+    assert abs(u_first[0] - u_first[1]).max() > 1e-6
+
+
+def test_facade_rejects_what_the_gpu_path_cannot_do():
+    g = load_case("em_linear_T60")
+    model = make_env_model("LinearKnown", None)
+    args = (model, 60, g["Q"], g["R"], g["Qf"], 800.0, 0.0, g["mu_u"], g["sig_u"], None, None)
+    with pytest.raises(NotImplementedError):
+        I2cGraph(*args, Linearize(), lib=hostsim.load(), device="cpu")
+    with pytest.raises(NotImplementedError):
+        I2cGraph(*args, GaussHermiteQuadrature(3), lib=hostsim.load(), device="cpu")
+
+    class PythonModel:  # an arbitrary callable plugin cannot run inside a kernel
+        dim_x, dim_u, dim_z = 2, 1, 3
+
+    with pytest.raises(TypeError):
+        I2cGraph(PythonModel(), 60, g["Q"], g["R"], g["Qf"], 800.0, 0.0, g["mu_u"], g["sig_u"], None, None,
+                 CubatureQuadrature(1, 0, 0), lib=hostsim.load(), device="cpu")
+
+
+def test_product_never_falls_back_to_cpu():
+    """The HIP library refuses CPU tensors, and the host simulation refuses to pose as a GPU."""
+    import importlib
+
+    pkg = importlib.import_module("input-inference-for-control_amd")
+    g = load_case("em_linear_T60")
+    model = make_env_model("LinearKnown", None)
+    lib = pkg.load_library()  # the real gfx950 build (loads without a GPU; no compute call is made)
+    assert not lib.is_host_sim
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.BatchedI2c(model, 60, g["Q"], g["R"], g["Qf"], 800.0, 0.0, g["mu_u"], g["sig_u"], device="cpu", lib=lib)
+    with pytest.raises(RuntimeError):
+        pkg.BatchedI2c(model, 60, g["Q"], g["R"], g["Qf"], 800.0, 0.0, g["mu_u"], g["sig_u"], device="cuda",
+                       lib=hostsim.load())
+
+
+def test_exp_types_match_reference_vectors():
+    q = load_case("quadrature_vectors")
+    for deg in (2, 3, 4):
+        r = GaussHermiteQuadrature(deg)
+        assert_close(r.pts(3), q[f"gh{deg}/pts"], 1e-15)
+        sf, w, _ = r.weights(3)
+        assert_close(w, q[f"gh{deg}/w"], 1e-14)
+    from oracle.i2c_numpy import CubatureRule
+
+    for prm in [(1, 0, 0), (0.7, 2.0, 0.5), (1.3, 0.0, 1.0)]:
+        for dim in (2, 3, 7):
+            sf, wm, ws = CubatureQuadrature(*prm).weights(dim)
+            sf2, wm2, ws2 = CubatureRule(*prm).weights(dim)
+            assert_close(sf, sf2, 1e-15)
+            assert_close(wm, wm2, 1e-14)
+            assert_close(ws, ws2, 1e-14)
+            assert_close(CubatureQuadrature.pts(dim), CubatureRule(*prm).points(dim), 0)
+    cfg = GaussianI2c(inference=CubatureQuadrature(1, 0, 0), Q=None, R=np.eye(1), Qf=None, alpha=1.0, alpha_update_tol=0.0,
+                      mu_u=np.zeros((3, 1)), sig_u=np.eye(1), mu_x_term=None, sig_x_term=None)
+    assert cfg.alpha == 1.0
