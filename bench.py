@@ -41,13 +41,56 @@ def synthetic_pendulum_inputs(B, T, rank=0):
     return x0, mu_u
 
 
-def make_engine(pkg, B, T, dtype, device, rank=0):
+def make_engine(pkg, B, T, dtype, device, rank=0, backward_mode="auto"):
     from i2c.known_models import make_env_model
 
     x0, mu_u = synthetic_pendulum_inputs(B, T, rank)
     Q, R = np.diag([1.0, 100.0, 1.0]), np.diag([2.0])  # scripts/experiments/pendulum_known_quad.py:22-33
     return pkg.BatchedI2c(make_env_model("PendulumKnown"), T, Q, R, Q, 100.0, 0.0, mu_u, 2.0 * np.eye(1), x0=x0,
-                          dtype=dtype, device=device, keep_zpost=False)
+                          dtype=dtype, device=device, keep_zpost=False, keep_xm=False, backward_mode=backward_mode)
+
+
+def timed_iterations(eng, K, sync):
+    """K EM iterations with HIP events around each sweep (recorded on the launch stream).
+    Returns (wall seconds, mean ms of forward / backward / mstep)."""
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
+    sync()
+    t0 = time.perf_counter()
+    for i in range(K):
+        eng.em_iter += 1
+        ev[i][0].record()
+        eng.forward_sweep()
+        ev[i][1].record()
+        eng.backward_sweep()
+        ev[i][2].record()
+        eng.maximize()
+        ev[i][3].record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    ms = [float(np.mean([ev[i][j].elapsed_time(ev[i][j + 1]) for i in range(K)])) for j in range(3)]
+    return elapsed, ms
+
+
+def saturated_leg(pkg, T, dtype, device, el, wbytes, B=131072, K=6):
+    """Same kernels at a batch that fills the chip (2 wavefronts per SIMD): shows the HBM-bound
+    regime the headline batch (64 wavefronts on 1024 SIMDs) cannot reach."""
+    eng = make_engine(pkg, B, T, dtype, device, rank=7)
+    for _ in range(2):
+        eng.learn_msgs()
+    elapsed, ms = timed_iterations(eng, K, lambda: torch.cuda.synchronize(device))
+    cells = B * T
+    return {
+        "batch": B,
+        "value": cells * K / elapsed,
+        "unit": "timestep-messages/s",
+        "ms_per_step": elapsed / K * 1e3,
+        "backward": "fused" if eng.fused_backward else "two_pass",
+        "kernel_ms": {"forward_sweep": ms[0], "backward_sweep": ms[1], "mstep": ms[2]},
+        "forward_GBps": el["forward"] * wbytes * cells / (ms[0] * 1e-3) / 1e9,
+        "backward_GBps": el["backward"] * wbytes * cells / (ms[1] * 1e-3) / 1e9,
+        "whole_iteration_GBps": el["total"] * wbytes * cells / (elapsed / K) / 1e9,
+        "whole_iteration_frac_of_peak": el["total"] * wbytes * cells / (elapsed / K) / 1e9 / HBM_PEAK_GBS,
+    }
 
 
 def algorithmic_elements(d, nx, nu):
@@ -59,7 +102,18 @@ def algorithmic_elements(d, nx, nu):
     return dict(forward=fwd_read + fwd_write, backward=fwd_write + bwd_write, total=fwd_read + 2 * fwd_write + bwd_write)
 
 
-def cpu_baseline(T, sample_B=512, iters=6):
+def measured_traffic(B, T, dtype, kernel):
+    """HBM bytes per launch from the committed PMC passes (tools/pmc_summary.py), if one matches."""
+    path = os.path.join(ROOT, "profiles", f"r1_B{B}_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    if (d["B"], d["T"], d["dtype"]) != (B, T, dtype) or kernel not in d["kernels"]:
+        return None
+    return d["kernels"][kernel]["hbm_bytes_per_launch"]
+
+
+def cpu_baseline(T, sample_B=512, iters=30):
     """The oracle (NumPy restatement, batch-vectorised, one core) timed on this host: a bounded
     sample of the same workload (sample_B trajectories x T cells x `iters` EM iterations)."""
     from oracle.i2c_numpy import CubatureRule, I2cOracle
@@ -92,6 +146,8 @@ def main():
     ap.add_argument("--horizon", type=int, default=200)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-saturated", action="store_true", help="skip the extra B=131072 leg")
+    ap.add_argument("--backward", default="auto", choices=["auto", "two_pass", "fused"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,7 +166,7 @@ def main():
     pkg = importlib.import_module(PKG)
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
     B, T = args.batch, args.horizon
-    eng = make_engine(pkg, B, T, dtype, device, rank)
+    eng = make_engine(pkg, B, T, dtype, device, rank, args.backward)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -120,31 +176,14 @@ def main():
 
     for _ in range(args.warmup):
         eng.learn_msgs()
-    barrier()
 
     # ---- timed region: exactly K EM iterations; per-kernel HIP events on the launch stream ----
     K = args.steps
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
-    t0 = time.perf_counter()
-    for i in range(K):
-        eng.em_iter += 1
-        ev[i][0].record()
-        eng.forward_sweep()
-        ev[i][1].record()
-        eng.backward_sweep()
-        ev[i][2].record()
-        eng.maximize()
-        ev[i][3].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, (fwd_ms, bwd_ms, mst_ms) = timed_iterations(eng, K, barrier)
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-
-    fwd_ms = float(np.mean([ev[i][0].elapsed_time(ev[i][1]) for i in range(K)]))
-    bwd_ms = float(np.mean([ev[i][1].elapsed_time(ev[i][2]) for i in range(K)]))
-    mst_ms = float(np.mean([ev[i][2].elapsed_time(ev[i][3]) for i in range(K)]))
     n_fail = len(eng.failures())
 
     # ---- the one collective of the job: all-gather of the final controllers -------
@@ -190,7 +229,8 @@ def main():
             "horizon": T,
             "parallelism": f"batch-sharded x{world}, no collective in the EM loop",
         },
-        "kernel_ms": {"forward_sweep": fwd_ms, "backward_sweep(scan+cell)": bwd_ms, "mstep": mst_ms},
+        "kernel_ms": {"forward_sweep": fwd_ms, "backward_sweep": bwd_ms, "mstep": mst_ms},
+        "backward": "fused" if eng.fused_backward else "two_pass (scan + per-cell + reduce)",
         "failed_trajectories": n_fail,
         "roofline": {
             "kernel": "k_forward (forward sweep, the dominant kernel)",
@@ -199,13 +239,18 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": measured_traffic(B, T, args.dtype, "k_forward"),
+            "traffic_note": "bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                            "(FETCH_SIZE x2, gfx950 correction; profiles/r1_B*_pmc_traffic.json); algorithmic = "
+                            + str(fwd_bytes),
             "algorithmic_bytes_per_cell": {k: v * wbytes for k, v in el.items()},
             "whole_iteration_GBps": el["total"] * wbytes * B * T / (elapsed / K) / 1e9,
             "note": "latency-bound at B=4096: 64 wavefronts walk 2*T dependent cells; see DESIGN.md",
         },
         "final_allgather_ms": allgather_ms,
     }
+    if not args.no_saturated and world == 1:
+        out["saturated_batch"] = saturated_leg(pkg, T, dtype, device, el, wbytes)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(T)
     print(json.dumps(out))

@@ -55,6 +55,14 @@ enum {
 
 enum { I2C_F64 = 0, I2C_F32 = 1 };
 
+/* how i2c_backward_sweep is scheduled (results are identical up to summation order of the cost) */
+enum {
+  I2C_BWD_AUTO = 0,     /* two-pass below I2C_BWD_FUSED_MIN_B trajectories, fused from there on */
+  I2C_BWD_TWO_PASS = 1, /* sequential nx x nx scan + one lane per (t, b) + reduction: lowest latency */
+  I2C_BWD_FUSED = 2     /* one lane per trajectory does the whole cell: lowest HBM traffic           */
+};
+#define I2C_BWD_FUSED_MIN_B 32768
+
 enum {
   I2C_OK = 0,
   I2C_EINVAL = -1,   /* bad argument (null pointer, unknown model / dtype, B or T < 1) */
@@ -97,6 +105,8 @@ typedef struct I2cProblem {
   int32_t has_Qf;          /* terminal cost observation (Qf given, i2c.py:787-793)             */
   int32_t has_x_terminal;  /* covariance control: terminal state prior (i2c.py:548-559)        */
   int32_t z_per_cell;      /* 0: target = zg for every cell; 1: device targets `z` [T][nz][B]  */
+  int32_t backward_mode;   /* I2C_BWD_AUTO | I2C_BWD_TWO_PASS | I2C_BWD_FUSED (see i2c_backward_sweep) */
+  int32_t reserved0;
   /* CubatureQuadrature(alpha, beta, kappa): i2c/exp_types.py:31-49 */
   double quad_alpha, quad_beta, quad_kappa;
   double dtemp;            /* terminal-prior annealing rate (i2c.py:66,552)                    */
@@ -165,24 +175,30 @@ int i2c_forward_sweep(const I2cProblem* p, const void* prior, void* fwd, void* p
  * Backward smoother + controller extraction + M-step statistics: replaces
  * I2cGraph._backward_msgs (i2c.py:882-886) calling I2cCell._backward_msgs_quadrature
  * (i2c.py:544-610) and the per-cell parts of calc_cost / get_z_covar (i2c.py:1034-1053,
- * 680-683, 983-992). Two launches: a light sequential scan of the x-marginal recursion (one
- * lane per trajectory) and a fully parallel per-cell pass (one lane per (t, b)).
+ * 680-683, 983-992).
+ *   TWO-PASS (small batches): a light sequential scan of the x-marginal recursion (one lane per
+ *   trajectory, nx x nx blocks only), then a fully parallel per-cell pass (one lane per (t, b)),
+ *   then a deterministic reduction of the per-cell cost over t.
+ *   FUSED (large batches): one lane per trajectory does everything; each forward row is read once.
  *   fwd        [T][e_fwd][B]   in
- *   xm         [T][e_xm][B]    out (workspace that is also a result: mu_x3_m, sig_x3_m)
+ *   xm         [T][e_xm][B]    out: mu_x3_m, sig_x3_m (two-pass: required workspace;
+ *                              fused: optional, NULL to skip)
  *   post       [T][e_post][B]  out (may alias the `prior` given to the forward sweep)
  *   zpost      [T][e_zpost][B] out, optional (NULL to skip)
  *   cell_stats [T][2][B]       out: per-cell expected cost mean m_t and variance v_t
- *                              (compute_cost_gaussian, i2c.py:1034-1043); m_t is also the cell's
- *                              contribution tr(QR (err err^T + sig_z0_m)) to alpha (i2c.py:913-919)
- *   term_stats [3 + nzt + SYM(nzt)][B] out: tr(Qf (errT errT^T + sig_z3_m)) (i2c.py:989-992), two
- *                              reserved rows, then mu_z3_m, sig_z3_m; zero when !has_Qf
+ *                              (compute_cost_gaussian, i2c.py:1034-1043); two-pass: required
+ *                              workspace; fused: optional. m_t is also the cell's contribution
+ *                              tr(QR (err err^T + sig_z0_m)) to alpha (i2c.py:913-919)
+ *   term_stats [3 + nzt + SYM(nzt)][B] out: row 0 = tr(Qf (errT errT^T + sig_z3_m))
+ *                              (i2c.py:989-992; 0 when !has_Qf), row 1 = sum_t m_t, row 2 = sum_t v_t,
+ *                              then mu_z3_m, sig_z3_m
  */
 int i2c_backward_sweep(const I2cProblem* p, const void* fwd, void* xm, void* post, void* zpost,
                        void* cell_stats, void* term_stats, int32_t* status, void* stream);
 
 /*
  * M-step on the temperature: replaces calc_cost's sums, calculate_alpha, update_alpha and
- * update_xi (i2c.py:913-981, 1045-1053).
+ * update_xi (i2c.py:913-981, 1045-1053). O(B): the sums over t come from term_stats.
  *   alpha_update_tol  as I2cGraph.alpha_update_tol (>= 0: clamp ratio to [tol, 2 - tol];
  *                     < 0: keep alpha)
  *   update            0: only report alpha_hat (compute_update_alpha(False))
@@ -190,8 +206,8 @@ int i2c_backward_sweep(const I2cProblem* p, const void* fwd, void* xm, void* pos
  *                     cost mean (costs_m), cost variance (costs_m_var)
  * p->alpha is updated in place when update != 0.
  */
-int i2c_mstep(const I2cProblem* p, const void* cell_stats, const void* term_stats,
-              double alpha_update_tol, int update, void* stats_out, void* stream);
+int i2c_mstep(const I2cProblem* p, const void* term_stats, double alpha_update_tol, int update,
+              void* stats_out, void* stream);
 
 /*
  * Closed-loop propagation of the controller distribution: replaces I2cGraph.propagate
@@ -199,10 +215,11 @@ int i2c_mstep(const I2cProblem* p, const void* cell_stats, const void* term_stat
  * per-cell propagated cost statistics (i2c.py:685-688, 1055-1063).
  *   post       [T][e_post][B]  in  (posterior + controller from i2c_backward_sweep)
  *   prop       [T][e_prop][B]  out: mu_xu0_pf[d] | sig_xu0_pf[SYM(d)] | mu_x3_pf[nx] | sig_x3_pf[SYM(nx)]
- *   cell_stats_pf [T][2][B]    out: propagated cost mean / variance per cell
+ *   prop_stats [2][B]          out: sum over cells of the propagated cost mean / variance
+ *                              (costs_pf, costs_pf_var; row 0 / (nz T) is alpha_pf, i2c.py:934-939)
  *   use_expert_controller      cells' use_expert_controller flag (i2c.py:143,160)
  */
-int i2c_propagate(const I2cProblem* p, const void* post, void* prop, void* cell_stats_pf,
+int i2c_propagate(const I2cProblem* p, const void* post, void* prop, void* prop_stats,
                   int use_expert_controller, int32_t* status, void* stream);
 
 #ifdef __cplusplus

@@ -18,6 +18,7 @@ def _sym(n):
 
 
 F64, F32 = 0, 1
+BWD_AUTO, BWD_TWO_PASS, BWD_FUSED = 0, 1, 2
 
 MODEL_IDS = {
     "PendulumKnown": 0,
@@ -55,6 +56,8 @@ class I2cProblem(C.Structure):
         ("has_Qf", C.c_int32),
         ("has_x_terminal", C.c_int32),
         ("z_per_cell", C.c_int32),
+        ("backward_mode", C.c_int32),
+        ("reserved0", C.c_int32),
         ("quad_alpha", C.c_double),
         ("quad_beta", C.c_double),
         ("quad_kappa", C.c_double),
@@ -87,7 +90,7 @@ _SIGNATURES = {
         C.c_int,
         [C.POINTER(I2cProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
-    "i2c_mstep": (C.c_int, [C.POINTER(I2cProblem), C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
+    "i2c_mstep": (C.c_int, [C.POINTER(I2cProblem), C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
     "i2c_propagate": (C.c_int, [C.POINTER(I2cProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
 }
 

@@ -11,6 +11,7 @@
 #include "i2c_cell.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace i2c {
@@ -20,10 +21,20 @@ namespace i2c {
 // 64 different CUs, each wave with a CU's issue ports, L1 and scalar cache to itself.
 constexpr int SWEEP_BLOCK = 64;
 constexpr int CELL_BLOCK = 256;
+// Experiment knob (not part of the ABI): I2C_SWEEP_LANES=<n<=64> launches the sequential sweeps with
+// n active lanes per wavefront (more, emptier waves on more SIMDs).
+static int sweep_lanes() {
+  static int v = [] {
+    const char* e = getenv("I2C_SWEEP_LANES");
+    const int n = e ? atoi(e) : SWEEP_BLOCK;
+    return (n >= 1 && n <= SWEEP_BLOCK) ? n : SWEEP_BLOCK;
+  }();
+  return v;
+}
 
 template <class M, typename R>
 __global__ __launch_bounds__(SWEEP_BLOCK) void k_forward(const Consts<M, R> c, const FwdArgs<R> a) {
-  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < c.B) forward_sweep_body<M, R>(c, a, b);
 }
 template <class M, typename R>
@@ -36,6 +47,32 @@ __global__ __launch_bounds__(CELL_BLOCK) void k_cell(const Consts<M, R> c, const
   const int b = blockIdx.x * CELL_BLOCK + threadIdx.x;
   const int t = blockIdx.y;
   if (b < c.B) backward_cell_body<M, R>(c, a, t, b);
+}
+template <class M, typename R>
+__global__ __launch_bounds__(SWEEP_BLOCK) void k_bwd_fused(const Consts<M, R> c, const CellArgs<R> a) {
+  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
+  if (b < c.B) backward_fused_body<M, R>(c, a, b);
+}
+// sum the per-cell cost statistics over t: REDUCE_PARTS lanes per trajectory, fixed summation order
+constexpr int REDUCE_PARTS = 8;
+template <class M, typename R>
+__global__ __launch_bounds__(SWEEP_BLOCK* REDUCE_PARTS) void k_reduce(const Consts<M, R> c, const CellArgs<R> a) {
+  __shared__ R sm[REDUCE_PARTS][SWEEP_BLOCK], sv[REDUCE_PARTS][SWEEP_BLOCK];
+  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
+  R m = R(0), v = R(0);
+  if (b < c.B) reduce_partial<M, R>(c, a.cell_stats, b, threadIdx.y, REDUCE_PARTS, &m, &v);
+  sm[threadIdx.y][threadIdx.x] = m;
+  sv[threadIdx.y][threadIdx.x] = v;
+  __syncthreads();
+  if (threadIdx.y == 0 && b < c.B) {
+#pragma unroll
+    for (int q = 1; q < REDUCE_PARTS; ++q) {
+      m += sm[q][threadIdx.x];
+      v += sv[q][threadIdx.x];
+    }
+    a.term_stats[(long)c.B + b] = m;
+    a.term_stats[2 * (long)c.B + b] = v;
+  }
 }
 template <class M, typename R>
 __global__ __launch_bounds__(SWEEP_BLOCK) void k_mstep(const Consts<M, R> c, const MstepArgs<R> a) {
@@ -114,38 +151,68 @@ template <class M, typename R> struct Impl {
     for (int b = 0; b < p->B; ++b) forward_sweep_body<M, R>(c, a, b);
     return I2C_OK;
 #else
-    const int grid = (p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
-    hipLaunchKernelGGL((k_forward<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, a);
+    const int lanes = sweep_lanes();
+    const int grid = (p->B + lanes - 1) / lanes;
+    hipLaunchKernelGGL((k_forward<M, R>), dim3(grid), dim3(lanes), 0, (hipStream_t)stream, c, a);
     return launch_status();
 #endif
+  }
+
+  static bool use_fused(const I2cProblem* p) {
+    if (p->backward_mode == I2C_BWD_FUSED) return true;
+    if (p->backward_mode == I2C_BWD_TWO_PASS) return false;
+    return p->B >= I2C_BWD_FUSED_MIN_B;
   }
 
   static int backward(const I2cProblem* p, const void* fwd, void* xm, void* post, void* zpost, void* cell_stats,
                       void* term_stats, int32_t* status, void* stream) {
     const C c = make_consts<M, R>(p, 0.0, 0);
+    const bool fused = use_fused(p);
+    if (!fused && (!xm || !cell_stats)) return I2C_EINVAL;
     ScanArgs<R> s{(const R*)fwd, (R*)xm, (R*)p->temp, status};
-    CellArgs<R> a{(const R*)fwd, (const R*)xm, (const R*)p->z, (R*)post,
-                  (R*)zpost,     (R*)cell_stats, (R*)term_stats, status};
+    CellArgs<R> a{(const R*)fwd, (const R*)xm,   (const R*)p->z, (R*)post,  (R*)zpost,
+                  (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status};
 #ifdef I2C_HOST_SIM
     (void)stream;
+    if (fused) {
+      for (int b = 0; b < p->B; ++b) backward_fused_body<M, R>(c, a, b);
+      return I2C_OK;
+    }
     for (int b = 0; b < p->B; ++b) backward_scan_body<M, R>(c, s, b);
     for (int t = 0; t < p->T; ++t)
       for (int b = 0; b < p->B; ++b) backward_cell_body<M, R>(c, a, t, b);
+    for (int b = 0; b < p->B; ++b) {  // same partition and summation order as k_reduce
+      R m = R(0), v = R(0);
+      for (int q = 0; q < 8; ++q) {
+        R pm, pv;
+        reduce_partial<M, R>(c, a.cell_stats, b, q, 8, &pm, &pv);
+        m += pm;
+        v += pv;
+      }
+      a.term_stats[(long)p->B + b] = m;
+      a.term_stats[2 * (long)p->B + b] = v;
+    }
     return I2C_OK;
 #else
     const int grid = (p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+    if (fused) {
+      hipLaunchKernelGGL((k_bwd_fused<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, a);
+      return launch_status();
+    }
     hipLaunchKernelGGL((k_scan<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, s);
     if (launch_status() != I2C_OK) return I2C_ELAUNCH;
     const dim3 cgrid((p->B + CELL_BLOCK - 1) / CELL_BLOCK, p->T);
     hipLaunchKernelGGL((k_cell<M, R>), cgrid, dim3(CELL_BLOCK), 0, (hipStream_t)stream, c, a);
+    if (launch_status() != I2C_OK) return I2C_ELAUNCH;
+    hipLaunchKernelGGL((k_reduce<M, R>), dim3(grid), dim3(SWEEP_BLOCK, REDUCE_PARTS), 0, (hipStream_t)stream, c, a);
     return launch_status();
 #endif
   }
 
-  static int mstep(const I2cProblem* p, const void* cell_stats, const void* term_stats, double tol, int update,
-                   void* stats_out, void* stream) {
+  static int mstep(const I2cProblem* p, const void* term_stats, double tol, int update, void* stats_out,
+                   void* stream) {
     const C c = make_consts<M, R>(p, tol, 0);
-    MstepArgs<R> a{(const R*)cell_stats, (const R*)term_stats, (R*)p->alpha, (R*)stats_out, update};
+    MstepArgs<R> a{(const R*)term_stats, (R*)p->alpha, (R*)stats_out, update};
 #ifdef I2C_HOST_SIM
     (void)stream;
     for (int b = 0; b < p->B; ++b) mstep_body<M, R>(c, a, b);
@@ -157,10 +224,10 @@ template <class M, typename R> struct Impl {
 #endif
   }
 
-  static int propagate(const I2cProblem* p, const void* post, void* prop, void* cell_stats, int use_expert,
+  static int propagate(const I2cProblem* p, const void* post, void* prop, void* prop_stats, int use_expert,
                        int32_t* status, void* stream) {
     const C c = make_consts<M, R>(p, 0.0, use_expert);
-    PropArgs<R> a{(const R*)post, (R*)prop, (R*)cell_stats, (const R*)p->x0, (const R*)p->sig_x0,
+    PropArgs<R> a{(const R*)post, (R*)prop, (R*)prop_stats, (const R*)p->x0, (const R*)p->sig_x0,
                   (const R*)p->z, p->feedforward, status};
 #ifdef I2C_HOST_SIM
     (void)stream;
@@ -249,20 +316,20 @@ int i2c_forward_sweep(const I2cProblem* p, const void* prior, void* fwd, void* p
 
 int i2c_backward_sweep(const I2cProblem* p, const void* fwd, void* xm, void* post, void* zpost, void* cell_stats,
                        void* term_stats, int32_t* status, void* stream) {
-  if (!fwd || !xm || !post || !cell_stats || !term_stats || !status) return I2C_EINVAL;
+  if (!fwd || !post || !term_stats || !status) return I2C_EINVAL;
   I2C_DISPATCH(p, backward(p, fwd, xm, post, zpost, cell_stats, term_stats, status, stream));
 }
 
-int i2c_mstep(const I2cProblem* p, const void* cell_stats, const void* term_stats, double alpha_update_tol,
-              int update, void* stats_out, void* stream) {
-  if (!cell_stats || !term_stats || !stats_out) return I2C_EINVAL;
-  I2C_DISPATCH(p, mstep(p, cell_stats, term_stats, alpha_update_tol, update, stats_out, stream));
+int i2c_mstep(const I2cProblem* p, const void* term_stats, double alpha_update_tol, int update, void* stats_out,
+              void* stream) {
+  if (!term_stats || !stats_out) return I2C_EINVAL;
+  I2C_DISPATCH(p, mstep(p, term_stats, alpha_update_tol, update, stats_out, stream));
 }
 
-int i2c_propagate(const I2cProblem* p, const void* post, void* prop, void* cell_stats_pf, int use_expert_controller,
+int i2c_propagate(const I2cProblem* p, const void* post, void* prop, void* prop_stats, int use_expert_controller,
                   int32_t* status, void* stream) {
-  if (!post || !prop || !cell_stats_pf || !status) return I2C_EINVAL;
-  I2C_DISPATCH(p, propagate(p, post, prop, cell_stats_pf, use_expert_controller, status, stream));
+  if (!post || !prop || !prop_stats || !status) return I2C_EINVAL;
+  I2C_DISPATCH(p, propagate(p, post, prop, prop_stats, use_expert_controller, status, stream));
 }
 
 }  // extern "C"

@@ -137,7 +137,7 @@ I2C_FN void sp_transform(const Rule<R>& rule, const R* m, const R* Sin, const R*
           cp[q] = cm[q] = c0[q];
         } else {
           R sd, cd;
-          r_sincos(rule.sf * L[tri(M::ang(q), j)], &sd, &cd);
+          r_sincos_small(rule.sf * L[tri(M::ang(q), j)], &sd, &cd);
           sp[q] = s0[q] * cd + c0[q] * sd;
           cp[q] = c0[q] * cd - s0[q] * sd;
           sm[q] = s0[q] * cd - c0[q] * sd;
@@ -328,8 +328,11 @@ template <class M, typename R>
 I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a, const int b) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D;
-  const long B = c.B;
+  constexpr unsigned W = sizeof(R);
+  const unsigned long B = c.B;
   const int T = c.T;
+  const unsigned bo = (unsigned)b * W;     // the lane's byte offset inside any row
+  const unsigned rb = (unsigned)(B * W);   // bytes per row (wave-uniform)
   const R alpha = a.alpha[b];
 
   R mu_x[NX], sig_x[sym(NX)];
@@ -340,16 +343,22 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 
   // software prefetch of the next cell's prior rows: the loads do not depend on the recursion
   R pri[C::E_PRI], zt[NZ];
+  {
+    const Window w = make_window(a.prior, (unsigned long)C::E_POST * rb);
 #pragma unroll
-  for (int e = 0; e < C::E_PRI; ++e) pri[e] = a.prior[(long)e * B + b];
+    for (int e = 0; e < C::E_PRI; ++e) pri[e] = wld<R>(w, e * rb, bo);
+  }
 #pragma unroll
   for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[(long)k * B + b] : c.zg[k];
 
   for (int t = 0; t < T; ++t) {
     R nxt[C::E_PRI], zn[NZ];
     const int tn = t + 1 < T ? t + 1 : t;
+    {
+      const Window w = make_window(a.prior + (unsigned long)tn * C::E_POST * B, (unsigned long)C::E_POST * rb);
 #pragma unroll
-    for (int e = 0; e < C::E_PRI; ++e) nxt[e] = a.prior[((long)tn * C::E_POST + e) * B + b];
+      for (int e = 0; e < C::E_PRI; ++e) nxt[e] = wld<R>(w, e * rb, bo);
+    }
 #pragma unroll
     for (int k = 0; k < NZ; ++k) zn[k] = c.z_per_cell ? a.z[((long)tn * NZ + k) * B + b] : c.zg[k];
 
@@ -396,10 +405,11 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       joint_from_gain<NX, NU>(mu_x, sig_x, Kt, pmu, pmu + NX, sig_u, mu0, S0);
     }
     if (a.prior_out) {
+      const Window w = make_window(a.prior_out + (unsigned long)t * (D + sym(D)) * B, (unsigned long)(D + sym(D)) * rb);
 #pragma unroll
-      for (int e = 0; e < D; ++e) a.prior_out[((long)t * (D + sym(D)) + e) * B + b] = mu0[e];
+      for (int e = 0; e < D; ++e) wst(w, e * rb, bo, mu0[e]);
 #pragma unroll
-      for (int e = 0; e < sym(D); ++e) a.prior_out[((long)t * (D + sym(D)) + D + e) * B + b] = S0[e];
+      for (int e = 0; e < sym(D); ++e) wst(w, (D + e) * rb, bo, S0[e]);
     }
 
     // ---- 2. cost "observation": measurement update on z (i2c.py:390-407) --------------
@@ -415,11 +425,11 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       if (!kalman_update<D, NZ>(mu0, S0, mz, Sz, Sxz, zt)) set_status(a.status, b, 3, t);
     }
     // mu0 / S0 now hold mu_xu1_f / sig_xu1_f
-    R* out = a.fwd + ((long)t * C::E_FWD) * B + b;
+    const Window out = make_window(a.fwd + (unsigned long)t * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
-    for (int e = 0; e < D; ++e) out[(long)e * B] = mu0[e];
+    for (int e = 0; e < D; ++e) wst(out, e * rb, bo, mu0[e]);
 #pragma unroll
-    for (int e = 0; e < sym(D); ++e) out[(long)(D + e) * B] = S0[e];
+    for (int e = 0; e < sym(D); ++e) wst(out, (D + e) * rb, bo, S0[e]);
 
     // ---- 3. dynamics push-through (i2c.py:415-421) and smoother gain (i2c.py:423-425) --
     R Sxy[D * NX];
@@ -452,11 +462,11 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       if (!kalman_update<NX, NT>(mu_x, sig_x, mzt, Szt, Sxzt, c.zg_term)) set_status(a.status, b, 6, t);
     }
 #pragma unroll
-    for (int e = 0; e < NX; ++e) out[(long)(D + sym(D) + e) * B] = mu_x[e];
+    for (int e = 0; e < NX; ++e) wst(out, (D + sym(D) + e) * rb, bo, mu_x[e]);
 #pragma unroll
-    for (int e = 0; e < sym(NX); ++e) out[(long)(D + sym(D) + NX + e) * B] = sig_x[e];
+    for (int e = 0; e < sym(NX); ++e) wst(out, (D + sym(D) + NX + e) * rb, bo, sig_x[e]);
 #pragma unroll
-    for (int e = 0; e < D * NX; ++e) out[(long)(D + sym(D) + NX + sym(NX) + e) * B] = Sxy[e];
+    for (int e = 0; e < D * NX; ++e) wst(out, (D + sym(D) + NX + sym(NX) + e) * rb, bo, Sxy[e]);
 
 #pragma unroll
     for (int e = 0; e < C::E_PRI; ++e) pri[e] = nxt[e];
@@ -466,62 +476,22 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 }
 
 // ------------------------------------------------------------------------------------------
-// Backward pass, part 1: the x-marginal recursion (i2c.py:544-583 restricted to the xx block).
-//   mu_x0_m = mu_x1_f + Jx (mu_x3_m - mu_x3_f);  sig_x0_m = sig_x1_f + Jx (sig_x3_m - sig_x3_f) Jx^T
-// It is affine in (mu_x3_m, sig_x3_m), touches only nx x nx blocks, and is the ONLY sequential
-// part of the backward pass; everything else is independent per cell (part 2).
+// Backward pass building blocks (i2c.py:544-610), all on registers of one lane.
 // ------------------------------------------------------------------------------------------
-template <typename R> struct ScanArgs {
-  const R* fwd;  // [T][E_FWD][B]
-  R* xm;         // [T][E_XM][B]
-  R* temp;       // [B] or null
-  int32_t* status;
-};
 
-template <int NX, typename R> struct ScanRow {  // the rows of one cell the recursion needs
-  R mu1[NX], S1[sym(NX)], m3f[NX], S3f[sym(NX)], Jx[NX * NX];
-};
-
+// End of chain (i2c.py:546-564): the smoothed terminal state, either the filtered one or, for
+// covariance control, its product with the tempered terminal prior (i2c.py:548-559).
 template <class M, typename R>
-I2C_HD inline void backward_scan_body(const Consts<M, R>& c, const ScanArgs<R>& a, const int b) {
-  using C = Consts<M, R>;
-  constexpr int NX = C::NX, D = C::D;
-  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
-  // The recursion itself is ~40 FMAs per cell; what bounds this kernel is load latency with only
-  // B/64 wavefronts in flight. Cells are therefore fetched U at a time, one chunk ahead.
-  constexpr int U = NX <= 2 ? 4 : 1;
-  const long B = c.B;
-  const int T = c.T;
-  using Row = ScanRow<NX, R>;
-
-  auto load = [&](int t, Row& r) {
-    const R* in = a.fwd + ((long)(t > 0 ? t : 0) * C::E_FWD) * B + b;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) r.mu1[i] = in[(long)i * B];
-#pragma unroll
-    for (int i = 0; i < sym(NX); ++i) r.S1[i] = in[(long)(D + i) * B];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) r.m3f[i] = in[(long)(O_MU3 + i) * B];
-#pragma unroll
-    for (int i = 0; i < sym(NX); ++i) r.S3f[i] = in[(long)(O_S3 + i) * B];
-#pragma unroll
-    for (int i = 0; i < NX * NX; ++i) r.Jx[i] = in[(long)(O_J + i) * B];
-  };
-  Row cur[U], nxt[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) load(T - 1 - u, cur[u]);
-
-  R m3m[NX], S3m[sym(NX)];
-  // end of chain (i2c.py:546-564)
-  if (c.has_x_terminal) {  // covariance control with a tempered terminal prior (i2c.py:548-559)
-    const R* m3f = cur[0].m3f;
-    const R* S3f = cur[0].S3f;
-    const R temp = a.temp[b];
-    a.temp[b] = temp + c.dtemp;
+I2C_FN void end_of_chain(const Consts<M, R>& c, R* temp, const int b, const R* m3f, const R* S3f, R* m3m, R* S3m,
+                         int32_t* status) {
+  constexpr int NX = M::NX;
+  if (c.has_x_terminal) {
+    const R tmp = temp[b];
+    temp[b] = tmp + c.dtemp;
     R St[sym(NX)], Ssum[sym(NX)], rinv[NX];
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) {
-      St[i] = temp * S3f[i];
+      St[i] = tmp * S3f[i];
       Ssum[i] = c.sig_x_term[i] + St[i];
     }
     bool ok = chol<NX>(Ssum, rinv);
@@ -565,45 +535,12 @@ I2C_HD inline void backward_scan_body(const Consts<M, R>& c, const ScanArgs<R>& 
 #pragma unroll
     for (int i = 0; i < NX; ++i) r1[i] += r2[i];
     symv<NX>(S3m, r1, m3m);
-    if (!ok) set_status(a.status, b, 6, T - 1);
+    if (!ok) set_status(status, b, 6, c.T - 1);
   } else {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) m3m[i] = cur[0].m3f[i];
+    for (int i = 0; i < NX; ++i) m3m[i] = m3f[i];
 #pragma unroll
-    for (int i = 0; i < sym(NX); ++i) S3m[i] = cur[0].S3f[i];
-  }
-
-  for (int t0 = T - 1; t0 >= 0; t0 -= U) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) load(t0 - U - u, nxt[u]);  // next chunk (clamped at cell 0)
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int t = t0 - u;
-      if (t < 0) break;
-      const Row& r = cur[u];
-      R* out = a.xm + ((long)t * C::E_XM) * B + b;
-#pragma unroll
-      for (int i = 0; i < NX; ++i) out[(long)i * B] = m3m[i];
-#pragma unroll
-      for (int i = 0; i < sym(NX); ++i) out[(long)(NX + i) * B] = S3m[i];
-      R dm[NX], dS[sym(NX)];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) dm[i] = m3m[i] - r.m3f[i];
-#pragma unroll
-      for (int i = 0; i < sym(NX); ++i) dS[i] = S3m[i] - r.S3f[i];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) {
-        R v = r.mu1[i];
-#pragma unroll
-        for (int k = 0; k < NX; ++k) v += r.Jx[i * NX + k] * dm[k];
-        m3m[i] = v;
-      }
-#pragma unroll
-      for (int i = 0; i < sym(NX); ++i) S3m[i] = r.S1[i];
-      add_JDJt<NX, NX>(r.Jx, dS, S3m);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    for (int i = 0; i < sym(NX); ++i) S3m[i] = S3f[i];
   }
 }
 
@@ -640,26 +577,211 @@ template <int N, typename R> I2C_FN void gaussian_cost(const R* W, const R* mz, 
   *v = R(2) * tr2 + R(4) * quad;
 }
 
+// Terminal observation statistics (i2c.py:567-570, 989-992): tr(Qf (errT errT^T + sig_z3_m)).
+template <class M, typename R>
+I2C_FN R terminal_obs_stats(const Consts<M, R>& c, const int b, const R* m3m, const R* S3m, R* term_stats,
+                            int32_t* status) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NZT = C::NZT;
+  const long B = c.B;
+  R trT = R(0);
+  if (NZT > 0 && c.has_Qf) {
+    constexpr int NT = C::NZT1;
+    R L3[sym(NX)], rinv3[NX], mzt[NT], Szt[sym(NT)];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) L3[i] = S3m[i];
+    if (!chol<NX>(L3, rinv3)) set_status(status, b, 6, c.T - 1);
+    sp_transform<M, TermStruct<M>, NX, NT, false>(c.rule_x, m3m, S3m, L3, ObserveTermF<M, R>{c.params}, mzt, Szt,
+                                                  (R*)nullptr);
+    R tv;
+    gaussian_cost<NT>(c.Qf, mzt, Szt, c.zg_term, &trT, &tv);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) term_stats[(long)(3 + k) * B + b] = mzt[k];
+#pragma unroll
+    for (int k = 0; k < sym(NT); ++k) term_stats[(long)(3 + NT + k) * B + b] = Szt[k];
+  }
+  term_stats[b] = trT;
+  return trT;
+}
+
+// One backward cell given the smoothed next state: RTS update of the joint (i2c.py:580-583),
+// posterior observation statistics (i2c.py:594-596) with their expected cost (i2c.py:1034-1043),
+// and the controller (i2c.py:600-608) read off the Cholesky factor L of the posterior joint:
+//   K L_xx = L_ux  ->  K^T = L_xx^{-T} L_ux^T ;  sigK = L_uu L_uu^T ;  k = mu_u - K mu_x.
+// In: mu/S = mu_xu1_f / sig_xu1_f, J, dm = mu_x3_m - mu_x3_f, dS = sig_x3_m - sig_x3_f.
+// Out: mu/S = mu_xu0_m / sig_xu0_m, ctl = [K | k | sigK], mz/Sz, cost mean / variance.
+template <class M, typename R>
+I2C_FN bool cell_posterior(const Consts<M, R>& c, const R* zt, R* mu, R* S, const R* J, const R* dm, const R* dS,
+                           R* ctl, R* mz, R* Sz, R* cm, R* cv) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, D = C::D;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    R v = mu[i];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) v += J[i * NX + k] * dm[k];
+    mu[i] = v;
+  }
+  add_JDJt<D, NX>(J, dS, S);
+  R Lm[sym(D)], rinv[D];
+#pragma unroll
+  for (int e = 0; e < sym(D); ++e) Lm[e] = S[e];
+  const bool ok = chol<D>(Lm, rinv);
+  sp_transform<M, ObsStruct<M>, D, NZ, false>(c.rule_xu, mu, S, Lm, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
+  gaussian_cost<NZ>(c.QR, mz, Sz, zt, cm, cv);
+#pragma unroll
+  for (int p = 0; p < NU; ++p) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) ctl[p * NX + k] = Lm[tri(NX + p, k)];
+    bsub<NX>(Lm, rinv, &ctl[p * NX]);  // leading NX x NX block of L is chol(sig_xx)
+  }
+#pragma unroll
+  for (int p = 0; p < NU; ++p) {
+    R v = mu[NX + p];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) v -= ctl[p * NX + k] * mu[k];
+    ctl[NU * NX + p] = v;
+  }
+#pragma unroll
+  for (int p = 0; p < NU; ++p)
+#pragma unroll
+    for (int q = 0; q <= p; ++q) {
+      R v = R(0);
+#pragma unroll
+      for (int k = 0; k <= q; ++k) v += Lm[tri(NX + p, NX + k)] * Lm[tri(NX + q, NX + k)];
+      ctl[NU * NX + NU + tri(p, q)] = v;
+    }
+  return ok;
+}
+
 // ------------------------------------------------------------------------------------------
-// Backward pass, part 2: independent per cell (t, b): RTS update of the joint, posterior
-// observation statistics, controller, and the M-step / cost statistics (i2c.py:578-608,
-// 680-683, 1034-1043). One lane per (t, b).
+// Backward sweep, TWO-PASS form (small batches): (1) a light sequential scan of the x-marginal
+// recursion
+//   mu_x0_m = mu_x1_f + Jx (mu_x3_m - mu_x3_f);  sig_x0_m = sig_x1_f + Jx (sig_x3_m - sig_x3_f) Jx^T,
+// which is affine in (mu_x3_m, sig_x3_m), touches only nx x nx blocks and is the ONLY sequential
+// part of the backward pass; (2) everything else, independent per cell, one lane per (t, b);
+// (3) a deterministic reduction of the per-cell cost statistics over t.
 // ------------------------------------------------------------------------------------------
+template <typename R> struct ScanArgs {
+  const R* fwd;  // [T][E_FWD][B]
+  R* xm;         // [T][E_XM][B]
+  R* temp;       // [B] or null
+  int32_t* status;
+};
+
+template <int NX, typename R> struct ScanRow {  // the rows of one cell the recursion needs
+  R mu1[NX], S1[sym(NX)], m3f[NX], S3f[sym(NX)], Jx[NX * NX];
+};
+
+template <class M, typename R>
+I2C_HD inline void backward_scan_body(const Consts<M, R>& c, const ScanArgs<R>& a, const int b) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, D = C::D;
+  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  // The recursion itself is ~40 FMAs per cell; what bounds this kernel is load latency with only
+  // B/64 wavefronts in flight. Cells are therefore fetched U at a time, one chunk ahead.
+  constexpr int U = NX <= 2 ? 4 : 1;
+  const long B = c.B;
+  const int T = c.T;
+  using Row = ScanRow<NX, R>;
+
+  auto load = [&](int t, Row& r) {
+    const R* in = a.fwd + ((long)(t > 0 ? t : 0) * C::E_FWD) * B + b;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) r.mu1[i] = in[(long)i * B];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) r.S1[i] = in[(long)(D + i) * B];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) r.m3f[i] = in[(long)(O_MU3 + i) * B];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) r.S3f[i] = in[(long)(O_S3 + i) * B];
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) r.Jx[i] = in[(long)(O_J + i) * B];
+  };
+  Row cur[U], nxt[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) load(T - 1 - u, cur[u]);
+
+  R m3m[NX], S3m[sym(NX)];
+  end_of_chain<M, R>(c, a.temp, b, cur[0].m3f, cur[0].S3f, m3m, S3m, a.status);
+
+  for (int t0 = T - 1; t0 >= 0; t0 -= U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) load(t0 - U - u, nxt[u]);  // next chunk (clamped at cell 0)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 - u;
+      if (t < 0) break;
+      const Row& r = cur[u];
+      R* out = a.xm + ((long)t * C::E_XM) * B + b;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) out[(long)i * B] = m3m[i];
+#pragma unroll
+      for (int i = 0; i < sym(NX); ++i) out[(long)(NX + i) * B] = S3m[i];
+      R dm[NX], dS[sym(NX)];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dm[i] = m3m[i] - r.m3f[i];
+#pragma unroll
+      for (int i = 0; i < sym(NX); ++i) dS[i] = S3m[i] - r.S3f[i];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        R v = r.mu1[i];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) v += r.Jx[i * NX + k] * dm[k];
+        m3m[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < sym(NX); ++i) S3m[i] = r.S1[i];
+      add_JDJt<NX, NX>(r.Jx, dS, S3m);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+  }
+}
+
 template <typename R> struct CellArgs {
   const R* fwd;      // [T][E_FWD][B]
-  const R* xm;       // [T][E_XM][B]
+  const R* xm;       // [T][E_XM][B]   (two-pass: input; fused: optional output)
   const R* z;        // [T][NZ][B] or null
   R* post;           // [T][E_POST][B]
   R* zpost;          // [T][E_ZPOST][B] or null
-  R* cell_stats;     // [T][2][B]
+  R* cell_stats;     // [T][2][B]      (two-pass: required workspace; fused: optional output)
   R* term_stats;     // [E_TERM][B]
+  R* temp;           // [B] or null (fused only)
   int32_t* status;
 };
 
 template <class M, typename R>
+I2C_FN void store_cell(const Consts<M, R>& c, const CellArgs<R>& a, const int t, const int b, const R* mu, const R* S,
+                       const R* ctl, const R* mz, const R* Sz, const R cm, const R cv) {
+  using C = Consts<M, R>;
+  constexpr int NZ = C::NZ, D = C::D;
+  const long B = c.B;
+  R* out = a.post + ((long)t * C::E_POST) * B + b;
+#pragma unroll
+  for (int e = 0; e < D; ++e) out[(long)e * B] = mu[e];
+#pragma unroll
+  for (int e = 0; e < sym(D); ++e) out[(long)(D + e) * B] = S[e];
+#pragma unroll
+  for (int e = 0; e < C::E_POST - D - sym(D); ++e) out[(long)(D + sym(D) + e) * B] = ctl[e];
+  if (a.zpost) {
+    R* zo = a.zpost + ((long)t * C::E_ZPOST) * B + b;
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) zo[(long)k * B] = mz[k];
+#pragma unroll
+    for (int k = 0; k < sym(NZ); ++k) zo[(long)(NZ + k) * B] = Sz[k];
+  }
+  if (a.cell_stats) {
+    a.cell_stats[((long)t * 2 + 0) * B + b] = cm;
+    a.cell_stats[((long)t * 2 + 1) * B + b] = cv;
+  }
+}
+
+// pass (2): one lane per (t, b)
+template <class M, typename R>
 I2C_HD inline void backward_cell_body(const Consts<M, R>& c, const CellArgs<R>& a, const int t, const int b) {
   using C = Consts<M, R>;
-  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D;
+  constexpr int NX = C::NX, NZ = C::NZ, D = C::D;
   constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
   const long B = c.B;
   const R* in = a.fwd + ((long)t * C::E_FWD) * B + b;
@@ -682,100 +804,102 @@ I2C_HD inline void backward_cell_body(const Consts<M, R>& c, const CellArgs<R>& 
   }
 #pragma unroll
   for (int e = 0; e < D * NX; ++e) J[e] = in[(long)(O_J + e) * B];
-
-  // RTS update of the joint (i2c.py:580-583)
-#pragma unroll
-  for (int i = 0; i < D; ++i) {
-    R v = mu[i];
-#pragma unroll
-    for (int k = 0; k < NX; ++k) v += J[i * NX + k] * dm[k];
-    mu[i] = v;
-  }
-  add_JDJt<D, NX>(J, dS, S);
-
-  R* out = a.post + ((long)t * C::E_POST) * B + b;
-#pragma unroll
-  for (int e = 0; e < D; ++e) out[(long)e * B] = mu[e];
-#pragma unroll
-  for (int e = 0; e < sym(D); ++e) out[(long)(D + e) * B] = S[e];
-
-  // posterior observation moments (i2c.py:594-596) from chol(sig_xu0_m)
-  R Lm[sym(D)], rinv[D];
-#pragma unroll
-  for (int e = 0; e < sym(D); ++e) Lm[e] = S[e];
-  if (!chol<D>(Lm, rinv)) set_status(a.status, b, 7, t);
-  R zt[NZ], mz[NZ], Sz[sym(NZ)];
+  R zt[NZ];
 #pragma unroll
   for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
-  sp_transform<M, ObsStruct<M>, D, NZ, false>(c.rule_xu, mu, S, Lm, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
-  if (a.zpost) {
-    R* zo = a.zpost + ((long)t * C::E_ZPOST) * B + b;
-#pragma unroll
-    for (int k = 0; k < NZ; ++k) zo[(long)k * B] = mz[k];
-#pragma unroll
-    for (int k = 0; k < sym(NZ); ++k) zo[(long)(NZ + k) * B] = Sz[k];
-  }
-  R cm, cv;
-  gaussian_cost<NZ>(c.QR, mz, Sz, zt, &cm, &cv);
-  a.cell_stats[((long)t * 2 + 0) * B + b] = cm;
-  a.cell_stats[((long)t * 2 + 1) * B + b] = cv;
 
-  // controller p(u | x) from the Cholesky factor L of the posterior joint (i2c.py:600-608):
-  //   K L_xx = L_ux  ->  K^T = L_xx^{-T} L_ux^T ;  sigK = L_uu L_uu^T ;  k = mu_u - K mu_x
-  R Kc[NU * NX];
-#pragma unroll
-  for (int p = 0; p < NU; ++p) {
-#pragma unroll
-    for (int k = 0; k < NX; ++k) Kc[p * NX + k] = Lm[tri(NX + p, k)];
-    bsub<NX>(Lm, rinv, &Kc[p * NX]);  // leading NX x NX block of L is chol(sig_xx)
-  }
-#pragma unroll
-  for (int e = 0; e < NU * NX; ++e) out[(long)(D + sym(D) + e) * B] = Kc[e];
-#pragma unroll
-  for (int p = 0; p < NU; ++p) {
-    R v = mu[NX + p];
-#pragma unroll
-    for (int k = 0; k < NX; ++k) v -= Kc[p * NX + k] * mu[k];
-    out[(long)(C::E_PRI + p) * B] = v;
-  }
-#pragma unroll
-  for (int p = 0; p < NU; ++p)
-#pragma unroll
-    for (int q = 0; q <= p; ++q) {
-      R v = R(0);
-#pragma unroll
-      for (int k = 0; k <= q; ++k) v += Lm[tri(NX + p, NX + k)] * Lm[tri(NX + q, NX + k)];
-      out[(long)(C::E_PRI + NU + tri(p, q)) * B] = v;
-    }
+  R ctl[C::E_POST - D - sym(D)], mz[NZ], Sz[sym(NZ)], cm, cv;
+  if (!cell_posterior<M, R>(c, zt, mu, S, J, dm, dS, ctl, mz, Sz, &cm, &cv)) set_status(a.status, b, 7, t);
+  store_cell<M, R>(c, a, t, b, mu, S, ctl, mz, Sz, cm, cv);
+  if (t == c.T - 1) terminal_obs_stats<M, R>(c, b, m3m, S3m, a.term_stats, a.status);
+}
 
-  // terminal observation statistics on the last cell (i2c.py:567-570, 989-992)
-  if (t == c.T - 1) {
-    R trT = R(0);
-    if (NZT > 0 && c.has_Qf) {
-      constexpr int NT = C::NZT1;
-      R L3[sym(NX)], rinv3[NX], mzt[NT], Szt[sym(NT)];
-#pragma unroll
-      for (int i = 0; i < sym(NX); ++i) L3[i] = S3m[i];
-      if (!chol<NX>(L3, rinv3)) set_status(a.status, b, 6, t);
-      sp_transform<M, TermStruct<M>, NX, NT, false>(c.rule_x, m3m, S3m, L3, ObserveTermF<M, R>{c.params}, mzt, Szt, (R*)nullptr);
-      R tv;
-      gaussian_cost<NT>(c.Qf, mzt, Szt, c.zg_term, &trT, &tv);
-#pragma unroll
-      for (int k = 0; k < NT; ++k) a.term_stats[(long)(3 + k) * B + b] = mzt[k];
-#pragma unroll
-      for (int k = 0; k < sym(NT); ++k) a.term_stats[(long)(3 + NT + k) * B + b] = Szt[k];
-    }
-    a.term_stats[b] = trT;
-    a.term_stats[B + b] = R(0);
-    a.term_stats[2 * B + b] = R(0);
+// pass (3): term_stats rows 1, 2 = sum_t m_t, sum_t v_t. `part`/`nparts` split t between the
+// cooperating lanes of one trajectory; the caller adds the partial sums in a fixed order.
+template <class M, typename R>
+I2C_FN void reduce_partial(const Consts<M, R>& c, const R* cell_stats, const int b, const int part, const int nparts,
+                           R* m, R* v) {
+  const long B = c.B;
+  R sm = R(0), sv = R(0);
+#pragma unroll 4
+  for (int t = part; t < c.T; t += nparts) {
+    sm += cell_stats[((long)t * 2 + 0) * B + b];
+    sv += cell_stats[((long)t * 2 + 1) * B + b];
   }
+  *m = sm;
+  *v = sv;
 }
 
 // ------------------------------------------------------------------------------------------
-// M-step on the temperature (i2c.py:913-963, 1045-1053). One lane per trajectory.
+// Backward sweep, FUSED form (large batches): one lane walks one trajectory from T-1 to 0 doing
+// the whole cell; each forward row is read once and the cost sums stay in registers, so the pass
+// moves E_FWD + E_POST elements per cell instead of the two-pass form's ~2x that.
+// ------------------------------------------------------------------------------------------
+template <class M, typename R>
+I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R>& a, const int b) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NZ = C::NZ, D = C::D;
+  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  constexpr unsigned W = sizeof(R);
+  const unsigned long B = c.B;
+  const int T = c.T;
+  const unsigned bo = (unsigned)b * W, rb = (unsigned)(B * W);
+
+  R row[C::E_FWD], nxt[C::E_FWD];
+  {
+    const Window w = make_window(a.fwd + (unsigned long)(T - 1) * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
+#pragma unroll
+    for (int e = 0; e < C::E_FWD; ++e) row[e] = wld<R>(w, e * rb, bo);
+  }
+  R m3m[NX], S3m[sym(NX)];
+  end_of_chain<M, R>(c, a.temp, b, row + O_MU3, row + O_S3, m3m, S3m, a.status);
+  terminal_obs_stats<M, R>(c, b, m3m, S3m, a.term_stats, a.status);
+
+  R sum_m = R(0), sum_v = R(0);
+  for (int t = T - 1; t >= 0; --t) {
+    {
+      const int tp = t > 0 ? t - 1 : 0;
+      const Window w = make_window(a.fwd + (unsigned long)tp * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
+#pragma unroll
+      for (int e = 0; e < C::E_FWD; ++e) nxt[e] = wld<R>(w, e * rb, bo);
+    }
+    if (a.xm) {
+      R* xo = const_cast<R*>(a.xm) + ((long)t * C::E_XM) * B + b;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xo[(long)i * B] = m3m[i];
+#pragma unroll
+      for (int i = 0; i < sym(NX); ++i) xo[(long)(NX + i) * B] = S3m[i];
+    }
+    R dm[NX], dS[sym(NX)], zt[NZ];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dm[i] = m3m[i] - row[O_MU3 + i];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) dS[i] = S3m[i] - row[O_S3 + i];
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
+    R* mu = row;
+    R* S = row + D;
+    R ctl[C::E_POST - D - sym(D)], mz[NZ], Sz[sym(NZ)], cm, cv;
+    if (!cell_posterior<M, R>(c, zt, mu, S, row + O_J, dm, dS, ctl, mz, Sz, &cm, &cv)) set_status(a.status, b, 7, t);
+    store_cell<M, R>(c, a, t, b, mu, S, ctl, mz, Sz, cm, cv);
+    sum_m += cm;
+    sum_v += cv;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) m3m[i] = mu[i];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) S3m[i] = S[i];  // xx block = packed prefix
+#pragma unroll
+    for (int e = 0; e < C::E_FWD; ++e) row[e] = nxt[e];
+  }
+  a.term_stats[B + b] = sum_m;
+  a.term_stats[2 * B + b] = sum_v;
+}
+
+// ------------------------------------------------------------------------------------------
+// M-step on the temperature (i2c.py:913-963, 1045-1053). One lane per trajectory, O(1) work:
+// the sums over t were produced by the backward sweep (term_stats rows 1, 2).
 // ------------------------------------------------------------------------------------------
 template <typename R> struct MstepArgs {
-  const R* cell_stats;  // [T][2][B]
   const R* term_stats;  // [E_TERM][B]
   R* alpha;             // [B]
   R* stats_out;         // [4][B]
@@ -786,12 +910,7 @@ template <class M, typename R>
 I2C_HD inline void mstep_body(const Consts<M, R>& c, const MstepArgs<R>& a, const int b) {
   using C = Consts<M, R>;
   const long B = c.B;
-  R m = R(0), v = R(0);
-#pragma unroll 8
-  for (int t = 0; t < c.T; ++t) {
-    m += a.cell_stats[((long)t * 2 + 0) * B + b];
-    v += a.cell_stats[((long)t * 2 + 1) * B + b];
-  }
+  const R m = a.term_stats[B + b], v = a.term_stats[2 * B + b];
   R tr = m, sf = R(C::NZ) * R(c.T);
   if (C::NZT > 0 && c.has_Qf) {
     tr += a.term_stats[b];
@@ -822,7 +941,7 @@ I2C_HD inline void mstep_body(const Consts<M, R>& c, const MstepArgs<R>& a, cons
 template <typename R> struct PropArgs {
   const R* post;   // [T][E_POST][B]
   R* prop;         // [T][E_PROP][B]
-  R* cell_stats;   // [T][2][B]
+  R* prop_stats;   // [2][B]: sum_t of the propagated cost mean / variance
   const R* x0;
   const R* sig_x0;
   const R* z;
@@ -844,6 +963,7 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
   R pri[C::E_PRI];
 #pragma unroll
   for (int e = 0; e < C::E_PRI; ++e) pri[e] = a.post[(long)e * B + b];
+  R sum_m = R(0), sum_v = R(0);
 
   for (int t = 0; t < T; ++t) {
     R nxt[C::E_PRI];
@@ -903,8 +1023,8 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
     sp_transform<M, ObsStruct<M>, D, NZ, false>(c.rule_xu, mu0, S0, L0, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
     R cm, cv;
     gaussian_cost<NZ>(c.QR, mz, Sz, zt, &cm, &cv);
-    a.cell_stats[((long)t * 2 + 0) * B + b] = cm;
-    a.cell_stats[((long)t * 2 + 1) * B + b] = cv;
+    sum_m += cm;
+    sum_v += cv;
 
     sp_transform<M, DenseStruct<D>, D, NX, false>(c.rule_xu, mu0, S0, L0, DynamicsF<M, R>{c.params}, mu_x, sig_x, (R*)nullptr);
 #pragma unroll
@@ -916,6 +1036,8 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
 #pragma unroll
     for (int e = 0; e < C::E_PRI; ++e) pri[e] = nxt[e];
   }
+  a.prop_stats[b] = sum_m;
+  a.prop_stats[B + b] = sum_v;
 }
 
 }  // namespace i2c

@@ -96,6 +96,68 @@ I2C_FN void r_sincos(double x, double* s, double* c) {
   *s = (q & 2) ? -ss : ss;
   *c = ((q + 1) & 2) ? -cc : cc;
 }
+// sincos for the small sigma-point offsets d = sf L[i][j]: no range reduction while |x| <= pi/4.
+I2C_FN void r_sincos_small(double x, double* s, double* c) {
+  if (!(m_fabs(x) <= 0.78539816339744830962)) {
+    r_sincos(x, s, c);
+    return;
+  }
+  const double z = x * x;
+  double ps = m_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = m_fma(z, ps, 2.75573137070700676789e-06);
+  ps = m_fma(z, ps, -1.98412698298579493134e-04);
+  ps = m_fma(z, ps, 8.33333333332248946124e-03);
+  *s = m_fma(z * x, m_fma(z, ps, -1.66666666666666324348e-01), x);
+  double pc = m_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = m_fma(z, pc, -2.75573143513906633035e-07);
+  pc = m_fma(z, pc, 2.48015872894767294178e-05);
+  pc = m_fma(z, pc, -1.38888888888741095749e-03);
+  pc = m_fma(z, pc, 4.16666666666666019037e-02);
+  *c = 1.0 - m_fma(0.5, z, -(z * z) * pc);
+}
+I2C_FN void r_sincos_small(float x, float* s, float* c) { r_sincos(x, s, c); }
+
+// Global memory access for the [row][B] buffers: a wave-uniform window (buffer resource in SGPRs)
+// + a wave-uniform row byte offset (SGPR soffset) + the lane's byte offset (one VGPR, computed
+// once per kernel). No per-element 64-bit VALU address arithmetic; rows advance by scalar adds.
+#ifdef I2C_HOST_SIM
+struct Window {
+  char* p;
+};
+I2C_FN Window make_window(const void* base, unsigned long) { return Window{(char*)base}; }
+template <typename R> I2C_FN R wld(const Window& w, unsigned row_off, unsigned lane_off) {
+  return *reinterpret_cast<const R*>(w.p + row_off + lane_off);
+}
+template <typename R> I2C_FN void wst(const Window& w, unsigned row_off, unsigned lane_off, R v) {
+  *reinterpret_cast<R*>(w.p + row_off + lane_off) = v;
+}
+#else
+struct Window {
+  __amdgpu_buffer_rsrc_t r;
+};
+// `base` and `bytes` must be wave-uniform. A window addresses at most 4 GiB.
+I2C_FN Window make_window(const void* base, unsigned long bytes) {
+  const unsigned n = bytes > 0xFFFFFFFFul ? 0xFFFFFFFFu : (unsigned)bytes;
+  return Window{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000)};
+}
+template <typename R> I2C_FN R wld(const Window& w, unsigned row_off, unsigned lane_off) {
+  if constexpr (sizeof(R) == 8) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(w.r, lane_off, row_off, 0);
+    return __builtin_bit_cast(R, v);
+  } else {
+    return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b32(w.r, lane_off, row_off, 0));
+  }
+}
+I2C_FN void wst(const Window& w, unsigned row_off, unsigned lane_off, double v) {
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), w.r, lane_off, row_off, 0);
+}
+I2C_FN void wst(const Window& w, unsigned row_off, unsigned lane_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), w.r, lane_off, row_off, 0);
+}
+#endif
+
 template <typename R> I2C_FN R r_clip(R x, R lo, R hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // In-place Cholesky of a packed SPD matrix: a <- L (lower), rinv[j] = 1 / L[j][j].

@@ -53,7 +53,7 @@ class BatchedI2c:
     def __init__(self, model, horizon, Q, R, Qf, alpha, alpha_update_tol, mu_u, sig_u,
                  mu_x_terminal=None, sig_x_terminal=None, quad=(1.0, 0.0, 0.0), x0=None, sig_x0=None,
                  z_traj=None, batch=None, dtype=torch.float64, device=None, lib=None, dtemp=1.0,
-                 keep_zpost=True, keep_prior=False):
+                 keep_zpost=True, keep_prior=False, keep_xm=True, backward_mode="auto"):
         self.lib = lib if lib is not None else _native.load_library()
         if device is None:
             device = "cpu" if self.lib.is_host_sim else "cuda"
@@ -138,15 +138,19 @@ class BatchedI2c:
         post[:, o_k + nu:, :] = pack_sym_np(sig_u)[None, :, None]
         self.post = to(post)
         self.fwd = zeros(T, dims.e_fwd, B)
-        self.xm = zeros(T, dims.e_xm, B)
         self.zpost = zeros(T, dims.e_zpost, B) if keep_zpost else None
         self.prior_out = zeros(T, d + sym_size(d), B) if keep_prior else None
-        self.cell_stats = zeros(T, 2, B)
+        self.backward_mode = {"auto": _native.BWD_AUTO, "two_pass": _native.BWD_TWO_PASS, "fused": _native.BWD_FUSED}[backward_mode]
+        fused = self.backward_mode == _native.BWD_FUSED or (self.backward_mode == _native.BWD_AUTO and B >= 32768)
+        self.fused_backward = fused
+        # the two-pass backward needs xm / cell_stats as workspace; the fused one only writes them on request
+        self.xm = zeros(T, dims.e_xm, B) if (keep_xm or not fused) else None
+        self.cell_stats = None if fused else zeros(T, 2, B)
         self.e_term = 3 + nzt + sym_size(nzt)
         self.term_stats = zeros(self.e_term, B)
         self.stats_out = zeros(4, B)
         self.prop = None
-        self.cell_stats_pf = None
+        self.prop_stats = None
         self.x0 = to(x0.T)
         self.sig_x0 = to(pack_sym_np(sig_x0).T)
         self.alpha = to(np.broadcast_to(np.asarray(alpha, np.float64), (B,)))
@@ -182,6 +186,7 @@ class BatchedI2c:
         p.has_Qf = int(self.has_Qf)
         p.has_x_terminal = int(self.has_x_terminal)
         p.z_per_cell = int(self.z is not None)
+        p.backward_mode = self.backward_mode
         p.quad_alpha, p.quad_beta, p.quad_kappa = self.quad
         p.dtemp = self.dtemp
 
@@ -254,9 +259,9 @@ class BatchedI2c:
         """I2cGraph.propagate (i2c.py:1247-1251)."""
         if self.prop is None:
             self.prop = torch.zeros(self.H, self.dims.e_prop, self.B, dtype=self.dtype, device=self.device)
-            self.cell_stats_pf = torch.zeros(self.H, 2, self.B, dtype=self.dtype, device=self.device)
+            self.prop_stats = torch.zeros(2, self.B, dtype=self.dtype, device=self.device)
         rc = self.lib.i2c_propagate(C.byref(self._problem), self._ptr(self.post), self._ptr(self.prop),
-                                    self._ptr(self.cell_stats_pf), int(self.use_expert_controller),
+                                    self._ptr(self.prop_stats), int(self.use_expert_controller),
                                     self._ptr(self.status), self._stream())
         self._check(rc, "i2c_propagate")
 
@@ -266,27 +271,22 @@ class BatchedI2c:
         if self.tau > 0:
             self.feedforward[: self.tau + 1] = 0
 
-    def _alpha_from_stats(self, cell_stats, with_terminal):
-        m = cell_stats[:, 0, :].sum(dim=0)
-        sf = float(self.nz * self.H)
-        if with_terminal and self.has_Qf:
-            m = m + self.term_stats[0]
-            sf += float(self.nzt)
-        return m / sf
+    def _alpha_from_propagation(self):
+        """calculate_alpha(sum of propagated observation covariances) (i2c.py:901-904, 934-939)."""
+        return self.prop_stats[0] / float(self.nz * self.H)
 
     def maximize(self, update_alpha=True):
         """I2cGraph._maximize (i2c.py:1004-1019): cost, prior update, temperature M-step."""
-        rc = self.lib.i2c_mstep(C.byref(self._problem), self._ptr(self.cell_stats), self._ptr(self.term_stats),
-                                self.alpha_update_tol, int(bool(update_alpha)), self._ptr(self.stats_out),
-                                self._stream())
+        rc = self.lib.i2c_mstep(C.byref(self._problem), self._ptr(self.term_stats), self.alpha_update_tol,
+                                int(bool(update_alpha)), self._ptr(self.stats_out), self._stream())
         self._check(rc, "i2c_mstep")
         out = self.stats_out.clone()
         self.costs_m.append(out[2])
         self.costs_m_var.append(out[3])
         if self._propagate:
-            self.costs_pf.append(self.cell_stats_pf[:, 0, :].sum(dim=0))
-            self.costs_pf_var.append(self.cell_stats_pf[:, 1, :].sum(dim=0))
-            self.alphas_pf.append(self._alpha_from_stats(self.cell_stats_pf, False))
+            self.costs_pf.append(self.prop_stats[0].clone())
+            self.costs_pf_var.append(self.prop_stats[1].clone())
+            self.alphas_pf.append(self._alpha_from_propagation())
         else:
             self.costs_pf.append(torch.full_like(out[2], -1.0))  # i2c.py:1065
         self.update_priors()
@@ -307,7 +307,7 @@ class BatchedI2c:
         """I2cGraph.calibrate_alpha (i2c.py:895-911)."""
         assert self._propagate
         self.propagate()
-        a = self._alpha_from_stats(self.cell_stats_pf, False)
+        a = self._alpha_from_propagation()
         if only_decrease:
             a = torch.where(a < self.alpha, a, self.alpha)
         self.alpha.copy_(a)
@@ -375,6 +375,7 @@ class BatchedI2c:
         )
 
     def smoothed_next_state(self):
+        assert self.xm is not None, "constructed with keep_xm=False"
         return self._rows(self.xm, 0, self.nx), self._sym_rows(self.xm, self.nx, self.nx)
 
     def observed_marginal(self):

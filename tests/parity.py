@@ -79,10 +79,10 @@ def compare_detail(eng, ref_get, it, tol, name, b=0, check_prop=False):
             assert_close(np_(p[key])[b], ref_get(key), tol, f"{name} it{it} {key}")
 
 
-def check_against_golden(name, lib, device, tol_detail=1e-8, tol_summary=1e-7, n_iters=None, dtype=torch.float64):
+def check_against_golden(name, lib, device, tol_detail=1e-8, tol_summary=1e-7, n_iters=None, dtype=torch.float64, **kw):
     """Free-running EM of the engine vs the reference's captured run (B = 1)."""
     g = load_case(name)
-    eng = engine_from_case(g, lib, device, dtype=dtype)
+    eng = engine_from_case(g, lib, device, dtype=dtype, **kw)
     meta = g.meta
     if meta.get("calibrate_first"):
         eng.calibrate_alpha()

@@ -56,4 +56,4 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     lib = pkg.load_library()
     p = pkg._native.I2cProblem()
     assert lib.i2c_forward_sweep(ctypes.byref(p), None, None, None, None, None) == -1  # I2C_EINVAL
-    assert lib.i2c_mstep(ctypes.byref(p), None, None, 0.0, 1, None, None) == -1
+    assert lib.i2c_mstep(ctypes.byref(p), None, 0.0, 1, None, None) == -1

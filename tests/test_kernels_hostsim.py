@@ -32,3 +32,32 @@ def test_hostsim_vs_reference_golden(lib, name, tol_d, tol_s):
 @pytest.mark.parametrize("name,B,iters", [("em_pendulum_T200", 8, 4), ("em_dcp_T60", 4, 3), ("em_covctrl_T100", 4, 4)])
 def test_hostsim_batch_vs_oracle(lib, name, B, iters):
     parity.check_batch_against_oracle(name, lib, "cpu", B, iters, tol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["em_pendulum_T200", "em_covctrl_T100", "em_dcp_T60"])
+def test_hostsim_fused_backward_matches_reference(lib, name):
+    """The fused single-pass backward (large-batch schedule) against the same golden vectors."""
+    parity.check_against_golden(name, lib, "cpu", 1e-7, 1e-6, n_iters=4, backward_mode="fused")
+
+
+def test_hostsim_general_weights_sum_not_one(lib):
+    """CubatureQuadrature with 1 - alpha^2 + beta != 0 (weights do not sum to 1): the correction
+    terms of the centred accumulation against the oracle's literal reference formula."""
+    import numpy as np
+    from golden_util import Case, load_case
+
+    g = load_case("em_pendulum_T40_quad_general")
+    meta = dict(g.meta, quad=[1.0, -0.03, 0.4], T=12)
+    g2 = Case({**g, "meta": np.array(__import__("json").dumps(meta)), "mu_u": g["mu_u"][:12]})
+    x0, mu_u = parity.batched_inputs(g2, 3)
+    eng = parity.engine_from_case(g2, lib, "cpu", x0=x0, mu_u=mu_u)
+    from golden_util import oracle_from_case
+
+    o = oracle_from_case(Case({**g2, "mu_u": mu_u}), x0=x0)
+    for it in range(3):
+        eng.learn_msgs()
+        o.learn_msgs()
+        mu, sig = eng.marginal_state_action()
+        parity.assert_close(parity.np_(mu), o.mu_xu0_m, 1e-9, f"W!=1 it{it} mu")
+        parity.assert_close(parity.np_(sig), o.sig_xu0_m, 1e-9, f"W!=1 it{it} sig")
+        parity.assert_close(parity.np_(eng.alpha), o.alpha, 1e-9, f"W!=1 it{it} alpha")
