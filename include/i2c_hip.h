@@ -79,7 +79,8 @@ enum {
   I2C_FAIL_PRED_COV = 5,      /* chol(sig_x3_f)               (i2c.py:423)                           */
   I2C_FAIL_TERMINAL = 6,      /* terminal observation update  (i2c.py:430-443, 548-570)              */
   I2C_FAIL_POSTERIOR = 7,     /* chol(sig_xu0_m)              (quadrature.py:17-24 via i2c.py:594)   */
-  I2C_FAIL_PROPAGATE = 8      /* closed-loop propagation      (i2c.py:196-197)                       */
+  I2C_FAIL_PROPAGATE = 8,     /* closed-loop propagation      (i2c.py:196-197)                       */
+  I2C_FAIL_FILTER = 9         /* cubature Kalman filter step  (mpc.py:129, 140-142)                  */
 };
 
 typedef struct I2cDims {
@@ -90,6 +91,7 @@ typedef struct I2cDims {
   int32_t e_zpost;         /* elements per cell of the optional z-moment buffer: nz + SYM(nz) */
   int32_t e_prop;          /* elements per cell of the propagation buffer (see I2cProp)     */
   int32_t n_params;        /* number of doubles the model reads from I2cProblem.model_params */
+  int32_t ny;              /* dim_y of sys.measure (state estimator of the MPC loop)         */
 } I2cDims;
 
 /*
@@ -106,7 +108,8 @@ typedef struct I2cProblem {
   int32_t has_x_terminal;  /* covariance control: terminal state prior (i2c.py:548-559)        */
   int32_t z_per_cell;      /* 0: target = zg for every cell; 1: device targets `z` [T][nz][B]  */
   int32_t backward_mode;   /* I2C_BWD_AUTO | I2C_BWD_TWO_PASS | I2C_BWD_FUSED (see i2c_backward_sweep) */
-  int32_t reserved0;
+  int32_t terminal_cell;   /* index of the cell whose FORWARD pass applies the terminal cost update (i2c.py:430-443;
+                              `terminal_cell` flag, i2c.py:82,822); T-1 normally, moves with the MPC shift, -1: none */
   /* CubatureQuadrature(alpha, beta, kappa): i2c/exp_types.py:31-49 */
   double quad_alpha, quad_beta, quad_kappa;
   double dtemp;            /* terminal-prior annealing rate (i2c.py:66,552)                    */
@@ -126,6 +129,9 @@ typedef struct I2cProblem {
   const void* sig_x0;   /* [SYM(nx)][B]   sys.sig_x0   (i2c.py:878)                              */
   const void* z;        /* [T][nz][B] per-cell targets (mpc.py:29-31) or NULL when !z_per_cell   */
   void* alpha;          /* [B] temperature; read by the sweeps, updated in place by i2c_mstep    */
+  const void* alpha_cell; /* optional [T][B]: per-cell temperature used INSTEAD of alpha[b] for sig_xi /
+                             sig_xi_terminal of cell t. NULL normally; the MPC loop needs it because a cell
+                             appended by deepcopy(cell_init) keeps its stale sig_xi (mpc.py:175, i2c.py:976-981) */
   void* temp;           /* [B] terminal-prior temperature (i2c.py:147,552) or NULL               */
   const uint8_t* feedforward; /* [T] bytes: 1 = cell in feed-forward mode
                                  (state_action_independence, i2c.py:132,355,1212-1213)            */
@@ -221,6 +227,19 @@ int i2c_mstep(const I2cProblem* p, const void* term_stats, double alpha_update_t
  */
 int i2c_propagate(const I2cProblem* p, const void* post, void* prop, void* prop_stats,
                   int use_expert_controller, int32_t* status, void* stream);
+
+/*
+ * One cubature-Kalman-filter step of the MPC state estimator: replaces
+ * PartiallyObservedMpcPolicy.filter (i2c/policy/mpc.py:125-145; duplicate in
+ * scripts/mpc_state_est/mpc_quad.py:135-155): predict the belief N(mu, cov) through sys.forward
+ * with the applied action u, then innovate on the measurement y through sys.measure.
+ *   sig_zeta  HOST [SYM(ny)] double: measurement noise sys.sig_zeta
+ *   y [ny][B], u [nu][B]      in
+ *   mu [nx][B], cov [SYM(nx)][B]  in/out
+ * Only p->model_id, dtype, B, quad_*, sig_eta and model_params are read from the problem.
+ */
+int i2c_ckf_filter(const I2cProblem* p, const double* sig_zeta, const void* y, const void* u, void* mu,
+                   void* cov, int32_t* status, void* stream);
 
 #ifdef __cplusplus
 }

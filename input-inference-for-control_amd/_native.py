@@ -39,11 +39,12 @@ FAIL_REASONS = {
     6: "terminal observation / terminal prior update failed",
     7: "posterior joint covariance sig_xu0_m is not positive definite",
     8: "closed-loop propagation covariance is not positive definite",
+    9: "cubature Kalman filter covariance is not positive definite",
 }
 
 
 class I2cDims(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("nx", "nu", "nz", "nzt", "e_post", "e_fwd", "e_xm", "e_zpost", "e_prop", "n_params")]
+    _fields_ = [(n, C.c_int32) for n in ("nx", "nu", "nz", "nzt", "e_post", "e_fwd", "e_xm", "e_zpost", "e_prop", "n_params", "ny")]
 
 
 class I2cProblem(C.Structure):
@@ -57,7 +58,7 @@ class I2cProblem(C.Structure):
         ("has_x_terminal", C.c_int32),
         ("z_per_cell", C.c_int32),
         ("backward_mode", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("terminal_cell", C.c_int32),
         ("quad_alpha", C.c_double),
         ("quad_beta", C.c_double),
         ("quad_kappa", C.c_double),
@@ -76,6 +77,7 @@ class I2cProblem(C.Structure):
         ("sig_x0", C.c_void_p),
         ("z", C.c_void_p),
         ("alpha", C.c_void_p),
+        ("alpha_cell", C.c_void_p),
         ("temp", C.c_void_p),
         ("feedforward", C.c_void_p),
     ]
@@ -91,6 +93,10 @@ _SIGNATURES = {
         [C.POINTER(I2cProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
     "i2c_mstep": (C.c_int, [C.POINTER(I2cProblem), C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
+    "i2c_ckf_filter": (
+        C.c_int,
+        [C.POINTER(I2cProblem), C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
     "i2c_propagate": (C.c_int, [C.POINTER(I2cProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
 }
 

@@ -84,6 +84,14 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void k_propagate(const Consts<M, R> c,
   const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
   if (b < c.B) propagate_body<M, R>(c, a, b);
 }
+template <class M, typename R> struct ZetaArg {
+  R v[sym(M::NY)];
+};
+template <class M, typename R>
+__global__ __launch_bounds__(SWEEP_BLOCK) void k_ckf(const Consts<M, R> c, const ZetaArg<M, R> z, const CkfArgs<R> a) {
+  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
+  if (b < c.B) ckf_filter_body<M, R>(c, z.v, a, b);
+}
 static int launch_status() { return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH; }
 #endif
 
@@ -112,6 +120,7 @@ template <class M, typename R> static Consts<M, R> make_consts(const I2cProblem*
   c.has_x_terminal = p->has_x_terminal;
   c.z_per_cell = p->z_per_cell && p->z != nullptr;
   c.use_expert = use_expert;
+  c.terminal_cell = p->terminal_cell;
   c.rule_xu = make_rule<R>(p, C::D);
   c.rule_x = make_rule<R>(p, C::NX);
   c.dtemp = (R)p->dtemp;
@@ -145,7 +154,7 @@ template <class M, typename R> struct Impl {
                      void* stream) {
     const C c = make_consts<M, R>(p, 0.0, 0);
     FwdArgs<R> a{(const R*)prior, (R*)fwd, (R*)prior_out, (const R*)p->x0, (const R*)p->sig_x0,
-                 (const R*)p->z,  (const R*)p->alpha, p->feedforward, status};
+                 (const R*)p->z,  (const R*)p->alpha, (const R*)p->alpha_cell, p->feedforward, status};
 #ifdef I2C_HOST_SIM
     (void)stream;
     for (int b = 0; b < p->B; ++b) forward_sweep_body<M, R>(c, a, b);
@@ -224,6 +233,25 @@ template <class M, typename R> struct Impl {
 #endif
   }
 
+  static int ckf(const I2cProblem* p, const double* sig_zeta, const void* y, const void* u, void* mu, void* cov,
+                 int32_t* status, void* stream) {
+  const Consts<M, R> c = make_consts<M, R>(p, 0.0, 0);
+  R zeta[sym(M::NY)];
+  for (int i = 0; i < sym(M::NY); ++i) zeta[i] = (R)sig_zeta[i];
+  CkfArgs<R> a{(const R*)y, (const R*)u, (R*)mu, (R*)cov, status};
+#ifdef I2C_HOST_SIM
+  (void)stream;
+  for (int b = 0; b < p->B; ++b) ckf_filter_body<M, R>(c, zeta, a, b);
+  return I2C_OK;
+#else
+  ZetaArg<M, R> z;
+  for (int i = 0; i < sym(M::NY); ++i) z.v[i] = zeta[i];
+  const int grid = (p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+  hipLaunchKernelGGL((k_ckf<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, z, a);
+  return launch_status();
+#endif
+  }
+
   static int propagate(const I2cProblem* p, const void* post, void* prop, void* prop_stats, int use_expert,
                        int32_t* status, void* stream) {
     const C c = make_consts<M, R>(p, 0.0, use_expert);
@@ -253,6 +281,7 @@ template <class M> static void fill_dims(I2cDims* d) {
   d->e_zpost = C::E_ZPOST;
   d->e_prop = C::E_PROP;
   d->n_params = M::NP;
+  d->ny = M::NY;
 }
 
 }  // namespace i2c
@@ -330,6 +359,12 @@ int i2c_propagate(const I2cProblem* p, const void* post, void* prop, void* prop_
                   int32_t* status, void* stream) {
   if (!post || !prop || !prop_stats || !status) return I2C_EINVAL;
   I2C_DISPATCH(p, propagate(p, post, prop, prop_stats, use_expert_controller, status, stream));
+}
+
+int i2c_ckf_filter(const I2cProblem* p, const double* sig_zeta, const void* y, const void* u, void* mu, void* cov,
+                   int32_t* status, void* stream) {
+  if (!sig_zeta || !y || !u || !mu || !cov || !status) return I2C_EINVAL;
+  I2C_DISPATCH(p, ckf(p, sig_zeta, y, u, mu, cov, status, stream));
 }
 
 }  // extern "C"

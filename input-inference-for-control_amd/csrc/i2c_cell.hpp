@@ -37,7 +37,7 @@ template <class M, typename R> struct Consts {
   static constexpr int E_PROP = D + sym(D) + NX + sym(NX);
   static constexpr int E_TERM = 3 + NZT + sym(NZT);
   int B, T;
-  int has_Qf, has_x_terminal, z_per_cell, use_expert;
+  int has_Qf, has_x_terminal, z_per_cell, use_expert, terminal_cell;
   Rule<R> rule_xu, rule_x;
   R dtemp, tol;
   R sig_eta[sym(NX)], sig_xi0[sym(NZ)], QR[sym(NZ)], sig_xiT0[sym(NZT1)], Qf[sym(NZT1)];
@@ -52,6 +52,23 @@ template <class M, typename R> struct ObserveF {
 template <class M, typename R> struct DynamicsF {
   const R* p;
   I2C_HD inline void operator()(const R* x, const R* sn, const R* cs, R* y) const { M::dynamics(p, x, sn, cs, y); }
+};
+template <class M, typename R> struct MeasureF {
+  const R* p;
+  I2C_HD inline void operator()(const R* x, const R* sn, const R* cs, R* y) const { M::measure(p, x, sn, cs, y); }
+};
+// dynamics as a function of the state only, with a known action appended (CKF prediction, mpc.py:129-131)
+template <class M, typename R> struct DynamicsFixedUF {
+  const R* p;
+  const R* u;
+  I2C_HD inline void operator()(const R* x, const R* sn, const R* cs, R* y) const {
+    R xu[M::NX + M::NU];
+#pragma unroll
+    for (int i = 0; i < M::NX; ++i) xu[i] = x[i];
+#pragma unroll
+    for (int i = 0; i < M::NU; ++i) xu[M::NX + i] = u[i];
+    M::dynamics(p, xu, sn, cs, y);
+  }
 };
 template <class M, typename R> struct ObserveTermF {
   const R* p;
@@ -71,6 +88,10 @@ template <class M> struct ObsStruct {
 template <class M> struct TermStruct {
   I2C_HD static constexpr int lin(int k) { return M::term_lin(k); }
   I2C_HD static constexpr int dep(int k) { return M::term_dep(k); }
+};
+template <class M> struct MeasStruct {
+  I2C_HD static constexpr int lin(int k) { return M::meas_lin(k); }
+  I2C_HD static constexpr int dep(int k) { return M::meas_dep(k); }
 };
 template <int DIN> struct DenseStruct {
   I2C_HD static constexpr int lin(int) { return -1; }
@@ -320,6 +341,7 @@ template <typename R> struct FwdArgs {
   const R* sig_x0;  // [sym NX][B]
   const R* z;       // [T][NZ][B] or null
   const R* alpha;   // [B]
+  const R* alpha_cell;  // [T][B] or null
   const uint8_t* ff;  // [T]
   int32_t* status;  // [B]
 };
@@ -333,7 +355,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
   const int T = c.T;
   const unsigned bo = (unsigned)b * W;     // the lane's byte offset inside any row
   const unsigned rb = (unsigned)(B * W);   // bytes per row (wave-uniform)
-  const R alpha = a.alpha[b];
+  const R alpha_traj = a.alpha[b];
 
   R mu_x[NX], sig_x[sym(NX)];
 #pragma unroll
@@ -362,6 +384,8 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 #pragma unroll
     for (int k = 0; k < NZ; ++k) zn[k] = c.z_per_cell ? a.z[((long)tn * NZ + k) * B + b] : c.zg[k];
 
+    // per-cell temperature only in the MPC loop (stale sig_xi of appended cells); else the trajectory's
+    const R alpha = a.alpha_cell ? a.alpha_cell[(long)t * B + b] : alpha_traj;
     const R* pmu = pri;               // prior joint mean  (== previous posterior, see i2c_hip.h)
     const R* psig = pri + D;          // prior joint covariance
     const R* Kprev = pri + D + sym(D);
@@ -453,7 +477,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     }
 
     // ---- 4. terminal cost observation on the last cell, after J (i2c.py:430-443) -------
-    if (NZT > 0 && t == T - 1 && c.has_Qf) {
+    if (NZT > 0 && t == c.terminal_cell && c.has_Qf) {
       constexpr int NT = C::NZT1;
       R mzt[NT], Szt[sym(NT)], Sxzt[NX * NT];
       sp_transform<M, TermStruct<M>, NX, NT, true>(c.rule_x, mu_x, sig_x, L3, ObserveTermF<M, R>{c.params}, mzt, Szt, Sxzt);
@@ -1038,6 +1062,54 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
   }
   a.prop_stats[b] = sum_m;
   a.prop_stats[B + b] = sum_v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Cubature Kalman filter step of the MPC state estimator (PartiallyObservedMpcPolicy.filter,
+// i2c/policy/mpc.py:125-145): predict the belief through the dynamics with the applied action,
+// then innovate on the measurement y. One lane per trajectory.
+// ------------------------------------------------------------------------------------------
+template <typename R> struct CkfArgs {
+  const R* y;       // [NY][B]
+  const R* u;       // [NU][B]
+  R* mu;            // [NX][B]      in/out
+  R* cov;           // [sym NX][B]  in/out
+  int32_t* status;  // [B]
+};
+
+template <class M, typename R>
+I2C_HD inline void ckf_filter_body(const Consts<M, R>& c, const R* sig_zeta, const CkfArgs<R>& a, const int b) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NU = C::NU, NY = M::NY;
+  const long B = c.B;
+  R mu[NX], S[sym(NX)], L[sym(NX)], rinv[NX], u[NU], y[NY];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) mu[i] = a.mu[(long)i * B + b];
+#pragma unroll
+  for (int i = 0; i < sym(NX); ++i) L[i] = S[i] = a.cov[(long)i * B + b];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) u[i] = a.u[(long)i * B + b];
+#pragma unroll
+  for (int i = 0; i < NY; ++i) y[i] = a.y[(long)i * B + b];
+  bool ok = chol<NX>(L, rinv);
+  // prediction (mpc.py:129-137): x-only sigma points, the action is appended unchanged
+  R mf[NX], Sf[sym(NX)];
+  sp_transform<M, DenseStruct<NX>, NX, NX, false>(c.rule_x, mu, S, L, DynamicsFixedUF<M, R>{c.params, u}, mf, Sf,
+                                                  (R*)nullptr);
+#pragma unroll
+  for (int i = 0; i < sym(NX); ++i) L[i] = Sf[i] = Sf[i] + c.rule_x.W * c.sig_eta[i];
+  ok = chol<NX>(L, rinv) && ok;
+  // innovation (mpc.py:139-145): K = sig_xy sig_y^{-1}; mu = mu_f + K (y - mu_y); cov = sig_f - K sig_y K^T
+  R my[NY], Sy[sym(NY)], Sxy[NX * NY];
+  sp_transform<M, MeasStruct<M>, NX, NY, true>(c.rule_x, mf, Sf, L, MeasureF<M, R>{c.params}, my, Sy, Sxy);
+#pragma unroll
+  for (int i = 0; i < sym(NY); ++i) Sy[i] += sig_zeta[i];
+  ok = kalman_update<NX, NY>(mf, Sf, my, Sy, Sxy, y) && ok;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) a.mu[(long)i * B + b] = mf[i];
+#pragma unroll
+  for (int i = 0; i < sym(NX); ++i) a.cov[(long)i * B + b] = Sf[i];
+  if (!ok) set_status(a.status, b, 9, 0);
 }
 
 }  // namespace i2c

@@ -20,6 +20,13 @@ struct Pendulum {
   I2C_HD static constexpr int obs_dep(int) { return 0; }
   I2C_HD static constexpr int term_lin(int k) { return k < 2 ? -1 : 1; }
   I2C_HD static constexpr int term_dep(int) { return 0; }
+  // measurement of the MPC state estimator (build-defined: the reference has no `measure` here)
+  static constexpr int NY = 3;
+  I2C_HD static constexpr int meas_lin(int k) { return k < 2 ? -1 : 1; }
+  I2C_HD static constexpr int meas_dep(int) { return 0; }
+  template <typename R> I2C_FN void measure(const R* p, const R* x, const R* sn, const R* cs, R* y) {
+    observe_terminal(p, x, sn, cs, y);
+  }
   template <typename R> I2C_FN void dynamics(const R*, const R* xu, const R* sn, const R*, R* xn) {
     const R dt = R(0.05), damp = R(1e-2), u_max = R(2.0);
     const R c_grav = R(-3.0 * 9.80665 / (2 * 1.0));  // -3 g / (2 l)
@@ -52,6 +59,12 @@ struct PendulumActReg {
   I2C_HD static constexpr int obs_dep(int) { return 0; }
   I2C_HD static constexpr int term_lin(int) { return 0; }
   I2C_HD static constexpr int term_dep(int) { return 0; }
+  static constexpr int NY = 3;
+  I2C_HD static constexpr int meas_lin(int k) { return k < 2 ? -1 : 1; }
+  I2C_HD static constexpr int meas_dep(int) { return 0; }
+  template <typename R> I2C_FN void measure(const R* p, const R* x, const R* sn, const R* cs, R* y) {
+    Pendulum::observe_terminal(p, x, sn, cs, y);
+  }
   template <typename R> I2C_FN void dynamics(const R* p, const R* xu, const R* sn, const R* cs, R* xn) {
     Pendulum::dynamics(p, xu, sn, cs, xn);
   }
@@ -68,6 +81,12 @@ struct Cartpole {
   I2C_HD static constexpr int obs_dep(int) { return 1; }
   I2C_HD static constexpr int term_lin(int k) { return k == 0 ? 0 : (k < 3 ? -1 : k - 1); }
   I2C_HD static constexpr int term_dep(int) { return 1; }
+  static constexpr int NY = 5;
+  I2C_HD static constexpr int meas_lin(int k) { return term_lin(k); }
+  I2C_HD static constexpr int meas_dep(int) { return 1; }
+  template <typename R> I2C_FN void measure(const R* p, const R* x, const R* sn, const R* cs, R* y) {
+    observe_terminal(p, x, sn, cs, y);
+  }
   template <typename R> I2C_FN void dynamics(const R*, const R* xu, const R* sn, const R* cs, R* xn) {
     const R grav = R(9.81), m_cart = R(0.37), m_pole = R(0.127), len = R(0.3365);
     const R dt = R(1.0 / 250.0), u_max = R(5.0);
@@ -110,6 +129,12 @@ struct DoubleCartpole {
   I2C_HD static constexpr int obs_dep(int k) { return k < 3 ? 1 : 2; }
   I2C_HD static constexpr int term_lin(int k) { return k == 0 ? 0 : (k < 5 ? -1 : k - 2); }
   I2C_HD static constexpr int term_dep(int k) { return k < 3 ? 1 : 2; }
+  static constexpr int NY = 8;
+  I2C_HD static constexpr int meas_lin(int k) { return term_lin(k); }
+  I2C_HD static constexpr int meas_dep(int k) { return term_dep(k); }
+  template <typename R> I2C_FN void measure(const R* p, const R* x, const R* sn, const R* cs, R* y) {
+    observe_terminal(p, x, sn, cs, y);
+  }
   template <typename R> I2C_FN void dynamics(const R*, const R* xu, const R* sn, const R* cs, R* xn) {
     const R dt = R(1.0 / 125.0), grav = R(9.81);
     const R m_c = R(0.37), m1 = R(0.127), m2 = R(0.127);
@@ -177,6 +202,13 @@ struct Linear {
   I2C_HD static constexpr int obs_dep(int) { return 0; }
   I2C_HD static constexpr int term_lin(int k) { return k; }
   I2C_HD static constexpr int term_dep(int) { return 0; }
+  static constexpr int NY = 2;  // y = x
+  I2C_HD static constexpr int meas_lin(int k) { return k; }
+  I2C_HD static constexpr int meas_dep(int) { return 0; }
+  template <typename R> I2C_FN void measure(const R*, const R* x, const R*, const R*, R* y) {
+    y[0] = x[0];
+    y[1] = x[1];
+  }
   template <typename R> I2C_FN void dynamics(const R* p, const R* xu, const R*, const R*, R* xn) {
     xn[0] = xu[0] * p[0] + xu[1] * p[1] + xu[2] * p[4] + p[6];
     xn[1] = xu[0] * p[2] + xu[1] * p[3] + xu[2] * p[5] + p[7];
@@ -200,6 +232,13 @@ struct LinearMinEnergy {
   I2C_HD static constexpr int obs_dep(int) { return 0; }
   I2C_HD static constexpr int term_lin(int k) { return k; }
   I2C_HD static constexpr int term_dep(int) { return 0; }
+  static constexpr int NY = 2;  // y = x
+  I2C_HD static constexpr int meas_lin(int k) { return k; }
+  I2C_HD static constexpr int meas_dep(int) { return 0; }
+  template <typename R> I2C_FN void measure(const R*, const R* x, const R*, const R*, R* y) {
+    y[0] = x[0];
+    y[1] = x[1];
+  }
   template <typename R> I2C_FN void dynamics(const R* p, const R* xu, const R* sn, const R* cs, R* xn) {
     Linear::dynamics(p, xu, sn, cs, xn);
   }
@@ -210,10 +249,13 @@ struct LinearMinEnergy {
   }
 };
 
-// Build-defined analytic planar quadrotor with the reference's interface and dimensions
-// (scripts/mpc_state_est/mpc_quad.py:219-383: dim_x 6, dim_u 2, dim_z 8, observe = identity).
-// The reference steps a Box2D body, which cannot be reproduced (not vendored / pinned); this is
-// a semi-implicit Euler rigid-body step with the same constants. params = {mass, inertia, u_max}.
+// Build-defined analytic planar quadrotor with the reference's interface, dimensions and constants
+// (scripts/mpc_state_est/mpc_quad.py:219-383: dim_x 6, dim_u 2, dim_z 8, observe = identity,
+// dt = 1/FS = 0.1, arm = vehicle_dx = W/25 = 0.8, angularDamping 0.5, g = 9.81, thrust along the
+// body normal at +/- arm, forces clipped to [0, force_mx]). The reference steps a Box2D body, which
+// cannot be reproduced (not vendored / pinned); this is Box2D's integrator for a free body:
+// velocities first (semi-implicit Euler, damping as 1 / (1 + dt c)), then positions.
+// params = {mass, inertia, u_max}.
 struct Quadrotor {
   static constexpr int ID = 6, NX = 6, NU = 2, NZ = 8, NZT = 6, NP = 3, NA = 1;
   I2C_HD static constexpr int ang(int) { return 2; }
@@ -221,6 +263,22 @@ struct Quadrotor {
   I2C_HD static constexpr int obs_dep(int) { return 0; }
   I2C_HD static constexpr int term_lin(int k) { return k; }
   I2C_HD static constexpr int term_dep(int) { return 0; }
+  // measure(): positions and velocities of the two rotor tips, mpc_quad.py:370-383 -- INCLUDING the
+  // reference's operator slip in rxd / ryd (`+ vehicle_dx - sin(th) thd`, `+ vehicle_dx + cos(th) thd`).
+  static constexpr int NY = 8;
+  I2C_HD static constexpr int meas_lin(int) { return -1; }
+  I2C_HD static constexpr int meas_dep(int) { return 5; }
+  template <typename R> I2C_FN void measure(const R*, const R* x, const R* sn, const R* cs, R* y) {
+    const R dx = R(0.8), s = sn[0], c = cs[0];
+    y[0] = x[0] - dx * c;
+    y[1] = x[1] - dx * s;
+    y[2] = x[0] + dx * c;
+    y[3] = x[1] + dx * s;
+    y[4] = x[3] - dx * (-s) * x[5];
+    y[5] = x[4] - dx * c * x[5];
+    y[6] = x[3] + dx - s * x[5];
+    y[7] = x[4] + dx + c * x[5];
+  }
   template <typename R> I2C_FN void dynamics(const R* p, const R* xu, const R* sn, const R* cs, R* xn) {
     const R dt = R(0.1), arm = R(0.8), ang_damp = R(0.5), grav = R(9.81);
     const R mass = p[0], inertia = p[1], u_max = p[2];

@@ -165,6 +165,10 @@ class BatchedI2c:
         self.zg = np.asarray(model.zg, np.float64).reshape(nz)
         self.zg_term = None if model.zg_term is None else np.asarray(model.zg_term, np.float64).reshape(-1)
 
+        self.alpha_cell = None      # [T][B] per-cell temperature, only in the MPC loop (see enable_per_cell_alpha)
+        self.alpha_init = None
+        self.terminal_cell = T - 1  # cell whose forward pass applies the terminal cost update (i2c.py:82,822)
+        self.cell_init = self.post[0].clone()  # a fresh cell (I2cCell.__init__), appended by shift_horizon()
         self.tau = T - 1  # i2c.py:833
         self._propagate = False
         self.use_expert_controller = True
@@ -187,6 +191,7 @@ class BatchedI2c:
         p.has_x_terminal = int(self.has_x_terminal)
         p.z_per_cell = int(self.z is not None)
         p.backward_mode = self.backward_mode
+        p.terminal_cell = int(self.terminal_cell)
         p.quad_alpha, p.quad_beta, p.quad_kappa = self.quad
         p.dtemp = self.dtemp
 
@@ -214,6 +219,7 @@ class BatchedI2c:
         p.sig_x0 = self.sig_x0.data_ptr()
         p.z = self.z.data_ptr() if self.z is not None else None
         p.alpha = self.alpha.data_ptr()
+        p.alpha_cell = self.alpha_cell.data_ptr() if self.alpha_cell is not None else None
         p.temp = self.temp.data_ptr()
         p.feedforward = self.feedforward.data_ptr()
         return p
@@ -292,6 +298,8 @@ class BatchedI2c:
         self.update_priors()
         self.alphas_desired.append(out[0])
         self.alphas.append(out[1])
+        if update_alpha:
+            self._broadcast_alpha()
         if self.has_x_terminal:
             self.kl_terms.append(self._terminal_kl())
 
@@ -311,7 +319,73 @@ class BatchedI2c:
         if only_decrease:
             a = torch.where(a < self.alpha, a, self.alpha)
         self.alpha.copy_(a)
+        self._broadcast_alpha()
         self.alphas[-1] = self.alpha.clone()
+
+    # ------------------------------------------------------------------ MPC building blocks
+    def set_initial_state(self, mu, cov):
+        """sys.x0 / sys.sig_x0 of every trajectory (mpc.py:149-150). mu (B, nx) or (nx,), cov (B, nx, nx) or (nx, nx)."""
+        mu = np.broadcast_to(np.asarray(mu, np.float64).reshape(-1, self.nx), (self.B, self.nx))
+        cov = np.broadcast_to(np.asarray(cov, np.float64), (self.B, self.nx, self.nx))
+        self.x0.copy_(torch.as_tensor(np.array(mu.T, order="C"), dtype=self.dtype))
+        self.sig_x0.copy_(torch.as_tensor(np.array(pack_sym_np(cov).T, order="C"), dtype=self.dtype))
+
+    def ckf_filter(self, y, u, sig_zeta, mu=None, cov=None):
+        """One cubature Kalman filter step on the belief (mu [nx][B], cov [sym nx][B]; default: the
+        solver's x0 / sig_x0 tensors, updated in place) -- PartiallyObservedMpcPolicy.filter, mpc.py:125-145.
+        y: [ny][B] tensor, u: [nu][B] tensor, sig_zeta: (ny, ny) array."""
+        mu = self.x0 if mu is None else mu
+        cov = self.sig_x0 if cov is None else cov
+        ny = self.dims.ny
+        assert y.shape == (ny, self.B) and u.shape == (self.nu, self.B) and y.dtype == self.dtype
+        zeta = (C.c_double * sym_size(ny))(*pack_sym_np(np.asarray(sig_zeta, np.float64)).reshape(-1))
+        rc = self.lib.i2c_ckf_filter(C.byref(self._problem), zeta, self._ptr(y.contiguous()), self._ptr(u.contiguous()),
+                                     self._ptr(mu), self._ptr(cov), self._ptr(self.status), self._stream())
+        self._check(rc, "i2c_ckf_filter")
+        return mu, cov
+
+    def enable_per_cell_alpha(self):
+        """The reference's MPC appends `deepcopy(cell_init)`: that cell keeps the sig_xi it was copied with
+        (the temperature at policy construction), because update_xi (i2c.py:976-981) only reaches the cells
+        in the list when alpha changes and alpha is frozen inside the loop. Reproduced with a [T][B]
+        per-cell temperature that follows the cells through the shift."""
+        if self.alpha_cell is None:
+            self.alpha_init = self.alpha.clone()
+            self.alpha_cell = self.alpha.reshape(1, -1).repeat(self.H, 1).contiguous()
+            self.refresh_problem()
+
+    def _broadcast_alpha(self):
+        """update_xi (i2c.py:976-981): every cell currently in the chain takes the graph's alpha."""
+        if self.alpha_cell is not None:
+            self.alpha_cell.copy_(self.alpha.reshape(1, -1).expand(self.H, -1))
+
+    def shift_horizon(self, z_new=None):
+        """Receding horizon (mpc.py:174-181): drop cell 0, append a fresh feed-forward cell whose target
+        is z_new ([nz][B] tensor) or, if None, the previous last cell's target. Buffers keep their address.
+        The `terminal_cell` flag stays with the cell it was set on (i2c.py:822), so it moves forward too."""
+        self.post.copy_(torch.roll(self.post, -1, 0))
+        self.post[-1] = self.cell_init
+        if self.alpha_cell is not None:
+            self.alpha_cell.copy_(torch.roll(self.alpha_cell, -1, 0))
+            self.alpha_cell[-1] = self.alpha_init
+        if self.terminal_cell >= 0:
+            self.terminal_cell -= 1
+            self._problem.terminal_cell = int(self.terminal_cell)
+        self.feedforward.copy_(torch.roll(self.feedforward, -1, 0))
+        self.feedforward[-1] = 1
+        if self.z is not None:
+            self.z.copy_(torch.roll(self.z, -1, 0))
+            self.z[-1] = self.z[-2] if z_new is None else z_new
+
+    def set_targets(self, z_traj):
+        """Per-cell targets (mpc.py:29-31): z_traj (T, nz) or (B, T, nz)."""
+        z = np.broadcast_to(np.asarray(z_traj, np.float64), (self.B, self.H, self.nz))
+        zt = torch.as_tensor(np.array(np.transpose(z, (1, 2, 0)), order="C"), dtype=self.dtype, device=self.device)
+        if self.z is None:
+            self.z = zt
+            self.refresh_problem()
+        else:
+            self.z.copy_(zt)
 
     def _terminal_kl(self):
         """mvn_kl_divergence(x3_pf[T-1] || terminal prior) (i2c.py:1012-1019, 1223-1229)."""

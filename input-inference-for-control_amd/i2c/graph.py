@@ -31,7 +31,7 @@ DEBUG_PLOTS = False
 
 
 def _np(t):
-    return t.detach().to(torch.float64).cpu().numpy()
+    return np.array(t.detach().to(torch.float64).cpu().numpy(), copy=True)  # never alias a device/host buffer
 
 
 class I2cCell:
@@ -270,6 +270,7 @@ class I2cGraph:
     def alpha(self, value):
         self.engine.alpha.copy_(torch.as_tensor(np.broadcast_to(np.asarray(value, float), (self.B,)).copy(),
                                                 dtype=self.engine.dtype))
+        self.engine._broadcast_alpha()
 
     @property
     def sig_xi(self):

@@ -71,6 +71,13 @@ class KnownModel:
     def observe_terminal_x(self, x):
         return self.observe_terminal(x)
 
+    sig_zeta = None
+
+    def measure(self, x):
+        """Measurement of the MPC state estimator. The reference defines it only for its quadrotor; the
+        other models observe their terminal features here (matches the device functor)."""
+        return self.observe_terminal(x)
+
     def forward(self, xu):
         xn = self.dynamics(xu)
         return xn, np.broadcast_to(self.sig_eta, (xu.shape[0],) + self.sig_eta.shape).copy()
@@ -172,6 +179,9 @@ class PendulumKnownActReg(PendulumKnown):
 
     def observe_terminal(self, x):
         return None
+
+    def measure(self, x):
+        return PendulumKnown.observe_terminal(self, x)
 
 
 class CartpoleKnown(KnownModel):
@@ -340,45 +350,44 @@ class LinearMinimumEnergy(LinearExact):
 
 
 class PlanarQuadrotor(KnownModel):
-    """Build-defined analytic planar quadrotor with the interface of the reference's Box2D
-    QuadrotorDef (scripts/mpc_state_est/mpc_quad.py:219-383); see csrc/i2c_models.hpp."""
+    """Build-defined analytic planar quadrotor with the interface, dimensions and constants of the
+    reference's Box2D QuadrotorDef (scripts/mpc_state_est/mpc_quad.py:219-383); see
+    csrc/i2c_models.hpp for what is and is not reproducible."""
 
     name = "2D Quadrotor"
     model_name = "PlanarQuadrotor"
     model_id = 6
     dim_x, dim_u, dim_z, dim_y = 6, 2, 8, 8
     dim_z_term = 6
-    dt, arm, half_h, density, ang_damp, grav = 0.1, 0.8, 0.8 / 6.0, 5.0, 0.5, 9.81
+    W, H = 20.0, 40.0 / 3.0
+    dt, arm, half_h, density, ang_damp, grav, force_mx = 0.1, 0.8, (40.0 / 3.0) / 100.0, 5.0, 0.5, 9.81, 30.0
 
     def __init__(self, model=None, model_def=None):
         super().__init__(model, model_def)
         w, h = 2 * self.arm, 2 * self.half_h
         self.mass = self.density * w * h
         self.inertia = self.mass * (w * w + h * h) / 12.0
-        hover = 0.5 * self.mass * self.grav
-        self.u_max = 4.0 * hover
-        self.x0 = np.zeros((6, 1))
-        self.sig_x0 = 1e-4 * np.eye(6)
-        self.sig_eta = 1e-6 * np.eye(6)
-        self.xag = np.array([[2.0, 2.0, 0.0, 0.0, 0.0, 0.0]]).T
-        self._zg = np.vstack((self.xag, np.full((2, 1), hover)))
-        self.sig_zeta = None
-        self.xu_lim = np.array([[-_INF] * 6 + [0.0, 0.0], [_INF] * 6 + [self.u_max] * 2])
+        self.x0 = np.array([[self.W / 4, self.H / 2, 0.0, 0.0, 0.0, 0.0]]).T
+        self.sig_x0 = 1e-5 * np.eye(6)
+        self.sig_eta = np.diag([1e-6] * 3 + [1e-4] * 3)
+        self.xag = np.array([[3 * self.W / 4, self.H / 2, 0.0, 0.0, 0.0, 0.0]]).T
+        self.sig_zeta = None  # set by the experiment (mpc_quad.py:552-556)
+        self.xu_lim = np.array([[-_INF] * 6 + [0.0, 0.0], [_INF] * 6 + [self.force_mx] * 2])
 
     @property
-    def zg(self):
-        return self._zg
+    def gravity(self):
+        return self.grav * self.mass
 
     @property
     def zg_term(self):
         return self.xag
 
     def device_params(self):
-        return [self.mass, self.inertia, self.u_max]
+        return [self.mass, self.inertia, self.force_mx]
 
     def dynamics(self, xu):
         xu = np.asarray(xu, dtype=float)
-        f1, f2 = np.clip(xu[:, 6], 0.0, self.u_max), np.clip(xu[:, 7], 0.0, self.u_max)
+        f1, f2 = np.clip(xu[:, 6], 0.0, self.force_mx), np.clip(xu[:, 7], 0.0, self.force_mx)
         thrust = f1 + f2
         vx = xu[:, 3] - self.dt * thrust * np.sin(xu[:, 2]) / self.mass
         vy = xu[:, 4] + self.dt * (thrust * np.cos(xu[:, 2]) / self.mass - self.grav)
@@ -390,6 +399,12 @@ class PlanarQuadrotor(KnownModel):
 
     def observe_terminal(self, x):
         return np.array(x, dtype=float)
+
+    def measure(self, x):
+        """Rotor-tip positions and velocities, with the reference's rxd / ryd expressions verbatim in meaning."""
+        d, s, c, w = self.arm, np.sin(x[:, 2]), np.cos(x[:, 2]), x[:, 5]
+        return np.column_stack((x[:, 0] - d * c, x[:, 1] - d * s, x[:, 0] + d * c, x[:, 1] + d * s,
+                                x[:, 3] + d * s * w, x[:, 4] - d * c * w, x[:, 3] + d - s * w, x[:, 4] + d + c * w))
 
 
 ENVIRONMENTS = {

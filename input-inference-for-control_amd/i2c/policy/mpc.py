@@ -1,0 +1,188 @@
+"""i2c model-predictive controllers with the reference's class names and call protocol
+(reference i2c/policy/mpc.py:16-182), batched: one policy drives B closed loops at once.
+
+Every step of the loop is device work: the cubature Kalman filter (`i2c_ckf_filter`), `n_iter`
+forward/backward sweeps warm-started from the shifted posterior, and the receding-horizon shift
+(the reference's `cells.pop(0); cells.append(deepcopy(cell_init))` list surgery becomes a roll of
+the [T][E][B] buffers plus a fresh last row). With B == 1 shapes are the reference's
+((n, 1) columns); with B > 1 arrays carry a leading batch axis.
+"""
+import numpy as np
+import torch
+
+
+def _np(t):
+    return np.array(t.detach().to(torch.float64).cpu().numpy(), copy=True)  # never alias a device/host buffer
+
+
+class MpcPolicy:
+    """Fully observed MPC (reference mpc.py:16-111). NB the reference's own __call__ is broken
+    (it passes unknown kwargs to compute_update_alpha); this one runs."""
+
+    def __init__(self, i2c, n_iter, sig_u, z_traj=None):
+        self.i2c = i2c
+        self.engine = e = i2c.engine
+        self.B = e.B
+        self.dim_u, self.dim_x = e.nu, e.nx
+        self.sig_u = sig_u
+        self.model = i2c.sys
+        self.n_iter = n_iter
+        self.set_control(True)  # mpc.py:21-22
+        e.enable_per_cell_alpha()  # cell_init is copied NOW (mpc.py:26): appended cells carry today's sig_xi
+        self.z_traj = None if z_traj is None else np.asarray(z_traj, dtype=float)
+        if self.z_traj is not None:
+            zt = self.z_traj if self.z_traj.ndim == 3 else self.z_traj[None]
+            e.set_targets(zt[:, : e.H])
+        self._init_state = {k: getattr(e, k).clone() for k in ("post", "alpha", "alpha_cell", "feedforward", "x0", "sig_x0")}
+        self._init_terminal = e.terminal_cell
+        self._init_z = None if e.z is None else e.z.clone()
+        self.record_history = self.B == 1
+        self.xu_history, self.z_history = [], []
+
+    def set_control(self, feedforward):
+        """mpc.py:35-41: feed-forward keeps every cell's action prior independent of the state."""
+        e = self.engine
+        if feedforward:
+            e.tau = 0
+        else:
+            e.tau = e.H
+
+    def reset(self):
+        e = self.engine
+        for k, v in self._init_state.items():
+            getattr(e, k).copy_(v)
+        if self._init_z is not None:
+            e.z.copy_(self._init_z)
+        e.status.zero_()
+        e.terminal_cell = self._init_terminal
+        e._problem.terminal_cell = int(e.terminal_cell)
+        self.xu_history, self.z_history = [], []
+
+    def _squeeze(self, a, column=False):
+        if self.B == 1:
+            a = a[0]
+            return a.reshape(-1, 1) if column else a
+        return a
+
+    def _next_target(self, i):
+        """Target of the cell that enters the horizon at step i (mpc.py:73-77, 177-181)."""
+        if self.z_traj is None:
+            return None
+        e = self.engine
+        zt = self.z_traj if self.z_traj.ndim == 3 else self.z_traj[None]
+        if i + e.H < zt.shape[1]:
+            z = np.broadcast_to(zt[:, i + e.H], (self.B, e.nz))
+            return torch.as_tensor(np.array(z.T, order="C"), dtype=e.dtype, device=e.device)
+        return None  # keep the previous last cell's target
+
+    def _plan(self, n_iter):
+        e = self.engine
+        for _ in range(n_iter):
+            e.forward_backward()
+            e.update_priors()
+        if self.B == 1:
+            e.raise_on_failure()
+        self.i2c._invalidate()
+
+    def _first_action(self, deterministic):
+        e = self.engine
+        mu, sig = e.marginal_state_action()
+        mu_u = _np(mu[:, 0, e.nx:])
+        if not deterministic:
+            sig_u = _np(sig[:, 0, e.nx:, e.nx:])
+            mu_u = np.stack([np.random.multivariate_normal(m, s) for m, s in zip(mu_u, sig_u)])
+        return mu_u
+
+    def _record(self):
+        if self.record_history:
+            self.xu_history.append(self.i2c.get_marginal_state_action())
+            self.z_history.append(self.i2c.get_marginal_observed_trajectory()[0])
+
+    def optimize(self, n_iter, x):
+        x = np.asarray(x, dtype=float)
+        assert x.reshape(-1, self.dim_x).shape[0] in (1, self.B), f"{x.shape}, {(self.dim_x, 1)}"
+        e = self.engine
+        e.set_initial_state(x.reshape(-1, self.dim_x), _np(unpack(e)))
+        if self.B == 1:
+            self.i2c.sys.x0 = x.reshape(self.dim_x, 1)
+            self.i2c._x0_seen = None
+        self._plan(n_iter)
+
+    def __call__(self, i, x, deterministic=True):
+        self.optimize(self.n_iter, x)
+        self._record()
+        u = self._first_action(deterministic)
+        self.engine.shift_horizon(self._next_target(i))
+        self.i2c._invalidate()
+        return self._squeeze(u, column=True)
+
+    def update_models(self, sys):
+        raise NotImplementedError("models are compiled device functors; construct a new I2cGraph")
+
+
+def unpack(e):
+    from .. import core
+
+    return core.engine.unpack_sym(e.sig_x0.T, e.nx)
+
+
+class PartiallyObservedMpcPolicy(MpcPolicy):
+    """MPC on a cubature-Kalman-filtered belief (reference mpc.py:113-182)."""
+
+    def __init__(self, i2c, n_iter, sig_u, z_traj=None):
+        super().__init__(i2c, n_iter, sig_u, z_traj)
+        e = self.engine
+        # the belief lives in the solver's x0 / sig_x0 tensors: filter() updates them in place and the
+        # next forward sweep starts from them, with no host round trip
+        self.mus, self.covars = [], []
+
+    # -- belief as reference-shaped arrays ----------------------------------------------------
+    @property
+    def mu(self):
+        return self._squeeze(_np(self.engine.x0.T), column=True)
+
+    @property
+    def covar(self):
+        return self._squeeze(_np(unpack(self.engine)))
+
+    def _dev(self, a, n):
+        e = self.engine
+        a = np.broadcast_to(np.asarray(a, dtype=float).reshape(-1, n), (self.B, n))
+        return torch.as_tensor(np.array(a.T, order="C"), dtype=e.dtype, device=e.device)
+
+    def filter(self, y, u):
+        """mpc.py:125-145. y: (dim_y, 1) or (B, dim_y); u: (dim_u, 1) or (B, dim_u)."""
+        e = self.engine
+        sig_zeta = self.i2c.sys.sig_zeta
+        if sig_zeta is None:
+            raise ValueError("sys.sig_zeta (measurement noise) must be set before filtering")
+        e.ckf_filter(self._dev(y, e.dims.ny), self._dev(u, e.nu), sig_zeta)
+        if self.B == 1:
+            e.raise_on_failure()
+        return self.mu, self.covar
+
+    def optimize(self, n_iter, mu=None, covar=None):
+        """mpc.py:147-154. With no arguments the current (filtered) belief is used as is."""
+        e = self.engine
+        if mu is not None:
+            mu = np.asarray(mu, dtype=float)
+            assert mu.reshape(-1, self.dim_x).shape[0] in (1, self.B), f"{mu.shape}, {(self.dim_x, 1)}"
+            e.set_initial_state(mu.reshape(-1, self.dim_x), covar)
+        if self.B == 1:  # keep the facade's view of sys.x0 / sig_x0 consistent (mpc.py:149-150)
+            self.i2c.sys.x0, self.i2c.sys.sig_x0 = self.mu, self.covar
+            self.i2c._x0_seen = (np.asarray(self.i2c.sys.x0, float).reshape(-1).tobytes(),
+                                 np.asarray(self.i2c.sys.sig_x0, float).tobytes())
+        self._plan(n_iter)
+
+    def __call__(self, i, y, u, deterministic=True):
+        if i > 0:
+            self.filter(y, u)
+        if self.record_history:
+            self.mus.append(self.mu)
+            self.covars.append(self.covar)
+        self.optimize(self.n_iter)
+        self._record()
+        ctrl = self._first_action(deterministic)
+        self.engine.shift_horizon(self._next_target(i))
+        self.i2c._invalidate()
+        return self._squeeze(ctrl, column=True)

@@ -278,6 +278,162 @@ def case_models():
     save("models_vectors", out)
 
 
+def _mpc_loop(policy, model, steps, out, rng, plant_noise=True):
+    """Closed loop of scripts/mpc_state_est/mpc_quad.py:632-650 with a seeded NumPy plant."""
+    x = np.array(model.x0, dtype=float).reshape(-1, 1)
+    Lz = np.linalg.cholesky(model.sig_zeta)
+    Le = np.linalg.cholesky(model.sig_eta)
+    y = model.measure(x.T).T + Lz @ rng.normal(size=(Lz.shape[0], 1))
+    u = np.zeros((model.dim_u, 1))
+    ys, us_prev, mus, covs, ctrls, alphas = [], [], [], [], [], []
+    for t in range(steps):
+        ys.append(y[:, 0].copy())
+        us_prev.append(u[:, 0].copy())
+        u = policy(t, y, u)
+        u = np.clip(u.T, model.xu_lim[0, model.dim_x:], model.xu_lim[1, model.dim_x:]).T
+        mus.append(np.asarray(policy.mu, float).reshape(-1).copy())
+        covs.append(np.asarray(policy.covar, float).copy())
+        ctrls.append(u[:, 0].copy())
+        alphas.append(float(policy.i2c.alpha))
+        x = model.dynamics(np.hstack((x.T, u.T))).T
+        if plant_noise:
+            x = x + Le @ rng.normal(size=x.shape)
+        y = model.measure(x.T).T + Lz @ rng.normal(size=(Lz.shape[0], 1))
+    out["y"], out["u_prev"] = np.array(ys), np.array(us_prev)
+    out["mu"], out["covar"], out["ctrl"], out["alpha_steps"] = np.array(mus), np.array(covs), np.array(ctrls), np.array(alphas)
+    out["xu_plan_last"] = np.asarray(policy.xu_history[-1], float)[:, :, 0]
+
+
+def case_mpc_pendulum(feedforward, name):
+    """PartiallyObservedMpcPolicy (i2c/policy/mpc.py:113-182) on the pendulum with a stand-in
+    measurement model y = observe_terminal(x) + N(0, sig_zeta) (the reference defines `measure`
+    only for its Box2D quadrotor). Protocol of mpc_quad.py:624-650: calibrate_alpha, warm start,
+    calibrate_alpha, then the closed loop with per-cell targets."""
+    from i2c.policy.mpc import PartiallyObservedMpcPolicy
+
+    H, steps, n_iter, warm = 10, 25, 2, 8
+    rng = np.random.default_rng(5)
+    model = make_env_model("PendulumKnown", None)
+    model.sig_zeta = np.diag([1e-4, 1e-4, 1e-3])
+    model.measure = lambda x: model.observe_terminal(x)
+    model.dim_y = 3
+    Q, R = np.diag([1, 100.0, 1]), np.diag([2.0])
+    mu_u = 0.1 * rng.normal(size=(H, 1))
+    sig_u = 2.0 * np.eye(1)
+    z_traj = np.tile(np.asarray(model.zg, float).reshape(1, -1), (steps + H, 1))
+    z_traj[:, 2] = 0.3 * np.sin(np.linspace(0, 3, steps + H))  # a moving velocity target
+    g = I2cGraph(model, H, Q, R, Q, 10.0, 1.0, mu_u, sig_u, None, None, CubatureQuadrature(1, 0, 0))
+    g._propagate = True
+    policy = PartiallyObservedMpcPolicy(g, n_iter, sig_u, np.copy(z_traj))
+    policy.set_control(feedforward=feedforward)
+    out = problem_inputs("PendulumKnown", model, H, Q, R, Q, 10.0, 1.0, mu_u, sig_u, None, None, (1, 0, 0),
+                         feedforward=bool(feedforward), steps=steps, n_iter=n_iter, warm=warm)
+    out["z_traj"], out["sig_zeta"] = z_traj, model.sig_zeta
+    g.calibrate_alpha()
+    out["alpha_cal1"] = np.array(g.alpha)
+    policy.optimize(warm, model.x0, model.sig_x0)
+    g.calibrate_alpha()
+    out["alpha_cal2"] = np.array(g.alpha)
+    _mpc_loop(policy, model, steps, out, rng)
+    save(name, out)
+
+
+def case_mpc_pendulum_ff():
+    case_mpc_pendulum(True, "mpc_pendulum_ff")
+
+
+def case_mpc_pendulum_fb():
+    case_mpc_pendulum(False, "mpc_pendulum_fb")
+
+
+def _reference_quadrotor():
+    """The build-defined analytic quadrotor (oracle/models_numpy.PlanarQuadrotor) wrapped in the
+    REFERENCE's own model base classes, so that the reference solver and MPC policy run on it."""
+    from i2c.env_def import BaseDef
+    from i2c.model import BaseModelKnown
+    from models_numpy import PlanarQuadrotor
+
+    q = PlanarQuadrotor()
+
+    class QuadrotorAnalytic(BaseDef, BaseModelKnown):
+        name = "2D Quadrotor (analytic)"
+        dim_x, dim_u, dim_z, dim_y = 6, 2, 8, 8
+        dim_z_term = 6
+        x0 = q.x0.reshape(-1, 1)
+        sig_x0 = q.sig_x0
+        sig_eta = q.sig_eta
+        xag = q.zg_term.reshape(-1, 1)
+        zg_term = xag
+        sig_zeta = None
+        gravity = q.gravity
+        xu_lim = np.array([[-np.inf] * 6 + [0.0, 0.0], [np.inf] * 6 + [30.0, 30.0]])
+
+        @staticmethod
+        def dynamics(xu):
+            return q.dynamics(xu)
+
+        @staticmethod
+        def observe(xu):
+            return xu
+
+        @staticmethod
+        def observe_terminal(x):
+            return x
+
+        @staticmethod
+        def measure(x):
+            return q.measure(x)
+
+    return QuadrotorAnalytic()
+
+
+def case_em_quadrotor(T=20, n_detail=2, n_total=8):
+    """Solver parity for config 4 with build-defined dynamics: reference I2cGraph on the analytic quadrotor."""
+    model = _reference_quadrotor()
+    rng = np.random.default_rng(2)
+    Q = np.diag([1e3, 1e3, 1e3, 1, 1, 1]) / 1e3
+    R = np.diag([1e-3, 1e-3])
+    mu_u = 0.5 * model.gravity * np.ones((T, 2)) + 1e-2 * rng.normal(size=(T, 2))
+    sig_u = 1e-2 * np.eye(2)
+    g = I2cGraph(model, T, Q, R, Q, 1.0, 0.5, mu_u, sig_u, None, None, CubatureQuadrature(1, 0, 0))
+    out = problem_inputs("PlanarQuadrotor", model, T, Q, R, Q, 1.0, 0.5, mu_u, sig_u, None, None, (1, 0, 0))
+    run_em(g, n_detail, n_total, out)
+    save("em_quadrotor_T20", out)
+
+
+def case_mpc_quadrotor():
+    """mpc_quad.py:538-650 (i2c, feedback, low noise) on the analytic quadrotor: tracking a moving target."""
+    from i2c.policy.mpc import PartiallyObservedMpcPolicy
+
+    H, steps, n_iter, warm = 10, 15, 2, 10
+    rng = np.random.default_rng(9)
+    model = _reference_quadrotor()
+    model.sig_zeta = np.diag([1e-6] * 8)
+    W_, H_ = 20.0, 40.0 / 3.0
+    z_traj = np.zeros((steps + H, 8))
+    z_traj[:, 0] = np.linspace(W_ / 4, W_ / 4 + 2.0, steps + H)
+    z_traj[:, 1] = H_ / 2 + 0.5 * np.sin(np.linspace(0, 2.0, steps + H))
+    Q = np.diag([1e3, 1e3, 1e3, 1, 1, 1])
+    R = np.diag([1e-3, 1e-3])
+    Qf = Q / 1e3
+    mu_u = 0.5 * model.gravity * np.ones((H, 2))
+    sig_u = 1e-2 * np.eye(2)
+    g = I2cGraph(model, H, Q, R, Qf, 1.0, 1.0, mu_u, sig_u, None, None, CubatureQuadrature(1, 0, 0))
+    g._propagate = True
+    policy = PartiallyObservedMpcPolicy(g, n_iter, sig_u, np.copy(z_traj))
+    policy.set_control(feedforward=False)
+    out = problem_inputs("PlanarQuadrotor", model, H, Q, R, Qf, 1.0, 1.0, mu_u, sig_u, None, None, (1, 0, 0),
+                         feedforward=False, steps=steps, n_iter=n_iter, warm=warm)
+    out["z_traj"], out["sig_zeta"] = z_traj, model.sig_zeta
+    g.calibrate_alpha()
+    out["alpha_cal1"] = np.array(g.alpha)
+    policy.optimize(warm, model.x0, model.sig_x0)
+    g.calibrate_alpha()
+    out["alpha_cal2"] = np.array(g.alpha)
+    _mpc_loop(policy, model, steps, out, rng)
+    save("mpc_quadrotor_fb", out)
+
+
 CASES = {
     "pendulum": case_pendulum,
     "pendulum_long": case_pendulum_long,
@@ -290,6 +446,10 @@ CASES = {
     "propagate": case_propagate_expert,
     "quadrature": case_quadrature,
     "models": case_models,
+    "mpc_ff": case_mpc_pendulum_ff,
+    "mpc_fb": case_mpc_pendulum_fb,
+    "em_quad": case_em_quadrotor,
+    "mpc_quad": case_mpc_quadrotor,
 }
 
 if __name__ == "__main__":

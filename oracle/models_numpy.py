@@ -282,37 +282,39 @@ class PlanarQuadrotor(_Model):
     The reference's quadrotor (scripts/mpc_state_est/mpc_quad.py:219-383) steps a Box2D rigid
     body; Box2D is a third-party C++ engine that is neither vendored, pinned nor installed
     (SURVEY.md section 8c), so its arithmetic cannot be reproduced. This model keeps the
-    reference's *interface and dimensions* (dim_x=6: x, y, th, xd, yd, thd; dim_u=2 rotor
-    thrusts; dim_z=8; measure() -> 8) and its physical constants (dt = 1/10, body
-    1.6 m x 0.267 m at density 5 => m ~= 2.13 kg, arm = 0.8 m, angular damping 0.5,
-    g = 9.81), with a semi-implicit Euler rigid-body step (velocities first, then positions),
-    which is what Box2D's solver does for an unconstrained body.
+    reference's *interface, dimensions and constants* (dim_x=6: x, y, th, xd, yd, thd; dim_u=2
+    rotor thrusts in [0, 30]; dim_z=8; measure() -> 8; FS = 10 -> dt = 0.1; W = 20, H = 40/3;
+    body 2 vehicle_dx x 2 vehicle_dy = 1.6 x 0.2667 m at density 5 -> m = 2.133 kg; arm =
+    vehicle_dx = 0.8 m; angularDamping 0.5; g = 9.81; x0 = [W/4, H/2, 0...], goal [3W/4, H/2, 0...])
+    with Box2D's integrator for a free body: velocities first (semi-implicit Euler, damping as
+    1 / (1 + dt c)), then positions.
     Solver parity for config 4 is pinned by feeding THIS model to the real reference
-    I2cGraph in-container (oracle/gen_golden.py).
+    I2cGraph / PartiallyObservedMpcPolicy in-container (oracle/gen_golden.py).
     """
 
     name = "PlanarQuadrotor"
     model_id = 6
-    dim_x, dim_u, dim_z, dim_z_term = 6, 2, 8, 6
+    dim_x, dim_u, dim_z, dim_z_term, dim_y = 6, 2, 8, 6, 8
+    W, H = 20.0, 40.0 / 3.0
     dt = 0.1
-    arm = 0.8
-    half_h = 0.8 / 6.0
+    arm = 20.0 / 25.0
+    half_h = (40.0 / 3.0) / 100.0
     density = 5.0
     ang_damp = 0.5
     grav = 9.81
+    u_max = 30.0
 
     def __init__(self):
         w, h = 2 * self.arm, 2 * self.half_h
         self.mass = self.density * w * h
         self.inertia = self.mass * (w * w + h * h) / 12.0
-        self.x0 = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 0.0])
-        self.sig_x0 = 1e-4 * np.eye(6)
-        self.sig_eta = 1e-6 * np.eye(6)
-        hover = 0.5 * self.mass * self.grav
-        self.u_hover = np.array([hover, hover])
-        self.zg = np.concatenate((np.array([2.0, 2.0, 0.0, 0.0, 0.0, 0.0]), self.u_hover))
-        self.zg_term = np.array([2.0, 2.0, 0.0, 0.0, 0.0, 0.0])
-        self.u_max = 4.0 * hover
+        self.gravity = self.grav * self.mass  # mpc_quad.py:321-323
+        self.x0 = np.array([self.W / 4, self.H / 2, 0.0, 0.0, 0.0, 0.0])  # mpc_quad.py:243
+        self.sig_x0 = 1e-5 * np.eye(6)  # mpc_quad.py:244
+        self.sig_eta = np.diag([1e-6] * 3 + [1e-4] * 3)  # mpc_quad.py:245
+        self.zg_term = np.array([3 * self.W / 4, self.H / 2, 0.0, 0.0, 0.0, 0.0])  # mpc_quad.py:250-251
+        self.zg = np.concatenate((self.zg_term, np.zeros(2)))
+        self.sig_zeta = np.diag([1e-6] * 8)  # low-noise setting, mpc_quad.py:552-554
 
     def dynamics(self, xu):
         px, py, th, vx, vy, om = (xu[..., i] for i in range(6))
@@ -335,6 +337,39 @@ class PlanarQuadrotor(_Model):
     def observe_terminal(self, x):
         return x + 0.0
 
+    def measure(self, x):
+        """mpc_quad.py:370-383, including the reference's operator slip in rxd / ryd."""
+        dx = self.arm
+        s, c = np.sin(x[..., 2]), np.cos(x[..., 2])
+        return np.stack(
+            (
+                x[..., 0] - dx * c,
+                x[..., 1] - dx * s,
+                x[..., 0] + dx * c,
+                x[..., 1] + dx * s,
+                x[..., 3] - dx * -s * x[..., 5],
+                x[..., 4] - dx * c * x[..., 5],
+                x[..., 3] + dx - s * x[..., 5],
+                x[..., 4] + dx + c * x[..., 5],
+            ),
+            axis=-1,
+        )
+
+
+def _terminal_features_as_measurement(cls):
+    """The reference defines `measure` only for its quadrotor. For the other models the build's state
+    estimator observes the terminal features (no action), e.g. [sin th, cos th, thd]."""
+
+    def measure(self, x):
+        return self.observe_terminal(x)
+
+    cls.measure = measure
+    return cls
+
+
+for _c in (Pendulum, Cartpole, DoubleCartpole, Linear, LinearMinimumEnergy):
+    _terminal_features_as_measurement(_c)
+PendulumActReg.measure = lambda self, x: Pendulum.observe_terminal(self, x)
 
 MODELS = {
     m.name: m

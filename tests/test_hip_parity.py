@@ -26,6 +26,7 @@ GOLDEN = [
     ("em_linear_T60", 1e-8, 1e-7),
     ("em_covctrl_T100", 1e-7, 1e-6),
     ("em_pendulum_T50_propagate", 1e-8, 1e-7),
+    ("em_quadrotor_T20", 1e-6, 1e-5),
 ]
 
 

@@ -21,6 +21,7 @@ GOLDEN = [
     ("em_linear_T60", 1e-9, 1e-8),
     ("em_covctrl_T100", 1e-8, 1e-7),
     ("em_pendulum_T50_propagate", 1e-9, 1e-8),
+    ("em_quadrotor_T20", 1e-7, 1e-6),
 ]
 
 

@@ -1,0 +1,167 @@
+"""Row (f2): the MPC loop either side of the solver -- batched cubature Kalman filter
+(i2c_ckf_filter), warm-started sweeps, receding-horizon shift -- replayed against what the
+REFERENCE's PartiallyObservedMpcPolicy (i2c/policy/mpc.py:113-182) did on the same measurement
+stream (tests/golden/mpc_*.npz, oracle/gen_golden.py). Protocol of mpc_quad.py:624-650:
+calibrate_alpha, warm start, calibrate_alpha, closed loop with per-cell moving targets."""
+import numpy as np
+import pytest
+import torch
+
+import hostsim
+import parity
+from golden_util import assert_close, load_case
+from i2c.exp_types import CubatureQuadrature
+from i2c.i2c import I2cGraph
+from i2c.policy.mpc import PartiallyObservedMpcPolicy
+
+
+def _policy(g, lib, device, batch=None):
+    meta = g.meta
+    model = parity.product_model(g)
+    model.sig_zeta = g["sig_zeta"]
+    i2c = I2cGraph(model, meta["T"], g.get("Q"), g["R"], g.get("Qf"), meta["alpha"], meta["tol"], g["mu_u"], g["sig_u"],
+                   None, None, CubatureQuadrature(*meta["quad"]), lib=lib, device=device, batch=batch)
+    i2c._propagate = True
+    pol = PartiallyObservedMpcPolicy(i2c, meta["n_iter"], g["sig_u"], np.copy(g["z_traj"]))
+    pol.set_control(feedforward=meta["feedforward"])
+    return model, i2c, pol
+
+
+def _replay(name, lib, device, tol):
+    g = load_case(name)
+    meta = g.meta
+    model, i2c, pol = _policy(g, lib, device)
+    i2c.calibrate_alpha()
+    assert_close(i2c.alpha, g["alpha_cal1"], tol, "first alpha calibration")
+    pol.optimize(meta["warm"], model.x0, model.sig_x0)
+    i2c.calibrate_alpha()
+    assert_close(i2c.alpha, g["alpha_cal2"], tol, "second alpha calibration")
+    lo, hi = model.xu_lim[0, model.dim_x:], model.xu_lim[1, model.dim_x:]
+    for t in range(meta["steps"]):
+        u = pol(t, g["y"][t].reshape(-1, 1), g["u_prev"][t].reshape(-1, 1))
+        u = np.clip(u.T, lo, hi).T
+        assert u.shape == (model.dim_u, 1) and pol.mu.shape == (model.dim_x, 1)
+        assert_close(pol.mu[:, 0], g["mu"][t], tol, f"{name} belief mean, step {t}")
+        assert_close(pol.covar, g["covar"][t], tol * 10, f"{name} belief covariance, step {t}")
+        assert_close(u[:, 0], g["ctrl"][t], tol * 10, f"{name} control, step {t}")
+        assert_close(i2c.alpha, g["alpha_steps"][t], tol, f"{name} alpha, step {t}")
+    assert_close(pol.xu_history[-1][:, :, 0], g["xu_plan_last"], tol * 10, f"{name} last plan")
+    # the horizon shift: after the loop the last cell is a fresh feed-forward cell
+    assert i2c.cells[-1].state_action_independence
+    return pol
+
+
+@pytest.mark.parametrize("name", ["mpc_pendulum_ff", "mpc_pendulum_fb", "mpc_quadrotor_fb"])
+def test_mpc_replay_cpu(name):
+    _replay(name, hostsim.load(), "cpu", 1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mpc_pendulum_ff", "mpc_pendulum_fb", "mpc_quadrotor_fb"])
+def test_mpc_replay_gpu(name):
+    _replay(name, None, "cuda", 1e-6)
+
+
+def _ckf_oracle(model, rule_w, mu, cov, u, y, sig_zeta):
+    """PartiallyObservedMpcPolicy.filter (mpc.py:125-145), batched, with the oracle's transform."""
+    from oracle.i2c_numpy import CubatureRule, SigmaPointTransform
+
+    tf = SigmaPointTransform(CubatureRule(*rule_w), model.dim_x)
+    X = tf.points(mu, cov)
+    XU = np.concatenate((X, np.broadcast_to(u[:, None, :], X.shape[:2] + (u.shape[-1],))), axis=-1)
+    Xf = model.dynamics(XU)
+    w = tf.w
+    mu_f = np.einsum("p,bpi->bi", w, Xf)
+    sig_f = np.einsum("p,bpi,bpj->bij", w, Xf, Xf) - mu_f[:, :, None] * mu_f[:, None, :] + w.sum() * model.sig_eta
+    mu_y, sig_y, sig_xy, _, _ = tf.forward(model.measure, mu_f, sig_f)
+    sig_y = sig_y + sig_zeta
+    K = np.swapaxes(np.linalg.solve(np.swapaxes(sig_y, -1, -2), np.swapaxes(sig_xy, -1, -2)), -1, -2)
+    return mu_f + np.einsum("bij,bj->bi", K, y - mu_y), sig_f - K @ sig_y @ np.swapaxes(K, -1, -2)
+
+
+def _ckf_batch(lib, device, model_name, B=37):
+    """The filter kernel on a ragged batch of random beliefs against the oracle restatement."""
+    from oracle.models_numpy import make_model
+
+    g = load_case("mpc_quadrotor_fb" if model_name == "PlanarQuadrotor" else "mpc_pendulum_ff")
+    rng = np.random.default_rng(3)
+    om = make_model(model_name)
+    nx, nu = om.dim_x, om.dim_u
+    ny = om.measure(np.zeros((1, nx))).shape[-1]
+    mu = np.asarray(om.x0) + 0.1 * rng.normal(size=(B, nx))
+    A = rng.normal(size=(B, nx, nx))
+    cov = 1e-3 * (A @ np.swapaxes(A, -1, -2)) + 1e-5 * np.eye(nx)
+    u = rng.normal(size=(B, nu)) + (om.u_max / 4 if hasattr(om, "u_max") else 0.0)
+    sig_zeta = np.diag(10.0 ** rng.uniform(-5, -2, size=ny))
+    y = om.measure(mu) + 0.01 * rng.normal(size=(B, ny))
+    _, i2c, pol = _policy(g, lib, device, batch=B)
+    i2c.sys.sig_zeta = sig_zeta
+    i2c.engine.set_initial_state(mu, cov)
+    pol.filter(y, u)
+    mu_o, cov_o = _ckf_oracle(om, (1, 0, 0), mu, cov, u, y, sig_zeta)
+    assert_close(pol.mu, mu_o, 1e-9, "filtered mean")
+    assert_close(pol.covar, cov_o, 1e-8, "filtered covariance")
+    assert i2c.engine.failures() == []
+
+
+@pytest.mark.parametrize("model_name", ["PendulumKnown", "PlanarQuadrotor"])
+def test_ckf_batch_cpu(model_name):
+    _ckf_batch(hostsim.load(), "cpu", model_name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_name", ["PendulumKnown", "PlanarQuadrotor"])
+def test_ckf_batch_gpu(model_name):
+    _ckf_batch(None, "cuda", model_name)
+
+
+def _batched_loop_matches_single(lib, device):
+    """B closed loops driven at once: every lane reproduces the B = 1 loop on the same stream."""
+    g = load_case("mpc_pendulum_fb")
+    meta = g.meta
+    B = 5
+    _, i1, p1 = _policy(g, lib, device)
+    _, iB, pB = _policy(g, lib, device, batch=B)
+    for pol, i2c in ((p1, i1), (pB, iB)):
+        i2c.calibrate_alpha()
+        pol.optimize(meta["warm"], g["x0"], g["sig_x0"])
+        i2c.calibrate_alpha()
+    for t in range(6):
+        y, u = g["y"][t].reshape(-1, 1), g["u_prev"][t].reshape(-1, 1)
+        u1 = p1(t, y, u)
+        uB = pB(t, np.tile(y.T, (B, 1)), np.tile(u.T, (B, 1)))
+        assert uB.shape == (B, 1)
+        assert_close(uB, np.tile(u1.T, (B, 1)), 1e-12, f"batched control, step {t}")
+        assert_close(pB.mu, np.tile(p1.mu.T, (B, 1)), 1e-12, f"batched belief, step {t}")
+
+
+def test_batched_mpc_loop_cpu():
+    _batched_loop_matches_single(hostsim.load(), "cpu")
+
+
+@pytest.mark.gpu
+def test_batched_mpc_loop_gpu():
+    _batched_loop_matches_single(None, "cuda")
+
+
+def test_quadrature_inference_mirror_matches_reference_vectors():
+    """The host-side QuadratureInference class that callers use directly (mpc_quad.py:129-152)."""
+    from i2c.inference.quadrature import QuadratureInference
+    from i2c.model import make_env_model
+
+    q = load_case("quadrature_vectors")
+    model = make_env_model("PendulumKnown")
+    for n in range(int(q["n"])):
+        pre = f"q{n}/"
+        qi = QuadratureInference(CubatureQuadrature(*q[pre + "quad"]), 3)
+        m, S = q[pre + "m"].reshape(-1, 1), q[pre + "S"]
+        m_z, S_z = qi.forward(model.observe, m, S)
+        assert m_z.shape == (4, 1)
+        assert_close(qi.x_pts, q[pre + "x_pts"], 1e-14)
+        assert_close(m_z[:, 0], q[pre + "obs_m"], 1e-13)
+        assert_close(S_z, q[pre + "obs_S"], 1e-12)
+        assert_close(qi.sig_xy, q[pre + "obs_Sxy"], 1e-12)
+        m_y, S_y, S_n = qi.forward_gaussian(model.forward, m, S)
+        assert_close(m_y[:, 0], q[pre + "dyn_m"], 1e-13)
+        assert_close(S_y, q[pre + "dyn_S"], 1e-11)
+        assert_close(S_n, q[pre + "dyn_noise"], 1e-15)

@@ -140,6 +140,11 @@ def test_em_covariance_control_T100():
     _run_and_check("em_covctrl_T100", 1e-8, 1e-7)
 
 
+def test_em_quadrotor_T20():
+    """Build-defined analytic quadrotor fed to the REAL reference solver (dynamics unpinned, solver pinned)."""
+    _run_and_check("em_quadrotor_T20", 1e-8, 1e-7)
+
+
 def test_em_propagate_expert_T50():
     _run_and_check("em_pendulum_T50_propagate", 1e-9, 1e-8)
 
