@@ -126,6 +126,7 @@ template <class M, typename R> static Consts<M, R> make_consts(const I2cProblem*
   c.dtemp = (R)p->dtemp;
   c.tol = (R)tol;
   for (int i = 0; i < sym(C::NX); ++i) c.sig_eta[i] = (R)p->sig_eta[i];
+  for (int i = 0; i < sym(C::NX); ++i) c.sig_eta_w[i] = c.rule_xu.W * c.sig_eta[i];
   for (int i = 0; i < sym(C::NZ); ++i) c.sig_xi0[i] = (R)p->sig_xi0[i];
   for (int i = 0; i < sym(C::NZ); ++i) c.QR[i] = (R)p->QR[i];
   for (int i = 0; i < sym(C::NZT); ++i) c.sig_xiT0[i] = (R)p->sig_xiT0[i];

@@ -40,6 +40,7 @@ template <class M, typename R> struct Consts {
   int has_Qf, has_x_terminal, z_per_cell, use_expert, terminal_cell;
   Rule<R> rule_xu, rule_x;
   R dtemp, tol;
+  R sig_eta_w[sym(NX)];  // W(d) * sig_eta, W = sum of the d-dimensional rule's weights
   R sig_eta[sym(NX)], sig_xi0[sym(NZ)], QR[sym(NZ)], sig_xiT0[sym(NZT1)], Qf[sym(NZT1)];
   R zg[NZ], zg_term[NZT1], mu_x_term[NX], sig_x_term[sym(NX)], params[NP1];
 };
@@ -193,6 +194,7 @@ I2C_FN void sp_transform(const Rule<R>& rule, const R* m, const R* Sin, const R*
         for (int i = j; i < DIN; ++i) Sxy[i * DOUT + k] += L[tri(i, j)] * dl[k];
       }
     }
+    sched_fence<(DIN >= 6)>();
   }
   const R hw = R(0.5) * rule.wi, w2 = rule.wi * rule.wi, cs = rule.wi * rule.sf;
 #pragma unroll
@@ -242,6 +244,7 @@ I2C_FN bool kalman_update(R* mu, R* S, const R* mz, R* Sz, R* Sxz, const R* zt) 
 #pragma unroll
     for (int k = 0; k < DZ; ++k) v += Sxz[i * DZ + k] * q[k];
     mu[i] = v;
+    sched_fence<(DZ >= 8)>();
   }
 #pragma unroll
   for (int i = 0; i < DX; ++i)
@@ -376,16 +379,27 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
   for (int t = 0; t < T; ++t) {
     R nxt[C::E_PRI], zn[NZ];
     const int tn = t + 1 < T ? t + 1 : t;
-    {
+    // Small models prefetch the next cell's prior rows a whole cell ahead (the loads do not depend on
+    // the recursion). For d >= 6 those d + s(d) + nu nx doubles would sit on top of a register peak that
+    // already fills the 512-VGPR file, so the rows are simply loaded at the top of their own cell: one
+    // exposed HBM round trip (~1 us) per ~15 us cell instead of scratch traffic throughout.
+    constexpr bool PREFETCH = C::D <= 5;
+    if (PREFETCH) {
       const Window w = make_window(a.prior + (unsigned long)tn * C::E_POST * B, (unsigned long)C::E_POST * rb);
 #pragma unroll
       for (int e = 0; e < C::E_PRI; ++e) nxt[e] = wld<R>(w, e * rb, bo);
-    }
 #pragma unroll
-    for (int k = 0; k < NZ; ++k) zn[k] = c.z_per_cell ? a.z[((long)tn * NZ + k) * B + b] : c.zg[k];
+      for (int k = 0; k < NZ; ++k) zn[k] = c.z_per_cell ? a.z[((long)tn * NZ + k) * B + b] : c.zg[k];
+    } else if (t > 0) {
+      const Window w = make_window(a.prior + (unsigned long)t * C::E_POST * B, (unsigned long)C::E_POST * rb);
+#pragma unroll
+      for (int e = 0; e < C::E_PRI; ++e) pri[e] = wld<R>(w, e * rb, bo);
+#pragma unroll
+      for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
+    }
 
     // per-cell temperature only in the MPC loop (stale sig_xi of appended cells); else the trajectory's
-    const R alpha = a.alpha_cell ? a.alpha_cell[(long)t * B + b] : alpha_traj;
+    const R alpha = opaque(a.alpha_cell ? a.alpha_cell[(long)t * B + b] : alpha_traj);
     const R* pmu = pri;               // prior joint mean  (== previous posterior, see i2c_hip.h)
     const R* psig = pri + D;          // prior joint covariance
     const R* Kprev = pri + D + sym(D);
@@ -437,6 +451,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     }
 
     // ---- 2. cost "observation": measurement update on z (i2c.py:390-407) --------------
+    sched_fence<(D >= 6)>();
     {
       R L[sym(D)], rinv[D];
 #pragma unroll
@@ -456,6 +471,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     for (int e = 0; e < sym(D); ++e) wst(out, (D + e) * rb, bo, S0[e]);
 
     // ---- 3. dynamics push-through (i2c.py:415-421) and smoother gain (i2c.py:423-425) --
+    sched_fence<(D >= 6)>();
     R Sxy[D * NX];
     {
       R L[sym(D)], rinv[D];
@@ -465,18 +481,26 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       sp_transform<M, DenseStruct<D>, D, NX, true>(c.rule_xu, mu0, S0, L, DynamicsF<M, R>{c.params}, mu_x, sig_x, Sxy);
     }
 #pragma unroll
-    for (int i = 0; i < sym(NX); ++i) sig_x[i] += c.rule_xu.W * c.sig_eta[i];
+    for (int i = 0; i < sym(NX); ++i) sig_x[i] += c.sig_eta_w[i];  // sum_p w_p sig_eta (quadrature.py:57)
     R L3[sym(NX)], rinv3[NX];
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) L3[i] = sig_x[i];
     if (!chol<NX>(L3, rinv3)) set_status(a.status, b, 5, t);
+    sched_fence<(D >= 6)>();
 #pragma unroll
     for (int i = 0; i < D; ++i) {  // J = sig_xy sig_x3^{-1}, row by row
       fsub<NX>(L3, rinv3, &Sxy[i * NX]);
       bsub<NX>(L3, rinv3, &Sxy[i * NX]);
+      sched_fence<(D >= 6)>();
     }
 
-    // ---- 4. terminal cost observation on the last cell, after J (i2c.py:430-443) -------
+    // J is written out BEFORE the terminal update so that its d*nx registers are dead there (with J
+    // live the terminal block is the register peak of the large models and spills to scratch)
+#pragma unroll
+    for (int e = 0; e < D * NX; ++e) wst(out, (D + sym(D) + NX + sym(NX) + e) * rb, bo, Sxy[e]);
+    sched_fence<(D >= 6)>();
+
+    // ---- 4. terminal cost observation on the flagged cell, after J (i2c.py:430-443) ----
     if (NZT > 0 && t == c.terminal_cell && c.has_Qf) {
       constexpr int NT = C::NZT1;
       R mzt[NT], Szt[sym(NT)], Sxzt[NX * NT];
@@ -489,13 +513,13 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     for (int e = 0; e < NX; ++e) wst(out, (D + sym(D) + e) * rb, bo, mu_x[e]);
 #pragma unroll
     for (int e = 0; e < sym(NX); ++e) wst(out, (D + sym(D) + NX + e) * rb, bo, sig_x[e]);
-#pragma unroll
-    for (int e = 0; e < D * NX; ++e) wst(out, (D + sym(D) + NX + sym(NX) + e) * rb, bo, Sxy[e]);
 
+    if (PREFETCH) {
 #pragma unroll
-    for (int e = 0; e < C::E_PRI; ++e) pri[e] = nxt[e];
+      for (int e = 0; e < C::E_PRI; ++e) pri[e] = nxt[e];
 #pragma unroll
-    for (int k = 0; k < NZ; ++k) zt[k] = zn[k];
+      for (int k = 0; k < NZ; ++k) zt[k] = zn[k];
+    }
   }
 }
 
@@ -1052,7 +1076,7 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
 
     sp_transform<M, DenseStruct<D>, D, NX, false>(c.rule_xu, mu0, S0, L0, DynamicsF<M, R>{c.params}, mu_x, sig_x, (R*)nullptr);
 #pragma unroll
-    for (int i = 0; i < sym(NX); ++i) sig_x[i] += c.rule_xu.W * c.sig_eta[i];
+    for (int i = 0; i < sym(NX); ++i) sig_x[i] += c.sig_eta_w[i];
 #pragma unroll
     for (int e = 0; e < NX; ++e) out[(long)(D + sym(D) + e) * B] = mu_x[e];
 #pragma unroll

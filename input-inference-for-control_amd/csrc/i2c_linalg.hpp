@@ -158,6 +158,25 @@ I2C_FN void wst(const Window& w, unsigned row_off, unsigned lane_off, float v) {
 }
 #endif
 
+// Scheduling fence for the LARGE models only: the cell is thousands of fully unrolled straight-line
+// instructions; left alone the scheduler interleaves independent columns / phases for ILP and the
+// live ranges overflow 512 VGPRs into scratch. A fence per column / phase bounds the live state.
+template <bool ON> I2C_FN void sched_fence() {
+#ifndef I2C_HOST_SIM
+  if (ON) __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// Makes a per-lane value opaque to loop-invariant code motion. Products like alpha * sig_xi0[i]
+// (alpha fixed per trajectory, sig_xi0 a kernel-argument constant) are otherwise hoisted out of the
+// time loop and pinned in dozens of VGPRs for the whole sweep; recomputing them per cell is one FMA.
+template <typename R> I2C_FN R opaque(R x) {
+#ifndef I2C_HOST_SIM
+  asm volatile("" : "+v"(x));
+#endif
+  return x;
+}
+
 template <typename R> I2C_FN R r_clip(R x, R lo, R hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // In-place Cholesky of a packed SPD matrix: a <- L (lower), rinv[j] = 1 / L[j][j].

@@ -1,0 +1,56 @@
+"""Time one EM iteration (forward / backward / M-step) for any model:  python tools/bench_models.py [model ...]"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "input-inference-for-control_amd")]
+pkg = importlib.import_module("input-inference-for-control_amd")
+from i2c.known_models import make_env_model  # noqa: E402
+
+CONFIGS = {  # hyper-parameters of the reference's experiment files
+    "PendulumKnown": dict(T=200, Q=np.diag([1, 100.0, 1]), R=np.diag([2.0]), alpha=100.0, tol=0.0, sig_u=2.0, mu_u=1e-2),
+    "CartpoleKnown": dict(T=500, Q=np.diag([1.0, 1.0, 100.0, 10.0, 1.0]), R=np.diag([1.0]), alpha=80.0, tol=0.0, sig_u=1.0, mu_u=1e-3),
+    "DoubleCartpoleKnown": dict(T=300, Q=1e-3 * np.diag([1.0, 1.0, 100.0, 1.0, 100.0, 10.0, 1.0, 1.0]), R=1e-3 * np.diag([0.1]),
+                                alpha=0.05, tol=0.99, sig_u=1.0, mu_u=1e-2),
+    "PlanarQuadrotor": dict(T=50, Q=np.diag([1e3, 1e3, 1e3, 1, 1, 1]) / 1e3, R=np.diag([1e-3, 1e-3]), alpha=1.0, tol=1.0,
+                            sig_u=1e-2, mu_u=0.0),
+}
+
+
+def run(name, B, dtype, iters=10, mode="auto"):
+    cfg = CONFIGS[name]
+    model = make_env_model(name)
+    T, nu = cfg["T"], model.dim_u
+    rng = np.random.default_rng(0)
+    x0 = np.asarray(model.x0, float).reshape(1, -1) + 1e-3 * rng.normal(size=(B, model.dim_x))
+    base = 0.5 * model.gravity if name == "PlanarQuadrotor" else 0.0
+    mu_u = base + cfg["mu_u"] * rng.normal(size=(B, T, nu))
+    eng = pkg.BatchedI2c(model, T, cfg["Q"], cfg["R"], cfg["Q"], cfg["alpha"], cfg["tol"], mu_u, cfg["sig_u"] * np.eye(nu), x0=x0,
+                         dtype=dtype, keep_zpost=False, keep_xm=False, backward_mode=mode)
+    for _ in range(3):
+        eng.learn_msgs()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(iters)]
+    torch.cuda.synchronize()
+    for i in range(iters):
+        ev[i][0].record(); eng.forward_sweep(); ev[i][1].record(); eng.backward_sweep(); ev[i][2].record(); eng.maximize(); ev[i][3].record()
+    torch.cuda.synchronize()
+    ms = [np.mean([ev[i][j].elapsed_time(ev[i][j + 1]) for i in range(iters)]) for j in range(3)]
+    d = eng.dims
+    w = 8 if dtype == torch.float64 else 4
+    el = (d.e_post - nu - nu * (nu + 1) // 2) + 2 * d.e_fwd + d.e_post
+    tot = sum(ms)
+    print(f"{name:22s} B={B:6d} T={T:3d} {str(dtype)[6:]:8s} fwd {ms[0]:8.3f} bwd {ms[1]:8.3f} mstep {ms[2]:6.3f} ms | "
+          f"{B * T / tot * 1e3:10.3e} msg/s | {el * w * B * T / tot / 1e6:8.1f} GB/s | fails {len(eng.failures())}")
+
+
+if __name__ == "__main__":
+    names = [a for a in sys.argv[1:] if a in CONFIGS] or list(CONFIGS)
+    Bs = [int(a) for a in sys.argv[1:] if a.isdigit()] or [4096]
+    for n in names:
+        for B in Bs:
+            for dt in (torch.float64, torch.float32):
+                run(n, B, dt)
