@@ -95,6 +95,8 @@ class BatchedI2c:
         R = np.atleast_2d(np.asarray(R, dtype=np.float64))
         if Q is not None:
             Q = np.atleast_2d(np.asarray(Q, dtype=np.float64))
+            assert Q.shape[0] == Q.shape[1] and R.shape[0] == R.shape[1] and Q.shape[0] + R.shape[0] == nz, (
+                f"blkdiag(Q, R) must be ({nz},{nz}), got Q {Q.shape}, R {R.shape}")
             QR = np.zeros((nz, nz))
             QR[: Q.shape[0], : Q.shape[0]] = Q
             QR[Q.shape[0]:, Q.shape[0]:] = R

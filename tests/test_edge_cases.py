@@ -1,0 +1,85 @@
+"""Edge cases of the hot path: shortest horizons, single trajectory, ragged batches, argument
+validation. CPU (host simulation of the kernels) against the oracle; GPU twins marked gpu."""
+import numpy as np
+import pytest
+import torch
+
+import hostsim
+import parity
+from golden_util import Case, assert_close, load_case, oracle_from_case
+
+
+def _short_case(T):
+    g = load_case("em_pendulum_T40_quad_general")
+    meta = dict(g.meta, T=T)
+    import json
+
+    return Case({**g, "meta": np.array(json.dumps(meta)), "mu_u": g["mu_u"][:T]})
+
+
+def _check(lib, device, T, B, mode):
+    g = _short_case(T)
+    x0, mu_u = parity.batched_inputs(g, B)
+    eng = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u, backward_mode=mode)
+    o = oracle_from_case(Case({**g, "mu_u": mu_u}), x0=x0)
+    for it in range(3):
+        eng.learn_msgs()
+        o.learn_msgs()
+        mu, sig = eng.marginal_state_action()
+        assert_close(parity.np_(mu), o.mu_xu0_m, 1e-9, f"T={T} B={B} it{it} mu")
+        assert_close(parity.np_(sig), o.sig_xu0_m, 1e-9, f"T={T} B={B} it{it} sig")
+        assert_close(parity.np_(eng.alpha), o.alpha, 1e-9, f"T={T} B={B} it{it} alpha")
+        assert_close(parity.np_(eng.costs_m[-1]), o.costs_m[-1], 1e-9, f"T={T} B={B} it{it} cost")
+    assert eng.failures() == []
+
+
+@pytest.mark.parametrize("T,B,mode", [(1, 1, "two_pass"), (1, 3, "fused"), (2, 65, "two_pass"), (3, 129, "fused"), (5, 1, "auto")])
+def test_short_horizons_and_ragged_batches_cpu(T, B, mode):
+    _check(hostsim.load(), "cpu", T, B, mode)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B,mode", [(1, 1, "two_pass"), (1, 3, "fused"), (2, 65, "two_pass"), (3, 129, "fused"), (7, 1000, "auto")])
+def test_short_horizons_and_ragged_batches_gpu(T, B, mode):
+    _check(None, "cuda", T, B, mode)
+
+
+def test_constructor_validation():
+    lib = hostsim.load()
+    g = load_case("em_pendulum_T200")
+    m = parity.product_model(g)
+    ok = dict(lib=lib, device="cpu")
+    with pytest.raises(AssertionError):  # mu_u horizon mismatch
+        parity.pkg.BatchedI2c(m, 10, g["Q"], g["R"], g["Qf"], 1.0, 0.0, np.zeros((9, 1)), np.eye(1), **ok)
+    with pytest.raises(AssertionError):  # Q / R of the wrong size for dim_z
+        parity.pkg.BatchedI2c(m, 10, np.eye(2), g["R"], None, 1.0, 0.0, np.zeros((10, 1)), np.eye(1), **ok)
+    with pytest.raises(AssertionError):  # non-symmetric cost
+        parity.pkg.BatchedI2c(m, 10, np.array([[1, 2, 0], [0, 1, 0], [0, 0, 1.0]]), g["R"], None, 1.0, 0.0, np.zeros((10, 1)),
+                              np.eye(1), **ok)
+    with pytest.raises(TypeError):  # covariance control needs both terminal moments (the reference crashes, i2c.py:558)
+        parity.pkg.BatchedI2c(m, 10, g["Q"], g["R"], None, 1.0, 0.0, np.zeros((10, 1)), np.eye(1), None, 1e-3 * np.eye(2), **ok)
+    e = parity.pkg.BatchedI2c(m, 10, g["Q"], g["R"], None, 1.0, 0.0, np.zeros((10, 1)), np.eye(1), batch=7, **ok)
+    assert e.B == 7 and not e.has_Qf and e.post.shape == (10, 13, 7) and e.fwd.shape == (10, 20, 7)
+
+
+def test_alpha_is_per_trajectory():
+    """Each trajectory has its own temperature: different alpha0 per lane, same problem."""
+    lib = hostsim.load()
+    g = _short_case(20)
+    B = 4
+    alpha0 = np.array([10.0, 100.0, 300.0, 1000.0])
+    eng = parity.pkg.BatchedI2c(parity.product_model(g), 20, g["Q"], g["R"], g["Qf"], alpha0, 0.5, g["mu_u"], g["sig_u"],
+                                quad=tuple(g.meta["quad"]), batch=B, lib=lib, device="cpu")
+    singles = []
+    for a in alpha0:
+        s = parity.pkg.BatchedI2c(parity.product_model(g), 20, g["Q"], g["R"], g["Qf"], float(a), 0.5, g["mu_u"], g["sig_u"],
+                                  quad=tuple(g.meta["quad"]), lib=lib, device="cpu")
+        for _ in range(3):
+            s.learn_msgs()
+        singles.append(s)
+    for _ in range(3):
+        eng.learn_msgs()
+    for b, s in enumerate(singles):
+        assert torch.equal(eng.post[:, :, b], s.post[:, :, 0])
+        assert torch.equal(eng.alpha[b], s.alpha[0])
+    assert len(set(eng.alpha.tolist())) == B
