@@ -357,7 +357,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
   const unsigned long B = c.B;
   const int T = c.T;
   const unsigned bo = (unsigned)b * W;     // the lane's byte offset inside any row
-  const unsigned rb = (unsigned)(B * W);   // bytes per row (wave-uniform)
+  const unsigned rb0 = (unsigned)(B * W);  // bytes per row (wave-uniform)
   const R alpha_traj = a.alpha[b];
 
   R mu_x[NX], sig_x[sym(NX)];
@@ -369,6 +369,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
   // software prefetch of the next cell's prior rows: the loads do not depend on the recursion
   R pri[C::E_PRI], zt[NZ];
   {
+    const unsigned rb = rb0;
     const Window w = make_window(a.prior, (unsigned long)C::E_POST * rb);
 #pragma unroll
     for (int e = 0; e < C::E_PRI; ++e) pri[e] = wld<R>(w, e * rb, bo);
@@ -377,20 +378,15 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
   for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[(long)k * B + b] : c.zg[k];
 
   for (int t = 0; t < T; ++t) {
-    R nxt[C::E_PRI], zn[NZ];
     const int tn = t + 1 < T ? t + 1 : t;
-    // Small models prefetch the next cell's prior rows a whole cell ahead (the loads do not depend on
-    // the recursion). For d >= 6 those d + s(d) + nu nx doubles would sit on top of a register peak that
-    // already fills the 512-VGPR file, so the rows are simply loaded at the top of their own cell: one
-    // exposed HBM round trip (~1 us) per ~15 us cell instead of scratch traffic throughout.
+    const unsigned rb = opaque_uniform(rb0);  // see opaque_uniform(): no hoisting of e * rb
+    // Small models fetch the NEXT cell's prior rows right after this cell has consumed its own (below),
+    // straight into the same registers: a whole cell ahead of their use, no copies. For d >= 6 those
+    // d + s(d) + nu nx doubles would sit on top of a register peak that already fills the 512-VGPR file,
+    // so the rows are loaded at the top of their own cell instead: one exposed HBM round trip (~1 us) per
+    // ~15 us cell rather than scratch traffic throughout.
     constexpr bool PREFETCH = C::D <= 5;
-    if (PREFETCH) {
-      const Window w = make_window(a.prior + (unsigned long)tn * C::E_POST * B, (unsigned long)C::E_POST * rb);
-#pragma unroll
-      for (int e = 0; e < C::E_PRI; ++e) nxt[e] = wld<R>(w, e * rb, bo);
-#pragma unroll
-      for (int k = 0; k < NZ; ++k) zn[k] = c.z_per_cell ? a.z[((long)tn * NZ + k) * B + b] : c.zg[k];
-    } else if (t > 0) {
+    if (!PREFETCH && t > 0) {
       const Window w = make_window(a.prior + (unsigned long)t * C::E_POST * B, (unsigned long)C::E_POST * rb);
 #pragma unroll
       for (int e = 0; e < C::E_PRI; ++e) pri[e] = wld<R>(w, e * rb, bo);
@@ -450,6 +446,12 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       for (int e = 0; e < sym(D); ++e) wst(w, (D + e) * rb, bo, S0[e]);
     }
 
+    if (PREFETCH) {  // pri is dead from here on: refill it with the next cell's rows
+      const Window w = make_window(a.prior + (unsigned long)tn * C::E_POST * B, (unsigned long)C::E_POST * rb);
+#pragma unroll
+      for (int e = 0; e < C::E_PRI; ++e) pri[e] = wld<R>(w, e * rb, bo);
+    }
+
     // ---- 2. cost "observation": measurement update on z (i2c.py:390-407) --------------
     sched_fence<(D >= 6)>();
     {
@@ -462,6 +464,10 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 #pragma unroll
       for (int i = 0; i < sym(NZ); ++i) Sz[i] += alpha * c.sig_xi0[i];
       if (!kalman_update<D, NZ>(mu0, S0, mz, Sz, Sxz, zt)) set_status(a.status, b, 3, t);
+    }
+    if (PREFETCH && c.z_per_cell) {  // the target is consumed: fetch the next cell's
+#pragma unroll
+      for (int k = 0; k < NZ; ++k) zt[k] = a.z[((long)tn * NZ + k) * B + b];
     }
     // mu0 / S0 now hold mu_xu1_f / sig_xu1_f
     const Window out = make_window(a.fwd + (unsigned long)t * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
@@ -514,12 +520,6 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 #pragma unroll
     for (int e = 0; e < sym(NX); ++e) wst(out, (D + sym(D) + NX + e) * rb, bo, sig_x[e]);
 
-    if (PREFETCH) {
-#pragma unroll
-      for (int e = 0; e < C::E_PRI; ++e) pri[e] = nxt[e];
-#pragma unroll
-      for (int k = 0; k < NZ; ++k) zt[k] = zn[k];
-    }
   }
 }
 

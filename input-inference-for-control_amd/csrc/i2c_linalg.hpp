@@ -170,6 +170,15 @@ template <bool ON> I2C_FN void sched_fence() {
 // Makes a per-lane value opaque to loop-invariant code motion. Products like alpha * sig_xi0[i]
 // (alpha fixed per trajectory, sig_xi0 a kernel-argument constant) are otherwise hoisted out of the
 // time loop and pinned in dozens of VGPRs for the whole sweep; recomputing them per cell is one FMA.
+// Same for a wave-uniform integer (kept in an SGPR): row offsets e * row_bytes are then recomputed by
+// one scalar multiply next to each access instead of being hoisted into ~30 pinned SGPRs, which
+// otherwise starves the constant operands of the fp64 polynomial kernels of scalar registers.
+I2C_FN unsigned opaque_uniform(unsigned x) {
+#ifndef I2C_HOST_SIM
+  asm volatile("" : "+s"(x));
+#endif
+  return x;
+}
 template <typename R> I2C_FN R opaque(R x) {
 #ifndef I2C_HOST_SIM
   asm volatile("" : "+v"(x));
@@ -177,7 +186,13 @@ template <typename R> I2C_FN R opaque(R x) {
   return x;
 }
 
+// clip(x, lo, hi) = min(max(x, lo), hi): two v_max/v_min instead of compare + select chains
+#ifdef I2C_HOST_SIM
 template <typename R> I2C_FN R r_clip(R x, R lo, R hi) { return x < lo ? lo : (x > hi ? hi : x); }
+#else
+I2C_FN double r_clip(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+I2C_FN float r_clip(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+#endif
 
 // In-place Cholesky of a packed SPD matrix: a <- L (lower), rinv[j] = 1 / L[j][j].
 // Returns false if a pivot is not strictly positive (or NaN): the covariance is not PD.
