@@ -229,6 +229,23 @@ int i2c_propagate(const I2cProblem* p, const void* post, void* prop, void* prop_
                   int use_expert_controller, int32_t* status, void* stream);
 
 /*
+ * Policy rollouts through the noisy known model: replaces BaseSim.run / batch_eval
+ * (i2c/env.py:40-103; the reference farms n_eval rollouts out to mp.Pool(10)) for the time-indexed
+ * linear-Gaussian policies of i2c/policy/linear.py, whose parameters are read straight from `post`.
+ * N = n_rollouts * B lanes; rollout n = r * B + b is the r-th rollout of trajectory b.
+ *   policy   0: u = K_t x + k_t                       (TimeIndexedLinearGaussianPolicy, linear.py:31-43)
+ *            1: u = mu_u,t + exp(-e) K_t (x - mu_x,t), e = (x-mu)^T sig_x,t^{-1} (x-mu) / 2  (expert, soft)
+ *            2: as 1 with weight [e < 3]               (expert, hard; linear.py:73-90)
+ *   eps_x0 [nx][N], eps_x [T][nx][N], eps_u [T][nu][N]: standard-normal samples, each optional (NULL =
+ *            no noise of that kind): x0 ~ N(x0, sig_x0) (env.py:195-197), x' += chol(sig_eta) eps
+ *            (env.py:184-186), u += chol(sigK) eps (linear.py:39-41)
+ *   xu [T][d][N], z [T][nz][N], x_final [nx][N], z_term [nzt][N]: outputs, each optional
+ */
+int i2c_rollout(const I2cProblem* p, const void* post, int n_rollouts, int policy, const void* eps_x0,
+                const void* eps_x, const void* eps_u, void* xu, void* z, void* x_final, void* z_term,
+                void* stream);
+
+/*
  * One cubature-Kalman-filter step of the MPC state estimator: replaces
  * PartiallyObservedMpcPolicy.filter (i2c/policy/mpc.py:125-145; duplicate in
  * scripts/mpc_state_est/mpc_quad.py:135-155): predict the belief N(mu, cov) through sys.forward

@@ -92,6 +92,11 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void k_ckf(const Consts<M, R> c, const
   const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
   if (b < c.B) ckf_filter_body<M, R>(c, z.v, a, b);
 }
+template <class M, typename R>
+__global__ __launch_bounds__(SWEEP_BLOCK) void k_rollout(const Consts<M, R> c, const RolloutArgs<R> a) {
+  const long n = (long)blockIdx.x * SWEEP_BLOCK + threadIdx.x;
+  if (n < (long)a.n_rollouts * c.B) rollout_body<M, R>(c, a, (int)n);
+}
 static int launch_status() { return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH; }
 #endif
 
@@ -253,6 +258,24 @@ template <class M, typename R> struct Impl {
 #endif
   }
 
+  static int rollout(const I2cProblem* p, const void* post, int n_rollouts, int policy, const void* eps_x0,
+                     const void* eps_x, const void* eps_u, void* xu, void* z, void* x_final, void* z_term,
+                     void* stream) {
+    const C c = make_consts<M, R>(p, 0.0, 0);
+    RolloutArgs<R> a{(const R*)post, (const R*)p->x0, (const R*)p->sig_x0, (const R*)eps_x0, (const R*)eps_x,
+                     (const R*)eps_u, (R*)xu, (R*)z, (R*)x_final, (R*)z_term, n_rollouts, policy};
+    const long N = (long)n_rollouts * p->B;
+#ifdef I2C_HOST_SIM
+    (void)stream;
+    for (long n = 0; n < N; ++n) rollout_body<M, R>(c, a, (int)n);
+    return I2C_OK;
+#else
+    const int grid = (int)((N + SWEEP_BLOCK - 1) / SWEEP_BLOCK);
+    hipLaunchKernelGGL((k_rollout<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, a);
+    return launch_status();
+#endif
+  }
+
   static int propagate(const I2cProblem* p, const void* post, void* prop, void* prop_stats, int use_expert,
                        int32_t* status, void* stream) {
     const C c = make_consts<M, R>(p, 0.0, use_expert);
@@ -360,6 +383,12 @@ int i2c_propagate(const I2cProblem* p, const void* post, void* prop, void* prop_
                   int32_t* status, void* stream) {
   if (!post || !prop || !prop_stats || !status) return I2C_EINVAL;
   I2C_DISPATCH(p, propagate(p, post, prop, prop_stats, use_expert_controller, status, stream));
+}
+
+int i2c_rollout(const I2cProblem* p, const void* post, int n_rollouts, int policy, const void* eps_x0,
+                const void* eps_x, const void* eps_u, void* xu, void* z, void* x_final, void* z_term, void* stream) {
+  if (!post || n_rollouts < 1 || policy < 0 || policy > 2) return I2C_EINVAL;
+  I2C_DISPATCH(p, rollout(p, post, n_rollouts, policy, eps_x0, eps_x, eps_u, xu, z, x_final, z_term, stream));
 }
 
 int i2c_ckf_filter(const I2cProblem* p, const double* sig_zeta, const void* y, const void* u, void* mu, void* cov,

@@ -1136,4 +1136,136 @@ I2C_HD inline void ckf_filter_body(const Consts<M, R>& c, const R* sig_zeta, con
   if (!ok) set_status(a.status, b, 9, 0);
 }
 
+// ------------------------------------------------------------------------------------------
+// Policy rollouts through the (noisy) known model: replaces BaseSim.run / batch_eval
+// (i2c/env.py:40-103, BaseKnownSim.forward :180-187) driven by the time-indexed linear-Gaussian
+// policies of i2c/policy/linear.py. One lane per rollout n = r * B + b (r-th rollout of trajectory
+// b), T sequential steps; the disturbance samples are supplied by the caller as standard normals so
+// that a rollout is a deterministic function of its inputs.
+// ------------------------------------------------------------------------------------------
+template <typename R> struct RolloutArgs {
+  const R* post;     // [T][E_POST][B]  posterior + controller written by the backward sweep
+  const R* x0;       // [NX][B]
+  const R* sig_x0;   // [sym NX][B]
+  const R* eps_x0;   // [NX][N] or null: x0 ~ N(x0, sig_x0) (BaseLinear.init_env, env.py:195-197)
+  const R* eps_x;    // [T][NX][N] or null: process noise chol(sig_eta) eps (env.py:184-186)
+  const R* eps_u;    // [T][NU][N] or null: action noise chol(sigK) eps (linear.py:36-41, 86-90)
+  R* xu;             // [T][D][N]  or null: (x_t, u_t)                      (env.py:66-68)
+  R* z;              // [T][NZ][N] or null: observe(x_t, u_t)               (env.py:70)
+  R* x_final;        // [NX][N]    or null: state after the last step
+  R* z_term;         // [NZT][N]   or null: observe_terminal(x_T)           (env.py:73)
+  int n_rollouts;    // N = n_rollouts * B
+  int policy;        // 0: u = K x + k (TimeIndexedLinearGaussianPolicy); 1: expert, soft weight;
+                     // 2: expert, hard weight (ExpertTimeIndexedLinearGaussianPolicy, linear.py:46-90)
+};
+
+template <class M, typename R>
+I2C_HD inline void rollout_body(const Consts<M, R>& c, const RolloutArgs<R>& a, const int n) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D, NA1 = M::NA > 0 ? M::NA : 1;
+  const long B = c.B, N = (long)a.n_rollouts * B;
+  const int b = n % c.B;
+  const int T = c.T;
+  R x[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) x[i] = a.x0[i * B + b];
+  if (a.eps_x0) {
+    R L[sym(NX)], rinv[NX];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) L[i] = a.sig_x0[i * B + b];
+    chol<NX>(L, rinv);
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) x[i] += L[tri(i, j)] * a.eps_x0[(long)j * N + n];
+  }
+  R Le[sym(NX)], rinv_e[NX];  // chol(sig_eta), constant
+#pragma unroll
+  for (int i = 0; i < sym(NX); ++i) Le[i] = c.sig_eta[i];
+  if (a.eps_x) chol<NX>(Le, rinv_e);
+
+  for (int t = 0; t < T; ++t) {
+    const R* row = a.post + ((long)t * C::E_POST) * B + b;
+    R u[NU], Kc[NU * NX];
+#pragma unroll
+    for (int e = 0; e < NU * NX; ++e) Kc[e] = row[(long)(D + sym(D) + e) * B];
+    if (a.policy == 0) {  // u = K x + k
+#pragma unroll
+      for (int p = 0; p < NU; ++p) {
+        R v = row[(long)(C::E_PRI + p) * B];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) v += Kc[p * NX + k] * x[k];
+        u[p] = v;
+      }
+    } else {  // u = mu_u + w K (x - mu_x), w = exp(-maha/2) (soft) or [maha/2 < 3] (hard); lam = sig_x^{-1}
+      R dlt[NX], q[NX], S[sym(NX)], rinv[NX];
+#pragma unroll
+      for (int k = 0; k < NX; ++k) q[k] = dlt[k] = x[k] - row[(long)k * B];
+#pragma unroll
+      for (int k = 0; k < sym(NX); ++k) S[k] = row[(long)(D + k) * B];
+      chol<NX>(S, rinv);
+      fsub<NX>(S, rinv, q);
+      R half = R(0);
+#pragma unroll
+      for (int k = 0; k < NX; ++k) half += q[k] * q[k];
+      half *= R(0.5);
+      const R w = a.policy == 1 ? r_exp(-half) : (half < R(3) ? R(1) : R(0));
+#pragma unroll
+      for (int p = 0; p < NU; ++p) {
+        R v = R(0);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) v += Kc[p * NX + k] * dlt[k];
+        u[p] = row[(long)(NX + p) * B] + w * v;
+      }
+    }
+    if (a.eps_u) {  // u += chol(sigK) eps
+      R Lk[sym(NU)], rk[NU];
+#pragma unroll
+      for (int k = 0; k < sym(NU); ++k) Lk[k] = row[(long)(C::E_PRI + NU + k) * B];
+      chol<NU>(Lk, rk);
+#pragma unroll
+      for (int p = 0; p < NU; ++p)
+#pragma unroll
+        for (int q2 = 0; q2 <= p; ++q2) u[p] += Lk[tri(p, q2)] * a.eps_u[((long)t * NU + q2) * N + n];
+    }
+    R xu[D], sn[NA1], cs[NA1], zt[NZ], xn[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xu[i] = x[i];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) xu[NX + i] = u[i];
+#pragma unroll
+    for (int q2 = 0; q2 < M::NA; ++q2) r_sincos(xu[M::ang(q2)], &sn[q2], &cs[q2]);
+    M::observe(c.params, xu, sn, cs, zt);
+    M::dynamics(c.params, xu, sn, cs, xn);
+    if (a.xu) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) a.xu[((long)t * D + i) * N + n] = xu[i];
+    }
+    if (a.z) {
+#pragma unroll
+      for (int i = 0; i < NZ; ++i) a.z[((long)t * NZ + i) * N + n] = zt[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = xn[i];
+    if (a.eps_x) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) x[i] += Le[tri(i, j)] * a.eps_x[((long)t * NX + j) * N + n];
+    }
+  }
+  if (a.x_final) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) a.x_final[(long)i * N + n] = x[i];
+  }
+  if (NZT > 0 && a.z_term) {
+    R sn[NA1], cs[NA1], zT[C::NZT1];
+#pragma unroll
+    for (int q2 = 0; q2 < M::NA; ++q2) r_sincos(x[M::ang(q2)], &sn[q2], &cs[q2]);
+    M::observe_terminal(c.params, x, sn, cs, zT);
+#pragma unroll
+    for (int i = 0; i < NZT; ++i) a.z_term[(long)i * N + n] = zT[i];
+  }
+}
+
 }  // namespace i2c

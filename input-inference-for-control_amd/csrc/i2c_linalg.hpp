@@ -54,6 +54,18 @@ I2C_FN float r_exp(float x) { return expf(x); }
 I2C_FN void r_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
 #endif
 
+// Horner step p * z + c with a CONSTANT addend. hipcc otherwise emits v_mov_b64 (copy the constant) +
+// v_fmac_f64 (2-address form) for every step; the 3-address v_fma_f64 needs no copy.
+#ifdef I2C_HOST_SIM
+I2C_FN double p_fma(double p, double z, double c) { return std::fma(p, z, c); }
+#else
+I2C_FN double p_fma(double p, double z, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "v"(c));
+  return r;
+}
+#endif
+
 // 1/sqrt(x): ~2^-23 seed + one cubically convergent correction (relative error ~ e^3).
 I2C_FN double r_rsqrt(double x) {
   const double y = seed_rsq(x);
@@ -79,16 +91,16 @@ I2C_FN void r_sincos(double x, double* s, double* c) {
   r = m_fma(-n, 6.07710050630396597660e-11, r);
   r = m_fma(-n, 2.02226624871116645580e-21, r);
   const double z = r * r;
-  double ps = m_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  ps = m_fma(z, ps, 2.75573137070700676789e-06);
-  ps = m_fma(z, ps, -1.98412698298579493134e-04);
-  ps = m_fma(z, ps, 8.33333333332248946124e-03);
+  double ps = p_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = p_fma(ps, z, 2.75573137070700676789e-06);
+  ps = p_fma(ps, z, -1.98412698298579493134e-04);
+  ps = p_fma(ps, z, 8.33333333332248946124e-03);
   const double sr = m_fma(z * r, m_fma(z, ps, -1.66666666666666324348e-01), r);
-  double pc = m_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  pc = m_fma(z, pc, -2.75573143513906633035e-07);
-  pc = m_fma(z, pc, 2.48015872894767294178e-05);
-  pc = m_fma(z, pc, -1.38888888888741095749e-03);
-  pc = m_fma(z, pc, 4.16666666666666019037e-02);
+  double pc = p_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = p_fma(pc, z, -2.75573143513906633035e-07);
+  pc = p_fma(pc, z, 2.48015872894767294178e-05);
+  pc = p_fma(pc, z, -1.38888888888741095749e-03);
+  pc = p_fma(pc, z, 4.16666666666666019037e-02);
   const double cr = 1.0 - m_fma(0.5, z, -(z * z) * pc);
   const int q = (int)n;
   const double ss = (q & 1) ? cr : sr;
@@ -103,16 +115,16 @@ I2C_FN void r_sincos_small(double x, double* s, double* c) {
     return;
   }
   const double z = x * x;
-  double ps = m_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  ps = m_fma(z, ps, 2.75573137070700676789e-06);
-  ps = m_fma(z, ps, -1.98412698298579493134e-04);
-  ps = m_fma(z, ps, 8.33333333332248946124e-03);
+  double ps = p_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = p_fma(ps, z, 2.75573137070700676789e-06);
+  ps = p_fma(ps, z, -1.98412698298579493134e-04);
+  ps = p_fma(ps, z, 8.33333333332248946124e-03);
   *s = m_fma(z * x, m_fma(z, ps, -1.66666666666666324348e-01), x);
-  double pc = m_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  pc = m_fma(z, pc, -2.75573143513906633035e-07);
-  pc = m_fma(z, pc, 2.48015872894767294178e-05);
-  pc = m_fma(z, pc, -1.38888888888741095749e-03);
-  pc = m_fma(z, pc, 4.16666666666666019037e-02);
+  double pc = p_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = p_fma(pc, z, -2.75573143513906633035e-07);
+  pc = p_fma(pc, z, 2.48015872894767294178e-05);
+  pc = p_fma(pc, z, -1.38888888888741095749e-03);
+  pc = p_fma(pc, z, 4.16666666666666019037e-02);
   *c = 1.0 - m_fma(0.5, z, -(z * z) * pc);
 }
 I2C_FN void r_sincos_small(float x, float* s, float* c) { r_sincos(x, s, c); }

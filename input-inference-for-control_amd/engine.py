@@ -389,6 +389,37 @@ class BatchedI2c:
         else:
             self.z.copy_(zt)
 
+    def rollout(self, n_rollouts=1, policy="linear", process_noise=True, action_noise=False, sample_x0=False,
+                generator=None, want=("xu", "z", "x_final", "z_term")):
+        """Simulate the current controllers through the noisy model (env.batch_eval, i2c/env.py:93-103):
+        n_rollouts per trajectory, all B * n_rollouts in one launch. Returns a dict of (R, B, T, ...) tensors."""
+        N, T, dev, dt = int(n_rollouts) * self.B, self.H, self.device, self.dtype
+        code = {"linear": 0, "expert": 1, "expert_soft": 1, "expert_hard": 2}[policy]
+        rnd = lambda *s: torch.randn(*s, dtype=dt, device=dev, generator=generator)  # noqa: E731
+        eps_x0 = rnd(self.nx, N) if sample_x0 else None
+        eps_x = rnd(T, self.nx, N) if process_noise else None
+        eps_u = rnd(T, self.nu, N) if action_noise else None
+        out = {
+            "xu": torch.empty(T, self.d, N, dtype=dt, device=dev) if "xu" in want else None,
+            "z": torch.empty(T, self.nz, N, dtype=dt, device=dev) if "z" in want else None,
+            "x_final": torch.empty(self.nx, N, dtype=dt, device=dev) if "x_final" in want else None,
+            "z_term": torch.empty(self.nzt, N, dtype=dt, device=dev) if ("z_term" in want and self.nzt > 0) else None,
+        }
+        rc = self.lib.i2c_rollout(C.byref(self._problem), self._ptr(self.post), int(n_rollouts), code, self._ptr(eps_x0),
+                                  self._ptr(eps_x), self._ptr(eps_u), self._ptr(out["xu"]), self._ptr(out["z"]),
+                                  self._ptr(out["x_final"]), self._ptr(out["z_term"]), self._stream())
+        self._check(rc, "i2c_rollout")
+        R_, B = int(n_rollouts), self.B
+        res = {"eps_x0": eps_x0, "eps_x": eps_x, "eps_u": eps_u}
+        for k, v in out.items():
+            if v is None:
+                res[k] = None
+            elif v.dim() == 3:
+                res[k] = v.reshape(T, v.shape[1], R_, B).permute(2, 3, 0, 1)  # (R, B, T, n)
+            else:
+                res[k] = v.reshape(v.shape[0], R_, B).permute(1, 2, 0)  # (R, B, n)
+        return res
+
     def _terminal_kl(self):
         """mvn_kl_divergence(x3_pf[T-1] || terminal prior) (i2c.py:1012-1019, 1223-1229)."""
         nx = self.nx

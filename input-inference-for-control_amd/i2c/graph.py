@@ -486,7 +486,7 @@ class I2cGraph:
         np.save(os.path.join(res_dir, "xu_plan.npy"), np.hstack((sq(mu[..., :nx]), sq(mu[..., nx:]))) if self.B == 1 else mu)
         np.save(os.path.join(res_dir, "x_plan.npy"), sq(mu[..., :nx]))
         np.save(os.path.join(res_dir, "u_plan.npy"), sq(mu[..., nx:]))
-        np.save(os.path.join(res_dir, "z_plan.npy"), self._squeeze(mz))
+        np.save(os.path.join(res_dir, "z_plan.npy"), sq(mz))
 
     def state_dict(self):
         """Tensors that define the solver state (replaces the reference's whole-object dill pickle)."""

@@ -1,53 +1,90 @@
-"""Time-indexed linear-Gaussian policies that consume the solver's (K, k, sigK) output
-(reference i2c/policy/linear.py:9-90). Host-side consumers of the hot path's result."""
+"""Time-indexed linear-Gaussian policies that consume the solver's (K, k, sigK) output -- same class
+names, constructor and attributes as the reference (i2c/policy/linear.py:9-90). Called step by step
+they run on the host (NumPy); handed to `env.batch_eval` they are recognised and the whole batch of
+rollouts runs in one GPU launch (`i2c_rollout`)."""
 import numpy as np
 
 
 class TimeIndexedLinearGaussianPolicy:
-    """u_t ~ N(K_t x + k_t, sigK_t + sig_u)."""
+    """u_t ~ N(K_t x + k_t, sig_k_t)."""
 
-    def __init__(self, sig_u, horizon, dim_u, dim_x):
-        self.H, self.dim_u, self.dim_x = horizon, dim_u, dim_x
+    device_policy = "linear"
+
+    def __init__(self, sig_u, H, dim_u, dim_x, control_step=1):
+        self.H, self.dim_u, self.dim_x = H, dim_u, dim_x
         self.sig_u = np.asarray(sig_u, dtype=float)
-        self.zero()
+        self.control_step = control_step
+        self.source = None  # the I2cGraph whose controllers were last written (enables the device path)
+        self.init()
 
-    def zero(self):
+    def _blank(self):
         self.K = np.zeros((self.H, self.dim_u, self.dim_x))
         self.k = np.zeros((self.H, self.dim_u))
-        self.sigk = np.zeros((self.H, self.dim_u, self.dim_u))
 
-    def write(self, K, k, sigk):
-        self.K, self.k, self.sigk = np.array(K, dtype=float), np.array(k, dtype=float), np.array(sigk, dtype=float)
-
-    def mean(self, i, x):
-        return self.K[i] @ np.reshape(x, (self.dim_x, 1)) + self.k[i].reshape(self.dim_u, 1)
-
-    def __call__(self, i, x, deterministic=True):
-        mu = self.mean(i, x)
-        if deterministic:
-            return mu
-        cov = self.sigk[i] + self.sig_u
-        return np.random.multivariate_normal(mu[:, 0], cov, 1).reshape(self.dim_u, 1)
-
-
-class ExpertTimeIndexedLinearGaussianPolicy(TimeIndexedLinearGaussianPolicy):
-    """u_t = k_t + w K_t (x - mu_t) with the pdf-ratio weight w = N(x; mu_t, lam_t^-1) / N(mu_t; ...)
-    (`soft=True`) or w = 1; consumes get_local_expert_linear_policy() (reference linear.py:46-90)."""
-
-    def __init__(self, sig_u, horizon, dim_u, dim_x, soft=True):
-        self.soft = soft
-        super().__init__(sig_u, horizon, dim_u, dim_x)
+    def init(self):
+        self._blank()
+        self.sig_k = np.tile(self.sig_u, (self.H, 1, 1))
 
     def zero(self):
-        super().zero()
+        self._blank()
+        self.sig_k = np.zeros((self.H, self.dim_u, self.dim_u))
+        self.source = None
+
+    def write(self, K, k, sig_k):
+        self.K[...] = K
+        self.k[...] = k
+        self.sig_k[...] = sig_k
+
+    def __call__(self, i, x, deterministic=True):
+        assert i < self.H
+        if i % self.control_step == 0:
+            mean = self.K[i] @ x + self.k[i][:, None]
+            self.u = mean if deterministic else np.random.multivariate_normal(mean[:, 0], self.sig_k[i], 1)
+        return self.u
+
+
+class ExpertTimeIndexedLinearGaussianPolicy:
+    """u_t = k_t + p K_t (x - mu_t) with p = exp(-e) (soft) or [|e| < 3] (hard), e = (x-mu)' lam (x-mu) / 2;
+    consumes get_local_expert_linear_policy()."""
+
+    hard_exp_threshold = 3.0
+
+    def __init__(self, sig_u, H, dim_u, dim_x, soft=True):
+        self.H, self.dim_u, self.dim_x = H, dim_u, dim_x
+        self.sig_u = np.asarray(sig_u, dtype=float)
+        self.soft = soft
+        self.source = None
+        self.init()
+
+    @property
+    def device_policy(self):
+        return "expert_soft" if self.soft else "expert_hard"
+
+    def init(self):
+        self.K = np.zeros((self.H, self.dim_u, self.dim_x))
+        self.k = np.zeros((self.H, self.dim_u))
+        self.sig_k = np.tile(self.sig_u, (self.H, 1, 1))
         self.mu = np.zeros((self.H, self.dim_x))
-        self.lam = np.tile(np.eye(self.dim_x), (self.H, 1, 1))
+        self.lam = np.ones((self.H, self.dim_x, self.dim_x))
 
-    def write(self, K, k, sigk, mu, lam):
-        super().write(K, k, sigk)
-        self.mu, self.lam = np.array(mu, dtype=float), np.array(lam, dtype=float)
+    def zero(self):
+        self.init()
+        self.source = None
 
-    def mean(self, i, x):
-        dx = np.reshape(x, (self.dim_x, 1)) - self.mu[i].reshape(self.dim_x, 1)
-        w = float(np.exp(-0.5 * dx.T @ self.lam[i] @ dx)) if self.soft else 1.0
-        return self.k[i].reshape(self.dim_u, 1) + w * (self.K[i] @ dx)
+    def write(self, K, k, sig_k, mu, lam):
+        self.K[...] = K
+        self.k[...] = k
+        self.sig_k[...] = sig_k
+        self.mu[...] = mu
+        self.lam[...] = lam
+
+    def __call__(self, i, x, deterministic=True):
+        assert i < self.H
+        dist = x - self.mu[i][:, None]
+        e = (0.5 * dist.T @ self.lam[i] @ dist).item()
+        p = np.exp(-e) if self.soft else float(abs(e) < self.hard_exp_threshold)
+        mean = self.k[i][:, None] + p * (self.K[i] @ dist)
+        if deterministic:
+            return mean.reshape(self.dim_u, 1)
+        noise = np.random.multivariate_normal(np.zeros(self.dim_u), self.sig_k[i].reshape(self.dim_u, self.dim_u), 1)
+        return mean + noise.reshape(self.dim_u, 1)

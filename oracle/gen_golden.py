@@ -434,6 +434,40 @@ def case_mpc_quadrotor():
     save("mpc_quadrotor_fb", out)
 
 
+def case_i2c_run():
+    """The reference's own runner, scripts/i2c_run.py:run(), on its shipped pendulum config (seed 0,
+    N_INFERENCE cut to 6): what a user sees -- costs_m, alphas, the saved plan and the final policy."""
+    import importlib
+    import tempfile
+
+    np.random.seed(0)  # i2c_run.py:215 set_seed(args.random_seed) happens BEFORE the config import draws mu_u
+    runner = importlib.import_module("i2c_run")
+    experiment = importlib.import_module("experiments.pendulum_known_quad")
+    experiment.N_INFERENCE = 6
+    experiment.N_ITERS_PER_PLOT = 100
+    captured = {}
+    real_graph = runner.I2cGraph
+
+    def capture(*a, **k):
+        captured["i2c"] = real_graph(*a, **k)
+        return captured["i2c"]
+
+    runner.I2cGraph = capture
+    with tempfile.TemporaryDirectory() as res_dir:
+        runner.run(experiment, res_dir, None)
+        out = {k: np.load(os.path.join(res_dir, k + ".npy")) for k in ("xu_plan", "x_plan", "u_plan", "z_plan")}
+    runner.I2cGraph = real_graph
+    g = captured["i2c"]
+    out["mu_u"] = np.asarray(experiment.INFERENCE.mu_u, float)
+    out["costs_m"] = np.asarray(g.costs_m, float)
+    out["alphas"] = np.asarray(g.alphas, float)
+    out["alphas_desired"] = np.asarray(g.alphas_desired, float)
+    K, k, sigK = g.get_local_linear_policy()
+    out["K"], out["k"], out["sigK"] = K, k, sigK
+    out["meta"] = np.array(json.dumps(dict(config="pendulum_known_quad", seed=0, n_inference=6, T=int(experiment.N_DURATION))))
+    save("run_pendulum_seed0", out)
+
+
 CASES = {
     "pendulum": case_pendulum,
     "pendulum_long": case_pendulum_long,
@@ -450,6 +484,7 @@ CASES = {
     "mpc_fb": case_mpc_pendulum_fb,
     "em_quad": case_em_quadrotor,
     "mpc_quad": case_mpc_quadrotor,
+    "i2c_run": case_i2c_run,
 }
 
 if __name__ == "__main__":

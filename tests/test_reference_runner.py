@@ -1,0 +1,71 @@
+"""The drop-in claim, end to end: the REFERENCE's own runner `scripts/i2c_run.py:run()` and its own
+config module `scripts/experiments/pendulum_known_quad.py` executed, unmodified, with this build's
+`i2c` package on sys.path instead of the reference's -- and the numbers it produces compared with
+what the reference produced for the same call (tests/golden/run_pendulum_seed0.npz).
+
+Runs only where the reference checkout exists (this container); on a box without it the test is
+skipped. CPU: the kernels run as the host simulation (injected as the default library for the test)."""
+import importlib
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from golden_util import GOLDEN_DIR, assert_close, load_case
+
+REF = os.environ.get("I2C_REFERENCE_ROOT", "/root/reference")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "scripts")), reason="reference checkout not present")
+def test_reference_i2c_run_against_this_build(tmp_path):
+    script = textwrap.dedent(f"""
+        import importlib, os, sys
+        sys.dont_write_bytecode = True
+        import matplotlib; matplotlib.use("Agg")
+        sys.path[:0] = [{os.path.join(ROOT, "input-inference-for-control_amd")!r}, {ROOT!r}, {os.path.join(ROOT, "tests")!r},
+                        {os.path.join(REF, "scripts")!r}]
+        import numpy as np
+        import i2c
+        assert i2c.__file__.startswith({ROOT!r}), i2c.__file__          # this build's package, not the reference's
+        import hostsim
+        i2c.core._native._default = hostsim.load()                      # test-only: kernels as host simulation
+        np.random.seed(0)                                               # i2c_run.py:215
+        runner = importlib.import_module("i2c_run")                     # the reference's runner, unmodified
+        assert runner.__file__.startswith({REF!r})
+        experiment = importlib.import_module("experiments.pendulum_known_quad")
+        experiment.N_INFERENCE, experiment.N_ITERS_PER_PLOT = 6, 100
+        got = {{}}
+        real = runner.I2cGraph
+        def capture(*a, **k):
+            got["i2c"] = real(*a, **k)
+            return got["i2c"]
+        runner.I2cGraph = capture
+        res_dir = {str(tmp_path)!r}
+        runner.run(experiment, res_dir, None)
+        g = got["i2c"]
+        K, k, sigK = g.get_local_linear_policy()
+        np.savez(os.path.join(res_dir, "out.npz"), costs_m=np.array(g.costs_m), alphas=np.array(g.alphas),
+                 alphas_desired=np.array(g.alphas_desired), K=K, k=k, sigK=sigK, mu_u=np.asarray(experiment.INFERENCE.mu_u))
+    """)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", MPLBACKEND="Agg")
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    ref = load_case("run_pendulum_seed0")
+    out = np.load(os.path.join(tmp_path, "out.npz"))
+    assert np.array_equal(out["mu_u"], ref["mu_u"])  # the config module drew the same initial actions
+    assert_close(out["costs_m"], ref["costs_m"], 1e-8, "costs_m")
+    assert_close(out["alphas"], ref["alphas"], 1e-8, "alphas")
+    assert_close(out["alphas_desired"], ref["alphas_desired"], 1e-8, "alphas_desired")
+    assert_close(out["K"], ref["K"], 1e-6, "K")
+    assert_close(out["k"], ref["k"], 1e-6, "k")
+    assert_close(out["sigK"], ref["sigK"], 1e-6, "sigK")
+    for name in ("xu_plan", "x_plan", "u_plan", "z_plan"):  # the files the runner saved (i2c.py:1374-1382)
+        mine = np.load(os.path.join(tmp_path, name + ".npy"))
+        assert mine.shape == ref[name].shape, (name, mine.shape, ref[name].shape)
+        assert_close(mine, ref[name], 1e-7, name)
+    for name in ("xu_real", "dx_real", "x_real", "u_real"):  # i2c_run.py:176-184
+        assert os.path.exists(os.path.join(tmp_path, name + ".npy"))
