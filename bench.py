@@ -153,12 +153,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if "RANK" in os.environ and "MASTER_ADDR" in os.environ:  # launched by torch.distributed.run (also with N = 1)
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=device)  # RCCL on ROCm
@@ -191,7 +191,9 @@ def main():
     if dist is not None:
         gather_policy = importlib.import_module(PKG + ".dist").gather_policy
 
+        gather_policy(eng)  # first call pays RCCL's lazy channel setup; time the steady-state exchange
         torch.cuda.synchronize(device)
+        dist.barrier()
         t1 = time.perf_counter()
         gathered = gather_policy(eng)
         torch.cuda.synchronize(device)

@@ -53,7 +53,7 @@ def gather_policy(engine, group=None):
         ],
         dim=1,
     ).contiguous()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():  # also with one rank: same code path as N > 1
         flat = _all_gather_rows(flat, group)
     n = flat.shape[0]
     T, nu, nx = engine.H, engine.nu, engine.nx
