@@ -154,7 +154,9 @@ class I2cGraph:
         self.alpha_risk = []
         self.alpha_sigma = 0
         self.policy_valid = False
-        self._x0_seen = None
+        # the engine starts from the constructor's x0 / sig_x0; re-upload only when a caller later CHANGES
+        # sys.x0 / sys.sig_x0 (the MPC protocol, mpc.py:149-150)
+        self._x0_seen = self._x0_key()
         self.reset_metrics(False)
         self.costs_m_all, self.costs_p_all, self.costs_pf_all = [], [], []
         self._cache = {}
@@ -167,13 +169,16 @@ class I2cGraph:
         arr = np.asarray(arr)
         return float(arr.reshape(-1)[0]) if self.B == 1 else arr
 
+    def _x0_key(self):
+        return (np.asarray(self.sys.x0, dtype=float).reshape(-1).tobytes(), np.asarray(self.sys.sig_x0, dtype=float).tobytes())
+
     def _sync_initial_state(self):
         """MPC callers overwrite sys.x0 / sys.sig_x0 between sweeps (mpc.py:149-150)."""
         if self.B != 1:
             return
         x0 = np.asarray(self.sys.x0, dtype=float).reshape(-1)
         s0 = np.asarray(self.sys.sig_x0, dtype=float)
-        key = (x0.tobytes(), s0.tobytes())
+        key = self._x0_key()
         if key != self._x0_seen:
             pack_sym_np = core.engine.pack_sym_np
             e = self.engine

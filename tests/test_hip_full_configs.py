@@ -1,0 +1,103 @@
+"""BASELINE.json's configurations at their FULL sizes on the GPU. The oracle cannot run these sizes in
+seconds, so each test combines (i) an exact comparison with the oracle on a SUBSET of the trajectories
+(trajectories are independent, so lanes b < n of the big batch must equal an n-trajectory run) with
+(ii) size-independent properties: duplicate problems planted at far-apart batch positions give
+bit-identical results, no trajectory fails, temperatures stay per-trajectory."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import parity
+from golden_util import Case, assert_close, load_case, oracle_from_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _with(g, **meta_over):
+    return Case({**g, "meta": np.array(json.dumps(dict(g.meta, **meta_over)))})
+
+
+def _subset_vs_oracle(g, B, n_sub, iters, tol, mode="auto", plant=(), pre_propagate=False):
+    x0, mu_u = parity.batched_inputs(g, B)
+    for b in plant:  # duplicates of trajectory 0 far apart in the batch
+        x0[b], mu_u[b] = x0[0], mu_u[0]
+    eng = parity.engine_from_case(g, None, "cuda", x0=x0, mu_u=mu_u, backward_mode=mode)
+    o = oracle_from_case(Case({**g, "mu_u": mu_u[:n_sub]}), x0=x0[:n_sub])
+    if pre_propagate:
+        eng.propagate()
+        o.propagate()
+    for _ in range(iters):
+        eng.learn_msgs()
+        o.learn_msgs()
+    assert eng.failures() == []
+    mu, sig = eng.marginal_state_action()
+    K, k, sigK = eng.local_linear_policy()
+    assert_close(parity.np_(mu[:n_sub]), o.mu_xu0_m, tol, "posterior mean (subset vs oracle)")
+    assert_close(parity.np_(sig[:n_sub]), o.sig_xu0_m, tol, "posterior covariance (subset vs oracle)")
+    assert_close(parity.np_(K[:n_sub]), o.K, tol * 10, "K (subset vs oracle)")
+    assert_close(parity.np_(eng.alpha[:n_sub]), o.alpha, tol, "alpha (subset vs oracle)")
+    for b in plant:
+        assert torch.equal(eng.post[:, :, 0], eng.post[:, :, b]), f"lane {b} differs from lane 0"
+        assert torch.equal(eng.alpha[0], eng.alpha[b])
+    assert torch.isfinite(eng.post).all()
+    return eng
+
+
+def test_config3_double_cartpole_T300_B4096():
+    g = load_case("em_dcp_T300_run20")
+    _subset_vs_oracle(g, 4096, 16, 3, 1e-6, plant=(1000, 4095))
+
+
+def test_config5_covariance_control_B65536():
+    """Nonlinear covariance control, tempered terminal prior, closed-loop propagation; 65536 trajectories
+    (the 8-GPU shape of BASELINE.json on one GPU), fused backward."""
+    g = load_case("em_covctrl_T100")
+    eng = _subset_vs_oracle(g, 65536, 32, 4, 1e-6, plant=(32768, 65535), pre_propagate=True)
+    assert eng.fused_backward
+    assert float(eng.temp[0]) == 5.0  # temp = 1 + 4 * dtemp (i2c.py:552)
+    kl = eng.history(eng.kl_terms)
+    assert kl.shape == (4, 65536) and np.all(np.isfinite(kl)) and np.median(kl[-1]) < np.median(kl[0])  # KL to the target falls
+
+
+def test_config4_quadrotor_mpc_H50_B8192():
+    """Quadrotor MPC with the cubature-KF state estimator: horizon 50, 8192 closed loops at once."""
+    from i2c.exp_types import CubatureQuadrature
+    from i2c.i2c import I2cGraph
+    from i2c.policy.mpc import PartiallyObservedMpcPolicy
+
+    g = load_case("mpc_quadrotor_fb")
+    H, B, steps = 50, 8192, 3
+    rng = np.random.default_rng(0)
+    model = parity.product_model(g)
+    model.sig_zeta = g["sig_zeta"]
+    mu_u = np.tile(g["mu_u"][:1], (H, 1))
+    z_traj = np.tile(g["z_traj"][:1], (H + steps + 1, 1))
+    z_traj[:, 0] += np.linspace(0, 1.0, H + steps + 1)
+    x0 = np.tile(g["x0"], (B, 1)) + 1e-3 * rng.normal(size=(B, 6))
+    x0[[4000, 8191]] = x0[0]
+
+    def make(batch, x0_):
+        i2c = I2cGraph(model, H, g["Q"], g["R"], g["Qf"], 1.0, 1.0, mu_u, g["sig_u"], None, None, CubatureQuadrature(1, 0, 0),
+                       batch=batch, x0=x0_, device="cuda")
+        i2c._propagate = True
+        pol = PartiallyObservedMpcPolicy(i2c, 2, g["sig_u"], np.copy(z_traj))
+        pol.set_control(feedforward=False)
+        i2c.calibrate_alpha()
+        pol.optimize(5)
+        return i2c, pol
+
+    iB, pB = make(B, x0)
+    i1, p1 = make(1, x0[:1])
+    y = model.measure(x0)
+    u = np.tile(0.5 * model.gravity, (B, 2))
+    for t in range(steps):
+        uB = pB(t, y, u)
+        u1 = p1(t, y[:1], u[:1])
+        assert uB.shape == (B, 2) and np.all(np.isfinite(uB))
+        assert_close(uB[0], u1[:, 0], 1e-9, f"lane 0 of the batch vs the single loop, step {t}")
+        assert np.array_equal(uB[0], uB[4000]) and np.array_equal(uB[0], uB[8191])
+        u = np.clip(uB, 0.0, 30.0)
+        y = model.measure(model.dynamics(np.hstack((pB.mu, u))))
+    assert iB.engine.failures() == []
