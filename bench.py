@@ -184,6 +184,12 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    # the same K iterations enqueued from C++ in ONE call (i2c_learn): no Python between sweeps
+    barrier()
+    t2 = time.perf_counter()
+    eng.learn(K)
+    barrier()
+    fused_loop_ms = (time.perf_counter() - t2) / K * 1e3
     n_fail = len(eng.failures())
 
     # ---- the one collective of the job: all-gather of the final controllers -------
@@ -233,6 +239,7 @@ def main():
         },
         "kernel_ms": {"forward_sweep": fwd_ms, "backward_sweep": bwd_ms, "mstep": mst_ms},
         "backward": "fused" if eng.fused_backward else "two_pass (scan + per-cell + reduce)",
+        "ms_per_step_single_call_loop": fused_loop_ms,
         "failed_trajectories": n_fail,
         "roofline": {
             "kernel": "k_forward (forward sweep, the dominant kernel)",

@@ -216,6 +216,18 @@ int i2c_mstep(const I2cProblem* p, const void* term_stats, double alpha_update_t
               void* stats_out, void* stream);
 
 /*
+ * n_iters complete EM iterations enqueued back to back on `stream` with no host round trip:
+ * replaces a loop over I2cGraph.learn_msgs (i2c.py:1238-1245; scripts/i2c_run.py:89-94) when
+ * closed-loop propagation is off. Per iteration: forward sweep, backward sweep, M-step, and
+ * _update_priors' mode switch (cells 0..tau leave feed-forward mode, i2c.py:1210-1213; `tau` <= 0: none).
+ *   stats_hist [n_iters][4][B] out: the M-step's stats_out of every iteration
+ * Buffers as in the single calls; `prior` and `post` are the same buffer.
+ */
+int i2c_learn(const I2cProblem* p, void* post, void* fwd, void* xm, void* zpost, void* cell_stats,
+              void* term_stats, double alpha_update_tol, int tau, int n_iters, void* stats_hist,
+              int32_t* status, void* stream);
+
+/*
  * Closed-loop propagation of the controller distribution: replaces I2cGraph.propagate
  * (i2c.py:1247-1251) calling I2cCell._propagate_forward_quadrature (i2c.py:150-199), plus the
  * per-cell propagated cost statistics (i2c.py:685-688, 1055-1063).

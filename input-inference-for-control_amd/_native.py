@@ -93,6 +93,10 @@ _SIGNATURES = {
         [C.POINTER(I2cProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
     "i2c_mstep": (C.c_int, [C.POINTER(I2cProblem), C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
+    "i2c_learn": (
+        C.c_int,
+        [C.POINTER(I2cProblem)] + [C.c_void_p] * 6 + [C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
     "i2c_rollout": (C.c_int, [C.POINTER(I2cProblem), C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8),
     "i2c_ckf_filter": (
         C.c_int,

@@ -239,6 +239,29 @@ template <class M, typename R> struct Impl {
 #endif
   }
 
+  static int learn(const I2cProblem* p, void* post, void* fwd, void* xm, void* zpost, void* cell_stats,
+                   void* term_stats, double tol, int tau, int n_iters, void* stats_hist, int32_t* status,
+                   void* stream) {
+    for (int it = 0; it < n_iters; ++it) {
+      int rc = forward(p, post, fwd, nullptr, status, stream);
+      if (rc != I2C_OK) return rc;
+      rc = backward(p, fwd, xm, post, zpost, cell_stats, term_stats, status, stream);
+      if (rc != I2C_OK) return rc;
+      rc = mstep(p, term_stats, tol, 1, (R*)stats_hist + (size_t)it * 4 * p->B, stream);
+      if (rc != I2C_OK) return rc;
+      if (tau > 0) {  // _update_priors: cells with index <= tau switch to feedback mode
+        const size_t n = (size_t)(tau + 1 < p->T ? tau + 1 : p->T);
+#ifdef I2C_HOST_SIM
+        std::memset(const_cast<uint8_t*>(p->feedforward), 0, n);
+#else
+        if (hipMemsetAsync(const_cast<uint8_t*>(p->feedforward), 0, n, (hipStream_t)stream) != hipSuccess)
+          return I2C_ELAUNCH;
+#endif
+      }
+    }
+    return I2C_OK;
+  }
+
   static int ckf(const I2cProblem* p, const double* sig_zeta, const void* y, const void* u, void* mu, void* cov,
                  int32_t* status, void* stream) {
   const Consts<M, R> c = make_consts<M, R>(p, 0.0, 0);
@@ -383,6 +406,13 @@ int i2c_propagate(const I2cProblem* p, const void* post, void* prop, void* prop_
                   int32_t* status, void* stream) {
   if (!post || !prop || !prop_stats || !status) return I2C_EINVAL;
   I2C_DISPATCH(p, propagate(p, post, prop, prop_stats, use_expert_controller, status, stream));
+}
+
+int i2c_learn(const I2cProblem* p, void* post, void* fwd, void* xm, void* zpost, void* cell_stats, void* term_stats,
+              double alpha_update_tol, int tau, int n_iters, void* stats_hist, int32_t* status, void* stream) {
+  if (!post || !fwd || !term_stats || !stats_hist || !status || n_iters < 0) return I2C_EINVAL;
+  I2C_DISPATCH(p, learn(p, post, fwd, xm, zpost, cell_stats, term_stats, alpha_update_tol, tau, n_iters, stats_hist,
+                        status, stream));
 }
 
 int i2c_rollout(const I2cProblem* p, const void* post, int n_rollouts, int policy, const void* eps_x0,

@@ -313,6 +313,32 @@ class BatchedI2c:
             self.propagate()
         self.maximize()
 
+    def learn(self, n_iters):
+        """n_iters EM iterations enqueued from C++ with no host round trip (i2c_learn). Same results as
+        calling learn_msgs() n_iters times; available when closed-loop propagation is off."""
+        n_iters = int(n_iters)
+        if self._propagate or self.prior_out is not None or n_iters <= 0:
+            for _ in range(n_iters):
+                self.learn_msgs()
+            return
+        hist = torch.empty(n_iters, 4, self.B, dtype=self.dtype, device=self.device)
+        rc = self.lib.i2c_learn(C.byref(self._problem), self._ptr(self.post), self._ptr(self.fwd), self._ptr(self.xm),
+                                self._ptr(self.zpost), self._ptr(self.cell_stats), self._ptr(self.term_stats),
+                                self.alpha_update_tol, int(self.tau), n_iters, self._ptr(hist), self._ptr(self.status),
+                                self._stream())
+        self._check(rc, "i2c_learn")
+        self.em_iter += n_iters
+        minus_one = torch.full((self.B,), -1.0, dtype=self.dtype, device=self.device)
+        for it in range(n_iters):
+            self.alphas_desired.append(hist[it, 0])
+            self.alphas.append(hist[it, 1])
+            self.costs_m.append(hist[it, 2])
+            self.costs_m_var.append(hist[it, 3])
+            self.costs_pf.append(minus_one)
+            if self.has_x_terminal:
+                self.kl_terms.append(self._terminal_kl())
+        self._broadcast_alpha()
+
     def calibrate_alpha(self, only_decrease=False):
         """I2cGraph.calibrate_alpha (i2c.py:895-911)."""
         assert self._propagate

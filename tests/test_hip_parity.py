@@ -122,3 +122,18 @@ def test_hip_fp32_runs_and_tracks_fp64(lib):
     m32, _ = e32.marginal_state_action()
     assert e32.failures() == []
     assert_close(m32.double().cpu().numpy(), m64.cpu().numpy(), 5e-2, "fp32 vs fp64 posterior mean")
+
+
+def test_hip_fused_em_loop_matches_stepwise(lib):
+    """i2c_learn (N iterations enqueued from C++) == N x learn_msgs(), including the FF -> FB switch."""
+    g = load_case("em_pendulum_T200")
+    x0, mu_u = parity.batched_inputs(g, 200)
+    a = parity.engine_from_case(g, lib, "cuda", x0=x0, mu_u=mu_u)
+    b = parity.pkg.BatchedI2c(parity.product_model(g), g.meta["T"], g["Q"], g["R"], g["Qf"], g.meta["alpha"], g.meta["tol"],
+                              mu_u, g["sig_u"], quad=tuple(g.meta["quad"]), x0=x0, device="cuda")
+    for _ in range(6):
+        a.learn_msgs()
+    b.learn(6)
+    torch.cuda.synchronize()
+    assert torch.equal(a.post, b.post) and torch.equal(a.alpha, b.alpha) and torch.equal(a.feedforward, b.feedforward)
+    assert torch.equal(torch.stack(a.costs_m), torch.stack(b.costs_m))

@@ -62,3 +62,22 @@ def test_hostsim_general_weights_sum_not_one(lib):
         parity.assert_close(parity.np_(mu), o.mu_xu0_m, 1e-9, f"W!=1 it{it} mu")
         parity.assert_close(parity.np_(sig), o.sig_xu0_m, 1e-9, f"W!=1 it{it} sig")
         parity.assert_close(parity.np_(eng.alpha), o.alpha, 1e-9, f"W!=1 it{it} alpha")
+
+
+def test_hostsim_fused_em_loop_matches_stepwise(lib):
+    """i2c_learn (N iterations enqueued from C++) == N x learn_msgs(), including the FF -> FB switch."""
+    import torch
+    from golden_util import load_case
+
+    g = load_case("em_pendulum_T40_quad_general")
+    x0, mu_u = parity.batched_inputs(g, 5)
+    a = parity.engine_from_case(g, lib, "cpu", x0=x0, mu_u=mu_u)
+    b = parity.pkg.BatchedI2c(parity.product_model(g), g.meta["T"], g["Q"], g["R"], g["Qf"], g.meta["alpha"], g.meta["tol"],
+                              mu_u, g["sig_u"], quad=tuple(g.meta["quad"]), x0=x0, lib=lib, device="cpu")
+    for _ in range(5):
+        a.learn_msgs()
+    b.learn(5)
+    assert torch.equal(a.post, b.post) and torch.equal(a.alpha, b.alpha) and torch.equal(a.feedforward, b.feedforward)
+    assert b.em_iter == 5 and len(b.alphas) == 6 and len(b.costs_m) == 5
+    assert torch.equal(torch.stack(a.costs_m), torch.stack(b.costs_m))
+    assert torch.equal(torch.stack(a.alphas), torch.stack(b.alphas))
