@@ -57,9 +57,10 @@ enum { I2C_F64 = 0, I2C_F32 = 1 };
 
 /* how i2c_backward_sweep is scheduled (results are identical up to summation order of the cost) */
 enum {
-  I2C_BWD_AUTO = 0,     /* two-pass below I2C_BWD_FUSED_MIN_B trajectories, fused from there on */
-  I2C_BWD_TWO_PASS = 1, /* sequential nx x nx scan + one lane per (t, b) + reduction: lowest latency */
-  I2C_BWD_FUSED = 2     /* one lane per trajectory does the whole cell: lowest HBM traffic           */
+  I2C_BWD_AUTO = 0,     /* chunked (or two-pass without workspace) below I2C_BWD_FUSED_MIN_B trajectories, fused above */
+  I2C_BWD_TWO_PASS = 1, /* sequential nx x nx scan + one lane per (t, b) + reduction                  */
+  I2C_BWD_FUSED = 2,    /* one lane per trajectory does the whole cell: lowest HBM traffic            */
+  I2C_BWD_CHUNKED = 3   /* the affine x-recursion composed per chunk of cells: sequential depth ~2T/NC; needs `work` */
 };
 #define I2C_BWD_FUSED_MIN_B 32768
 
@@ -133,6 +134,7 @@ typedef struct I2cProblem {
                              sig_xi_terminal of cell t. NULL normally; the MPC loop needs it because a cell
                              appended by deepcopy(cell_init) keeps its stale sig_xi (mpc.py:175, i2c.py:976-981) */
   void* temp;           /* [B] terminal-prior temperature (i2c.py:147,552) or NULL               */
+  void* work;           /* optional device workspace of i2c_workspace_bytes() bytes for the chunked backward  */
   const uint8_t* feedforward; /* [T] bytes: 1 = cell in feed-forward mode
                                  (state_action_independence, i2c.py:132,355,1212-1213)            */
 } I2cProblem;
@@ -160,6 +162,9 @@ typedef struct I2cProblem {
 
 /* Query compile-time dimensions of a model. Replaces reading sys.dim_* (env_def.py:34-82). */
 int i2c_query(int model_id, I2cDims* out);
+
+/* Bytes of I2cProblem.work the chunked backward sweep needs for (model_id, dtype, B, T). */
+size_t i2c_workspace_bytes(int model_id, int dtype, int B, int T);
 
 /* Library self-description: ABI version, and the gfx target it was compiled for. */
 int i2c_abi_version(void);

@@ -18,7 +18,7 @@ def _sym(n):
 
 
 F64, F32 = 0, 1
-BWD_AUTO, BWD_TWO_PASS, BWD_FUSED = 0, 1, 2
+BWD_AUTO, BWD_TWO_PASS, BWD_FUSED, BWD_CHUNKED = 0, 1, 2, 3
 
 MODEL_IDS = {
     "PendulumKnown": 0,
@@ -79,6 +79,7 @@ class I2cProblem(C.Structure):
         ("alpha", C.c_void_p),
         ("alpha_cell", C.c_void_p),
         ("temp", C.c_void_p),
+        ("work", C.c_void_p),
         ("feedforward", C.c_void_p),
     ]
 
@@ -86,6 +87,7 @@ class I2cProblem(C.Structure):
 _SIGNATURES = {
     "i2c_abi_version": (C.c_int, []),
     "i2c_build_info": (C.c_char_p, []),
+    "i2c_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "i2c_query": (C.c_int, [C.c_int, C.POINTER(I2cDims)]),
     "i2c_forward_sweep": (C.c_int, [C.POINTER(I2cProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "i2c_backward_sweep": (

@@ -53,6 +53,21 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void k_bwd_fused(const Consts<M, R> c,
   const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
   if (b < c.B) backward_fused_body<M, R>(c, a, b);
 }
+template <class M, typename R>
+__global__ __launch_bounds__(SWEEP_BLOCK) void k_chunk_compose(const Consts<M, R> c, const ChunkArgs<R> a) {
+  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
+  if (b < c.B) chunk_compose_body<M, R>(c, a, blockIdx.y, b);
+}
+template <class M, typename R>
+__global__ __launch_bounds__(SWEEP_BLOCK) void k_chunk_stitch(const Consts<M, R> c, const ChunkArgs<R> a) {
+  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
+  if (b < c.B) chunk_stitch_body<M, R>(c, a, b);
+}
+template <class M, typename R>
+__global__ __launch_bounds__(SWEEP_BLOCK) void k_chunk_walk(const Consts<M, R> c, const ChunkArgs<R> a) {
+  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
+  if (b < c.B) chunk_walk_body<M, R>(c, a, blockIdx.y, b);
+}
 // sum the per-cell cost statistics over t: REDUCE_PARTS lanes per trajectory, fixed summation order
 constexpr int REDUCE_PARTS = 8;
 template <class M, typename R>
@@ -152,6 +167,24 @@ static int check_problem(const I2cProblem* p) {
   return I2C_OK;
 }
 
+// Chunk geometry of the chunked backward sweep: enough chunks to put ~64K lanes in flight, at least 4
+// cells per chunk, at most 32 chunks.
+static void chunk_geometry(int B, int T, int* n_chunks, int* chunk_len) {
+  int nc = (65536 + B - 1) / B;
+  if (nc > 32) nc = 32;
+  if (nc > T / 4) nc = T / 4;
+  if (nc < 1) nc = 1;
+  const int len = (T + nc - 1) / nc;
+  *chunk_len = len;
+  *n_chunks = (T + len - 1) / len;
+}
+template <class M> static size_t workspace_elems(int B, int T) {
+  int nc, len;
+  chunk_geometry(B, T, &nc, &len);
+  constexpr int NX = M::NX;
+  return (size_t)nc * (size_t)B * (size_t)((NX + NX * NX + sym(NX)) + (NX + sym(NX)) + 2);
+}
+
 // ---- per-(model, dtype) entry points ------------------------------------------------------
 template <class M, typename R> struct Impl {
   using C = Consts<M, R>;
@@ -173,53 +206,86 @@ template <class M, typename R> struct Impl {
 #endif
   }
 
-  static bool use_fused(const I2cProblem* p) {
-    if (p->backward_mode == I2C_BWD_FUSED) return true;
-    if (p->backward_mode == I2C_BWD_TWO_PASS) return false;
-    return p->B >= I2C_BWD_FUSED_MIN_B;
+  static int pick_mode(const I2cProblem* p) {
+    int mode = p->backward_mode;
+    if (mode == I2C_BWD_AUTO) mode = p->B >= I2C_BWD_FUSED_MIN_B ? I2C_BWD_FUSED : I2C_BWD_CHUNKED;
+    if (mode == I2C_BWD_CHUNKED && (!p->work || p->T < 8)) mode = I2C_BWD_TWO_PASS;  // no workspace / too short
+    return mode;
   }
 
   static int backward(const I2cProblem* p, const void* fwd, void* xm, void* post, void* zpost, void* cell_stats,
                       void* term_stats, int32_t* status, void* stream) {
     const C c = make_consts<M, R>(p, 0.0, 0);
-    const bool fused = use_fused(p);
-    if (!fused && (!xm || !cell_stats)) return I2C_EINVAL;
+    const int mode = pick_mode(p);
+    if (mode == I2C_BWD_TWO_PASS && (!xm || !cell_stats)) return I2C_EINVAL;
     ScanArgs<R> s{(const R*)fwd, (R*)xm, (R*)p->temp, status};
     CellArgs<R> a{(const R*)fwd, (const R*)xm,   (const R*)p->z, (R*)post,  (R*)zpost,
                   (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status};
+    ChunkArgs<R> ch{a, nullptr, nullptr, nullptr, 0, 0};
+    C cr = c;  // reduction over chunks instead of cells: same kernel, T := number of chunks
+    if (mode == I2C_BWD_CHUNKED) {
+      chunk_geometry(p->B, p->T, &ch.n_chunks, &ch.chunk_len);
+      constexpr int NX = M::NX;
+      ch.comp = (R*)p->work;
+      ch.bnd = ch.comp + (size_t)ch.n_chunks * (NX + NX * NX + sym(NX)) * p->B;
+      ch.part = ch.bnd + (size_t)ch.n_chunks * (NX + sym(NX)) * p->B;
+      cr.T = ch.n_chunks;
+    }
+    CellArgs<R> ared = a;
+    ared.cell_stats = ch.part;
 #ifdef I2C_HOST_SIM
     (void)stream;
-    if (fused) {
+    auto reduce_all = [&](const C& cc, const R* stats) {  // same partition and summation order as k_reduce
+      for (int b = 0; b < p->B; ++b) {
+        R m = R(0), v = R(0);
+        for (int q = 0; q < 8; ++q) {
+          R pm, pv;
+          reduce_partial<M, R>(cc, stats, b, q, 8, &pm, &pv);
+          m += pm;
+          v += pv;
+        }
+        a.term_stats[(long)p->B + b] = m;
+        a.term_stats[2 * (long)p->B + b] = v;
+      }
+    };
+    if (mode == I2C_BWD_FUSED) {
       for (int b = 0; b < p->B; ++b) backward_fused_body<M, R>(c, a, b);
+      return I2C_OK;
+    }
+    if (mode == I2C_BWD_CHUNKED) {
+      for (int q = 0; q < ch.n_chunks; ++q)
+        for (int b = 0; b < p->B; ++b) chunk_compose_body<M, R>(c, ch, q, b);
+      for (int b = 0; b < p->B; ++b) chunk_stitch_body<M, R>(c, ch, b);
+      for (int q = 0; q < ch.n_chunks; ++q)
+        for (int b = 0; b < p->B; ++b) chunk_walk_body<M, R>(c, ch, q, b);
+      reduce_all(cr, ch.part);
       return I2C_OK;
     }
     for (int b = 0; b < p->B; ++b) backward_scan_body<M, R>(c, s, b);
     for (int t = 0; t < p->T; ++t)
       for (int b = 0; b < p->B; ++b) backward_cell_body<M, R>(c, a, t, b);
-    for (int b = 0; b < p->B; ++b) {  // same partition and summation order as k_reduce
-      R m = R(0), v = R(0);
-      for (int q = 0; q < 8; ++q) {
-        R pm, pv;
-        reduce_partial<M, R>(c, a.cell_stats, b, q, 8, &pm, &pv);
-        m += pm;
-        v += pv;
-      }
-      a.term_stats[(long)p->B + b] = m;
-      a.term_stats[2 * (long)p->B + b] = v;
-    }
+    reduce_all(c, a.cell_stats);
     return I2C_OK;
 #else
     const int grid = (p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
-    if (fused) {
-      hipLaunchKernelGGL((k_bwd_fused<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == I2C_BWD_FUSED) {
+      hipLaunchKernelGGL((k_bwd_fused<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, st, c, a);
       return launch_status();
     }
-    hipLaunchKernelGGL((k_scan<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, s);
+    if (mode == I2C_BWD_CHUNKED) {
+      hipLaunchKernelGGL((k_chunk_compose<M, R>), dim3(grid, ch.n_chunks), dim3(SWEEP_BLOCK), 0, st, c, ch);
+      hipLaunchKernelGGL((k_chunk_stitch<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, st, c, ch);
+      hipLaunchKernelGGL((k_chunk_walk<M, R>), dim3(grid, ch.n_chunks), dim3(SWEEP_BLOCK), 0, st, c, ch);
+      hipLaunchKernelGGL((k_reduce<M, R>), dim3(grid), dim3(SWEEP_BLOCK, REDUCE_PARTS), 0, st, cr, ared);
+      return launch_status();
+    }
+    hipLaunchKernelGGL((k_scan<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, st, c, s);
     if (launch_status() != I2C_OK) return I2C_ELAUNCH;
     const dim3 cgrid((p->B + CELL_BLOCK - 1) / CELL_BLOCK, p->T);
-    hipLaunchKernelGGL((k_cell<M, R>), cgrid, dim3(CELL_BLOCK), 0, (hipStream_t)stream, c, a);
+    hipLaunchKernelGGL((k_cell<M, R>), cgrid, dim3(CELL_BLOCK), 0, st, c, a);
     if (launch_status() != I2C_OK) return I2C_ELAUNCH;
-    hipLaunchKernelGGL((k_reduce<M, R>), dim3(grid), dim3(SWEEP_BLOCK, REDUCE_PARTS), 0, (hipStream_t)stream, c, a);
+    hipLaunchKernelGGL((k_reduce<M, R>), dim3(grid), dim3(SWEEP_BLOCK, REDUCE_PARTS), 0, st, c, a);
     return launch_status();
 #endif
   }
@@ -367,6 +433,21 @@ const char* i2c_build_info(void) {
 #else
   return "i2c hip build: gfx950 (MI355X), wave64, one trajectory per lane";
 #endif
+}
+
+size_t i2c_workspace_bytes(int model_id, int dtype, int B, int T) {
+  if (B < 1 || T < 1) return 0;
+  const size_t w = dtype == I2C_F32 ? 4 : 8;
+  switch (model_id) {
+    case I2C_MODEL_PENDULUM: return w * i2c::workspace_elems<i2c::Pendulum>(B, T);
+    case I2C_MODEL_PENDULUM_ACTREG: return w * i2c::workspace_elems<i2c::PendulumActReg>(B, T);
+    case I2C_MODEL_CARTPOLE: return w * i2c::workspace_elems<i2c::Cartpole>(B, T);
+    case I2C_MODEL_DOUBLE_CARTPOLE: return w * i2c::workspace_elems<i2c::DoubleCartpole>(B, T);
+    case I2C_MODEL_LINEAR: return w * i2c::workspace_elems<i2c::Linear>(B, T);
+    case I2C_MODEL_LINEAR_MINENERGY: return w * i2c::workspace_elems<i2c::LinearMinEnergy>(B, T);
+    case I2C_MODEL_QUADROTOR: return w * i2c::workspace_elems<i2c::Quadrotor>(B, T);
+    default: return 0;
+  }
 }
 
 int i2c_query(int model_id, I2cDims* out) {

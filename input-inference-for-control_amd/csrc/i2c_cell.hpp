@@ -944,6 +944,195 @@ I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R>&
 }
 
 // ------------------------------------------------------------------------------------------
+// Backward sweep, CHUNKED form (small batches): the x-marginal recursion is affine,
+//   (m, S)_t = (a_t + Jx_t m_{t+1},  C_t + Jx_t S_{t+1} Jx_t^T),   a_t = mu_x1_f - Jx_t mu_x3_f,
+//                                                                   C_t = sig_x1_f - Jx_t sig_x3_f Jx_t^T,
+// so maps compose: T cells are cut into NC chunks, (1) every chunk's composite map (a, G, C) is built
+// in parallel [one lane per (chunk, b)], (2) one lane per trajectory applies the NC composites to get
+// the smoothed state entering every chunk, (3) every chunk is walked in parallel doing the complete
+// cell work from its boundary value. The sequential depth drops from T to ~2 T / NC + NC.
+// ------------------------------------------------------------------------------------------
+template <typename R> struct ChunkArgs {
+  CellArgs<R> cell;  // fwd, xm (optional out), z, post, zpost, cell_stats (optional out), term_stats, temp, status
+  R* comp;           // [NC][NX + NX*NX + sym(NX)][B]  composite maps
+  R* bnd;            // [NC][NX + sym(NX)][B]          smoothed state entering each chunk
+  R* part;           // [NC][2][B]                     per-chunk cost sums
+  int n_chunks, chunk_len;
+};
+
+template <class M, typename R>
+I2C_HD inline void chunk_compose_body(const Consts<M, R>& c, const ChunkArgs<R>& a, const int ch, const int b) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, D = C::D;
+  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  const long B = c.B;
+  const int t_lo = ch * a.chunk_len, t_hi = (t_lo + a.chunk_len < c.T) ? t_lo + a.chunk_len : c.T;
+  R av[NX], G[NX * NX], Cc[sym(NX)];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) av[i] = R(0);
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+#pragma unroll
+    for (int j = 0; j < NX; ++j) G[i * NX + j] = i == j ? R(1) : R(0);
+#pragma unroll
+  for (int i = 0; i < sym(NX); ++i) Cc[i] = R(0);
+  for (int t = t_hi - 1; t >= t_lo; --t) {
+    const R* in = a.cell.fwd + ((long)t * C::E_FWD) * B + b;
+    R mu1[NX], S1[sym(NX)], m3f[NX], S3n[sym(NX)], Jx[NX * NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) mu1[i] = in[(long)i * B];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) S1[i] = in[(long)(D + i) * B];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) m3f[i] = in[(long)(O_MU3 + i) * B];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) S3n[i] = Cc[i] - in[(long)(O_S3 + i) * B];  // C - sig_x3_f
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) Jx[i] = in[(long)(O_J + i) * B];
+    // a <- mu1 + Jx (a - m3f);  C <- S1 + Jx (C - S3f) Jx^T;  G <- Jx G
+    R an[NX], Gn[NX * NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      R v = mu1[i];
+#pragma unroll
+      for (int k = 0; k < NX; ++k) v += Jx[i * NX + k] * (av[k] - m3f[k]);
+      an[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) Cc[i] = S1[i];
+    add_JDJt<NX, NX>(Jx, S3n, Cc);
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        R v = R(0);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) v += Jx[i * NX + k] * G[k * NX + j];
+        Gn[i * NX + j] = v;
+      }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) av[i] = an[i];
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) G[i] = Gn[i];
+  }
+  constexpr int EC = NX + NX * NX + sym(NX);
+  R* out = a.comp + ((long)ch * EC) * B + b;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) out[(long)i * B] = av[i];
+#pragma unroll
+  for (int i = 0; i < NX * NX; ++i) out[(long)(NX + i) * B] = G[i];
+#pragma unroll
+  for (int i = 0; i < sym(NX); ++i) out[(long)(NX + NX * NX + i) * B] = Cc[i];
+}
+
+template <class M, typename R>
+I2C_HD inline void chunk_stitch_body(const Consts<M, R>& c, const ChunkArgs<R>& a, const int b) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, D = C::D;
+  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, EC = NX + NX * NX + sym(NX);
+  const long B = c.B;
+  const R* last = a.cell.fwd + ((long)(c.T - 1) * C::E_FWD) * B + b;
+  R m3f[NX], S3f[sym(NX)], m[NX], S[sym(NX)];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) m3f[i] = last[(long)(O_MU3 + i) * B];
+#pragma unroll
+  for (int i = 0; i < sym(NX); ++i) S3f[i] = last[(long)(O_S3 + i) * B];
+  end_of_chain<M, R>(c, a.cell.temp, b, m3f, S3f, m, S, a.cell.status);
+  terminal_obs_stats<M, R>(c, b, m, S, a.cell.term_stats, a.cell.status);
+  for (int ch = a.n_chunks - 1; ch >= 0; --ch) {
+    R* bo = a.bnd + ((long)ch * C::E_XM) * B + b;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) bo[(long)i * B] = m[i];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) bo[(long)(NX + i) * B] = S[i];
+    const R* cp = a.comp + ((long)ch * EC) * B + b;
+    R av[NX], G[NX * NX], Cc[sym(NX)], mn[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) av[i] = cp[(long)i * B];
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) G[i] = cp[(long)(NX + i) * B];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) Cc[i] = cp[(long)(NX + NX * NX + i) * B];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      R v = av[i];
+#pragma unroll
+      for (int k = 0; k < NX; ++k) v += G[i * NX + k] * m[k];
+      mn[i] = v;
+    }
+    add_JDJt<NX, NX>(G, S, Cc);  // C + G S G^T
+#pragma unroll
+    for (int i = 0; i < NX; ++i) m[i] = mn[i];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) S[i] = Cc[i];
+  }
+}
+
+template <class M, typename R>
+I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R>& a, const int ch, const int b) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NZ = C::NZ, D = C::D;
+  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  constexpr unsigned W = sizeof(R);
+  const unsigned long B = c.B;
+  const unsigned bo = (unsigned)b * W, rb = (unsigned)(B * W);
+  const int t_lo = ch * a.chunk_len, t_hi = (t_lo + a.chunk_len < c.T) ? t_lo + a.chunk_len : c.T;
+  const CellArgs<R>& ca = a.cell;
+  R m3m[NX], S3m[sym(NX)];
+  {
+    const R* bi = a.bnd + ((long)ch * C::E_XM) * B + b;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) m3m[i] = bi[(long)i * B];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) S3m[i] = bi[(long)(NX + i) * B];
+  }
+  R row[C::E_FWD], nxt[C::E_FWD];
+  {
+    const Window w = make_window(ca.fwd + (unsigned long)(t_hi - 1) * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
+#pragma unroll
+    for (int e = 0; e < C::E_FWD; ++e) row[e] = wld<R>(w, e * rb, bo);
+  }
+  R sum_m = R(0), sum_v = R(0);
+  for (int t = t_hi - 1; t >= t_lo; --t) {
+    {
+      const int tp = t > t_lo ? t - 1 : t_lo;
+      const Window w = make_window(ca.fwd + (unsigned long)tp * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
+#pragma unroll
+      for (int e = 0; e < C::E_FWD; ++e) nxt[e] = wld<R>(w, e * rb, bo);
+    }
+    if (ca.xm) {
+      R* xo = const_cast<R*>(ca.xm) + ((long)t * C::E_XM) * B + b;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xo[(long)i * B] = m3m[i];
+#pragma unroll
+      for (int i = 0; i < sym(NX); ++i) xo[(long)(NX + i) * B] = S3m[i];
+    }
+    R dm[NX], dS[sym(NX)], zt[NZ];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) dm[i] = m3m[i] - row[O_MU3 + i];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) dS[i] = S3m[i] - row[O_S3 + i];
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? ca.z[((long)t * NZ + k) * B + b] : c.zg[k];
+    R* mu = row;
+    R* S = row + D;
+    R ctl[C::E_POST - D - sym(D)], mz[NZ], Sz[sym(NZ)], cm, cv;
+    if (!cell_posterior<M, R>(c, zt, mu, S, row + O_J, dm, dS, ctl, mz, Sz, &cm, &cv)) set_status(ca.status, b, 7, t);
+    store_cell<M, R>(c, ca, t, b, mu, S, ctl, mz, Sz, cm, cv);
+    sum_m += cm;
+    sum_v += cv;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) m3m[i] = mu[i];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) S3m[i] = S[i];
+#pragma unroll
+    for (int e = 0; e < C::E_FWD; ++e) row[e] = nxt[e];
+  }
+  a.part[((long)ch * 2 + 0) * B + b] = sum_m;
+  a.part[((long)ch * 2 + 1) * B + b] = sum_v;
+}
+
+// ------------------------------------------------------------------------------------------
 // M-step on the temperature (i2c.py:913-963, 1045-1053). One lane per trajectory, O(1) work:
 // the sums over t were produced by the backward sweep (term_stats rows 1, 2).
 // ------------------------------------------------------------------------------------------

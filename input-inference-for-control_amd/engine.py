@@ -142,12 +142,23 @@ class BatchedI2c:
         self.fwd = zeros(T, dims.e_fwd, B)
         self.zpost = zeros(T, dims.e_zpost, B) if keep_zpost else None
         self.prior_out = zeros(T, d + sym_size(d), B) if keep_prior else None
-        self.backward_mode = {"auto": _native.BWD_AUTO, "two_pass": _native.BWD_TWO_PASS, "fused": _native.BWD_FUSED}[backward_mode]
-        fused = self.backward_mode == _native.BWD_FUSED or (self.backward_mode == _native.BWD_AUTO and B >= 32768)
-        self.fused_backward = fused
-        # the two-pass backward needs xm / cell_stats as workspace; the fused one only writes them on request
-        self.xm = zeros(T, dims.e_xm, B) if (keep_xm or not fused) else None
-        self.cell_stats = None if fused else zeros(T, 2, B)
+        self.backward_mode = {"auto": _native.BWD_AUTO, "two_pass": _native.BWD_TWO_PASS, "fused": _native.BWD_FUSED,
+                              "chunked": _native.BWD_CHUNKED}[backward_mode]
+        mode = self.backward_mode
+        if mode == _native.BWD_AUTO:
+            mode = _native.BWD_FUSED if B >= 32768 else _native.BWD_CHUNKED
+        if mode == _native.BWD_CHUNKED and T < 8:
+            mode = _native.BWD_TWO_PASS
+        self.fused_backward = mode == _native.BWD_FUSED
+        self.backward_schedule = {_native.BWD_TWO_PASS: "two_pass", _native.BWD_FUSED: "fused", _native.BWD_CHUNKED: "chunked"}[mode]
+        # the two-pass backward needs xm / cell_stats as workspace; the fused and chunked ones only write xm on request
+        two_pass = mode == _native.BWD_TWO_PASS
+        self.xm = zeros(T, dims.e_xm, B) if (keep_xm or two_pass) else None
+        self.cell_stats = zeros(T, 2, B) if two_pass else None
+        self.work = None
+        if mode == _native.BWD_CHUNKED:
+            nbytes = self.lib.i2c_workspace_bytes(self.model_id, F64 if dt == torch.float64 else F32, B, T)
+            self.work = torch.empty(nbytes // (8 if dt == torch.float64 else 4), dtype=dt, device=dev)
         self.e_term = 3 + nzt + sym_size(nzt)
         self.term_stats = zeros(self.e_term, B)
         self.stats_out = zeros(4, B)
@@ -223,6 +234,7 @@ class BatchedI2c:
         p.alpha = self.alpha.data_ptr()
         p.alpha_cell = self.alpha_cell.data_ptr() if self.alpha_cell is not None else None
         p.temp = self.temp.data_ptr()
+        p.work = self.work.data_ptr() if getattr(self, "work", None) is not None else None
         p.feedforward = self.feedforward.data_ptr()
         return p
 

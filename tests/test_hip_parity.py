@@ -50,10 +50,11 @@ def test_hip_batch_vs_oracle(lib, name, B, iters):
     parity.check_batch_against_oracle(name, lib, "cuda", B, iters, tol=1e-6)
 
 
+@pytest.mark.parametrize("mode", ["fused", "two_pass", "chunked"])
 @pytest.mark.parametrize("name", ["em_pendulum_T200", "em_covctrl_T100", "em_dcp_T60", "em_pendulum_T50_propagate"])
-def test_hip_fused_backward_vs_reference_golden(lib, name):
-    """The large-batch schedule of the backward sweep (one lane per trajectory) on the same vectors."""
-    parity.check_against_golden(name, lib, "cuda", 1e-6, 1e-5, backward_mode="fused")
+def test_hip_backward_schedules_vs_reference_golden(lib, name, mode):
+    """Every schedule of the backward sweep on the same vectors (auto = chunked below 32768 trajectories)."""
+    parity.check_against_golden(name, lib, "cuda", 1e-6, 1e-5, backward_mode=mode)
 
 
 def test_hip_fused_and_two_pass_backward_agree(lib):
@@ -61,9 +62,13 @@ def test_hip_fused_and_two_pass_backward_agree(lib):
     x0, mu_u = parity.batched_inputs(g, 300)
     a = parity.engine_from_case(g, lib, "cuda", x0=x0, mu_u=mu_u, backward_mode="two_pass")
     b = parity.engine_from_case(g, lib, "cuda", x0=x0, mu_u=mu_u, backward_mode="fused")
+    c = parity.engine_from_case(g, lib, "cuda", x0=x0, mu_u=mu_u, backward_mode="chunked")
+    assert (a.backward_schedule, b.backward_schedule, c.backward_schedule) == ("two_pass", "fused", "chunked")
     for _ in range(4):
         a.learn_msgs()
         b.learn_msgs()
+        c.learn_msgs()
+    assert_close(c.post.cpu().numpy(), a.post.cpu().numpy(), 1e-8, "chunked vs two-pass")
     # same cell arithmetic in two differently scheduled kernels: agreement to rounding
     assert_close(b.post.cpu().numpy(), a.post.cpu().numpy(), 1e-8, "posterior + controller buffer")
     assert_close(b.alpha.cpu().numpy(), a.alpha.cpu().numpy(), 1e-8, "alpha")

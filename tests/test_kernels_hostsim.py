@@ -35,10 +35,12 @@ def test_hostsim_batch_vs_oracle(lib, name, B, iters):
     parity.check_batch_against_oracle(name, lib, "cpu", B, iters, tol=1e-7)
 
 
+@pytest.mark.parametrize("mode", ["fused", "two_pass", "chunked"])
 @pytest.mark.parametrize("name", ["em_pendulum_T200", "em_covctrl_T100", "em_dcp_T60"])
-def test_hostsim_fused_backward_matches_reference(lib, name):
-    """The fused single-pass backward (large-batch schedule) against the same golden vectors."""
-    parity.check_against_golden(name, lib, "cpu", 1e-7, 1e-6, n_iters=4, backward_mode="fused")
+def test_hostsim_backward_schedules_match_reference(lib, name, mode):
+    """Every schedule of the backward sweep (fused single pass / scan + per-cell / chunk-composed) against
+    the same golden vectors; the default `auto` picks chunked here and is what the other tests run."""
+    parity.check_against_golden(name, lib, "cpu", 1e-7, 1e-6, n_iters=4, backward_mode=mode)
 
 
 def test_hostsim_general_weights_sum_not_one(lib):
