@@ -262,7 +262,7 @@ def main():
     }
     if not args.no_saturated and world == 1:
         out["saturated_batch"] = saturated_leg(pkg, T, dtype, device, el, wbytes)
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline(T)
     print(json.dumps(out))
     if dist is not None:

@@ -141,6 +141,14 @@ template <class M, typename R> static Consts<M, R> make_consts(const I2cProblem*
   c.z_per_cell = p->z_per_cell && p->z != nullptr;
   c.use_expert = use_expert;
   c.terminal_cell = p->terminal_cell;
+  auto is_diag = [](const double* W, int n) {
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < i; ++j)
+        if (W[i * (i + 1) / 2 + j] != 0.0) return 0;
+    return 1;
+  };
+  c.qr_diag = is_diag(p->QR, C::NZ);
+  c.qf_diag = is_diag(p->Qf, C::NZT);
   c.rule_xu = make_rule<R>(p, C::D);
   c.rule_x = make_rule<R>(p, C::NX);
   c.dtemp = (R)p->dtemp;
@@ -170,7 +178,11 @@ static int check_problem(const I2cProblem* p) {
 // Chunk geometry of the chunked backward sweep: enough chunks to put ~64K lanes in flight, at least 4
 // cells per chunk, at most 32 chunks.
 static void chunk_geometry(int B, int T, int* n_chunks, int* chunk_len) {
-  int nc = (65536 + B - 1) / B;
+  static const int forced = [] {  // experiment knob (not part of the ABI)
+    const char* e = getenv("I2C_CHUNKS");
+    return e ? atoi(e) : 0;
+  }();
+  int nc = forced > 0 ? forced : (65536 + B - 1) / B;
   if (nc > 32) nc = 32;
   if (nc > T / 4) nc = T / 4;
   if (nc < 1) nc = 1;

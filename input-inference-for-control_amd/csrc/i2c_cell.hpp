@@ -38,6 +38,7 @@ template <class M, typename R> struct Consts {
   static constexpr int E_TERM = 3 + NZT + sym(NZT);
   int B, T;
   int has_Qf, has_x_terminal, z_per_cell, use_expert, terminal_cell;
+  int qr_diag, qf_diag;  // cost weights are diagonal: cheap closed forms in gaussian_cost
   Rule<R> rule_xu, rule_x;
   R dtemp, tol;
   R sig_eta_w[sym(NX)];  // W(d) * sig_eta, W = sum of the d-dimensional rule's weights
@@ -594,10 +595,31 @@ I2C_FN void end_of_chain(const Consts<M, R>& c, R* temp, const int b, const R* m
 
 // Expected quadratic cost of N(mz, Sz) against target zt under weight W (packed sym):
 //   m = err^T W err + tr(Sz W),  v = 2 tr((Sz W)^2) + 4 err^T W Sz W err   (i2c.py:1034-1043)
-template <int N, typename R> I2C_FN void gaussian_cost(const R* W, const R* mz, const R* Sz, const R* zt, R* m, R* v) {
-  R err[N], We[N];
+template <int N, typename R>
+I2C_FN void gaussian_cost(const R* W, const bool w_diag, const R* mz, const R* Sz, const R* zt, R* m, R* v) {
+  R err[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) err[i] = mz[i] - zt[i];
+  if (w_diag) {  // W = diag(w): every shipped cost (Q, R, Qf diagonal). SW_ij = Sz_ij w_j
+    R mm = R(0), tr2 = R(0), quad = R(0), we[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      we[i] = W[tri(i, i)] * err[i];
+      mm += we[i] * err[i] + W[tri(i, i)] * Sz[tri(i, i)];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        const R sww = Sz[tri(i, j)] * (W[tri(i, i)] * W[tri(j, j)]);
+        tr2 += (i == j ? R(1) : R(2)) * Sz[tri(i, j)] * sww;
+        quad += (i == j ? R(1) : R(2)) * Sz[tri(i, j)] * (we[i] * we[j]);
+      }
+    *m = mm;
+    *v = R(2) * tr2 + R(4) * quad;
+    return;
+  }
+  R We[N];
   symv<N>(W, err, We);
   R SW[N * N];  // Sz W (not symmetric)
 #pragma unroll
@@ -642,7 +664,7 @@ I2C_FN R terminal_obs_stats(const Consts<M, R>& c, const int b, const R* m3m, co
     sp_transform<M, TermStruct<M>, NX, NT, false>(c.rule_x, m3m, S3m, L3, ObserveTermF<M, R>{c.params}, mzt, Szt,
                                                   (R*)nullptr);
     R tv;
-    gaussian_cost<NT>(c.Qf, mzt, Szt, c.zg_term, &trT, &tv);
+    gaussian_cost<NT>(c.Qf, c.qf_diag != 0, mzt, Szt, c.zg_term, &trT, &tv);
 #pragma unroll
     for (int k = 0; k < NT; ++k) term_stats[(long)(3 + k) * B + b] = mzt[k];
 #pragma unroll
@@ -676,7 +698,7 @@ I2C_FN bool cell_posterior(const Consts<M, R>& c, const R* zt, R* mu, R* S, cons
   for (int e = 0; e < sym(D); ++e) Lm[e] = S[e];
   const bool ok = chol<D>(Lm, rinv);
   sp_transform<M, ObsStruct<M>, D, NZ, false>(c.rule_xu, mu, S, Lm, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
-  gaussian_cost<NZ>(c.QR, mz, Sz, zt, cm, cv);
+  gaussian_cost<NZ>(c.QR, c.qr_diag != 0, mz, Sz, zt, cm, cv);
 #pragma unroll
   for (int p = 0; p < NU; ++p) {
 #pragma unroll
@@ -976,19 +998,31 @@ I2C_HD inline void chunk_compose_body(const Consts<M, R>& c, const ChunkArgs<R>&
     for (int j = 0; j < NX; ++j) G[i * NX + j] = i == j ? R(1) : R(0);
 #pragma unroll
   for (int i = 0; i < sym(NX); ++i) Cc[i] = R(0);
-  for (int t = t_hi - 1; t >= t_lo; --t) {
+  using Row = ScanRow<NX, R>;
+  auto load = [&](int t, Row& r) {
     const R* in = a.cell.fwd + ((long)t * C::E_FWD) * B + b;
-    R mu1[NX], S1[sym(NX)], m3f[NX], S3n[sym(NX)], Jx[NX * NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) mu1[i] = in[(long)i * B];
+    for (int i = 0; i < NX; ++i) r.mu1[i] = in[(long)i * B];
 #pragma unroll
-    for (int i = 0; i < sym(NX); ++i) S1[i] = in[(long)(D + i) * B];
+    for (int i = 0; i < sym(NX); ++i) r.S1[i] = in[(long)(D + i) * B];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) m3f[i] = in[(long)(O_MU3 + i) * B];
+    for (int i = 0; i < NX; ++i) r.m3f[i] = in[(long)(O_MU3 + i) * B];
 #pragma unroll
-    for (int i = 0; i < sym(NX); ++i) S3n[i] = Cc[i] - in[(long)(O_S3 + i) * B];  // C - sig_x3_f
+    for (int i = 0; i < sym(NX); ++i) r.S3f[i] = in[(long)(O_S3 + i) * B];
 #pragma unroll
-    for (int i = 0; i < NX * NX; ++i) Jx[i] = in[(long)(O_J + i) * B];
+    for (int i = 0; i < NX * NX; ++i) r.Jx[i] = in[(long)(O_J + i) * B];
+  };
+  Row cur, nxt;
+  load(t_hi - 1, cur);
+  for (int t = t_hi - 1; t >= t_lo; --t) {
+    load(t > t_lo ? t - 1 : t_lo, nxt);  // one cell ahead: the loads do not depend on the composition
+    const R* mu1 = cur.mu1;
+    const R* S1 = cur.S1;
+    const R* m3f = cur.m3f;
+    const R* Jx = cur.Jx;
+    R S3n[sym(NX)];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) S3n[i] = Cc[i] - cur.S3f[i];  // C - sig_x3_f
     // a <- mu1 + Jx (a - m3f);  C <- S1 + Jx (C - S3f) Jx^T;  G <- Jx G
     R an[NX], Gn[NX * NX];
 #pragma unroll
@@ -1014,6 +1048,7 @@ I2C_HD inline void chunk_compose_body(const Consts<M, R>& c, const ChunkArgs<R>&
     for (int i = 0; i < NX; ++i) av[i] = an[i];
 #pragma unroll
     for (int i = 0; i < NX * NX; ++i) G[i] = Gn[i];
+    cur = nxt;
   }
   constexpr int EC = NX + NX * NX + sym(NX);
   R* out = a.comp + ((long)ch * EC) * B + b;
@@ -1039,20 +1074,25 @@ I2C_HD inline void chunk_stitch_body(const Consts<M, R>& c, const ChunkArgs<R>& 
   for (int i = 0; i < sym(NX); ++i) S3f[i] = last[(long)(O_S3 + i) * B];
   end_of_chain<M, R>(c, a.cell.temp, b, m3f, S3f, m, S, a.cell.status);
   terminal_obs_stats<M, R>(c, b, m, S, a.cell.term_stats, a.cell.status);
+  R av[NX], G[NX * NX], Cc[sym(NX)], nav[NX], nG[NX * NX], nCc[sym(NX)];
+  auto loadc = [&](int ch, R* la, R* lG, R* lC) {
+    const R* cp = a.comp + ((long)(ch > 0 ? ch : 0) * EC) * B + b;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) la[i] = cp[(long)i * B];
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) lG[i] = cp[(long)(NX + i) * B];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) lC[i] = cp[(long)(NX + NX * NX + i) * B];
+  };
+  loadc(a.n_chunks - 1, av, G, Cc);
   for (int ch = a.n_chunks - 1; ch >= 0; --ch) {
+    loadc(ch - 1, nav, nG, nCc);  // next composite, one step ahead
     R* bo = a.bnd + ((long)ch * C::E_XM) * B + b;
 #pragma unroll
     for (int i = 0; i < NX; ++i) bo[(long)i * B] = m[i];
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) bo[(long)(NX + i) * B] = S[i];
-    const R* cp = a.comp + ((long)ch * EC) * B + b;
-    R av[NX], G[NX * NX], Cc[sym(NX)], mn[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) av[i] = cp[(long)i * B];
-#pragma unroll
-    for (int i = 0; i < NX * NX; ++i) G[i] = cp[(long)(NX + i) * B];
-#pragma unroll
-    for (int i = 0; i < sym(NX); ++i) Cc[i] = cp[(long)(NX + NX * NX + i) * B];
+    R mn[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       R v = av[i];
@@ -1065,6 +1105,12 @@ I2C_HD inline void chunk_stitch_body(const Consts<M, R>& c, const ChunkArgs<R>& 
     for (int i = 0; i < NX; ++i) m[i] = mn[i];
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) S[i] = Cc[i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) av[i] = nav[i];
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) G[i] = nG[i];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) Cc[i] = nCc[i];
   }
 }
 
@@ -1259,7 +1305,7 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
     for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
     sp_transform<M, ObsStruct<M>, D, NZ, false>(c.rule_xu, mu0, S0, L0, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
     R cm, cv;
-    gaussian_cost<NZ>(c.QR, mz, Sz, zt, &cm, &cv);
+    gaussian_cost<NZ>(c.QR, c.qr_diag != 0, mz, Sz, zt, &cm, &cv);
     sum_m += cm;
     sum_v += cv;
 

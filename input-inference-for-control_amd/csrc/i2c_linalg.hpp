@@ -148,25 +148,31 @@ struct Window {
   __amdgpu_buffer_rsrc_t r;
 };
 // `base` and `bytes` must be wave-uniform. A window addresses at most 4 GiB.
+// The descriptor inputs go through readfirstlane so that their uniformity is PROVABLE to hipcc: when it
+// is not (e.g. after the pointer was spilled through a VGPR), every buffer_load/store gets wrapped in a
+// ~10-instruction "waterfall" loop that also serialises consecutive memory operations.
+I2C_FN unsigned uniform_u32(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
 I2C_FN Window make_window(const void* base, unsigned long bytes) {
-  const unsigned n = bytes > 0xFFFFFFFFul ? 0xFFFFFFFFu : (unsigned)bytes;
-  return Window{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000)};
+  const unsigned long p = (unsigned long)base;
+  const unsigned long pu = ((unsigned long)uniform_u32((unsigned)(p >> 32)) << 32) | uniform_u32((unsigned)p);
+  const unsigned n = uniform_u32(bytes > 0xFFFFFFFFul ? 0xFFFFFFFFu : (unsigned)bytes);
+  return Window{__builtin_amdgcn_make_buffer_rsrc((void*)pu, 0, n, 0x00020000)};
 }
 template <typename R> I2C_FN R wld(const Window& w, unsigned row_off, unsigned lane_off) {
   if constexpr (sizeof(R) == 8) {
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
-    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(w.r, lane_off, row_off, 0);
+    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(w.r, lane_off, uniform_u32(row_off), 0);
     return __builtin_bit_cast(R, v);
   } else {
-    return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b32(w.r, lane_off, row_off, 0));
+    return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b32(w.r, lane_off, uniform_u32(row_off), 0));
   }
 }
 I2C_FN void wst(const Window& w, unsigned row_off, unsigned lane_off, double v) {
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), w.r, lane_off, row_off, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), w.r, lane_off, uniform_u32(row_off), 0);
 }
 I2C_FN void wst(const Window& w, unsigned row_off, unsigned lane_off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), w.r, lane_off, row_off, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), w.r, lane_off, uniform_u32(row_off), 0);
 }
 #endif
 

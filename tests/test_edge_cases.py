@@ -83,3 +83,36 @@ def test_alpha_is_per_trajectory():
         assert torch.equal(eng.post[:, :, b], s.post[:, :, 0])
         assert torch.equal(eng.alpha[b], s.alpha[0])
     assert len(set(eng.alpha.tolist())) == B
+
+
+def _dense_cost_case():
+    """Symmetric but NON-diagonal Q, R-coupled Qf: exercises the general-W branches of the cost statistics
+    (every shipped config has diagonal weights and takes the closed-form branch)."""
+    g = _short_case(12)
+    A = np.array([[2.0, 0.3, -0.1], [0.3, 50.0, 0.4], [-0.1, 0.4, 1.5]])
+    Af = np.array([[3.0, -0.2, 0.1], [-0.2, 20.0, 0.3], [0.1, 0.3, 2.5]])
+    return Case({**g, "Q": A, "Qf": Af})
+
+
+def _dense_cost(lib, device):
+    g = _dense_cost_case()
+    x0, mu_u = parity.batched_inputs(g, 3)
+    eng = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u)
+    o = oracle_from_case(Case({**g, "mu_u": mu_u}), x0=x0)
+    for it in range(3):
+        eng.learn_msgs()
+        o.learn_msgs()
+        assert_close(parity.np_(eng.alpha), o.alpha, 1e-9, f"dense cost it{it} alpha")
+        assert_close(parity.np_(eng.costs_m[-1]), o.costs_m[-1], 1e-9, f"dense cost it{it} cost mean")
+        assert_close(parity.np_(eng.costs_m_var[-1]), o.costs_m_var[-1], 1e-9, f"dense cost it{it} cost variance")
+        mu, _ = eng.marginal_state_action()
+        assert_close(parity.np_(mu), o.mu_xu0_m, 1e-9, f"dense cost it{it} mean")
+
+
+def test_non_diagonal_cost_weights_cpu():
+    _dense_cost(hostsim.load(), "cpu")
+
+
+@pytest.mark.gpu
+def test_non_diagonal_cost_weights_gpu():
+    _dense_cost(None, "cuda")
