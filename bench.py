@@ -113,28 +113,16 @@ def measured_traffic(B, T, dtype, kernel):
     return d["kernels"][kernel]["hbm_bytes_per_launch"]
 
 
-def cpu_baseline(T, sample_B=512, iters=30):
-    """The oracle (NumPy restatement, batch-vectorised, one core) timed on this host: a bounded
-    sample of the same workload (sample_B trajectories x T cells x `iters` EM iterations)."""
-    from oracle.i2c_numpy import CubatureRule, I2cOracle
-    from oracle.models_numpy import make_model
+def cpu_baseline(T):
+    """The oracle (NumPy restatement, batch-vectorised) timed on THIS host's cores, as a child process that
+    imports NumPy only (oracle/cpu_bench.py): one worker per core (capped at 128), a bounded sample."""
+    import subprocess
 
-    x0, mu_u = synthetic_pendulum_inputs(sample_B, T)
-    Q, R = np.diag([1.0, 100.0, 1.0]), np.diag([2.0])
-    o = I2cOracle(make_model("PendulumKnown"), T, Q, R, Q, 100.0, 0.0, mu_u, 2.0 * np.eye(1), rule=CubatureRule(1, 0, 0), x0=x0)
-    o.learn_msgs()  # warm-up (first iteration is the feed-forward branch)
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        o.learn_msgs()
-    dt = time.perf_counter() - t0
-    return {
-        "value": sample_B * T * iters / dt,
-        "unit": "timestep-messages/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"oracle/i2c_numpy.py (batch-vectorised NumPy fp64), pendulum T={T}, {sample_B} trajectories x {iters} EM "
-                  f"iterations after 1 warm-up = {dt:.1f} s on 1 of {os.cpu_count()} host cores",
-    }
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--horizon", str(T), "--batch", "512", "--iters", "10"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError("cpu baseline failed: " + r.stderr[-2000:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def main():
