@@ -115,7 +115,7 @@ def measured_traffic(B, T, dtype, kernel):
 
 def cpu_baseline(T):
     """The oracle (NumPy restatement, batch-vectorised) timed on THIS host's cores, as a child process that
-    imports NumPy only (oracle/cpu_bench.py): one worker per core (capped at 128), a bounded sample."""
+    imports NumPy only (oracle/cpu_bench.py): one worker per core (capped at 32), a bounded sample."""
     import subprocess
 
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--horizon", str(T), "--batch", "512", "--iters", "10"]

@@ -45,10 +45,10 @@ def main():
     ap.add_argument("--horizon", type=int, default=200)
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--workers", type=int, default=0, help="0 = all cores (capped at 128)")
+    ap.add_argument("--workers", type=int, default=0, help="0 = one per core, capped at 32 (beyond that the NumPy workers only contend for memory bandwidth)")
     a = ap.parse_args()
     cores = os.cpu_count() or 1
-    W = a.workers if a.workers > 0 else min(cores, 128)
+    W = a.workers if a.workers > 0 else min(cores, 32)
     t0 = time.perf_counter()
     if W == 1:
         times = [_work((0, a.horizon, a.batch, a.iters))]
