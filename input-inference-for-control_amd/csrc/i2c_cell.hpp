@@ -330,6 +330,11 @@ template <int NX, int NU, typename R> I2C_FN void gain_quad(const R* Kt, const R
     }
 }
 
+// Branch-free bookkeeping of the first failure: keeps the sweep's cells free of control flow, so that
+// each cell stays one large scheduling region.
+I2C_FN int note_failure(int fail, bool ok, int reason, int t) {
+  return (fail == 0 && !ok) ? ((reason << 16) | (t + 1)) : fail;
+}
 I2C_FN void set_status(int32_t* status, int b, int reason, int t) {
   if (status[b] == 0) status[b] = (reason << 16) | (t + 1);
 }
@@ -360,6 +365,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
   const unsigned bo = (unsigned)b * W;     // the lane's byte offset inside any row
   const unsigned rb0 = (unsigned)(B * W);  // bytes per row (wave-uniform)
   const R alpha_traj = a.alpha[b];
+  int fail = 0;  // first failure of this trajectory, (reason << 16) | (t + 1); kept in a register, stored once
 
   R mu_x[NX], sig_x[sym(NX)];
 #pragma unroll
@@ -421,7 +427,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       for (int i = 0; i < NX; ++i) delta[i] = mu_x[i] - pmu[i];
       bool ok;
       const R rho = pdf_ratio<NX>(S, delta, &ok);
-      if (!ok) set_status(a.status, b, 2, t);
+      fail = note_failure(fail, ok, 2, t);
       R Kt[NU * NX];
 #pragma unroll
       for (int i = 0; i < NU * NX; ++i) Kt[i] = rho * Kprev[i];
@@ -459,12 +465,12 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       R L[sym(D)], rinv[D];
 #pragma unroll
       for (int i = 0; i < sym(D); ++i) L[i] = S0[i];
-      if (!chol<D>(L, rinv)) set_status(a.status, b, 1, t);
+      fail = note_failure(fail, chol<D>(L, rinv), 1, t);
       R mz[NZ], Sz[sym(NZ)], Sxz[D * NZ];
       sp_transform<M, ObsStruct<M>, D, NZ, true>(c.rule_xu, mu0, S0, L, ObserveF<M, R>{c.params}, mz, Sz, Sxz);
 #pragma unroll
       for (int i = 0; i < sym(NZ); ++i) Sz[i] += alpha * c.sig_xi0[i];
-      if (!kalman_update<D, NZ>(mu0, S0, mz, Sz, Sxz, zt)) set_status(a.status, b, 3, t);
+      fail = note_failure(fail, kalman_update<D, NZ>(mu0, S0, mz, Sz, Sxz, zt), 3, t);
     }
     if (PREFETCH && c.z_per_cell) {  // the target is consumed: fetch the next cell's
 #pragma unroll
@@ -484,7 +490,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       R L[sym(D)], rinv[D];
 #pragma unroll
       for (int i = 0; i < sym(D); ++i) L[i] = S0[i];
-      if (!chol<D>(L, rinv)) set_status(a.status, b, 4, t);
+      fail = note_failure(fail, chol<D>(L, rinv), 4, t);
       sp_transform<M, DenseStruct<D>, D, NX, true>(c.rule_xu, mu0, S0, L, DynamicsF<M, R>{c.params}, mu_x, sig_x, Sxy);
     }
 #pragma unroll
@@ -492,7 +498,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     R L3[sym(NX)], rinv3[NX];
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) L3[i] = sig_x[i];
-    if (!chol<NX>(L3, rinv3)) set_status(a.status, b, 5, t);
+    fail = note_failure(fail, chol<NX>(L3, rinv3), 5, t);
     sched_fence<(D >= 6)>();
 #pragma unroll
     for (int i = 0; i < D; ++i) {  // J = sig_xy sig_x3^{-1}, row by row
@@ -514,7 +520,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       sp_transform<M, TermStruct<M>, NX, NT, true>(c.rule_x, mu_x, sig_x, L3, ObserveTermF<M, R>{c.params}, mzt, Szt, Sxzt);
 #pragma unroll
       for (int i = 0; i < sym(NT); ++i) Szt[i] += alpha * c.sig_xiT0[i];
-      if (!kalman_update<NX, NT>(mu_x, sig_x, mzt, Szt, Sxzt, c.zg_term)) set_status(a.status, b, 6, t);
+      fail = note_failure(fail, kalman_update<NX, NT>(mu_x, sig_x, mzt, Szt, Sxzt, c.zg_term), 6, t);
     }
 #pragma unroll
     for (int e = 0; e < NX; ++e) wst(out, (D + sym(D) + e) * rb, bo, mu_x[e]);
@@ -522,6 +528,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     for (int e = 0; e < sym(NX); ++e) wst(out, (D + sym(D) + NX + e) * rb, bo, sig_x[e]);
 
   }
+  if (fail != 0 && a.status[b] == 0) a.status[b] = fail;
 }
 
 // ------------------------------------------------------------------------------------------
