@@ -34,7 +34,6 @@ I2C_FN double seed_rcp(double x) { return (double)(float)(1.0 / x); }
 I2C_FN double m_fma(double a, double b, double c) { return std::fma(a, b, c); }
 I2C_FN double m_rint(double x) { return std::rint(x); }
 I2C_FN double m_fabs(double x) { return std::fabs(x); }
-I2C_FN void slow_sincos(double x, double* s, double* c) { *s = std::sin(x); *c = std::cos(x); }
 I2C_FN float r_rsqrt(float x) { return 1.0f / std::sqrt(x); }
 I2C_FN float r_rcp(float x) { return 1.0f / x; }
 I2C_FN double r_exp(double x) { return std::exp(x); }
@@ -46,7 +45,6 @@ I2C_FN double seed_rcp(double x) { return __builtin_amdgcn_rcp(x); }
 I2C_FN double m_fma(double a, double b, double c) { return fma(a, b, c); }
 I2C_FN double m_rint(double x) { return rint(x); }
 I2C_FN double m_fabs(double x) { return fabs(x); }
-I2C_FN void slow_sincos(double x, double* s, double* c) { sincos(x, s, c); }
 I2C_FN float r_rsqrt(float x) { return rsqrtf(x); }
 I2C_FN float r_rcp(float x) { return 1.0f / x; }
 I2C_FN double r_exp(double x) { return exp(x); }
@@ -78,14 +76,13 @@ I2C_FN double r_rcp(double x) {
   y = m_fma(m_fma(-x, y, 1.0), y, y);
   return m_fma(m_fma(-x, y, 1.0), y, y);
 }
-// sin and cos together. |x| < 1e5: three-term Cody-Waite reduction by pi/2 (each n * chunk
-// product is exact for |n| < 2^20) + the classic degree-13/14 minimax kernels on [-pi/4, pi/4];
-// otherwise (never on the shipped problems) the library's Payne-Hanek path.
+// sin and cos together, BRANCH-FREE (a branch per call would cut every cell into small scheduling
+// regions): three-term Cody-Waite reduction by pi/2 (each n * chunk product is exact for |n| < 2^20,
+// i.e. |x| < 1.6e6) + the classic degree-13/14 minimax kernels on [-pi/4, pi/4]; <= 1 ulp there.
+// |x| >= 1e6 rad (a diverged trajectory) yields NaN, which the next Cholesky flags in status[b] --
+// the reference would still evaluate np.sin exactly there; documented deviation.
 I2C_FN void r_sincos(double x, double* s, double* c) {
-  if (!(m_fabs(x) < 1.0e5)) {
-    slow_sincos(x, s, c);
-    return;
-  }
+  x = m_fabs(x) < 1.0e6 ? x : (x - x) / (x - x);  // NaN outside the supported range (select, no branch)
   const double n = m_rint(x * 6.36619772367581382433e-01);
   double r = m_fma(-n, 1.57079632673412561417e+00, x);
   r = m_fma(-n, 6.07710050630396597660e-11, r);
@@ -108,25 +105,8 @@ I2C_FN void r_sincos(double x, double* s, double* c) {
   *s = (q & 2) ? -ss : ss;
   *c = ((q + 1) & 2) ? -cc : cc;
 }
-// sincos for the small sigma-point offsets d = sf L[i][j]: no range reduction while |x| <= pi/4.
-I2C_FN void r_sincos_small(double x, double* s, double* c) {
-  if (!(m_fabs(x) <= 0.78539816339744830962)) {
-    r_sincos(x, s, c);
-    return;
-  }
-  const double z = x * x;
-  double ps = p_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  ps = p_fma(ps, z, 2.75573137070700676789e-06);
-  ps = p_fma(ps, z, -1.98412698298579493134e-04);
-  ps = p_fma(ps, z, 8.33333333332248946124e-03);
-  *s = m_fma(z * x, m_fma(z, ps, -1.66666666666666324348e-01), x);
-  double pc = p_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  pc = p_fma(pc, z, -2.75573143513906633035e-07);
-  pc = p_fma(pc, z, 2.48015872894767294178e-05);
-  pc = p_fma(pc, z, -1.38888888888741095749e-03);
-  pc = p_fma(pc, z, 4.16666666666666019037e-02);
-  *c = 1.0 - m_fma(0.5, z, -(z * z) * pc);
-}
+// the sigma-point offsets d = sf L[i][j] go through the same branch-free routine
+I2C_FN void r_sincos_small(double x, double* s, double* c) { r_sincos(x, s, c); }
 I2C_FN void r_sincos_small(float x, float* s, float* c) { r_sincos(x, s, c); }
 
 // Global memory access for the [row][B] buffers: a wave-uniform window (buffer resource in SGPRs)
