@@ -32,10 +32,10 @@ static int sweep_lanes() {
   return v;
 }
 
-template <class M, typename R>
+template <class M, typename R, bool LEAN>
 __global__ __launch_bounds__(SWEEP_BLOCK) void k_forward(const Consts<M, R> c, const FwdArgs<R> a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < c.B) forward_sweep_body<M, R>(c, a, b);
+  if (b < c.B) forward_sweep_body<M, R, LEAN>(c, a, b);
 }
 template <class M, typename R>
 __global__ __launch_bounds__(SWEEP_BLOCK) void k_scan(const Consts<M, R> c, const ScanArgs<R> a) {
@@ -208,12 +208,22 @@ template <class M, typename R> struct Impl {
                  (const R*)p->z,  (const R*)p->alpha, (const R*)p->alpha_cell, p->feedforward, status};
 #ifdef I2C_HOST_SIM
     (void)stream;
-    for (int b = 0; b < p->B; ++b) forward_sweep_body<M, R>(c, a, b);
+    const bool lean = c.rule_xu.unit && c.rule_x.unit && !c.z_per_cell && !a.alpha_cell && !a.prior_out;
+    for (int b = 0; b < p->B; ++b) {
+      if (lean)
+        forward_sweep_body<M, R, true>(c, a, b);
+      else
+        forward_sweep_body<M, R, false>(c, a, b);
+    }
     return I2C_OK;
 #else
     const int lanes = sweep_lanes();
     const int grid = (p->B + lanes - 1) / lanes;
-    hipLaunchKernelGGL((k_forward<M, R>), dim3(grid), dim3(lanes), 0, (hipStream_t)stream, c, a);
+    const bool lean = c.rule_xu.unit && c.rule_x.unit && !c.z_per_cell && !a.alpha_cell && !a.prior_out;
+    if (lean)
+      hipLaunchKernelGGL((k_forward<M, R, true>), dim3(grid), dim3(lanes), 0, (hipStream_t)stream, c, a);
+    else
+      hipLaunchKernelGGL((k_forward<M, R, false>), dim3(grid), dim3(lanes), 0, (hipStream_t)stream, c, a);
     return launch_status();
 #endif
   }

@@ -113,7 +113,7 @@ template <int DIN> struct DenseStruct {
 // Sin (2 wi sf^2 = 1 for every alpha, beta, kappa) and cost nothing.
 // Trig of the model's angle coordinates is computed once at the mean and once per (angle, column)
 // offset d = sf L[i][j], then rotated: sin(m +/- d) = s0 cd +/- c0 sd, cos(m +/- d) = c0 cd -/+ s0 sd.
-template <class M, class ST, int DIN, int DOUT, bool CROSS, typename R, class F>
+template <class M, class ST, int DIN, int DOUT, bool CROSS, bool UNITW = false, typename R, class F>
 I2C_FN void sp_transform(const Rule<R>& rule, const R* m, const R* Sin, const R* L, const F& f, R* my, R* Sy,
                          R* Sxy) {
   constexpr int NA = M::NA, NA1 = NA > 0 ? NA : 1;
@@ -200,7 +200,8 @@ I2C_FN void sp_transform(const Rule<R>& rule, const R* m, const R* Sin, const R*
   const R hw = R(0.5) * rule.wi, w2 = rule.wi * rule.wi, cs = rule.wi * rule.sf;
 #pragma unroll
   for (int k = 0; k < DOUT; ++k) {
-    my[k] = ST::lin(k) >= 0 ? rule.W * m[ST::lin(k) >= 0 ? ST::lin(k) : 0] : rule.W * y0[k] + rule.wi * A[k];
+    const R Wk = UNITW ? R(1) : rule.W;
+    my[k] = ST::lin(k) >= 0 ? Wk * m[ST::lin(k) >= 0 ? ST::lin(k) : 0] : Wk * y0[k] + rule.wi * A[k];
 #pragma unroll
     for (int l = 0; l <= k; ++l) {
       if (ST::lin(k) >= 0 && ST::lin(l) >= 0)
@@ -214,7 +215,7 @@ I2C_FN void sp_transform(const Rule<R>& rule, const R* m, const R* Sin, const R*
         Sxy[i * DOUT + k] = ST::lin(k) >= 0 ? Sin[tri_any(i, ST::lin(k) >= 0 ? ST::lin(k) : 0)] : cs * Sxy[i * DOUT + k];
     }
   }
-  if (!rule.unit) {  // sum of weights != 1: the reference's m m^T term no longer cancels
+  if (!UNITW && !rule.unit) {  // sum of weights != 1: the reference's m m^T term no longer cancels
     const R omw = R(1) - rule.W;
     R yc[DOUT];
 #pragma unroll
@@ -355,7 +356,10 @@ template <typename R> struct FwdArgs {
   int32_t* status;  // [B]
 };
 
-template <class M, typename R>
+// LEAN = the common case fixed at compile time (weights sum to 1, shared target, trajectory-level alpha, no
+// joint-prior output): the corresponding wave-uniform runtime branches disappear from the cell, which keeps
+// it one scheduling region. The generic variant (LEAN = false) handles everything.
+template <class M, typename R, bool LEAN = false>
 I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a, const int b) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D;
@@ -382,7 +386,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     for (int e = 0; e < C::E_PRI; ++e) pri[e] = wld<R>(w, e * rb, bo);
   }
 #pragma unroll
-  for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[(long)k * B + b] : c.zg[k];
+  for (int k = 0; k < NZ; ++k) zt[k] = (!LEAN && c.z_per_cell) ? a.z[(long)k * B + b] : c.zg[k];
 
   for (int t = 0; t < T; ++t) {
     const int tn = t + 1 < T ? t + 1 : t;
@@ -398,11 +402,11 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 #pragma unroll
       for (int e = 0; e < C::E_PRI; ++e) pri[e] = wld<R>(w, e * rb, bo);
 #pragma unroll
-      for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
+      for (int k = 0; k < NZ; ++k) zt[k] = (!LEAN && c.z_per_cell) ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
     }
 
     // per-cell temperature only in the MPC loop (stale sig_xi of appended cells); else the trajectory's
-    const R alpha = opaque(a.alpha_cell ? a.alpha_cell[(long)t * B + b] : alpha_traj);
+    const R alpha = opaque((!LEAN && a.alpha_cell) ? a.alpha_cell[(long)t * B + b] : alpha_traj);
     const R* pmu = pri;               // prior joint mean  (== previous posterior, see i2c_hip.h)
     const R* psig = pri + D;          // prior joint covariance
     const R* Kprev = pri + D + sym(D);
@@ -445,7 +449,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
         }
       joint_from_gain<NX, NU>(mu_x, sig_x, Kt, pmu, pmu + NX, sig_u, mu0, S0);
     }
-    if (a.prior_out) {
+    if (!LEAN && a.prior_out) {
       const Window w = make_window(a.prior_out + (unsigned long)t * (D + sym(D)) * B, (unsigned long)(D + sym(D)) * rb);
 #pragma unroll
       for (int e = 0; e < D; ++e) wst(w, e * rb, bo, mu0[e]);
@@ -467,12 +471,12 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       for (int i = 0; i < sym(D); ++i) L[i] = S0[i];
       fail = note_failure(fail, chol<D>(L, rinv), 1, t);
       R mz[NZ], Sz[sym(NZ)], Sxz[D * NZ];
-      sp_transform<M, ObsStruct<M>, D, NZ, true>(c.rule_xu, mu0, S0, L, ObserveF<M, R>{c.params}, mz, Sz, Sxz);
+      sp_transform<M, ObsStruct<M>, D, NZ, true, LEAN>(c.rule_xu, mu0, S0, L, ObserveF<M, R>{c.params}, mz, Sz, Sxz);
 #pragma unroll
       for (int i = 0; i < sym(NZ); ++i) Sz[i] += alpha * c.sig_xi0[i];
       fail = note_failure(fail, kalman_update<D, NZ>(mu0, S0, mz, Sz, Sxz, zt), 3, t);
     }
-    if (PREFETCH && c.z_per_cell) {  // the target is consumed: fetch the next cell's
+    if (!LEAN && PREFETCH && c.z_per_cell) {  // the target is consumed: fetch the next cell's
 #pragma unroll
       for (int k = 0; k < NZ; ++k) zt[k] = a.z[((long)tn * NZ + k) * B + b];
     }
@@ -491,10 +495,10 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 #pragma unroll
       for (int i = 0; i < sym(D); ++i) L[i] = S0[i];
       fail = note_failure(fail, chol<D>(L, rinv), 4, t);
-      sp_transform<M, DenseStruct<D>, D, NX, true>(c.rule_xu, mu0, S0, L, DynamicsF<M, R>{c.params}, mu_x, sig_x, Sxy);
+      sp_transform<M, DenseStruct<D>, D, NX, true, LEAN>(c.rule_xu, mu0, S0, L, DynamicsF<M, R>{c.params}, mu_x, sig_x, Sxy);
     }
 #pragma unroll
-    for (int i = 0; i < sym(NX); ++i) sig_x[i] += c.sig_eta_w[i];  // sum_p w_p sig_eta (quadrature.py:57)
+    for (int i = 0; i < sym(NX); ++i) sig_x[i] += LEAN ? c.sig_eta[i] : c.sig_eta_w[i];  // sum_p w_p sig_eta (quadrature.py:57)
     R L3[sym(NX)], rinv3[NX];
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) L3[i] = sig_x[i];
@@ -517,7 +521,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     if (NZT > 0 && t == c.terminal_cell && c.has_Qf) {
       constexpr int NT = C::NZT1;
       R mzt[NT], Szt[sym(NT)], Sxzt[NX * NT];
-      sp_transform<M, TermStruct<M>, NX, NT, true>(c.rule_x, mu_x, sig_x, L3, ObserveTermF<M, R>{c.params}, mzt, Szt, Sxzt);
+      sp_transform<M, TermStruct<M>, NX, NT, true, LEAN>(c.rule_x, mu_x, sig_x, L3, ObserveTermF<M, R>{c.params}, mzt, Szt, Sxzt);
 #pragma unroll
       for (int i = 0; i < sym(NT); ++i) Szt[i] += alpha * c.sig_xiT0[i];
       fail = note_failure(fail, kalman_update<NX, NT>(mu_x, sig_x, mzt, Szt, Sxzt, c.zg_term), 6, t);
