@@ -57,7 +57,8 @@ enum { I2C_F64 = 0, I2C_F32 = 1 };
 
 /* how i2c_backward_sweep is scheduled (results are identical up to summation order of the cost) */
 enum {
-  I2C_BWD_AUTO = 0,     /* chunked (or two-pass without workspace) below I2C_BWD_FUSED_MIN_B trajectories, fused above */
+  I2C_BWD_AUTO = 0,     /* resolved by i2c_backward_schedule(): chunked below I2C_BWD_FUSED_MIN_B trajectories; above, fused
+                           for nx+nu <= 5 and two-pass for the larger models (whose fused cell does not fit the registers) */
   I2C_BWD_TWO_PASS = 1, /* sequential nx x nx scan + one lane per (t, b) + reduction                  */
   I2C_BWD_FUSED = 2,    /* one lane per trajectory does the whole cell: lowest HBM traffic            */
   I2C_BWD_CHUNKED = 3   /* the affine x-recursion composed per chunk of cells: sequential depth ~2T/NC; needs `work` */
@@ -165,6 +166,11 @@ int i2c_query(int model_id, I2cDims* out);
 
 /* Bytes of I2cProblem.work the chunked backward sweep needs for (model_id, dtype, B, T). */
 size_t i2c_workspace_bytes(int model_id, int dtype, int B, int T);
+
+/* The schedule i2c_backward_sweep will run for a requested I2cProblem.backward_mode (resolves I2C_BWD_AUTO and the
+ * fall-backs: chunked needs T >= 8). Callers size their buffers from the answer: two-pass needs xm and cell_stats,
+ * chunked needs I2cProblem.work. Returns one of I2C_BWD_TWO_PASS / FUSED / CHUNKED, or 0 for an unknown model. */
+int i2c_backward_schedule(int model_id, int B, int T, int requested_mode);
 
 /* Library self-description: ABI version, and the gfx target it was compiled for. */
 int i2c_abi_version(void);

@@ -88,6 +88,7 @@ _SIGNATURES = {
     "i2c_abi_version": (C.c_int, []),
     "i2c_build_info": (C.c_char_p, []),
     "i2c_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "i2c_backward_schedule": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "i2c_query": (C.c_int, [C.c_int, C.POINTER(I2cDims)]),
     "i2c_forward_sweep": (C.c_int, [C.POINTER(I2cProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "i2c_backward_sweep": (

@@ -228,10 +228,19 @@ template <class M, typename R> struct Impl {
 #endif
   }
 
+  // Measured on MI355X (tools/bench_models.py): below ~32k trajectories the sequential depth decides -> chunked.
+  // Above, HBM traffic decides for the small models -> fused (264 instead of ~490 B/cell for the pendulum); the
+  // fused cell of the d >= 6 models spills ~800 B/lane and the spill-free two-pass kernels are 2x faster.
+  static int schedule(int B, int T, int requested) {
+    int mode = requested;
+    if (mode == I2C_BWD_AUTO)
+      mode = B < I2C_BWD_FUSED_MIN_B ? I2C_BWD_CHUNKED : (M::NX + M::NU <= 5 ? I2C_BWD_FUSED : I2C_BWD_TWO_PASS);
+    if (mode == I2C_BWD_CHUNKED && T < 8) mode = I2C_BWD_TWO_PASS;  // too short to chunk
+    return mode;
+  }
   static int pick_mode(const I2cProblem* p) {
-    int mode = p->backward_mode;
-    if (mode == I2C_BWD_AUTO) mode = p->B >= I2C_BWD_FUSED_MIN_B ? I2C_BWD_FUSED : I2C_BWD_CHUNKED;
-    if (mode == I2C_BWD_CHUNKED && (!p->work || p->T < 8)) mode = I2C_BWD_TWO_PASS;  // no workspace / too short
+    int mode = schedule(p->B, p->T, p->backward_mode);
+    if (mode == I2C_BWD_CHUNKED && !p->work) mode = I2C_BWD_TWO_PASS;  // no workspace
     return mode;
   }
 
@@ -455,6 +464,20 @@ const char* i2c_build_info(void) {
 #else
   return "i2c hip build: gfx950 (MI355X), wave64, one trajectory per lane";
 #endif
+}
+
+int i2c_backward_schedule(int model_id, int B, int T, int requested_mode) {
+  if (B < 1 || T < 1 || requested_mode < I2C_BWD_AUTO || requested_mode > I2C_BWD_CHUNKED) return 0;
+  switch (model_id) {
+    case I2C_MODEL_PENDULUM: return i2c::Impl<i2c::Pendulum, double>::schedule(B, T, requested_mode);
+    case I2C_MODEL_PENDULUM_ACTREG: return i2c::Impl<i2c::PendulumActReg, double>::schedule(B, T, requested_mode);
+    case I2C_MODEL_CARTPOLE: return i2c::Impl<i2c::Cartpole, double>::schedule(B, T, requested_mode);
+    case I2C_MODEL_DOUBLE_CARTPOLE: return i2c::Impl<i2c::DoubleCartpole, double>::schedule(B, T, requested_mode);
+    case I2C_MODEL_LINEAR: return i2c::Impl<i2c::Linear, double>::schedule(B, T, requested_mode);
+    case I2C_MODEL_LINEAR_MINENERGY: return i2c::Impl<i2c::LinearMinEnergy, double>::schedule(B, T, requested_mode);
+    case I2C_MODEL_QUADROTOR: return i2c::Impl<i2c::Quadrotor, double>::schedule(B, T, requested_mode);
+    default: return 0;
+  }
 }
 
 size_t i2c_workspace_bytes(int model_id, int dtype, int B, int T) {

@@ -144,11 +144,9 @@ class BatchedI2c:
         self.prior_out = zeros(T, d + sym_size(d), B) if keep_prior else None
         self.backward_mode = {"auto": _native.BWD_AUTO, "two_pass": _native.BWD_TWO_PASS, "fused": _native.BWD_FUSED,
                               "chunked": _native.BWD_CHUNKED}[backward_mode]
-        mode = self.backward_mode
-        if mode == _native.BWD_AUTO:
-            mode = _native.BWD_FUSED if B >= 32768 else _native.BWD_CHUNKED
-        if mode == _native.BWD_CHUNKED and T < 8:
-            mode = _native.BWD_TWO_PASS
+        mode = self.lib.i2c_backward_schedule(self.model_id, B, T, self.backward_mode)  # resolves "auto"
+        if mode not in (_native.BWD_TWO_PASS, _native.BWD_FUSED, _native.BWD_CHUNKED):
+            raise RuntimeError("i2c_backward_schedule() returned %d" % mode)
         self.fused_backward = mode == _native.BWD_FUSED
         self.backward_schedule = {_native.BWD_TWO_PASS: "two_pass", _native.BWD_FUSED: "fused", _native.BWD_CHUNKED: "chunked"}[mode]
         # the two-pass backward needs xm / cell_stats as workspace; the fused and chunked ones only write xm on request

@@ -57,3 +57,22 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     p = pkg._native.I2cProblem()
     assert lib.i2c_forward_sweep(ctypes.byref(p), None, None, None, None, None) == -1  # I2C_EINVAL
     assert lib.i2c_mstep(ctypes.byref(p), None, 0.0, 1, None, None) == -1
+
+
+def test_backward_schedule_rule():
+    """I2C_BWD_AUTO: chunked below 32768 trajectories; above, fused for d <= 5 and two-pass for d >= 6; chunked
+    needs T >= 8; explicit requests are honoured; unknown models / modes give 0."""
+    lib = pkg.load_library()
+    N = pkg._native
+    f = lib.i2c_backward_schedule
+    assert f(0, 4096, 200, N.BWD_AUTO) == N.BWD_CHUNKED
+    assert f(0, 32768, 200, N.BWD_AUTO) == N.BWD_FUSED
+    assert f(2, 65536, 500, N.BWD_AUTO) == N.BWD_FUSED       # cartpole, d = 5
+    assert f(3, 32768, 300, N.BWD_AUTO) == N.BWD_TWO_PASS    # double cartpole, d = 7
+    assert f(6, 32768, 50, N.BWD_AUTO) == N.BWD_TWO_PASS     # quadrotor, d = 8
+    assert f(3, 4096, 300, N.BWD_AUTO) == N.BWD_CHUNKED
+    assert f(0, 4096, 5, N.BWD_AUTO) == N.BWD_TWO_PASS
+    assert f(0, 4096, 5, N.BWD_CHUNKED) == N.BWD_TWO_PASS
+    for m in (N.BWD_TWO_PASS, N.BWD_FUSED, N.BWD_CHUNKED):
+        assert f(3, 100000, 300, m) == m
+    assert f(99, 4096, 200, N.BWD_AUTO) == 0 and f(0, 4096, 200, 7) == 0 and f(0, 0, 200, 0) == 0

@@ -1,4 +1,5 @@
-"""Time one EM iteration (forward / backward / M-step) for any model:  python tools/bench_models.py [model ...]"""
+"""Time one EM iteration (forward / backward / M-step) for any model:
+python tools/bench_models.py [model ...] [B ...] [two_pass|fused|chunked ...] [f64]"""
 import importlib
 import os
 import sys
@@ -44,13 +45,16 @@ def run(name, B, dtype, iters=10, mode="auto"):
     el = (d.e_post - nu - nu * (nu + 1) // 2) + 2 * d.e_fwd + d.e_post
     tot = sum(ms)
     print(f"{name:22s} B={B:6d} T={T:3d} {str(dtype)[6:]:8s} fwd {ms[0]:8.3f} bwd {ms[1]:8.3f} mstep {ms[2]:6.3f} ms | "
-          f"{B * T / tot * 1e3:10.3e} msg/s | {el * w * B * T / tot / 1e6:8.1f} GB/s | fails {len(eng.failures())}")
+          f"[{mode:8s}] {B * T / tot * 1e3:10.3e} msg/s | {el * w * B * T / tot / 1e6:8.1f} GB/s | fails {len(eng.failures())}")
 
 
 if __name__ == "__main__":
     names = [a for a in sys.argv[1:] if a in CONFIGS] or list(CONFIGS)
     Bs = [int(a) for a in sys.argv[1:] if a.isdigit()] or [4096]
+    modes = [a for a in sys.argv[1:] if a in ("auto", "two_pass", "fused", "chunked")] or ["auto"]
+    dts = (torch.float64,) if "f64" in sys.argv[1:] else (torch.float64, torch.float32)
     for n in names:
         for B in Bs:
-            for dt in (torch.float64, torch.float32):
-                run(n, B, dt)
+            for dt in dts:
+                for m in modes:
+                    run(n, B, dt, mode=m)
