@@ -468,6 +468,165 @@ def case_i2c_run():
     save("run_pendulum_seed0", out)
 
 
+# --------------------------------------------------------------------------------------
+# Linearize inference (i2c.py:244-348, 449-542, 612-678). Linear systems need no Jacobian (model.py:227-229): those
+# cases pin the solver algebra exactly. The nonlinear ones use ref_shim's complex-step stand-in for autograd.jacobian.
+LIN_KEYS_F = FWD_KEYS + ["A", "B", "a", "E", "F"]
+
+
+def _capture_lin(g, out, it, fwd):
+    keys = LIN_KEYS_F if fwd else BWD_KEYS
+    for k in keys:
+        arrs = [np.asarray(getattr(c, k), dtype=float) for c in g.cells]
+        a = np.stack(arrs)
+        if k.startswith("mu_") or k in ("k", "a"):
+            a = a.reshape(a.shape[0], -1)
+        out[f"it{it}/{k}"] = a
+
+
+def run_em_linearize(g, n_detail, n_total, out, pre_propagate=False):
+    from i2c.exp_types import Linearize  # noqa: F401
+
+    if pre_propagate:
+        g.propagate()
+    for it in range(1, n_total + 1):
+        g.em_iter += 1
+        g._forward_msgs()
+        if it <= n_detail:
+            _capture_lin(g, out, it, True)
+        g._backward_msgs()
+        if it <= n_detail:
+            _capture_lin(g, out, it, False)
+            c = g.cells[-1]
+            out[f"it{it}/mu_z3_m"] = np.asarray(c.mu_z3_m, dtype=float).reshape(-1)
+            out[f"it{it}/sig_z3_m"] = np.asarray(c.sig_z3_m, dtype=float)
+        if g._propagate:
+            g.propagate()
+            if it <= n_detail:
+                for k, v in capture(g, PF_KEYS).items():
+                    out[f"it{it}/{k}"] = v
+        g._maximize()
+    out["alphas"] = np.asarray(g.alphas, dtype=float)
+    out["alphas_desired"] = np.asarray(g.alphas_desired, dtype=float)
+    out["costs_m"] = np.asarray(g.costs_m, dtype=float)
+    out["costs_m_var"] = np.asarray(g.costs_m_var, dtype=float)
+    out["costs_pf"] = np.asarray(g.costs_pf, dtype=float)
+    if g._propagate:
+        out["alphas_pf"] = np.asarray(g.alphas_pf, dtype=float)
+        out["costs_pf_var"] = np.asarray(g.costs_pf_var, dtype=float)
+    if len(g.kl_terms):
+        out["kl_terms"] = np.asarray(g.kl_terms, dtype=float)
+    K, k, sigK = g.get_local_linear_policy()
+    out["final/K"], out["final/k"], out["final/sigK"] = K, k, sigK
+    mu, sig = g.get_marginal_state_action_distribution()
+    out["final/mu_xu0_m"], out["final/sig_xu0_m"] = mu, sig
+
+
+def case_lin_linear(T=60, n_detail=2, n_total=10, noise=1e-4):
+    """scripts/experiments/linear_known.py:20-31 with non-degenerate noise (the shipped 1e-20 makes sig_x3_f
+    numerically singular: cond ~1e20, no digits are reproducible)."""
+    from i2c.exp_types import Linearize
+
+    mu_u = np.zeros((T, 1))
+    Q, R = np.diag([10.0, 10.0]), np.diag([1.0])
+    model = make_env_model("LinearKnown", None)
+    model.sig_x0 = noise * np.eye(2)
+    model.sig_eta = noise * np.eye(2)
+    g = I2cGraph(model, T, Q, R, Q, 1e2, 0.0, mu_u, 1e2 * np.eye(1), None, None, Linearize())
+    out = problem_inputs("LinearKnown", model, T, Q, R, Q, 1e2, 0.0, mu_u, 1e2 * np.eye(1), None, None, (1, 0, 0),
+                         noise=noise, inference="linearize")
+    run_em_linearize(g, n_detail, n_total, out)
+    save("lin_linear_T60", out)
+
+
+def case_lin_lqr_compare(noise=1e-20):  # the shipped value: this path has no cancellation problem with it
+    """The protocol of scripts/lqr_compare.py:120-175 (config 0): redefined linear system, alpha 1e-5, feed-forward
+    cells, one forward/backward pass, then the Riccati messages; LQR solution from utils.finite_horizon_lqr."""
+    from i2c.exp_types import Linearize
+    from i2c.utils import finite_horizon_lqr
+    import experiments.linear_known as experiment
+
+    T = experiment.N_DURATION
+    model = make_env_model("LinearKnown", None)
+    model.sig_x0 = noise * np.eye(2)
+    model.sig_eta = noise * np.eye(2)
+    model.xag = 10 * np.ones((2, 1))
+    model.zg_term = 10 * np.ones((2, 1))
+    model.a = model.xag - model.A @ model.xag
+    Q, R, Qf = experiment.INFERENCE.Q, experiment.INFERENCE.R, experiment.INFERENCE.Qf
+    x_lqr, u_lqr, K_lqr, k_lqr, cost_lqr, P, p = finite_horizon_lqr(
+        T, model.A, model.a[:, 0], model.B, Q, R, model.x0[:, 0], model.xag[:, 0], np.zeros((1,)), 2, 1)
+    mu_u = np.zeros((T, 1))
+    g = I2cGraph(model, T, Q, R, Qf, 1e-5, experiment.INFERENCE.alpha_update_tol, mu_u, 1e2 * np.eye(1), None, None, Linearize())
+    g.use_expert_controller = False
+    out = problem_inputs("LinearKnown", model, T, Q, R, Qf, 1e-5, experiment.INFERENCE.alpha_update_tol, mu_u, 1e2 * np.eye(1),
+                         None, None, (1, 0, 0), noise=noise, inference="linearize", goal=10.0, use_expert_controller=False)
+    g._forward_backward_msgs()
+    _capture_lin(g, out, 1, True)
+    _capture_lin(g, out, 1, False)
+    g._backward_ricatti_msgs()
+    for k in ("K", "k", "sigK", "nu_x0_b", "lambda_x0_b"):
+        a = np.stack([np.asarray(getattr(c, k), float) for c in g.cells])
+        out["riccati/" + k] = a.reshape(a.shape[0], -1) if k in ("k", "nu_x0_b") else a
+    out["lqr/x"], out["lqr/u"], out["lqr/K"], out["lqr/k"] = x_lqr, u_lqr, K_lqr, k_lqr
+    out["lqr/P"], out["lqr/p"] = np.asarray(P, float), np.asarray(p, float)
+    save("lin_lqr_compare", out)
+
+
+def case_lin_covariance_control(n_detail=2):
+    """scripts/linear_gaussian_covariance_control.py:97-126 + experiments/linear_known_covariance_control.py."""
+    import experiments.linear_known_covariance_control as experiment
+
+    T, inf = experiment.N_DURATION, experiment.INFERENCE
+    model = make_env_model(experiment.ENVIRONMENT, None)
+    g = I2cGraph(model, T, inf.Q, inf.R, inf.Qf, inf.alpha, inf.alpha_update_tol, inf.mu_u, inf.sig_u, inf.mu_x_term,
+                 inf.sig_x_term, inf.inference)
+    for c in g.cells:
+        c.use_expert_controller = False
+    g._propagate = True
+    out = problem_inputs(experiment.ENVIRONMENT, model, T, inf.Q, inf.R, inf.Qf, inf.alpha, inf.alpha_update_tol, inf.mu_u,
+                         inf.sig_u, inf.mu_x_term, inf.sig_x_term, (1, 0, 0), inference="linearize", propagate=True,
+                         use_expert_controller=False)
+    run_em_linearize(g, n_detail, experiment.N_INFERENCE, out)
+    save("lin_covctrl_T50", out)
+
+
+def _case_lin_nonlinear(env, T, Q, R, Qf, alpha, tol, mu_u, sig_u, n_detail, n_total, name):
+    from i2c.exp_types import Linearize
+
+    model = make_env_model(env, None)
+    g = I2cGraph(model, T, Q, R, Qf, alpha, tol, mu_u, sig_u, None, None, Linearize())
+    out = problem_inputs(env, model, T, Q, R, Qf, alpha, tol, mu_u, sig_u, None, None, (1, 0, 0), inference="linearize",
+                         jacobian="complex-step stand-in for autograd.jacobian (oracle/ref_shim.py)")
+    run_em_linearize(g, n_detail, n_total, out)
+    save(name, out)
+
+
+def case_lin_pendulum():
+    """scripts/experiments/pendulum_known.py:21-33."""
+    T = 100
+    _case_lin_nonlinear("PendulumKnown", T, np.diag([1, 100.0, 1]), np.diag([1.0]), np.diag([1, 100.0, 1]), 100.0, 0.99,
+                        np.zeros((T, 1)), 0.2 * np.eye(1), 2, 30, "lin_pendulum_T100")
+
+
+def case_lin_cartpole():
+    """scripts/experiments/cartpole_known.py:21-33 at a shorter horizon."""
+    T = 100
+    np.random.seed(0)
+    Q = np.diag([1.0, 1.0, 100.0, 10.0, 1.0])
+    _case_lin_nonlinear("CartpoleKnown", T, Q, np.diag([1.0]), Q, 70.0, 0.99, 1e-2 * np.random.randn(T, 1), 0.25 * np.eye(1),
+                        2, 10, "lin_cartpole_T100")
+
+
+def case_lin_double_cartpole():
+    """scripts/experiments/double_cartpole_known.py:20-32 at a shorter horizon."""
+    T = 80
+    Q = np.diag([1.0, 1.0, 100.0, 1.0, 100.0, 1.0, 1.0, 1.0])
+    Qf = np.diag([1.0, 1000.0, 1000.0, 1000.0, 1000.0, 100.0, 100.0, 100.0])
+    _case_lin_nonlinear("DoubleCartpoleKnown", T, Q, np.diag([0.1]), Qf, 90.0, 0.9995, np.zeros((T, 1)), 0.04 * np.eye(1),
+                        2, 8, "lin_dcp_T80")
+
+
 CASES = {
     "pendulum": case_pendulum,
     "pendulum_long": case_pendulum_long,
@@ -485,6 +644,12 @@ CASES = {
     "em_quad": case_em_quadrotor,
     "mpc_quad": case_mpc_quadrotor,
     "i2c_run": case_i2c_run,
+    "lin_linear": case_lin_linear,
+    "lin_lqr": case_lin_lqr_compare,
+    "lin_covctrl": case_lin_covariance_control,
+    "lin_pendulum": case_lin_pendulum,
+    "lin_cartpole": case_lin_cartpole,
+    "lin_dcp": case_lin_double_cartpole,
 }
 
 if __name__ == "__main__":

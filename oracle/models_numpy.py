@@ -230,9 +230,10 @@ class Linear(_Model):
     model_id = 4
     dim_x, dim_u, dim_z, dim_z_term = 2, 1, 3, 2
 
-    def __init__(self, noise=1e-20):
+    def __init__(self, noise=1e-20, goal=None):
         self.x0 = np.array([5.0, 5.0])
-        self.xg = np.array([1.0, -1.0])
+        # scripts/lqr_compare.py:128-131 redefines the goal (xag, zg_term, a) on the instance: `goal`
+        self.xg = np.array([1.0, -1.0]) if goal is None else float(goal) * np.ones(2)
         self.sig_x0 = noise * np.eye(2)
         self.sig_eta = noise * np.eye(2)
         self.A = np.array([[1.1, 0.0], [0.1, 1.1]])

@@ -35,6 +35,8 @@ def oracle_model(case):
     kw = {}
     if meta["model"] == "LinearKnown" and "noise" in meta:
         kw["noise"] = meta["noise"]
+    if meta["model"] == "LinearKnown" and "goal" in meta:
+        kw["goal"] = meta["goal"]
     m = make_model(meta["model"], **kw)
     return m
 
@@ -44,7 +46,10 @@ def oracle_from_case(case, **over):
 
     meta = case.meta
     model = oracle_model(case)
-    o = I2cOracle(
+    cls = I2cOracle
+    if meta.get("inference") == "linearize":
+        from oracle.i2c_linearize_numpy import I2cLinearizeOracle as cls
+    o = cls(
         model,
         meta["T"],
         case.get("Q"),
