@@ -1,0 +1,12 @@
+// One translation unit per (model, dtype): compiled with
+//   -DI2C_TU_MODEL=<struct in i2c_models.hpp> -DI2C_TU_REAL=<double|float> -DI2C_TU_OPS=<ops_<name>_<f64|f32>>
+// (see build.py). All kernels of the pair are instantiated here and nowhere else.
+#include "i2c_impl.hpp"
+
+#if !defined(I2C_TU_MODEL) || !defined(I2C_TU_REAL) || !defined(I2C_TU_OPS)
+#error "compile with -DI2C_TU_MODEL=... -DI2C_TU_REAL=... -DI2C_TU_OPS=..."
+#endif
+
+namespace i2c {
+const ModelOps* I2C_TU_OPS() { return make_ops<I2C_TU_MODEL, I2C_TU_REAL>(); }
+}  // namespace i2c

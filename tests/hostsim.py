@@ -1,4 +1,4 @@
-"""Builds (once) and loads the HOST SIMULATION of the kernel math: csrc/i2c_capi.hip compiled
+"""Builds (once) and loads the HOST SIMULATION of the kernel math: the csrc/ translation units compiled
 by g++ with -DI2C_HOST_SIM, i.e. the very same templated cell code looped on the CPU.
 
 Test infrastructure only: it lets `-m "not gpu"` tests check the kernels' arithmetic against
@@ -6,6 +6,7 @@ the oracle in a container without a GPU. The product package never builds, looks
 loads this library.
 """
 import importlib
+import importlib.util
 import os
 import subprocess
 
@@ -20,11 +21,11 @@ def build(force=False):
     newest = max(os.path.getmtime(s) for s in srcs)
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
         return OUT
-    os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-x", "c++", "-DI2C_HOST_SIM",
-           os.path.join(CSRC, "i2c_capi.hip"), "-o", OUT]
-    subprocess.run(cmd, check=True)
-    return OUT
+    spec = importlib.util.spec_from_file_location("i2c_amd_build", os.path.join(ROOT, "input-inference-for-control_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    flags = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "c++", "-DI2C_HOST_SIM"]
+    return mod.compile_all("g++", flags, os.path.join(OUT_DIR, "obj"), OUT, ["-shared", "-fPIC"], verbose=False)
 
 
 _lib = None
