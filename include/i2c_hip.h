@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define I2C_ABI_VERSION 1
+#define I2C_ABI_VERSION 2
 
 #define I2C_MAX_NX 8
 #define I2C_MAX_NU 4
@@ -54,6 +54,13 @@ enum {
 };
 
 enum { I2C_F64 = 0, I2C_F32 = 1 };
+
+/* inference method of the E-step (the `inference` argument of I2cGraph, i2c/exp_types.py:22-68) */
+enum {
+  I2C_INF_CUBATURE = 0,  /* CubatureQuadrature(alpha, beta, kappa): sigma points (i2c.py:350-447, 544-610)                */
+  I2C_INF_LINEARIZE = 1  /* Linearize(): first-order expansion about the means (i2c.py:244-348, 449-542); the plan cost
+                            and the closed-loop propagation still use CubatureQuadrature(1, 0, 0) (i2c.py:109-115, 841-844) */
+};
 
 /* how i2c_backward_sweep is scheduled (results are identical up to summation order of the cost) */
 enum {
@@ -82,7 +89,8 @@ enum {
   I2C_FAIL_TERMINAL = 6,      /* terminal observation update  (i2c.py:430-443, 548-570)              */
   I2C_FAIL_POSTERIOR = 7,     /* chol(sig_xu0_m)              (quadrature.py:17-24 via i2c.py:594)   */
   I2C_FAIL_PROPAGATE = 8,     /* closed-loop propagation      (i2c.py:196-197)                       */
-  I2C_FAIL_FILTER = 9         /* cubature Kalman filter step  (mpc.py:129, 140-142)                  */
+  I2C_FAIL_FILTER = 9,        /* cubature Kalman filter step  (mpc.py:129, 140-142)                  */
+  I2C_FAIL_RICCATI = 10       /* improper backward message in the Riccati form (singular inv, i2c.py:615-660) */
 };
 
 typedef struct I2cDims {
@@ -112,6 +120,9 @@ typedef struct I2cProblem {
   int32_t backward_mode;   /* I2C_BWD_AUTO | I2C_BWD_TWO_PASS | I2C_BWD_FUSED (see i2c_backward_sweep) */
   int32_t terminal_cell;   /* index of the cell whose FORWARD pass applies the terminal cost update (i2c.py:430-443;
                               `terminal_cell` flag, i2c.py:82,822); T-1 normally, moves with the MPC shift, -1: none */
+  int32_t inference;       /* I2C_INF_CUBATURE | I2C_INF_LINEARIZE                                                  */
+  int32_t expert_controller; /* Linearize forward pass only: scale the feedback gain by the pdf ratio (use_expert_controller,
+                              i2c.py:143,259-265); the cubature forward pass always scales it (i2c.py:366-375)      */
   /* CubatureQuadrature(alpha, beta, kappa): i2c/exp_types.py:31-49 */
   double quad_alpha, quad_beta, quad_kappa;
   double dtemp;            /* terminal-prior annealing rate (i2c.py:66,552)                    */
@@ -206,9 +217,14 @@ int i2c_forward_sweep(const I2cProblem* p, const void* prior, void* fwd, void* p
  *                              (compute_cost_gaussian, i2c.py:1034-1043); two-pass: required
  *                              workspace; fused: optional. m_t is also the cell's contribution
  *                              tr(QR (err err^T + sig_z0_m)) to alpha (i2c.py:913-919)
- *   term_stats [3 + nzt + SYM(nzt)][B] out: row 0 = tr(Qf (errT errT^T + sig_z3_m))
+ *   term_stats [4 + nzt + SYM(nzt)][B] out: row 0 = tr(Qf (errT errT^T + sig_z3_m))
  *                              (i2c.py:989-992; 0 when !has_Qf), row 1 = sum_t m_t, row 2 = sum_t v_t,
- *                              then mu_z3_m, sig_z3_m
+ *                              then mu_z3_m, sig_z3_m; the last row is used by I2C_INF_LINEARIZE only
+ * I2C_INF_LINEARIZE: one schedule (a lane per trajectory walks T-1..0; backward_mode is ignored); the terminal cost
+ * update happens here, at the end of the chain (i2c.py:475-491), and needs p->alpha; zpost holds the LINEARISED marginal
+ * observation h(mu), C sig_xx C^T + D sig_uu D^T (i2c.py:537-540), whose trace statistic feeds alpha: row 1 of term_stats
+ * is sum_t tr(QR (err err^T + sig_z0_m)) while the plan cost of the graph's cubature transform (i2c.py:1034-1053) goes to
+ * the last row (mean) and row 2 (variance).
  */
 int i2c_backward_sweep(const I2cProblem* p, const void* fwd, void* xm, void* post, void* zpost,
                        void* cell_stats, void* term_stats, int32_t* status, void* stream);
@@ -225,6 +241,19 @@ int i2c_backward_sweep(const I2cProblem* p, const void* fwd, void* xm, void* pos
  */
 int i2c_mstep(const I2cProblem* p, const void* term_stats, double alpha_update_tol, int update,
               void* stats_out, void* stream);
+
+/*
+ * Riccati-form backward messages after a Linearize forward/backward pass: replaces I2cGraph._backward_ricatti_msgs
+ * (i2c.py:888-893) over I2cCell._backward_ricatti_msgs (i2c.py:612-678), the verification helper of
+ * scripts/lqr_compare.py:175. Requires p->inference == I2C_INF_LINEARIZE.
+ *   prior_out  [T][d+SYM(d)][B]  in: what i2c_forward_sweep wrote as `prior_out` (mu_xu0_f, sig_xu0_f)
+ *   fwd        [T][e_fwd][B]     in
+ *   xm         [T][e_xm][B]      in: what i2c_backward_sweep wrote (only cell T-1 is read)
+ *   post       [T][e_post][B]    in/out: K, k, sigK are OVERWRITTEN with the Riccati-form controller, as in the reference
+ *   ric        [T][nx + nx*nx][B] out: nu_x0_b, lambda_x0_b (row-major) -- the backward state message in information form
+ */
+int i2c_riccati_sweep(const I2cProblem* p, const void* prior_out, const void* fwd, const void* xm, void* post, void* ric,
+                      int32_t* status, void* stream);
 
 /*
  * n_iters complete EM iterations enqueued back to back on `stream` with no host round trip:

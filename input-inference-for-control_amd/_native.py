@@ -9,7 +9,7 @@ without a GPU; nothing in the package ever looks for it.)
 import ctypes as C
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_NX, MAX_NU, MAX_NZ, MAX_PARAMS = 8, 4, 12, 16
 
 
@@ -19,6 +19,7 @@ def _sym(n):
 
 F64, F32 = 0, 1
 BWD_AUTO, BWD_TWO_PASS, BWD_FUSED, BWD_CHUNKED = 0, 1, 2, 3
+INF_CUBATURE, INF_LINEARIZE = 0, 1
 
 MODEL_IDS = {
     "PendulumKnown": 0,
@@ -59,6 +60,8 @@ class I2cProblem(C.Structure):
         ("z_per_cell", C.c_int32),
         ("backward_mode", C.c_int32),
         ("terminal_cell", C.c_int32),
+        ("inference", C.c_int32),
+        ("expert_controller", C.c_int32),
         ("quad_alpha", C.c_double),
         ("quad_beta", C.c_double),
         ("quad_kappa", C.c_double),
@@ -100,6 +103,7 @@ _SIGNATURES = {
         C.c_int,
         [C.POINTER(I2cProblem)] + [C.c_void_p] * 6 + [C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "i2c_riccati_sweep": (C.c_int, [C.POINTER(I2cProblem)] + [C.c_void_p] * 7),
     "i2c_rollout": (C.c_int, [C.POINTER(I2cProblem), C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8),
     "i2c_ckf_filter": (
         C.c_int,

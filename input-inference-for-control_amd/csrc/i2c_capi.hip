@@ -20,6 +20,7 @@ int check_problem(const I2cProblem* p) {
   if (p->B < 1 || p->T < 1) return I2C_EINVAL;
   if (!p->x0 || !p->sig_x0 || !p->alpha || !p->feedforward) return I2C_EINVAL;
   if (p->has_x_terminal && !p->temp) return I2C_EINVAL;
+  if (p->inference != I2C_INF_CUBATURE && p->inference != I2C_INF_LINEARIZE) return I2C_EINVAL;
   return I2C_OK;
 }
 
@@ -101,6 +102,13 @@ int i2c_rollout(const I2cProblem* p, const void* post, int n_rollouts, int polic
                 const void* eps_x, const void* eps_u, void* xu, void* z, void* x_final, void* z_term, void* stream) {
   if (!post || n_rollouts < 1 || policy < 0 || policy > 2) return I2C_EINVAL;
   I2C_DISPATCH(p, rollout(p, post, n_rollouts, policy, eps_x0, eps_x, eps_u, xu, z, x_final, z_term, stream));
+}
+
+int i2c_riccati_sweep(const I2cProblem* p, const void* prior_out, const void* fwd, const void* xm, void* post, void* ric,
+                      int32_t* status, void* stream) {
+  if (!prior_out || !fwd || !xm || !post || !ric || !status) return I2C_EINVAL;
+  if (p && p->inference != I2C_INF_LINEARIZE) return I2C_EINVAL;
+  I2C_DISPATCH(p, riccati(p, prior_out, fwd, xm, post, ric, status, stream));
 }
 
 int i2c_ckf_filter(const I2cProblem* p, const double* sig_zeta, const void* y, const void* u, void* mu, void* cov,

@@ -12,6 +12,7 @@
 //   * the controller (K, k, sigK) falls out of the Cholesky factor of the posterior joint.
 #pragma once
 #include <stdint.h>
+#include "../../include/i2c_hip.h"
 #include "i2c_linalg.hpp"
 #include "i2c_models.hpp"
 
@@ -35,9 +36,9 @@ template <class M, typename R> struct Consts {
   static constexpr int E_XM = NX + sym(NX);
   static constexpr int E_ZPOST = NZ + sym(NZ);
   static constexpr int E_PROP = D + sym(D) + NX + sym(NX);
-  static constexpr int E_TERM = 3 + NZT + sym(NZT);
+  static constexpr int E_TERM = 4 + NZT + sym(NZT);  // last row: plan-cost sum of the Linearize path
   int B, T;
-  int has_Qf, has_x_terminal, z_per_cell, use_expert, terminal_cell;
+  int has_Qf, has_x_terminal, z_per_cell, use_expert, terminal_cell, inference;
   int qr_diag, qf_diag;  // cost weights are diagonal: cheap closed forms in gaussian_cost
   Rule<R> rule_xu, rule_x;
   R dtemp, tol;
@@ -830,6 +831,7 @@ template <typename R> struct CellArgs {
   R* term_stats;     // [E_TERM][B]
   R* temp;           // [B] or null (fused only)
   int32_t* status;
+  const R* alpha;    // [B] (Linearize backward only: terminal cost update at the end of the chain)
 };
 
 template <class M, typename R>
@@ -1204,8 +1206,11 @@ template <class M, typename R>
 I2C_HD inline void mstep_body(const Consts<M, R>& c, const MstepArgs<R>& a, const int b) {
   using C = Consts<M, R>;
   const long B = c.B;
-  const R m = a.term_stats[B + b], v = a.term_stats[2 * B + b];
-  R tr = m, sf = R(C::NZ) * R(c.T);
+  // row 1 is the alpha statistic sum_t tr(QR (err err^T + sig_z0_m)); in the sigma-point path it IS the plan cost,
+  // the Linearize path reports the cost of the graph's cubature transform separately (last row)
+  const R stat = a.term_stats[B + b], v = a.term_stats[2 * B + b];
+  const R m = c.inference == I2C_INF_LINEARIZE ? a.term_stats[(long)(C::E_TERM - 1) * B + b] : stat;
+  R tr = stat, sf = R(C::NZ) * R(c.T);
   if (C::NZT > 0 && c.has_Qf) {
     tr += a.term_stats[b];
     sf += R(C::NZT);

@@ -21,6 +21,8 @@ struct ModelOps {
                  const void* eps_u, void* xu, void* z, void* x_final, void* z_term, void* stream);
   int (*propagate)(const I2cProblem*, const void* post, void* prop, void* prop_stats, int use_expert, int32_t* status,
                    void* stream);
+  int (*riccati)(const I2cProblem*, const void* prior_out, const void* fwd, const void* xm, void* post, void* ric,
+                 int32_t* status, void* stream);
   void (*dims)(I2cDims*);
   size_t (*workspace_elems)(int B, int T);
   int (*schedule)(int B, int T, int requested);

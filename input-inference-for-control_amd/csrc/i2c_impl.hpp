@@ -10,6 +10,7 @@
 #pragma once
 #include "i2c_entry.hpp"
 #include "i2c_cell.hpp"
+#include "i2c_linearize.hpp"
 
 #include <cmath>
 #include <cstdlib>
@@ -37,6 +38,21 @@ template <class M, typename R, bool LEAN>
 __global__ __launch_bounds__(SWEEP_BLOCK) void k_forward(const Consts<M, R> c, const FwdArgs<R> a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < c.B) forward_sweep_body<M, R, LEAN>(c, a, b);
+}
+template <class M, typename R>
+__global__ __launch_bounds__(SWEEP_BLOCK) void k_forward_lin(const Consts<M, R> c, const FwdArgs<R> a) {
+  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
+  if (b < c.B) forward_lin_body<M, R>(c, a, b);
+}
+template <class M, typename R>
+__global__ __launch_bounds__(SWEEP_BLOCK) void k_bwd_lin(const Consts<M, R> c, const CellArgs<R> a) {
+  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
+  if (b < c.B) backward_lin_body<M, R>(c, a, b);
+}
+template <class M, typename R>
+__global__ __launch_bounds__(SWEEP_BLOCK) void k_riccati(const Consts<M, R> c, const RiccatiArgs<R> a) {
+  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
+  if (b < c.B) riccati_body<M, R>(c, a, b);
 }
 template <class M, typename R>
 __global__ __launch_bounds__(SWEEP_BLOCK) void k_scan(const Consts<M, R> c, const ScanArgs<R> a) {
@@ -142,6 +158,7 @@ template <class M, typename R> static Consts<M, R> make_consts(const I2cProblem*
   c.z_per_cell = p->z_per_cell && p->z != nullptr;
   c.use_expert = use_expert;
   c.terminal_cell = p->terminal_cell;
+  c.inference = p->inference;
   auto is_diag = [](const double* W, int n) {
     for (int i = 0; i < n; ++i)
       for (int j = 0; j < i; ++j)
@@ -196,9 +213,20 @@ template <class M, typename R> struct Impl {
 
   static int forward(const I2cProblem* p, const void* prior, void* fwd, void* prior_out, int32_t* status,
                      void* stream) {
-    const C c = make_consts<M, R>(p, 0.0, 0);
+    const C c = make_consts<M, R>(p, 0.0, p->inference == I2C_INF_LINEARIZE ? p->expert_controller : 0);
     FwdArgs<R> a{(const R*)prior, (R*)fwd, (R*)prior_out, (const R*)p->x0, (const R*)p->sig_x0,
                  (const R*)p->z,  (const R*)p->alpha, (const R*)p->alpha_cell, p->feedforward, status};
+    if (p->inference == I2C_INF_LINEARIZE) {
+#ifdef I2C_HOST_SIM
+      (void)stream;
+      for (int b = 0; b < p->B; ++b) forward_lin_body<M, R>(c, a, b);
+      return I2C_OK;
+#else
+      hipLaunchKernelGGL((k_forward_lin<M, R>), dim3((p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK), dim3(SWEEP_BLOCK), 0,
+                         (hipStream_t)stream, c, a);
+      return launch_status();
+#endif
+    }
 #ifdef I2C_HOST_SIM
     (void)stream;
     const bool lean = c.rule_xu.unit && c.rule_x.unit && !c.z_per_cell && !a.alpha_cell && !a.prior_out;
@@ -240,11 +268,25 @@ template <class M, typename R> struct Impl {
   static int backward(const I2cProblem* p, const void* fwd, void* xm, void* post, void* zpost, void* cell_stats,
                       void* term_stats, int32_t* status, void* stream) {
     const C c = make_consts<M, R>(p, 0.0, 0);
+    if (p->inference == I2C_INF_LINEARIZE) {  // one schedule: a lane per trajectory walks T-1..0
+      if (M::NZT == 0) return I2C_EINVAL;  // no terminal observation: the reference fails at i2c.py:500-501
+      CellArgs<R> al{(const R*)fwd, (const R*)xm,    (const R*)p->z, (R*)post, (R*)zpost,
+                     (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   (const R*)p->alpha};
+#ifdef I2C_HOST_SIM
+      (void)stream;
+      for (int b = 0; b < p->B; ++b) backward_lin_body<M, R>(c, al, b);
+      return I2C_OK;
+#else
+      hipLaunchKernelGGL((k_bwd_lin<M, R>), dim3((p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK), dim3(SWEEP_BLOCK), 0,
+                         (hipStream_t)stream, c, al);
+      return launch_status();
+#endif
+    }
     const int mode = pick_mode(p);
     if (mode == I2C_BWD_TWO_PASS && (!xm || !cell_stats)) return I2C_EINVAL;
     ScanArgs<R> s{(const R*)fwd, (R*)xm, (R*)p->temp, status};
     CellArgs<R> a{(const R*)fwd, (const R*)xm,   (const R*)p->z, (R*)post,  (R*)zpost,
-                  (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status};
+                  (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   (const R*)p->alpha};
     ChunkArgs<R> ch{a, nullptr, nullptr, nullptr, 0, 0};
     C cr = c;  // reduction over chunks instead of cells: same kernel, T := number of chunks
     if (mode == I2C_BWD_CHUNKED) {
@@ -310,6 +352,22 @@ template <class M, typename R> struct Impl {
     hipLaunchKernelGGL((k_cell<M, R>), cgrid, dim3(CELL_BLOCK), 0, st, c, a);
     if (launch_status() != I2C_OK) return I2C_ELAUNCH;
     hipLaunchKernelGGL((k_reduce<M, R>), dim3(grid), dim3(SWEEP_BLOCK, REDUCE_PARTS), 0, st, c, a);
+    return launch_status();
+#endif
+  }
+
+  static int riccati(const I2cProblem* p, const void* prior_out, const void* fwd, const void* xm, void* post, void* ric,
+                     int32_t* status, void* stream) {
+    const C c = make_consts<M, R>(p, 0.0, 0);
+    RiccatiArgs<R> a{(const R*)prior_out, (const R*)fwd, (const R*)xm, (const R*)p->z, (const R*)p->alpha,
+                     (R*)post,            (R*)ric,       status};
+#ifdef I2C_HOST_SIM
+    (void)stream;
+    for (int b = 0; b < p->B; ++b) riccati_body<M, R>(c, a, b);
+    return I2C_OK;
+#else
+    hipLaunchKernelGGL((k_riccati<M, R>), dim3((p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK), dim3(SWEEP_BLOCK), 0,
+                       (hipStream_t)stream, c, a);
     return launch_status();
 #endif
   }
@@ -424,7 +482,8 @@ template <class M> static void fill_dims(I2cDims* d) {
 template <class M, typename R> const ModelOps* make_ops() {
   using I = Impl<M, R>;
   static const ModelOps ops = {&I::forward, &I::backward,  &I::mstep,        &I::learn,           &I::ckf,
-                               &I::rollout, &I::propagate, &fill_dims<M>, &workspace_elems<M>, &I::schedule};
+                               &I::rollout, &I::propagate, &I::riccati,   &fill_dims<M>,       &workspace_elems<M>,
+                               &I::schedule};
   return &ops;
 }
 

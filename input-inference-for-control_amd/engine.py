@@ -53,7 +53,7 @@ class BatchedI2c:
     def __init__(self, model, horizon, Q, R, Qf, alpha, alpha_update_tol, mu_u, sig_u,
                  mu_x_terminal=None, sig_x_terminal=None, quad=(1.0, 0.0, 0.0), x0=None, sig_x0=None,
                  z_traj=None, batch=None, dtype=torch.float64, device=None, lib=None, dtemp=1.0,
-                 keep_zpost=True, keep_prior=False, keep_xm=True, backward_mode="auto"):
+                 keep_zpost=True, keep_prior=False, keep_xm=True, backward_mode="auto", inference="cubature"):
         self.lib = lib if lib is not None else _native.load_library()
         if device is None:
             device = "cpu" if self.lib.is_host_sim else "cuda"
@@ -115,6 +115,18 @@ class BatchedI2c:
             self.Qf = np.zeros((nx, nx))  # i2c.py:792
             self.sig_xi_terminal_base = None
         self.alpha_update_tol = float(alpha_update_tol)
+        # inference method of the E-step (I2cGraph's `inference`, i2c.py:103-127): "cubature" = sigma points with
+        # CubatureQuadrature(*quad); "linearize" = Linearize(), whose plan cost and propagation use
+        # CubatureQuadrature(1, 0, 0) (i2c.py:109-115, 841-844)
+        if inference not in ("cubature", "linearize"):
+            raise ValueError(f"unknown inference method {inference!r}")
+        self.inference = inference
+        self.linearize = inference == "linearize"
+        if self.linearize:
+            quad = (1.0, 0.0, 0.0)
+            if nzt == 0:
+                raise NotImplementedError("Linearize() needs a terminal observation: for this model the reference's "
+                                          "observe_terminal_linearize returns None and i2c.py:500-501 fails")
         self.quad = tuple(float(q) for q in quad)
         self.mu_x_terminal = None if mu_x_terminal is None else np.asarray(mu_x_terminal, np.float64).reshape(nx)
         self.sig_x_terminal = None if sig_x_terminal is None else np.asarray(sig_x_terminal, np.float64)
@@ -147,6 +159,8 @@ class BatchedI2c:
         mode = self.lib.i2c_backward_schedule(self.model_id, B, T, self.backward_mode)  # resolves "auto"
         if mode not in (_native.BWD_TWO_PASS, _native.BWD_FUSED, _native.BWD_CHUNKED):
             raise RuntimeError("i2c_backward_schedule() returned %d" % mode)
+        if self.linearize:
+            mode = _native.BWD_FUSED  # the Linearize backward has one schedule: a lane per trajectory
         self.fused_backward = mode == _native.BWD_FUSED
         self.backward_schedule = {_native.BWD_TWO_PASS: "two_pass", _native.BWD_FUSED: "fused", _native.BWD_CHUNKED: "chunked"}[mode]
         # the two-pass backward needs xm / cell_stats as workspace; the fused and chunked ones only write xm on request
@@ -157,7 +171,7 @@ class BatchedI2c:
         if mode == _native.BWD_CHUNKED:
             nbytes = self.lib.i2c_workspace_bytes(self.model_id, F64 if dt == torch.float64 else F32, B, T)
             self.work = torch.empty(nbytes // (8 if dt == torch.float64 else 4), dtype=dt, device=dev)
-        self.e_term = 3 + nzt + sym_size(nzt)
+        self.e_term = 4 + nzt + sym_size(nzt)
         self.term_stats = zeros(self.e_term, B)
         self.stats_out = zeros(4, B)
         self.prop = None
@@ -203,6 +217,8 @@ class BatchedI2c:
         p.z_per_cell = int(self.z is not None)
         p.backward_mode = self.backward_mode
         p.terminal_cell = int(self.terminal_cell)
+        p.inference = _native.INF_LINEARIZE if self.linearize else _native.INF_CUBATURE
+        p.expert_controller = int(bool(self.use_expert_controller))
         p.quad_alpha, p.quad_beta, p.quad_kappa = self.quad
         p.dtemp = self.dtemp
 
@@ -257,6 +273,7 @@ class BatchedI2c:
     # ------------------------------------------------------------------ sweeps
     def forward_sweep(self):
         """I2cGraph._forward_msgs (i2c.py:876-880)."""
+        self._problem.expert_controller = int(bool(self.use_expert_controller))
         rc = self.lib.i2c_forward_sweep(C.byref(self._problem), self._ptr(self.post), self._ptr(self.fwd),
                                         self._ptr(self.prior_out), self._ptr(self.status), self._stream())
         self._check(rc, "i2c_forward_sweep")
@@ -272,6 +289,24 @@ class BatchedI2c:
         """I2cGraph._forward_backward_msgs (i2c.py:1231-1236)."""
         self.forward_sweep()
         self.backward_sweep()
+
+    def riccati_sweep(self):
+        """I2cGraph._backward_ricatti_msgs (i2c.py:888-893): Riccati-form backward messages after a Linearize
+        forward/backward pass. Overwrites K, k, sigK with the Riccati-form controller (as the reference does) and
+        returns the backward state message in information form, (nu_x0_b (B, T, nx), lambda_x0_b (B, T, nx, nx))."""
+        if not self.linearize:
+            raise RuntimeError("the Riccati messages belong to the Linearize() path (i2c.py:612-678)")
+        if self.prior_out is None or self.xm is None:
+            raise RuntimeError("riccati_sweep() needs keep_prior=True and keep_xm=True")
+        nx = self.nx
+        self.ric = torch.zeros(self.H, nx + nx * nx, self.B, dtype=self.dtype, device=self.device)
+        rc = self.lib.i2c_riccati_sweep(C.byref(self._problem), self._ptr(self.prior_out), self._ptr(self.fwd),
+                                        self._ptr(self.xm), self._ptr(self.post), self._ptr(self.ric),
+                                        self._ptr(self.status), self._stream())
+        self._check(rc, "i2c_riccati_sweep")
+        nu = self.ric[:, :nx].permute(2, 0, 1)
+        lam = self.ric[:, nx:].permute(2, 0, 1).reshape(self.B, self.H, nx, nx)
+        return nu, lam
 
     def propagate(self):
         """I2cGraph.propagate (i2c.py:1247-1251)."""
@@ -331,6 +366,7 @@ class BatchedI2c:
             for _ in range(n_iters):
                 self.learn_msgs()
             return
+        self._problem.expert_controller = int(bool(self.use_expert_controller))
         hist = torch.empty(n_iters, 4, self.B, dtype=self.dtype, device=self.device)
         rc = self.lib.i2c_learn(C.byref(self._problem), self._ptr(self.post), self._ptr(self.fwd), self._ptr(self.xm),
                                 self._ptr(self.zpost), self._ptr(self.cell_stats), self._ptr(self.term_stats),
@@ -530,7 +566,7 @@ class BatchedI2c:
         if not self.has_Qf:
             return None, None
         nzt = self.nzt
-        return self.term_stats[3: 3 + nzt].T, unpack_sym(self.term_stats[3 + nzt:].T, nzt)
+        return self.term_stats[3: 3 + nzt].T, unpack_sym(self.term_stats[3 + nzt: 3 + nzt + sym_size(nzt)].T, nzt)
 
     def prior_state_action(self):
         assert self.prior_out is not None, "constructed with keep_prior=False"

@@ -11,8 +11,8 @@ listed in SURVEY.md section 8(b). Here every sweep is a HIP kernel launch on dev
   * extra keyword arguments (`batch`, `x0`, `sig_x0`, `z_traj`, `device`, `dtype`) expose the
     batch axis the reference does not have; with B == 1 all getters return reference shapes.
 
-Not offered: the Linearize / Gauss-Hermite inference paths on the GPU and the matplotlib
-figures (the `plot_*` methods are no-ops so that runner scripts keep working).
+`inference` may be `CubatureQuadrature(alpha, beta, kappa)` or `Linearize()`; not offered: Gauss-Hermite
+inference and the matplotlib figures (the `plot_*` methods are no-ops so that runner scripts keep working).
 """
 import logging
 import os
@@ -117,12 +117,12 @@ class I2cGraph:
     def __init__(self, sys, horizon, Q, R, Qf, alpha, alpha_update_tol, mu_u, sig_u, mu_x_terminal,
                  sig_x_terminal, inference, res_dir=None, *, batch=None, x0=None, sig_x0=None, z_traj=None,
                  device=None, dtype=torch.float64, lib=None):
-        if isinstance(inference, (Linearize, GaussHermiteQuadrature)):
+        if isinstance(inference, GaussHermiteQuadrature):
             raise NotImplementedError(
-                f"{type(inference).__name__} inference is not part of the MI355X hot path; "
-                "only CubatureQuadrature(alpha, beta, kappa) runs on the GPU"
+                "GaussHermiteQuadrature inference is not part of the MI355X hot path; CubatureQuadrature(alpha, beta, "
+                "kappa) and Linearize() run on the GPU"
             )
-        if not isinstance(inference, CubatureQuadrature):
+        if not isinstance(inference, (CubatureQuadrature, Linearize)):
             raise ValueError("Unknown inference method")
         if not hasattr(sys, "model_id") or sys.model_id is None:
             raise TypeError(
@@ -135,8 +135,10 @@ class I2cGraph:
         self.res_dir = res_dir
         self.engine = BatchedI2c(
             sys, horizon, Q, R, Qf, alpha, alpha_update_tol, mu_u, sig_u, mu_x_terminal, sig_x_terminal,
-            quad=inference.as_tuple(), x0=x0, sig_x0=sig_x0, z_traj=z_traj, batch=batch, dtype=dtype,
+            quad=(1.0, 0.0, 0.0) if isinstance(inference, Linearize) else inference.as_tuple(),
+            x0=x0, sig_x0=sig_x0, z_traj=z_traj, batch=batch, dtype=dtype,
             device=device, lib=lib, keep_zpost=True, keep_prior=True,
+            inference="linearize" if isinstance(inference, Linearize) else "cubature",
         )
         e = self.engine
         self.B = e.B
@@ -247,7 +249,29 @@ class I2cGraph:
             "mu_u0_pf": lambda: (G()["mu_xu0_pf"][..., nx:], True),
             "sig_u0_pf": lambda: (G()["sig_xu0_pf"][..., nx:, nx:], False),
             "mu_x3_pf": lambda: (G()["mu_x3_pf"], True), "sig_x3_pf": lambda: (G()["sig_x3_pf"], False),
+            # Riccati-form backward messages (after _backward_ricatti_msgs, i2c.py:612-678)
+            "nu_x0_b": lambda: (self._riccati_np()[0], True), "lambda_x0_b": lambda: (self._riccati_np()[1], False),
+            "nu_x3_b": lambda: (self._riccati_np()[2], True), "lambda_x3_b": lambda: (self._riccati_np()[3], False),
         }
+
+    def _riccati_np(self):
+        """(nu_x0_b, lambda_x0_b, nu_x3_b, lambda_x3_b) as (B, T, ...) arrays. The message entering cell t at x3 is the
+        one leaving cell t+1 at x0; at the end of the chain it is posterior minus filter in information form
+        (i2c.py:615-617)."""
+        if getattr(self, "_riccati", None) is None:
+            raise AttributeError("call _backward_ricatti_msgs() first (i2c.py:888-893)")
+
+        def make():
+            nu0, lam0 = (_np(x) for x in self._riccati)
+            f = {k: _np(v) for k, v in self.engine.forward_messages().items()}
+            m3m, s3m = (_np(x) for x in self.engine.smoothed_next_state())
+            lam_m, lam_f = np.linalg.inv(s3m[:, -1]), np.linalg.inv(f["sig_x3_f"][:, -1])
+            nu_end = (np.einsum("bij,bj->bi", lam_m, m3m[:, -1]) - np.einsum("bij,bj->bi", lam_f, f["mu_x3_f"][:, -1]))
+            nu3 = np.concatenate((nu0[:, 1:], nu_end[:, None]), axis=1)
+            lam3 = np.concatenate((lam0[:, 1:], (lam_m - lam_f)[:, None]), axis=1)
+            return nu0, lam0, nu3, lam3
+
+        return self._cached("riccati", make)
 
     def _cell_target(self, t):
         e = self.engine
@@ -353,6 +377,14 @@ class I2cGraph:
     def _forward_backward_msgs(self):
         self._forward_msgs()
         self._backward_msgs()
+
+    def _backward_ricatti_msgs(self):
+        """i2c.py:888-893 (the reference's spelling). Cells then expose the Riccati-form K / k / sigK and
+        nu_x0_b / lambda_x0_b."""
+        self._invalidate()
+        self._riccati = self.engine.riccati_sweep()
+        self._check()
+        self.policy_valid = True
 
     def _update_priors(self):
         self.engine.update_priors()

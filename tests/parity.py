@@ -25,6 +25,10 @@ def product_model(case):
     if meta["model"] == "LinearKnown" and "noise" in meta:
         m.sig_x0 = meta["noise"] * np.eye(2)
         m.sig_eta = meta["noise"] * np.eye(2)
+    if meta["model"] == "LinearKnown" and "goal" in meta:  # scripts/lqr_compare.py:128-131 on the product's plugin
+        m.xag = meta["goal"] * np.ones((2, 1))
+        m.zg_term = meta["goal"] * np.ones((2, 1))
+        m.a = m.xag - m.A @ m.xag
     return m
 
 
@@ -33,7 +37,8 @@ def engine_from_case(case, lib, device, dtype=torch.float64, x0=None, mu_u=None,
     eng = pkg.BatchedI2c(
         product_model(case), meta["T"], case.get("Q"), case["R"], case.get("Qf"), meta["alpha"], meta["tol"],
         case["mu_u"] if mu_u is None else mu_u, case["sig_u"], case.get("mu_x_term"), case.get("sig_x_term"),
-        quad=tuple(meta["quad"]), x0=x0, dtype=dtype, device=device, lib=lib, keep_prior=True, **kw,
+        quad=tuple(meta["quad"]), x0=x0, dtype=dtype, device=device, lib=lib, keep_prior=True,
+        inference=meta.get("inference", "cubature"), **kw,
     )
     if meta.get("propagate"):
         eng._propagate = True

@@ -99,10 +99,12 @@ def test_facade_rejects_what_the_gpu_path_cannot_do():
     g = load_case("em_linear_T60")
     model = make_env_model("LinearKnown", None)
     args = (model, 60, g["Q"], g["R"], g["Qf"], 800.0, 0.0, g["mu_u"], g["sig_u"], None, None)
-    with pytest.raises(NotImplementedError):
-        I2cGraph(*args, Linearize(), lib=hostsim.load(), device="cpu")
+    I2cGraph(*args, Linearize(), lib=hostsim.load(), device="cpu")  # runs on the device since ABI 2
     with pytest.raises(NotImplementedError):
         I2cGraph(*args, GaussHermiteQuadrature(3), lib=hostsim.load(), device="cpu")
+    with pytest.raises(NotImplementedError):  # no terminal observation: the reference's Linearize path fails too
+        I2cGraph(make_env_model("PendulumKnownActReg", None), 60, None, g["R"], None, 800.0, 0.0, g["mu_u"], g["sig_u"],
+                 None, None, Linearize(), lib=hostsim.load(), device="cpu")
 
     class PythonModel:  # an arbitrary callable plugin cannot run inside a kernel
         dim_x, dim_u, dim_z = 2, 1, 3

@@ -35,6 +35,26 @@ def test_hip_vs_reference_golden(lib, name, tol_d, tol_s):
     parity.check_against_golden(name, lib, "cuda", tol_d, tol_s)
 
 
+LINEARIZE = [
+    ("lin_linear_T60", 1e-7, 1e-6),
+    ("lin_covctrl_T50", 1e-7, 1e-6),
+    ("lin_pendulum_T100", 1e-7, 1e-5),
+    ("lin_cartpole_T100", 1e-6, 1e-5),
+    ("lin_dcp_T80", 1e-6, 1e-5),
+]
+
+
+@pytest.mark.parametrize("name,tol_d,tol_s", LINEARIZE)
+def test_hip_linearize_vs_reference_golden(lib, name, tol_d, tol_s):
+    """Linearize() inference on the device (k_forward_lin / k_bwd_lin) against the reference's captured runs."""
+    parity.check_against_golden(name, lib, "cuda", tol_d, tol_s)
+
+
+@pytest.mark.parametrize("name,B,iters", [("lin_pendulum_T100", 200, 4), ("lin_dcp_T80", 70, 3)])
+def test_hip_linearize_batch_vs_oracle(lib, name, B, iters):
+    parity.check_batch_against_oracle(name, lib, "cuda", B, iters, tol=1e-6)
+
+
 def test_hip_pendulum_200_iterations_vs_reference(lib):
     """Free-running 200 EM iterations (the shipped N_INFERENCE) against the reference's run."""
     parity.check_against_golden("em_pendulum_T200_run200", lib, "cuda", 1e-7, 1e-5)

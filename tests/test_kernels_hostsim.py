@@ -30,6 +30,27 @@ def test_hostsim_vs_reference_golden(lib, name, tol_d, tol_s):
     parity.check_against_golden(name, lib, "cpu", tol_d, tol_s)
 
 
+LINEARIZE = [
+    ("lin_linear_T60", 1e-8, 1e-7),
+    ("lin_covctrl_T50", 1e-8, 1e-7),
+    ("lin_pendulum_T100", 1e-8, 1e-6),
+    ("lin_cartpole_T100", 1e-7, 1e-6),
+    ("lin_dcp_T80", 1e-7, 1e-6),
+]
+
+
+@pytest.mark.parametrize("name,tol_d,tol_s", LINEARIZE)
+def test_hostsim_linearize_vs_reference_golden(lib, name, tol_d, tol_s):
+    """Linearize() inference (i2c.py:244-348, 449-542): Jacobians by forward-mode differentiation of the model
+    functors, against the reference's captured runs (linear systems: exact pin; nonlinear: see the oracle header)."""
+    parity.check_against_golden(name, lib, "cpu", tol_d, tol_s)
+
+
+@pytest.mark.parametrize("name,B,iters", [("lin_pendulum_T100", 6, 4), ("lin_dcp_T80", 3, 3)])
+def test_hostsim_linearize_batch_vs_oracle(lib, name, B, iters):
+    parity.check_batch_against_oracle(name, lib, "cpu", B, iters, tol=1e-7)
+
+
 @pytest.mark.parametrize("name,B,iters", [("em_pendulum_T200", 8, 4), ("em_dcp_T60", 4, 3), ("em_covctrl_T100", 4, 4)])
 def test_hostsim_batch_vs_oracle(lib, name, B, iters):
     parity.check_batch_against_oracle(name, lib, "cpu", B, iters, tol=1e-7)

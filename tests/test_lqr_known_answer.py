@@ -69,3 +69,58 @@ def test_cubature_i2c_equals_lqr_cpu():
 @pytest.mark.gpu
 def test_cubature_i2c_equals_lqr_gpu():
     _check(None, "cuda")
+
+
+def _check_linearize_protocol(lib, device):
+    """scripts/lqr_compare.py:120-175 as the reference runs it: Linearize(), alpha = 1e-5, feed-forward cells, expert
+    controller off, ONE forward/backward pass, then the Riccati messages -- against the reference's own output for the
+    same call (tests/golden/lin_lqr_compare.npz) and against closed-form LQR."""
+    from golden_util import assert_close, load_case
+    from i2c.exp_types import Linearize
+
+    g = load_case("lin_lqr_compare")
+    T = g.meta["T"]
+    model = make_env_model("LinearKnown", None)
+    model.xag = 10 * np.ones((2, 1))
+    model.zg_term = 10 * np.ones((2, 1))
+    model.a = model.xag - model.A @ model.xag
+    Q, R = g["Q"], g["R"]
+    i2c = I2cGraph(model, T, Q, R, g["Qf"], 1e-5, 0.0, np.zeros((T, 1)), 1e2 * np.eye(1), None, None, Linearize(),
+                   lib=lib, device=device)
+    i2c.use_expert_controller = False
+    for c in i2c.cells:
+        c.state_action_independence = True
+    i2c._forward_backward_msgs()
+    K, k, sigK = i2c.get_local_linear_policy()
+    xu = i2c.get_marginal_trajectory()
+    assert_close(K, g.at(1, "K"), 1e-6, "K (message passing)")
+    assert_close(k, g.at(1, "k"), 1e-6, "k (message passing)")
+    assert_close(xu, g.at(1, "mu_xu0_m"), 1e-7, "posterior trajectory")
+    n = T // 2
+    assert_close(K[:n], g["lqr/K"][:n], 1e-5, "K vs LQR")
+    assert_close(k[:n], g["lqr/k"][:n].reshape(n, -1), 1e-5, "k vs LQR")
+    assert_close(xu[:, :2], g["lqr/x"][:T], 1e-6, "x vs LQR")
+
+    # The Riccati form inverts matrices of scale 1e20 (sig_eta = 1e-20): the reference's own Riccati-form gain is 2e-4
+    # away from LQR, and two fp64 implementations of it agree to ~1e-5 (LAPACK LU there, Cholesky here).
+    i2c._backward_ricatti_msgs()
+    Kr = np.stack([c.K for c in i2c.cells])
+    kr = np.stack([c.k for c in i2c.cells]).reshape(T, -1)
+    assert_close(Kr, g["riccati/K"], 1e-4, "Riccati-form K")
+    assert_close(kr, g["riccati/k"], 1e-4, "Riccati-form k")
+    assert_close(np.stack([c.sigK for c in i2c.cells]), g["riccati/sigK"], 1e-6, "Riccati-form sigK")
+    assert_close(np.stack([c.lambda_x0_b for c in i2c.cells]), g["riccati/lambda_x0_b"], 1e-6, "lambda_x0_b")
+    assert_close(np.stack([c.nu_x0_b for c in i2c.cells]).reshape(T, -1), g["riccati/nu_x0_b"], 1e-6, "nu_x0_b")
+    assert_close(Kr[:n], g["lqr/K"][:n], 1e-3, "Riccati-form K vs LQR")
+    # the value function of LQR is the backward message scaled by alpha (scripts/lqr_compare.py:87-104)
+    lam3 = np.stack([c.lambda_x3_b for c in i2c.cells]) * 1e-5
+    assert_close(lam3[:n], g["lqr/P"][:n], 1e-6, "alpha * lambda_x3_b vs the Riccati matrix P")
+
+
+def test_linearize_lqr_compare_protocol_cpu():
+    _check_linearize_protocol(hostsim.load(), "cpu")
+
+
+@pytest.mark.gpu
+def test_linearize_lqr_compare_protocol_gpu():
+    _check_linearize_protocol(None, "cuda")
