@@ -434,7 +434,7 @@ def case_mpc_quadrotor():
     save("mpc_quadrotor_fb", out)
 
 
-def case_i2c_run():
+def case_i2c_run(config="pendulum_known_quad", name="run_pendulum_seed0"):
     """The reference's own runner, scripts/i2c_run.py:run(), on its shipped pendulum config (seed 0,
     N_INFERENCE cut to 6): what a user sees -- costs_m, alphas, the saved plan and the final policy."""
     import importlib
@@ -442,7 +442,7 @@ def case_i2c_run():
 
     np.random.seed(0)  # i2c_run.py:215 set_seed(args.random_seed) happens BEFORE the config import draws mu_u
     runner = importlib.import_module("i2c_run")
-    experiment = importlib.import_module("experiments.pendulum_known_quad")
+    experiment = importlib.import_module("experiments." + config)
     experiment.N_INFERENCE = 6
     experiment.N_ITERS_PER_PLOT = 100
     captured = {}
@@ -464,8 +464,13 @@ def case_i2c_run():
     out["alphas_desired"] = np.asarray(g.alphas_desired, float)
     K, k, sigK = g.get_local_linear_policy()
     out["K"], out["k"], out["sigK"] = K, k, sigK
-    out["meta"] = np.array(json.dumps(dict(config="pendulum_known_quad", seed=0, n_inference=6, T=int(experiment.N_DURATION))))
-    save("run_pendulum_seed0", out)
+    out["meta"] = np.array(json.dumps(dict(config=config, seed=0, n_inference=6, T=int(experiment.N_DURATION))))
+    save(name, out)
+
+
+def case_i2c_run_linearize():
+    """The same runner on the shipped Linearize config scripts/experiments/pendulum_known.py."""
+    case_i2c_run("pendulum_known", "run_pendulum_linearize_seed0")
 
 
 # --------------------------------------------------------------------------------------
@@ -603,10 +608,12 @@ def _case_lin_nonlinear(env, T, Q, R, Qf, alpha, tol, mu_u, sig_u, n_detail, n_t
 
 
 def case_lin_pendulum():
-    """scripts/experiments/pendulum_known.py:21-33."""
+    """scripts/experiments/pendulum_known.py:21-33, but with a small random initial action sequence: with the shipped
+    mu_u = 0 the pendulum hangs at rest and the first iterations only move rounding noise."""
     T = 100
+    np.random.seed(2)
     _case_lin_nonlinear("PendulumKnown", T, np.diag([1, 100.0, 1]), np.diag([1.0]), np.diag([1, 100.0, 1]), 100.0, 0.99,
-                        np.zeros((T, 1)), 0.2 * np.eye(1), 2, 30, "lin_pendulum_T100")
+                        1e-1 * np.random.randn(T, 1), 0.2 * np.eye(1), 2, 40, "lin_pendulum_T100")
 
 
 def case_lin_cartpole():
@@ -619,12 +626,13 @@ def case_lin_cartpole():
 
 
 def case_lin_double_cartpole():
-    """scripts/experiments/double_cartpole_known.py:20-32 at a shorter horizon."""
+    """scripts/experiments/double_cartpole_known.py:20-32 at a shorter horizon, random initial actions (see above)."""
     T = 80
+    np.random.seed(3)
     Q = np.diag([1.0, 1.0, 100.0, 1.0, 100.0, 1.0, 1.0, 1.0])
     Qf = np.diag([1.0, 1000.0, 1000.0, 1000.0, 1000.0, 100.0, 100.0, 100.0])
-    _case_lin_nonlinear("DoubleCartpoleKnown", T, Q, np.diag([0.1]), Qf, 90.0, 0.9995, np.zeros((T, 1)), 0.04 * np.eye(1),
-                        2, 8, "lin_dcp_T80")
+    _case_lin_nonlinear("DoubleCartpoleKnown", T, Q, np.diag([0.1]), Qf, 90.0, 0.9995, 1e-1 * np.random.randn(T, 1),
+                        0.04 * np.eye(1), 2, 8, "lin_dcp_T80")
 
 
 CASES = {
@@ -644,6 +652,7 @@ CASES = {
     "em_quad": case_em_quadrotor,
     "mpc_quad": case_mpc_quadrotor,
     "i2c_run": case_i2c_run,
+    "i2c_run_lin": case_i2c_run_linearize,
     "lin_linear": case_lin_linear,
     "lin_lqr": case_lin_lqr_compare,
     "lin_covctrl": case_lin_covariance_control,
