@@ -39,6 +39,7 @@ extern "C" {
 #define I2C_MAX_NU 4
 #define I2C_MAX_NZ 12
 #define I2C_MAX_PARAMS 16
+#define I2C_MAX_GH_DEGREE 8
 #define I2C_SYM(n) ((n) * ((n) + 1) / 2)
 
 /* model plugins (the reference's `sys` objects, i2c/model.py:19-44) */
@@ -58,8 +59,10 @@ enum { I2C_F64 = 0, I2C_F32 = 1 };
 /* inference method of the E-step (the `inference` argument of I2cGraph, i2c/exp_types.py:22-68) */
 enum {
   I2C_INF_CUBATURE = 0,  /* CubatureQuadrature(alpha, beta, kappa): sigma points (i2c.py:350-447, 544-610)                */
-  I2C_INF_LINEARIZE = 1  /* Linearize(): first-order expansion about the means (i2c.py:244-348, 449-542); the plan cost
+  I2C_INF_LINEARIZE = 1, /* Linearize(): first-order expansion about the means (i2c.py:244-348, 449-542); the plan cost
                             and the closed-loop propagation still use CubatureQuadrature(1, 0, 0) (i2c.py:109-115, 841-844) */
+  I2C_INF_GAUSS_HERMITE = 2 /* GaussHermiteQuadrature(degree) (exp_types.py:52-68): the sigma-point cells with a tensor
+                            grid of gh_degree^dim points m + sqrt(2) L xi; one backward schedule (a lane per trajectory) */
 };
 
 /* how i2c_backward_sweep is scheduled (results are identical up to summation order of the cost) */
@@ -123,9 +126,13 @@ typedef struct I2cProblem {
   int32_t inference;       /* I2C_INF_CUBATURE | I2C_INF_LINEARIZE                                                  */
   int32_t expert_controller; /* Linearize forward pass only: scale the feedback gain by the pdf ratio (use_expert_controller,
                               i2c.py:143,259-265); the cubature forward pass always scales it (i2c.py:366-375)      */
+  int32_t gh_degree;       /* I2C_INF_GAUSS_HERMITE: 1 <= degree <= I2C_MAX_GH_DEGREE                               */
+  int32_t reserved0;
   /* CubatureQuadrature(alpha, beta, kappa): i2c/exp_types.py:31-49 */
   double quad_alpha, quad_beta, quad_kappa;
   double dtemp;            /* terminal-prior annealing rate (i2c.py:66,552)                    */
+  /* I2C_INF_GAUSS_HERMITE: numpy.polynomial.hermite.hermgauss(gh_degree) nodes and weights (exp_types.py:57) */
+  double gh_nodes[I2C_MAX_GH_DEGREE], gh_weights[I2C_MAX_GH_DEGREE];
   /* HOST constants (double, packed lower where symmetric) */
   double sig_eta[I2C_SYM(I2C_MAX_NX)];   /* sys.sig_eta                                          */
   double sig_xi0[I2C_SYM(I2C_MAX_NZ)];   /* inv(QR)   (i2c.py:786)  -> sig_xi = alpha * sig_xi0  */

@@ -11,6 +11,7 @@ import os
 
 ABI_VERSION = 2
 MAX_NX, MAX_NU, MAX_NZ, MAX_PARAMS = 8, 4, 12, 16
+MAX_GH_DEGREE = 8
 
 
 def _sym(n):
@@ -19,7 +20,7 @@ def _sym(n):
 
 F64, F32 = 0, 1
 BWD_AUTO, BWD_TWO_PASS, BWD_FUSED, BWD_CHUNKED = 0, 1, 2, 3
-INF_CUBATURE, INF_LINEARIZE = 0, 1
+INF_CUBATURE, INF_LINEARIZE, INF_GAUSS_HERMITE = 0, 1, 2
 
 MODEL_IDS = {
     "PendulumKnown": 0,
@@ -62,10 +63,14 @@ class I2cProblem(C.Structure):
         ("terminal_cell", C.c_int32),
         ("inference", C.c_int32),
         ("expert_controller", C.c_int32),
+        ("gh_degree", C.c_int32),
+        ("reserved0", C.c_int32),
         ("quad_alpha", C.c_double),
         ("quad_beta", C.c_double),
         ("quad_kappa", C.c_double),
         ("dtemp", C.c_double),
+        ("gh_nodes", C.c_double * MAX_GH_DEGREE),
+        ("gh_weights", C.c_double * MAX_GH_DEGREE),
         ("sig_eta", C.c_double * _sym(MAX_NX)),
         ("sig_xi0", C.c_double * _sym(MAX_NZ)),
         ("QR", C.c_double * _sym(MAX_NZ)),

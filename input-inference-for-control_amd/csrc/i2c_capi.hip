@@ -20,7 +20,8 @@ int check_problem(const I2cProblem* p) {
   if (p->B < 1 || p->T < 1) return I2C_EINVAL;
   if (!p->x0 || !p->sig_x0 || !p->alpha || !p->feedforward) return I2C_EINVAL;
   if (p->has_x_terminal && !p->temp) return I2C_EINVAL;
-  if (p->inference != I2C_INF_CUBATURE && p->inference != I2C_INF_LINEARIZE) return I2C_EINVAL;
+  if (p->inference < I2C_INF_CUBATURE || p->inference > I2C_INF_GAUSS_HERMITE) return I2C_EINVAL;
+  if (p->inference == I2C_INF_GAUSS_HERMITE && (p->gh_degree < 1 || p->gh_degree > I2C_MAX_GH_DEGREE)) return I2C_EINVAL;
   return I2C_OK;
 }
 

@@ -25,6 +25,10 @@ template <typename R> struct Rule {
   R wi;   // weights_sig[1:]
   R W;    // sum of weights_sig (= 1 unless 1 - alpha^2 + beta != 0)
   int unit;  // W == 1 exactly: skip the correction terms
+  // Gauss-Hermite tensor grid (i2c/exp_types.py:52-68), used by the GRID variants only: gh_degree^dim points
+  // m + sqrt(2) L xi, xi in gh_x^dim, weight = prod gh_w (the 1-D weights already divided by sqrt(pi))
+  int gh_degree, gh_points;
+  R gh_x[I2C_MAX_GH_DEGREE], gh_w[I2C_MAX_GH_DEGREE];
 };
 
 template <class M, typename R> struct Consts {
@@ -344,6 +348,95 @@ I2C_FN void set_status(int32_t* status, int b, int reason, int t) {
 // ------------------------------------------------------------------------------------------
 // Forward sweep: one lane walks one trajectory through all T cells (i2c.py:876-880, 350-447).
 // ------------------------------------------------------------------------------------------
+// Gaussian push-through with a tensor-grid rule (GaussHermiteQuadrature): the same moments as sp_transform,
+//   my = sum_p w_p y_p,  Sy = sum_p w_p y_p y_p^T - my my^T,  Sxy = sum_p w_p x_p y_p^T - m my^T   (quadrature.py:34-44),
+// accumulated about the centre value y0 = f(m):  my = y0 + s1,  Sy = S2 - s1 s1^T,  Sxy = sum_p w_p dx_p dy_p^T
+// (the weights sum to 1 and the grid is symmetric, so the terms in (1 - W) and sum_p w_p dx_p vanish to rounding).
+// The point index runs through a mixed-radix odometer in registers; gh_degree^DIN points, no structure is exploited.
+template <class M, int DIN, int DOUT, bool CROSS, typename R, class F>
+I2C_FN void grid_transform(const Rule<R>& rule, const R* m, const R* L, const F& f, R* my, R* Sy, R* Sxy) {
+  constexpr int NA = M::NA, NA1 = NA > 0 ? NA : 1;
+  R sn[NA1], cs[NA1], y0[DOUT], s1[DOUT];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) r_sincos(m[M::ang(a)], &sn[a], &cs[a]);
+  f(m, sn, cs, y0);
+#pragma unroll
+  for (int k = 0; k < DOUT; ++k) s1[k] = R(0);
+#pragma unroll
+  for (int k = 0; k < sym(DOUT); ++k) Sy[k] = R(0);
+  if (CROSS) {
+#pragma unroll
+    for (int k = 0; k < DIN * DOUT; ++k) Sxy[k] = R(0);
+  }
+  int dig[DIN];
+#pragma unroll
+  for (int i = 0; i < DIN; ++i) dig[i] = 0;
+  const int deg = rule.gh_degree;
+  for (int p = 0; p < rule.gh_points; ++p) {
+    R xi[DIN], w = R(1);
+#pragma unroll
+    for (int i = 0; i < DIN; ++i) {
+      R xv = rule.gh_x[0], wv = rule.gh_w[0];
+#pragma unroll
+      for (int q = 1; q < I2C_MAX_GH_DEGREE; ++q) {
+        xv = dig[i] == q ? rule.gh_x[q] : xv;
+        wv = dig[i] == q ? rule.gh_w[q] : wv;
+      }
+      xi[i] = xv;
+      w *= wv;
+    }
+    R dx[DIN], x[DIN], y[DOUT];
+#pragma unroll
+    for (int i = 0; i < DIN; ++i) {
+      R v = R(0);
+#pragma unroll
+      for (int j = 0; j <= i; ++j) v += L[tri(i, j)] * xi[j];
+      dx[i] = rule.sf * v;
+      x[i] = m[i] + dx[i];
+    }
+#pragma unroll
+    for (int a = 0; a < NA; ++a) r_sincos(x[M::ang(a)], &sn[a], &cs[a]);
+    f(x, sn, cs, y);
+#pragma unroll
+    for (int k = 0; k < DOUT; ++k) y[k] -= y0[k];
+#pragma unroll
+    for (int k = 0; k < DOUT; ++k) {
+      const R wy = w * y[k];
+      s1[k] += wy;
+#pragma unroll
+      for (int l = 0; l <= k; ++l) Sy[tri(k, l)] += wy * y[l];
+      if (CROSS) {
+#pragma unroll
+        for (int i = 0; i < DIN; ++i) Sxy[i * DOUT + k] += dx[i] * wy;
+      }
+    }
+    // odometer: dig[0] is the fastest digit
+    bool carry = true;
+#pragma unroll
+    for (int i = 0; i < DIN; ++i) {
+      const int nd = dig[i] + (carry ? 1 : 0);
+      carry = nd >= deg;
+      dig[i] = carry ? 0 : nd;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < DOUT; ++k) my[k] = y0[k] + s1[k];
+#pragma unroll
+  for (int k = 0; k < DOUT; ++k)
+#pragma unroll
+    for (int l = 0; l <= k; ++l) Sy[tri(k, l)] -= s1[k] * s1[l];
+}
+
+// GRID selects the tensor-grid rule at compile time; the sigma-point kernels are unchanged by it.
+template <bool GRID, class M, class ST, int DIN, int DOUT, bool CROSS, bool UNITW = false, typename R, class F>
+I2C_FN void transform(const Rule<R>& rule, const R* m, const R* Sin, const R* L, const F& f, R* my, R* Sy, R* Sxy) {
+  if constexpr (GRID)
+    grid_transform<M, DIN, DOUT, CROSS>(rule, m, L, f, my, Sy, Sxy);
+  else
+    sp_transform<M, ST, DIN, DOUT, CROSS, UNITW>(rule, m, Sin, L, f, my, Sy, Sxy);
+}
+
+
 template <typename R> struct FwdArgs {
   const R* prior;   // [T][E_POST][B]
   R* fwd;           // [T][E_FWD][B]
@@ -360,7 +453,7 @@ template <typename R> struct FwdArgs {
 // LEAN = the common case fixed at compile time (weights sum to 1, shared target, trajectory-level alpha, no
 // joint-prior output): the corresponding wave-uniform runtime branches disappear from the cell, which keeps
 // it one scheduling region. The generic variant (LEAN = false) handles everything.
-template <class M, typename R, bool LEAN = false>
+template <class M, typename R, bool LEAN = false, bool GRID = false>
 I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a, const int b) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D;
@@ -472,7 +565,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       for (int i = 0; i < sym(D); ++i) L[i] = S0[i];
       fail = note_failure(fail, chol<D>(L, rinv), 1, t);
       R mz[NZ], Sz[sym(NZ)], Sxz[D * NZ];
-      sp_transform<M, ObsStruct<M>, D, NZ, true, LEAN>(c.rule_xu, mu0, S0, L, ObserveF<M, R>{c.params}, mz, Sz, Sxz);
+      transform<GRID, M, ObsStruct<M>, D, NZ, true, LEAN>(c.rule_xu, mu0, S0, L, ObserveF<M, R>{c.params}, mz, Sz, Sxz);
 #pragma unroll
       for (int i = 0; i < sym(NZ); ++i) Sz[i] += alpha * c.sig_xi0[i];
       fail = note_failure(fail, kalman_update<D, NZ>(mu0, S0, mz, Sz, Sxz, zt), 3, t);
@@ -496,7 +589,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 #pragma unroll
       for (int i = 0; i < sym(D); ++i) L[i] = S0[i];
       fail = note_failure(fail, chol<D>(L, rinv), 4, t);
-      sp_transform<M, DenseStruct<D>, D, NX, true, LEAN>(c.rule_xu, mu0, S0, L, DynamicsF<M, R>{c.params}, mu_x, sig_x, Sxy);
+      transform<GRID, M, DenseStruct<D>, D, NX, true, LEAN>(c.rule_xu, mu0, S0, L, DynamicsF<M, R>{c.params}, mu_x, sig_x, Sxy);
     }
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) sig_x[i] += LEAN ? c.sig_eta[i] : c.sig_eta_w[i];  // sum_p w_p sig_eta (quadrature.py:57)
@@ -522,7 +615,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     if (NZT > 0 && t == c.terminal_cell && c.has_Qf) {
       constexpr int NT = C::NZT1;
       R mzt[NT], Szt[sym(NT)], Sxzt[NX * NT];
-      sp_transform<M, TermStruct<M>, NX, NT, true, LEAN>(c.rule_x, mu_x, sig_x, L3, ObserveTermF<M, R>{c.params}, mzt, Szt, Sxzt);
+      transform<GRID, M, TermStruct<M>, NX, NT, true, LEAN>(c.rule_x, mu_x, sig_x, L3, ObserveTermF<M, R>{c.params}, mzt, Szt, Sxzt);
 #pragma unroll
       for (int i = 0; i < sym(NT); ++i) Szt[i] += alpha * c.sig_xiT0[i];
       fail = note_failure(fail, kalman_update<NX, NT>(mu_x, sig_x, mzt, Szt, Sxzt, c.zg_term), 6, t);
@@ -660,7 +753,7 @@ I2C_FN void gaussian_cost(const R* W, const bool w_diag, const R* mz, const R* S
 }
 
 // Terminal observation statistics (i2c.py:567-570, 989-992): tr(Qf (errT errT^T + sig_z3_m)).
-template <class M, typename R>
+template <class M, typename R, bool GRID = false>
 I2C_FN R terminal_obs_stats(const Consts<M, R>& c, const int b, const R* m3m, const R* S3m, R* term_stats,
                             int32_t* status) {
   using C = Consts<M, R>;
@@ -673,7 +766,7 @@ I2C_FN R terminal_obs_stats(const Consts<M, R>& c, const int b, const R* m3m, co
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) L3[i] = S3m[i];
     if (!chol<NX>(L3, rinv3)) set_status(status, b, 6, c.T - 1);
-    sp_transform<M, TermStruct<M>, NX, NT, false>(c.rule_x, m3m, S3m, L3, ObserveTermF<M, R>{c.params}, mzt, Szt,
+    transform<GRID, M, TermStruct<M>, NX, NT, false>(c.rule_x, m3m, S3m, L3, ObserveTermF<M, R>{c.params}, mzt, Szt,
                                                   (R*)nullptr);
     R tv;
     gaussian_cost<NT>(c.Qf, c.qf_diag != 0, mzt, Szt, c.zg_term, &trT, &tv);
@@ -692,7 +785,7 @@ I2C_FN R terminal_obs_stats(const Consts<M, R>& c, const int b, const R* m3m, co
 //   K L_xx = L_ux  ->  K^T = L_xx^{-T} L_ux^T ;  sigK = L_uu L_uu^T ;  k = mu_u - K mu_x.
 // In: mu/S = mu_xu1_f / sig_xu1_f, J, dm = mu_x3_m - mu_x3_f, dS = sig_x3_m - sig_x3_f.
 // Out: mu/S = mu_xu0_m / sig_xu0_m, ctl = [K | k | sigK], mz/Sz, cost mean / variance.
-template <class M, typename R>
+template <class M, typename R, bool GRID = false>
 I2C_FN bool cell_posterior(const Consts<M, R>& c, const R* zt, R* mu, R* S, const R* J, const R* dm, const R* dS,
                            R* ctl, R* mz, R* Sz, R* cm, R* cv) {
   using C = Consts<M, R>;
@@ -709,7 +802,7 @@ I2C_FN bool cell_posterior(const Consts<M, R>& c, const R* zt, R* mu, R* S, cons
 #pragma unroll
   for (int e = 0; e < sym(D); ++e) Lm[e] = S[e];
   const bool ok = chol<D>(Lm, rinv);
-  sp_transform<M, ObsStruct<M>, D, NZ, false>(c.rule_xu, mu, S, Lm, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
+  transform<GRID, M, ObsStruct<M>, D, NZ, false>(c.rule_xu, mu, S, Lm, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
   gaussian_cost<NZ>(c.QR, c.qr_diag != 0, mz, Sz, zt, cm, cv);
 #pragma unroll
   for (int p = 0; p < NU; ++p) {
@@ -918,7 +1011,7 @@ I2C_FN void reduce_partial(const Consts<M, R>& c, const R* cell_stats, const int
 // the whole cell; each forward row is read once and the cost sums stay in registers, so the pass
 // moves E_FWD + E_POST elements per cell instead of the two-pass form's ~2x that.
 // ------------------------------------------------------------------------------------------
-template <class M, typename R>
+template <class M, typename R, bool GRID = false>
 I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R>& a, const int b) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NZ = C::NZ, D = C::D;
@@ -936,7 +1029,7 @@ I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R>&
   }
   R m3m[NX], S3m[sym(NX)];
   end_of_chain<M, R>(c, a.temp, b, row + O_MU3, row + O_S3, m3m, S3m, a.status);
-  terminal_obs_stats<M, R>(c, b, m3m, S3m, a.term_stats, a.status);
+  terminal_obs_stats<M, R, GRID>(c, b, m3m, S3m, a.term_stats, a.status);
 
   R sum_m = R(0), sum_v = R(0);
   for (int t = T - 1; t >= 0; --t) {
@@ -963,7 +1056,7 @@ I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R>&
     R* mu = row;
     R* S = row + D;
     R ctl[C::E_POST - D - sym(D)], mz[NZ], Sz[sym(NZ)], cm, cv;
-    if (!cell_posterior<M, R>(c, zt, mu, S, row + O_J, dm, dS, ctl, mz, Sz, &cm, &cv)) set_status(a.status, b, 7, t);
+    if (!cell_posterior<M, R, GRID>(c, zt, mu, S, row + O_J, dm, dS, ctl, mz, Sz, &cm, &cv)) set_status(a.status, b, 7, t);
     store_cell<M, R>(c, a, t, b, mu, S, ctl, mz, Sz, cm, cv);
     sum_m += cm;
     sum_v += cv;
@@ -1248,7 +1341,7 @@ template <typename R> struct PropArgs {
   int32_t* status;
 };
 
-template <class M, typename R>
+template <class M, typename R, bool GRID = false>
 I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, const int b) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, D = C::D;
@@ -1319,13 +1412,13 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
     R zt[NZ], mz[NZ], Sz[sym(NZ)];
 #pragma unroll
     for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
-    sp_transform<M, ObsStruct<M>, D, NZ, false>(c.rule_xu, mu0, S0, L0, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
+    transform<GRID, M, ObsStruct<M>, D, NZ, false>(c.rule_xu, mu0, S0, L0, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
     R cm, cv;
     gaussian_cost<NZ>(c.QR, c.qr_diag != 0, mz, Sz, zt, &cm, &cv);
     sum_m += cm;
     sum_v += cv;
 
-    sp_transform<M, DenseStruct<D>, D, NX, false>(c.rule_xu, mu0, S0, L0, DynamicsF<M, R>{c.params}, mu_x, sig_x, (R*)nullptr);
+    transform<GRID, M, DenseStruct<D>, D, NX, false>(c.rule_xu, mu0, S0, L0, DynamicsF<M, R>{c.params}, mu_x, sig_x, (R*)nullptr);
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) sig_x[i] += c.sig_eta_w[i];
 #pragma unroll

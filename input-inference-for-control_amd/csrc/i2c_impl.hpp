@@ -34,10 +34,10 @@ static int sweep_lanes() {
   return v;
 }
 
-template <class M, typename R, bool LEAN>
+template <class M, typename R, bool LEAN, bool GRID = false>
 __global__ __launch_bounds__(SWEEP_BLOCK) void k_forward(const Consts<M, R> c, const FwdArgs<R> a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < c.B) forward_sweep_body<M, R, LEAN>(c, a, b);
+  if (b < c.B) forward_sweep_body<M, R, LEAN, GRID>(c, a, b);
 }
 template <class M, typename R>
 __global__ __launch_bounds__(SWEEP_BLOCK) void k_forward_lin(const Consts<M, R> c, const FwdArgs<R> a) {
@@ -65,10 +65,10 @@ __global__ __launch_bounds__(CELL_BLOCK) void k_cell(const Consts<M, R> c, const
   const int t = blockIdx.y;
   if (b < c.B) backward_cell_body<M, R>(c, a, t, b);
 }
-template <class M, typename R>
+template <class M, typename R, bool GRID = false>
 __global__ __launch_bounds__(SWEEP_BLOCK) void k_bwd_fused(const Consts<M, R> c, const CellArgs<R> a) {
   const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
-  if (b < c.B) backward_fused_body<M, R>(c, a, b);
+  if (b < c.B) backward_fused_body<M, R, GRID>(c, a, b);
 }
 template <class M, typename R>
 __global__ __launch_bounds__(SWEEP_BLOCK) void k_chunk_compose(const Consts<M, R> c, const ChunkArgs<R> a) {
@@ -111,10 +111,10 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void k_mstep(const Consts<M, R> c, con
   const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
   if (b < c.B) mstep_body<M, R>(c, a, b);
 }
-template <class M, typename R>
+template <class M, typename R, bool GRID = false>
 __global__ __launch_bounds__(SWEEP_BLOCK) void k_propagate(const Consts<M, R> c, const PropArgs<R> a) {
   const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
-  if (b < c.B) propagate_body<M, R>(c, a, b);
+  if (b < c.B) propagate_body<M, R, GRID>(c, a, b);
 }
 template <class M, typename R> struct ZetaArg {
   R v[sym(M::NY)];
@@ -144,6 +144,23 @@ template <typename R> static Rule<R> make_rule(const I2cProblem* p, int dim) {
   r.wi = (R)wi;
   r.unit = std::fabs(W - 1.0) < 1e-14;
   r.W = r.unit ? (R)1 : (R)W;
+  r.gh_degree = 0;
+  r.gh_points = 0;
+  for (int q = 0; q < I2C_MAX_GH_DEGREE; ++q) r.gh_x[q] = r.gh_w[q] = (R)0;
+  if (p->inference == I2C_INF_GAUSS_HERMITE) {  // GaussHermiteQuadrature.weights, i2c/exp_types.py:63-68
+    r.sf = (R)std::sqrt(2.0);
+    r.w0 = r.wi = (R)0;
+    r.W = (R)1;
+    r.unit = 1;
+    r.gh_degree = p->gh_degree;
+    long n = 1;
+    for (int i = 0; i < dim; ++i) n *= p->gh_degree;
+    r.gh_points = (int)n;
+    for (int q = 0; q < p->gh_degree; ++q) {
+      r.gh_x[q] = (R)p->gh_nodes[q];
+      r.gh_w[q] = (R)(p->gh_weights[q] / std::sqrt(3.14159265358979323846));
+    }
+  }
   return r;
 }
 
@@ -227,6 +244,17 @@ template <class M, typename R> struct Impl {
       return launch_status();
 #endif
     }
+    if (p->inference == I2C_INF_GAUSS_HERMITE) {
+#ifdef I2C_HOST_SIM
+      (void)stream;
+      for (int b = 0; b < p->B; ++b) forward_sweep_body<M, R, false, true>(c, a, b);
+      return I2C_OK;
+#else
+      hipLaunchKernelGGL((k_forward<M, R, false, true>), dim3((p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK), dim3(SWEEP_BLOCK),
+                         0, (hipStream_t)stream, c, a);
+      return launch_status();
+#endif
+    }
 #ifdef I2C_HOST_SIM
     (void)stream;
     const bool lean = c.rule_xu.unit && c.rule_x.unit && !c.z_per_cell && !a.alpha_cell && !a.prior_out;
@@ -279,6 +307,19 @@ template <class M, typename R> struct Impl {
 #else
       hipLaunchKernelGGL((k_bwd_lin<M, R>), dim3((p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK), dim3(SWEEP_BLOCK), 0,
                          (hipStream_t)stream, c, al);
+      return launch_status();
+#endif
+    }
+    if (p->inference == I2C_INF_GAUSS_HERMITE) {  // one schedule: the fused walk with the grid transform
+      CellArgs<R> ag{(const R*)fwd, (const R*)xm,    (const R*)p->z, (R*)post, (R*)zpost,
+                     (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   (const R*)p->alpha};
+#ifdef I2C_HOST_SIM
+      (void)stream;
+      for (int b = 0; b < p->B; ++b) backward_fused_body<M, R, true>(c, ag, b);
+      return I2C_OK;
+#else
+      hipLaunchKernelGGL((k_bwd_fused<M, R, true>), dim3((p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK), dim3(SWEEP_BLOCK), 0,
+                         (hipStream_t)stream, c, ag);
       return launch_status();
 #endif
     }
@@ -452,13 +493,22 @@ template <class M, typename R> struct Impl {
     const C c = make_consts<M, R>(p, 0.0, use_expert);
     PropArgs<R> a{(const R*)post, (R*)prop, (R*)prop_stats, (const R*)p->x0, (const R*)p->sig_x0,
                   (const R*)p->z, p->feedforward, status};
+    const bool gh = p->inference == I2C_INF_GAUSS_HERMITE;
 #ifdef I2C_HOST_SIM
     (void)stream;
-    for (int b = 0; b < p->B; ++b) propagate_body<M, R>(c, a, b);
+    for (int b = 0; b < p->B; ++b) {
+      if (gh)
+        propagate_body<M, R, true>(c, a, b);
+      else
+        propagate_body<M, R>(c, a, b);
+    }
     return I2C_OK;
 #else
     const int grid = (p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
-    hipLaunchKernelGGL((k_propagate<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, a);
+    if (gh)
+      hipLaunchKernelGGL((k_propagate<M, R, true>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, a);
+    else
+      hipLaunchKernelGGL((k_propagate<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, a);
     return launch_status();
 #endif
   }

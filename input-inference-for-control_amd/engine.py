@@ -53,7 +53,8 @@ class BatchedI2c:
     def __init__(self, model, horizon, Q, R, Qf, alpha, alpha_update_tol, mu_u, sig_u,
                  mu_x_terminal=None, sig_x_terminal=None, quad=(1.0, 0.0, 0.0), x0=None, sig_x0=None,
                  z_traj=None, batch=None, dtype=torch.float64, device=None, lib=None, dtemp=1.0,
-                 keep_zpost=True, keep_prior=False, keep_xm=True, backward_mode="auto", inference="cubature"):
+                 keep_zpost=True, keep_prior=False, keep_xm=True, backward_mode="auto", inference="cubature",
+                 gh_degree=None):
         self.lib = lib if lib is not None else _native.load_library()
         if device is None:
             device = "cpu" if self.lib.is_host_sim else "cuda"
@@ -118,10 +119,20 @@ class BatchedI2c:
         # inference method of the E-step (I2cGraph's `inference`, i2c.py:103-127): "cubature" = sigma points with
         # CubatureQuadrature(*quad); "linearize" = Linearize(), whose plan cost and propagation use
         # CubatureQuadrature(1, 0, 0) (i2c.py:109-115, 841-844)
-        if inference not in ("cubature", "linearize"):
+        # "gauss_hermite" = GaussHermiteQuadrature(gh_degree): tensor grid of gh_degree ** dim points (exp_types.py:52-68)
+        if inference not in ("cubature", "linearize", "gauss_hermite"):
             raise ValueError(f"unknown inference method {inference!r}")
         self.inference = inference
         self.linearize = inference == "linearize"
+        self.gauss_hermite = inference == "gauss_hermite"
+        self.gh_degree = 0
+        if self.gauss_hermite:
+            self.gh_degree = int(gh_degree)
+            if not 1 <= self.gh_degree <= _native.MAX_GH_DEGREE:
+                raise ValueError(f"gh_degree must be in 1..{_native.MAX_GH_DEGREE}")
+            if self.gh_degree ** (nx + nu) > 2 ** 31 - 1:
+                raise ValueError("gh_degree ** (nx + nu) points do not fit the kernels' 32-bit point counter")
+            quad = (1.0, 0.0, 0.0)
         if self.linearize:
             quad = (1.0, 0.0, 0.0)
             if nzt == 0:
@@ -159,8 +170,8 @@ class BatchedI2c:
         mode = self.lib.i2c_backward_schedule(self.model_id, B, T, self.backward_mode)  # resolves "auto"
         if mode not in (_native.BWD_TWO_PASS, _native.BWD_FUSED, _native.BWD_CHUNKED):
             raise RuntimeError("i2c_backward_schedule() returned %d" % mode)
-        if self.linearize:
-            mode = _native.BWD_FUSED  # the Linearize backward has one schedule: a lane per trajectory
+        if self.linearize or self.gauss_hermite:
+            mode = _native.BWD_FUSED  # these inference methods have one backward schedule: a lane per trajectory
         self.fused_backward = mode == _native.BWD_FUSED
         self.backward_schedule = {_native.BWD_TWO_PASS: "two_pass", _native.BWD_FUSED: "fused", _native.BWD_CHUNKED: "chunked"}[mode]
         # the two-pass backward needs xm / cell_stats as workspace; the fused and chunked ones only write xm on request
@@ -217,7 +228,13 @@ class BatchedI2c:
         p.z_per_cell = int(self.z is not None)
         p.backward_mode = self.backward_mode
         p.terminal_cell = int(self.terminal_cell)
-        p.inference = _native.INF_LINEARIZE if self.linearize else _native.INF_CUBATURE
+        p.inference = (_native.INF_LINEARIZE if self.linearize else
+                       _native.INF_GAUSS_HERMITE if self.gauss_hermite else _native.INF_CUBATURE)
+        p.gh_degree = self.gh_degree
+        if self.gauss_hermite:
+            gx, gw = np.polynomial.hermite.hermgauss(self.gh_degree)  # exp_types.py:57
+            for i in range(self.gh_degree):
+                p.gh_nodes[i], p.gh_weights[i] = float(gx[i]), float(gw[i])
         p.expert_controller = int(bool(self.use_expert_controller))
         p.quad_alpha, p.quad_beta, p.quad_kappa = self.quad
         p.dtemp = self.dtemp

@@ -62,7 +62,7 @@ class CubatureQuadrature:
 
 @dataclasses.dataclass
 class GaussHermiteQuadrature:
-    """Tensor-grid Gauss-Hermite rule with degree ** dim points (host-side only)."""
+    """Tensor-grid Gauss-Hermite rule with degree ** dim points (runs on the device up to degree 8)."""
 
     degree: int
 

@@ -11,8 +11,8 @@ listed in SURVEY.md section 8(b). Here every sweep is a HIP kernel launch on dev
   * extra keyword arguments (`batch`, `x0`, `sig_x0`, `z_traj`, `device`, `dtype`) expose the
     batch axis the reference does not have; with B == 1 all getters return reference shapes.
 
-`inference` may be `CubatureQuadrature(alpha, beta, kappa)` or `Linearize()`; not offered: Gauss-Hermite
-inference and the matplotlib figures (the `plot_*` methods are no-ops so that runner scripts keep working).
+`inference` may be `CubatureQuadrature(alpha, beta, kappa)`, `GaussHermiteQuadrature(degree)` or `Linearize()`; not
+offered: the matplotlib figures (the `plot_*` methods are no-ops so that runner scripts keep working).
 """
 import logging
 import os
@@ -117,12 +117,7 @@ class I2cGraph:
     def __init__(self, sys, horizon, Q, R, Qf, alpha, alpha_update_tol, mu_u, sig_u, mu_x_terminal,
                  sig_x_terminal, inference, res_dir=None, *, batch=None, x0=None, sig_x0=None, z_traj=None,
                  device=None, dtype=torch.float64, lib=None):
-        if isinstance(inference, GaussHermiteQuadrature):
-            raise NotImplementedError(
-                "GaussHermiteQuadrature inference is not part of the MI355X hot path; CubatureQuadrature(alpha, beta, "
-                "kappa) and Linearize() run on the GPU"
-            )
-        if not isinstance(inference, (CubatureQuadrature, Linearize)):
+        if not isinstance(inference, (CubatureQuadrature, GaussHermiteQuadrature, Linearize)):
             raise ValueError("Unknown inference method")
         if not hasattr(sys, "model_id") or sys.model_id is None:
             raise TypeError(
@@ -135,10 +130,12 @@ class I2cGraph:
         self.res_dir = res_dir
         self.engine = BatchedI2c(
             sys, horizon, Q, R, Qf, alpha, alpha_update_tol, mu_u, sig_u, mu_x_terminal, sig_x_terminal,
-            quad=(1.0, 0.0, 0.0) if isinstance(inference, Linearize) else inference.as_tuple(),
+            quad=inference.as_tuple() if isinstance(inference, CubatureQuadrature) else (1.0, 0.0, 0.0),
             x0=x0, sig_x0=sig_x0, z_traj=z_traj, batch=batch, dtype=dtype,
             device=device, lib=lib, keep_zpost=True, keep_prior=True,
-            inference="linearize" if isinstance(inference, Linearize) else "cubature",
+            inference=("linearize" if isinstance(inference, Linearize) else
+                       "gauss_hermite" if isinstance(inference, GaussHermiteQuadrature) else "cubature"),
+            gh_degree=getattr(inference, "degree", None),
         )
         e = self.engine
         self.B = e.B

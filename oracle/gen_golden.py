@@ -635,6 +635,36 @@ def case_lin_double_cartpole():
                         0.04 * np.eye(1), 2, 8, "lin_dcp_T80")
 
 
+
+def case_gh_pendulum(T=40, degree=3, n_detail=2, n_total=8):
+    """GaussHermiteQuadrature(degree) as the inference method (exp_types.py:52-68): 27 points per joint transform, 9 for
+    the terminal one. No reference script ships such a config; hyper-parameters of pendulum_known_quad.py."""
+    np.random.seed(4)
+    mu_u = 1e-2 * np.random.randn(T, 1)
+    Q, R, Qf = np.diag([1, 100.0, 1]), np.diag([2.0]), np.diag([1, 100.0, 1])
+    model = make_env_model("PendulumKnown", None)
+    g = I2cGraph(model, T, Q, R, Qf, 100.0, 0.0, mu_u, 2.0 * np.eye(1), None, None, GaussHermiteQuadrature(degree))
+    g._propagate = True
+    out = problem_inputs("PendulumKnown", model, T, Q, R, Qf, 100.0, 0.0, mu_u, 2.0 * np.eye(1), None, None, (1, 0, 0),
+                         seed=4, inference="gauss_hermite", gh_degree=degree, propagate=True)
+    run_em(g, n_detail, n_total, out)
+    save(f"gh{degree}_pendulum_T{T}", out)
+
+
+def case_gh_linear(T=30, degree=4, n_detail=2, n_total=6, noise=1e-4):
+    """Gauss-Hermite degree 4 on LinearKnown (non-degenerate noise): 64 points per joint transform."""
+    mu_u = np.zeros((T, 1))
+    Q, R = np.diag([10.0, 10.0]), np.diag([1.0])
+    model = make_env_model("LinearKnown", None)
+    model.sig_x0 = noise * np.eye(2)
+    model.sig_eta = noise * np.eye(2)
+    g = I2cGraph(model, T, Q, R, Q, 800.0, 0.0, mu_u, np.eye(1), None, None, GaussHermiteQuadrature(degree))
+    out = problem_inputs("LinearKnown", model, T, Q, R, Q, 800.0, 0.0, mu_u, np.eye(1), None, None, (1, 0, 0), noise=noise,
+                         inference="gauss_hermite", gh_degree=degree)
+    run_em(g, n_detail, n_total, out)
+    save(f"gh{degree}_linear_T{T}", out)
+
+
 CASES = {
     "pendulum": case_pendulum,
     "pendulum_long": case_pendulum_long,
@@ -653,6 +683,8 @@ CASES = {
     "mpc_quad": case_mpc_quadrotor,
     "i2c_run": case_i2c_run,
     "i2c_run_lin": case_i2c_run_linearize,
+    "gh_pendulum": case_gh_pendulum,
+    "gh_linear": case_gh_linear,
     "lin_linear": case_lin_linear,
     "lin_lqr": case_lin_lqr_compare,
     "lin_covctrl": case_lin_covariance_control,

@@ -42,7 +42,7 @@ def oracle_model(case):
 
 
 def oracle_from_case(case, **over):
-    from oracle.i2c_numpy import CubatureRule, I2cOracle
+    from oracle.i2c_numpy import CubatureRule, GaussHermiteRule, I2cOracle
 
     meta = case.meta
     model = oracle_model(case)
@@ -61,7 +61,7 @@ def oracle_from_case(case, **over):
         case["sig_u"],
         case.get("mu_x_term"),
         case.get("sig_x_term"),
-        CubatureRule(*meta["quad"]),
+        GaussHermiteRule(meta["gh_degree"]) if meta.get("inference") == "gauss_hermite" else CubatureRule(*meta["quad"]),
         **over,
     )
     if meta.get("propagate"):

@@ -100,8 +100,9 @@ def test_facade_rejects_what_the_gpu_path_cannot_do():
     model = make_env_model("LinearKnown", None)
     args = (model, 60, g["Q"], g["R"], g["Qf"], 800.0, 0.0, g["mu_u"], g["sig_u"], None, None)
     I2cGraph(*args, Linearize(), lib=hostsim.load(), device="cpu")  # runs on the device since ABI 2
-    with pytest.raises(NotImplementedError):
-        I2cGraph(*args, GaussHermiteQuadrature(3), lib=hostsim.load(), device="cpu")
+    I2cGraph(*args, GaussHermiteQuadrature(3), lib=hostsim.load(), device="cpu")
+    with pytest.raises(ValueError):
+        I2cGraph(*args, GaussHermiteQuadrature(9), lib=hostsim.load(), device="cpu")  # degree > I2C_MAX_GH_DEGREE
     with pytest.raises(NotImplementedError):  # no terminal observation: the reference's Linearize path fails too
         I2cGraph(make_env_model("PendulumKnownActReg", None), 60, None, g["R"], None, 800.0, 0.0, g["mu_u"], g["sig_u"],
                  None, None, Linearize(), lib=hostsim.load(), device="cpu")

@@ -50,6 +50,16 @@ def test_hip_linearize_vs_reference_golden(lib, name, tol_d, tol_s):
     parity.check_against_golden(name, lib, "cuda", tol_d, tol_s)
 
 
+@pytest.mark.parametrize("name", ["gh3_pendulum_T40", "gh4_linear_T30"])
+def test_hip_gauss_hermite_vs_reference_golden(lib, name):
+    """GaussHermiteQuadrature(degree) inference on the device (tensor-grid transform) against the reference's runs."""
+    parity.check_against_golden(name, lib, "cuda", 1e-7, 1e-6)
+
+
+def test_hip_gauss_hermite_batch_vs_oracle(lib):
+    parity.check_batch_against_oracle("gh3_pendulum_T40", lib, "cuda", 130, 3, tol=1e-6)
+
+
 @pytest.mark.parametrize("name,B,iters", [("lin_pendulum_T100", 200, 4), ("lin_dcp_T80", 70, 3)])
 def test_hip_linearize_batch_vs_oracle(lib, name, B, iters):
     parity.check_batch_against_oracle(name, lib, "cuda", B, iters, tol=1e-6)

@@ -46,6 +46,17 @@ def test_hostsim_linearize_vs_reference_golden(lib, name, tol_d, tol_s):
     parity.check_against_golden(name, lib, "cpu", tol_d, tol_s)
 
 
+@pytest.mark.parametrize("name", ["gh3_pendulum_T40", "gh4_linear_T30"])
+def test_hostsim_gauss_hermite_vs_reference_golden(lib, name):
+    """GaussHermiteQuadrature(degree) inference (exp_types.py:52-68): tensor-grid transform in the forward, backward
+    and propagation kernels, against the reference's captured runs."""
+    parity.check_against_golden(name, lib, "cpu", 1e-8, 1e-7)
+
+
+def test_hostsim_gauss_hermite_batch_vs_oracle(lib):
+    parity.check_batch_against_oracle("gh3_pendulum_T40", lib, "cpu", 5, 3, tol=1e-7)
+
+
 @pytest.mark.parametrize("name,B,iters", [("lin_pendulum_T100", 6, 4), ("lin_dcp_T80", 3, 3)])
 def test_hostsim_linearize_batch_vs_oracle(lib, name, B, iters):
     parity.check_batch_against_oracle(name, lib, "cpu", B, iters, tol=1e-7)

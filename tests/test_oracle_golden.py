@@ -154,3 +154,9 @@ def test_em_long_runs(name, n):
     """Free-running EM against the reference: no teacher forcing (perturbations
     stay ~1e-11 over 100 iterations)."""
     _run_and_check(name, 1e-8, 1e-6)
+
+
+@pytest.mark.parametrize("name", ["gh3_pendulum_T40", "gh4_linear_T30"])
+def test_em_gauss_hermite(name):
+    """GaussHermiteQuadrature(degree) as the inference rule (exp_types.py:52-68), with closed-loop propagation."""
+    _run_and_check(name, 1e-8, 1e-7)
