@@ -42,6 +42,7 @@ FAIL_REASONS = {
     7: "posterior joint covariance sig_xu0_m is not positive definite",
     8: "closed-loop propagation covariance is not positive definite",
     9: "cubature Kalman filter covariance is not positive definite",
+    10: "improper backward message in the Riccati form (a matrix to invert is not positive definite)",
 }
 
 

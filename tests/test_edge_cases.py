@@ -116,3 +116,70 @@ def test_non_diagonal_cost_weights_cpu():
 @pytest.mark.gpu
 def test_non_diagonal_cost_weights_gpu():
     _dense_cost(None, "cuda")
+
+
+# ---- the other inference methods: shortest horizons, ragged batches, failure isolation ----
+def _check_inference(lib, device, golden, T, B):
+    import json
+
+    g = load_case(golden)
+    g = Case({**g, "meta": np.array(json.dumps(dict(g.meta, T=T))), "mu_u": g["mu_u"][:T]})
+    x0, mu_u = parity.batched_inputs(g, B)
+    eng = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u)
+    o = oracle_from_case(Case({**g, "mu_u": mu_u}), x0=x0)
+    for it in range(3):
+        eng.learn_msgs()
+        o.learn_msgs()
+        mu, sig = eng.marginal_state_action()
+        assert_close(parity.np_(mu), o.mu_xu0_m, 1e-8, f"{golden} T={T} B={B} it{it} mu")
+        assert_close(parity.np_(sig), o.sig_xu0_m, 1e-8, f"{golden} T={T} B={B} it{it} sig")
+        assert_close(parity.np_(eng.alpha), o.alpha, 1e-8, f"{golden} T={T} B={B} it{it} alpha")
+        assert_close(parity.np_(eng.costs_m[-1]), o.costs_m[-1], 1e-8, f"{golden} T={T} B={B} it{it} cost")
+    assert eng.failures() == []
+
+
+INFERENCE_EDGE = [("lin_pendulum_T100", 1, 1), ("lin_pendulum_T100", 2, 67), ("lin_cartpole_T100", 3, 5),
+                  ("gh3_pendulum_T40", 1, 3), ("gh3_pendulum_T40", 4, 66)]
+
+
+@pytest.mark.parametrize("golden,T,B", INFERENCE_EDGE)
+def test_linearize_and_gauss_hermite_short_horizons_cpu(golden, T, B):
+    _check_inference(hostsim.load(), "cpu", golden, T, B)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("golden,T,B", INFERENCE_EDGE)
+def test_linearize_and_gauss_hermite_short_horizons_gpu(golden, T, B):
+    _check_inference(None, "cuda", golden, T, B)
+
+
+def _check_failure_isolation(lib, device, golden):
+    """A trajectory whose initial covariance is not positive definite is flagged in status[b] and goes NaN; its
+    neighbours are bit-identical to a run without it (the reference would raise for the whole problem)."""
+    g = load_case(golden)
+    B = 5
+    x0, mu_u = parity.batched_inputs(g, B)
+    sig_x0 = np.broadcast_to(g["sig_x0"], (B,) + g["sig_x0"].shape).copy()
+    good = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u, sig_x0=sig_x0)
+    sig_x0[2] = -sig_x0[2]
+    bad = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u, sig_x0=sig_x0)
+    for _ in range(2):
+        good.learn_msgs()
+        bad.learn_msgs()
+    fails = bad.failures()
+    assert [f[0] for f in fails] == [2], fails
+    keep = [0, 1, 3, 4]
+    a, b = parity.np_(good.marginal_state_action()[0]), parity.np_(bad.marginal_state_action()[0])
+    assert np.array_equal(a[keep], b[keep])
+    assert not np.all(np.isfinite(b[2]))
+
+
+@pytest.mark.parametrize("golden", ["lin_pendulum_T100", "gh3_pendulum_T40"])
+def test_failure_isolation_other_inference_cpu(golden):
+    _check_failure_isolation(hostsim.load(), "cpu", golden)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("golden", ["lin_pendulum_T100", "gh3_pendulum_T40"])
+def test_failure_isolation_other_inference_gpu(golden):
+    _check_failure_isolation(None, "cuda", golden)
