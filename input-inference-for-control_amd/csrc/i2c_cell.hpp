@@ -482,6 +482,20 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 #pragma unroll
   for (int k = 0; k < NZ; ++k) zt[k] = (!LEAN && c.z_per_cell) ? a.z[(long)k * B + b] : c.zg[k];
 
+  // Small models never factor the prior joint: its Cholesky factor is assembled from the factor Lx of the incoming
+  // sig_x0_f (= chol(sig_x3_f) of the previous cell, already needed for the smoother gain) as
+  //   L0 = [[Lx, 0], [K~ Lx, chol(sig_u|x)]],  sig_u|x = sig_u0_m - K~ sig_ux^T   (feed-forward: K~ = 0, sig_u|x = sig_u0_f),
+  // which takes one nu x nu factorisation instead of a d x d one off the critical path. (For d >= 6 the carried
+  // factor would cost nx(nx+1)/2 more live registers across the whole cell.)
+  constexpr bool STRUCT_L0 = C::D <= 5;
+  R Lx[STRUCT_L0 ? sym(NX) : 1];
+  if (STRUCT_L0) {
+    R rx[NX];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) Lx[i] = sig_x[i];
+    fail = note_failure(fail, chol<NX>(Lx, rx), 1, 0);
+  }
+
   for (int t = 0; t < T; ++t) {
     const int tn = t + 1 < T ? t + 1 : t;
     const unsigned rb = opaque_uniform(rb0);  // see opaque_uniform(): no hoisting of e * rb
@@ -507,6 +521,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 
     // ---- 1. joint prior over (x, u) ---------------------------------------------------
     R mu0[D], S0[sym(D)];
+    R L0[STRUCT_L0 ? sym(D) : 1], Luu[sym(NU)], ruu[NU];  // Luu: conditional action covariance, then its factor
     if (a.ff[t]) {  // feed-forward: independent action prior (i2c.py:355-360)
 #pragma unroll
       for (int i = 0; i < NX; ++i) mu0[i] = mu_x[i];
@@ -517,6 +532,16 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 #pragma unroll
         for (int j = 0; j <= i; ++j)
           S0[tri(i, j)] = (i < NX) ? sig_x[tri(i, j)] : (j >= NX ? psig[tri(i, j)] : R(0));
+      if (STRUCT_L0) {
+#pragma unroll
+        for (int p = 0; p < NU; ++p)
+#pragma unroll
+          for (int q = 0; q <= p; ++q) Luu[tri(p, q)] = psig[tri(NX + p, NX + q)];
+#pragma unroll
+        for (int p = 0; p < NU; ++p)
+#pragma unroll
+          for (int j = 0; j < NX; ++j) L0[tri(NX + p, j)] = R(0);
+      }
     } else {  // feedback: condition the previous controller on the new state message (i2c.py:361-387)
       R S[sym(NX)], delta[NX];
 #pragma unroll
@@ -536,12 +561,33 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       for (int p = 0; p < NU; ++p)
 #pragma unroll
         for (int q = 0; q <= p; ++q) {
-          R v = psig[tri(NX + p, NX + q)] + sig_u[tri(p, q)];
+          R v = psig[tri(NX + p, NX + q)];
 #pragma unroll
           for (int k = 0; k < NX; ++k) v -= Kt[p * NX + k] * psig[tri(NX + q, k)];
-          sig_u[tri(p, q)] = v;
+          Luu[tri(p, q)] = v;  // sig_u0_m - K~ sig_ux^T
+          sig_u[tri(p, q)] += v;
         }
       joint_from_gain<NX, NU>(mu_x, sig_x, Kt, pmu, pmu + NX, sig_u, mu0, S0);
+      if (STRUCT_L0) {
+#pragma unroll
+        for (int p = 0; p < NU; ++p)
+#pragma unroll
+          for (int j = 0; j < NX; ++j) {
+            R v = R(0);
+#pragma unroll
+            for (int k = j; k < NX; ++k) v += Kt[p * NX + k] * Lx[tri(k, j)];
+            L0[tri(NX + p, j)] = v;
+          }
+      }
+    }
+    if (STRUCT_L0) {
+#pragma unroll
+      for (int i = 0; i < sym(NX); ++i) L0[i] = Lx[i];  // xx block = packed prefix
+      fail = note_failure(fail, chol<NU>(Luu, ruu), 1, t);
+#pragma unroll
+      for (int p = 0; p < NU; ++p)
+#pragma unroll
+        for (int q = 0; q <= p; ++q) L0[tri(NX + p, NX + q)] = Luu[tri(p, q)];
     }
     if (!LEAN && a.prior_out) {
       const Window w = make_window(a.prior_out + (unsigned long)t * (D + sym(D)) * B, (unsigned long)(D + sym(D)) * rb);
@@ -560,10 +606,13 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     // ---- 2. cost "observation": measurement update on z (i2c.py:390-407) --------------
     sched_fence<(D >= 6)>();
     {
-      R L[sym(D)], rinv[D];
+      R Lf[STRUCT_L0 ? 1 : sym(D)], rinv[D];
+      if (!STRUCT_L0) {
 #pragma unroll
-      for (int i = 0; i < sym(D); ++i) L[i] = S0[i];
-      fail = note_failure(fail, chol<D>(L, rinv), 1, t);
+        for (int i = 0; i < sym(D); ++i) Lf[i] = S0[i];
+        fail = note_failure(fail, chol<D>(Lf, rinv), 1, t);
+      }
+      const R* L = STRUCT_L0 ? L0 : Lf;
       R mz[NZ], Sz[sym(NZ)], Sxz[D * NZ];
       transform<GRID, M, ObsStruct<M>, D, NZ, true, LEAN>(c.rule_xu, mu0, S0, L, ObserveF<M, R>{c.params}, mz, Sz, Sxz);
 #pragma unroll
@@ -619,6 +668,15 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 #pragma unroll
       for (int i = 0; i < sym(NT); ++i) Szt[i] += alpha * c.sig_xiT0[i];
       fail = note_failure(fail, kalman_update<NX, NT>(mu_x, sig_x, mzt, Szt, Sxzt, c.zg_term), 6, t);
+      if (STRUCT_L0) {  // the next cell (MPC: the flagged cell can sit mid-horizon) needs the factor of the UPDATED sig_x
+#pragma unroll
+        for (int i = 0; i < sym(NX); ++i) L3[i] = sig_x[i];
+        fail = note_failure(fail, chol<NX>(L3, rinv3), 6, t);
+      }
+    }
+    if (STRUCT_L0) {
+#pragma unroll
+      for (int i = 0; i < sym(NX); ++i) Lx[i] = L3[i];
     }
 #pragma unroll
     for (int e = 0; e < NX; ++e) wst(out, (D + sym(D) + e) * rb, bo, mu_x[e]);
