@@ -82,7 +82,9 @@ I2C_FN double r_rcp(double x) {
 // |x| >= 1e6 rad (a diverged trajectory) yields NaN, which the next Cholesky flags in status[b] --
 // the reference would still evaluate np.sin exactly there; documented deviation.
 I2C_FN void r_sincos(double x, double* s, double* c) {
-  x = m_fabs(x) < 1.0e6 ? x : (x - x) / (x - x);  // NaN outside the supported range (select, no branch)
+  // NaN outside the supported range. The NaN must be a CONSTANT: written as (x - x) / (x - x) the compiler guards the
+  // IEEE division with a divergent branch (s_and_saveexec / s_cbranch_execz) that splits every cell's scheduling region.
+  x = m_fabs(x) < 1.0e6 ? x : __builtin_nan("");
   const double n = m_rint(x * 6.36619772367581382433e-01);
   double r = m_fma(-n, 1.57079632673412561417e+00, x);
   r = m_fma(-n, 6.07710050630396597660e-11, r);
