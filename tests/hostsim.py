@@ -35,6 +35,7 @@ def load():
     global _lib
     if _lib is None:
         pkg = importlib.import_module("input-inference-for-control_amd")
-        _lib = pkg.load_library(build())
+        # I2C_HOSTSIM_LIB: a pre-built variant of the host simulation, e.g. the ASan / UBSan build of tools/sanitize.sh
+        _lib = pkg.load_library(os.environ.get("I2C_HOSTSIM_LIB") or build())
         assert _lib.is_host_sim
     return _lib
