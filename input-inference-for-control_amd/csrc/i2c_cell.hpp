@@ -471,13 +471,22 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 #pragma unroll
   for (int i = 0; i < sym(NX); ++i) sig_x[i] = a.sig_x0[i * B + b];
 
+  // Per-row byte offsets bo + e * rb as VGPR values (small models): a buffer access then needs no scalar multiply for its
+  // row offset. The lone wave of the small-batch regime is instruction-issue-bound and a SALU instruction costs it the
+  // same 4 clocks as a VALU one (profiles/r1_k_forward_sq_counters.json); VGPRs are plentiful here.
+  constexpr bool VOFF = C::D <= 5;
+  unsigned voff[VOFF ? C::E_FWD : 1];
+  if (VOFF) {
+#pragma unroll
+    for (int e = 0; e < C::E_FWD; ++e) voff[e] = bo + (unsigned)e * rb0;
+  }
   // software prefetch of the next cell's prior rows: the loads do not depend on the recursion
   R pri[C::E_PRI], zt[NZ];
   {
     const unsigned rb = rb0;
     const Window w = make_window(a.prior, (unsigned long)C::E_POST * rb);
 #pragma unroll
-    for (int e = 0; e < C::E_PRI; ++e) pri[e] = wld<R>(w, e * rb, bo);
+    for (int e = 0; e < C::E_PRI; ++e) pri[e] = wld<R>(w, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo);
   }
 #pragma unroll
   for (int k = 0; k < NZ; ++k) zt[k] = (!LEAN && c.z_per_cell) ? a.z[(long)k * B + b] : c.zg[k];
@@ -525,7 +534,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     if (!PREFETCH && t > 0) {
       const Window w = make_window(a.prior + (unsigned long)t * C::E_POST * B, (unsigned long)C::E_POST * rb);
 #pragma unroll
-      for (int e = 0; e < C::E_PRI; ++e) pri[e] = wld<R>(w, e * rb, bo);
+      for (int e = 0; e < C::E_PRI; ++e) pri[e] = wld<R>(w, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo);
 #pragma unroll
       for (int k = 0; k < NZ; ++k) zt[k] = (!LEAN && c.z_per_cell) ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
     }
@@ -609,16 +618,16 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     if (!LEAN && a.prior_out) {
       const Window w = make_window(a.prior_out + (unsigned long)t * (D + sym(D)) * B, (unsigned long)(D + sym(D)) * rb);
 #pragma unroll
-      for (int e = 0; e < D; ++e) wst(w, e * rb, bo, mu0[e]);
+      for (int e = 0; e < D; ++e) wst(w, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo, mu0[e]);
 #pragma unroll
-      for (int e = 0; e < sym(D); ++e) wst(w, (D + e) * rb, bo, S0[e]);
+      for (int e = 0; e < sym(D); ++e) wst(w, VOFF ? 0u : (D + e) * rb, VOFF ? voff[D + e] : bo, S0[e]);
     }
 
     ff_cur = a.ff[tn];  // the next cell's flag, a whole cell ahead of its use
     if (PREFETCH) {  // pri is dead from here on: refill it with the next cell's rows
       const Window w = make_window(a.prior + (unsigned long)tn * C::E_POST * B, (unsigned long)C::E_POST * rb);
 #pragma unroll
-      for (int e = 0; e < C::E_PRI; ++e) pri[e] = wld<R>(w, e * rb, bo);
+      for (int e = 0; e < C::E_PRI; ++e) pri[e] = wld<R>(w, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo);
     }
 
     // ---- 2. cost "observation": measurement update on z (i2c.py:390-407) --------------
@@ -644,9 +653,9 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     // mu0 / S0 now hold mu_xu1_f / sig_xu1_f
     const Window out = make_window(a.fwd + (unsigned long)t * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
-    for (int e = 0; e < D; ++e) wst(out, e * rb, bo, mu0[e]);
+    for (int e = 0; e < D; ++e) wst(out, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo, mu0[e]);
 #pragma unroll
-    for (int e = 0; e < sym(D); ++e) wst(out, (D + e) * rb, bo, S0[e]);
+    for (int e = 0; e < sym(D); ++e) wst(out, VOFF ? 0u : (D + e) * rb, VOFF ? voff[D + e] : bo, S0[e]);
 
     // ---- 3. dynamics push-through (i2c.py:415-421) and smoother gain (i2c.py:423-425) --
     sched_fence<(D >= 6)>();
@@ -686,7 +695,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     // J is written out BEFORE the terminal update so that its d*nx registers are dead there (with J
     // live the terminal block is the register peak of the large models and spills to scratch)
 #pragma unroll
-    for (int e = 0; e < D * NX; ++e) wst(out, (D + sym(D) + NX + sym(NX) + e) * rb, bo, Sxy[e]);
+    for (int e = 0; e < D * NX; ++e) wst(out, VOFF ? 0u : (D + sym(D) + NX + sym(NX) + e) * rb, VOFF ? voff[D + sym(D) + NX + sym(NX) + e] : bo, Sxy[e]);
     sched_fence<(D >= 6)>();
 
     // ---- 4. terminal cost observation on the flagged cell, after J (i2c.py:430-443) ----
@@ -708,9 +717,9 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       for (int i = 0; i < sym(NX); ++i) Lx[i] = L3[i];
     }
 #pragma unroll
-    for (int e = 0; e < NX; ++e) wst(out, (D + sym(D) + e) * rb, bo, mu_x[e]);
+    for (int e = 0; e < NX; ++e) wst(out, VOFF ? 0u : (D + sym(D) + e) * rb, VOFF ? voff[D + sym(D) + e] : bo, mu_x[e]);
 #pragma unroll
-    for (int e = 0; e < sym(NX); ++e) wst(out, (D + sym(D) + NX + e) * rb, bo, sig_x[e]);
+    for (int e = 0; e < sym(NX); ++e) wst(out, VOFF ? 0u : (D + sym(D) + NX + e) * rb, VOFF ? voff[D + sym(D) + NX + e] : bo, sig_x[e]);
 
   }
   if (fail != 0 && a.status[b] == 0) a.status[b] = fail;
