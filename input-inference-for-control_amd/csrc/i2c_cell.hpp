@@ -523,8 +523,10 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
   const R alpha_settled = opaque(alpha_traj);
   // Per-cell constants as VGPR values (small models): left as kernel arguments they sit in ~30 SGPRs for the whole
   // sweep, and the scalar file then spills (v_readlane) and re-materialises polynomial literals (s_mov) in every cell.
-  R xi0_v[VOFF ? sym(NZ) : 1], eta_v[VOFF ? sym(NX) : 1];
-  if (VOFF) {
+  // Only where the register file has room: the cartpole (21 + 10 doubles) already overflows into AGPRs and slows down.
+  constexpr bool CONST_V = VOFF && (sym(NZ) + sym(NX) <= 16);
+  R xi0_v[CONST_V ? sym(NZ) : 1], eta_v[CONST_V ? sym(NX) : 1];
+  if (CONST_V) {
 #pragma unroll
     for (int i = 0; i < sym(NZ); ++i) xi0_v[i] = opaque(c.sig_xi0[i]);
 #pragma unroll
@@ -652,7 +654,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       R mz[NZ], Sz[sym(NZ)], Sxz[D * NZ];
       transform<GRID, M, ObsStruct<M>, D, NZ, true, LEAN>(c.rule_xu, mu0, S0, L, ObserveF<M, R>{c.params}, mz, Sz, Sxz);
 #pragma unroll
-      for (int i = 0; i < sym(NZ); ++i) Sz[i] += alpha * (VOFF ? xi0_v[i] : c.sig_xi0[i]);
+      for (int i = 0; i < sym(NZ); ++i) Sz[i] += alpha * (CONST_V ? xi0_v[i] : c.sig_xi0[i]);
       fail = note_failure(fail, kalman_update<D, NZ>(mu0, S0, mz, Sz, Sxz, zt), 3, t);
     }
     if (!LEAN && PREFETCH && c.z_per_cell) {  // the target is consumed: fetch the next cell's
@@ -677,7 +679,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       transform<GRID, M, DenseStruct<D>, D, NX, true, LEAN>(c.rule_xu, mu0, S0, L, DynamicsF<M, R>{c.params}, mu_x, sig_x, Sxy);
     }
 #pragma unroll
-    for (int i = 0; i < sym(NX); ++i) sig_x[i] += VOFF ? eta_v[i] : (LEAN ? c.sig_eta[i] : c.sig_eta_w[i]);  // sum_p w_p sig_eta (quadrature.py:57)
+    for (int i = 0; i < sym(NX); ++i) sig_x[i] += CONST_V ? eta_v[i] : (LEAN ? c.sig_eta[i] : c.sig_eta_w[i]);  // sum_p w_p sig_eta (quadrature.py:57)
     R L3[sym(NX)], rinv3[NX];
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) L3[i] = sig_x[i];
