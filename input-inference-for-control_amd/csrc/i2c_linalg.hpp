@@ -196,6 +196,10 @@ I2C_FN float r_clip(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi
 
 // In-place Cholesky of a packed SPD matrix: a <- L (lower), rinv[j] = 1 / L[j][j].
 // Returns false if a pivot is not strictly positive (or NaN): the covariance is not PD.
+// Only the LAST pivot is tested: a pivot s_j <= 0 (or NaN) makes 1/sqrt(s_j) NaN or inf, which reaches every later row
+// through L[i][j] = v / sqrt(s_j) (0 * inf is NaN too) and turns every later pivot, in particular the last, into NaN or
+// -inf -- so `last pivot > 0` is equivalent to `all pivots > 0` at one compare per factorisation instead of one compare
+// and one mask update per pivot (the lone wave of the small-batch regime is instruction-issue-bound).
 template <int N, typename R> I2C_FN bool chol(R* a, R* rinv) {
   bool ok = true;
 #pragma unroll
@@ -203,7 +207,7 @@ template <int N, typename R> I2C_FN bool chol(R* a, R* rinv) {
     R s = a[tri(j, j)];
 #pragma unroll
     for (int k = 0; k < j; ++k) s -= a[tri(j, k)] * a[tri(j, k)];
-    ok = ok && (s > R(0));
+    if (j == N - 1) ok = s > R(0);
     const R r = r_rsqrt(s);
     rinv[j] = r;
     a[tri(j, j)] = s * r;
