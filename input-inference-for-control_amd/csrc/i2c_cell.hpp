@@ -120,11 +120,16 @@ template <int DIN> struct DenseStruct {
 // offset d = sf L[i][j], then rotated: sin(m +/- d) = s0 cd +/- c0 sd, cos(m +/- d) = c0 cd -/+ s0 sd.
 template <class M, class ST, int DIN, int DOUT, bool CROSS, bool UNITW = false, typename R, class F>
 I2C_FN void sp_transform(const Rule<R>& rule, const R* m, const R* Sin, const R* L, const F& f, R* my, R* Sy,
-                         R* Sxy) {
+                         R* Sxy, const PolyTab<R>* tab = nullptr) {
   constexpr int NA = M::NA, NA1 = NA > 0 ? NA : 1;
   R s0[NA1], c0[NA1];
 #pragma unroll
-  for (int a = 0; a < NA; ++a) r_sincos(m[M::ang(a)], &s0[a], &c0[a]);
+  for (int a = 0; a < NA; ++a) {
+    if (tab)
+      r_sincos(m[M::ang(a)], *tab, &s0[a], &c0[a]);
+    else
+      r_sincos(m[M::ang(a)], &s0[a], &c0[a]);
+  }
   R y0[DOUT];
   f(m, s0, c0, y0);
   R A[DOUT];
@@ -165,7 +170,10 @@ I2C_FN void sp_transform(const Rule<R>& rule, const R* m, const R* Sin, const R*
           cp[q] = cm[q] = c0[q];
         } else {
           R sd, cd;
-          r_sincos_small(rule.sf * L[tri(M::ang(q), j)], &sd, &cd);
+          if (tab)
+            r_sincos(rule.sf * L[tri(M::ang(q), j)], *tab, &sd, &cd);
+          else
+            r_sincos_small(rule.sf * L[tri(M::ang(q), j)], &sd, &cd);
           sp[q] = s0[q] * cd + c0[q] * sd;
           cp[q] = c0[q] * cd - s0[q] * sd;
           sm[q] = s0[q] * cd - c0[q] * sd;
@@ -266,7 +274,7 @@ I2C_FN bool kalman_update(R* mu, R* S, const R* mz, R* Sz, R* Sxz, const R* zt) 
 }
 
 // exp(-1/2 delta^T S^{-1} delta): the ratio N(x; m, S) / N(m; m, S) of i2c.py:369-374, 162-165.
-template <int N, typename R> I2C_FN R pdf_ratio(R* S, const R* delta, bool* ok) {
+template <int N, typename R> I2C_FN R pdf_ratio(R* S, const R* delta, bool* ok, const PolyTab<R>* tab = nullptr) {
   R rinv[N], q[N];
   *ok = chol<N>(S, rinv);
 #pragma unroll
@@ -275,6 +283,7 @@ template <int N, typename R> I2C_FN R pdf_ratio(R* S, const R* delta, bool* ok) 
   R maha = R(0);
 #pragma unroll
   for (int i = 0; i < N; ++i) maha += q[i] * q[i];
+  (void)tab;
   return r_exp(R(-0.5) * maha);
 }
 
@@ -429,11 +438,12 @@ I2C_FN void grid_transform(const Rule<R>& rule, const R* m, const R* L, const F&
 
 // GRID selects the tensor-grid rule at compile time; the sigma-point kernels are unchanged by it.
 template <bool GRID, class M, class ST, int DIN, int DOUT, bool CROSS, bool UNITW = false, typename R, class F>
-I2C_FN void transform(const Rule<R>& rule, const R* m, const R* Sin, const R* L, const F& f, R* my, R* Sy, R* Sxy) {
+I2C_FN void transform(const Rule<R>& rule, const R* m, const R* Sin, const R* L, const F& f, R* my, R* Sy, R* Sxy,
+                      const PolyTab<R>* tab = nullptr) {
   if constexpr (GRID)
     grid_transform<M, DIN, DOUT, CROSS>(rule, m, L, f, my, Sy, Sxy);
   else
-    sp_transform<M, ST, DIN, DOUT, CROSS, UNITW>(rule, m, Sin, L, f, my, Sy, Sxy);
+    sp_transform<M, ST, DIN, DOUT, CROSS, UNITW>(rule, m, Sin, L, f, my, Sy, Sxy, tab);
 }
 
 
@@ -525,6 +535,9 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
   // sweep, and the scalar file then spills (v_readlane) and re-materialises polynomial literals (s_mov) in every cell.
   // Only where the register file has room: the cartpole (21 + 10 doubles) already overflows into AGPRs and slows down.
   constexpr bool CONST_V = VOFF && (sym(NZ) + sym(NX) <= 16);
+  PolyTab<R> ptab;  // sincos / exp coefficients as VGPR values (see PolyTab), same condition
+  if (CONST_V) poly_tab_init(ptab);
+  const PolyTab<R>* const tab = CONST_V ? &ptab : nullptr;
   R xi0_v[CONST_V ? sym(NZ) : 1], eta_v[CONST_V ? sym(NX) : 1];
   if (CONST_V) {
 #pragma unroll
@@ -586,7 +599,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 #pragma unroll
       for (int i = 0; i < NX; ++i) delta[i] = mu_x[i] - pmu[i];
       bool ok;
-      const R rho = pdf_ratio<NX>(S, delta, &ok);
+      const R rho = pdf_ratio<NX>(S, delta, &ok, tab);
       fail = note_failure(fail, ok, 2, t);
       R Kt[NU * NX];
 #pragma unroll
@@ -652,7 +665,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       }
       const R* L = STRUCT_L0 ? L0 : Lf;
       R mz[NZ], Sz[sym(NZ)], Sxz[D * NZ];
-      transform<GRID, M, ObsStruct<M>, D, NZ, true, LEAN>(c.rule_xu, mu0, S0, L, ObserveF<M, R>{c.params}, mz, Sz, Sxz);
+      transform<GRID, M, ObsStruct<M>, D, NZ, true, LEAN>(c.rule_xu, mu0, S0, L, ObserveF<M, R>{c.params}, mz, Sz, Sxz, tab);
 #pragma unroll
       for (int i = 0; i < sym(NZ); ++i) Sz[i] += alpha * (CONST_V ? xi0_v[i] : c.sig_xi0[i]);
       fail = note_failure(fail, kalman_update<D, NZ>(mu0, S0, mz, Sz, Sxz, zt), 3, t);
@@ -676,7 +689,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 #pragma unroll
       for (int i = 0; i < sym(D); ++i) L[i] = S0[i];
       fail = note_failure(fail, chol<D>(L, rinv), 4, t);
-      transform<GRID, M, DenseStruct<D>, D, NX, true, LEAN>(c.rule_xu, mu0, S0, L, DynamicsF<M, R>{c.params}, mu_x, sig_x, Sxy);
+      transform<GRID, M, DenseStruct<D>, D, NX, true, LEAN>(c.rule_xu, mu0, S0, L, DynamicsF<M, R>{c.params}, mu_x, sig_x, Sxy, tab);
     }
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) sig_x[i] += CONST_V ? eta_v[i] : (LEAN ? c.sig_eta[i] : c.sig_eta_w[i]);  // sum_p w_p sig_eta (quadrature.py:57)

@@ -107,6 +107,86 @@ I2C_FN void r_sincos(double x, double* s, double* c) {
   *s = (q & 2) ? -ss : ss;
   *c = ((q + 1) & 2) ? -cc : cc;
 }
+// ---- polynomial constants held in VGPRs ---------------------------------------------------------------------------
+// A VALU instruction reads at most one scalar / literal operand, so a Horner step with a literal coefficient costs the
+// lone, issue-bound wave an extra instruction (s_mov pair or v_mov copy) per step. PolyTab keeps the coefficients of
+// sincos and exp as opaque per-lane VALUES that the register allocator leaves in VGPRs for the whole sweep (30 + 30
+// registers; only worth it where the VGPR file has room, i.e. the small models' forward sweep).
+template <typename R> struct PolyTab {
+  R two_over_pi, pio2_1, pio2_2, pio2_3, s1, s2, s3, s4, s5, s6, c1, c2, c3, c4, c5, c6;
+  R log2e, ln2_hi, ln2_lo, e[12];
+};
+template <typename R> I2C_FN R tab_value(double v) {
+  R x = (R)v;
+#ifndef I2C_HOST_SIM
+  asm volatile("" : "+v"(x));
+#endif
+  return x;
+}
+template <typename R> I2C_FN void poly_tab_init(PolyTab<R>& t) {
+  t.two_over_pi = tab_value<R>(6.36619772367581382433e-01);
+  t.pio2_1 = tab_value<R>(1.57079632673412561417e+00);
+  t.pio2_2 = tab_value<R>(6.07710050630396597660e-11);
+  t.pio2_3 = tab_value<R>(2.02226624871116645580e-21);
+  t.s6 = tab_value<R>(1.58969099521155010221e-10);
+  t.s5 = tab_value<R>(-2.50507602534068634195e-08);
+  t.s4 = tab_value<R>(2.75573137070700676789e-06);
+  t.s3 = tab_value<R>(-1.98412698298579493134e-04);
+  t.s2 = tab_value<R>(8.33333333332248946124e-03);
+  t.s1 = tab_value<R>(-1.66666666666666324348e-01);
+  t.c6 = tab_value<R>(-1.13596475577881948265e-11);
+  t.c5 = tab_value<R>(2.08757232129817482790e-09);
+  t.c4 = tab_value<R>(-2.75573143513906633035e-07);
+  t.c3 = tab_value<R>(2.48015872894767294178e-05);
+  t.c2 = tab_value<R>(-1.38888888888741095749e-03);
+  t.c1 = tab_value<R>(4.16666666666666019037e-02);
+}
+// r_sincos with the constants taken from the table: the same formulas, instruction for instruction
+I2C_FN void r_sincos(double x, const PolyTab<double>& t, double* s, double* c) {
+  x = m_fabs(x) < 1.0e6 ? x : __builtin_nan("");
+  const double n = m_rint(x * t.two_over_pi);
+  double r = m_fma(-n, t.pio2_1, x);
+  r = m_fma(-n, t.pio2_2, r);
+  r = m_fma(-n, t.pio2_3, r);
+  const double z = r * r;
+  double ps = p_fma(z, t.s6, t.s5);
+  ps = p_fma(ps, z, t.s4);
+  ps = p_fma(ps, z, t.s3);
+  ps = p_fma(ps, z, t.s2);
+  const double sr = m_fma(z * r, p_fma(z, ps, t.s1), r);
+  double pc = p_fma(z, t.c6, t.c5);
+  pc = p_fma(pc, z, t.c4);
+  pc = p_fma(pc, z, t.c3);
+  pc = p_fma(pc, z, t.c2);
+  pc = p_fma(pc, z, t.c1);
+  const double cr = 1.0 - m_fma(0.5, z, -(z * z) * pc);
+  const int q = (int)n;
+  const double ss = (q & 1) ? cr : sr;
+  const double cc = (q & 1) ? sr : cr;
+  *s = (q & 2) ? -ss : ss;
+  *c = ((q + 1) & 2) ? -cc : cc;
+}
+I2C_FN void r_sincos(float x, const PolyTab<float>&, float* s, float* c) { r_sincos(x, s, c); }
+// exp(x) for x <= 0 (the pdf ratio exp(-maha / 2)): Cody-Waite reduction by ln 2, degree-13 Taylor kernel on
+// [-ln2/2, ln2/2] (truncation 4e-18), scaling by v_ldexp; NaN propagates, x < -750 gives 0.
+I2C_FN double r_exp_neg(double x, const PolyTab<double>& t) {
+  x = x < -750.0 ? -750.0 : x;
+  const double k = m_rint(x * t.log2e);
+  double r = m_fma(-k, t.ln2_hi, x);
+  r = m_fma(-k, t.ln2_lo, r);
+  double p = p_fma(r, t.e[11], t.e[10]);
+#pragma unroll
+  for (int n = 9; n >= 0; --n) p = p_fma(p, r, t.e[n]);
+  p = m_fma(p, r, 1.0);  // 1 + r (...)
+  p = m_fma(p, r, 1.0);  // 1 + r + r^2 (...)
+#ifdef I2C_HOST_SIM
+  return std::ldexp(p, (int)k);
+#else
+  return __builtin_amdgcn_ldexp(p, (int)k);
+#endif
+}
+I2C_FN float r_exp_neg(float x, const PolyTab<float>&) { return r_exp(x); }
+
 // the sigma-point offsets d = sf L[i][j] go through the same branch-free routine
 I2C_FN void r_sincos_small(double x, double* s, double* c) { r_sincos(x, s, c); }
 I2C_FN void r_sincos_small(float x, float* s, float* c) { r_sincos(x, s, c); }
