@@ -192,6 +192,7 @@ int i2c_backward_schedule(int model_id, int B, int T, int requested_mode);
 
 /* Library self-description: ABI version, and the gfx target it was compiled for. */
 int i2c_abi_version(void);
+size_t i2c_problem_size(void); /* sizeof(I2cProblem) as compiled: bindings compare it with their own struct layout */
 const char* i2c_build_info(void);
 
 /*

@@ -95,6 +95,7 @@ class I2cProblem(C.Structure):
 
 _SIGNATURES = {
     "i2c_abi_version": (C.c_int, []),
+    "i2c_problem_size": (C.c_size_t, []),
     "i2c_build_info": (C.c_char_p, []),
     "i2c_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "i2c_backward_schedule": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -144,6 +145,9 @@ class NativeLibrary:
             setattr(self, name, fn)
         if self.i2c_abi_version() != ABI_VERSION:
             raise ImportError(f"{path}: ABI version {self.i2c_abi_version()} != {ABI_VERSION}")
+        if self.i2c_problem_size() != C.sizeof(I2cProblem):
+            raise ImportError(f"{path}: sizeof(I2cProblem) = {self.i2c_problem_size()} but the ctypes mirror has "
+                              f"{C.sizeof(I2cProblem)} bytes (include/i2c_hip.h and _native.py disagree)")
         self.build_info = self.i2c_build_info().decode()
         self.is_host_sim = "host-simulation" in self.build_info
 

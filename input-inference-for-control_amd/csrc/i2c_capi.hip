@@ -41,6 +41,8 @@ extern "C" {
 
 int i2c_abi_version(void) { return I2C_ABI_VERSION; }
 
+size_t i2c_problem_size(void) { return sizeof(I2cProblem); }
+
 const char* i2c_build_info(void) {
 #ifdef I2C_HOST_SIM
   return "i2c host-simulation build (CPU, tests only)";
