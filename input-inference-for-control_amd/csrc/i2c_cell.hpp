@@ -549,6 +549,11 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
   for (int t = 0; t < T; ++t) {
     const int tn = t + 1 < T ? t + 1 : t;
     const unsigned rb = opaque_uniform(rb0);  // see opaque_uniform(): no hoisting of e * rb
+    // Large models: an index the compiler cannot see through (always 0) makes the big constant tables of the kernel
+    // argument (sig_xi0: 45 doubles for the double cartpole, sig_eta: 21) scalar LOADS next to their single use in each
+    // cell; hoisted out of the time loop they occupy ~130 SGPRs and the scalar file spills through v_writelane /
+    // v_readlane (540 of the 7 800 instructions of that kernel).
+    const int kz = (C::D >= 6) ? (int)opaque_uniform(0u) : 0;
     // Small models fetch the NEXT cell's prior rows right after this cell has consumed its own (below),
     // straight into the same registers: a whole cell ahead of their use, no copies. For d >= 6 those
     // d + s(d) + nu nx doubles would sit on top of a register peak that already fills the 512-VGPR file,
@@ -667,7 +672,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       R mz[NZ], Sz[sym(NZ)], Sxz[D * NZ];
       transform<GRID, M, ObsStruct<M>, D, NZ, true, LEAN>(c.rule_xu, mu0, S0, L, ObserveF<M, R>{c.params}, mz, Sz, Sxz, tab);
 #pragma unroll
-      for (int i = 0; i < sym(NZ); ++i) Sz[i] += alpha * (CONST_V ? xi0_v[i] : c.sig_xi0[i]);
+      for (int i = 0; i < sym(NZ); ++i) Sz[i] += alpha * (CONST_V ? xi0_v[i] : c.sig_xi0[i + kz]);
       fail = note_failure(fail, kalman_update<D, NZ>(mu0, S0, mz, Sz, Sxz, zt), 3, t);
     }
     if (!LEAN && PREFETCH && c.z_per_cell) {  // the target is consumed: fetch the next cell's
@@ -692,7 +697,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       transform<GRID, M, DenseStruct<D>, D, NX, true, LEAN>(c.rule_xu, mu0, S0, L, DynamicsF<M, R>{c.params}, mu_x, sig_x, Sxy, tab);
     }
 #pragma unroll
-    for (int i = 0; i < sym(NX); ++i) sig_x[i] += CONST_V ? eta_v[i] : (LEAN ? c.sig_eta[i] : c.sig_eta_w[i]);  // sum_p w_p sig_eta (quadrature.py:57)
+    for (int i = 0; i < sym(NX); ++i) sig_x[i] += CONST_V ? eta_v[i] : (LEAN ? c.sig_eta[i + kz] : c.sig_eta_w[i + kz]);  // sum_p w_p sig_eta (quadrature.py:57)
     R L3[sym(NX)], rinv3[NX];
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) L3[i] = sig_x[i];
