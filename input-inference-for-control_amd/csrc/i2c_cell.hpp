@@ -1146,7 +1146,8 @@ I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R>&
   const int T = c.T;
   const unsigned bo = (unsigned)b * W, rb = (unsigned)(B * W);
 
-  R row[C::E_FWD], nxt[C::E_FWD];
+  constexpr bool DOUBLE_BUFFER = C::D <= 5;  // see chunk_walk_body
+  R row[C::E_FWD], nxt[DOUBLE_BUFFER ? C::E_FWD : 1];
   {
     const Window w = make_window(a.fwd + (unsigned long)(T - 1) * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
@@ -1158,11 +1159,15 @@ I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R>&
 
   R sum_m = R(0), sum_v = R(0);
   for (int t = T - 1; t >= 0; --t) {
-    {
+    if (DOUBLE_BUFFER) {
       const int tp = t > 0 ? t - 1 : 0;
       const Window w = make_window(a.fwd + (unsigned long)tp * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
-      for (int e = 0; e < C::E_FWD; ++e) nxt[e] = wld<R>(w, e * rb, bo);
+      for (int e = 0; e < C::E_FWD; ++e) nxt[DOUBLE_BUFFER ? e : 0] = wld<R>(w, e * rb, bo);
+    } else if (t < T - 1) {
+      const Window w = make_window(a.fwd + (unsigned long)t * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
+#pragma unroll
+      for (int e = 0; e < C::E_FWD; ++e) row[e] = wld<R>(w, e * rb, bo);
     }
     if (a.xm) {
       R* xo = const_cast<R*>(a.xm) + ((long)t * C::E_XM) * B + b;
@@ -1189,8 +1194,10 @@ I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R>&
     for (int i = 0; i < NX; ++i) m3m[i] = mu[i];
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) S3m[i] = S[i];  // xx block = packed prefix
+    if (DOUBLE_BUFFER) {
 #pragma unroll
-    for (int e = 0; e < C::E_FWD; ++e) row[e] = nxt[e];
+      for (int e = 0; e < C::E_FWD; ++e) row[e] = nxt[DOUBLE_BUFFER ? e : 0];
+    }
   }
   a.term_stats[B + b] = sum_m;
   a.term_stats[2 * B + b] = sum_v;
@@ -1363,8 +1370,12 @@ I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R>& a,
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) S3m[i] = bi[(long)(NX + i) * B];
   }
-  R row[C::E_FWD], nxt[C::E_FWD];
-  {
+  // The next cell's forward row is fetched while this cell computes -- but only where a second row fits: for d >= 6 a
+  // row is 100+ doubles, two of them overflow the register file into scratch and the walk then waits on scratch traffic
+  // 80 % of the time (SQ counters); there the row is loaded at the top of its own cell.
+  constexpr bool DOUBLE_BUFFER = C::D <= 5;
+  R row[C::E_FWD], nxt[DOUBLE_BUFFER ? C::E_FWD : 1];
+  if (DOUBLE_BUFFER) {
     const Window w = make_window(ca.fwd + (unsigned long)(t_hi - 1) * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
     for (int e = 0; e < C::E_FWD; ++e) row[e] = wld<R>(w, e * rb, bo);
@@ -1372,10 +1383,10 @@ I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R>& a,
   R sum_m = R(0), sum_v = R(0);
   for (int t = t_hi - 1; t >= t_lo; --t) {
     {
-      const int tp = t > t_lo ? t - 1 : t_lo;
+      const int tp = DOUBLE_BUFFER ? (t > t_lo ? t - 1 : t_lo) : t;
       const Window w = make_window(ca.fwd + (unsigned long)tp * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
-      for (int e = 0; e < C::E_FWD; ++e) nxt[e] = wld<R>(w, e * rb, bo);
+      for (int e = 0; e < C::E_FWD; ++e) (DOUBLE_BUFFER ? nxt[DOUBLE_BUFFER ? e : 0] : row[e]) = wld<R>(w, e * rb, bo);
     }
     if (ca.xm) {
       R* xo = const_cast<R*>(ca.xm) + ((long)t * C::E_XM) * B + b;
@@ -1402,8 +1413,10 @@ I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R>& a,
     for (int i = 0; i < NX; ++i) m3m[i] = mu[i];
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) S3m[i] = S[i];
+    if (DOUBLE_BUFFER) {
 #pragma unroll
-    for (int e = 0; e < C::E_FWD; ++e) row[e] = nxt[e];
+      for (int e = 0; e < C::E_FWD; ++e) row[e] = nxt[DOUBLE_BUFFER ? e : 0];
+    }
   }
   a.part[((long)ch * 2 + 0) * B + b] = sum_m;
   a.part[((long)ch * 2 + 1) * B + b] = sum_v;

@@ -14,6 +14,7 @@ namespace i2c {
 // PendulumKnown: i2c/env_def.py:233-309, step i2c/env_autograd.py:5-19
 struct Pendulum {
   static constexpr int ID = 0, NX = 2, NU = 1, NZ = 4, NZT = 3, NP = 0, NA = 1;
+  static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
   I2C_HD static constexpr int ang(int) { return 0; }
   // z = [sin th, cos th, thd, u],  zT = [sin th, cos th, thd]
   I2C_HD static constexpr int obs_lin(int k) { return k < 2 ? -1 : k - 1; }
@@ -54,6 +55,7 @@ struct Pendulum {
 // PendulumKnownActReg: i2c/env_def.py:312-346 (only the action is observed; no terminal observation)
 struct PendulumActReg {
   static constexpr int ID = 1, NX = 2, NU = 1, NZ = 1, NZT = 0, NP = 0, NA = 1;
+  static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int) { return 2; }  // z = [u]
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -75,6 +77,7 @@ struct PendulumActReg {
 // CartpoleKnown: i2c/env_def.py:491-612, step i2c/env_autograd.py:25-54
 struct Cartpole {
   static constexpr int ID = 2, NX = 4, NU = 1, NZ = 6, NZT = 5, NP = 0, NA = 1;
+  static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
   I2C_HD static constexpr int ang(int) { return 1; }
   // z = [x, sin th, cos th, xd, thd, u],  zT = [x, sin th, cos th, xd, thd]
   I2C_HD static constexpr int obs_lin(int k) { return k == 0 ? 0 : (k < 3 ? -1 : k - 1); }
@@ -123,6 +126,7 @@ struct Cartpole {
 // DoubleCartpoleKnown: i2c/env_def.py:615-761, step i2c/env_autograd.py:60-167
 struct DoubleCartpole {
   static constexpr int ID = 3, NX = 6, NU = 1, NZ = 9, NZT = 8, NP = 0, NA = 2;
+  static constexpr bool FUSED_BACKWARD_FITS = false;  // see Impl::schedule (i2c_impl.hpp)
   I2C_HD static constexpr int ang(int a) { return a == 0 ? 1 : 2; }
   // z = [x, sin th1, cos th1, sin th2, cos th2, xd, th1d, th2d, u],  zT = z without u
   I2C_HD static constexpr int obs_lin(int k) { return k == 0 ? 0 : (k < 5 ? -1 : k - 2); }
@@ -197,6 +201,7 @@ struct DoubleCartpole {
 // LinearKnown: i2c/env_def.py:139-191, i2c/model.py:226-246.  params = A (2x2 row-major), B (2), a (2)
 struct Linear {
   static constexpr int ID = 4, NX = 2, NU = 1, NZ = 3, NZT = 2, NP = 8, NA = 0;
+  static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -227,6 +232,7 @@ struct Linear {
 // LinearKnownMinimumEnergy: i2c/env_def.py:194-230 (only the action is observed; terminal = state)
 struct LinearMinEnergy {
   static constexpr int ID = 5, NX = 2, NU = 1, NZ = 1, NZT = 2, NP = 8, NA = 0;
+  static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int) { return 2; }  // z = [u], zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -258,6 +264,7 @@ struct LinearMinEnergy {
 // params = {mass, inertia, u_max}.
 struct Quadrotor {
   static constexpr int ID = 6, NX = 6, NU = 2, NZ = 8, NZT = 6, NP = 3, NA = 1;
+  static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
   I2C_HD static constexpr int ang(int) { return 2; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
