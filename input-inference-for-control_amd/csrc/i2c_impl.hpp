@@ -88,7 +88,8 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void k_chunk_walk(const Consts<M, R> c
 // sum the per-cell cost statistics over t: REDUCE_PARTS lanes per trajectory, fixed summation order
 constexpr int REDUCE_PARTS = 8;
 template <class M, typename R>
-__global__ __launch_bounds__(SWEEP_BLOCK* REDUCE_PARTS) void k_reduce(const Consts<M, R> c, const CellArgs<R> a) {
+__global__ __launch_bounds__(SWEEP_BLOCK* REDUCE_PARTS) void k_reduce(const Consts<M, R> c, const CellArgs<R> a,
+                                                                      const MstepArgs<R> ms, const int T_mstep) {
   __shared__ R sm[REDUCE_PARTS][SWEEP_BLOCK], sv[REDUCE_PARTS][SWEEP_BLOCK];
   const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
   R m = R(0), v = R(0);
@@ -104,6 +105,11 @@ __global__ __launch_bounds__(SWEEP_BLOCK* REDUCE_PARTS) void k_reduce(const Cons
     }
     a.term_stats[(long)c.B + b] = m;
     a.term_stats[2 * (long)c.B + b] = v;
+    if (ms.alpha) {  // i2c_learn: the temperature M-step rides on the reduction (one launch less per EM iteration)
+      Consts<M, R> cm = c;
+      cm.T = T_mstep;  // c.T is the number of summands here (cells or chunks), the M-step needs the horizon
+      mstep_body<M, R>(cm, ms, b);
+    }
   }
 }
 template <class M, typename R>
@@ -294,9 +300,22 @@ template <class M, typename R> struct Impl {
     return mode;
   }
 
+  // `fuse` (i2c_learn only): run the M-step inside the reduction kernel of the two-pass / chunked schedules.
+  struct MstepFuse {
+    double tol;
+    int update;
+    void* stats_out;
+    bool done;
+  };
   static int backward(const I2cProblem* p, const void* fwd, void* xm, void* post, void* zpost, void* cell_stats,
                       void* term_stats, int32_t* status, void* stream) {
-    const C c = make_consts<M, R>(p, 0.0, 0);
+    return backward_impl(p, fwd, xm, post, zpost, cell_stats, term_stats, status, stream, nullptr);
+  }
+  static int backward_impl(const I2cProblem* p, const void* fwd, void* xm, void* post, void* zpost, void* cell_stats,
+                           void* term_stats, int32_t* status, void* stream, MstepFuse* fuse) {
+    const C c = make_consts<M, R>(p, fuse ? fuse->tol : 0.0, 0);
+    MstepArgs<R> ms{(const R*)term_stats, fuse ? (R*)p->alpha : nullptr, fuse ? (R*)fuse->stats_out : nullptr,
+                    fuse ? fuse->update : 0};
     if (p->inference == I2C_INF_LINEARIZE) {  // one schedule: a lane per trajectory walks T-1..0
       if (M::NZT == 0) return I2C_EINVAL;  // no terminal observation: the reference fails at i2c.py:500-501
       CellArgs<R> al{(const R*)fwd, (const R*)xm,    (const R*)p->z, (R*)post, (R*)zpost,
@@ -354,7 +373,9 @@ template <class M, typename R> struct Impl {
         }
         a.term_stats[(long)p->B + b] = m;
         a.term_stats[2 * (long)p->B + b] = v;
+        if (ms.alpha) mstep_body<M, R>(c, ms, b);
       }
+      if (fuse) fuse->done = true;
     };
     if (mode == I2C_BWD_FUSED) {
       for (int b = 0; b < p->B; ++b) backward_fused_body<M, R>(c, a, b);
@@ -385,7 +406,8 @@ template <class M, typename R> struct Impl {
       hipLaunchKernelGGL((k_chunk_compose<M, R>), dim3(grid, ch.n_chunks), dim3(SWEEP_BLOCK), 0, st, c, ch);
       hipLaunchKernelGGL((k_chunk_stitch<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, st, c, ch);
       hipLaunchKernelGGL((k_chunk_walk<M, R>), dim3(grid, ch.n_chunks), dim3(SWEEP_BLOCK), 0, st, c, ch);
-      hipLaunchKernelGGL((k_reduce<M, R>), dim3(grid), dim3(SWEEP_BLOCK, REDUCE_PARTS), 0, st, cr, ared);
+      hipLaunchKernelGGL((k_reduce<M, R>), dim3(grid), dim3(SWEEP_BLOCK, REDUCE_PARTS), 0, st, cr, ared, ms, p->T);
+      if (fuse) fuse->done = true;
       return launch_status();
     }
     hipLaunchKernelGGL((k_scan<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, st, c, s);
@@ -393,7 +415,8 @@ template <class M, typename R> struct Impl {
     const dim3 cgrid((p->B + CELL_BLOCK - 1) / CELL_BLOCK, p->T);
     hipLaunchKernelGGL((k_cell<M, R>), cgrid, dim3(CELL_BLOCK), 0, st, c, a);
     if (launch_status() != I2C_OK) return I2C_ELAUNCH;
-    hipLaunchKernelGGL((k_reduce<M, R>), dim3(grid), dim3(SWEEP_BLOCK, REDUCE_PARTS), 0, st, c, a);
+    hipLaunchKernelGGL((k_reduce<M, R>), dim3(grid), dim3(SWEEP_BLOCK, REDUCE_PARTS), 0, st, c, a, ms, p->T);
+    if (fuse) fuse->done = true;
     return launch_status();
 #endif
   }
@@ -435,10 +458,13 @@ template <class M, typename R> struct Impl {
     for (int it = 0; it < n_iters; ++it) {
       int rc = forward(p, post, fwd, nullptr, status, stream);
       if (rc != I2C_OK) return rc;
-      rc = backward(p, fwd, xm, post, zpost, cell_stats, term_stats, status, stream);
+      MstepFuse fuse{tol, 1, (R*)stats_hist + (size_t)it * 4 * p->B, false};
+      rc = backward_impl(p, fwd, xm, post, zpost, cell_stats, term_stats, status, stream, &fuse);
       if (rc != I2C_OK) return rc;
-      rc = mstep(p, term_stats, tol, 1, (R*)stats_hist + (size_t)it * 4 * p->B, stream);
-      if (rc != I2C_OK) return rc;
+      if (!fuse.done) {  // fused / Linearize / Gauss-Hermite schedules have no reduction kernel
+        rc = mstep(p, term_stats, tol, 1, (R*)stats_hist + (size_t)it * 4 * p->B, stream);
+        if (rc != I2C_OK) return rc;
+      }
       if (tau > 0) {  // _update_priors: cells with index <= tau switch to feedback mode
         const size_t n = (size_t)(tau + 1 < p->T ? tau + 1 : p->T);
 #ifdef I2C_HOST_SIM
