@@ -350,6 +350,19 @@ template <int NX, int NU, typename R> I2C_FN void gain_quad(const R* Kt, const R
 I2C_FN int note_failure(int fail, bool ok, int reason, int t) {
   return (fail == 0 && !ok) ? ((reason << 16) | (t + 1)) : fail;
 }
+// Cheaper bookkeeping inside a forward cell: each stage only raises a small integer (inline constants, no `fail == 0`
+// test), and the first-failure status word is formed once per cell. Stages in execution order 0..5 = pdf ratio, prior
+// joint, observation, updated joint, prediction, terminal update (reasons 2, 1, 3, 4, 5, 6); the FIRST failed stage has
+// the largest value, and later stages of a poisoned cell cannot override it.
+I2C_FN int flag_stage(int cell_bad, bool ok, int order) {
+  const int v = ok ? 0 : 7 - order;
+  return cell_bad > v ? cell_bad : v;
+}
+I2C_FN int fold_cell_failure(int fail, int cell_bad, int t) {
+  const int order = 7 - cell_bad;
+  const int reason = order == 0 ? 2 : (order == 1 ? 1 : order + 1);
+  return (fail == 0 && cell_bad != 0) ? ((reason << 16) | (t + 1)) : fail;
+}
 I2C_FN void set_status(int32_t* status, int b, int reason, int t) {
   if (status[b] == 0) status[b] = (reason << 16) | (t + 1);
 }
@@ -575,6 +588,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     const R* Kprev = pri + D + sym(D);
 
     // ---- 1. joint prior over (x, u) ---------------------------------------------------
+    int cell_bad = 0;  // 0, or 7 - (execution order of the first failed stage of this cell), see flag_stage()
     R mu0[D], S0[sym(D)];
     R L0[STRUCT_L0 ? sym(D) : 1], Luu[sym(NU)], ruu[NU];  // Luu: conditional action covariance, then its factor
     if (ff_cur != 0) {  // feed-forward: independent action prior (i2c.py:355-360)
@@ -605,7 +619,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       for (int i = 0; i < NX; ++i) delta[i] = mu_x[i] - pmu[i];
       bool ok;
       const R rho = pdf_ratio<NX>(S, delta, &ok, tab);
-      fail = note_failure(fail, ok, 2, t);
+      cell_bad = flag_stage(cell_bad, ok, 0);
       R Kt[NU * NX];
 #pragma unroll
       for (int i = 0; i < NU * NX; ++i) Kt[i] = rho * Kprev[i];
@@ -638,7 +652,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     if (STRUCT_L0) {
 #pragma unroll
       for (int i = 0; i < sym(NX); ++i) L0[i] = Lx[i];  // xx block = packed prefix
-      fail = note_failure(fail, chol<NU>(Luu, ruu), 1, t);
+      cell_bad = flag_stage(cell_bad, chol<NU>(Luu, ruu), 1);
 #pragma unroll
       for (int p = 0; p < NU; ++p)
 #pragma unroll
@@ -666,14 +680,14 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       if (!STRUCT_L0) {
 #pragma unroll
         for (int i = 0; i < sym(D); ++i) Lf[i] = S0[i];
-        fail = note_failure(fail, chol<D>(Lf, rinv), 1, t);
+        cell_bad = flag_stage(cell_bad, chol<D>(Lf, rinv), 1);
       }
       const R* L = STRUCT_L0 ? L0 : Lf;
       R mz[NZ], Sz[sym(NZ)], Sxz[D * NZ];
       transform<GRID, M, ObsStruct<M>, D, NZ, true, LEAN>(c.rule_xu, mu0, S0, L, ObserveF<M, R>{c.params}, mz, Sz, Sxz, tab);
 #pragma unroll
       for (int i = 0; i < sym(NZ); ++i) Sz[i] += alpha * (CONST_V ? xi0_v[i] : c.sig_xi0[i + kz]);
-      fail = note_failure(fail, kalman_update<D, NZ>(mu0, S0, mz, Sz, Sxz, zt), 3, t);
+      cell_bad = flag_stage(cell_bad, kalman_update<D, NZ>(mu0, S0, mz, Sz, Sxz, zt), 2);
     }
     if (!LEAN && PREFETCH && c.z_per_cell) {  // the target is consumed: fetch the next cell's
 #pragma unroll
@@ -693,7 +707,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       R L[sym(D)], rinv[D];
 #pragma unroll
       for (int i = 0; i < sym(D); ++i) L[i] = S0[i];
-      fail = note_failure(fail, chol<D>(L, rinv), 4, t);
+      cell_bad = flag_stage(cell_bad, chol<D>(L, rinv), 3);
       transform<GRID, M, DenseStruct<D>, D, NX, true, LEAN>(c.rule_xu, mu0, S0, L, DynamicsF<M, R>{c.params}, mu_x, sig_x, Sxy, tab);
     }
 #pragma unroll
@@ -701,7 +715,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     R L3[sym(NX)], rinv3[NX];
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) L3[i] = sig_x[i];
-    fail = note_failure(fail, chol<NX>(L3, rinv3), 5, t);
+    cell_bad = flag_stage(cell_bad, chol<NX>(L3, rinv3), 4);
     sched_fence<(D >= 6)>();
 #pragma unroll
     for (int i = 0; i < D; ++i) {  // J = sig_xy sig_x3^{-1}, row by row
@@ -734,17 +748,18 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
       transform<GRID, M, TermStruct<M>, NX, NT, true, LEAN>(c.rule_x, mu_x, sig_x, L3, ObserveTermF<M, R>{c.params}, mzt, Szt, Sxzt);
 #pragma unroll
       for (int i = 0; i < sym(NT); ++i) Szt[i] += alpha * c.sig_xiT0[i];
-      fail = note_failure(fail, kalman_update<NX, NT>(mu_x, sig_x, mzt, Szt, Sxzt, c.zg_term), 6, t);
+      cell_bad = flag_stage(cell_bad, kalman_update<NX, NT>(mu_x, sig_x, mzt, Szt, Sxzt, c.zg_term), 5);
       if (STRUCT_L0) {  // the next cell (MPC: the flagged cell can sit mid-horizon) needs the factor of the UPDATED sig_x
 #pragma unroll
         for (int i = 0; i < sym(NX); ++i) L3[i] = sig_x[i];
-        fail = note_failure(fail, chol<NX>(L3, rinv3), 6, t);
+        cell_bad = flag_stage(cell_bad, chol<NX>(L3, rinv3), 5);
       }
     }
     if (STRUCT_L0) {
 #pragma unroll
       for (int i = 0; i < sym(NX); ++i) Lx[i] = L3[i];
     }
+    fail = fold_cell_failure(fail, cell_bad, t);
 #pragma unroll
     for (int e = 0; e < NX; ++e) wst(out, VOFF ? 0u : (D + sym(D) + e) * rb, VOFF ? voff[D + sym(D) + e] : bo, mu_x[e]);
 #pragma unroll
