@@ -85,11 +85,15 @@ class MpcPolicy:
         self.i2c._invalidate()
 
     def _first_action(self, deterministic):
+        """cells[0].mu_u0_m (and sig_u0_m when sampling): only cell 0 of the posterior buffer is read back."""
         e = self.engine
-        mu, sig = e.marginal_state_action()
-        mu_u = _np(mu[:, 0, e.nx:])
+        d, nx = e.d, e.nx
+        mu_u = _np(e.post[0, nx:d, :].T)  # (B, nu)
         if not deterministic:
-            sig_u = _np(sig[:, 0, e.nx:, e.nx:])
+            from .. import core
+
+            sig = core.engine.unpack_sym(e.post[0, d: d + d * (d + 1) // 2, :].T, d)  # (B, d, d), cell 0 only
+            sig_u = _np(sig[:, nx:, nx:])
             mu_u = np.stack([np.random.multivariate_normal(m, s) for m, s in zip(mu_u, sig_u)])
         return mu_u
 
