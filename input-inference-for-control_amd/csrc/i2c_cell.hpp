@@ -544,6 +544,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 #pragma unroll
   for (int k = 0; k < NZ; ++k) zt[k] = opaque(zt[k]);
   const R alpha_settled = opaque(alpha_traj);
+  R alpha_cur = opaque((!LEAN && a.alpha_cell) ? a.alpha_cell[b] : alpha_settled);  // per-cell temperature, fetched a cell ahead
   // Per-cell constants as VGPR values (small models): left as kernel arguments they sit in ~30 SGPRs for the whole
   // sweep, and the scalar file then spills (v_readlane) and re-materialises polynomial literals (s_mov) in every cell.
   // Only where the register file has room: the cartpole (21 + 10 doubles) already overflows into AGPRs and slows down.
@@ -582,7 +583,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     }
 
     // per-cell temperature only in the MPC loop (stale sig_xi of appended cells); else the trajectory's
-    const R alpha = opaque((!LEAN && a.alpha_cell) ? a.alpha_cell[(long)t * B + b] : alpha_settled);
+    const R alpha = opaque(alpha_cur);
     const R* pmu = pri;               // prior joint mean  (== previous posterior, see i2c_hip.h)
     const R* psig = pri + D;          // prior joint covariance
     const R* Kprev = pri + D + sym(D);
@@ -667,6 +668,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     }
 
     ff_cur = a.ff[tn];  // the next cell's flag, a whole cell ahead of its use
+    if (!LEAN && a.alpha_cell) alpha_cur = a.alpha_cell[(long)tn * B + b];
     if (PREFETCH) {  // pri is dead from here on: refill it with the next cell's rows
       const Window w = make_window(a.prior + (unsigned long)tn * C::E_POST * B, (unsigned long)C::E_POST * rb);
 #pragma unroll
