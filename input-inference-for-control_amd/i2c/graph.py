@@ -460,6 +460,20 @@ class I2cGraph:
         mzt = _np(mzt)
         return mz, (mzt[0].reshape(1, -1) if self.B == 1 else mzt)
 
+    @staticmethod
+    def list_minima(list_, n_min, n_steps):
+        """i2c.py:1172-1182."""
+        if len(list_) > n_min:
+            if len(list_) > n_steps and n_steps > 0:
+                return all(list_[-1 - i] < list_[-2 - i] for i in range(n_steps))
+            return False
+
+    @staticmethod
+    def indexed_confidence_bound(mu, sig, idx):
+        """Two-sigma band of component idx along a trajectory (i2c.py:1184-1189)."""
+        std = 2.0 * np.sqrt(sig[:, idx, idx])
+        return mu[:, idx] + std, mu[:, idx] - std
+
     def get_state_action_prior(self):
         mu = _np(self.engine.prior_state_action()[0])
         return mu[0][:, :, None] if self.B == 1 else mu
