@@ -131,3 +131,34 @@ def write_commit(res_dir):
         sha = "unknown"
     with open(os.path.join(res_dir, "git_commit.txt"), "w") as f:
         f.write(sha)
+
+
+# ---- figure helpers the covariance-control scripts import (reference i2c/utils.py:378-419) ----
+def covariance_2d(covar, mean, axis, n_std=2.0, facecolor="b", **kwargs):
+    """Outline of the n_std ellipse of a 2-D Gaussian on `axis` (scripts/nonlinear_covariance_control.py:32-52,
+    scripts/linear_gaussian_covariance_control.py:38-55). Returns the patch."""
+    from matplotlib.patches import Ellipse
+
+    covar = np.asarray(covar, dtype=float)
+    evals, evecs = np.linalg.eigh(0.5 * (covar + covar.T))
+    if not np.all(np.isfinite(evals)) or np.any(evals < 0.0):
+        raise ValueError("covariance_2d needs a finite positive semi-definite 2x2 covariance")
+    major = evecs[:, 1]  # eigh sorts ascending: column 1 is the long axis
+    patch = Ellipse(
+        xy=np.asarray(mean, dtype=float).reshape(-1)[:2],
+        width=2.0 * n_std * float(np.sqrt(evals[1])),
+        height=2.0 * n_std * float(np.sqrt(evals[0])),
+        angle=float(np.degrees(np.arctan2(major[1], major[0]))),
+        edgecolor=facecolor,
+        facecolor="none",
+        **kwargs,
+    )
+    return axis.add_patch(patch)
+
+
+def plot_uncertainty(ax, x, mean, variance, stds=(2,), color="b", alpha=0.1):
+    """Shaded +/- k sigma bands around a mean curve."""
+    x, mean, variance = (np.asarray(v, dtype=float).squeeze() for v in (x, mean, variance))
+    for k in stds:
+        half = k * np.sqrt(variance)
+        ax.fill_between(x, mean + half, mean - half, where=half > 0, color=color, alpha=alpha)
