@@ -281,7 +281,8 @@ int i2c_learn(const I2cProblem* p, void* post, void* fwd, void* xm, void* zpost,
  * per-cell propagated cost statistics (i2c.py:685-688, 1055-1063).
  *   post       [T][e_post][B]  in  (posterior + controller from i2c_backward_sweep)
  *   prop       [T][e_prop][B]  out: mu_xu0_pf[d] | sig_xu0_pf[SYM(d)] | mu_x3_pf[nx] | sig_x3_pf[SYM(nx)]
- *   prop_stats [2][B]          out: sum over cells of the propagated cost mean / variance
+ *   prop_stats [3][B]          out: sum over cells of the propagated cost mean / variance; row 2 = KL(x3_pf[T-1] || terminal
+ *                              prior) for covariance control (i2c.py:1012-1019, 1223-1229), 0 otherwise
  *                              (costs_pf, costs_pf_var; row 0 / (nz T) is alpha_pf, i2c.py:934-939)
  *   use_expert_controller      cells' use_expert_controller flag (i2c.py:143,160)
  */

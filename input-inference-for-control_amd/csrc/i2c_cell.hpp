@@ -1488,7 +1488,7 @@ I2C_HD inline void mstep_body(const Consts<M, R>& c, const MstepArgs<R>& a, cons
 template <typename R> struct PropArgs {
   const R* post;   // [T][E_POST][B]
   R* prop;         // [T][E_PROP][B]
-  R* prop_stats;   // [2][B]: sum_t of the propagated cost mean / variance
+  R* prop_stats;   // [3][B]: sum_t of the propagated cost mean / variance, KL of the final state to the terminal prior
   const R* x0;
   const R* sig_x0;
   const R* z;
@@ -1585,6 +1585,40 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
   }
   a.prop_stats[b] = sum_m;
   a.prop_stats[B + b] = sum_v;
+  // KL(x3_pf[T-1] || terminal prior) of covariance control (I2cGraph._maximize, i2c.py:1012-1019, mvn_kl_divergence
+  // :1223-1229) from the two Cholesky factors: log det ratio = 2 sum log(L2_ii / L1_ii), tr(S2^-1 S1) = ||L2^-1 L1||_F^2.
+  R kl = R(0);
+  if (c.has_x_terminal) {
+    R L1[sym(NX)], r1[NX], L2[sym(NX)], r2[NX];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) {
+      L1[i] = sig_x[i];
+      L2[i] = c.sig_x_term[i];
+    }
+    const bool ok = chol<NX>(L1, r1) && chol<NX>(L2, r2);
+    if (!ok) set_status(a.status, b, 8, T - 1);
+    R logdet = R(0), tr = R(0), dq[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      logdet += r_log(r1[i]) - r_log(r2[i]);  // log(L2_ii) - log(L1_ii) with r = 1 / L_ii
+      dq[i] = c.mu_x_term[i] - mu_x[i];
+    }
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {  // column j of L2^-1 L1
+      R col[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) col[i] = i >= j ? L1[tri(i, j)] : R(0);
+      fsub<NX>(L2, r2, col);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) tr += col[i] * col[i];
+    }
+    fsub<NX>(L2, r2, dq);
+    R maha = R(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) maha += dq[i] * dq[i];
+    kl = R(0.5) * (R(2) * logdet + tr + maha - R(NX));
+  }
+  a.prop_stats[2 * B + b] = kl;
 }
 
 // ------------------------------------------------------------------------------------------

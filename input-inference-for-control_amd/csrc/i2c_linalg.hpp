@@ -38,6 +38,8 @@ I2C_FN float r_rsqrt(float x) { return 1.0f / std::sqrt(x); }
 I2C_FN float r_rcp(float x) { return 1.0f / x; }
 I2C_FN double r_exp(double x) { return std::exp(x); }
 I2C_FN float r_exp(float x) { return std::exp(x); }
+I2C_FN double r_log(double x) { return std::log(x); }
+I2C_FN float r_log(float x) { return std::log(x); }
 I2C_FN void r_sincos(float x, float* s, float* c) { *s = std::sin(x); *c = std::cos(x); }
 #else
 I2C_FN double seed_rsq(double x) { return __builtin_amdgcn_rsq(x); }
@@ -49,6 +51,8 @@ I2C_FN float r_rsqrt(float x) { return rsqrtf(x); }
 I2C_FN float r_rcp(float x) { return 1.0f / x; }
 I2C_FN double r_exp(double x) { return exp(x); }
 I2C_FN float r_exp(float x) { return expf(x); }
+I2C_FN double r_log(double x) { return log(x); }
+I2C_FN float r_log(float x) { return logf(x); }
 I2C_FN void r_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
 #endif
 

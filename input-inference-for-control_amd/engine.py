@@ -329,7 +329,7 @@ class BatchedI2c:
         """I2cGraph.propagate (i2c.py:1247-1251)."""
         if self.prop is None:
             self.prop = torch.zeros(self.H, self.dims.e_prop, self.B, dtype=self.dtype, device=self.device)
-            self.prop_stats = torch.zeros(2, self.B, dtype=self.dtype, device=self.device)
+            self.prop_stats = torch.zeros(3, self.B, dtype=self.dtype, device=self.device)
         rc = self.lib.i2c_propagate(C.byref(self._problem), self._ptr(self.post), self._ptr(self.prop),
                                     self._ptr(self.prop_stats), int(self.use_expert_controller),
                                     self._ptr(self.status), self._stream())
@@ -512,6 +512,8 @@ class BatchedI2c:
     def _terminal_kl(self):
         """mvn_kl_divergence(x3_pf[T-1] || terminal prior) (i2c.py:1012-1019, 1223-1229)."""
         nx = self.nx
+        if self.prop is not None and self._propagate:
+            return self.prop_stats[2].to(torch.float64).clone()  # computed by k_propagate for the state it just propagated
         if self.prop is None:
             mu1 = self.x0.T.to(torch.float64)
             sig1 = unpack_sym(self.sig_x0.T.to(torch.float64), nx)
