@@ -97,9 +97,10 @@ def _check_linearize_protocol(lib, device):
     assert_close(k, g.at(1, "k"), 1e-6, "k (message passing)")
     assert_close(xu, g.at(1, "mu_xu0_m"), 1e-7, "posterior trajectory")
     n = T // 2
-    assert_close(K[:n], g["lqr/K"][:n], 1e-5, "K vs LQR")
-    assert_close(k[:n], g["lqr/k"][:n].reshape(n, -1), 1e-5, "k vs LQR")
-    assert_close(xu[:, :2], g["lqr/x"][:T], 1e-6, "x vs LQR")
+    # SURVEY 8(c) thresholds for the lqr_compare counterpart (the reference itself reaches 2.2e-7, 2.6e-7, 3.8e-6, 2.8e-8)
+    assert np.abs(xu[:, :2] - g["lqr/x"][:T]).max() <= 1e-6, "x vs LQR"
+    assert np.abs(K[:n] - g["lqr/K"][:n]).max() <= 1e-6, "K vs LQR"
+    assert np.abs(k[:n] - g["lqr/k"][:n].reshape(n, -1)).max() <= 1e-5, "k vs LQR"
 
     # The Riccati form inverts matrices of scale 1e20 (sig_eta = 1e-20): the reference's own Riccati-form gain is 2e-4
     # away from LQR, and two fp64 implementations of it agree to ~1e-5 (LAPACK LU there, Cholesky here).
@@ -114,7 +115,8 @@ def _check_linearize_protocol(lib, device):
     assert_close(Kr[:n], g["lqr/K"][:n], 1e-3, "Riccati-form K vs LQR")
     # the value function of LQR is the backward message scaled by alpha (scripts/lqr_compare.py:87-104)
     lam3 = np.stack([c.lambda_x3_b for c in i2c.cells]) * 1e-5
-    assert_close(lam3[:n], g["lqr/P"][:n], 1e-6, "alpha * lambda_x3_b vs the Riccati matrix P")
+    assert np.abs(lam3[:n] - g["lqr/P"][:n]).max() / np.abs(g["lqr/P"]).max() <= 1e-7, "alpha * lambda_x3_b vs the Riccati matrix P"
+
 
 
 def test_linearize_lqr_compare_protocol_cpu():
