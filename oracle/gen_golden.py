@@ -130,6 +130,12 @@ def case_pendulum_long():
     case_pendulum(T=200, n_detail=0, n_total=200, seed=0, name="em_pendulum_T200_run200")
 
 
+def case_pendulum_seeds():
+    """free-running EM for other seeds of the initial action sequence (summary only)."""
+    for seed in (1, 2):
+        case_pendulum(T=200, n_detail=0, n_total=60, seed=seed, name=f"em_pendulum_T200_seed{seed}_run60")
+
+
 def case_pendulum_general_weights():
     case_pendulum(T=40, n_detail=2, n_total=6, seed=3, quad=(1.2, 0.44, 0.5), name="em_pendulum_T40_quad_general")
 
@@ -150,6 +156,11 @@ def case_double_cartpole(T=60, n_detail=2, n_total=10, name="em_dcp_T60"):
 
 def case_double_cartpole_T300():
     case_double_cartpole(T=300, n_detail=0, n_total=20, name="em_dcp_T300_run20")
+
+
+def case_double_cartpole_T300_long():
+    """50 free-running iterations of the double cartpole at the full horizon."""
+    case_double_cartpole(T=300, n_detail=0, n_total=50, name="em_dcp_T300_run50")
 
 
 def case_cartpole(T=100, n_detail=2, n_total=10):
@@ -668,9 +679,11 @@ def case_gh_linear(T=30, degree=4, n_detail=2, n_total=6, noise=1e-4):
 CASES = {
     "pendulum": case_pendulum,
     "pendulum_long": case_pendulum_long,
+    "pendulum_seeds": case_pendulum_seeds,
     "pendulum_general": case_pendulum_general_weights,
     "dcp": case_double_cartpole,
     "dcp300": case_double_cartpole_T300,
+    "dcp300_long": case_double_cartpole_T300_long,
     "cartpole": case_cartpole,
     "linear": case_linear,
     "covctrl": case_covariance_control,

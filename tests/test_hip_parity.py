@@ -74,6 +74,13 @@ def test_hip_double_cartpole_T300_vs_reference(lib):
     parity.check_against_golden("em_dcp_T300_run20", lib, "cuda", 1e-6, 1e-5)
 
 
+@pytest.mark.parametrize("name,n", [("em_pendulum_T200_seed1_run60", 60), ("em_pendulum_T200_seed2_run60", 24), ("em_dcp_T300_run50", 50)])
+def test_hip_more_free_running_em_vs_reference(lib, name, n):
+    """Other seeds / longer double-cartpole run; seed 2 only while the reference itself is reproducible
+    (see tests/test_oracle_golden.py::test_em_long_runs)."""
+    parity.check_against_golden(name, lib, "cuda", 1e-6, 1e-5, n_iters=n)
+
+
 @pytest.mark.parametrize("name,B,iters", [("em_pendulum_T200", 256, 4), ("em_dcp_T60", 64, 3), ("em_covctrl_T100", 64, 4),
                                           ("em_cartpole_T100", 64, 3)])
 def test_hip_batch_vs_oracle(lib, name, B, iters):

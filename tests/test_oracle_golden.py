@@ -149,11 +149,14 @@ def test_em_propagate_expert_T50():
     _run_and_check("em_pendulum_T50_propagate", 1e-9, 1e-8)
 
 
-@pytest.mark.parametrize("name,n", [("em_pendulum_T200_run200", 200), ("em_dcp_T300_run20", 20)])
+@pytest.mark.parametrize("name,n", [("em_pendulum_T200_run200", 200), ("em_dcp_T300_run20", 20), ("em_pendulum_T200_seed1_run60", 60),
+                                    ("em_pendulum_T200_seed2_run60", 24), ("em_dcp_T300_run50", 50)])
 def test_em_long_runs(name, n):
     """Free-running EM against the reference: no teacher forcing (perturbations
-    stay ~1e-11 over 100 iterations)."""
-    _run_and_check(name, 1e-8, 1e-6)
+    stay ~1e-11 over 100 iterations). Seed 2 is the exception that shows the limit: after ~25 iterations its swing-up
+    enters a regime that amplifies rounding noise 100x every 6 iterations (this restatement and the reference, same
+    formulas, drift apart to 4e-4 by iteration 60), so it is compared over its first 24 iterations only."""
+    _run_and_check(name, 1e-8, 1e-6, n_iters=n)
 
 
 @pytest.mark.parametrize("name", ["gh3_pendulum_T40", "gh4_linear_T30"])
