@@ -251,6 +251,38 @@ int i2c_mstep(const I2cProblem* p, const void* term_stats, double alpha_update_t
               void* stats_out, void* stream);
 
 /*
+ * One control step of the model-predictive loop in ONE call with no host round trip: replaces the body of
+ * PartiallyObservedMpcPolicy.__call__ / MpcPolicy.__call__ (i2c/policy/mpc.py:156-182, 95-111):
+ *   if do_filter: i2c_ckf_filter on (p->x0, p->sig_x0) with measurement y and previous action u (mpc.py:125-145)
+ *   n_iter x { i2c_forward_sweep; i2c_backward_sweep; _update_priors (cells <= tau to feedback mode) }
+ *   action <- cells[0].mu_u0_m, sig_u0_m;  cells.pop(0); cells.append(deepcopy(cell_init))    (mpc.py:171-181)
+ * The shift is out of place: the caller owns two sets of {post, alpha_cell, z, feedforward}; `*_next` receive the
+ * shifted horizon and become p->... of the next step (p->terminal_cell moves on the host).
+ */
+typedef struct I2cMpcStep {
+  int32_t do_filter, n_iter, tau, reserved0;
+  double sig_zeta[I2C_SYM(I2C_MAX_NZ)]; /* packed measurement noise, ny x ny (sys.sig_zeta) */
+  const void* y;            /* [ny][B] or NULL */
+  const void* u;            /* [nu][B] or NULL: the action applied since the last step */
+  void* post;               /* [T][e_post][B] in/out: prior in, posterior of this step out */
+  void* post_next;          /* [T][e_post][B] out: the shifted horizon */
+  void* fwd;                /* [T][e_fwd][B] */
+  void* xm;                 /* [T][e_xm][B] or NULL (as i2c_backward_sweep) */
+  void* zpost;              /* optional */
+  void* cell_stats;         /* as i2c_backward_sweep */
+  void* term_stats;
+  const void* cell_init;    /* [e_post][B]: the cell appended at the end of the horizon (I2cCell.__init__ state) */
+  const void* alpha_init;   /* [B]: temperature the appended cell keeps (NULL iff p->alpha_cell is NULL) */
+  void* alpha_cell_next;    /* [T][B] (NULL iff p->alpha_cell is NULL) */
+  const void* z_new;        /* [nz][B] target of the appended cell, or NULL: the previous last cell's */
+  void* z_next;             /* [T][nz][B] (NULL iff targets are not per cell) */
+  uint8_t* feedforward_next; /* [T] */
+  void* action;             /* [nu + SYM(nu)][B] out, or NULL */
+  int32_t* status;          /* [B] */
+} I2cMpcStep;
+int i2c_mpc_step(const I2cProblem* p, const I2cMpcStep* step, void* stream);
+
+/*
  * Riccati-form backward messages after a Linearize forward/backward pass: replaces I2cGraph._backward_ricatti_msgs
  * (i2c.py:888-893) over I2cCell._backward_ricatti_msgs (i2c.py:612-678), the verification helper of
  * scripts/lqr_compare.py:175. Requires p->inference == I2C_INF_LINEARIZE.

@@ -93,6 +93,17 @@ class I2cProblem(C.Structure):
     ]
 
 
+class I2cMpcStep(C.Structure):
+    _fields_ = [
+        ("do_filter", C.c_int32), ("n_iter", C.c_int32), ("tau", C.c_int32), ("reserved0", C.c_int32),
+        ("sig_zeta", C.c_double * _sym(MAX_NZ)),
+        ("y", C.c_void_p), ("u", C.c_void_p), ("post", C.c_void_p), ("post_next", C.c_void_p), ("fwd", C.c_void_p),
+        ("xm", C.c_void_p), ("zpost", C.c_void_p), ("cell_stats", C.c_void_p), ("term_stats", C.c_void_p),
+        ("cell_init", C.c_void_p), ("alpha_init", C.c_void_p), ("alpha_cell_next", C.c_void_p), ("z_new", C.c_void_p),
+        ("z_next", C.c_void_p), ("feedforward_next", C.c_void_p), ("action", C.c_void_p), ("status", C.c_void_p),
+    ]
+
+
 _SIGNATURES = {
     "i2c_abi_version": (C.c_int, []),
     "i2c_problem_size": (C.c_size_t, []),
@@ -111,6 +122,7 @@ _SIGNATURES = {
         [C.POINTER(I2cProblem)] + [C.c_void_p] * 6 + [C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
     "i2c_riccati_sweep": (C.c_int, [C.POINTER(I2cProblem)] + [C.c_void_p] * 7),
+    "i2c_mpc_step": (C.c_int, [C.POINTER(I2cProblem), C.POINTER(I2cMpcStep), C.c_void_p]),
     "i2c_rollout": (C.c_int, [C.POINTER(I2cProblem), C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8),
     "i2c_ckf_filter": (
         C.c_int,

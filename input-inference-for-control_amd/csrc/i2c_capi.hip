@@ -114,6 +114,17 @@ int i2c_riccati_sweep(const I2cProblem* p, const void* prior_out, const void* fw
   I2C_DISPATCH(p, riccati(p, prior_out, fwd, xm, post, ric, status, stream));
 }
 
+int i2c_mpc_step(const I2cProblem* p, const I2cMpcStep* m, void* stream) {
+  if (!m || !m->post || !m->post_next || !m->fwd || !m->term_stats || !m->cell_init || !m->feedforward_next || !m->status ||
+      m->n_iter < 0)
+    return I2C_EINVAL;
+  if (m->do_filter && (!m->y || !m->u)) return I2C_EINVAL;
+  if (p && ((p->alpha_cell != nullptr) != (m->alpha_cell_next != nullptr) || (p->alpha_cell && !m->alpha_init) ||
+            ((p->z != nullptr && p->z_per_cell) != (m->z_next != nullptr))))
+    return I2C_EINVAL;
+  I2C_DISPATCH(p, mpc_step(p, m, stream));
+}
+
 int i2c_ckf_filter(const I2cProblem* p, const double* sig_zeta, const void* y, const void* u, void* mu, void* cov,
                    int32_t* status, void* stream) {
   if (!sig_zeta || !y || !u || !mu || !cov || !status) return I2C_EINVAL;

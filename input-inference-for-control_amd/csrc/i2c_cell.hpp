@@ -1801,4 +1801,58 @@ I2C_HD inline void rollout_body(const Consts<M, R>& c, const RolloutArgs<R>& a, 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Receding-horizon shift of the MPC loop (PartiallyObservedMpcPolicy.__call__, i2c/policy/mpc.py:171-181):
+//   u = cells[0].mu_u0_m;  cells.pop(0);  cells.append(deepcopy(cell_init)) with the next target.
+// Out of place (cell t of the new buffers = cell t+1 of the old ones, last cell = a fresh one), one lane per (t, b); the
+// first action and its covariance are copied out on the way. The fresh cell keeps the temperature `alpha_init` it was
+// copied with (see I2cProblem.alpha_cell).
+// ------------------------------------------------------------------------------------------
+template <typename R> struct ShiftArgs {
+  const R* post;         // [T][E_POST][B]
+  R* post_next;          // [T][E_POST][B]
+  const R* cell_init;    // [E_POST][B]
+  const R* alpha_cell;   // [T][B] or null
+  R* alpha_cell_next;    // [T][B] or null
+  const R* alpha_init;   // [B] or null
+  const R* z;            // [T][NZ][B] or null
+  R* z_next;             // [T][NZ][B] or null
+  const R* z_new;        // [NZ][B] or null: target of the appended cell (null: the previous last cell's)
+  const uint8_t* ff;     // [T]
+  uint8_t* ff_next;      // [T]
+  R* action;             // [NU + sym(NU)][B]: cells[0].mu_u0_m, sig_u0_m (packed) BEFORE the shift
+};
+
+template <class M, typename R>
+I2C_HD inline void mpc_shift_body(const Consts<M, R>& c, const ShiftArgs<R>& a, const int t, const int b) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, D = C::D;
+  const long B = c.B;
+  const int T = c.T;
+  const bool last = t == T - 1;
+  const R* src = last ? a.cell_init + b : a.post + ((long)(t + 1) * C::E_POST) * B + b;
+  R* dst = a.post_next + ((long)t * C::E_POST) * B + b;
+#pragma unroll
+  for (int e = 0; e < C::E_POST; ++e) dst[(long)e * B] = src[(long)e * B];
+  if (a.alpha_cell_next) a.alpha_cell_next[(long)t * B + b] = last ? a.alpha_init[b] : a.alpha_cell[(long)(t + 1) * B + b];
+  if (a.z_next) {
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) {
+      const R v = !last ? a.z[((long)(t + 1) * NZ + k) * B + b]
+                        : (a.z_new ? a.z_new[(long)k * B + b] : a.z[((long)(T - 1) * NZ + k) * B + b]);
+      a.z_next[((long)t * NZ + k) * B + b] = v;
+    }
+  }
+  if (b == 0) a.ff_next[t] = last ? (uint8_t)1 : a.ff[t + 1];
+  if (t == 0 && a.action) {
+    const R* p0 = a.post + b;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) a.action[(long)i * B + b] = p0[(long)(NX + i) * B];
+#pragma unroll
+    for (int p = 0; p < NU; ++p)
+#pragma unroll
+      for (int q = 0; q <= p; ++q) a.action[(long)(NU + tri(p, q)) * B + b] = p0[(long)(D + tri(NX + p, NX + q)) * B];
+  }
+}
+
 }  // namespace i2c

@@ -23,6 +23,7 @@ struct ModelOps {
                    void* stream);
   int (*riccati)(const I2cProblem*, const void* prior_out, const void* fwd, const void* xm, void* post, void* ric,
                  int32_t* status, void* stream);
+  int (*mpc_step)(const I2cProblem*, const I2cMpcStep*, void* stream);
   void (*dims)(I2cDims*);
   size_t (*workspace_elems)(int B, int T);
   int (*schedule)(int B, int T, int requested);

@@ -131,6 +131,11 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void k_ckf(const Consts<M, R> c, const
   if (b < c.B) ckf_filter_body<M, R>(c, z.v, a, b);
 }
 template <class M, typename R>
+__global__ __launch_bounds__(CELL_BLOCK) void k_mpc_shift(const Consts<M, R> c, const ShiftArgs<R> a) {
+  const int b = blockIdx.x * CELL_BLOCK + threadIdx.x;
+  if (b < c.B) mpc_shift_body<M, R>(c, a, blockIdx.y, b);
+}
+template <class M, typename R>
 __global__ __launch_bounds__(SWEEP_BLOCK) void k_rollout(const Consts<M, R> c, const RolloutArgs<R> a) {
   const long n = (long)blockIdx.x * SWEEP_BLOCK + threadIdx.x;
   if (n < (long)a.n_rollouts * c.B) rollout_body<M, R>(c, a, (int)n);
@@ -497,6 +502,39 @@ template <class M, typename R> struct Impl {
 #endif
   }
 
+  // One control step of the MPC loop enqueued by one call (i2c/policy/mpc.py:156-182): filter, n_iter x (forward,
+  // backward, _update_priors), first action, horizon shift into the second set of buffers.
+  static int mpc_step(const I2cProblem* p, const I2cMpcStep* m, void* stream) {
+    int rc = I2C_OK;
+    if (m->do_filter) rc = ckf(p, m->sig_zeta, m->y, m->u, const_cast<void*>(p->x0), const_cast<void*>(p->sig_x0), m->status, stream);
+    for (int it = 0; it < m->n_iter && rc == I2C_OK; ++it) {
+      rc = forward(p, m->post, m->fwd, nullptr, m->status, stream);
+      if (rc == I2C_OK) rc = backward(p, m->fwd, m->xm, m->post, m->zpost, m->cell_stats, m->term_stats, m->status, stream);
+      if (rc == I2C_OK && m->tau > 0) {  // _update_priors: cells with index <= tau switch to feedback mode
+        const size_t n = (size_t)(m->tau + 1 < p->T ? m->tau + 1 : p->T);
+#ifdef I2C_HOST_SIM
+        std::memset(const_cast<uint8_t*>(p->feedforward), 0, n);
+#else
+        if (hipMemsetAsync(const_cast<uint8_t*>(p->feedforward), 0, n, (hipStream_t)stream) != hipSuccess) rc = I2C_ELAUNCH;
+#endif
+      }
+    }
+    if (rc != I2C_OK) return rc;
+    const C c = make_consts<M, R>(p, 0.0, 0);
+    ShiftArgs<R> a{(const R*)m->post,       (R*)m->post_next, (const R*)m->cell_init, (const R*)p->alpha_cell, (R*)m->alpha_cell_next,
+                   (const R*)m->alpha_init, (const R*)p->z,   (R*)m->z_next,          (const R*)m->z_new,      p->feedforward,
+                   m->feedforward_next,     (R*)m->action};
+#ifdef I2C_HOST_SIM
+    for (int t = 0; t < p->T; ++t)
+      for (int b = 0; b < p->B; ++b) mpc_shift_body<M, R>(c, a, t, b);
+    return I2C_OK;
+#else
+    const dim3 grid((p->B + CELL_BLOCK - 1) / CELL_BLOCK, p->T);
+    hipLaunchKernelGGL((k_mpc_shift<M, R>), grid, dim3(CELL_BLOCK), 0, (hipStream_t)stream, c, a);
+    return launch_status();
+#endif
+  }
+
   static int rollout(const I2cProblem* p, const void* post, int n_rollouts, int policy, const void* eps_x0,
                      const void* eps_x, const void* eps_u, void* xu, void* z, void* x_final, void* z_term,
                      void* stream) {
@@ -559,8 +597,8 @@ template <class M> static void fill_dims(I2cDims* d) {
 template <class M, typename R> const ModelOps* make_ops() {
   using I = Impl<M, R>;
   static const ModelOps ops = {&I::forward, &I::backward,  &I::mstep,        &I::learn,           &I::ckf,
-                               &I::rollout, &I::propagate, &I::riccati,   &fill_dims<M>,       &workspace_elems<M>,
-                               &I::schedule};
+                               &I::rollout, &I::propagate, &I::riccati,   &I::mpc_step,        &fill_dims<M>,
+                               &workspace_elems<M>, &I::schedule};
   return &ops;
 }
 

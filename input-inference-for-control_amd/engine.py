@@ -443,6 +443,7 @@ class BatchedI2c:
         if self.alpha_cell is None:
             self.alpha_init = self.alpha.clone()
             self.alpha_cell = self.alpha.reshape(1, -1).repeat(self.H, 1).contiguous()
+            self._mpc_next = None
             self.refresh_problem()
 
     def _broadcast_alpha(self):
@@ -468,12 +469,62 @@ class BatchedI2c:
             self.z.copy_(torch.roll(self.z, -1, 0))
             self.z[-1] = self.z[-2] if z_new is None else z_new
 
+    def mpc_step(self, n_iter, y=None, u=None, sig_zeta=None, z_new=None):
+        """One control step of the MPC loop in one library call (i2c_mpc_step): optional filter step on the belief, n_iter
+        sweeps, first action, receding-horizon shift -- no host round trip, no torch ops. Returns (mu_u (B, nu),
+        sig_u packed (B, sym nu)) device tensors: the first planned action BEFORE the shift (cells[0].mu_u0_m, sig_u0_m).
+        Same numbers as ckf_filter + n_iter x (forward_backward, update_priors) + shift_horizon."""
+        st = _native.I2cMpcStep()
+        st.do_filter = int(y is not None)
+        st.n_iter, st.tau = int(n_iter), int(self.tau)
+        if y is not None:
+            ny = self.dims.ny
+            assert y.shape == (ny, self.B) and u.shape == (self.nu, self.B) and y.dtype == self.dtype
+            for i, v in enumerate(pack_sym_np(np.asarray(sig_zeta, np.float64)).reshape(-1)):
+                st.sig_zeta[i] = float(v)
+            y, u = y.contiguous(), u.contiguous()
+            st.y, st.u = y.data_ptr(), u.data_ptr()
+        if getattr(self, "_mpc_next", None) is None:  # the second set of buffers of the out-of-place shift
+            self._mpc_next = {"post": torch.empty_like(self.post), "feedforward": torch.empty_like(self.feedforward),
+                              "alpha_cell": None if self.alpha_cell is None else torch.empty_like(self.alpha_cell),
+                              "z": None if self.z is None else torch.empty_like(self.z)}
+            self._mpc_action = torch.empty(self.nu + sym_size(self.nu), self.B, dtype=self.dtype, device=self.device)
+        nxt = self._mpc_next
+        st.post, st.post_next, st.fwd = self.post.data_ptr(), nxt["post"].data_ptr(), self.fwd.data_ptr()
+        opt = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        st.xm, st.zpost, st.cell_stats, st.term_stats = opt(self.xm), opt(self.zpost), opt(self.cell_stats), self.term_stats.data_ptr()
+        st.cell_init = self.cell_init.data_ptr()
+        st.alpha_init, st.alpha_cell_next = opt(self.alpha_init), opt(nxt["alpha_cell"])
+        if z_new is not None:
+            z_new = z_new.contiguous()
+        st.z_new, st.z_next = opt(z_new), opt(nxt["z"])
+        st.feedforward_next, st.action, st.status = nxt["feedforward"].data_ptr(), self._mpc_action.data_ptr(), self.status.data_ptr()
+        self._problem.expert_controller = int(bool(self.use_expert_controller))
+        rc = self.lib.i2c_mpc_step(C.byref(self._problem), C.byref(st), self._stream())
+        self._check(rc, "i2c_mpc_step")
+        # the shifted horizon becomes the current one
+        self.post, nxt["post"] = nxt["post"], self.post
+        self.feedforward, nxt["feedforward"] = nxt["feedforward"], self.feedforward
+        if self.alpha_cell is not None:
+            self.alpha_cell, nxt["alpha_cell"] = nxt["alpha_cell"], self.alpha_cell
+        if self.z is not None:
+            self.z, nxt["z"] = nxt["z"], self.z
+        if self.terminal_cell >= 0:
+            self.terminal_cell -= 1
+        p = self._problem
+        p.terminal_cell = int(self.terminal_cell)
+        p.feedforward = self.feedforward.data_ptr()
+        p.alpha_cell = opt(self.alpha_cell)
+        p.z = opt(self.z)
+        return self._mpc_action[: self.nu].T, self._mpc_action[self.nu:].T
+
     def set_targets(self, z_traj):
         """Per-cell targets (mpc.py:29-31): z_traj (T, nz) or (B, T, nz)."""
         z = np.broadcast_to(np.asarray(z_traj, np.float64), (self.B, self.H, self.nz))
         zt = torch.as_tensor(np.array(np.transpose(z, (1, 2, 0)), order="C"), dtype=self.dtype, device=self.device)
         if self.z is None:
             self.z = zt
+            self._mpc_next = None
             self.refresh_problem()
         else:
             self.z.copy_(zt)

@@ -112,7 +112,23 @@ class MpcPolicy:
             self.i2c._x0_seen = None
         self._plan(n_iter)
 
+    def _sample_or_mean(self, mu_u, sig_u_packed, deterministic):
+        mu_u = _np(mu_u)
+        if not deterministic:
+            from .. import core
+
+            sig_u = _np(core.engine.unpack_sym(sig_u_packed, self.dim_u))
+            mu_u = np.stack([np.random.multivariate_normal(m, s) for m, s in zip(mu_u, sig_u)])
+        return mu_u
+
     def __call__(self, i, x, deterministic=True):
+        if not self.record_history:  # batched closed loops: the whole control step is one library call
+            x = np.asarray(x, dtype=float)
+            e = self.engine
+            e.set_initial_state(x.reshape(-1, self.dim_x), _np(unpack(e)))
+            mu_u, sig_u = e.mpc_step(self.n_iter, z_new=self._next_target(i))
+            self.i2c._invalidate()
+            return self._squeeze(self._sample_or_mean(mu_u, sig_u, deterministic), column=True)
         self.optimize(self.n_iter, x)
         self._record()
         u = self._first_action(deterministic)
@@ -179,6 +195,18 @@ class PartiallyObservedMpcPolicy(MpcPolicy):
         self._plan(n_iter)
 
     def __call__(self, i, y, u, deterministic=True):
+        if not self.record_history:  # batched closed loops: filter + plan + first action + shift in one library call
+            e = self.engine
+            if i > 0:
+                sig_zeta = self.i2c.sys.sig_zeta
+                if sig_zeta is None:
+                    raise ValueError("sys.sig_zeta (measurement noise) must be set before filtering")
+                mu_u, sig_u = e.mpc_step(self.n_iter, self._dev(y, e.dims.ny), self._dev(u, e.nu), sig_zeta,
+                                         z_new=self._next_target(i))
+            else:
+                mu_u, sig_u = e.mpc_step(self.n_iter, z_new=self._next_target(i))
+            self.i2c._invalidate()
+            return self._squeeze(self._sample_or_mean(mu_u, sig_u, deterministic), column=True)
         if i > 0:
             self.filter(y, u)
         if self.record_history:
