@@ -165,3 +165,52 @@ def test_quadrature_inference_mirror_matches_reference_vectors():
         assert_close(m_y[:, 0], q[pre + "dyn_m"], 1e-13)
         assert_close(S_y, q[pre + "dyn_S"], 1e-11)
         assert_close(S_n, q[pre + "dyn_noise"], 1e-15)
+
+
+def _native_step_equals_stepwise(name, lib, device):
+    """i2c_mpc_step (one library call per control step) against the same step made of separate calls (filter, sweeps,
+    _update_priors, read-out, shift_horizon), which the replays above pin to the reference: bit-identical buffers."""
+    g = load_case(name)
+    meta = g.meta
+    B = 3
+    engines = []
+    for _ in range(2):
+        _, i2c, pol = _policy(g, lib, device, batch=B)
+        i2c.calibrate_alpha()
+        pol.optimize(meta["warm"], g["x0"] if "x0" in g else i2c.sys.x0, g["sig_x0"] if "sig_x0" in g else i2c.sys.sig_x0)
+        i2c.calibrate_alpha()
+        engines.append((i2c.engine, pol))
+    (ea, pa), (eb, pb) = engines
+    nz = ea.nz
+    for t in range(5):
+        y = np.tile(g["y"][t].reshape(1, -1), (B, 1))
+        u = np.tile(g["u_prev"][t].reshape(1, -1), (B, 1))
+        yd, ud = pa._dev(y, ea.dims.ny), pa._dev(u, ea.nu)
+        z_new = pa._next_target(t)
+        # (a) separate calls
+        if t > 0:
+            ea.ckf_filter(yd, ud, pa.i2c.sys.sig_zeta)
+        for _ in range(meta["n_iter"]):
+            ea.forward_backward()
+            ea.update_priors()
+        mu_a = ea.post[0, ea.nx: ea.d, :].T.clone()
+        ea.shift_horizon(z_new)
+        # (b) one call
+        mu_b, _ = eb.mpc_step(meta["n_iter"], yd if t > 0 else None, ud if t > 0 else None, pb.i2c.sys.sig_zeta, z_new=z_new)
+        assert torch.equal(mu_a, mu_b), f"{name} step {t}: first action"
+        for key in ("post", "x0", "sig_x0", "feedforward", "alpha_cell", "z"):
+            ta, tb = getattr(ea, key), getattr(eb, key)
+            if ta is not None:
+                assert torch.equal(ta, tb), f"{name} step {t}: {key}"
+        assert ea.terminal_cell == eb.terminal_cell and nz == eb.nz
+
+
+@pytest.mark.parametrize("name", ["mpc_pendulum_fb", "mpc_quadrotor_fb"])
+def test_native_mpc_step_cpu(name):
+    _native_step_equals_stepwise(name, hostsim.load(), "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mpc_pendulum_fb", "mpc_quadrotor_fb"])
+def test_native_mpc_step_gpu(name):
+    _native_step_equals_stepwise(name, None, "cuda")
