@@ -244,7 +244,8 @@ def main():
                             + str(fwd_bytes),
             "algorithmic_bytes_per_cell": {k: v * wbytes for k, v in el.items()},
             "whole_iteration_GBps": el["total"] * wbytes * B * T / (elapsed / K) / 1e9,
-            "note": "latency-bound at B=4096: 64 wavefronts walk 2*T dependent cells; see DESIGN.md",
+            "note": "instruction-issue-bound at B=4096 per GPU: 64 lone wavefronts (1024 SIMDs), each issuing ~88 % of its cycles "
+                    "(profiles/r1_k_forward_sq_counters.json); HBM-bound from B ~ 32768 (saturated_batch); see DESIGN.md section 6",
         },
         "final_allgather_ms": allgather_ms,
     }
