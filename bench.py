@@ -79,12 +79,26 @@ def saturated_leg(pkg, T, dtype, device, el, wbytes, B=131072, K=6):
         eng.learn_msgs()
     elapsed, ms = timed_iterations(eng, K, lambda: torch.cuda.synchronize(device))
     cells = B * T
+    schedule = eng.backward_schedule
+    del eng
+    # for scale: the streaming-copy rate of this device (read + write of a 1 GiB fp64 tensor), measured live
+    x = torch.empty(1024 ** 3 // 8, dtype=torch.float64, device=device).normal_()
+    y = torch.empty_like(x)
+    y.copy_(x)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(10):
+        y.copy_(x)
+    ev1.record()
+    torch.cuda.synchronize(device)
+    copy_gbps = 2 * x.numel() * 8 / (ev0.elapsed_time(ev1) / 10 * 1e-3) / 1e9
     return {
         "batch": B,
+        "device_memcpy_GBps": copy_gbps,
         "value": cells * K / elapsed,
         "unit": "timestep-messages/s",
         "ms_per_step": elapsed / K * 1e3,
-        "backward": eng.backward_schedule,
+        "backward": schedule,
         "kernel_ms": {"forward_sweep": ms[0], "backward_sweep": ms[1], "mstep": ms[2]},
         "forward_GBps": el["forward"] * wbytes * cells / (ms[0] * 1e-3) / 1e9,
         "backward_GBps": el["backward"] * wbytes * cells / (ms[1] * 1e-3) / 1e9,
