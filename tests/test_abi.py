@@ -76,3 +76,17 @@ def test_backward_schedule_rule():
     for m in (N.BWD_TWO_PASS, N.BWD_FUSED, N.BWD_CHUNKED):
         assert f(3, 100000, 300, m) == m
     assert f(99, 4096, 200, N.BWD_AUTO) == 0 and f(0, 4096, 200, 7) == 0 and f(0, 0, 200, 0) == 0
+
+
+def test_bad_arguments_of_the_newer_entry_points():
+    lib = pkg.load_library()
+    N = pkg._native
+    p = N.I2cProblem()
+    p.abi_version = N.ABI_VERSION
+    assert lib.i2c_mpc_step(ctypes.byref(p), None, None) == -1            # no step descriptor
+    st = N.I2cMpcStep()
+    assert lib.i2c_mpc_step(ctypes.byref(p), ctypes.byref(st), None) == -1  # null buffers
+    assert lib.i2c_riccati_sweep(ctypes.byref(p), None, None, None, None, None, None, None) == -1
+    assert lib.i2c_problem_size() == ctypes.sizeof(N.I2cProblem)
+    p.inference = 7
+    assert lib.i2c_forward_sweep(ctypes.byref(p), None, None, None, None, None) == -1
