@@ -470,7 +470,7 @@ template <class M, typename R> struct Impl {
         rc = mstep(p, term_stats, tol, 1, (R*)stats_hist + (size_t)it * 4 * p->B, stream);
         if (rc != I2C_OK) return rc;
       }
-      if (tau > 0) {  // _update_priors: cells with index <= tau switch to feedback mode
+      if (tau > 0 && it == 0) {  // _update_priors: cells with index <= tau switch to feedback mode (idempotent: once per call)
         const size_t n = (size_t)(tau + 1 < p->T ? tau + 1 : p->T);
 #ifdef I2C_HOST_SIM
         std::memset(const_cast<uint8_t*>(p->feedforward), 0, n);
