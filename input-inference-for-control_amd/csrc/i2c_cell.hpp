@@ -514,15 +514,15 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
 #pragma unroll
   for (int k = 0; k < NZ; ++k) zt[k] = (!LEAN && c.z_per_cell) ? a.z[(long)k * B + b] : c.zg[k];
 
+  // The feed-forward flag of a cell is a byte in global memory: loaded at the top of its own cell it is a dependent
+  // vector load whose full latency (plus, vmcnt being shared, the acknowledgement of the previous cell's last stores)
+  // is exposed EVERY cell. It is therefore fetched one cell ahead, together with the prior rows.
+  unsigned ff_cur = a.ff[0];
   // Small models never factor the prior joint: its Cholesky factor is assembled from the factor Lx of the incoming
   // sig_x0_f (= chol(sig_x3_f) of the previous cell, already needed for the smoother gain) as
   //   L0 = [[Lx, 0], [K~ Lx, chol(sig_u|x)]],  sig_u|x = sig_u0_m - K~ sig_ux^T   (feed-forward: K~ = 0, sig_u|x = sig_u0_f),
   // which takes one nu x nu factorisation instead of a d x d one off the critical path. (For d >= 6 the carried
   // factor would cost nx(nx+1)/2 more live registers across the whole cell.)
-  // The feed-forward flag of a cell is a byte in global memory: loaded at the top of its own cell it is a dependent
-  // vector load whose full latency (plus, vmcnt being shared, the acknowledgement of the previous cell's last stores)
-  // is exposed EVERY cell. It is therefore fetched one cell ahead, together with the prior rows.
-  unsigned ff_cur = a.ff[0];
   constexpr bool STRUCT_L0 = C::D <= 5;
   R Lx[STRUCT_L0 ? sym(NX) : 1];
   if (STRUCT_L0) {
@@ -549,7 +549,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
   // sweep, and the scalar file then spills (v_readlane) and re-materialises polynomial literals (s_mov) in every cell.
   // Only where the register file has room: the cartpole (21 + 10 doubles) already overflows into AGPRs and slows down.
   constexpr bool CONST_V = VOFF && (sym(NZ) + sym(NX) <= 16);
-  PolyTab<R> ptab;  // sincos / exp coefficients as VGPR values (see PolyTab), same condition
+  PolyTab<R> ptab;  // sincos coefficients as VGPR values (see PolyTab), same condition
   if (CONST_V) poly_tab_init(ptab);
   const PolyTab<R>* const tab = CONST_V ? &ptab : nullptr;
   R xi0_v[CONST_V ? sym(NZ) : 1], eta_v[CONST_V ? sym(NX) : 1];

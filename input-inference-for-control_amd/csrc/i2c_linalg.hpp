@@ -114,11 +114,11 @@ I2C_FN void r_sincos(double x, double* s, double* c) {
 // ---- polynomial constants held in VGPRs ---------------------------------------------------------------------------
 // A VALU instruction reads at most one scalar / literal operand, so a Horner step with a literal coefficient costs the
 // lone, issue-bound wave an extra instruction (s_mov pair or v_mov copy) per step. PolyTab keeps the coefficients of
-// sincos and exp as opaque per-lane VALUES that the register allocator leaves in VGPRs for the whole sweep (30 + 30
-// registers; only worth it where the VGPR file has room, i.e. the small models' forward sweep).
+// sincos as opaque per-lane VALUES that the register allocator leaves in VGPRs for the whole sweep (32 registers; only
+// worth it where the VGPR file has room, i.e. the small models' forward sweep). Doing the same for exp (15 more
+// coefficients) pushed the kernel past 256 VGPRs into scratch (610 us) and was dropped.
 template <typename R> struct PolyTab {
   R two_over_pi, pio2_1, pio2_2, pio2_3, s1, s2, s3, s4, s5, s6, c1, c2, c3, c4, c5, c6;
-  R log2e, ln2_hi, ln2_lo, e[12];
 };
 template <typename R> I2C_FN R tab_value(double v) {
   R x = (R)v;
@@ -171,25 +171,6 @@ I2C_FN void r_sincos(double x, const PolyTab<double>& t, double* s, double* c) {
   *c = ((q + 1) & 2) ? -cc : cc;
 }
 I2C_FN void r_sincos(float x, const PolyTab<float>&, float* s, float* c) { r_sincos(x, s, c); }
-// exp(x) for x <= 0 (the pdf ratio exp(-maha / 2)): Cody-Waite reduction by ln 2, degree-13 Taylor kernel on
-// [-ln2/2, ln2/2] (truncation 4e-18), scaling by v_ldexp; NaN propagates, x < -750 gives 0.
-I2C_FN double r_exp_neg(double x, const PolyTab<double>& t) {
-  x = x < -750.0 ? -750.0 : x;
-  const double k = m_rint(x * t.log2e);
-  double r = m_fma(-k, t.ln2_hi, x);
-  r = m_fma(-k, t.ln2_lo, r);
-  double p = p_fma(r, t.e[11], t.e[10]);
-#pragma unroll
-  for (int n = 9; n >= 0; --n) p = p_fma(p, r, t.e[n]);
-  p = m_fma(p, r, 1.0);  // 1 + r (...)
-  p = m_fma(p, r, 1.0);  // 1 + r + r^2 (...)
-#ifdef I2C_HOST_SIM
-  return std::ldexp(p, (int)k);
-#else
-  return __builtin_amdgcn_ldexp(p, (int)k);
-#endif
-}
-I2C_FN float r_exp_neg(float x, const PolyTab<float>&) { return r_exp(x); }
 
 // the sigma-point offsets d = sf L[i][j] go through the same branch-free routine
 I2C_FN void r_sincos_small(double x, double* s, double* c) { r_sincos(x, s, c); }
