@@ -733,6 +733,13 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     // pre-loop loads (above; the waitcnt pass joins the loop-entry state with the back-edge state), leaves the loop
     // top without any s_waitcnt: 372 -> 357 us. (Measured alternative: touching after the tail stores, 363 us.)
     ff_cur = opaque(ff_cur);
+    if (!LEAN) {  // the per-cell temperature and targets of the MPC loop were fetched ahead as well
+      alpha_cur = opaque(alpha_cur);
+      if (PREFETCH) {
+#pragma unroll
+        for (int k = 0; k < NZ; ++k) zt[k] = opaque(zt[k]);
+      }
+    }
     if (PREFETCH) {
 #pragma unroll
       for (int e = 0; e < C::E_PRI; ++e) pri[e] = opaque(pri[e]);
