@@ -33,11 +33,11 @@
 extern "C" {
 #endif
 
-#define I2C_ABI_VERSION 2
+#define I2C_ABI_VERSION 3
 
-#define I2C_MAX_NX 8
+#define I2C_MAX_NX 12
 #define I2C_MAX_NU 4
-#define I2C_MAX_NZ 12
+#define I2C_MAX_NZ 16
 #define I2C_MAX_PARAMS 16
 #define I2C_MAX_GH_DEGREE 8
 #define I2C_SYM(n) ((n) * ((n) + 1) / 2)
@@ -51,7 +51,8 @@ enum {
   I2C_MODEL_LINEAR = 4,           /* LinearKnown           env_def.py:139-191, model.py:226-246       */
   I2C_MODEL_LINEAR_MINENERGY = 5, /* LinearKnownMinimumEnergy env_def.py:194-230                      */
   I2C_MODEL_QUADROTOR = 6,        /* build-defined planar quadrotor (Box2D physics is not reproducible) */
-  I2C_NUM_MODELS = 7
+  I2C_MODEL_QUADROTOR12 = 7,      /* build-defined 12-state / 4-rotor quadrotor (BASELINE config 4: nx = 12); group kernels only */
+  I2C_NUM_MODELS = 8
 };
 
 enum { I2C_F64 = 0, I2C_F32 = 1 };
@@ -105,6 +106,9 @@ typedef struct I2cDims {
   int32_t e_prop;          /* elements per cell of the propagation buffer (see I2cProp)     */
   int32_t n_params;        /* number of doubles the model reads from I2cProblem.model_params */
   int32_t ny;              /* dim_y of sys.measure (state estimator of the MPC loop)         */
+  int32_t group_lanes;     /* G of the model's group kernels (G lanes of a wavefront per trajectory, blocks row-distributed
+                              over the lanes and exchanged through LDS); 0: none compiled                                  */
+  int32_t group_only;      /* 1: only the group kernels exist for this model (nx + nu > 8 does not fit one lane)           */
 } I2cDims;
 
 /*
@@ -127,7 +131,10 @@ typedef struct I2cProblem {
   int32_t expert_controller; /* Linearize forward pass only: scale the feedback gain by the pdf ratio (use_expert_controller,
                               i2c.py:143,259-265); the cubature forward pass always scales it (i2c.py:366-375)      */
   int32_t gh_degree;       /* I2C_INF_GAUSS_HERMITE: 1 <= degree <= I2C_MAX_GH_DEGREE                               */
-  int32_t reserved0;
+  int32_t group_lanes;     /* 0: the model's default kernels (one lane per trajectory; the group kernels for a group_only
+                              model); I2cDims.group_lanes: run forward / backward / propagate / filter with that many lanes of
+                              a wavefront per trajectory (fp64, cubature rule, diagonal cost weights, no terminal state prior;
+                              the backward sweep then has one schedule, the fused walk); anything else: I2C_ENOTSUP            */
   /* CubatureQuadrature(alpha, beta, kappa): i2c/exp_types.py:31-49 */
   double quad_alpha, quad_beta, quad_kappa;
   double dtemp;            /* terminal-prior annealing rate (i2c.py:66,552)                    */

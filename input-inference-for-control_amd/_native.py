@@ -9,8 +9,8 @@ without a GPU; nothing in the package ever looks for it.)
 import ctypes as C
 import os
 
-ABI_VERSION = 2
-MAX_NX, MAX_NU, MAX_NZ, MAX_PARAMS = 8, 4, 12, 16
+ABI_VERSION = 3
+MAX_NX, MAX_NU, MAX_NZ, MAX_PARAMS = 12, 4, 16, 16
 MAX_GH_DEGREE = 8
 
 
@@ -30,6 +30,7 @@ MODEL_IDS = {
     "LinearKnown": 4,
     "LinearKnownMinimumEnergy": 5,
     "PlanarQuadrotor": 6,
+    "Quadrotor12": 7,
 }
 
 FAIL_REASONS = {
@@ -47,7 +48,8 @@ FAIL_REASONS = {
 
 
 class I2cDims(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("nx", "nu", "nz", "nzt", "e_post", "e_fwd", "e_xm", "e_zpost", "e_prop", "n_params", "ny")]
+    _fields_ = [(n, C.c_int32) for n in ("nx", "nu", "nz", "nzt", "e_post", "e_fwd", "e_xm", "e_zpost", "e_prop", "n_params", "ny",
+                                          "group_lanes", "group_only")]
 
 
 class I2cProblem(C.Structure):
@@ -65,7 +67,7 @@ class I2cProblem(C.Structure):
         ("inference", C.c_int32),
         ("expert_controller", C.c_int32),
         ("gh_degree", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("group_lanes", C.c_int32),
         ("quad_alpha", C.c_double),
         ("quad_beta", C.c_double),
         ("quad_kappa", C.c_double),

@@ -22,7 +22,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"] + os.environ.get("I2C_HIPCC_EXTRA", "").split()
 
 # (struct in csrc/i2c_models.hpp, name used in csrc/i2c_entry.hpp); heaviest first so the pool stays busy
-MODELS = [("DoubleCartpole", "double_cartpole"), ("Quadrotor", "quadrotor"), ("Cartpole", "cartpole"),
+MODELS = [("Quadrotor12", "quadrotor12"), ("DoubleCartpole", "double_cartpole"), ("Quadrotor", "quadrotor"), ("Cartpole", "cartpole"),
           ("Pendulum", "pendulum"), ("PendulumActReg", "pendulum_actreg"), ("Linear", "linear"),
           ("LinearMinEnergy", "linear_minenergy")]
 DTYPES = [("double", "f64"), ("float", "f32")]

@@ -37,7 +37,8 @@ struct ModelOps {
   X(I2C_MODEL_DOUBLE_CARTPOLE, DoubleCartpole, double_cartpole)                                             \
   X(I2C_MODEL_LINEAR, Linear, linear)                                                                       \
   X(I2C_MODEL_LINEAR_MINENERGY, LinearMinEnergy, linear_minenergy)                                          \
-  X(I2C_MODEL_QUADROTOR, Quadrotor, quadrotor)
+  X(I2C_MODEL_QUADROTOR, Quadrotor, quadrotor)                                                              \
+  X(I2C_MODEL_QUADROTOR12, Quadrotor12, quadrotor12)
 #define I2C_DECLARE_OPS(ID, MODEL, name) \
   const ModelOps* ops_##name##_f64();    \
   const ModelOps* ops_##name##_f32();

@@ -1,0 +1,1003 @@
+// Multi-lane ("group") form of the cubature cells: G lanes of one wavefront cooperate on ONE trajectory.
+//
+// The one-lane-per-trajectory cells of i2c_cell.hpp keep every block of a trajectory in the registers of a single lane.
+// That stops scaling at d = nx + nu = 8 (a 16 x 16 joint covariance alone is 272 VGPRs) and it leaves a small batch on a
+// few wavefronts, each issuing the whole cell. Here the blocks are ROW-DISTRIBUTED over the G lanes of a group:
+//   * lane r owns row r of every matrix of the cell (joint covariance, Cholesky factor, cross-covariances, gains) in
+//     registers, as a FULL row (symmetric matrices are not packed inside the kernel; they are packed again in HBM);
+//   * vectors (means, targets, innovations) are REPLICATED in every lane of the group;
+//   * lane j evaluates the model at the sigma-point pair m +/- sf L[:, j]  (the 2d + 1 points of quadrature.py:15-25
+//     are spread over the lanes instead of being walked by one lane);
+//   * everything that has to cross lanes (a Cholesky column, the rows of a gain, the sigma-point differences) goes
+//     through the group's private LDS region. A group lives inside one wavefront, so LDS traffic is ordered by the
+//     hardware (a wave's DS instructions execute in issue order): no s_barrier, only a compiler fence.
+// The math is the reference's I2cCell (i2c/i2c.py:350-447, 544-610, 150-199) and QuadratureInference
+// (i2c/inference/quadrature.py:15-58), in the centred pairwise form of i2c_cell.hpp::sp_transform.
+//
+// The host simulation (tests only) runs the G lanes of a group as G threads with a barrier where the device has the
+// fence, so the SAME code is checked on a CPU-only box, including its synchronisation.
+#pragma once
+#include "i2c_cell.hpp"
+
+#ifdef I2C_HOST_SIM
+#include <sched.h>
+#include <atomic>
+#include <thread>
+#include <vector>
+#endif
+
+#define I2C_MEM I2C_HD inline __attribute__((always_inline))
+
+namespace i2c {
+
+#ifdef I2C_HOST_SIM
+struct HostBarrier {  // sense-reversing spin barrier for the G lane-threads of one group
+  explicit HostBarrier(int n_) : n(n_) {}
+  void wait() {
+    const int g = gen.load(std::memory_order_acquire);
+    if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+      count.store(0, std::memory_order_relaxed);
+      gen.store(g + 1, std::memory_order_release);
+    } else {
+      while (gen.load(std::memory_order_acquire) == g) sched_yield();
+    }
+  }
+  std::atomic<int> count{0}, gen{0};
+  int n;
+};
+template <typename R> using lds_ptr = R*;
+#else
+template <typename R> using lds_ptr = __attribute__((address_space(3))) R*;
+#endif
+
+// One lane's view of its group: rank, the group's LDS region (three G x (G+2) matrices + four G-vectors).
+// Rows are padded to G + 2 elements: lanes writing "their" row then hit different bank pairs (a row step of 2G + 4 dwords
+// visits G distinct even residues modulo 64 for G = 4, 8, 16) and every row stays 16-byte aligned.
+template <typename R, int G> struct Grp {
+  static constexpr int LD = G + 2, MAT = G * LD, NVEC = 4;
+  // region size = 2 (mod 32) elements: the regions of the groups of a wave start 4 banks apart, so the broadcast reads
+  // (all lanes of a group at one address) of different groups never share a bank
+  static constexpr int RAW = 3 * MAT + NVEC * G;
+  static constexpr int SIZE = RAW + ((34 - RAW % 32) % 32);
+  int r;
+  lds_ptr<R> sh;
+#ifdef I2C_HOST_SIM
+  HostBarrier* bar;
+#endif
+  I2C_MEM lds_ptr<R> mat(int i) const { return sh + i * MAT; }
+  I2C_MEM lds_ptr<R> vec(int i) const { return sh + 3 * MAT + i * G; }
+  // Orders the group's LDS writes before its later LDS reads (and earlier reads before later writes).
+  I2C_MEM void sync() const {
+#ifdef I2C_HOST_SIM
+    bar->wait();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
+  }
+};
+
+// Batch-wide constants a lane needs by ROW (runtime row index): unpacked, in LDS, filled once per workgroup.
+template <class M, typename R> struct GConst {
+  static constexpr int NX = M::NX, NZ = M::NZ, NT = M::NZT > 0 ? M::NZT : 1, NY = M::NY;
+  R sig_xi0[NZ * NZ], sig_eta[NX * NX], sig_xiT0[NT * NT], sig_zeta[NY * NY];
+  R qr_d[NZ], qf_d[NT];
+};
+// `c` and `zeta` must be addressable memory (the host's structs; on the device the kernel-argument segment itself, see
+// k_group): indexing a by-value kernel argument with a per-lane value would make hipcc copy its arrays to scratch.
+template <class M, typename R, class DST>
+I2C_FN void gconst_fill(DST& k, const Consts<M, R>* c, const R* zeta, const int tid, const int nthreads) {
+  constexpr int NX = M::NX, NZ = M::NZ, NT = M::NZT > 0 ? M::NZT : 1, NY = M::NY;
+  for (int e = tid; e < NZ * NZ; e += nthreads) k.sig_xi0[e] = c->sig_xi0[tri_any(e / NZ, e % NZ)];
+  for (int e = tid; e < NX * NX; e += nthreads) k.sig_eta[e] = c->sig_eta[tri_any(e / NX, e % NX)];
+  for (int e = tid; e < NT * NT; e += nthreads) k.sig_xiT0[e] = c->sig_xiT0[tri_any(e / NT, e % NT)];
+  for (int e = tid; e < NY * NY; e += nthreads) k.sig_zeta[e] = zeta ? zeta[tri_any(e / NY, e % NY)] : R(0);
+  for (int e = tid; e < NZ; e += nthreads) k.qr_d[e] = c->QR[tri(e, e)];
+  for (int e = tid; e < NT; e += nthreads) k.qf_d[e] = c->Qf[tri(e, e)];
+}
+
+// A per-lane integer the optimiser cannot see through. Without it hipcc recognises `j <= r` guards of an unrolled loop as
+// a loop bound (trip count r + 1, array indexed at run time) and select chains on `r == i` as a table look-up: both turn
+// a register array into a scratch array.
+I2C_FN int opaque_i(int x) {
+#ifndef I2C_HOST_SIM
+  asm volatile("" : "+v"(x));
+#endif
+  return x;
+}
+// element r of a replicated vector (r is a per-lane value: a select chain, not an indexed register file)
+template <int N, typename R> I2C_FN R g_sel(const R* v, const int r) {
+  R x = v[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) x = (opaque_i(r) == i) ? v[i] : x;
+  return x;
+}
+// packed index of (r, j) of a symmetric matrix, r a per-lane value with tr = r (r + 1) / 2
+I2C_FN int symidx(const int r, const int tr, const int j) { return j <= r ? tr + j : tri(j, j) - j + r; }
+
+// every lane contributes one value (its rank's), every lane receives all N
+template <int N, typename R, int G> I2C_FN void g_gather(const Grp<R, G>& g, const int slot, const R v, R* out) {
+  const auto s = g.vec(slot);
+  g.sync();
+  s[g.r] = v;
+  g.sync();
+#pragma unroll
+  for (int i = 0; i < N; ++i) out[i] = s[i];
+}
+// sum over the first N ranks of three per-lane values, in rank order (deterministic)
+template <int N, typename R, int G>
+I2C_FN void g_sum3(const Grp<R, G>& g, const R v0, const R v1, const R v2, R* s0, R* s1, R* s2) {
+  const auto a = g.vec(0), b = g.vec(1), c = g.vec(2);
+  g.sync();
+  a[g.r] = v0;
+  b[g.r] = v1;
+  c[g.r] = v2;
+  g.sync();
+  R x = R(0), y = R(0), z = R(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    x += a[i];
+    y += b[i];
+    z += c[i];
+  }
+  *s0 = x;
+  *s1 = y;
+  *s2 = z;
+}
+
+// Cholesky of an N x N SPD matrix whose row r sits in lane r (full row). Right-looking, one LDS exchange per column:
+// the lanes publish the current column k UNSCALED, everybody reads it (pivot included), takes 1/sqrt(pivot) itself and
+// updates its own trailing row. On return: row = row r of L with zeros above the diagonal, rinv[j] = 1 / L[j][j] in
+// every lane, L row-major in LDS matrix `m`. Returns (in every lane) whether the last pivot is positive, which is
+// equivalent to all pivots being positive (see chol() in i2c_linalg.hpp).
+template <int N, typename R, int G> I2C_FN bool g_chol(const Grp<R, G>& g, const int m, R* row, R* rinv) {
+  constexpr int LD = Grp<R, G>::LD;
+  constexpr bool FENCE = N >= 6;  // bound the live state per column (see sched_fence, i2c_linalg.hpp)
+  const auto Tm = g.mat(m);
+  const int r = g.r;
+  R last = R(0);
+  g.sync();
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    Tm[k * LD + r] = row[k];
+    g.sync();
+    R col[N];
+#pragma unroll
+    for (int j = k; j < N; ++j) col[j] = Tm[k * LD + j];
+    if (k == N - 1) last = col[k];
+    const R rk = r_rsqrt(col[k]);
+    rinv[k] = rk;
+    const R lrk = row[k] * rk;
+    const R tk = lrk * rk;
+#pragma unroll
+    for (int j = k + 1; j < N; ++j) row[j] -= tk * col[j];
+    row[k] = lrk;
+    sched_fence<FENCE>();
+  }
+  g.sync();  // the unscaled columns are consumed: the matrix now receives L itself
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    row[j] = (j <= r) ? row[j] : R(0);
+    Tm[r * LD + j] = row[j];
+  }
+  g.sync();
+  return last > R(0);
+}
+
+// L y = b (forward substitution) for one or two right-hand sides per lane; L is in LDS matrix m, rinv replicated.
+// Row i + 1 of L is fetched while row i is consumed; a scheduling fence per row keeps the live state at two rows.
+template <int N, int NRHS, typename R, int G>
+I2C_FN void g_fsub(const Grp<R, G>& g, const int m, const R* rinv, R* b0, R* b1) {
+  constexpr int LD = Grp<R, G>::LD;
+  constexpr bool FENCE = N >= 6;
+  const auto L = g.mat(m);
+  R lc[N], ln[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (i + 1 < N) {
+#pragma unroll
+      for (int k = 0; k <= i; ++k) ln[k] = L[(i + 1) * LD + k];
+    }
+    R v0 = b0[i], v1 = NRHS > 1 ? b1[i] : R(0);
+#pragma unroll
+    for (int k = 0; k < i; ++k) {
+      v0 -= lc[k] * b0[k];
+      if (NRHS > 1) v1 -= lc[k] * b1[k];
+    }
+    b0[i] = v0 * rinv[i];
+    if (NRHS > 1) b1[i] = v1 * rinv[i];
+#pragma unroll
+    for (int k = 0; k <= i && k < N - 1; ++k) lc[k] = ln[k];
+    sched_fence<FENCE>();
+  }
+}
+// L^T x = y (back substitution), one right-hand side per lane (column i of L fetched one step ahead)
+template <int N, typename R, int G> I2C_FN void g_bsub(const Grp<R, G>& g, const int m, const R* rinv, R* y) {
+  constexpr int LD = Grp<R, G>::LD;
+  constexpr bool FENCE = N >= 6;
+  const auto L = g.mat(m);
+  R lc[N], ln[N];
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    if (i > 0) {
+#pragma unroll
+      for (int k = i; k < N; ++k) ln[k] = L[k * LD + (i - 1)];
+    }
+    R v = y[i];
+#pragma unroll
+    for (int k = i + 1; k < N; ++k) v -= lc[k] * y[k];
+    y[i] = v * rinv[i];
+    if (i > 0) {
+#pragma unroll
+      for (int k = i; k < N; ++k) lc[k] = ln[k];
+    }
+    sched_fence<FENCE>();
+  }
+}
+
+template <class ST, int DOUT> constexpr bool st_identity() {
+  for (int k = 0; k < DOUT; ++k)
+    if (ST::lin(k) != k) return false;
+  return true;
+}
+
+// Gaussian push-through N(m, L L^T) -> (my, Sy [, Sxy])  (quadrature.py:27-58), rows distributed:
+//   in : m [DIN] replicated; Lrow = row r of L (zeros above the diagonal); L row-major in LDS matrix mL
+//   out: my [DOUT] replicated; Sy = row r of the output covariance (lanes r < DOUT); Sxy = row r of the DIN x DOUT
+//        cross-covariance (lanes r < DIN)
+// Lane j evaluates the pair m +/- sf L[:, j] and publishes a_j = (y+ - y0) + (y- - y0), d_j = y+ - y-; pass-through
+// outputs (ST::lin(k) >= 0) need no evaluation: a_j = 0 and d_j = 2 sf L[lin(k)][j] exactly. Then every lane
+// accumulates ITS row of  Sy = wi/2 sum_j (a_j a_j^T + d_j d_j^T) - wi^2 A A^T (+ terms in 1 - W)  and of
+// Sxy = wi sf L [d_0 .. d_{DIN-1}]^T from the published vectors -- the formulas of sp_transform (i2c_cell.hpp).
+// LDS matrices mA and mD hold the a_j and d_j (row j); mL may be overwritten afterwards.
+template <class M, class ST, int DIN, int DOUT, bool CROSS, typename R, int G, class F>
+I2C_FN void g_transform(const Grp<R, G>& g, const int mL, const int mA, const int mD, const Rule<R>& rule, const R* m,
+                        const R* Lrow, const F& f, R* my, R* Sy, R* Sxy) {
+  constexpr int LD = Grp<R, G>::LD;
+  constexpr int NA = M::NA, NA1 = NA > 0 ? NA : 1;
+  const int r = g.r;
+  const auto Lm = g.mat(mL), Am = g.mat(mA), Dm = g.mat(mD);
+  R s0[NA1], c0[NA1];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) r_sincos(m[M::ang(q)], &s0[q], &c0[q]);
+  R y0[DOUT];
+  f(m, s0, c0, y0);
+  {
+    // column r of sf L (zero for the lanes beyond the input dimension)
+    R col[DIN], xp[DIN], xm[DIN];
+#pragma unroll
+    for (int i = 0; i < DIN; ++i) {
+      const R l = Lm[i * LD + r];
+      col[i] = (r < DIN) ? rule.sf * l : R(0);
+      xp[i] = m[i] + col[i];
+      xm[i] = m[i] - col[i];
+    }
+    R sp[NA1], cp[NA1], sm[NA1], cm[NA1];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      R sd, cd;
+      r_sincos_small(col[M::ang(q)], &sd, &cd);
+      sp[q] = s0[q] * cd + c0[q] * sd;
+      cp[q] = c0[q] * cd - s0[q] * sd;
+      sm[q] = s0[q] * cd - c0[q] * sd;
+      cm[q] = c0[q] * cd + s0[q] * sd;
+    }
+    R yp[DOUT], ym[DOUT];
+    f(xp, sp, cp, yp);
+    f(xm, sm, cm, ym);
+    g.sync();  // mA / mD may still be read by the previous user
+#pragma unroll
+    for (int k = 0; k < DOUT; ++k) {
+      const bool lin = ST::lin(k) >= 0;
+      const R ak = lin ? R(0) : (yp[k] - y0[k]) + (ym[k] - y0[k]);
+      const R dk = lin ? R(2) * col[lin ? ST::lin(k) : 0] : yp[k] - ym[k];
+      Am[r * LD + k] = ak;
+      Dm[r * LD + k] = dk;
+    }
+    g.sync();
+  }
+  R A[DOUT], Ar = R(0);
+#pragma unroll
+  for (int k = 0; k < DOUT; ++k) {
+    A[k] = R(0);
+    Sy[k] = R(0);
+    if (CROSS) Sxy[k] = R(0);
+  }
+  // the published vectors of point j + 1 are fetched while those of point j are consumed
+  constexpr bool FENCE = DIN >= 6;
+  R dc[DOUT], ac[DOUT], dn[DOUT], an[DOUT], arc, drc, arn = R(0), drn = R(0);
+  auto fetch = [&](const int j, R* d, R* al, R* ar, R* dr) {
+#pragma unroll
+    for (int l = 0; l < DOUT; ++l) {
+      d[l] = Dm[j * LD + l];
+      al[l] = ST::lin(l) < 0 ? Am[j * LD + l] : R(0);
+    }
+    *ar = Am[j * LD + r];  // junk for r >= DOUT: those lanes' Sy is never used
+    *dr = Dm[j * LD + r];
+  };
+  fetch(0, dc, ac, &arc, &drc);
+#pragma unroll
+  for (int j = 0; j < DIN; ++j) {
+    if (j + 1 < DIN) fetch(j + 1, dn, an, &arn, &drn);
+    Ar += arc;
+#pragma unroll
+    for (int l = 0; l < DOUT; ++l) {
+      R acc = Sy[l] + drc * dc[l];
+      if (ST::lin(l) < 0) {
+        A[l] += ac[l];
+        acc += arc * ac[l];
+      }
+      Sy[l] = acc;
+      if (CROSS) Sxy[l] += Lrow[j] * dc[l];
+    }
+    if (j + 1 < DIN) {
+#pragma unroll
+      for (int l = 0; l < DOUT; ++l) {
+        dc[l] = dn[l];
+        ac[l] = an[l];
+      }
+      arc = arn;
+      drc = drn;
+    }
+    sched_fence<FENCE>();
+  }
+  const R hw = R(0.5) * rule.wi, w2 = rule.wi * rule.wi, cs = rule.wi * rule.sf;
+  R yc[DOUT];
+#pragma unroll
+  for (int k = 0; k < DOUT; ++k) {
+    yc[k] = ST::lin(k) >= 0 ? m[ST::lin(k) >= 0 ? ST::lin(k) : 0] : y0[k];
+    my[k] = rule.W * yc[k] + rule.wi * A[k];
+    Sy[k] = hw * Sy[k] - w2 * Ar * A[k];
+    if (CROSS) Sxy[k] = cs * Sxy[k];
+  }
+  if (!rule.unit) {  // sum of weights != 1: the reference's m m^T term no longer cancels (see sp_transform)
+    const R omw = R(1) - rule.W, ycr = g_sel<DOUT>(yc, r);
+#pragma unroll
+    for (int l = 0; l < DOUT; ++l) Sy[l] += omw * (rule.W * ycr * yc[l] + rule.wi * (Ar * yc[l] + ycr * A[l]));
+  }
+}
+
+// Kalman-style update of N(mu, S) (dimension DX) on an observation with moments (mz, Sz + noise, Sxz) and target zt
+// (i2c.py:394-403 / 435-443), rows distributed: mu and the innovation q = zt - mz replicated; S row r (lanes r < DX); Sz
+// row r (lanes r < DZ, noise included); Sxz row r (lanes r < DX). With C = chol(Sz): V = Sxz C^-T (row r per lane), mu += V C^-1 q,
+// S -= V V^T. Uses LDS matrices 0 (C) and 1 (V) and vector slot 0. *mu_own receives element r of the new mean.
+template <int DX, int DZ, typename R, int G>
+I2C_FN bool g_kalman(const Grp<R, G>& g, R* mu, R* S, R* q, R* Sz, R* Sxz, R* mu_own) {
+  constexpr int LD = Grp<R, G>::LD;
+  const int r = g.r;
+  R rinv[DZ];
+  const bool ok = g_chol<DZ>(g, 0, Sz, rinv);
+  g_fsub<DZ, 2>(g, 0, rinv, q, Sxz);
+  R dmu = R(0);
+#pragma unroll
+  for (int k = 0; k < DZ; ++k) dmu += Sxz[k] * q[k];
+  const R own = g_sel<DX>(mu, r) + dmu;
+  *mu_own = own;
+  const auto Vm = g.mat(1);
+  g.sync();
+#pragma unroll
+  for (int k = 0; k < DZ; ++k) Vm[r * LD + k] = Sxz[k];
+  g_gather<DX>(g, 0, own, mu);  // its syncs also publish V
+  constexpr bool FENCE = DZ >= 6;
+  R vc[DZ], vn[DZ];
+#pragma unroll
+  for (int k = 0; k < DZ; ++k) vc[k] = Vm[k];
+#pragma unroll
+  for (int j = 0; j < DX; ++j) {  // row j + 1 of V is fetched while row j is consumed
+    if (j + 1 < DX) {
+#pragma unroll
+      for (int k = 0; k < DZ; ++k) vn[k] = Vm[(j + 1) * LD + k];
+    }
+    R v = S[j];
+#pragma unroll
+    for (int k = 0; k < DZ; ++k) v -= Sxz[k] * vc[k];
+    S[j] = v;
+    if (j + 1 < DX) {
+#pragma unroll
+      for (int k = 0; k < DZ; ++k) vc[k] = vn[k];
+    }
+    sched_fence<FENCE>();
+  }
+  return ok;
+}
+
+// Expected quadratic cost of N(mz, Sz) under a DIAGONAL weight (every shipped Q, R, Qf): m = err^T W err + tr(Sz W),
+// v = 2 tr((Sz W)^2) + 4 err^T W Sz W err (i2c.py:1034-1043). Sz row r per lane; wd = diag(W) in LDS.
+template <int N, typename R, int G, class WD>
+I2C_FN void g_cost(const Grp<R, G>& g, const WD wd, const R* mz, const R* Sz, const R* zt, R* m, R* v) {
+  const int r = g.r;
+  R err[N], we[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    err[i] = mz[i] - zt[i];
+    we[i] = wd[i] * err[i];
+  }
+  const int rc = r < N ? r : N - 1;
+  const R wr = wd[rc], er = g_sel<N>(err, r), Srr = g_sel<N>(Sz, r);
+  R tr2 = R(0), quad = R(0);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    tr2 += Sz[j] * (Sz[j] * (wr * wd[j]));
+    quad += Sz[j] * ((wr * er) * we[j]);
+  }
+  const bool on = r < N;
+  R mm, t2, qd;
+  g_sum3<N>(g, on ? wr * er * er + wr * Srr : R(0), on ? tr2 : R(0), on ? quad : R(0), &mm, &t2, &qd);
+  *m = mm;
+  *v = R(2) * t2 + R(4) * qd;
+}
+
+// addressing of one [E][B] cell block of a device buffer for the lanes of trajectory b
+template <typename R> struct GIO {
+  Window w;
+  unsigned rb, bo;
+  I2C_MEM R ld(const int e) const { return wld<R>(w, 0u, (unsigned)e * rb + bo); }
+  I2C_MEM void st(const int e, const R v) const { wst(w, 0u, (unsigned)e * rb + bo, v); }
+};
+template <typename R> I2C_FN GIO<R> gio(const R* base, const unsigned long elems, const unsigned rb, const unsigned bo) {
+  return GIO<R>{make_window(base, elems * rb), rb, bo};
+}
+
+// Joint over (x, u) from a state message (mu_x replicated, sx = row r of sig_x for the state lanes) and a controller
+// row block (i2c.py:361-387 forward feedback prior with Kt = rho K; i2c.py:158-179 propagation):
+//   mean_u = qmu_u + Kt (mu_x - qmu_x);  cross = Kt sig_x;
+//   sig_u[p][q] = puu[p][q] - sub * Kt[p] . pux[q] + Kt (sig_x - sq * qxx) Kt^T [p][q]        (p >= q)
+// forward feedback prior: sub = 1, sq = 0 (pux = prior action-state block); propagation: sub = 0, sq = 1 (qxx = the
+// posterior state covariance); add_quad = false drops the quadratic term (feed-forward cells of the propagation). Kt rows (scaled) arrive in the action lanes' Krow; prow = row r of the prior joint.
+// Uses LDS matrices 0, 1, 2. Out: mu0 replicated, s0 = row r of the joint covariance.
+template <int NX, int NU, typename R, int G>
+I2C_FN void g_joint(const Grp<R, G>& g, const R* mu_x, const R* sx, const R* Krow, const R* prow, const R* qmu_x,
+                    const R* qmu_u, const bool sub_ux, const bool sub_qxx, const bool add_quad, R* mu0, R* s0) {
+  constexpr int LD = Grp<R, G>::LD, D = NX + NU;
+  static_assert(2 * NU <= LD, "group too narrow for the action block exchange");
+  const int r = g.r;
+  const bool is_x = r < NX, is_u = r >= NX && r < D;
+  const int ru = is_u ? r - NX : 0;
+  const auto XC = g.mat(0), Km = g.mat(1), Pm = g.mat(2);
+  g.sync();
+  if (is_u) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      Km[ru * LD + k] = Krow[k];
+      Pm[ru * LD + k] = prow[k];
+    }
+  }
+  g.sync();
+#pragma unroll
+  for (int i = 0; i < NX; ++i) mu0[i] = mu_x[i];
+  R cr[NU], crd[NU];
+#pragma unroll
+  for (int a = 0; a < NU; ++a) {
+    R v = qmu_u[a], c1 = R(0), c2 = R(0);
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const R kt = Km[a * LD + k];
+      v += kt * (mu_x[k] - qmu_x[k]);
+      c1 += sx[k] * kt;
+      c2 += (sub_qxx ? sx[k] - prow[k] : sx[k]) * kt;
+    }
+    mu0[NX + a] = v;
+    cr[a] = c1;
+    crd[a] = c2;
+  }
+  if (is_x) {  // matrix 0 is not read between the sync above and here
+#pragma unroll
+    for (int a = 0; a < NU; ++a) {
+      XC[r * LD + a] = cr[a];
+      XC[r * LD + NU + a] = crd[a];
+    }
+  }
+  g.sync();
+  R su[D];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) su[j] = XC[j * LD + ru];
+#pragma unroll
+  for (int c = 0; c < NU; ++c) {
+    const int p = ru > c ? ru : c, q = ru > c ? c : ru;
+    R v = prow[NX + c];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const R ktq = Km[q * LD + k];
+      if (sub_ux) v -= Km[p * LD + k] * Pm[q * LD + k];
+      if (add_quad) v += XC[k * LD + NU + p] * ktq;
+    }
+    su[NX + c] = v;
+  }
+#pragma unroll
+  for (int j = 0; j < D; ++j) s0[j] = is_x ? (j < NX ? sx[j] : cr[j < NX ? 0 : j - NX]) : su[j];
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward sweep (i2c.py:876-880 over :350-447): the group walks its trajectory through all T cells.
+// ------------------------------------------------------------------------------------------
+template <class M, typename R, int G, class KC>
+I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const FwdArgs<R>& a, const int b,
+                                      const Grp<R, G>& g) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D, NT = C::NZT1;
+  static_assert(G >= D && G >= NZ && G >= NT, "one matrix row per lane");
+  constexpr int O_K = D + sym(D), O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  constexpr bool OBS_ID = st_identity<ObsStruct<M>, NZ>() && NZ <= D;
+  constexpr bool TERM_ID = st_identity<TermStruct<M>, NT>() && NT <= NX;
+  const int r = g.r;
+  const unsigned long B = c.B;
+  const int T = c.T;
+  const unsigned W = sizeof(R), bo = (unsigned)b * W, rb = (unsigned)(B * W);
+  const int rx = r < NX ? r : NX - 1, rd = r < D ? r : D - 1, rz = r < NZ ? r : NZ - 1, rt = r < NT ? r : NT - 1;
+  const int trx = rx * (rx + 1) / 2, trd = rd * (rd + 1) / 2;
+  const bool is_u = r >= NX && r < D;
+  const int ru = is_u ? r - NX : 0;
+  const R alpha_traj = a.alpha[b];
+  int fail = 0;
+
+  R mu_x[NX], sx[NX];
+  g_gather<NX>(g, 0, a.x0[(long)rx * B + b], mu_x);
+#pragma unroll
+  for (int j = 0; j < NX; ++j) sx[j] = a.sig_x0[(long)symidx(rx, trx, j) * B + b];
+
+  for (int t = 0; t < T; ++t) {
+    const GIO<R> pri = gio(a.prior + (unsigned long)t * C::E_POST * B, C::E_POST, rb, bo);
+    const GIO<R> out = gio(a.fwd + (unsigned long)t * C::E_FWD * B, C::E_FWD, rb, bo);
+    R pmu[D], prow[D];
+    g_gather<D>(g, 0, pri.ld(rd), pmu);
+#pragma unroll
+    for (int j = 0; j < D; ++j) prow[j] = pri.ld(D + symidx(rd, trd, j));
+    const R alpha = a.alpha_cell ? a.alpha_cell[(long)t * B + b] : alpha_traj;
+    int cell_bad = 0;
+
+    // ---- 1. joint prior over (x, u) ---------------------------------------------------
+    R mu0[D], s0[D];
+    if (a.ff[t] != 0) {  // feed-forward: independent action prior (i2c.py:355-360)
+#pragma unroll
+      for (int i = 0; i < D; ++i) mu0[i] = i < NX ? mu_x[i] : pmu[i];
+#pragma unroll
+      for (int j = 0; j < D; ++j) s0[j] = r < NX ? (j < NX ? sx[j < NX ? j : 0] : R(0)) : (j >= NX ? prow[j] : R(0));
+    } else {  // feedback: condition the previous controller on the new state message (i2c.py:361-387)
+      R Sr[NX], rinvS[NX], q[NX];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        Sr[j] = prow[j] + sx[j];
+        q[j] = mu_x[j] - pmu[j];
+      }
+      cell_bad = flag_stage(cell_bad, g_chol<NX>(g, 0, Sr, rinvS), 0);
+      g_fsub<NX, 1>(g, 0, rinvS, q, (R*)nullptr);
+      R maha = R(0);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) maha += q[i] * q[i];
+      const R rho = r_exp(R(-0.5) * maha);
+      R Krow[NX];
+#pragma unroll
+      for (int k = 0; k < NX; ++k) Krow[k] = rho * pri.ld(O_K + ru * NX + k);
+      g_joint<NX, NU>(g, mu_x, sx, Krow, prow, pmu, pmu + NX, true, false, true, mu0, s0);
+    }
+    if (a.prior_out) {
+      const GIO<R> po = gio(a.prior_out + (unsigned long)t * (D + sym(D)) * B, D + sym(D), rb, bo);
+      if (r < D) po.st(r, g_sel<D>(mu0, r));
+#pragma unroll
+      for (int j = 0; j < D; ++j)
+        if (r < D && j <= opaque_i(r)) po.st(D + trd + j, s0[j]);
+    }
+
+    // ---- 2. cost "observation": measurement update on z (i2c.py:390-407) --------------
+    R mu1_own;
+    {
+      R mz[NZ], szr[NZ], sxz[NZ];
+      if (OBS_ID && c.rule_xu.unit) {  // z is a leading slice of (x, u): its moments are blocks of the prior joint
+#pragma unroll
+        for (int k = 0; k < NZ; ++k) {
+          mz[k] = mu0[k < D ? k : 0];
+          szr[k] = sxz[k] = s0[k < D ? k : 0];
+        }
+      } else {
+        R L0[D], rinv0[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) L0[j] = s0[j];
+        cell_bad = flag_stage(cell_bad, g_chol<D>(g, 0, L0, rinv0), 1);
+        g_transform<M, ObsStruct<M>, D, NZ, true>(g, 0, 1, 2, c.rule_xu, mu0, L0, ObserveF<M, R>{c.params}, mz, szr, sxz);
+      }
+#pragma unroll
+      for (int l = 0; l < NZ; ++l) {
+        szr[l] += alpha * kc.sig_xi0[rz * NZ + l];
+        mz[l] = (c.z_per_cell ? a.z[((long)t * NZ + l) * B + b] : c.zg[l]) - mz[l];  // the innovation
+      }
+      cell_bad = flag_stage(cell_bad, g_kalman<D, NZ>(g, mu0, s0, mz, szr, sxz, &mu1_own), 2);
+    }
+    // mu0 / s0 now hold mu_xu1_f / row r of sig_xu1_f
+    if (r < D) out.st(r, mu1_own);
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+      if (r < D && j <= opaque_i(r)) out.st(D + trd + j, s0[j]);
+
+    // ---- 3. dynamics push-through (i2c.py:415-421) and smoother gain (i2c.py:423-425) --
+    R L3[NX], rinv3[NX];
+    {
+      R L1[D], rinv1[D], sxy[NX];
+#pragma unroll
+      for (int j = 0; j < D; ++j) L1[j] = s0[j];
+      cell_bad = flag_stage(cell_bad, g_chol<D>(g, 0, L1, rinv1), 3);
+      g_transform<M, DenseStruct<D>, D, NX, true>(g, 0, 1, 2, c.rule_xu, mu0, L1, DynamicsF<M, R>{c.params}, mu_x, sx, sxy);
+#pragma unroll
+      for (int l = 0; l < NX; ++l) {
+        sx[l] += c.rule_xu.W * kc.sig_eta[rx * NX + l];  // sum_p w_p sig_eta (quadrature.py:57)
+        L3[l] = sx[l];
+      }
+      cell_bad = flag_stage(cell_bad, g_chol<NX>(g, 0, L3, rinv3), 4);
+      g_fsub<NX, 1>(g, 0, rinv3, sxy, (R*)nullptr);  // row r of J = sig_xy sig_x3^-1
+      g_bsub<NX>(g, 0, rinv3, sxy);
+#pragma unroll
+      for (int l = 0; l < NX; ++l)
+        if (r < D) out.st(O_J + rd * NX + l, sxy[l]);
+    }
+
+    // ---- 4. terminal cost observation on the flagged cell, after J (i2c.py:430-443) ----
+    if (NZT > 0 && t == c.terminal_cell && c.has_Qf) {
+      R mzt[NT], sztr[NT], sxzt[NT], own;
+      if (TERM_ID && c.rule_x.unit) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+          mzt[k] = mu_x[k < NX ? k : 0];
+          sztr[k] = sxzt[k] = sx[k < NX ? k : 0];
+        }
+      } else {  // chol(sig_x3_f) is still in LDS matrix 0 and its row in L3
+        g_transform<M, TermStruct<M>, NX, NT, true>(g, 0, 1, 2, c.rule_x, mu_x, L3, ObserveTermF<M, R>{c.params}, mzt, sztr, sxzt);
+      }
+#pragma unroll
+      for (int l = 0; l < NT; ++l) {
+        sztr[l] += alpha * kc.sig_xiT0[rt * NT + l];
+        mzt[l] = c.zg_term[l] - mzt[l];
+      }
+      cell_bad = flag_stage(cell_bad, g_kalman<NX, NT>(g, mu_x, sx, mzt, sztr, sxzt, &own), 5);
+    }
+    fail = fold_cell_failure(fail, cell_bad, t);
+    if (r < NX) out.st(O_MU3 + r, g_sel<NX>(mu_x, r));
+#pragma unroll
+    for (int j = 0; j < NX; ++j)
+      if (r < NX && j <= opaque_i(r)) out.st(O_S3 + trx + j, sx[j]);
+  }
+  if (r == 0 && fail != 0 && a.status[b] == 0) a.status[b] = fail;
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward sweep (i2c.py:882-886 over :544-610), fused form: the group walks T-1..0 doing the whole cell -- RTS update of
+// the joint, posterior observation moments and their expected cost, controller from the factor of the posterior joint.
+// Terminal state prior (covariance control, i2c.py:548-559) is not available in the group form (the launcher refuses it).
+// ------------------------------------------------------------------------------------------
+template <class M, typename R, int G, class KC>
+I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, const CellArgs<R>& a, const int b,
+                                       const Grp<R, G>& g) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D, NT = C::NZT1, LD = Grp<R, G>::LD;
+  static_assert(G >= D && G >= NZ && G >= NT, "one matrix row per lane");
+  constexpr int O_K = D + sym(D), O_k = O_K + NU * NX, O_SK = O_k + NU;
+  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  constexpr bool OBS_ID = st_identity<ObsStruct<M>, NZ>() && NZ <= D;
+  constexpr bool TERM_ID = st_identity<TermStruct<M>, NT>() && NT <= NX;
+  const int r = g.r;
+  const unsigned long B = c.B;
+  const int T = c.T;
+  const unsigned W = sizeof(R), bo = (unsigned)b * W, rb = (unsigned)(B * W);
+  const int rx = r < NX ? r : NX - 1, rd = r < D ? r : D - 1;
+  const int trx = rx * (rx + 1) / 2, trd = rd * (rd + 1) / 2, trr = r * (r + 1) / 2;
+  const bool is_x = r < NX, is_u = r >= NX && r < D;
+  const int ru = is_u ? r - NX : 0;
+
+  // end of the chain (i2c.py:546-564): the smoothed terminal state is the filtered one
+  R m3m[NX], s3m[NX];
+  {
+    const GIO<R> fw = gio(a.fwd + (unsigned long)(T - 1) * C::E_FWD * B, C::E_FWD, rb, bo);
+    g_gather<NX>(g, 0, fw.ld(O_MU3 + rx), m3m);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) s3m[j] = fw.ld(O_S3 + symidx(rx, trx, j));
+  }
+  // terminal observation statistics (i2c.py:567-570, 989-992): tr(Qf (errT errT^T + sig_z3_m))
+  R trT = R(0);
+  if (NZT > 0 && c.has_Qf) {
+    R mzt[NT], sztr[NT];
+    if (TERM_ID && c.rule_x.unit) {
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        mzt[k] = m3m[k < NX ? k : 0];
+        sztr[k] = s3m[k < NX ? k : 0];
+      }
+    } else {
+      R L3[NX], rinv3[NX];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) L3[j] = s3m[j];
+      if (!g_chol<NX>(g, 0, L3, rinv3) && r == 0) set_status(a.status, b, 6, T - 1);
+      g_transform<M, TermStruct<M>, NX, NT, false>(g, 0, 1, 2, c.rule_x, m3m, L3, ObserveTermF<M, R>{c.params}, mzt, sztr, (R*)nullptr);
+    }
+    R tv;
+    g_cost<NT>(g, kc.qf_d, mzt, sztr, c.zg_term, &trT, &tv);
+    if (r < NT) a.term_stats[(long)(3 + r) * B + b] = g_sel<NT>(mzt, r);
+#pragma unroll
+    for (int l = 0; l < NT; ++l)
+      if (r < NT && l <= opaque_i(r)) a.term_stats[(long)(3 + NT + trr + l) * B + b] = sztr[l];
+  }
+  if (r == 0) a.term_stats[b] = trT;
+
+  R sum_m = R(0), sum_v = R(0);
+  for (int t = T - 1; t >= 0; --t) {
+    const GIO<R> fw = gio(a.fwd + (unsigned long)t * C::E_FWD * B, C::E_FWD, rb, bo);
+    const GIO<R> po = gio(a.post + (unsigned long)t * C::E_POST * B, C::E_POST, rb, bo);
+    R mu[D], S[D], m3f[NX], s3f[NX], Jr[NX];
+    const R mu1_own = fw.ld(rd);
+    g_gather<NX>(g, 1, fw.ld(O_MU3 + rx), m3f);
+#pragma unroll
+    for (int j = 0; j < D; ++j) S[j] = fw.ld(D + symidx(rd, trd, j));
+#pragma unroll
+    for (int j = 0; j < NX; ++j) s3f[j] = fw.ld(O_S3 + symidx(rx, trx, j));
+#pragma unroll
+    for (int l = 0; l < NX; ++l) Jr[l] = fw.ld(O_J + rd * NX + l);
+    if (a.xm) {
+      R* xo = const_cast<R*>(a.xm) + ((long)t * C::E_XM) * B + b;
+      if (is_x) xo[(long)r * B] = g_sel<NX>(m3m, r);
+#pragma unroll
+      for (int j = 0; j < NX; ++j)
+        if (is_x && j <= opaque_i(r)) xo[(long)(NX + trx + j) * B] = s3m[j];
+    }
+    R zt[NZ];
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
+
+    // RTS update of the joint (i2c.py:580-583): mu += J (m3m - m3f), S += J (S3m - S3f) J^T
+    const auto dSm = g.mat(1), Jm = g.mat(2);
+    g.sync();
+    if (is_x) {
+#pragma unroll
+      for (int j = 0; j < NX; ++j) dSm[r * LD + j] = s3m[j] - s3f[j];
+    }
+    if (r < D) {
+#pragma unroll
+      for (int l = 0; l < NX; ++l) Jm[r * LD + l] = Jr[l];
+    }
+    R mu_own = mu1_own;
+#pragma unroll
+    for (int l = 0; l < NX; ++l) mu_own += Jr[l] * (m3m[l] - m3f[l]);
+    g_gather<D>(g, 0, mu_own, mu);  // its syncs also publish dS and J
+    {
+      constexpr bool FENCE = NX >= 6;
+      R JD[NX];
+#pragma unroll
+      for (int k = 0; k < NX; ++k) JD[k] = R(0);
+#pragma unroll
+      for (int l = 0; l < NX; ++l) {  // JD = J_r dS, one row of dS per step
+#pragma unroll
+        for (int k = 0; k < NX; ++k) JD[k] += Jr[l] * dSm[l * LD + k];
+        sched_fence<FENCE>();
+      }
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        R v = S[j];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) v += JD[k] * Jm[j * LD + k];
+        S[j] = v;
+        sched_fence<FENCE>();
+      }
+    }
+    R Lm[D], rinv[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) Lm[j] = S[j];
+    if (!g_chol<D>(g, 0, Lm, rinv) && r == 0) set_status(a.status, b, 7, t);
+
+    // controller from the factor (i2c.py:600-608): K L_xx = L_ux, sigK = L_uu L_uu^T, k = mu_u - K mu_x
+    // (before the transform, which may overwrite LDS matrices 1 and 2 but leaves L in matrix 0 ... and reads it)
+    R ctl[NX], sigK[NU];
+    {
+      const auto L = g.mat(0);
+#pragma unroll
+      for (int k = 0; k < NX; ++k) ctl[k] = Lm[k];
+      g_bsub<NX>(g, 0, rinv, ctl);
+#pragma unroll
+      for (int q = 0; q < NU; ++q) {
+        R v = R(0);
+#pragma unroll
+        for (int k = 0; k <= q; ++k) v += Lm[NX + k] * L[(NX + q) * LD + NX + k];
+        sigK[q] = v;
+      }
+    }
+    // posterior observation moments (i2c.py:594-596) and their expected cost (i2c.py:1034-1043)
+    R mz[NZ], szr[NZ], cm, cv;
+    if (OBS_ID && c.rule_xu.unit) {
+#pragma unroll
+      for (int k = 0; k < NZ; ++k) {
+        mz[k] = mu[k < D ? k : 0];
+        szr[k] = S[k < D ? k : 0];
+      }
+    } else {
+      g_transform<M, ObsStruct<M>, D, NZ, false>(g, 0, 1, 2, c.rule_xu, mu, Lm, ObserveF<M, R>{c.params}, mz, szr, (R*)nullptr);
+    }
+    g_cost<NZ>(g, kc.qr_d, mz, szr, zt, &cm, &cv);
+    sum_m += cm;
+    sum_v += cv;
+
+    if (r < D) po.st(r, mu_own);
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+      if (r < D && j <= opaque_i(r)) po.st(D + trd + j, S[j]);
+    if (is_u) {
+      R kk = mu_own;
+#pragma unroll
+      for (int k = 0; k < NX; ++k) {
+        po.st(O_K + ru * NX + k, ctl[k]);
+        kk -= ctl[k] * mu[k];
+      }
+      po.st(O_k + ru, kk);
+#pragma unroll
+      for (int q = 0; q < NU; ++q)
+        if (q <= opaque_i(ru)) po.st(O_SK + ru * (ru + 1) / 2 + q, sigK[q]);
+    }
+    if (a.zpost) {
+      R* zo = a.zpost + ((long)t * C::E_ZPOST) * B + b;
+      if (r < NZ) zo[(long)r * B] = g_sel<NZ>(mz, r);
+#pragma unroll
+      for (int l = 0; l < NZ; ++l)
+        if (r < NZ && l <= opaque_i(r)) zo[(long)(NZ + trr + l) * B] = szr[l];
+    }
+    if (a.cell_stats && r == 0) {
+      a.cell_stats[((long)t * 2 + 0) * B + b] = cm;
+      a.cell_stats[((long)t * 2 + 1) * B + b] = cv;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      m3m[i] = mu[i];
+      s3m[i] = S[i];  // state lanes: row r of the xx block
+    }
+  }
+  if (r == 0) {
+    a.term_stats[B + b] = sum_m;
+    a.term_stats[2 * B + b] = sum_v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Closed-loop propagation (i2c.py:150-199, 1247-1251) in the group form.
+// ------------------------------------------------------------------------------------------
+template <class M, typename R, int G, class KC>
+I2C_HD inline void propagate_group_body(const Consts<M, R>& c, const KC& kc, const PropArgs<R>& a, const int b,
+                                        const Grp<R, G>& g) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, D = C::D;
+  static_assert(G >= D && G >= NZ, "one matrix row per lane");
+  constexpr int O_K = D + sym(D), O_X3 = D + sym(D), O_SX3 = O_X3 + NX;
+  constexpr bool OBS_ID = st_identity<ObsStruct<M>, NZ>() && NZ <= D;
+  const int r = g.r;
+  const unsigned long B = c.B;
+  const int T = c.T;
+  const unsigned W = sizeof(R), bo = (unsigned)b * W, rb = (unsigned)(B * W);
+  const int rx = r < NX ? r : NX - 1, rd = r < D ? r : D - 1;
+  const int trx = rx * (rx + 1) / 2, trd = rd * (rd + 1) / 2;
+  const bool is_u = r >= NX && r < D;
+  const int ru = is_u ? r - NX : 0;
+
+  R mu_x[NX], sx[NX];
+  g_gather<NX>(g, 0, a.x0[(long)rx * B + b], mu_x);
+#pragma unroll
+  for (int j = 0; j < NX; ++j) sx[j] = a.sig_x0[(long)symidx(rx, trx, j) * B + b];
+  R sum_m = R(0), sum_v = R(0);
+
+  for (int t = 0; t < T; ++t) {
+    const GIO<R> pri = gio(a.post + (unsigned long)t * C::E_POST * B, C::E_POST, rb, bo);
+    const GIO<R> out = gio(a.prop + (unsigned long)t * C::E_PROP * B, C::E_PROP, rb, bo);
+    R qmu[D], prow[D], Krow[NX];
+    g_gather<D>(g, 0, pri.ld(rd), qmu);
+#pragma unroll
+    for (int j = 0; j < D; ++j) prow[j] = pri.ld(D + symidx(rd, trd, j));
+#pragma unroll
+    for (int k = 0; k < NX; ++k) Krow[k] = pri.ld(O_K + ru * NX + k);
+    const bool ff = a.ff[t] != 0;
+    if (!ff && c.use_expert) {  // i2c.py:160-167
+      R Sr[NX], rinvS[NX], q[NX];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        Sr[j] = prow[j] + sx[j];
+        q[j] = mu_x[j] - qmu[j];
+      }
+      const bool ok = g_chol<NX>(g, 0, Sr, rinvS);
+      g_fsub<NX, 1>(g, 0, rinvS, q, (R*)nullptr);
+      R maha = R(0);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) maha += q[i] * q[i];
+      const R rho = ok ? r_exp(R(-0.5) * maha) : R(1);  // the reference logs the exception and keeps K unscaled
+#pragma unroll
+      for (int k = 0; k < NX; ++k) Krow[k] *= rho;
+    }
+    // feed-forward cells use the action marginal but the joint still carries K sig_x (i2c.py:155-157, 173-179)
+    R mu0[D], s0[D], qx[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) qx[i] = ff ? mu_x[i] : qmu[i];
+    g_joint<NX, NU>(g, mu_x, sx, Krow, prow, qx, qmu + NX, false, !ff, !ff, mu0, s0);
+    if (r < D) out.st(r, g_sel<D>(mu0, r));
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+      if (r < D && j <= opaque_i(r)) out.st(D + trd + j, s0[j]);
+
+    R L0[D], rinv0[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) L0[j] = s0[j];
+    if (!g_chol<D>(g, 0, L0, rinv0) && r == 0) set_status(a.status, b, 8, t);
+    R zt[NZ], mz[NZ], szr[NZ], cm, cv;
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
+    if (OBS_ID && c.rule_xu.unit) {
+#pragma unroll
+      for (int k = 0; k < NZ; ++k) {
+        mz[k] = mu0[k < D ? k : 0];
+        szr[k] = s0[k < D ? k : 0];
+      }
+    } else {
+      // writes LDS matrices 1 and 2 only: the factor in matrix 0 stays for the dynamics transform below
+      g_transform<M, ObsStruct<M>, D, NZ, false>(g, 0, 1, 2, c.rule_xu, mu0, L0, ObserveF<M, R>{c.params}, mz, szr, (R*)nullptr);
+    }
+    g_cost<NZ>(g, kc.qr_d, mz, szr, zt, &cm, &cv);
+    sum_m += cm;
+    sum_v += cv;
+
+    g_transform<M, DenseStruct<D>, D, NX, false>(g, 0, 1, 2, c.rule_xu, mu0, L0, DynamicsF<M, R>{c.params}, mu_x, sx, (R*)nullptr);
+#pragma unroll
+    for (int l = 0; l < NX; ++l) sx[l] += c.rule_xu.W * kc.sig_eta[rx * NX + l];
+    if (r < NX) out.st(O_X3 + r, g_sel<NX>(mu_x, r));
+#pragma unroll
+    for (int j = 0; j < NX; ++j)
+      if (r < NX && j <= opaque_i(r)) out.st(O_SX3 + trx + j, sx[j]);
+  }
+  if (r == 0) {
+    a.prop_stats[b] = sum_m;
+    a.prop_stats[B + b] = sum_v;
+    a.prop_stats[2 * B + b] = R(0);  // KL to the terminal prior: covariance control is not available in the group form
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Cubature Kalman filter step of the MPC state estimator (mpc.py:125-145) in the group form.
+// ------------------------------------------------------------------------------------------
+template <class M, typename R, int G, class KC>
+I2C_HD inline void ckf_group_body(const Consts<M, R>& c, const KC& kc, const CkfArgs<R>& a, const int b,
+                                  const Grp<R, G>& g) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NU = C::NU, NY = M::NY;
+  static_assert(G >= NX && G >= NY, "one matrix row per lane");
+  constexpr bool MEAS_ID = st_identity<MeasStruct<M>, NY>() && NY <= NX;
+  const int r = g.r;
+  const long B = c.B;
+  const int rx = r < NX ? r : NX - 1, ry = r < NY ? r : NY - 1;
+  const int trx = rx * (rx + 1) / 2;
+  R mu[NX], S[NX], L[NX], rinv[NX], u[NU], y[NY];
+  g_gather<NX>(g, 0, a.mu[(long)rx * B + b], mu);
+#pragma unroll
+  for (int j = 0; j < NX; ++j) L[j] = S[j] = a.cov[(long)symidx(rx, trx, j) * B + b];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) u[i] = a.u[(long)i * B + b];
+#pragma unroll
+  for (int i = 0; i < NY; ++i) y[i] = a.y[(long)i * B + b];
+  bool ok = g_chol<NX>(g, 0, L, rinv);
+  // prediction (mpc.py:129-137): x-only sigma points, the action is appended unchanged
+  R mf[NX], Sf[NX];
+  g_transform<M, DenseStruct<NX>, NX, NX, false>(g, 0, 1, 2, c.rule_x, mu, L, DynamicsFixedUF<M, R>{c.params, u}, mf, Sf, (R*)nullptr);
+#pragma unroll
+  for (int l = 0; l < NX; ++l) L[l] = Sf[l] = Sf[l] + c.rule_x.W * kc.sig_eta[rx * NX + l];
+  // innovation (mpc.py:139-145)
+  R my[NY], Syr[NY], Sxy[NY], own;
+  if (MEAS_ID && c.rule_x.unit) {
+#pragma unroll
+    for (int k = 0; k < NY; ++k) {
+      my[k] = mf[k < NX ? k : 0];
+      Syr[k] = Sxy[k] = Sf[k < NX ? k : 0];
+    }
+  } else {
+    ok = g_chol<NX>(g, 0, L, rinv) && ok;
+    g_transform<M, MeasStruct<M>, NX, NY, true>(g, 0, 1, 2, c.rule_x, mf, L, MeasureF<M, R>{c.params}, my, Syr, Sxy);
+  }
+#pragma unroll
+  for (int l = 0; l < NY; ++l) {
+    Syr[l] += kc.sig_zeta[ry * NY + l];
+    my[l] = y[l] - my[l];
+  }
+  ok = g_kalman<NX, NY>(g, mf, Sf, my, Syr, Sxy, &own) && ok;
+  if (r < NX) a.mu[(long)r * B + b] = own;
+#pragma unroll
+  for (int j = 0; j < NX; ++j)
+    if (r < NX && j <= opaque_i(r)) a.cov[(long)(trx + j) * B + b] = Sf[j];
+  if (!ok && r == 0) set_status(a.status, b, 9, 0);
+}
+
+}  // namespace i2c

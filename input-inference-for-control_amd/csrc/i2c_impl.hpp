@@ -10,6 +10,7 @@
 #pragma once
 #include "i2c_entry.hpp"
 #include "i2c_cell.hpp"
+#include "i2c_group.hpp"
 #include "i2c_linearize.hpp"
 
 #include <cmath>
@@ -18,11 +19,36 @@
 
 namespace i2c {
 
-#ifndef I2C_HOST_SIM
 // One wavefront per workgroup for the sequential sweeps: at B = 4096 that is 64 workgroups on
 // 64 different CUs, each wave with a CU's issue ports, L1 and scalar cache to itself.
 constexpr int SWEEP_BLOCK = 64;
 constexpr int CELL_BLOCK = 256;
+
+// ---- the ONE place that knows how a per-lane body runs ---------------------------------------------------------------
+// Device: a HIP kernel, lane index from the block / thread ids, started by launch() through hipLaunchKernelGGL.
+// Host simulation (tests only): the same function with the lane indices as leading arguments, looped by launch().
+// A kernel is written once:   template <...> I2C_KERNEL(BLOCK) k_name(I2C_LANE_PARAMS const C c, const A a) {
+//                               const int b = I2C_LANE_X(BLOCK); ... I2C_LANE_Y ... }
+#ifdef I2C_HOST_SIM
+#define I2C_KERNEL(BLOCK) static void
+#define I2C_LANE_PARAMS const long lane_x_, const int lane_y_,
+#define I2C_LANE_X(BLOCK) ((void)lane_y_, lane_x_)
+#define I2C_LANE_Y lane_y_
+template <class K, class... A>
+static int launch(K kernel, const long n, const int ny, const int /*block*/, void* /*stream*/, const A&... args) {
+  for (int y = 0; y < ny; ++y)
+    for (long x = 0; x < n; ++x) kernel(x, y, args...);
+  return I2C_OK;
+}
+static int clear_bytes(void* p, size_t n, void*) {
+  std::memset(p, 0, n);
+  return I2C_OK;
+}
+#else
+#define I2C_KERNEL(BLOCK) __global__ __launch_bounds__(BLOCK) void
+#define I2C_LANE_PARAMS
+#define I2C_LANE_X(BLOCK) ((long)blockIdx.x * (BLOCK) + threadIdx.x)
+#define I2C_LANE_Y ((int)blockIdx.y)
 // Experiment knob (not part of the ABI): I2C_SWEEP_LANES=<n<=64> launches the sequential sweeps with
 // n active lanes per wavefront (more, emptier waves on more SIMDs).
 static int sweep_lanes() {
@@ -33,60 +59,115 @@ static int sweep_lanes() {
   }();
   return v;
 }
+template <class K, class... A>
+static int launch(K kernel, const long n, const int ny, const int block, void* stream, const A&... args) {
+  hipLaunchKernelGGL(kernel, dim3((unsigned)((n + block - 1) / block), ny), dim3(block), 0, (hipStream_t)stream, args...);
+  return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
+}
+static int clear_bytes(void* p, size_t n, void* stream) {
+  return hipMemsetAsync(p, 0, n, (hipStream_t)stream) == hipSuccess ? I2C_OK : I2C_ELAUNCH;
+}
+#endif
 
 template <class M, typename R, bool LEAN, bool GRID = false>
-__global__ __launch_bounds__(SWEEP_BLOCK) void k_forward(const Consts<M, R> c, const FwdArgs<R> a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < c.B) forward_sweep_body<M, R, LEAN, GRID>(c, a, b);
+I2C_KERNEL(SWEEP_BLOCK) k_forward(I2C_LANE_PARAMS const Consts<M, R> c, const FwdArgs<R> a, const int block) {
+  const long b = I2C_LANE_X(block);  // `block` = active lanes per wave (I2C_SWEEP_LANES experiment), normally 64
+  if (b < c.B) forward_sweep_body<M, R, LEAN, GRID>(c, a, (int)b);
 }
-template <class M, typename R>
-__global__ __launch_bounds__(SWEEP_BLOCK) void k_forward_lin(const Consts<M, R> c, const FwdArgs<R> a) {
-  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
-  if (b < c.B) forward_lin_body<M, R>(c, a, b);
+template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_forward_lin(I2C_LANE_PARAMS const Consts<M, R> c, const FwdArgs<R> a) {
+  const long b = I2C_LANE_X(SWEEP_BLOCK);
+  if (b < c.B) forward_lin_body<M, R>(c, a, (int)b);
 }
-template <class M, typename R>
-__global__ __launch_bounds__(SWEEP_BLOCK) void k_bwd_lin(const Consts<M, R> c, const CellArgs<R> a) {
-  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
-  if (b < c.B) backward_lin_body<M, R>(c, a, b);
+template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_bwd_lin(I2C_LANE_PARAMS const Consts<M, R> c, const CellArgs<R> a) {
+  const long b = I2C_LANE_X(SWEEP_BLOCK);
+  if (b < c.B) backward_lin_body<M, R>(c, a, (int)b);
 }
-template <class M, typename R>
-__global__ __launch_bounds__(SWEEP_BLOCK) void k_riccati(const Consts<M, R> c, const RiccatiArgs<R> a) {
-  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
-  if (b < c.B) riccati_body<M, R>(c, a, b);
+template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_riccati(I2C_LANE_PARAMS const Consts<M, R> c, const RiccatiArgs<R> a) {
+  const long b = I2C_LANE_X(SWEEP_BLOCK);
+  if (b < c.B) riccati_body<M, R>(c, a, (int)b);
 }
-template <class M, typename R>
-__global__ __launch_bounds__(SWEEP_BLOCK) void k_scan(const Consts<M, R> c, const ScanArgs<R> a) {
-  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
-  if (b < c.B) backward_scan_body<M, R>(c, a, b);
+template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_scan(I2C_LANE_PARAMS const Consts<M, R> c, const ScanArgs<R> a) {
+  const long b = I2C_LANE_X(SWEEP_BLOCK);
+  if (b < c.B) backward_scan_body<M, R>(c, a, (int)b);
 }
-template <class M, typename R>
-__global__ __launch_bounds__(CELL_BLOCK) void k_cell(const Consts<M, R> c, const CellArgs<R> a) {
-  const int b = blockIdx.x * CELL_BLOCK + threadIdx.x;
-  const int t = blockIdx.y;
-  if (b < c.B) backward_cell_body<M, R>(c, a, t, b);
+template <class M, typename R> I2C_KERNEL(CELL_BLOCK) k_cell(I2C_LANE_PARAMS const Consts<M, R> c, const CellArgs<R> a) {
+  const long b = I2C_LANE_X(CELL_BLOCK);
+  if (b < c.B) backward_cell_body<M, R>(c, a, I2C_LANE_Y, (int)b);
 }
 template <class M, typename R, bool GRID = false>
-__global__ __launch_bounds__(SWEEP_BLOCK) void k_bwd_fused(const Consts<M, R> c, const CellArgs<R> a) {
-  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
-  if (b < c.B) backward_fused_body<M, R, GRID>(c, a, b);
+I2C_KERNEL(SWEEP_BLOCK) k_bwd_fused(I2C_LANE_PARAMS const Consts<M, R> c, const CellArgs<R> a) {
+  const long b = I2C_LANE_X(SWEEP_BLOCK);
+  if (b < c.B) backward_fused_body<M, R, GRID>(c, a, (int)b);
 }
+template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_chunk_compose(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R> a) {
+  const long b = I2C_LANE_X(SWEEP_BLOCK);
+  if (b < c.B) chunk_compose_body<M, R>(c, a, I2C_LANE_Y, (int)b);
+}
+template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_chunk_stitch(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R> a) {
+  const long b = I2C_LANE_X(SWEEP_BLOCK);
+  if (b < c.B) chunk_stitch_body<M, R>(c, a, (int)b);
+}
+template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_chunk_walk(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R> a) {
+  const long b = I2C_LANE_X(SWEEP_BLOCK);
+  if (b < c.B) chunk_walk_body<M, R>(c, a, I2C_LANE_Y, (int)b);
+}
+template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_mstep(I2C_LANE_PARAMS const Consts<M, R> c, const MstepArgs<R> a) {
+  const long b = I2C_LANE_X(SWEEP_BLOCK);
+  if (b < c.B) mstep_body<M, R>(c, a, (int)b);
+}
+template <class M, typename R, bool GRID = false>
+I2C_KERNEL(SWEEP_BLOCK) k_propagate(I2C_LANE_PARAMS const Consts<M, R> c, const PropArgs<R> a) {
+  const long b = I2C_LANE_X(SWEEP_BLOCK);
+  if (b < c.B) propagate_body<M, R, GRID>(c, a, (int)b);
+}
+template <class M, typename R> struct ZetaArg {
+  R v[sym(M::NY)];
+};
 template <class M, typename R>
-__global__ __launch_bounds__(SWEEP_BLOCK) void k_chunk_compose(const Consts<M, R> c, const ChunkArgs<R> a) {
-  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
-  if (b < c.B) chunk_compose_body<M, R>(c, a, blockIdx.y, b);
+I2C_KERNEL(SWEEP_BLOCK) k_ckf(I2C_LANE_PARAMS const Consts<M, R> c, const ZetaArg<M, R> z, const CkfArgs<R> a) {
+  const long b = I2C_LANE_X(SWEEP_BLOCK);
+  if (b < c.B) ckf_filter_body<M, R>(c, z.v, a, (int)b);
 }
-template <class M, typename R>
-__global__ __launch_bounds__(SWEEP_BLOCK) void k_chunk_stitch(const Consts<M, R> c, const ChunkArgs<R> a) {
-  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
-  if (b < c.B) chunk_stitch_body<M, R>(c, a, b);
+template <class M, typename R> I2C_KERNEL(CELL_BLOCK) k_mpc_shift(I2C_LANE_PARAMS const Consts<M, R> c, const ShiftArgs<R> a) {
+  const long b = I2C_LANE_X(CELL_BLOCK);
+  if (b < c.B) mpc_shift_body<M, R>(c, a, I2C_LANE_Y, (int)b);
 }
-template <class M, typename R>
-__global__ __launch_bounds__(SWEEP_BLOCK) void k_chunk_walk(const Consts<M, R> c, const ChunkArgs<R> a) {
-  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
-  if (b < c.B) chunk_walk_body<M, R>(c, a, blockIdx.y, b);
+template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_rollout(I2C_LANE_PARAMS const Consts<M, R> c, const RolloutArgs<R> a) {
+  const long n = I2C_LANE_X(SWEEP_BLOCK);
+  if (n < (long)a.n_rollouts * c.B) rollout_body<M, R>(c, a, (int)n);
 }
-// sum the per-cell cost statistics over t: REDUCE_PARTS lanes per trajectory, fixed summation order
+
+// Sum of the per-cell cost statistics over t: REDUCE_PARTS lanes per trajectory, fixed summation order; with `ms.alpha`
+// set (i2c_learn) the temperature M-step rides on it. The device form exchanges the partial sums through LDS; the host
+// form walks the same partition in the same order.
 constexpr int REDUCE_PARTS = 8;
+template <class M, typename R>
+I2C_FN void reduce_finish(const Consts<M, R>& c, const CellArgs<R>& a, const MstepArgs<R>& ms, const int T_mstep, const int b,
+                          const R m, const R v) {
+  a.term_stats[(long)c.B + b] = m;
+  a.term_stats[2 * (long)c.B + b] = v;
+  if (ms.alpha) {
+    Consts<M, R> cm = c;
+    cm.T = T_mstep;  // c.T is the number of summands here (cells or chunks), the M-step needs the horizon
+    mstep_body<M, R>(cm, ms, b);
+  }
+}
+#ifdef I2C_HOST_SIM
+template <class M, typename R>
+static int launch_reduce(const Consts<M, R>& c, const CellArgs<R>& a, const MstepArgs<R>& ms, const int T_mstep, void*) {
+  for (int b = 0; b < c.B; ++b) {
+    R m = R(0), v = R(0);
+    for (int q = 0; q < REDUCE_PARTS; ++q) {
+      R pm, pv;
+      reduce_partial<M, R>(c, a.cell_stats, b, q, REDUCE_PARTS, &pm, &pv);
+      m += pm;
+      v += pv;
+    }
+    reduce_finish<M, R>(c, a, ms, T_mstep, b, m, v);
+  }
+  return I2C_OK;
+}
+#else
 template <class M, typename R>
 __global__ __launch_bounds__(SWEEP_BLOCK* REDUCE_PARTS) void k_reduce(const Consts<M, R> c, const CellArgs<R> a,
                                                                       const MstepArgs<R> ms, const int T_mstep) {
@@ -98,49 +179,79 @@ __global__ __launch_bounds__(SWEEP_BLOCK* REDUCE_PARTS) void k_reduce(const Cons
   sv[threadIdx.y][threadIdx.x] = v;
   __syncthreads();
   if (threadIdx.y == 0 && b < c.B) {
+    m = sm[0][threadIdx.x];
+    v = sv[0][threadIdx.x];
 #pragma unroll
     for (int q = 1; q < REDUCE_PARTS; ++q) {
       m += sm[q][threadIdx.x];
       v += sv[q][threadIdx.x];
     }
-    a.term_stats[(long)c.B + b] = m;
-    a.term_stats[2 * (long)c.B + b] = v;
-    if (ms.alpha) {  // i2c_learn: the temperature M-step rides on the reduction (one launch less per EM iteration)
-      Consts<M, R> cm = c;
-      cm.T = T_mstep;  // c.T is the number of summands here (cells or chunks), the M-step needs the horizon
-      mstep_body<M, R>(cm, ms, b);
-    }
+    reduce_finish<M, R>(c, a, ms, T_mstep, b, m, v);
   }
 }
 template <class M, typename R>
-__global__ __launch_bounds__(SWEEP_BLOCK) void k_mstep(const Consts<M, R> c, const MstepArgs<R> a) {
-  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
-  if (b < c.B) mstep_body<M, R>(c, a, b);
+static int launch_reduce(const Consts<M, R>& c, const CellArgs<R>& a, const MstepArgs<R>& ms, const int T_mstep, void* stream) {
+  hipLaunchKernelGGL((k_reduce<M, R>), dim3((c.B + SWEEP_BLOCK - 1) / SWEEP_BLOCK), dim3(SWEEP_BLOCK, REDUCE_PARTS), 0,
+                     (hipStream_t)stream, c, a, ms, T_mstep);
+  return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
 }
-template <class M, typename R, bool GRID = false>
-__global__ __launch_bounds__(SWEEP_BLOCK) void k_propagate(const Consts<M, R> c, const PropArgs<R> a) {
-  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
-  if (b < c.B) propagate_body<M, R, GRID>(c, a, b);
+#endif
+
+// ---- group kernels (i2c_group.hpp): G lanes per trajectory, 64 / G trajectories per wavefront ------------------------
+// KIND selects the sweep; the bodies share their argument plumbing. Device: one wave per workgroup, the batch constants
+// and every group's exchange region in LDS. Host simulation: the G lanes of a group are G threads.
+enum { GK_FORWARD = 0, GK_BACKWARD = 1, GK_PROPAGATE = 2, GK_CKF = 3 };
+template <int KIND, class M, typename R, int G, class KC, class A>
+I2C_FN void group_body(const Consts<M, R>& c, const KC& kc, const A& a, const int b, const Grp<R, G>& g) {
+  if constexpr (KIND == GK_FORWARD) forward_group_body<M, R, G>(c, kc, a, b, g);
+  if constexpr (KIND == GK_BACKWARD) backward_group_body<M, R, G>(c, kc, a, b, g);
+  if constexpr (KIND == GK_PROPAGATE) propagate_group_body<M, R, G>(c, kc, a, b, g);
+  if constexpr (KIND == GK_CKF) ckf_group_body<M, R, G>(c, kc, a, b, g);
 }
-template <class M, typename R> struct ZetaArg {
-  R v[sym(M::NY)];
-};
-template <class M, typename R>
-__global__ __launch_bounds__(SWEEP_BLOCK) void k_ckf(const Consts<M, R> c, const ZetaArg<M, R> z, const CkfArgs<R> a) {
-  const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
-  if (b < c.B) ckf_filter_body<M, R>(c, z.v, a, b);
+#ifdef I2C_HOST_SIM
+template <int KIND, class M, typename R, int G, class A>
+static int launch_group(const Consts<M, R>& c, const ZetaArg<M, R>* zeta, const A& a, void*) {
+  GConst<M, R> kc;
+  gconst_fill<M, R>(kc, &c, zeta ? zeta->v : (const R*)nullptr, 0, 1);
+  for (int b = 0; b < c.B; ++b) {
+    std::vector<R> sh((size_t)Grp<R, G>::SIZE, R(0));
+    HostBarrier bar(G);
+    std::vector<std::thread> lanes;
+    for (int r = 0; r < G; ++r)
+      lanes.emplace_back([&, r] { group_body<KIND, M, R, G>(c, kc, a, b, Grp<R, G>{r, sh.data(), &bar}); });
+    for (auto& th : lanes) th.join();
+  }
+  return I2C_OK;
 }
-template <class M, typename R>
-__global__ __launch_bounds__(CELL_BLOCK) void k_mpc_shift(const Consts<M, R> c, const ShiftArgs<R> a) {
-  const int b = blockIdx.x * CELL_BLOCK + threadIdx.x;
-  if (b < c.B) mpc_shift_body<M, R>(c, a, blockIdx.y, b);
+#else
+template <int KIND, class M, typename R, int G, class A>
+__global__ __launch_bounds__(SWEEP_BLOCK) void k_group(const Consts<M, R> c, const ZetaArg<M, R> zeta, const int has_zeta, const A a) {
+  __shared__ GConst<M, R> kc;
+  __shared__ R sh[(SWEEP_BLOCK / G) * Grp<R, G>::SIZE];
+  {
+    // The batch constants are unpacked into LDS with per-lane indices, read straight from the kernel-argument segment:
+    // `c` is the first kernel parameter (offset 0), `zeta` follows it at its natural alignment.
+    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr size_t zoff = (sizeof(Consts<M, R>) + alignof(ZetaArg<M, R>) - 1) / alignof(ZetaArg<M, R>) * alignof(ZetaArg<M, R>);
+    gconst_fill<M, R>(kc, (const Consts<M, R>*)ka, has_zeta ? ((const ZetaArg<M, R>*)(ka + zoff))->v : (const R*)nullptr,
+                      (int)threadIdx.x, SWEEP_BLOCK);
+  }
+  __syncthreads();
+  const long lane = (long)blockIdx.x * SWEEP_BLOCK + threadIdx.x;
+  const long b = lane / G;
+  if (b >= c.B) return;
+  const Grp<R, G> g{(int)(threadIdx.x % G), (lds_ptr<R>)(sh + (threadIdx.x / G) * Grp<R, G>::SIZE)};
+  group_body<KIND, M, R, G>(c, kc, a, (int)b, g);
 }
-template <class M, typename R>
-__global__ __launch_bounds__(SWEEP_BLOCK) void k_rollout(const Consts<M, R> c, const RolloutArgs<R> a) {
-  const long n = (long)blockIdx.x * SWEEP_BLOCK + threadIdx.x;
-  if (n < (long)a.n_rollouts * c.B) rollout_body<M, R>(c, a, (int)n);
+template <int KIND, class M, typename R, int G, class A>
+static int launch_group(const Consts<M, R>& c, const ZetaArg<M, R>* zeta, const A& a, void* stream) {
+  ZetaArg<M, R> z{};
+  if (zeta) z = *zeta;
+  const long lanes = (long)c.B * G;
+  hipLaunchKernelGGL((k_group<KIND, M, R, G, A>), dim3((unsigned)((lanes + SWEEP_BLOCK - 1) / SWEEP_BLOCK)), dim3(SWEEP_BLOCK), 0,
+                     (hipStream_t)stream, c, z, zeta ? 1 : 0, a);
+  return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
 }
-static int launch_status() { return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH; }
 #endif
 
 template <typename R> static Rule<R> make_rule(const I2cProblem* p, int dim) {
@@ -236,63 +347,66 @@ template <class M> static size_t workspace_elems(int B, int T) {
 }
 
 // ---- per-(model, dtype) entry points ------------------------------------------------------
+// Which kernels serve a call:
+//   M::GROUP      lanes per trajectory of the model's group kernels (0: none compiled); fp64 only
+//   M::GROUP_ONLY the one-lane-per-trajectory kernels are NOT compiled for this model (d = nx + nu > 8 does not fit one
+//                 lane's registers): every call runs the group kernels
+//   I2cProblem.group_lanes   0: the model's default (group kernels iff GROUP_ONLY); G = M::GROUP: ask for the group
+//                 kernels; anything else: I2C_ENOTSUP
 template <class M, typename R> struct Impl {
   using C = Consts<M, R>;
+  static constexpr int G = M::GROUP;
+  static constexpr bool HAS_GROUP = G > 0 && sizeof(R) == 8;
+  static constexpr bool LANE = !M::GROUP_ONLY;  // one-lane-per-trajectory kernels exist
+
+  // 1: group kernels, 0: one lane per trajectory, < 0: error code
+  static int use_group(const I2cProblem* p) {
+    if (p->group_lanes == 0) return M::GROUP_ONLY ? (HAS_GROUP ? 1 : I2C_ENOTSUP) : 0;
+    return (HAS_GROUP && p->group_lanes == G) ? 1 : I2C_ENOTSUP;
+  }
+  // what the group form does not cover (yet): other inference rules, covariance control, non-diagonal cost weights
+  static int group_supported(const I2cProblem* p, const C& c) {
+    if (p->inference != I2C_INF_CUBATURE || p->has_x_terminal) return I2C_ENOTSUP;
+    if (!c.qr_diag || (c.has_Qf && !c.qf_diag)) return I2C_ENOTSUP;
+    return I2C_OK;
+  }
 
   static int forward(const I2cProblem* p, const void* prior, void* fwd, void* prior_out, int32_t* status,
                      void* stream) {
     const C c = make_consts<M, R>(p, 0.0, p->inference == I2C_INF_LINEARIZE ? p->expert_controller : 0);
     FwdArgs<R> a{(const R*)prior, (R*)fwd, (R*)prior_out, (const R*)p->x0, (const R*)p->sig_x0,
                  (const R*)p->z,  (const R*)p->alpha, (const R*)p->alpha_cell, p->feedforward, status};
-    if (p->inference == I2C_INF_LINEARIZE) {
-#ifdef I2C_HOST_SIM
-      (void)stream;
-      for (int b = 0; b < p->B; ++b) forward_lin_body<M, R>(c, a, b);
-      return I2C_OK;
-#else
-      hipLaunchKernelGGL((k_forward_lin<M, R>), dim3((p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK), dim3(SWEEP_BLOCK), 0,
-                         (hipStream_t)stream, c, a);
-      return launch_status();
-#endif
+    const int grp = use_group(p);
+    if (grp < 0) return grp;
+    if (grp) {
+      if constexpr (HAS_GROUP) {
+        const int rc = group_supported(p, c);
+        return rc != I2C_OK ? rc : launch_group<GK_FORWARD, M, R, G>(c, nullptr, a, stream);
+      }
     }
-    if (p->inference == I2C_INF_GAUSS_HERMITE) {
+    if constexpr (LANE) {
+      if (p->inference == I2C_INF_LINEARIZE) return launch(k_forward_lin<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+      if (p->inference == I2C_INF_GAUSS_HERMITE)
+        return launch(k_forward<M, R, false, true>, p->B, 1, SWEEP_BLOCK, stream, c, a, SWEEP_BLOCK);
 #ifdef I2C_HOST_SIM
-      (void)stream;
-      for (int b = 0; b < p->B; ++b) forward_sweep_body<M, R, false, true>(c, a, b);
-      return I2C_OK;
+      const int lanes = SWEEP_BLOCK;
 #else
-      hipLaunchKernelGGL((k_forward<M, R, false, true>), dim3((p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK), dim3(SWEEP_BLOCK),
-                         0, (hipStream_t)stream, c, a);
-      return launch_status();
+      const int lanes = sweep_lanes();
 #endif
+      const bool lean = c.rule_xu.unit && c.rule_x.unit && !c.z_per_cell && !a.alpha_cell && !a.prior_out;
+      if (lean) return launch(k_forward<M, R, true>, p->B, 1, lanes, stream, c, a, lanes);
+      return launch(k_forward<M, R, false>, p->B, 1, lanes, stream, c, a, lanes);
     }
-#ifdef I2C_HOST_SIM
-    (void)stream;
-    const bool lean = c.rule_xu.unit && c.rule_x.unit && !c.z_per_cell && !a.alpha_cell && !a.prior_out;
-    for (int b = 0; b < p->B; ++b) {
-      if (lean)
-        forward_sweep_body<M, R, true>(c, a, b);
-      else
-        forward_sweep_body<M, R, false>(c, a, b);
-    }
-    return I2C_OK;
-#else
-    const int lanes = sweep_lanes();
-    const int grid = (p->B + lanes - 1) / lanes;
-    const bool lean = c.rule_xu.unit && c.rule_x.unit && !c.z_per_cell && !a.alpha_cell && !a.prior_out;
-    if (lean)
-      hipLaunchKernelGGL((k_forward<M, R, true>), dim3(grid), dim3(lanes), 0, (hipStream_t)stream, c, a);
-    else
-      hipLaunchKernelGGL((k_forward<M, R, false>), dim3(grid), dim3(lanes), 0, (hipStream_t)stream, c, a);
-    return launch_status();
-#endif
+    return I2C_ENOTSUP;
   }
 
   // Measured on MI355X (tools/bench_models.py): below ~32k trajectories the sequential depth decides -> chunked.
   // Above, HBM traffic decides -> fused (264 instead of ~490 B/cell for the pendulum), except for the double cartpole,
   // whose fused cell (d = 7, nz = 9 with four trigonometric outputs) still spills ~400 B/lane: its chunk walk does not,
   // and stays the fastest schedule at every batch size (B = 32768: chunked 3.5, two-pass 5.8, fused 6.6 ms).
+  // Models that only have group kernels run the fused walk.
   static int schedule(int B, int T, int requested) {
+    if (M::GROUP_ONLY) return I2C_BWD_FUSED;
     int mode = requested;
     if (mode == I2C_BWD_AUTO)
       mode = B < I2C_BWD_FUSED_MIN_B ? I2C_BWD_CHUNKED : (M::FUSED_BACKWARD_FITS ? I2C_BWD_FUSED : I2C_BWD_CHUNKED);
@@ -321,140 +435,77 @@ template <class M, typename R> struct Impl {
     const C c = make_consts<M, R>(p, fuse ? fuse->tol : 0.0, 0);
     MstepArgs<R> ms{(const R*)term_stats, fuse ? (R*)p->alpha : nullptr, fuse ? (R*)fuse->stats_out : nullptr,
                     fuse ? fuse->update : 0};
-    if (p->inference == I2C_INF_LINEARIZE) {  // one schedule: a lane per trajectory walks T-1..0
-      if (M::NZT == 0) return I2C_EINVAL;  // no terminal observation: the reference fails at i2c.py:500-501
-      CellArgs<R> al{(const R*)fwd, (const R*)xm,    (const R*)p->z, (R*)post, (R*)zpost,
-                     (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   (const R*)p->alpha};
-#ifdef I2C_HOST_SIM
-      (void)stream;
-      for (int b = 0; b < p->B; ++b) backward_lin_body<M, R>(c, al, b);
-      return I2C_OK;
-#else
-      hipLaunchKernelGGL((k_bwd_lin<M, R>), dim3((p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK), dim3(SWEEP_BLOCK), 0,
-                         (hipStream_t)stream, c, al);
-      return launch_status();
-#endif
-    }
-    if (p->inference == I2C_INF_GAUSS_HERMITE) {  // one schedule: the fused walk with the grid transform
-      CellArgs<R> ag{(const R*)fwd, (const R*)xm,    (const R*)p->z, (R*)post, (R*)zpost,
-                     (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   (const R*)p->alpha};
-#ifdef I2C_HOST_SIM
-      (void)stream;
-      for (int b = 0; b < p->B; ++b) backward_fused_body<M, R, true>(c, ag, b);
-      return I2C_OK;
-#else
-      hipLaunchKernelGGL((k_bwd_fused<M, R, true>), dim3((p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK), dim3(SWEEP_BLOCK), 0,
-                         (hipStream_t)stream, c, ag);
-      return launch_status();
-#endif
-    }
-    const int mode = pick_mode(p);
-    if (mode == I2C_BWD_TWO_PASS && (!xm || !cell_stats)) return I2C_EINVAL;
-    ScanArgs<R> s{(const R*)fwd, (R*)xm, (R*)p->temp, status};
     CellArgs<R> a{(const R*)fwd, (const R*)xm,   (const R*)p->z, (R*)post,  (R*)zpost,
                   (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   (const R*)p->alpha};
-    ChunkArgs<R> ch{a, nullptr, nullptr, nullptr, 0, 0};
-    C cr = c;  // reduction over chunks instead of cells: same kernel, T := number of chunks
-    if (mode == I2C_BWD_CHUNKED) {
-      chunk_geometry(p->B, p->T, &ch.n_chunks, &ch.chunk_len);
-      constexpr int NX = M::NX;
-      ch.comp = (R*)p->work;
-      ch.bnd = ch.comp + (size_t)ch.n_chunks * (NX + NX * NX + sym(NX)) * p->B;
-      ch.part = ch.bnd + (size_t)ch.n_chunks * (NX + sym(NX)) * p->B;
-      cr.T = ch.n_chunks;
-    }
-    CellArgs<R> ared = a;
-    ared.cell_stats = ch.part;
-#ifdef I2C_HOST_SIM
-    (void)stream;
-    auto reduce_all = [&](const C& cc, const R* stats) {  // same partition and summation order as k_reduce
-      for (int b = 0; b < p->B; ++b) {
-        R m = R(0), v = R(0);
-        for (int q = 0; q < 8; ++q) {
-          R pm, pv;
-          reduce_partial<M, R>(cc, stats, b, q, 8, &pm, &pv);
-          m += pm;
-          v += pv;
-        }
-        a.term_stats[(long)p->B + b] = m;
-        a.term_stats[2 * (long)p->B + b] = v;
-        if (ms.alpha) mstep_body<M, R>(c, ms, b);
+    const int grp = use_group(p);
+    if (grp < 0) return grp;
+    if (grp) {  // one schedule: the group walks T-1..0 (the fused form); backward_mode is ignored
+      if constexpr (HAS_GROUP) {
+        const int rc = group_supported(p, c);
+        return rc != I2C_OK ? rc : launch_group<GK_BACKWARD, M, R, G>(c, nullptr, a, stream);
       }
+    }
+    if constexpr (LANE) {
+      if (p->inference == I2C_INF_LINEARIZE) {  // one schedule: a lane per trajectory walks T-1..0
+        if (M::NZT == 0) return I2C_EINVAL;     // no terminal observation: the reference fails at i2c.py:500-501
+        return launch(k_bwd_lin<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+      }
+      if (p->inference == I2C_INF_GAUSS_HERMITE)  // one schedule: the fused walk with the grid transform
+        return launch(k_bwd_fused<M, R, true>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+      const int mode = pick_mode(p);
+      if (mode == I2C_BWD_FUSED) return launch(k_bwd_fused<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+      if (mode == I2C_BWD_CHUNKED) {
+        ChunkArgs<R> ch{a, nullptr, nullptr, nullptr, 0, 0};
+        chunk_geometry(p->B, p->T, &ch.n_chunks, &ch.chunk_len);
+        constexpr int NX = M::NX;
+        ch.comp = (R*)p->work;
+        ch.bnd = ch.comp + (size_t)ch.n_chunks * (NX + NX * NX + sym(NX)) * p->B;
+        ch.part = ch.bnd + (size_t)ch.n_chunks * (NX + sym(NX)) * p->B;
+        C cr = c;  // reduction over chunks instead of cells: same kernel, T := number of chunks
+        cr.T = ch.n_chunks;
+        CellArgs<R> ared = a;
+        ared.cell_stats = ch.part;
+        int rc = launch(k_chunk_compose<M, R>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
+        if (rc == I2C_OK) rc = launch(k_chunk_stitch<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, ch);
+        if (rc == I2C_OK) rc = launch(k_chunk_walk<M, R>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
+        if (rc == I2C_OK) rc = launch_reduce<M, R>(cr, ared, ms, p->T, stream);
+        if (fuse) fuse->done = true;
+        return rc;
+      }
+      if (!xm || !cell_stats) return I2C_EINVAL;  // two-pass needs both as workspace
+      ScanArgs<R> sc{(const R*)fwd, (R*)xm, (R*)p->temp, status};
+      int rc = launch(k_scan<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, sc);
+      if (rc == I2C_OK) rc = launch(k_cell<M, R>, p->B, p->T, CELL_BLOCK, stream, c, a);
+      if (rc == I2C_OK) rc = launch_reduce<M, R>(c, a, ms, p->T, stream);
       if (fuse) fuse->done = true;
-    };
-    if (mode == I2C_BWD_FUSED) {
-      for (int b = 0; b < p->B; ++b) backward_fused_body<M, R>(c, a, b);
-      return I2C_OK;
+      return rc;
     }
-    if (mode == I2C_BWD_CHUNKED) {
-      for (int q = 0; q < ch.n_chunks; ++q)
-        for (int b = 0; b < p->B; ++b) chunk_compose_body<M, R>(c, ch, q, b);
-      for (int b = 0; b < p->B; ++b) chunk_stitch_body<M, R>(c, ch, b);
-      for (int q = 0; q < ch.n_chunks; ++q)
-        for (int b = 0; b < p->B; ++b) chunk_walk_body<M, R>(c, ch, q, b);
-      reduce_all(cr, ch.part);
-      return I2C_OK;
-    }
-    for (int b = 0; b < p->B; ++b) backward_scan_body<M, R>(c, s, b);
-    for (int t = 0; t < p->T; ++t)
-      for (int b = 0; b < p->B; ++b) backward_cell_body<M, R>(c, a, t, b);
-    reduce_all(c, a.cell_stats);
-    return I2C_OK;
-#else
-    const int grid = (p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
-    hipStream_t st = (hipStream_t)stream;
-    if (mode == I2C_BWD_FUSED) {
-      hipLaunchKernelGGL((k_bwd_fused<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, st, c, a);
-      return launch_status();
-    }
-    if (mode == I2C_BWD_CHUNKED) {
-      hipLaunchKernelGGL((k_chunk_compose<M, R>), dim3(grid, ch.n_chunks), dim3(SWEEP_BLOCK), 0, st, c, ch);
-      hipLaunchKernelGGL((k_chunk_stitch<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, st, c, ch);
-      hipLaunchKernelGGL((k_chunk_walk<M, R>), dim3(grid, ch.n_chunks), dim3(SWEEP_BLOCK), 0, st, c, ch);
-      hipLaunchKernelGGL((k_reduce<M, R>), dim3(grid), dim3(SWEEP_BLOCK, REDUCE_PARTS), 0, st, cr, ared, ms, p->T);
-      if (fuse) fuse->done = true;
-      return launch_status();
-    }
-    hipLaunchKernelGGL((k_scan<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, st, c, s);
-    if (launch_status() != I2C_OK) return I2C_ELAUNCH;
-    const dim3 cgrid((p->B + CELL_BLOCK - 1) / CELL_BLOCK, p->T);
-    hipLaunchKernelGGL((k_cell<M, R>), cgrid, dim3(CELL_BLOCK), 0, st, c, a);
-    if (launch_status() != I2C_OK) return I2C_ELAUNCH;
-    hipLaunchKernelGGL((k_reduce<M, R>), dim3(grid), dim3(SWEEP_BLOCK, REDUCE_PARTS), 0, st, c, a, ms, p->T);
-    if (fuse) fuse->done = true;
-    return launch_status();
-#endif
+    return I2C_ENOTSUP;
   }
 
   static int riccati(const I2cProblem* p, const void* prior_out, const void* fwd, const void* xm, void* post, void* ric,
                      int32_t* status, void* stream) {
-    const C c = make_consts<M, R>(p, 0.0, 0);
-    RiccatiArgs<R> a{(const R*)prior_out, (const R*)fwd, (const R*)xm, (const R*)p->z, (const R*)p->alpha,
-                     (R*)post,            (R*)ric,       status};
-#ifdef I2C_HOST_SIM
-    (void)stream;
-    for (int b = 0; b < p->B; ++b) riccati_body<M, R>(c, a, b);
-    return I2C_OK;
-#else
-    hipLaunchKernelGGL((k_riccati<M, R>), dim3((p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK), dim3(SWEEP_BLOCK), 0,
-                       (hipStream_t)stream, c, a);
-    return launch_status();
-#endif
+    if constexpr (LANE) {
+      if (use_group(p) != 0) return I2C_ENOTSUP;
+      const C c = make_consts<M, R>(p, 0.0, 0);
+      RiccatiArgs<R> a{(const R*)prior_out, (const R*)fwd, (const R*)xm, (const R*)p->z, (const R*)p->alpha,
+                       (R*)post,            (R*)ric,       status};
+      return launch(k_riccati<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+    }
+    return I2C_ENOTSUP;
   }
 
   static int mstep(const I2cProblem* p, const void* term_stats, double tol, int update, void* stats_out,
                    void* stream) {
     const C c = make_consts<M, R>(p, tol, 0);
     MstepArgs<R> a{(const R*)term_stats, (R*)p->alpha, (R*)stats_out, update};
-#ifdef I2C_HOST_SIM
-    (void)stream;
-    for (int b = 0; b < p->B; ++b) mstep_body<M, R>(c, a, b);
-    return I2C_OK;
-#else
-    const int grid = (p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
-    hipLaunchKernelGGL((k_mstep<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, a);
-    return launch_status();
-#endif
+    return launch(k_mstep<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+  }
+
+  // _update_priors (i2c.py:1210-1213): cells with index <= tau switch to feedback mode
+  static int to_feedback(const I2cProblem* p, int tau, void* stream) {
+    const size_t n = (size_t)(tau + 1 < p->T ? tau + 1 : p->T);
+    return clear_bytes(const_cast<uint8_t*>(p->feedforward), n, stream);
   }
 
   static int learn(const I2cProblem* p, void* post, void* fwd, void* xm, void* zpost, void* cell_stats,
@@ -466,18 +517,13 @@ template <class M, typename R> struct Impl {
       MstepFuse fuse{tol, 1, (R*)stats_hist + (size_t)it * 4 * p->B, false};
       rc = backward_impl(p, fwd, xm, post, zpost, cell_stats, term_stats, status, stream, &fuse);
       if (rc != I2C_OK) return rc;
-      if (!fuse.done) {  // fused / Linearize / Gauss-Hermite schedules have no reduction kernel
+      if (!fuse.done) {  // fused / group / Linearize / Gauss-Hermite schedules have no reduction kernel
         rc = mstep(p, term_stats, tol, 1, (R*)stats_hist + (size_t)it * 4 * p->B, stream);
         if (rc != I2C_OK) return rc;
       }
-      if (tau > 0 && it == 0) {  // _update_priors: cells with index <= tau switch to feedback mode (idempotent: once per call)
-        const size_t n = (size_t)(tau + 1 < p->T ? tau + 1 : p->T);
-#ifdef I2C_HOST_SIM
-        std::memset(const_cast<uint8_t*>(p->feedforward), 0, n);
-#else
-        if (hipMemsetAsync(const_cast<uint8_t*>(p->feedforward), 0, n, (hipStream_t)stream) != hipSuccess)
-          return I2C_ELAUNCH;
-#endif
+      if (tau > 0 && it == 0) {  // idempotent: once per call
+        rc = to_feedback(p, tau, stream);
+        if (rc != I2C_OK) return rc;
       }
     }
     return I2C_OK;
@@ -485,21 +531,17 @@ template <class M, typename R> struct Impl {
 
   static int ckf(const I2cProblem* p, const double* sig_zeta, const void* y, const void* u, void* mu, void* cov,
                  int32_t* status, void* stream) {
-  const Consts<M, R> c = make_consts<M, R>(p, 0.0, 0);
-  R zeta[sym(M::NY)];
-  for (int i = 0; i < sym(M::NY); ++i) zeta[i] = (R)sig_zeta[i];
-  CkfArgs<R> a{(const R*)y, (const R*)u, (R*)mu, (R*)cov, status};
-#ifdef I2C_HOST_SIM
-  (void)stream;
-  for (int b = 0; b < p->B; ++b) ckf_filter_body<M, R>(c, zeta, a, b);
-  return I2C_OK;
-#else
-  ZetaArg<M, R> z;
-  for (int i = 0; i < sym(M::NY); ++i) z.v[i] = zeta[i];
-  const int grid = (p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
-  hipLaunchKernelGGL((k_ckf<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, z, a);
-  return launch_status();
-#endif
+    const C c = make_consts<M, R>(p, 0.0, 0);
+    ZetaArg<M, R> z;
+    for (int i = 0; i < sym(M::NY); ++i) z.v[i] = (R)sig_zeta[i];
+    CkfArgs<R> a{(const R*)y, (const R*)u, (R*)mu, (R*)cov, status};
+    const int grp = use_group(p);
+    if (grp < 0) return grp;
+    if (grp) {
+      if constexpr (HAS_GROUP) return launch_group<GK_CKF, M, R, G>(c, &z, a, stream);
+    }
+    if constexpr (LANE) return launch(k_ckf<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, z, a);
+    return I2C_ENOTSUP;
   }
 
   // One control step of the MPC loop enqueued by one call (i2c/policy/mpc.py:156-182): filter, n_iter x (forward,
@@ -510,29 +552,14 @@ template <class M, typename R> struct Impl {
     for (int it = 0; it < m->n_iter && rc == I2C_OK; ++it) {
       rc = forward(p, m->post, m->fwd, nullptr, m->status, stream);
       if (rc == I2C_OK) rc = backward(p, m->fwd, m->xm, m->post, m->zpost, m->cell_stats, m->term_stats, m->status, stream);
-      if (rc == I2C_OK && m->tau > 0) {  // _update_priors: cells with index <= tau switch to feedback mode
-        const size_t n = (size_t)(m->tau + 1 < p->T ? m->tau + 1 : p->T);
-#ifdef I2C_HOST_SIM
-        std::memset(const_cast<uint8_t*>(p->feedforward), 0, n);
-#else
-        if (hipMemsetAsync(const_cast<uint8_t*>(p->feedforward), 0, n, (hipStream_t)stream) != hipSuccess) rc = I2C_ELAUNCH;
-#endif
-      }
+      if (rc == I2C_OK && m->tau > 0) rc = to_feedback(p, m->tau, stream);
     }
     if (rc != I2C_OK) return rc;
     const C c = make_consts<M, R>(p, 0.0, 0);
     ShiftArgs<R> a{(const R*)m->post,       (R*)m->post_next, (const R*)m->cell_init, (const R*)p->alpha_cell, (R*)m->alpha_cell_next,
                    (const R*)m->alpha_init, (const R*)p->z,   (R*)m->z_next,          (const R*)m->z_new,      p->feedforward,
                    m->feedforward_next,     (R*)m->action};
-#ifdef I2C_HOST_SIM
-    for (int t = 0; t < p->T; ++t)
-      for (int b = 0; b < p->B; ++b) mpc_shift_body<M, R>(c, a, t, b);
-    return I2C_OK;
-#else
-    const dim3 grid((p->B + CELL_BLOCK - 1) / CELL_BLOCK, p->T);
-    hipLaunchKernelGGL((k_mpc_shift<M, R>), grid, dim3(CELL_BLOCK), 0, (hipStream_t)stream, c, a);
-    return launch_status();
-#endif
+    return launch(k_mpc_shift<M, R>, p->B, p->T, CELL_BLOCK, stream, c, a);
   }
 
   static int rollout(const I2cProblem* p, const void* post, int n_rollouts, int policy, const void* eps_x0,
@@ -541,16 +568,7 @@ template <class M, typename R> struct Impl {
     const C c = make_consts<M, R>(p, 0.0, 0);
     RolloutArgs<R> a{(const R*)post, (const R*)p->x0, (const R*)p->sig_x0, (const R*)eps_x0, (const R*)eps_x,
                      (const R*)eps_u, (R*)xu, (R*)z, (R*)x_final, (R*)z_term, n_rollouts, policy};
-    const long N = (long)n_rollouts * p->B;
-#ifdef I2C_HOST_SIM
-    (void)stream;
-    for (long n = 0; n < N; ++n) rollout_body<M, R>(c, a, (int)n);
-    return I2C_OK;
-#else
-    const int grid = (int)((N + SWEEP_BLOCK - 1) / SWEEP_BLOCK);
-    hipLaunchKernelGGL((k_rollout<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, a);
-    return launch_status();
-#endif
+    return launch(k_rollout<M, R>, (long)n_rollouts * p->B, 1, SWEEP_BLOCK, stream, c, a);
   }
 
   static int propagate(const I2cProblem* p, const void* post, void* prop, void* prop_stats, int use_expert,
@@ -558,24 +576,19 @@ template <class M, typename R> struct Impl {
     const C c = make_consts<M, R>(p, 0.0, use_expert);
     PropArgs<R> a{(const R*)post, (R*)prop, (R*)prop_stats, (const R*)p->x0, (const R*)p->sig_x0,
                   (const R*)p->z, p->feedforward, status};
-    const bool gh = p->inference == I2C_INF_GAUSS_HERMITE;
-#ifdef I2C_HOST_SIM
-    (void)stream;
-    for (int b = 0; b < p->B; ++b) {
-      if (gh)
-        propagate_body<M, R, true>(c, a, b);
-      else
-        propagate_body<M, R>(c, a, b);
+    const int grp = use_group(p);
+    if (grp < 0) return grp;
+    if (grp) {
+      if constexpr (HAS_GROUP) {
+        const int rc = group_supported(p, c);
+        return rc != I2C_OK ? rc : launch_group<GK_PROPAGATE, M, R, G>(c, nullptr, a, stream);
+      }
     }
-    return I2C_OK;
-#else
-    const int grid = (p->B + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
-    if (gh)
-      hipLaunchKernelGGL((k_propagate<M, R, true>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, a);
-    else
-      hipLaunchKernelGGL((k_propagate<M, R>), dim3(grid), dim3(SWEEP_BLOCK), 0, (hipStream_t)stream, c, a);
-    return launch_status();
-#endif
+    if constexpr (LANE) {
+      if (p->inference == I2C_INF_GAUSS_HERMITE) return launch(k_propagate<M, R, true>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+      return launch(k_propagate<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+    }
+    return I2C_ENOTSUP;
   }
 };
 
@@ -592,6 +605,8 @@ template <class M> static void fill_dims(I2cDims* d) {
   d->e_prop = C::E_PROP;
   d->n_params = M::NP;
   d->ny = M::NY;
+  d->group_lanes = M::GROUP;
+  d->group_only = M::GROUP_ONLY ? 1 : 0;
 }
 
 template <class M, typename R> const ModelOps* make_ops() {

@@ -15,6 +15,8 @@ namespace i2c {
 struct Pendulum {
   static constexpr int ID = 0, NX = 2, NU = 1, NZ = 4, NZT = 3, NP = 0, NA = 1;
   static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
+  static constexpr int GROUP = 4;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
+  static constexpr bool GROUP_ONLY = false;
   I2C_HD static constexpr int ang(int) { return 0; }
   // z = [sin th, cos th, thd, u],  zT = [sin th, cos th, thd]
   I2C_HD static constexpr int obs_lin(int k) { return k < 2 ? -1 : k - 1; }
@@ -56,6 +58,8 @@ struct Pendulum {
 struct PendulumActReg {
   static constexpr int ID = 1, NX = 2, NU = 1, NZ = 1, NZT = 0, NP = 0, NA = 1;
   static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
+  static constexpr int GROUP = 4;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
+  static constexpr bool GROUP_ONLY = false;
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int) { return 2; }  // z = [u]
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -78,6 +82,8 @@ struct PendulumActReg {
 struct Cartpole {
   static constexpr int ID = 2, NX = 4, NU = 1, NZ = 6, NZT = 5, NP = 0, NA = 1;
   static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
+  static constexpr int GROUP = 8;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
+  static constexpr bool GROUP_ONLY = false;
   I2C_HD static constexpr int ang(int) { return 1; }
   // z = [x, sin th, cos th, xd, thd, u],  zT = [x, sin th, cos th, xd, thd]
   I2C_HD static constexpr int obs_lin(int k) { return k == 0 ? 0 : (k < 3 ? -1 : k - 1); }
@@ -127,6 +133,8 @@ struct Cartpole {
 struct DoubleCartpole {
   static constexpr int ID = 3, NX = 6, NU = 1, NZ = 9, NZT = 8, NP = 0, NA = 2;
   static constexpr bool FUSED_BACKWARD_FITS = false;  // see Impl::schedule (i2c_impl.hpp)
+  static constexpr int GROUP = 16;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
+  static constexpr bool GROUP_ONLY = false;
   I2C_HD static constexpr int ang(int a) { return a == 0 ? 1 : 2; }
   // z = [x, sin th1, cos th1, sin th2, cos th2, xd, th1d, th2d, u],  zT = z without u
   I2C_HD static constexpr int obs_lin(int k) { return k == 0 ? 0 : (k < 5 ? -1 : k - 2); }
@@ -202,6 +210,8 @@ struct DoubleCartpole {
 struct Linear {
   static constexpr int ID = 4, NX = 2, NU = 1, NZ = 3, NZT = 2, NP = 8, NA = 0;
   static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
+  static constexpr int GROUP = 4;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
+  static constexpr bool GROUP_ONLY = false;
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -233,6 +243,8 @@ struct Linear {
 struct LinearMinEnergy {
   static constexpr int ID = 5, NX = 2, NU = 1, NZ = 1, NZT = 2, NP = 8, NA = 0;
   static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
+  static constexpr int GROUP = 0;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
+  static constexpr bool GROUP_ONLY = false;
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int) { return 2; }  // z = [u], zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -265,6 +277,8 @@ struct LinearMinEnergy {
 struct Quadrotor {
   static constexpr int ID = 6, NX = 6, NU = 2, NZ = 8, NZT = 6, NP = 3, NA = 1;
   static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
+  static constexpr int GROUP = 8;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
+  static constexpr bool GROUP_ONLY = false;
   I2C_HD static constexpr int ang(int) { return 2; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -310,6 +324,80 @@ struct Quadrotor {
   template <typename R> I2C_FN void observe_terminal(const R*, const R* x, const R*, const R*, R* z) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) z[i] = x[i];
+  }
+};
+
+// Build-defined 12-state quadrotor (BASELINE config 4 names nx = 12; the reference only has the planar Box2D body of
+// scripts/mpc_state_est/mpc_quad.py:219-383, so, like Quadrotor above, this is an analytic model with the reference's
+// plugin interface). State x = [p (3) | roll, pitch, yaw | v (3, world) | body rates (3)], action = four rotor thrusts
+// clipped to [0, u_max], "+" configuration: roll torque arm (f2 - f4), pitch torque arm (f3 - f1), yaw torque
+// kq (f1 - f2 + f3 - f4). Integrator as the planar model (Box2D's order for a free body): velocities first
+// (semi-implicit Euler, angular damping as 1 / (1 + dt c)), then positions and Euler angles with the NEW velocities.
+// observe = identity on (x, u), observe_terminal = identity on x, measure = [p | angles | body rates].
+// params = {mass, Ixx, Iyy, Izz, u_max}. d = 16: only the group kernels are compiled (GROUP_ONLY).
+struct Quadrotor12 {
+  static constexpr int ID = 7, NX = 12, NU = 4, NZ = 16, NZT = 12, NP = 5, NA = 3;
+  static constexpr bool FUSED_BACKWARD_FITS = true;
+  static constexpr int GROUP = 16;
+  static constexpr bool GROUP_ONLY = true;
+  I2C_HD static constexpr int ang(int a) { return 3 + a; }
+  I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
+  I2C_HD static constexpr int obs_dep(int) { return 0; }
+  I2C_HD static constexpr int term_lin(int k) { return k; }
+  I2C_HD static constexpr int term_dep(int) { return 0; }
+  static constexpr int NY = 9;  // y = [p, angles, body rates]
+  I2C_HD static constexpr int meas_lin(int k) { return k < 6 ? k : k + 3; }
+  I2C_HD static constexpr int meas_dep(int) { return 0; }
+  template <typename R> I2C_FN void measure(const R*, const R* x, const R*, const R*, R* y) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] = x[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) y[6 + i] = x[9 + i];
+  }
+  template <typename R> I2C_FN void dynamics(const R* p, const R* xu, const R* sn, const R* cs, R* xn) {
+    const R dt = R(0.05), arm = R(0.25), kq = R(0.05), ang_damp = R(0.5), grav = R(9.81);
+    const R mass = p[0], Ixx = p[1], Iyy = p[2], Izz = p[3], u_max = p[4];
+    const R f1 = r_clip(xu[12], R(0), u_max), f2 = r_clip(xu[13], R(0), u_max);
+    const R f3 = r_clip(xu[14], R(0), u_max), f4 = r_clip(xu[15], R(0), u_max);
+    const R thrust = (f1 + f2) + (f3 + f4);
+    const R tx = arm * (f2 - f4), ty = arm * (f3 - f1), tz = kq * ((f1 - f2) + (f3 - f4));
+    const R sph = sn[0], cph = cs[0], sth = sn[1], cth = cs[1], sps = sn[2], cps = cs[2];
+    const R wx = xu[9], wy = xu[10], wz = xu[11];
+    // body rates: I w' = tau - w x (I w)
+    const R damp = R(1) / (R(1) + dt * ang_damp);
+    const R wxn = (wx + dt * (tx - (Izz - Iyy) * wy * wz) / Ixx) * damp;
+    const R wyn = (wy + dt * (ty - (Ixx - Izz) * wz * wx) / Iyy) * damp;
+    const R wzn = (wz + dt * (tz - (Iyy - Ixx) * wx * wy) / Izz) * damp;
+    // world-frame acceleration: thrust along the body z axis R(roll, pitch, yaw) e3
+    const R am = thrust / mass;
+    const R vxn = xu[6] + dt * am * (cph * sth * cps + sph * sps);
+    const R vyn = xu[7] + dt * am * (cph * sth * sps - sph * cps);
+    const R vzn = xu[8] + dt * (am * (cph * cth) - grav);
+    // Euler-angle rates from the new body rates
+    const R icth = r_rcp(cth), tth = sth * icth;
+    const R roll_d = wxn + tth * (sph * wyn + cph * wzn);
+    const R pitch_d = cph * wyn - sph * wzn;
+    const R yaw_d = (sph * wyn + cph * wzn) * icth;
+    xn[0] = xu[0] + dt * vxn;
+    xn[1] = xu[1] + dt * vyn;
+    xn[2] = xu[2] + dt * vzn;
+    xn[3] = xu[3] + dt * roll_d;
+    xn[4] = xu[4] + dt * pitch_d;
+    xn[5] = xu[5] + dt * yaw_d;
+    xn[6] = vxn;
+    xn[7] = vyn;
+    xn[8] = vzn;
+    xn[9] = wxn;
+    xn[10] = wyn;
+    xn[11] = wzn;
+  }
+  template <typename R> I2C_FN void observe(const R*, const R* xu, const R*, const R*, R* z) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = xu[i];
+  }
+  template <typename R> I2C_FN void observe_terminal(const R*, const R* x, const R*, const R*, R* z) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) z[i] = x[i];
   }
 };
 

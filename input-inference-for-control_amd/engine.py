@@ -54,7 +54,7 @@ class BatchedI2c:
                  mu_x_terminal=None, sig_x_terminal=None, quad=(1.0, 0.0, 0.0), x0=None, sig_x0=None,
                  z_traj=None, batch=None, dtype=torch.float64, device=None, lib=None, dtemp=1.0,
                  keep_zpost=True, keep_prior=False, keep_xm=True, backward_mode="auto", inference="cubature",
-                 gh_degree=None):
+                 gh_degree=None, group_lanes=0):
         self.lib = lib if lib is not None else _native.load_library()
         if device is None:
             device = "cpu" if self.lib.is_host_sim else "cuda"
@@ -74,6 +74,14 @@ class BatchedI2c:
         assert (nx, nu, nz) == (model.dim_x, model.dim_u, model.dim_z), "model plugin / library dimension mismatch"
         self.nx, self.nu, self.nz, self.nzt, self.d = nx, nu, nz, nzt, nx + nu
         self.H = T = int(horizon)
+        # group kernels (csrc/i2c_group.hpp): `group_lanes` lanes of a wavefront per trajectory. 0 = the model's default
+        # (one lane per trajectory, except for models that only have group kernels); True = the model's group width.
+        if group_lanes is True:
+            group_lanes = dims.group_lanes
+        self.group_lanes = int(group_lanes or 0)
+        if self.group_lanes not in (0, dims.group_lanes):
+            raise ValueError(f"group_lanes={self.group_lanes}: this model's group kernels use {dims.group_lanes} lanes")
+        self.uses_group_kernels = bool(self.group_lanes or dims.group_only)
 
         mu_u = np.asarray(mu_u, dtype=np.float64)
         if mu_u.ndim == 2:
@@ -170,8 +178,8 @@ class BatchedI2c:
         mode = self.lib.i2c_backward_schedule(self.model_id, B, T, self.backward_mode)  # resolves "auto"
         if mode not in (_native.BWD_TWO_PASS, _native.BWD_FUSED, _native.BWD_CHUNKED):
             raise RuntimeError("i2c_backward_schedule() returned %d" % mode)
-        if self.linearize or self.gauss_hermite:
-            mode = _native.BWD_FUSED  # these inference methods have one backward schedule: a lane per trajectory
+        if self.linearize or self.gauss_hermite or self.uses_group_kernels:
+            mode = _native.BWD_FUSED  # one backward schedule: a lane (or a group of lanes) per trajectory walks T-1..0
         self.fused_backward = mode == _native.BWD_FUSED
         self.backward_schedule = {_native.BWD_TWO_PASS: "two_pass", _native.BWD_FUSED: "fused", _native.BWD_CHUNKED: "chunked"}[mode]
         # the two-pass backward needs xm / cell_stats as workspace; the fused and chunked ones only write xm on request
@@ -231,6 +239,7 @@ class BatchedI2c:
         p.inference = (_native.INF_LINEARIZE if self.linearize else
                        _native.INF_GAUSS_HERMITE if self.gauss_hermite else _native.INF_CUBATURE)
         p.gh_degree = self.gh_degree
+        p.group_lanes = self.group_lanes
         if self.gauss_hermite:
             gx, gw = np.polynomial.hermite.hermgauss(self.gh_degree)  # exp_types.py:57
             for i in range(self.gh_degree):

@@ -407,6 +407,70 @@ class PlanarQuadrotor(KnownModel):
                                 x[:, 3] + d * s * w, x[:, 4] - d * c * w, x[:, 3] + d - s * w, x[:, 4] + d + c * w))
 
 
+class Quadrotor12(KnownModel):
+    """Build-defined 12-state, 4-rotor quadrotor (BASELINE config 4: nx = 12) with the plugin interface of the reference's
+    QuadrotorDef (scripts/mpc_state_est/mpc_quad.py:219-383); see csrc/i2c_models.hpp. Runs on the group kernels only."""
+
+    name = "3D Quadrotor"
+    model_name = "Quadrotor12"
+    model_id = 7
+    dim_x, dim_u, dim_z, dim_y = 12, 4, 16, 9
+    dim_z_term = 12
+    dt, arm, kq, ang_damp, grav = 0.05, 0.25, 0.05, 0.5, 9.81
+    mass, Ixx, Iyy, Izz, force_mx = 1.0, 0.02, 0.02, 0.04, 6.0
+
+    def __init__(self, model=None, model_def=None):
+        super().__init__(model, model_def)
+        self.x0 = np.zeros((12, 1))
+        self.sig_x0 = 1e-5 * np.eye(12)
+        self.sig_eta = np.diag([1e-6] * 6 + [1e-4] * 6)
+        self.xag = np.array([[1.0, 1.0, 1.0] + [0.0] * 9]).T
+        self.sig_zeta = None  # set by the experiment, as mpc_quad.py:552-556
+        self.xu_lim = np.array([[-_INF] * 12 + [0.0] * 4, [_INF] * 12 + [self.force_mx] * 4])
+
+    @property
+    def gravity(self):
+        return self.grav * self.mass
+
+    @property
+    def zg_term(self):
+        return self.xag
+
+    def device_params(self):
+        return [self.mass, self.Ixx, self.Iyy, self.Izz, self.force_mx]
+
+    def dynamics(self, xu):
+        xu = np.asarray(xu, dtype=float)
+        f1, f2, f3, f4 = (np.clip(xu[:, 12 + i], 0.0, self.force_mx) for i in range(4))
+        thrust = (f1 + f2) + (f3 + f4)
+        torque = (self.arm * (f2 - f4), self.arm * (f3 - f1), self.kq * ((f1 - f2) + (f3 - f4)))
+        s, c = np.sin(xu[:, 3:6]), np.cos(xu[:, 3:6])
+        w = xu[:, 9:12]
+        damp = 1.0 / (1.0 + self.dt * self.ang_damp)
+        inertia = (self.Ixx, self.Iyy, self.Izz)
+        gyro = ((self.Izz - self.Iyy) * w[:, 1] * w[:, 2], (self.Ixx - self.Izz) * w[:, 2] * w[:, 0],
+                (self.Iyy - self.Ixx) * w[:, 0] * w[:, 1])
+        wn = [(w[:, i] + self.dt * (torque[i] - gyro[i]) / inertia[i]) * damp for i in range(3)]
+        am = thrust / self.mass
+        vn = [xu[:, 6] + self.dt * am * (c[:, 0] * s[:, 1] * c[:, 2] + s[:, 0] * s[:, 2]),
+              xu[:, 7] + self.dt * am * (c[:, 0] * s[:, 1] * s[:, 2] - s[:, 0] * c[:, 2]),
+              xu[:, 8] + self.dt * (am * (c[:, 0] * c[:, 1]) - self.grav)]
+        mix = s[:, 0] * wn[1] + c[:, 0] * wn[2]
+        rates = [wn[0] + (s[:, 1] / c[:, 1]) * mix, c[:, 0] * wn[1] - s[:, 0] * wn[2], mix / c[:, 1]]
+        return np.column_stack([xu[:, i] + self.dt * vn[i] for i in range(3)]
+                               + [xu[:, 3 + i] + self.dt * rates[i] for i in range(3)] + vn + wn)
+
+    def observe(self, xu):
+        return np.array(xu, dtype=float)
+
+    def observe_terminal(self, x):
+        return np.array(x, dtype=float)
+
+    def measure(self, x):
+        x = np.asarray(x, dtype=float)
+        return np.column_stack((x[:, :6], x[:, 9:12]))
+
+
 ENVIRONMENTS = {
     "LinearKnown": LinearExact,
     "LinearKnownMinimumEnergy": LinearMinimumEnergy,
@@ -415,6 +479,7 @@ ENVIRONMENTS = {
     "CartpoleKnown": CartpoleKnown,
     "DoubleCartpoleKnown": DoubleCartpoleKnown,
     "PlanarQuadrotor": PlanarQuadrotor,
+    "Quadrotor12": Quadrotor12,
 }
 
 

@@ -445,6 +445,110 @@ def case_mpc_quadrotor():
     save("mpc_quadrotor_fb", out)
 
 
+def _reference_quad12():
+    """The build-defined 12-state quadrotor (oracle/models_numpy.Quadrotor12) wrapped in the REFERENCE's own model base
+    classes, so that the reference solver and MPC policy run on it (as _reference_quadrotor does for the planar model)."""
+    from i2c.env_def import BaseDef
+    from i2c.model import BaseModelKnown
+    from models_numpy import Quadrotor12
+
+    q = Quadrotor12()
+
+    class Quad12Analytic(BaseDef, BaseModelKnown):
+        name = "3D Quadrotor (analytic)"
+        dim_x, dim_u, dim_z, dim_y = 12, 4, 16, 9
+        dim_z_term = 12
+        x0 = q.x0.reshape(-1, 1)
+        sig_x0 = q.sig_x0
+        sig_eta = q.sig_eta
+        xag = q.zg_term.reshape(-1, 1)
+        zg_term = xag
+        sig_zeta = None
+        gravity = q.gravity
+        xu_lim = np.array([[-np.inf] * 12 + [0.0] * 4, [np.inf] * 12 + [q.u_max] * 4])
+
+        @staticmethod
+        def dynamics(xu):
+            return q.dynamics(xu)
+
+        @staticmethod
+        def observe(xu):
+            return xu
+
+        @staticmethod
+        def observe_terminal(x):
+            return x
+
+        @staticmethod
+        def measure(x):
+            return q.measure(x)
+
+    return Quad12Analytic()
+
+
+QUAD12_Q = np.diag([10.0] * 3 + [1.0] * 3 + [0.1] * 6)
+QUAD12_R = 1e-2 * np.eye(4)
+
+
+def case_em_quad12(T=20, n_detail=2, n_total=8):
+    """Solver parity for config 4 at nx = 12: the reference I2cGraph on the build-defined 12-state quadrotor."""
+    model = _reference_quad12()
+    rng = np.random.default_rng(12)
+    mu_u = 0.25 * model.gravity * np.ones((T, 4)) + 1e-2 * rng.normal(size=(T, 4))
+    sig_u = 1e-2 * np.eye(4)
+    g = I2cGraph(model, T, QUAD12_Q, QUAD12_R, QUAD12_Q, 1.0, 0.5, mu_u, sig_u, None, None, CubatureQuadrature(1, 0, 0))
+    out = problem_inputs("Quadrotor12", model, T, QUAD12_Q, QUAD12_R, QUAD12_Q, 1.0, 0.5, mu_u, sig_u, None, None, (1, 0, 0))
+    run_em(g, n_detail, n_total, out)
+    save("em_quad12_T20", out)
+
+
+def case_em_quad12_propagate(T=12, n_detail=2, n_total=4):
+    """The same with closed-loop propagation in every iteration (expert controller) and calibrate_alpha first."""
+    model = _reference_quad12()
+    rng = np.random.default_rng(13)
+    mu_u = 0.25 * model.gravity * np.ones((T, 4)) + 1e-2 * rng.normal(size=(T, 4))
+    sig_u = 1e-2 * np.eye(4)
+    g = I2cGraph(model, T, QUAD12_Q, QUAD12_R, QUAD12_Q, 1.0, 0.5, mu_u, sig_u, None, None, CubatureQuadrature(1, 0, 0))
+    g._propagate = True
+    out = problem_inputs("Quadrotor12", model, T, QUAD12_Q, QUAD12_R, QUAD12_Q, 1.0, 0.5, mu_u, sig_u, None, None, (1, 0, 0),
+                         propagate=True)
+    run_em(g, n_detail, n_total, out, pre_propagate=True)
+    save("em_quad12_T12_propagate", out)
+
+
+def case_mpc_quad12():
+    """mpc_quad.py:538-650 (i2c, feedback, low noise) on the 12-state quadrotor: tracking a moving position target."""
+    from i2c.policy.mpc import PartiallyObservedMpcPolicy
+
+    H, steps, n_iter, warm = 8, 10, 2, 6
+    rng = np.random.default_rng(14)
+    model = _reference_quad12()
+    model.sig_zeta = 1e-6 * np.eye(9)
+    z_traj = np.zeros((steps + H, 16))
+    z_traj[:, 0] = np.linspace(0.0, 0.6, steps + H)
+    z_traj[:, 1] = 0.2 * np.sin(np.linspace(0, 2.0, steps + H))
+    z_traj[:, 2] = np.linspace(0.0, 0.3, steps + H)
+    z_traj[:, 12:] = 0.25 * model.gravity
+    Q, R = QUAD12_Q, QUAD12_R
+    Qf = Q / 10.0
+    mu_u = 0.25 * model.gravity * np.ones((H, 4))
+    sig_u = 1e-2 * np.eye(4)
+    g = I2cGraph(model, H, Q, R, Qf, 1.0, 1.0, mu_u, sig_u, None, None, CubatureQuadrature(1, 0, 0))
+    g._propagate = True
+    policy = PartiallyObservedMpcPolicy(g, n_iter, sig_u, np.copy(z_traj))
+    policy.set_control(feedforward=False)
+    out = problem_inputs("Quadrotor12", model, H, Q, R, Qf, 1.0, 1.0, mu_u, sig_u, None, None, (1, 0, 0),
+                         feedforward=False, steps=steps, n_iter=n_iter, warm=warm)
+    out["z_traj"], out["sig_zeta"] = z_traj, model.sig_zeta
+    g.calibrate_alpha()
+    out["alpha_cal1"] = np.array(g.alpha)
+    policy.optimize(warm, model.x0, model.sig_x0)
+    g.calibrate_alpha()
+    out["alpha_cal2"] = np.array(g.alpha)
+    _mpc_loop(policy, model, steps, out, rng)
+    save("mpc_quad12_fb", out)
+
+
 def case_i2c_run(config="pendulum_known_quad", name="run_pendulum_seed0"):
     """The reference's own runner, scripts/i2c_run.py:run(), on its shipped pendulum config (seed 0,
     N_INFERENCE cut to 6): what a user sees -- costs_m, alphas, the saved plan and the final policy."""
@@ -694,6 +798,9 @@ CASES = {
     "mpc_fb": case_mpc_pendulum_fb,
     "em_quad": case_em_quadrotor,
     "mpc_quad": case_mpc_quadrotor,
+    "em_quad12": case_em_quad12,
+    "em_quad12_pf": case_em_quad12_propagate,
+    "mpc_quad12": case_mpc_quad12,
     "i2c_run": case_i2c_run,
     "i2c_run_lin": case_i2c_run_linearize,
     "gh_pendulum": case_gh_pendulum,

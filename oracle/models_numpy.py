@@ -357,6 +357,69 @@ class PlanarQuadrotor(_Model):
         )
 
 
+class Quadrotor12(_Model):
+    """BUILD-DEFINED 12-state, 4-rotor quadrotor (BASELINE config 4 names nx = 12; the reference only has the planar
+    Box2D body of scripts/mpc_state_est/mpc_quad.py:219-383, so dynamics parity is UNPINNED by construction).
+
+    x = [p (3) | roll, pitch, yaw | v (3, world frame) | body rates (3)], u = four rotor thrusts clipped to [0, u_max],
+    "+" configuration: roll torque arm (f2 - f4), pitch torque arm (f3 - f1), yaw torque kq (f1 - f2 + f3 - f4).
+    Integrator in the order of the planar model (Box2D's for a free body): velocities first (semi-implicit Euler, angular
+    damping as 1 / (1 + dt c)), then positions and Euler angles with the NEW velocities. observe / observe_terminal are the
+    identity (as mpc_quad.py:355-368), measure = [p | angles | body rates].
+    Solver parity is pinned by feeding THIS model to the real reference I2cGraph / PartiallyObservedMpcPolicy
+    in-container (oracle/gen_golden.py: em_quad12_T20, mpc_quad12_fb).
+    """
+
+    name = "Quadrotor12"
+    model_id = 7
+    dim_x, dim_u, dim_z, dim_z_term, dim_y = 12, 4, 16, 12, 9
+    dt, arm, kq, ang_damp, grav = 0.05, 0.25, 0.05, 0.5, 9.81
+    mass, Ixx, Iyy, Izz, u_max = 1.0, 0.02, 0.02, 0.04, 6.0
+
+    def __init__(self):
+        self.gravity = self.grav * self.mass
+        self.x0 = np.zeros(12)
+        self.sig_x0 = 1e-5 * np.eye(12)
+        self.sig_eta = np.diag([1e-6] * 6 + [1e-4] * 6)
+        self.zg_term = np.array([1.0, 1.0, 1.0] + [0.0] * 9)
+        self.zg = np.concatenate((self.zg_term, np.zeros(4)))
+        self.sig_zeta = 1e-6 * np.eye(9)
+
+    def dynamics(self, xu):
+        f = [np.clip(xu[..., 12 + i], 0.0, self.u_max) for i in range(4)]
+        thrust = (f[0] + f[1]) + (f[2] + f[3])
+        tx, ty, tz = self.arm * (f[1] - f[3]), self.arm * (f[2] - f[0]), self.kq * ((f[0] - f[1]) + (f[2] - f[3]))
+        sph, cph = np.sin(xu[..., 3]), np.cos(xu[..., 3])
+        sth, cth = np.sin(xu[..., 4]), np.cos(xu[..., 4])
+        sps, cps = np.sin(xu[..., 5]), np.cos(xu[..., 5])
+        wx, wy, wz = xu[..., 9], xu[..., 10], xu[..., 11]
+        damp = 1.0 / (1.0 + self.dt * self.ang_damp)
+        wxn = (wx + self.dt * (tx - (self.Izz - self.Iyy) * wy * wz) / self.Ixx) * damp
+        wyn = (wy + self.dt * (ty - (self.Ixx - self.Izz) * wz * wx) / self.Iyy) * damp
+        wzn = (wz + self.dt * (tz - (self.Iyy - self.Ixx) * wx * wy) / self.Izz) * damp
+        am = thrust / self.mass
+        vxn = xu[..., 6] + self.dt * am * (cph * sth * cps + sph * sps)
+        vyn = xu[..., 7] + self.dt * am * (cph * sth * sps - sph * cps)
+        vzn = xu[..., 8] + self.dt * (am * (cph * cth) - self.grav)
+        tth = sth / cth
+        roll_d = wxn + tth * (sph * wyn + cph * wzn)
+        pitch_d = cph * wyn - sph * wzn
+        yaw_d = (sph * wyn + cph * wzn) / cth
+        return np.stack(
+            (xu[..., 0] + self.dt * vxn, xu[..., 1] + self.dt * vyn, xu[..., 2] + self.dt * vzn,
+             xu[..., 3] + self.dt * roll_d, xu[..., 4] + self.dt * pitch_d, xu[..., 5] + self.dt * yaw_d,
+             vxn, vyn, vzn, wxn, wyn, wzn), axis=-1)
+
+    def observe(self, xu):
+        return xu + 0.0
+
+    def observe_terminal(self, x):
+        return x + 0.0
+
+    def measure(self, x):
+        return np.concatenate((x[..., :6], x[..., 9:12]), axis=-1)
+
+
 def _terminal_features_as_measurement(cls):
     """The reference defines `measure` only for its quadrotor. For the other models the build's state
     estimator observes the terminal features (no action), e.g. [sin th, cos th, thd]."""
@@ -374,7 +437,8 @@ PendulumActReg.measure = lambda self, x: Pendulum.observe_terminal(self, x)
 
 MODELS = {
     m.name: m
-    for m in (Pendulum, PendulumActReg, Cartpole, DoubleCartpole, Linear, LinearMinimumEnergy, PlanarQuadrotor)
+    for m in (Pendulum, PendulumActReg, Cartpole, DoubleCartpole, Linear, LinearMinimumEnergy, PlanarQuadrotor,
+              Quadrotor12)
 }
 
 

@@ -143,11 +143,11 @@ def batched_inputs(case, B, seed=1234, x0_scale=1e-2):
     return x0, mu_u
 
 
-def check_batch_against_oracle(name, lib, device, B, n_iters, tol=1e-8, dtype=torch.float64, tol_policy=None):
+def check_batch_against_oracle(name, lib, device, B, n_iters, tol=1e-8, dtype=torch.float64, tol_policy=None, **kw):
     """Batched engine vs the batched CPU oracle on identical inputs, all trajectories, every cell."""
     g = load_case(name)
     x0, mu_u = batched_inputs(g, B)
-    eng = engine_from_case(g, lib, device, dtype=dtype, x0=x0, mu_u=mu_u)
+    eng = engine_from_case(g, lib, device, dtype=dtype, x0=x0, mu_u=mu_u, **kw)
     g2 = dict(g)
     o = oracle_from_case(type(g)({**g2, "mu_u": mu_u}), x0=x0)
     if g.meta.get("propagate"):

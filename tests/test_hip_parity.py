@@ -27,12 +27,37 @@ GOLDEN = [
     ("em_covctrl_T100", 1e-7, 1e-6),
     ("em_pendulum_T50_propagate", 1e-8, 1e-7),
     ("em_quadrotor_T20", 1e-6, 1e-5),
+    ("em_quad12_T20", 1e-6, 1e-5),            # 12-state quadrotor: group kernels only (d = 16)
+    ("em_quad12_T12_propagate", 1e-6, 1e-5),
 ]
 
 
 @pytest.mark.parametrize("name,tol_d,tol_s", GOLDEN)
 def test_hip_vs_reference_golden(lib, name, tol_d, tol_s):
     parity.check_against_golden(name, lib, "cuda", tol_d, tol_s)
+
+
+# the group kernels (G lanes of a wavefront per trajectory, LDS exchange) on the models that also have one-lane kernels
+GROUP_GOLDEN = [
+    ("em_pendulum_T200", 1e-8, 1e-7),              # G = 4
+    ("em_pendulum_T40_quad_general", 1e-8, 1e-7),
+    ("em_dcp_T60", 1e-6, 1e-5),                    # G = 16
+    ("em_cartpole_T100", 1e-6, 1e-5),              # G = 8
+    ("em_linear_T60", 1e-8, 1e-7),
+    ("em_pendulum_T50_propagate", 1e-8, 1e-7),
+    ("em_quadrotor_T20", 1e-6, 1e-5),              # G = 8
+]
+
+
+@pytest.mark.parametrize("name,tol_d,tol_s", GROUP_GOLDEN)
+def test_hip_group_kernels_vs_reference_golden(lib, name, tol_d, tol_s):
+    parity.check_against_golden(name, lib, "cuda", tol_d, tol_s, group_lanes=True)
+
+
+@pytest.mark.parametrize("name,B,group", [("em_quad12_T20", 203, 0), ("em_dcp_T60", 77, True), ("em_pendulum_T200", 1000, True)])
+def test_hip_group_kernels_batch_vs_oracle(lib, name, B, group):
+    """Ragged batches (not a multiple of the 64 / G trajectories of a wavefront) against the batched oracle."""
+    parity.check_batch_against_oracle(name, lib, "cuda", B, 3, tol=1e-6, group_lanes=group)
 
 
 LINEARIZE = [

@@ -22,12 +22,50 @@ GOLDEN = [
     ("em_covctrl_T100", 1e-8, 1e-7),
     ("em_pendulum_T50_propagate", 1e-9, 1e-8),
     ("em_quadrotor_T20", 1e-7, 1e-6),
+    ("em_quad12_T20", 1e-7, 1e-6),            # group kernels only (d = 16)
+    ("em_quad12_T12_propagate", 1e-7, 1e-6),
 ]
 
 
 @pytest.mark.parametrize("name,tol_d,tol_s", GOLDEN)
 def test_hostsim_vs_reference_golden(lib, name, tol_d, tol_s):
     parity.check_against_golden(name, lib, "cpu", tol_d, tol_s)
+
+
+# The GROUP kernels (csrc/i2c_group.hpp: G lanes of a wavefront per trajectory, blocks row-distributed, exchange through
+# LDS) on the models that also have one-lane-per-trajectory kernels: the same golden vectors. The host simulation runs
+# the G lanes of a group as G threads with a barrier where the device has its LDS fence.
+GROUP_GOLDEN = [
+    ("em_pendulum_T200", 1e-9, 1e-8, 8),              # G = 4
+    ("em_pendulum_T40_quad_general", 1e-9, 1e-8, None),  # weights that do not sum to 1
+    ("em_dcp_T60", 1e-7, 1e-6, None),                 # G = 16, trigonometric observation
+    ("em_cartpole_T100", 1e-7, 1e-6, None),           # G = 8
+    ("em_linear_T60", 1e-9, 1e-8, None),
+    ("em_pendulum_T50_propagate", 1e-9, 1e-8, None),  # propagation with the expert controller
+    ("em_quadrotor_T20", 1e-7, 1e-6, None),           # G = 8, identity observation
+]
+
+
+@pytest.mark.parametrize("name,tol_d,tol_s,n_iters", GROUP_GOLDEN)
+def test_hostsim_group_kernels_vs_reference_golden(lib, name, tol_d, tol_s, n_iters):
+    parity.check_against_golden(name, lib, "cpu", tol_d, tol_s, n_iters=n_iters, group_lanes=True)
+
+
+def test_hostsim_group_kernels_batch_vs_oracle(lib):
+    parity.check_batch_against_oracle("em_quad12_T20", lib, "cpu", 5, 3, tol=1e-7)
+    parity.check_batch_against_oracle("em_dcp_T60", lib, "cpu", 3, 3, tol=1e-7, group_lanes=True)
+
+
+def test_group_kernels_refuse_what_they_do_not_cover(lib):
+    """Covariance control (terminal state prior), other inference rules and non-diagonal cost weights are not
+    available in the group form: the library says I2C_ENOTSUP instead of computing something else."""
+    from golden_util import load_case
+
+    eng = parity.engine_from_case(load_case("em_covctrl_T100"), lib, "cpu", group_lanes=True)
+    with pytest.raises(RuntimeError, match="-2"):
+        eng.forward_sweep()
+    with pytest.raises(ValueError):
+        parity.engine_from_case(load_case("em_pendulum_T200"), lib, "cpu", group_lanes=16)
 
 
 LINEARIZE = [

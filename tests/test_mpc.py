@@ -51,13 +51,13 @@ def _replay(name, lib, device, tol):
     return pol
 
 
-@pytest.mark.parametrize("name", ["mpc_pendulum_ff", "mpc_pendulum_fb", "mpc_quadrotor_fb"])
+@pytest.mark.parametrize("name", ["mpc_pendulum_ff", "mpc_pendulum_fb", "mpc_quadrotor_fb", "mpc_quad12_fb"])
 def test_mpc_replay_cpu(name):
     _replay(name, hostsim.load(), "cpu", 1e-7)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["mpc_pendulum_ff", "mpc_pendulum_fb", "mpc_quadrotor_fb"])
+@pytest.mark.parametrize("name", ["mpc_pendulum_ff", "mpc_pendulum_fb", "mpc_quadrotor_fb", "mpc_quad12_fb"])
 def test_mpc_replay_gpu(name):
     _replay(name, None, "cuda", 1e-6)
 
@@ -83,7 +83,7 @@ def _ckf_batch(lib, device, model_name, B=37):
     """The filter kernel on a ragged batch of random beliefs against the oracle restatement."""
     from oracle.models_numpy import make_model
 
-    g = load_case("mpc_quadrotor_fb" if model_name == "PlanarQuadrotor" else "mpc_pendulum_ff")
+    g = load_case({"PlanarQuadrotor": "mpc_quadrotor_fb", "Quadrotor12": "mpc_quad12_fb"}.get(model_name, "mpc_pendulum_ff"))
     rng = np.random.default_rng(3)
     om = make_model(model_name)
     nx, nu = om.dim_x, om.dim_u
@@ -104,13 +104,13 @@ def _ckf_batch(lib, device, model_name, B=37):
     assert i2c.engine.failures() == []
 
 
-@pytest.mark.parametrize("model_name", ["PendulumKnown", "PlanarQuadrotor"])
+@pytest.mark.parametrize("model_name", ["PendulumKnown", "PlanarQuadrotor", "Quadrotor12"])
 def test_ckf_batch_cpu(model_name):
     _ckf_batch(hostsim.load(), "cpu", model_name)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model_name", ["PendulumKnown", "PlanarQuadrotor"])
+@pytest.mark.parametrize("model_name", ["PendulumKnown", "PlanarQuadrotor", "Quadrotor12"])
 def test_ckf_batch_gpu(model_name):
     _ckf_batch(None, "cuda", model_name)
 
@@ -205,12 +205,12 @@ def _native_step_equals_stepwise(name, lib, device):
         assert ea.terminal_cell == eb.terminal_cell and nz == eb.nz
 
 
-@pytest.mark.parametrize("name", ["mpc_pendulum_fb", "mpc_quadrotor_fb"])
+@pytest.mark.parametrize("name", ["mpc_pendulum_fb", "mpc_quadrotor_fb", "mpc_quad12_fb"])
 def test_native_mpc_step_cpu(name):
     _native_step_equals_stepwise(name, hostsim.load(), "cpu")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["mpc_pendulum_fb", "mpc_quadrotor_fb"])
+@pytest.mark.parametrize("name", ["mpc_pendulum_fb", "mpc_quadrotor_fb", "mpc_quad12_fb"])
 def test_native_mpc_step_gpu(name):
     _native_step_equals_stepwise(name, None, "cuda")

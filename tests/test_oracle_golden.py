@@ -145,6 +145,15 @@ def test_em_quadrotor_T20():
     _run_and_check("em_quadrotor_T20", 1e-8, 1e-7)
 
 
+def test_em_quad12_T20():
+    """Build-defined 12-state quadrotor (BASELINE config 4, nx = 12, d = 16) fed to the REAL reference solver."""
+    _run_and_check("em_quad12_T20", 1e-8, 1e-7)
+
+
+def test_em_quad12_propagate():
+    _run_and_check("em_quad12_T12_propagate", 1e-8, 1e-7)
+
+
 def test_em_propagate_expert_T50():
     _run_and_check("em_pendulum_T50_propagate", 1e-9, 1e-8)
 

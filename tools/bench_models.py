@@ -1,5 +1,6 @@
 """Time one EM iteration (forward / backward / M-step) for any model:
-python tools/bench_models.py [model ...] [B ...] [two_pass|fused|chunked ...] [f64]"""
+python tools/bench_models.py [model ...] [B ...] [two_pass|fused|chunked ...] [f64] [group]
+`group` runs the group kernels (G lanes per trajectory) as well where a model has both forms."""
 import importlib
 import os
 import sys
@@ -19,19 +20,21 @@ CONFIGS = {  # hyper-parameters of the reference's experiment files
                                 alpha=0.05, tol=0.99, sig_u=1.0, mu_u=1e-2),
     "PlanarQuadrotor": dict(T=50, Q=np.diag([1e3, 1e3, 1e3, 1, 1, 1]) / 1e3, R=np.diag([1e-3, 1e-3]), alpha=1.0, tol=1.0,
                             sig_u=1e-2, mu_u=0.0),
+    "Quadrotor12": dict(T=50, Q=np.diag([10.0] * 3 + [1.0] * 3 + [0.1] * 6), R=1e-2 * np.eye(4), alpha=1.0, tol=0.5, sig_u=1e-2,
+                        mu_u=1e-2),
 }
 
 
-def run(name, B, dtype, iters=10, mode="auto"):
+def run(name, B, dtype, iters=10, mode="auto", group=0):
     cfg = CONFIGS[name]
     model = make_env_model(name)
     T, nu = cfg["T"], model.dim_u
     rng = np.random.default_rng(0)
     x0 = np.asarray(model.x0, float).reshape(1, -1) + 1e-3 * rng.normal(size=(B, model.dim_x))
-    base = 0.5 * model.gravity if name == "PlanarQuadrotor" else 0.0
+    base = {"PlanarQuadrotor": 0.5, "Quadrotor12": 0.25}.get(name, 0.0) * getattr(model, "gravity", 0.0)
     mu_u = base + cfg["mu_u"] * rng.normal(size=(B, T, nu))
     eng = pkg.BatchedI2c(model, T, cfg["Q"], cfg["R"], cfg["Q"], cfg["alpha"], cfg["tol"], mu_u, cfg["sig_u"] * np.eye(nu), x0=x0,
-                         dtype=dtype, keep_zpost=False, keep_xm=False, backward_mode=mode)
+                         dtype=dtype, keep_zpost=False, keep_xm=False, backward_mode=mode, group_lanes=group)
     for _ in range(3):
         eng.learn_msgs()
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(iters)]
@@ -45,7 +48,7 @@ def run(name, B, dtype, iters=10, mode="auto"):
     el = (d.e_post - nu - nu * (nu + 1) // 2) + 2 * d.e_fwd + d.e_post
     tot = sum(ms)
     print(f"{name:22s} B={B:6d} T={T:3d} {str(dtype)[6:]:8s} fwd {ms[0]:8.3f} bwd {ms[1]:8.3f} mstep {ms[2]:6.3f} ms | "
-          f"[{mode:8s}] {B * T / tot * 1e3:10.3e} msg/s | {el * w * B * T / tot / 1e6:8.1f} GB/s | fails {len(eng.failures())}")
+          f"[{eng.backward_schedule:8s}{' G=%d' % eng.dims.group_lanes if eng.uses_group_kernels else '':5s}] {B * T / tot * 1e3:10.3e} msg/s | {el * w * B * T / tot / 1e6:8.1f} GB/s | fails {len(eng.failures())}")
 
 
 if __name__ == "__main__":
@@ -53,8 +56,12 @@ if __name__ == "__main__":
     Bs = [int(a) for a in sys.argv[1:] if a.isdigit()] or [4096]
     modes = [a for a in sys.argv[1:] if a in ("auto", "two_pass", "fused", "chunked")] or ["auto"]
     dts = (torch.float64,) if "f64" in sys.argv[1:] else (torch.float64, torch.float32)
+    groups = (0, True) if "group" in sys.argv[1:] else (0,)
     for n in names:
         for B in Bs:
             for dt in dts:
                 for m in modes:
-                    run(n, B, dt, mode=m)
+                    for grp in groups:
+                        if grp and (dt != torch.float64 or n == "Quadrotor12" or m != modes[0]):
+                            continue
+                        run(n, B, dt, mode=m, group=grp)
