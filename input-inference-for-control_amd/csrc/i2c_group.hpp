@@ -185,52 +185,38 @@ template <int N, typename R, int G> I2C_FN bool g_chol(const Grp<R, G>& g, const
 }
 
 // L y = b (forward substitution) for one or two right-hand sides per lane; L is in LDS matrix m, rinv replicated.
-// Row i + 1 of L is fetched while row i is consumed; a scheduling fence per row keeps the live state at two rows.
+// A scheduling fence per row keeps the live state at one row of L (an explicit one-row-ahead prefetch cost the d = 16
+// forward kernel 30 more live doubles and pushed it into scratch).
 template <int N, int NRHS, typename R, int G>
 I2C_FN void g_fsub(const Grp<R, G>& g, const int m, const R* rinv, R* b0, R* b1) {
   constexpr int LD = Grp<R, G>::LD;
   constexpr bool FENCE = N >= 6;
   const auto L = g.mat(m);
-  R lc[N], ln[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    if (i + 1 < N) {
-#pragma unroll
-      for (int k = 0; k <= i; ++k) ln[k] = L[(i + 1) * LD + k];
-    }
     R v0 = b0[i], v1 = NRHS > 1 ? b1[i] : R(0);
 #pragma unroll
     for (int k = 0; k < i; ++k) {
-      v0 -= lc[k] * b0[k];
-      if (NRHS > 1) v1 -= lc[k] * b1[k];
+      const R l = L[i * LD + k];
+      v0 -= l * b0[k];
+      if (NRHS > 1) v1 -= l * b1[k];
     }
     b0[i] = v0 * rinv[i];
     if (NRHS > 1) b1[i] = v1 * rinv[i];
-#pragma unroll
-    for (int k = 0; k <= i && k < N - 1; ++k) lc[k] = ln[k];
     sched_fence<FENCE>();
   }
 }
-// L^T x = y (back substitution), one right-hand side per lane (column i of L fetched one step ahead)
+// L^T x = y (back substitution), one right-hand side per lane
 template <int N, typename R, int G> I2C_FN void g_bsub(const Grp<R, G>& g, const int m, const R* rinv, R* y) {
   constexpr int LD = Grp<R, G>::LD;
   constexpr bool FENCE = N >= 6;
   const auto L = g.mat(m);
-  R lc[N], ln[N];
 #pragma unroll
   for (int i = N - 1; i >= 0; --i) {
-    if (i > 0) {
-#pragma unroll
-      for (int k = i; k < N; ++k) ln[k] = L[k * LD + (i - 1)];
-    }
     R v = y[i];
 #pragma unroll
-    for (int k = i + 1; k < N; ++k) v -= lc[k] * y[k];
+    for (int k = i + 1; k < N; ++k) v -= L[k * LD + i] * y[k];
     y[i] = v * rinv[i];
-    if (i > 0) {
-#pragma unroll
-      for (int k = i; k < N; ++k) lc[k] = ln[k];
-    }
     sched_fence<FENCE>();
   }
 }
@@ -303,55 +289,46 @@ I2C_FN void g_transform(const Grp<R, G>& g, const int mL, const int mA, const in
     Sy[k] = R(0);
     if (CROSS) Sxy[k] = R(0);
   }
-  // the published vectors of point j + 1 are fetched while those of point j are consumed
-  constexpr bool FENCE = DIN >= 6;
-  R dc[DOUT], ac[DOUT], dn[DOUT], an[DOUT], arc, drc, arn = R(0), drn = R(0);
-  auto fetch = [&](const int j, R* d, R* al, R* ar, R* dr) {
+  // base of the mean now, so that neither m nor y0 has to survive the accumulation loop
+  R myb[DOUT];
 #pragma unroll
-    for (int l = 0; l < DOUT; ++l) {
-      d[l] = Dm[j * LD + l];
-      al[l] = ST::lin(l) < 0 ? Am[j * LD + l] : R(0);
-    }
-    *ar = Am[j * LD + r];  // junk for r >= DOUT: those lanes' Sy is never used
-    *dr = Dm[j * LD + r];
-  };
-  fetch(0, dc, ac, &arc, &drc);
-#pragma unroll
+  for (int k = 0; k < DOUT; ++k) myb[k] = rule.W * (ST::lin(k) >= 0 ? m[ST::lin(k) >= 0 ? ST::lin(k) : 0] : y0[k]);
+  // A ROLLED loop over the points: no register array is indexed by j (the lane's own row of L is read back from LDS
+  // matrix mL, which phase 1 left intact), so the live state is the three accumulator rows and one published pair.
+  // Fully unrolled, this loop alone drove the d = 16 forward kernel 1.3 KB per lane into scratch.
+  const auto Lr = Lm + r * LD;
+  constexpr int UF = DIN * DOUT >= 96 ? 1 : DIN;  // small models: the unrolled form fits and saves the loop overhead
+#pragma unroll UF
   for (int j = 0; j < DIN; ++j) {
-    if (j + 1 < DIN) fetch(j + 1, dn, an, &arn, &drn);
+    const R arc = Am[j * LD + r], drc = Dm[j * LD + r];  // junk for r >= DOUT: those lanes' Sy is never used
+    const R lj = CROSS ? Lr[j] : R(0);
     Ar += arc;
 #pragma unroll
     for (int l = 0; l < DOUT; ++l) {
-      R acc = Sy[l] + drc * dc[l];
+      const R dl = Dm[j * LD + l];
+      R acc = Sy[l] + drc * dl;
       if (ST::lin(l) < 0) {
-        A[l] += ac[l];
-        acc += arc * ac[l];
+        const R al = Am[j * LD + l];
+        A[l] += al;
+        acc += arc * al;
       }
       Sy[l] = acc;
-      if (CROSS) Sxy[l] += Lrow[j] * dc[l];
+      if (CROSS) Sxy[l] += lj * dl;
     }
-    if (j + 1 < DIN) {
-#pragma unroll
-      for (int l = 0; l < DOUT; ++l) {
-        dc[l] = dn[l];
-        ac[l] = an[l];
-      }
-      arc = arn;
-      drc = drn;
-    }
-    sched_fence<FENCE>();
   }
   const R hw = R(0.5) * rule.wi, w2 = rule.wi * rule.wi, cs = rule.wi * rule.sf;
-  R yc[DOUT];
 #pragma unroll
   for (int k = 0; k < DOUT; ++k) {
-    yc[k] = ST::lin(k) >= 0 ? m[ST::lin(k) >= 0 ? ST::lin(k) : 0] : y0[k];
-    my[k] = rule.W * yc[k] + rule.wi * A[k];
+    my[k] = myb[k] + rule.wi * A[k];
     Sy[k] = hw * Sy[k] - w2 * Ar * A[k];
     if (CROSS) Sxy[k] = cs * Sxy[k];
   }
   if (!rule.unit) {  // sum of weights != 1: the reference's m m^T term no longer cancels (see sp_transform)
-    const R omw = R(1) - rule.W, ycr = g_sel<DOUT>(yc, r);
+    const R omw = R(1) - rule.W, iw = r_rcp(rule.W);
+    R yc[DOUT];
+#pragma unroll
+    for (int l = 0; l < DOUT; ++l) yc[l] = myb[l] * iw;
+    const R ycr = g_sel<DOUT>(yc, r);
 #pragma unroll
     for (int l = 0; l < DOUT; ++l) Sy[l] += omw * (rule.W * ycr * yc[l] + rule.wi * (Ar * yc[l] + ycr * A[l]));
   }
@@ -378,25 +355,14 @@ I2C_FN bool g_kalman(const Grp<R, G>& g, R* mu, R* S, R* q, R* Sz, R* Sxz, R* mu
 #pragma unroll
   for (int k = 0; k < DZ; ++k) Vm[r * LD + k] = Sxz[k];
   g_gather<DX>(g, 0, own, mu);  // its syncs also publish V
-  constexpr bool FENCE = DZ >= 6;
-  R vc[DZ], vn[DZ];
+  // S_r -= V_r V^T as a ROLLED loop over the observation index: column k of V per step, the lane's own V_r[k] read back
+  // from LDS, so that no register array is indexed by the loop variable
+  constexpr int UF = DX * DZ >= 96 ? 1 : DZ;
+#pragma unroll UF
+  for (int k = 0; k < DZ; ++k) {
+    const R vk = Vm[r * LD + k];
 #pragma unroll
-  for (int k = 0; k < DZ; ++k) vc[k] = Vm[k];
-#pragma unroll
-  for (int j = 0; j < DX; ++j) {  // row j + 1 of V is fetched while row j is consumed
-    if (j + 1 < DX) {
-#pragma unroll
-      for (int k = 0; k < DZ; ++k) vn[k] = Vm[(j + 1) * LD + k];
-    }
-    R v = S[j];
-#pragma unroll
-    for (int k = 0; k < DZ; ++k) v -= Sxz[k] * vc[k];
-    S[j] = v;
-    if (j + 1 < DX) {
-#pragma unroll
-      for (int k = 0; k < DZ; ++k) vc[k] = vn[k];
-    }
-    sched_fence<FENCE>();
+    for (int j = 0; j < DX; ++j) S[j] -= vk * Vm[j * LD + k];
   }
   return ok;
 }
@@ -479,6 +445,7 @@ I2C_FN void g_joint(const Grp<R, G>& g, const R* mu_x, const R* sx, const R* Kro
     mu0[NX + a] = v;
     cr[a] = c1;
     crd[a] = c2;
+    sched_fence<(NX >= 6)>();  // one gain row in flight at a time (all NU * NX reads at once overflow the registers)
   }
   if (is_x) {  // matrix 0 is not read between the sync above and here
 #pragma unroll
@@ -495,8 +462,8 @@ I2C_FN void g_joint(const Grp<R, G>& g, const R* mu_x, const R* sx, const R* Kro
   for (int c = 0; c < NU; ++c) {
     const int p = ru > c ? ru : c, q = ru > c ? c : ru;
     R v = prow[NX + c];
-#pragma unroll
-    for (int k = 0; k < NX; ++k) {
+#pragma unroll (NX >= 8 ? 1 : NX)
+    for (int k = 0; k < NX; ++k) {  // rolled for the large models: nothing but LDS is indexed by k
       const R ktq = Km[q * LD + k];
       if (sub_ux) v -= Km[p * LD + k] * Pm[q * LD + k];
       if (add_quad) v += XC[k * LD + NU + p] * ktq;
@@ -512,17 +479,18 @@ I2C_FN void g_joint(const Grp<R, G>& g, const R* mu_x, const R* sx, const R* Kro
 // ------------------------------------------------------------------------------------------
 template <class M, typename R, int G, class KC>
 I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const FwdArgs<R>& a, const int b,
-                                      const Grp<R, G>& g) {
+                                      const Grp<R, G>& g_in) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D, NT = C::NZT1;
   static_assert(G >= D && G >= NZ && G >= NT, "one matrix row per lane");
   constexpr int O_K = D + sym(D), O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
   constexpr bool OBS_ID = st_identity<ObsStruct<M>, NZ>() && NZ <= D;
   constexpr bool TERM_ID = st_identity<TermStruct<M>, NT>() && NT <= NX;
+  const Grp<R, G>& g = g_in;
   const int r = g.r;
   const unsigned long B = c.B;
   const int T = c.T;
-  const unsigned W = sizeof(R), bo = (unsigned)b * W, rb = (unsigned)(B * W);
+  const unsigned W = sizeof(R), bo = (unsigned)b * W, rb0 = (unsigned)(B * W);
   const int rx = r < NX ? r : NX - 1, rd = r < D ? r : D - 1, rz = r < NZ ? r : NZ - 1, rt = r < NT ? r : NT - 1;
   const int trx = rx * (rx + 1) / 2, trd = rd * (rd + 1) / 2;
   const bool is_u = r >= NX && r < D;
@@ -536,6 +504,18 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
   for (int j = 0; j < NX; ++j) sx[j] = a.sig_x0[(long)symidx(rx, trx, j) * B + b];
 
   for (int t = 0; t < T; ++t) {
+    // Nothing that depends on the rank or on the row stride may be hoisted out of the time loop (the byte offsets of ~100
+    // rows and the batch constants of "my" row would be pinned in registers for the whole sweep): the cell works on an
+    // opaque copy of both.
+    Grp<R, G> g = g_in;
+    g.r = opaque_i(g_in.r);
+    const int r = g.r;
+    const unsigned rb = opaque_uniform(rb0);
+    const int rx = r < NX ? r : NX - 1, rd = r < D ? r : D - 1, rz = r < NZ ? r : NZ - 1, rt = r < NT ? r : NT - 1;
+    const int trx = rx * (rx + 1) / 2, trd = rd * (rd + 1) / 2;
+    const bool is_u = r >= NX && r < D;
+    const int ru = is_u ? r - NX : 0;
+
     const GIO<R> pri = gio(a.prior + (unsigned long)t * C::E_POST * B, C::E_POST, rb, bo);
     const GIO<R> out = gio(a.fwd + (unsigned long)t * C::E_FWD * B, C::E_FWD, rb, bo);
     R pmu[D], prow[D];
@@ -664,7 +644,7 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
 // ------------------------------------------------------------------------------------------
 template <class M, typename R, int G, class KC>
 I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, const CellArgs<R>& a, const int b,
-                                       const Grp<R, G>& g) {
+                                       const Grp<R, G>& g_in) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D, NT = C::NZT1, LD = Grp<R, G>::LD;
   static_assert(G >= D && G >= NZ && G >= NT, "one matrix row per lane");
@@ -672,10 +652,11 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
   constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
   constexpr bool OBS_ID = st_identity<ObsStruct<M>, NZ>() && NZ <= D;
   constexpr bool TERM_ID = st_identity<TermStruct<M>, NT>() && NT <= NX;
+  const Grp<R, G>& g = g_in;
   const int r = g.r;
   const unsigned long B = c.B;
   const int T = c.T;
-  const unsigned W = sizeof(R), bo = (unsigned)b * W, rb = (unsigned)(B * W);
+  const unsigned W = sizeof(R), bo = (unsigned)b * W, rb0 = (unsigned)(B * W);
   const int rx = r < NX ? r : NX - 1, rd = r < D ? r : D - 1;
   const int trx = rx * (rx + 1) / 2, trd = rd * (rd + 1) / 2, trr = r * (r + 1) / 2;
   const bool is_x = r < NX, is_u = r >= NX && r < D;
@@ -684,7 +665,7 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
   // end of the chain (i2c.py:546-564): the smoothed terminal state is the filtered one
   R m3m[NX], s3m[NX];
   {
-    const GIO<R> fw = gio(a.fwd + (unsigned long)(T - 1) * C::E_FWD * B, C::E_FWD, rb, bo);
+    const GIO<R> fw = gio(a.fwd + (unsigned long)(T - 1) * C::E_FWD * B, C::E_FWD, rb0, bo);
     g_gather<NX>(g, 0, fw.ld(O_MU3 + rx), m3m);
 #pragma unroll
     for (int j = 0; j < NX; ++j) s3m[j] = fw.ld(O_S3 + symidx(rx, trx, j));
@@ -717,6 +698,18 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
 
   R sum_m = R(0), sum_v = R(0);
   for (int t = T - 1; t >= 0; --t) {
+    // Nothing that depends on the rank or on the row stride may be hoisted out of the time loop (the byte offsets of ~100
+    // rows and the batch constants of "my" row would be pinned in registers for the whole sweep): the cell works on an
+    // opaque copy of both.
+    Grp<R, G> g = g_in;
+    g.r = opaque_i(g_in.r);
+    const int r = g.r;
+    const unsigned rb = opaque_uniform(rb0);
+    const int rx = r < NX ? r : NX - 1, rd = r < D ? r : D - 1;
+    const int trx = rx * (rx + 1) / 2, trd = rd * (rd + 1) / 2, trr = r * (r + 1) / 2;
+    const bool is_x = r < NX, is_u = r >= NX && r < D;
+    const int ru = is_u ? r - NX : 0;
+
     const GIO<R> fw = gio(a.fwd + (unsigned long)t * C::E_FWD * B, C::E_FWD, rb, bo);
     const GIO<R> po = gio(a.post + (unsigned long)t * C::E_POST * B, C::E_POST, rb, bo);
     R mu[D], S[D], m3f[NX], s3f[NX], Jr[NX];
@@ -754,24 +747,27 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
 #pragma unroll
     for (int l = 0; l < NX; ++l) mu_own += Jr[l] * (m3m[l] - m3f[l]);
     g_gather<D>(g, 0, mu_own, mu);  // its syncs also publish dS and J
-    {
-      constexpr bool FENCE = NX >= 6;
+    {  // both products as ROLLED loops (see g_transform): JD = J_r dS, then S_r += JD J^T with JD_r parked in LDS
       R JD[NX];
 #pragma unroll
       for (int k = 0; k < NX; ++k) JD[k] = R(0);
+      constexpr int UF = D * NX >= 96 ? 1 : NX;
+#pragma unroll UF
+      for (int l = 0; l < NX; ++l) {
+        const R jl = Jm[r * LD + l];
 #pragma unroll
-      for (int l = 0; l < NX; ++l) {  // JD = J_r dS, one row of dS per step
-#pragma unroll
-        for (int k = 0; k < NX; ++k) JD[k] += Jr[l] * dSm[l * LD + k];
-        sched_fence<FENCE>();
+        for (int k = 0; k < NX; ++k) JD[k] += jl * dSm[l * LD + k];
       }
+      const auto JDm = g.mat(0);  // free until the factorisation below
+      g.sync();
 #pragma unroll
-      for (int j = 0; j < D; ++j) {
-        R v = S[j];
+      for (int k = 0; k < NX; ++k) JDm[r * LD + k] = JD[k];
+      g.sync();
+#pragma unroll UF
+      for (int k = 0; k < NX; ++k) {
+        const R jd = JDm[r * LD + k];
 #pragma unroll
-        for (int k = 0; k < NX; ++k) v += JD[k] * Jm[j * LD + k];
-        S[j] = v;
-        sched_fence<FENCE>();
+        for (int j = 0; j < D; ++j) S[j] += jd * Jm[j * LD + k];
       }
     }
     R Lm[D], rinv[D];
@@ -854,16 +850,17 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
 // ------------------------------------------------------------------------------------------
 template <class M, typename R, int G, class KC>
 I2C_HD inline void propagate_group_body(const Consts<M, R>& c, const KC& kc, const PropArgs<R>& a, const int b,
-                                        const Grp<R, G>& g) {
+                                        const Grp<R, G>& g_in) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, D = C::D;
   static_assert(G >= D && G >= NZ, "one matrix row per lane");
   constexpr int O_K = D + sym(D), O_X3 = D + sym(D), O_SX3 = O_X3 + NX;
   constexpr bool OBS_ID = st_identity<ObsStruct<M>, NZ>() && NZ <= D;
+  const Grp<R, G>& g = g_in;
   const int r = g.r;
   const unsigned long B = c.B;
   const int T = c.T;
-  const unsigned W = sizeof(R), bo = (unsigned)b * W, rb = (unsigned)(B * W);
+  const unsigned W = sizeof(R), bo = (unsigned)b * W, rb0 = (unsigned)(B * W);
   const int rx = r < NX ? r : NX - 1, rd = r < D ? r : D - 1;
   const int trx = rx * (rx + 1) / 2, trd = rd * (rd + 1) / 2;
   const bool is_u = r >= NX && r < D;
@@ -876,6 +873,18 @@ I2C_HD inline void propagate_group_body(const Consts<M, R>& c, const KC& kc, con
   R sum_m = R(0), sum_v = R(0);
 
   for (int t = 0; t < T; ++t) {
+    // Nothing that depends on the rank or on the row stride may be hoisted out of the time loop (the byte offsets of ~100
+    // rows and the batch constants of "my" row would be pinned in registers for the whole sweep): the cell works on an
+    // opaque copy of both.
+    Grp<R, G> g = g_in;
+    g.r = opaque_i(g_in.r);
+    const int r = g.r;
+    const unsigned rb = opaque_uniform(rb0);
+    const int rx = r < NX ? r : NX - 1, rd = r < D ? r : D - 1;
+    const int trx = rx * (rx + 1) / 2, trd = rd * (rd + 1) / 2;
+    const bool is_u = r >= NX && r < D;
+    const int ru = is_u ? r - NX : 0;
+
     const GIO<R> pri = gio(a.post + (unsigned long)t * C::E_POST * B, C::E_POST, rb, bo);
     const GIO<R> out = gio(a.prop + (unsigned long)t * C::E_PROP * B, C::E_PROP, rb, bo);
     R qmu[D], prow[D], Krow[NX];
