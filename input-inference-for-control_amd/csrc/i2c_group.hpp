@@ -145,33 +145,55 @@ I2C_FN void g_sum3(const Grp<R, G>& g, const R v0, const R v1, const R v2, R* s0
   *s2 = z;
 }
 
-// Cholesky of an N x N SPD matrix whose row r sits in lane r (full row). Right-looking, one LDS exchange per column:
-// the lanes publish the current column k UNSCALED, everybody reads it (pivot included), takes 1/sqrt(pivot) itself and
-// updates its own trailing row. On return: row = row r of L with zeros above the diagonal, rinv[j] = 1 / L[j][j] in
-// every lane, L row-major in LDS matrix `m`. Returns (in every lane) whether the last pivot is positive, which is
-// equivalent to all pivots being positive (see chol() in i2c_linalg.hpp).
+// Cholesky of an N x N SPD matrix whose row r sits in lane r (full row). Right-looking, TWO columns per LDS exchange (the
+// exchange latency, not the arithmetic, bounds a lone wave): the lanes publish the current columns k and k + 1 UNSCALED,
+// everybody reads both (pivots included) and forms, redundantly,
+//   l_k = c_k / sqrt(c_k[k]),   c'_{k+1} = c_{k+1} - l_k l_k[k+1]   (the step-k update of column k + 1),
+//   l_{k+1} = c'_{k+1} / sqrt(c'_{k+1}[k+1]),
+// then updates its own trailing row with both. On return: row = row r of L with zeros above the diagonal, rinv[j] =
+// 1 / L[j][j] in every lane, L row-major in LDS matrix `m`. Returns (in every lane) whether the last pivot is positive,
+// which is equivalent to all pivots being positive (see chol() in i2c_linalg.hpp).
 template <int N, typename R, int G> I2C_FN bool g_chol(const Grp<R, G>& g, const int m, R* row, R* rinv) {
   constexpr int LD = Grp<R, G>::LD;
-  constexpr bool FENCE = N >= 6;  // bound the live state per column (see sched_fence, i2c_linalg.hpp)
+  constexpr bool FENCE = N >= 6;  // bound the live state per step (see sched_fence, i2c_linalg.hpp)
   const auto Tm = g.mat(m);
   const int r = g.r;
   R last = R(0);
   g.sync();
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
+  for (int k = 0; k < N; k += 2) {
+    const bool two = k + 1 < N;
     Tm[k * LD + r] = row[k];
+    if (two) Tm[(k + 1) * LD + r] = row[k + 1];
     g.sync();
-    R col[N];
+    R c0[N], c1[N];
 #pragma unroll
-    for (int j = k; j < N; ++j) col[j] = Tm[k * LD + j];
-    if (k == N - 1) last = col[k];
-    const R rk = r_rsqrt(col[k]);
-    rinv[k] = rk;
-    const R lrk = row[k] * rk;
-    const R tk = lrk * rk;
+    for (int j = k; j < N; ++j) {
+      c0[j] = Tm[k * LD + j];
+      if (two && j > k) c1[j] = Tm[(k + 1) * LD + j];
+    }
+    const R r0 = r_rsqrt(c0[k]);
+    rinv[k] = r0;
+    const R l0 = row[k] * r0;  // L[r][k]
+    if (!two) {
+      last = c0[k];
+      row[k] = l0;
+    } else {
+      // column k + 1 after the step-k update, for every row j > k (replicated): c1[j] - c0[j] c0[k+1] / c0[k]
+      const R s01 = c0[k + 1] * (r0 * r0);
 #pragma unroll
-    for (int j = k + 1; j < N; ++j) row[j] -= tk * col[j];
-    row[k] = lrk;
+      for (int j = k + 1; j < N; ++j) c1[j] -= c0[j] * s01;
+      if (k + 1 == N - 1) last = c1[k + 1];
+      const R r1 = r_rsqrt(c1[k + 1]);
+      rinv[k + 1] = r1;
+      const R t0 = l0 * r0;                                 // L[r][k] / sqrt(pivot_k)
+      const R l1 = (row[k + 1] - c0[k + 1] * t0) * r1;      // L[r][k+1]
+      const R t1 = l1 * r1;
+#pragma unroll
+      for (int j = k + 2; j < N; ++j) row[j] -= t0 * c0[j] + t1 * c1[j];
+      row[k] = l0;
+      row[k + 1] = l1;
+    }
     sched_fence<FENCE>();
   }
   g.sync();  // the unscaled columns are consumed: the matrix now receives L itself
@@ -518,11 +540,15 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
 
     const GIO<R> pri = gio(a.prior + (unsigned long)t * C::E_POST * B, C::E_POST, rb, bo);
     const GIO<R> out = gio(a.fwd + (unsigned long)t * C::E_FWD * B, C::E_FWD, rb, bo);
-    R pmu[D], prow[D];
-    g_gather<D>(g, 0, pri.ld(rd), pmu);
+    // every global load of the cell is issued here, together: one memory round trip per cell instead of three
+    R pmu[D], prow[D], Krow[NX];
+    const R pmu_own = pri.ld(rd);
 #pragma unroll
     for (int j = 0; j < D; ++j) prow[j] = pri.ld(D + symidx(rd, trd, j));
+#pragma unroll
+    for (int k = 0; k < NX; ++k) Krow[k] = pri.ld(O_K + ru * NX + k);
     const R alpha = a.alpha_cell ? a.alpha_cell[(long)t * B + b] : alpha_traj;
+    g_gather<D>(g, 0, pmu_own, pmu);
     int cell_bad = 0;
 
     // ---- 1. joint prior over (x, u) ---------------------------------------------------
@@ -545,9 +571,8 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
 #pragma unroll
       for (int i = 0; i < NX; ++i) maha += q[i] * q[i];
       const R rho = r_exp(R(-0.5) * maha);
-      R Krow[NX];
 #pragma unroll
-      for (int k = 0; k < NX; ++k) Krow[k] = rho * pri.ld(O_K + ru * NX + k);
+      for (int k = 0; k < NX; ++k) Krow[k] *= rho;
       g_joint<NX, NU>(g, mu_x, sx, Krow, prow, pmu, pmu + NX, true, false, true, mu0, s0);
     }
     if (a.prior_out) {
