@@ -1,6 +1,9 @@
 """Headline benchmark: i2c EM iterations/s and timestep-messages/s, pendulum T=200, B=4096 per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--horizon T] [--dtype f64|f32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--horizon T]
+
+`--gpus N` with N > 1 starts its own N workers (one process per GPU through torch.distributed.run on 127.0.0.1) unless it
+is already running under torchrun (RANK / WORLD_SIZE in the environment, the way the driver launches it).
 
 A "step" is ONE EM iteration (I2cGraph.learn_msgs: forward sweep, backward sweep, temperature
 M-step) over the whole local batch; inputs are resident in HBM before the timed region. One
@@ -8,7 +11,9 @@ cell-iteration ("timestep-message") = one (trajectory, timestep) cell through fo
 backward message + M-step statistics. N > 1: one process per GPU (torchrun),
 the batch axis is sharded with no collective inside the EM loop (weak scaling: B per GPU is
 fixed); the single RCCL all-gather of the final controllers runs after the timed steps and is
-reported separately.
+reported separately. Two STRONG-scaling legs (global batch 4096 and 65536 split over the ranks) and, at
+N = 1, legs for the other BASELINE configs (double cartpole T=300 B=4096, 12-state quadrotor MPC step H=50 B=8192,
+pendulum covariance control T=100 B=8192) ride on the same JSON line.
 
 Prints ONE JSON line on rank 0.
 """
@@ -41,13 +46,14 @@ def synthetic_pendulum_inputs(B, T, rank=0):
     return x0, mu_u
 
 
-def make_engine(pkg, B, T, dtype, device, rank=0, backward_mode="auto"):
+def make_engine(pkg, B, T, dtype, device, rank=0, backward_mode="auto", lib=None, group_lanes=0, storage_dtype=None):
     from i2c.known_models import make_env_model
 
     x0, mu_u = synthetic_pendulum_inputs(B, T, rank)
     Q, R = np.diag([1.0, 100.0, 1.0]), np.diag([2.0])  # scripts/experiments/pendulum_known_quad.py:22-33
     return pkg.BatchedI2c(make_env_model("PendulumKnown"), T, Q, R, Q, 100.0, 0.0, mu_u, 2.0 * np.eye(1), x0=x0,
-                          dtype=dtype, device=device, keep_zpost=False, keep_xm=False, backward_mode=backward_mode)
+                          dtype=dtype, device=device, keep_zpost=False, keep_xm=False, backward_mode=backward_mode, lib=lib,
+                          group_lanes=group_lanes, storage_dtype=storage_dtype)
 
 
 def timed_iterations(eng, K, sync):
@@ -71,10 +77,11 @@ def timed_iterations(eng, K, sync):
     return elapsed, ms
 
 
-def saturated_leg(pkg, T, dtype, device, el, wbytes, B=131072, K=6):
+def saturated_leg(pkg, T, dtype, device, el, wbytes, B=131072, K=6, storage_dtype=None):
     """Same kernels at a batch that fills the chip (2 wavefronts per SIMD): shows the HBM-bound
-    regime the headline batch (64 wavefronts on 1024 SIMDs) cannot reach."""
-    eng = make_engine(pkg, B, T, dtype, device, rank=7)
+    regime the headline batch (64 wavefronts on 1024 SIMDs) cannot reach. With storage_dtype=torch.float32: the mixed mode
+    (fp64 arithmetic on fp32-stored messages, half the bytes; deviation from fp64 bounded by tests/test_precision.py)."""
+    eng = make_engine(pkg, B, T, dtype, device, rank=7, storage_dtype=storage_dtype)
     for _ in range(2):
         eng.learn_msgs()
     elapsed, ms = timed_iterations(eng, K, lambda: torch.cuda.synchronize(device))
@@ -139,6 +146,125 @@ def cpu_baseline(T):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def launch_workers(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start N workers (one per GPU) as a child `torch.distributed.run` and relay
+    rank 0's JSON line. This process never touches the GPU (no torch.cuda call), so nothing that has initialised HIP is
+    ever re-executed."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
+def strong_scaling_legs(pkg, T, dtype, device, rank, world, dist, barrier, K, lib=None, globals_=(4096, 65536)):
+    """Fixed GLOBAL batch split over the ranks (contiguous shards, no collective in the loop): K EM iterations each."""
+    shard_range = importlib.import_module(PKG + ".dist").shard_range
+    legs = []
+    for Bg in globals_:
+        lo, hi = shard_range(Bg, rank, world)
+        eng = make_engine(pkg, max(hi - lo, 1), T, dtype, device, rank, lib=lib)
+        for _ in range(2):
+            eng.learn_msgs()
+        barrier()
+        t0 = time.perf_counter()
+        eng.learn(K)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        legs.append({"global_batch": Bg, "batch_per_gpu": hi - lo, "ms_per_step": el / K * 1e3,
+                     "value": Bg * T * K / el, "unit": "timestep-messages/s", "scaling": "strong"})
+        del eng
+    return legs
+
+
+def _gbps(eng, B, T, ms, wbytes=8):
+    d = eng.dims
+    el = (d.e_post - eng.nu - eng.nu * (eng.nu + 1) // 2) + 2 * d.e_fwd + d.e_post
+    return el * wbytes * B * T / (ms * 1e-3) / 1e9
+
+
+def extra_config_legs(pkg, device, K=10):
+    """The other BASELINE.json configs on one GPU, fp64, same timing discipline (synchronise, K steps, synchronise)."""
+    from i2c.known_models import make_env_model
+
+    out = {}
+    sync = lambda: torch.cuda.synchronize(device)  # noqa: E731
+    rng = np.random.default_rng(7)
+
+    # config 2: double cartpole swing-up, T=300, B=4096 (scripts/experiments/double_cartpole_known_cq.py:23-39)
+    m = make_env_model("DoubleCartpoleKnown")
+    B, T = 4096, 300
+    Q, R = 1e-3 * np.diag([1.0, 1.0, 100.0, 1.0, 100.0, 10.0, 1.0, 1.0]), 1e-3 * np.diag([0.1])
+    x0 = np.asarray(m.x0, float).reshape(1, -1) + 1e-3 * rng.normal(size=(B, m.dim_x))
+    eng = pkg.BatchedI2c(m, T, Q, R, Q, 0.05, 0.99, 1e-2 * rng.normal(size=(B, T, 1)), np.eye(1), x0=x0, device=device,
+                         keep_zpost=False, keep_xm=False)
+    eng.learn(2)
+    sync(); t0 = time.perf_counter(); eng.learn(K); sync()
+    ms = (time.perf_counter() - t0) / K * 1e3
+    out["double_cartpole_T300_B4096"] = {"ms_per_step": ms, "value": B * T / ms * 1e3, "unit": "timestep-messages/s",
+                                         "algorithmic_GBps": _gbps(eng, B, T, ms), "backward": eng.backward_schedule,
+                                         "failed_trajectories": len(eng.failures())}
+    del eng
+
+    # config 4: quadrotor MPC + cubature-KF state estimation at nx = 12, horizon 50, B = 8192 closed loops: one control step
+    # = filter + n_iter x (forward, backward, prior update) + first action + horizon shift, ONE library call (i2c_mpc_step)
+    m = make_env_model("Quadrotor12")
+    B, T, n_iter = 8192, 50, 1
+    Q, R = np.diag([10.0] * 3 + [1.0] * 3 + [0.1] * 6), 1e-2 * np.eye(4)
+    x0 = 1e-2 * rng.normal(size=(B, 12))
+    mu_u = 0.25 * m.gravity + 1e-2 * rng.normal(size=(B, T, 4))
+    eng = pkg.BatchedI2c(m, T, Q, R, Q / 10.0, 0.02, 1.0, mu_u, 1e-2 * np.eye(4), x0=x0, device=device, keep_zpost=False, keep_xm=False,
+                         z_traj=np.broadcast_to(np.concatenate((m.zg_term.reshape(-1), 0.25 * m.gravity * np.ones(4))), (T, 16)))
+    eng.tau = T - 1
+    eng.enable_per_cell_alpha()
+    sig_zeta = 1e-4 * np.eye(9)
+    y = torch.as_tensor(np.ascontiguousarray(m.measure(x0).T), dtype=torch.float64, device=device)
+    u = torch.as_tensor(np.ascontiguousarray(mu_u[:, 0, :].T), dtype=torch.float64, device=device)
+    for _ in range(2):
+        act, _ = eng.mpc_step(n_iter, y, u, sig_zeta)
+    sync(); t0 = time.perf_counter()
+    for _ in range(K):
+        act, _ = eng.mpc_step(n_iter, y, u, sig_zeta)
+    sync()
+    ms = (time.perf_counter() - t0) / K * 1e3
+    out["quadrotor12_mpc_H50_B8192"] = {"ms_per_control_step": ms, "closed_loop_steps_per_s": B / ms * 1e3, "em_iters_per_step": n_iter,
+                                        "value": B * T * n_iter / ms * 1e3, "unit": "timestep-messages/s",
+                                        "algorithmic_GBps": _gbps(eng, B, T * n_iter, ms), "kernels": "group (16 lanes per trajectory)",
+                                        "failed_trajectories": len(eng.failures())}
+    del eng
+
+    # config 5: nonlinear covariance control (pendulum, action-only cost, annealed terminal prior, closed-loop propagation
+    # and KL every iteration; scripts/experiments/pendulum_known_act_reg_quad.py:22-33), T=100, B=8192 = one GPU's share of 65536
+    m = make_env_model("PendulumKnownActReg")
+    B, T = 8192, 100
+    x0 = np.array([np.pi, 0.0]) + 1e-2 * rng.normal(size=(B, 2))
+    eng = pkg.BatchedI2c(m, T, None, np.diag([1.0]), None, 300.0, 1.0, np.zeros((B, T, 1)), 0.5 * np.eye(1), np.array([0.0, 0.0]),
+                         np.diag([1e-3, 1e-3]), x0=x0, device=device, keep_zpost=False)
+    eng.use_expert_controller = False
+    eng._propagate = True
+    eng.propagate()
+    for _ in range(2):
+        eng.learn_msgs()
+    sync(); t0 = time.perf_counter()
+    for _ in range(K):
+        eng.learn_msgs()
+    sync()
+    ms = (time.perf_counter() - t0) / K * 1e3
+    out["covariance_control_T100_B8192"] = {"ms_per_step": ms, "value": B * T / ms * 1e3, "unit": "timestep-messages/s",
+                                            "includes": "forward, backward, closed-loop propagation, KL, M-step",
+                                            "failed_trajectories": len(eng.failures())}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,42 +272,64 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="trajectories PER GPU")
     ap.add_argument("--horizon", type=int, default=200)
-    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--dtype", default="f64", choices=["f64"], help="the path computes in fp64 (the reference's arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturated", action="store_true", help="skip the extra B=131072 leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the legs of the other BASELINE configs and strong scaling")
     ap.add_argument("--backward", default="auto", choices=["auto", "two_pass", "fused", "chunked"])
+    ap.add_argument("--group-lanes", type=int, default=0, help="run the group kernels (lanes per trajectory) in the headline leg")
+    ap.add_argument("--test-hostsim", action="store_true",
+                    help="TESTS ONLY: gloo + the host simulation of the kernels on CPU, to exercise the launcher / N > 1 "
+                         "plumbing without a GPU; its numbers mean nothing")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:  # not under torchrun yet: become the launcher (before any GPU call)
+        sys.exit(launch_workers(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    lib = None
+    if args.test_hostsim:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        lib = importlib.import_module("hostsim").load()
+        device = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     dist = None
     if "RANK" in os.environ and "MASTER_ADDR" in os.environ:  # launched by torch.distributed.run (also with N = 1)
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)  # RCCL on ROCm
+        if args.test_hostsim:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)  # RCCL on ROCm
 
     pkg = importlib.import_module(PKG)
-    dtype = torch.float64 if args.dtype == "f64" else torch.float32
+    dtype = torch.float64
     B, T = args.batch, args.horizon
-    eng = make_engine(pkg, B, T, dtype, device, rank, args.backward)
+    eng = make_engine(pkg, B, T, dtype, device, rank, args.backward, lib=lib, group_lanes=args.group_lanes)
 
     def barrier():
-        torch.cuda.synchronize(device)
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
 
     for _ in range(args.warmup):
         eng.learn_msgs()
 
     # ---- per-kernel timing: K EM iterations stepped from Python with HIP events around each sweep -----
     K = args.steps
-    stepwise_s, (fwd_ms, bwd_ms, mst_ms) = timed_iterations(eng, K, barrier)
+    if device.type == "cuda":
+        stepwise_s, (fwd_ms, bwd_ms, mst_ms) = timed_iterations(eng, K, barrier)
+    else:
+        stepwise_s, (fwd_ms, bwd_ms, mst_ms) = 0.0, (float("nan"),) * 3
 
     # ---- THE timed region: exactly K EM iterations, enqueued by ONE i2c_learn call (the way a caller runs
     # N iterations: no Python between sweeps), bracketed by barrier + synchronize on both sides ---------
@@ -202,13 +350,18 @@ def main():
         gather_policy = importlib.import_module(PKG + ".dist").gather_policy
 
         gather_policy(eng)  # first call pays RCCL's lazy channel setup; time the steady-state exchange
-        torch.cuda.synchronize(device)
-        dist.barrier()
+        barrier()
         t1 = time.perf_counter()
         gathered = gather_policy(eng)
-        torch.cuda.synchronize(device)
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
         allgather_ms = (time.perf_counter() - t1) * 1e3
         assert gathered["K"].shape[0] == B * world
+
+    strong = None
+    if not args.no_extra:  # every rank takes part (collective timing)
+        strong = strong_scaling_legs(pkg, T, dtype, device, rank, world, dist, barrier, max(K // 5, 2), lib=lib,
+                                     globals_=(4096, 65536) if not args.test_hostsim else (8,))
 
     if rank != 0:
         if dist is not None:
@@ -216,7 +369,7 @@ def main():
         return
 
     cells = B * T * world
-    wbytes = 8 if args.dtype == "f64" else 4
+    wbytes = 8
     el = algorithmic_elements(eng.d, eng.nx, eng.nu)
     fwd_bytes = el["forward"] * wbytes * B * T  # per launch of the forward-sweep kernel
     achieved = fwd_bytes / (fwd_ms * 1e-3) / 1e9
@@ -233,14 +386,16 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": args.dtype,
-        "data": "synthetic",
+        "data": "synthetic" if not args.test_hostsim else "synthetic (TEST MODE: host simulation on CPU, numbers meaningless)",
         "config": {
             "workload": f"pendulum_known_quad cubature i2c (nx=2, nu=1, nz=4), T={T}, B={B} trajectories per GPU, "
                         f"global batch {B * world}, CubatureQuadrature(1,0,0), alpha0=100, tol=0",
             "batch_per_gpu": B,
             "horizon": T,
             "parallelism": f"batch-sharded x{world}, no collective in the EM loop",
+            "kernels": "group, %d lanes per trajectory" % args.group_lanes if args.group_lanes else "one lane per trajectory",
         },
+        "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
         "kernel_ms": {"forward_sweep": fwd_ms, "backward_sweep": bwd_ms, "mstep": mst_ms},
         "backward": eng.backward_schedule,
         "ms_per_step_stepped_from_python": stepwise_s / K * 1e3,
@@ -259,14 +414,27 @@ def main():
             "algorithmic_bytes_per_cell": {k: v * wbytes for k, v in el.items()},
             "whole_iteration_GBps": el["total"] * wbytes * B * T / (elapsed / K) / 1e9,
             "note": "instruction-issue-bound at B=4096 per GPU: 64 lone wavefronts (1024 SIMDs), each issuing ~88 % of its cycles "
-                    "(profiles/r1_k_forward_sq_counters.json); HBM-bound from B ~ 32768 (saturated_batch); see DESIGN.md section 6",
+                    "(profiles/r1_k_forward_sq_counters.json); spreading a trajectory over 4 lanes (group kernels) is SLOWER for "
+                    "this model (profiles/r2_pendulum_group_sq_counters.json); HBM-bound from B ~ 32768 (saturated_batch); "
+                    "see DESIGN.md section 6",
         },
         "final_allgather_ms": allgather_ms,
+        "strong_scaling": strong,
     }
-    if not args.no_saturated and world == 1:
-        out["saturated_batch"] = saturated_leg(pkg, T, dtype, device, el, wbytes)
-    if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
-        out["cpu_baseline"] = cpu_baseline(T)
+    if device.type == "cuda":
+        if not args.no_saturated and world == 1:
+            out["saturated_batch"] = saturated_leg(pkg, T, dtype, device, el, wbytes)
+            mixed = saturated_leg(pkg, T, dtype, device, el, 4, storage_dtype=torch.float32)
+            mixed.pop("device_memcpy_GBps")
+            mixed["precision"] = ("fp64 arithmetic on fp32-stored messages (I2C_F64_F32S): NOT the parity-grade path; deviation of the "
+                                  "posterior mean from the fp64 run over 12 EM iterations at T=200, B=4096: <= 2e-5 after one iteration; "
+                                  "median over the batch <= 1e-4, 99th percentile <= 3e-2 (asserted, tests/test_precision.py); the few "
+                                  "trajectories at the swing-up bifurcation deviate O(1) under ANY perturbation")
+            out["saturated_batch_fp32_storage"] = mixed
+        if not args.no_extra and world == 1:
+            out["extra"] = extra_config_legs(pkg, device)
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
+            out["cpu_baseline"] = cpu_baseline(T)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

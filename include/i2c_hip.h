@@ -55,7 +55,13 @@ enum {
   I2C_NUM_MODELS = 8
 };
 
-enum { I2C_F64 = 0, I2C_F32 = 1 };
+/* I2cProblem.dtype. I2C_F64: the reference's arithmetic, parity-grade. I2C_F64_F32S: fp64 ARITHMETIC on fp32-STORED per-cell
+ * buffers (prior/post, fwd, xm, zpost, prior_out are float; everything per trajectory -- x0, sig_x0, z, alpha, alpha_cell, temp,
+ * term_stats, cell_stats, stats, the chunk workspace -- stays double): half the HBM bytes of the sweeps; deviation from fp64
+ * bounded (tests/test_hip_precision.py). Only the cubature EM path of the one-lane kernels (forward, backward, M-step,
+ * i2c_learn); other entry points return I2C_ENOTSUP. I2C_F32: fp32 arithmetic and storage -- NOT parity-grade (the sigma-point
+ * curvature terms are below fp32 resolution; O(1) deviation after a few EM iterations): for tolerance sweeps only. */
+enum { I2C_F64 = 0, I2C_F32 = 1, I2C_F64_F32S = 2 };
 
 /* inference method of the E-step (the `inference` argument of I2cGraph, i2c/exp_types.py:22-68) */
 enum {

@@ -18,7 +18,7 @@ def _sym(n):
     return n * (n + 1) // 2
 
 
-F64, F32 = 0, 1
+F64, F32, F64_F32S = 0, 1, 2  # I2cProblem.dtype (include/i2c_hip.h): F64_F32S = fp64 arithmetic on fp32-stored per-cell buffers
 BWD_AUTO, BWD_TWO_PASS, BWD_FUSED, BWD_CHUNKED = 0, 1, 2, 3
 INF_CUBATURE, INF_LINEARIZE, INF_GAUSS_HERMITE = 0, 1, 2
 

@@ -25,7 +25,7 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"] + os.environ.get
 MODELS = [("Quadrotor12", "quadrotor12"), ("DoubleCartpole", "double_cartpole"), ("Quadrotor", "quadrotor"), ("Cartpole", "cartpole"),
           ("Pendulum", "pendulum"), ("PendulumActReg", "pendulum_actreg"), ("Linear", "linear"),
           ("LinearMinEnergy", "linear_minenergy")]
-DTYPES = [("double", "f64"), ("float", "f32")]
+DTYPES = [("double", "f64", None), ("float", "f32", None), ("double", "f64s", "float")]  # (arithmetic, tag, storage)
 
 
 def sources():
@@ -35,8 +35,9 @@ def sources():
 def translation_units():
     """[(object name, source, extra -D flags)]"""
     tus = [(f"{name}_{tag}.o", "i2c_model_tu.hip",
-            [f"-DI2C_TU_MODEL={struct}", f"-DI2C_TU_REAL={real}", f"-DI2C_TU_OPS=ops_{name}_{tag}"])
-           for struct, name in MODELS for real, tag in DTYPES]
+            [f"-DI2C_TU_MODEL={struct}", f"-DI2C_TU_REAL={real}", f"-DI2C_TU_OPS=ops_{name}_{tag}"]
+            + ([f"-DI2C_TU_STORE={store}"] if store else []))
+           for struct, name in MODELS for real, tag, store in DTYPES]
     return tus + [("capi.o", "i2c_capi.hip", [])]
 
 

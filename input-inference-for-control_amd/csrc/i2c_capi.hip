@@ -5,10 +5,10 @@
 namespace {
 
 const i2c::ModelOps* find_ops(int model_id, int dtype) {
-  if (dtype != I2C_F64 && dtype != I2C_F32) return nullptr;
+  if (dtype != I2C_F64 && dtype != I2C_F32 && dtype != I2C_F64_F32S) return nullptr;
   switch (model_id) {
 #define I2C_CASE(ID, MODEL, name) \
-  case ID: return dtype == I2C_F64 ? i2c::ops_##name##_f64() : i2c::ops_##name##_f32();
+  case ID: return dtype == I2C_F64 ? i2c::ops_##name##_f64() : (dtype == I2C_F32 ? i2c::ops_##name##_f32() : i2c::ops_##name##_f64s());
     I2C_FOR_EACH_MODEL(I2C_CASE)
 #undef I2C_CASE
     default: return nullptr;
@@ -60,7 +60,7 @@ int i2c_backward_schedule(int model_id, int B, int T, int requested_mode) {
 size_t i2c_workspace_bytes(int model_id, int dtype, int B, int T) {
   if (B < 1 || T < 1) return 0;
   const i2c::ModelOps* ops = find_ops(model_id, I2C_F64);
-  return ops ? (dtype == I2C_F32 ? 4 : 8) * ops->workspace_elems(B, T) : 0;
+  return ops ? (dtype == I2C_F32 ? 4 : 8) * ops->workspace_elems(B, T) : 0;  // the workspace is arithmetic-typed (fp64 in I2C_F64_F32S)
 }
 
 int i2c_query(int model_id, I2cDims* out) {

@@ -460,10 +460,12 @@ I2C_FN void transform(const Rule<R>& rule, const R* m, const R* Sin, const R* L,
 }
 
 
-template <typename R> struct FwdArgs {
-  const R* prior;   // [T][E_POST][B]
-  R* fwd;           // [T][E_FWD][B]
-  R* prior_out;     // [T][D + sym(D)][B] or null
+// S = element type of the PER-CELL buffers in HBM (prior/post, fwd, prior_out, xm, zpost): R normally, float with R =
+// double in the mixed mode I2C_F64_F32S (fp64 arithmetic on fp32-stored messages). Per-trajectory data stays R.
+template <typename R, typename S = R> struct FwdArgs {
+  const S* prior;   // [T][E_POST][B]
+  S* fwd;           // [T][E_FWD][B]
+  S* prior_out;     // [T][D + sym(D)][B] or null
   const R* x0;      // [NX][B]
   const R* sig_x0;  // [sym NX][B]
   const R* z;       // [T][NZ][B] or null
@@ -476,11 +478,11 @@ template <typename R> struct FwdArgs {
 // LEAN = the common case fixed at compile time (weights sum to 1, shared target, trajectory-level alpha, no
 // joint-prior output): the corresponding wave-uniform runtime branches disappear from the cell, which keeps
 // it one scheduling region. The generic variant (LEAN = false) handles everything.
-template <class M, typename R, bool LEAN = false, bool GRID = false>
-I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a, const int b) {
+template <class M, typename R, bool LEAN = false, bool GRID = false, typename ST_ = R>
+I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R, ST_>& a, const int b) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D;
-  constexpr unsigned W = sizeof(R);
+  constexpr unsigned W = sizeof(ST_);
   const unsigned long B = c.B;
   const int T = c.T;
   const unsigned bo = (unsigned)b * W;     // the lane's byte offset inside any row
@@ -509,7 +511,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     const unsigned rb = rb0;
     const Window w = make_window(a.prior, (unsigned long)C::E_POST * rb);
 #pragma unroll
-    for (int e = 0; e < C::E_PRI; ++e) pri[e] = wld<R>(w, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo);
+    for (int e = 0; e < C::E_PRI; ++e) pri[e] = (R)wld<ST_>(w, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo);
   }
 #pragma unroll
   for (int k = 0; k < NZ; ++k) zt[k] = (!LEAN && c.z_per_cell) ? a.z[(long)k * B + b] : c.zg[k];
@@ -577,7 +579,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     if (!PREFETCH && t > 0) {
       const Window w = make_window(a.prior + (unsigned long)t * C::E_POST * B, (unsigned long)C::E_POST * rb);
 #pragma unroll
-      for (int e = 0; e < C::E_PRI; ++e) pri[e] = wld<R>(w, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo);
+      for (int e = 0; e < C::E_PRI; ++e) pri[e] = (R)wld<ST_>(w, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo);
 #pragma unroll
       for (int k = 0; k < NZ; ++k) zt[k] = (!LEAN && c.z_per_cell) ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
     }
@@ -662,9 +664,9 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     if (!LEAN && a.prior_out) {
       const Window w = make_window(a.prior_out + (unsigned long)t * (D + sym(D)) * B, (unsigned long)(D + sym(D)) * rb);
 #pragma unroll
-      for (int e = 0; e < D; ++e) wst(w, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo, mu0[e]);
+      for (int e = 0; e < D; ++e) wst(w, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo, (ST_)mu0[e]);
 #pragma unroll
-      for (int e = 0; e < sym(D); ++e) wst(w, VOFF ? 0u : (D + e) * rb, VOFF ? voff[D + e] : bo, S0[e]);
+      for (int e = 0; e < sym(D); ++e) wst(w, VOFF ? 0u : (D + e) * rb, VOFF ? voff[D + e] : bo, (ST_)S0[e]);
     }
 
     ff_cur = a.ff[tn];  // the next cell's flag, a whole cell ahead of its use
@@ -672,7 +674,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     if (PREFETCH) {  // pri is dead from here on: refill it with the next cell's rows
       const Window w = make_window(a.prior + (unsigned long)tn * C::E_POST * B, (unsigned long)C::E_POST * rb);
 #pragma unroll
-      for (int e = 0; e < C::E_PRI; ++e) pri[e] = wld<R>(w, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo);
+      for (int e = 0; e < C::E_PRI; ++e) pri[e] = (R)wld<ST_>(w, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo);
     }
 
     // ---- 2. cost "observation": measurement update on z (i2c.py:390-407) --------------
@@ -698,9 +700,9 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     // mu0 / S0 now hold mu_xu1_f / sig_xu1_f
     const Window out = make_window(a.fwd + (unsigned long)t * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
-    for (int e = 0; e < D; ++e) wst(out, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo, mu0[e]);
+    for (int e = 0; e < D; ++e) wst(out, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo, (ST_)mu0[e]);
 #pragma unroll
-    for (int e = 0; e < sym(D); ++e) wst(out, VOFF ? 0u : (D + e) * rb, VOFF ? voff[D + e] : bo, S0[e]);
+    for (int e = 0; e < sym(D); ++e) wst(out, VOFF ? 0u : (D + e) * rb, VOFF ? voff[D + e] : bo, (ST_)S0[e]);
 
     // ---- 3. dynamics push-through (i2c.py:415-421) and smoother gain (i2c.py:423-425) --
     sched_fence<(D >= 6)>();
@@ -747,7 +749,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     // J is written out BEFORE the terminal update so that its d*nx registers are dead there (with J
     // live the terminal block is the register peak of the large models and spills to scratch)
 #pragma unroll
-    for (int e = 0; e < D * NX; ++e) wst(out, VOFF ? 0u : (D + sym(D) + NX + sym(NX) + e) * rb, VOFF ? voff[D + sym(D) + NX + sym(NX) + e] : bo, Sxy[e]);
+    for (int e = 0; e < D * NX; ++e) wst(out, VOFF ? 0u : (D + sym(D) + NX + sym(NX) + e) * rb, VOFF ? voff[D + sym(D) + NX + sym(NX) + e] : bo, (ST_)Sxy[e]);
     sched_fence<(D >= 6)>();
 
     // ---- 4. terminal cost observation on the flagged cell, after J (i2c.py:430-443) ----
@@ -770,9 +772,9 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R>& a
     }
     fail = fold_cell_failure(fail, cell_bad, t);
 #pragma unroll
-    for (int e = 0; e < NX; ++e) wst(out, VOFF ? 0u : (D + sym(D) + e) * rb, VOFF ? voff[D + sym(D) + e] : bo, mu_x[e]);
+    for (int e = 0; e < NX; ++e) wst(out, VOFF ? 0u : (D + sym(D) + e) * rb, VOFF ? voff[D + sym(D) + e] : bo, (ST_)mu_x[e]);
 #pragma unroll
-    for (int e = 0; e < sym(NX); ++e) wst(out, VOFF ? 0u : (D + sym(D) + NX + e) * rb, VOFF ? voff[D + sym(D) + NX + e] : bo, sig_x[e]);
+    for (int e = 0; e < sym(NX); ++e) wst(out, VOFF ? 0u : (D + sym(D) + NX + e) * rb, VOFF ? voff[D + sym(D) + NX + e] : bo, (ST_)sig_x[e]);
 
   }
   if (fail != 0 && a.status[b] == 0) a.status[b] = fail;
@@ -986,9 +988,9 @@ I2C_FN bool cell_posterior(const Consts<M, R>& c, const R* zt, R* mu, R* S, cons
 // part of the backward pass; (2) everything else, independent per cell, one lane per (t, b);
 // (3) a deterministic reduction of the per-cell cost statistics over t.
 // ------------------------------------------------------------------------------------------
-template <typename R> struct ScanArgs {
-  const R* fwd;  // [T][E_FWD][B]
-  R* xm;         // [T][E_XM][B]
+template <typename R, typename S = R> struct ScanArgs {
+  const S* fwd;  // [T][E_FWD][B]
+  S* xm;         // [T][E_XM][B]
   R* temp;       // [B] or null
   int32_t* status;
 };
@@ -997,8 +999,8 @@ template <int NX, typename R> struct ScanRow {  // the rows of one cell the recu
   R mu1[NX], S1[sym(NX)], m3f[NX], S3f[sym(NX)], Jx[NX * NX];
 };
 
-template <class M, typename R>
-I2C_HD inline void backward_scan_body(const Consts<M, R>& c, const ScanArgs<R>& a, const int b) {
+template <class M, typename R, typename S = R>
+I2C_HD inline void backward_scan_body(const Consts<M, R>& c, const ScanArgs<R, S>& a, const int b) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, D = C::D;
   constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
@@ -1010,7 +1012,7 @@ I2C_HD inline void backward_scan_body(const Consts<M, R>& c, const ScanArgs<R>& 
   using Row = ScanRow<NX, R>;
 
   auto load = [&](int t, Row& r) {
-    const R* in = a.fwd + ((long)(t > 0 ? t : 0) * C::E_FWD) * B + b;
+    const S* in = a.fwd + ((long)(t > 0 ? t : 0) * C::E_FWD) * B + b;
 #pragma unroll
     for (int i = 0; i < NX; ++i) r.mu1[i] = in[(long)i * B];
 #pragma unroll
@@ -1037,7 +1039,7 @@ I2C_HD inline void backward_scan_body(const Consts<M, R>& c, const ScanArgs<R>& 
       const int t = t0 - u;
       if (t < 0) break;
       const Row& r = cur[u];
-      R* out = a.xm + ((long)t * C::E_XM) * B + b;
+      S* out = a.xm + ((long)t * C::E_XM) * B + b;
 #pragma unroll
       for (int i = 0; i < NX; ++i) out[(long)i * B] = m3m[i];
 #pragma unroll
@@ -1063,12 +1065,12 @@ I2C_HD inline void backward_scan_body(const Consts<M, R>& c, const ScanArgs<R>& 
   }
 }
 
-template <typename R> struct CellArgs {
-  const R* fwd;      // [T][E_FWD][B]
-  const R* xm;       // [T][E_XM][B]   (two-pass: input; fused: optional output)
+template <typename R, typename S = R> struct CellArgs {
+  const S* fwd;      // [T][E_FWD][B]
+  const S* xm;       // [T][E_XM][B]   (two-pass: input; fused: optional output)
   const R* z;        // [T][NZ][B] or null
-  R* post;           // [T][E_POST][B]
-  R* zpost;          // [T][E_ZPOST][B] or null
+  S* post;           // [T][E_POST][B]
+  S* zpost;          // [T][E_ZPOST][B] or null
   R* cell_stats;     // [T][2][B]      (two-pass: required workspace; fused: optional output)
   R* term_stats;     // [E_TERM][B]
   R* temp;           // [B] or null (fused only)
@@ -1076,25 +1078,25 @@ template <typename R> struct CellArgs {
   const R* alpha;    // [B] (Linearize backward only: terminal cost update at the end of the chain)
 };
 
-template <class M, typename R>
-I2C_FN void store_cell(const Consts<M, R>& c, const CellArgs<R>& a, const int t, const int b, const R* mu, const R* S,
+template <class M, typename R, typename S_>
+I2C_FN void store_cell(const Consts<M, R>& c, const CellArgs<R, S_>& a, const int t, const int b, const R* mu, const R* S,
                        const R* ctl, const R* mz, const R* Sz, const R cm, const R cv) {
   using C = Consts<M, R>;
   constexpr int NZ = C::NZ, D = C::D;
   const long B = c.B;
-  R* out = a.post + ((long)t * C::E_POST) * B + b;
+  S_* out = a.post + ((long)t * C::E_POST) * B + b;
 #pragma unroll
-  for (int e = 0; e < D; ++e) out[(long)e * B] = mu[e];
+  for (int e = 0; e < D; ++e) out[(long)e * B] = (S_)mu[e];
 #pragma unroll
-  for (int e = 0; e < sym(D); ++e) out[(long)(D + e) * B] = S[e];
+  for (int e = 0; e < sym(D); ++e) out[(long)(D + e) * B] = (S_)S[e];
 #pragma unroll
-  for (int e = 0; e < C::E_POST - D - sym(D); ++e) out[(long)(D + sym(D) + e) * B] = ctl[e];
+  for (int e = 0; e < C::E_POST - D - sym(D); ++e) out[(long)(D + sym(D) + e) * B] = (S_)ctl[e];
   if (a.zpost) {
-    R* zo = a.zpost + ((long)t * C::E_ZPOST) * B + b;
+    S_* zo = a.zpost + ((long)t * C::E_ZPOST) * B + b;
 #pragma unroll
-    for (int k = 0; k < NZ; ++k) zo[(long)k * B] = mz[k];
+    for (int k = 0; k < NZ; ++k) zo[(long)k * B] = (S_)mz[k];
 #pragma unroll
-    for (int k = 0; k < sym(NZ); ++k) zo[(long)(NZ + k) * B] = Sz[k];
+    for (int k = 0; k < sym(NZ); ++k) zo[(long)(NZ + k) * B] = (S_)Sz[k];
   }
   if (a.cell_stats) {
     a.cell_stats[((long)t * 2 + 0) * B + b] = cm;
@@ -1103,14 +1105,14 @@ I2C_FN void store_cell(const Consts<M, R>& c, const CellArgs<R>& a, const int t,
 }
 
 // pass (2): one lane per (t, b)
-template <class M, typename R>
-I2C_HD inline void backward_cell_body(const Consts<M, R>& c, const CellArgs<R>& a, const int t, const int b) {
+template <class M, typename R, typename S_ = R>
+I2C_HD inline void backward_cell_body(const Consts<M, R>& c, const CellArgs<R, S_>& a, const int t, const int b) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NZ = C::NZ, D = C::D;
   constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
   const long B = c.B;
-  const R* in = a.fwd + ((long)t * C::E_FWD) * B + b;
-  const R* xin = a.xm + ((long)t * C::E_XM) * B + b;
+  const S_* in = a.fwd + ((long)t * C::E_FWD) * B + b;
+  const S_* xin = a.xm + ((long)t * C::E_XM) * B + b;
 
   R mu[D], S[sym(D)], J[D * NX], dm[NX], dS[sym(NX)], m3m[NX], S3m[sym(NX)];
 #pragma unroll
@@ -1135,7 +1137,7 @@ I2C_HD inline void backward_cell_body(const Consts<M, R>& c, const CellArgs<R>& 
 
   R ctl[C::E_POST - D - sym(D)], mz[NZ], Sz[sym(NZ)], cm, cv;
   if (!cell_posterior<M, R>(c, zt, mu, S, J, dm, dS, ctl, mz, Sz, &cm, &cv)) set_status(a.status, b, 7, t);
-  store_cell<M, R>(c, a, t, b, mu, S, ctl, mz, Sz, cm, cv);
+  store_cell<M, R, S_>(c, a, t, b, mu, S, ctl, mz, Sz, cm, cv);
   if (t == c.T - 1) terminal_obs_stats<M, R>(c, b, m3m, S3m, a.term_stats, a.status);
 }
 
@@ -1160,12 +1162,12 @@ I2C_FN void reduce_partial(const Consts<M, R>& c, const R* cell_stats, const int
 // the whole cell; each forward row is read once and the cost sums stay in registers, so the pass
 // moves E_FWD + E_POST elements per cell instead of the two-pass form's ~2x that.
 // ------------------------------------------------------------------------------------------
-template <class M, typename R, bool GRID = false>
-I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R>& a, const int b) {
+template <class M, typename R, bool GRID = false, typename S_ = R>
+I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R, S_>& a, const int b) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NZ = C::NZ, D = C::D;
   constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
-  constexpr unsigned W = sizeof(R);
+  constexpr unsigned W = sizeof(S_);
   const unsigned long B = c.B;
   const int T = c.T;
   const unsigned bo = (unsigned)b * W, rb = (unsigned)(B * W);
@@ -1175,7 +1177,7 @@ I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R>&
   {
     const Window w = make_window(a.fwd + (unsigned long)(T - 1) * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
-    for (int e = 0; e < C::E_FWD; ++e) row[e] = wld<R>(w, e * rb, bo);
+    for (int e = 0; e < C::E_FWD; ++e) row[e] = (R)wld<S_>(w, e * rb, bo);
   }
   R m3m[NX], S3m[sym(NX)];
   end_of_chain<M, R>(c, a.temp, b, row + O_MU3, row + O_S3, m3m, S3m, a.status);
@@ -1187,18 +1189,18 @@ I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R>&
       const int tp = t > 0 ? t - 1 : 0;
       const Window w = make_window(a.fwd + (unsigned long)tp * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
-      for (int e = 0; e < C::E_FWD; ++e) nxt[DOUBLE_BUFFER ? e : 0] = wld<R>(w, e * rb, bo);
+      for (int e = 0; e < C::E_FWD; ++e) nxt[DOUBLE_BUFFER ? e : 0] = (R)wld<S_>(w, e * rb, bo);
     } else if (t < T - 1) {
       const Window w = make_window(a.fwd + (unsigned long)t * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
-      for (int e = 0; e < C::E_FWD; ++e) row[e] = wld<R>(w, e * rb, bo);
+      for (int e = 0; e < C::E_FWD; ++e) row[e] = (R)wld<S_>(w, e * rb, bo);
     }
     if (a.xm) {
-      R* xo = const_cast<R*>(a.xm) + ((long)t * C::E_XM) * B + b;
+      S_* xo = const_cast<S_*>(a.xm) + ((long)t * C::E_XM) * B + b;
 #pragma unroll
-      for (int i = 0; i < NX; ++i) xo[(long)i * B] = m3m[i];
+      for (int i = 0; i < NX; ++i) xo[(long)i * B] = (S_)m3m[i];
 #pragma unroll
-      for (int i = 0; i < sym(NX); ++i) xo[(long)(NX + i) * B] = S3m[i];
+      for (int i = 0; i < sym(NX); ++i) xo[(long)(NX + i) * B] = (S_)S3m[i];
     }
     R dm[NX], dS[sym(NX)], zt[NZ];
 #pragma unroll
@@ -1211,7 +1213,7 @@ I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R>&
     R* S = row + D;
     R ctl[C::E_POST - D - sym(D)], mz[NZ], Sz[sym(NZ)], cm, cv;
     if (!cell_posterior<M, R, GRID>(c, zt, mu, S, row + O_J, dm, dS, ctl, mz, Sz, &cm, &cv)) set_status(a.status, b, 7, t);
-    store_cell<M, R>(c, a, t, b, mu, S, ctl, mz, Sz, cm, cv);
+    store_cell<M, R, S_>(c, a, t, b, mu, S, ctl, mz, Sz, cm, cv);
     sum_m += cm;
     sum_v += cv;
 #pragma unroll
@@ -1236,16 +1238,16 @@ I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R>&
 // the smoothed state entering every chunk, (3) every chunk is walked in parallel doing the complete
 // cell work from its boundary value. The sequential depth drops from T to ~2 T / NC + NC.
 // ------------------------------------------------------------------------------------------
-template <typename R> struct ChunkArgs {
-  CellArgs<R> cell;  // fwd, xm (optional out), z, post, zpost, cell_stats (optional out), term_stats, temp, status
+template <typename R, typename S_ = R> struct ChunkArgs {
+  CellArgs<R, S_> cell;  // fwd, xm (optional out), z, post, zpost, cell_stats (optional out), term_stats, temp, status
   R* comp;           // [NC][NX + NX*NX + sym(NX)][B]  composite maps
   R* bnd;            // [NC][NX + sym(NX)][B]          smoothed state entering each chunk
   R* part;           // [NC][2][B]                     per-chunk cost sums
   int n_chunks, chunk_len;
 };
 
-template <class M, typename R>
-I2C_HD inline void chunk_compose_body(const Consts<M, R>& c, const ChunkArgs<R>& a, const int ch, const int b) {
+template <class M, typename R, typename S_ = R>
+I2C_HD inline void chunk_compose_body(const Consts<M, R>& c, const ChunkArgs<R, S_>& a, const int ch, const int b) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, D = C::D;
   constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
@@ -1262,7 +1264,7 @@ I2C_HD inline void chunk_compose_body(const Consts<M, R>& c, const ChunkArgs<R>&
   for (int i = 0; i < sym(NX); ++i) Cc[i] = R(0);
   using Row = ScanRow<NX, R>;
   auto load = [&](int t, Row& r) {
-    const R* in = a.cell.fwd + ((long)t * C::E_FWD) * B + b;
+    const S_* in = a.cell.fwd + ((long)t * C::E_FWD) * B + b;
 #pragma unroll
     for (int i = 0; i < NX; ++i) r.mu1[i] = in[(long)i * B];
 #pragma unroll
@@ -1322,13 +1324,13 @@ I2C_HD inline void chunk_compose_body(const Consts<M, R>& c, const ChunkArgs<R>&
   for (int i = 0; i < sym(NX); ++i) out[(long)(NX + NX * NX + i) * B] = Cc[i];
 }
 
-template <class M, typename R>
-I2C_HD inline void chunk_stitch_body(const Consts<M, R>& c, const ChunkArgs<R>& a, const int b) {
+template <class M, typename R, typename S_ = R>
+I2C_HD inline void chunk_stitch_body(const Consts<M, R>& c, const ChunkArgs<R, S_>& a, const int b) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, D = C::D;
   constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, EC = NX + NX * NX + sym(NX);
   const long B = c.B;
-  const R* last = a.cell.fwd + ((long)(c.T - 1) * C::E_FWD) * B + b;
+  const S_* last = a.cell.fwd + ((long)(c.T - 1) * C::E_FWD) * B + b;
   R m3f[NX], S3f[sym(NX)], m[NX], S[sym(NX)];
 #pragma unroll
   for (int i = 0; i < NX; ++i) m3f[i] = last[(long)(O_MU3 + i) * B];
@@ -1376,16 +1378,16 @@ I2C_HD inline void chunk_stitch_body(const Consts<M, R>& c, const ChunkArgs<R>& 
   }
 }
 
-template <class M, typename R>
-I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R>& a, const int ch, const int b) {
+template <class M, typename R, typename S_ = R>
+I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R, S_>& a, const int ch, const int b) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NZ = C::NZ, D = C::D;
   constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
-  constexpr unsigned W = sizeof(R);
+  constexpr unsigned W = sizeof(S_);
   const unsigned long B = c.B;
   const unsigned bo = (unsigned)b * W, rb = (unsigned)(B * W);
   const int t_lo = ch * a.chunk_len, t_hi = (t_lo + a.chunk_len < c.T) ? t_lo + a.chunk_len : c.T;
-  const CellArgs<R>& ca = a.cell;
+  const CellArgs<R, S_>& ca = a.cell;
   R m3m[NX], S3m[sym(NX)];
   {
     const R* bi = a.bnd + ((long)ch * C::E_XM) * B + b;
@@ -1402,7 +1404,7 @@ I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R>& a,
   if (DOUBLE_BUFFER) {
     const Window w = make_window(ca.fwd + (unsigned long)(t_hi - 1) * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
-    for (int e = 0; e < C::E_FWD; ++e) row[e] = wld<R>(w, e * rb, bo);
+    for (int e = 0; e < C::E_FWD; ++e) row[e] = (R)wld<S_>(w, e * rb, bo);
   }
   R sum_m = R(0), sum_v = R(0);
   for (int t = t_hi - 1; t >= t_lo; --t) {
@@ -1410,14 +1412,14 @@ I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R>& a,
       const int tp = DOUBLE_BUFFER ? (t > t_lo ? t - 1 : t_lo) : t;
       const Window w = make_window(ca.fwd + (unsigned long)tp * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
-      for (int e = 0; e < C::E_FWD; ++e) (DOUBLE_BUFFER ? nxt[DOUBLE_BUFFER ? e : 0] : row[e]) = wld<R>(w, e * rb, bo);
+      for (int e = 0; e < C::E_FWD; ++e) (DOUBLE_BUFFER ? nxt[DOUBLE_BUFFER ? e : 0] : row[e]) = (R)wld<S_>(w, e * rb, bo);
     }
     if (ca.xm) {
-      R* xo = const_cast<R*>(ca.xm) + ((long)t * C::E_XM) * B + b;
+      S_* xo = const_cast<S_*>(ca.xm) + ((long)t * C::E_XM) * B + b;
 #pragma unroll
-      for (int i = 0; i < NX; ++i) xo[(long)i * B] = m3m[i];
+      for (int i = 0; i < NX; ++i) xo[(long)i * B] = (S_)m3m[i];
 #pragma unroll
-      for (int i = 0; i < sym(NX); ++i) xo[(long)(NX + i) * B] = S3m[i];
+      for (int i = 0; i < sym(NX); ++i) xo[(long)(NX + i) * B] = (S_)S3m[i];
     }
     R dm[NX], dS[sym(NX)], zt[NZ];
 #pragma unroll
@@ -1430,7 +1432,7 @@ I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R>& a,
     R* S = row + D;
     R ctl[C::E_POST - D - sym(D)], mz[NZ], Sz[sym(NZ)], cm, cv;
     if (!cell_posterior<M, R>(c, zt, mu, S, row + O_J, dm, dS, ctl, mz, Sz, &cm, &cv)) set_status(ca.status, b, 7, t);
-    store_cell<M, R>(c, ca, t, b, mu, S, ctl, mz, Sz, cm, cv);
+    store_cell<M, R, S_>(c, ca, t, b, mu, S, ctl, mz, Sz, cm, cv);
     sum_m += cm;
     sum_v += cv;
 #pragma unroll

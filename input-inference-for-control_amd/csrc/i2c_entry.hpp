@@ -41,7 +41,8 @@ struct ModelOps {
   X(I2C_MODEL_QUADROTOR12, Quadrotor12, quadrotor12)
 #define I2C_DECLARE_OPS(ID, MODEL, name) \
   const ModelOps* ops_##name##_f64();    \
-  const ModelOps* ops_##name##_f32();
+  const ModelOps* ops_##name##_f32();    \
+  const ModelOps* ops_##name##_f64s();
 I2C_FOR_EACH_MODEL(I2C_DECLARE_OPS)
 #undef I2C_DECLARE_OPS
 

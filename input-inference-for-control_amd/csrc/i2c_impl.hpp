@@ -69,10 +69,10 @@ static int clear_bytes(void* p, size_t n, void* stream) {
 }
 #endif
 
-template <class M, typename R, bool LEAN, bool GRID = false>
-I2C_KERNEL(SWEEP_BLOCK) k_forward(I2C_LANE_PARAMS const Consts<M, R> c, const FwdArgs<R> a, const int block) {
+template <class M, typename R, bool LEAN, bool GRID = false, typename S = R>
+I2C_KERNEL(SWEEP_BLOCK) k_forward(I2C_LANE_PARAMS const Consts<M, R> c, const FwdArgs<R, S> a, const int block) {
   const long b = I2C_LANE_X(block);  // `block` = active lanes per wave (I2C_SWEEP_LANES experiment), normally 64
-  if (b < c.B) forward_sweep_body<M, R, LEAN, GRID>(c, a, (int)b);
+  if (b < c.B) forward_sweep_body<M, R, LEAN, GRID, S>(c, a, (int)b);
 }
 template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_forward_lin(I2C_LANE_PARAMS const Consts<M, R> c, const FwdArgs<R> a) {
   const long b = I2C_LANE_X(SWEEP_BLOCK);
@@ -86,30 +86,35 @@ template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_riccati(I2C_LANE_PARAMS
   const long b = I2C_LANE_X(SWEEP_BLOCK);
   if (b < c.B) riccati_body<M, R>(c, a, (int)b);
 }
-template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_scan(I2C_LANE_PARAMS const Consts<M, R> c, const ScanArgs<R> a) {
+template <class M, typename R, typename S = R>
+I2C_KERNEL(SWEEP_BLOCK) k_scan(I2C_LANE_PARAMS const Consts<M, R> c, const ScanArgs<R, S> a) {
   const long b = I2C_LANE_X(SWEEP_BLOCK);
-  if (b < c.B) backward_scan_body<M, R>(c, a, (int)b);
+  if (b < c.B) backward_scan_body<M, R, S>(c, a, (int)b);
 }
-template <class M, typename R> I2C_KERNEL(CELL_BLOCK) k_cell(I2C_LANE_PARAMS const Consts<M, R> c, const CellArgs<R> a) {
+template <class M, typename R, typename S = R>
+I2C_KERNEL(CELL_BLOCK) k_cell(I2C_LANE_PARAMS const Consts<M, R> c, const CellArgs<R, S> a) {
   const long b = I2C_LANE_X(CELL_BLOCK);
-  if (b < c.B) backward_cell_body<M, R>(c, a, I2C_LANE_Y, (int)b);
+  if (b < c.B) backward_cell_body<M, R, S>(c, a, I2C_LANE_Y, (int)b);
 }
-template <class M, typename R, bool GRID = false>
-I2C_KERNEL(SWEEP_BLOCK) k_bwd_fused(I2C_LANE_PARAMS const Consts<M, R> c, const CellArgs<R> a) {
+template <class M, typename R, bool GRID = false, typename S = R>
+I2C_KERNEL(SWEEP_BLOCK) k_bwd_fused(I2C_LANE_PARAMS const Consts<M, R> c, const CellArgs<R, S> a) {
   const long b = I2C_LANE_X(SWEEP_BLOCK);
-  if (b < c.B) backward_fused_body<M, R, GRID>(c, a, (int)b);
+  if (b < c.B) backward_fused_body<M, R, GRID, S>(c, a, (int)b);
 }
-template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_chunk_compose(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R> a) {
+template <class M, typename R, typename S = R>
+I2C_KERNEL(SWEEP_BLOCK) k_chunk_compose(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, S> a) {
   const long b = I2C_LANE_X(SWEEP_BLOCK);
-  if (b < c.B) chunk_compose_body<M, R>(c, a, I2C_LANE_Y, (int)b);
+  if (b < c.B) chunk_compose_body<M, R, S>(c, a, I2C_LANE_Y, (int)b);
 }
-template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_chunk_stitch(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R> a) {
+template <class M, typename R, typename S = R>
+I2C_KERNEL(SWEEP_BLOCK) k_chunk_stitch(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, S> a) {
   const long b = I2C_LANE_X(SWEEP_BLOCK);
-  if (b < c.B) chunk_stitch_body<M, R>(c, a, (int)b);
+  if (b < c.B) chunk_stitch_body<M, R, S>(c, a, (int)b);
 }
-template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_chunk_walk(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R> a) {
+template <class M, typename R, typename S = R>
+I2C_KERNEL(SWEEP_BLOCK) k_chunk_walk(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, S> a) {
   const long b = I2C_LANE_X(SWEEP_BLOCK);
-  if (b < c.B) chunk_walk_body<M, R>(c, a, I2C_LANE_Y, (int)b);
+  if (b < c.B) chunk_walk_body<M, R, S>(c, a, I2C_LANE_Y, (int)b);
 }
 template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_mstep(I2C_LANE_PARAMS const Consts<M, R> c, const MstepArgs<R> a) {
   const long b = I2C_LANE_X(SWEEP_BLOCK);
@@ -141,8 +146,8 @@ template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_rollout(I2C_LANE_PARAMS
 // set (i2c_learn) the temperature M-step rides on it. The device form exchanges the partial sums through LDS; the host
 // form walks the same partition in the same order.
 constexpr int REDUCE_PARTS = 8;
-template <class M, typename R>
-I2C_FN void reduce_finish(const Consts<M, R>& c, const CellArgs<R>& a, const MstepArgs<R>& ms, const int T_mstep, const int b,
+template <class M, typename R, class CA>
+I2C_FN void reduce_finish(const Consts<M, R>& c, const CA& a, const MstepArgs<R>& ms, const int T_mstep, const int b,
                           const R m, const R v) {
   a.term_stats[(long)c.B + b] = m;
   a.term_stats[2 * (long)c.B + b] = v;
@@ -153,8 +158,8 @@ I2C_FN void reduce_finish(const Consts<M, R>& c, const CellArgs<R>& a, const Mst
   }
 }
 #ifdef I2C_HOST_SIM
-template <class M, typename R>
-static int launch_reduce(const Consts<M, R>& c, const CellArgs<R>& a, const MstepArgs<R>& ms, const int T_mstep, void*) {
+template <class M, typename R, class CA>
+static int launch_reduce(const Consts<M, R>& c, const CA& a, const MstepArgs<R>& ms, const int T_mstep, void*) {
   for (int b = 0; b < c.B; ++b) {
     R m = R(0), v = R(0);
     for (int q = 0; q < REDUCE_PARTS; ++q) {
@@ -168,8 +173,8 @@ static int launch_reduce(const Consts<M, R>& c, const CellArgs<R>& a, const Mste
   return I2C_OK;
 }
 #else
-template <class M, typename R>
-__global__ __launch_bounds__(SWEEP_BLOCK* REDUCE_PARTS) void k_reduce(const Consts<M, R> c, const CellArgs<R> a,
+template <class M, typename R, class CA>
+__global__ __launch_bounds__(SWEEP_BLOCK* REDUCE_PARTS) void k_reduce(const Consts<M, R> c, const CA a,
                                                                       const MstepArgs<R> ms, const int T_mstep) {
   __shared__ R sm[REDUCE_PARTS][SWEEP_BLOCK], sv[REDUCE_PARTS][SWEEP_BLOCK];
   const int b = blockIdx.x * SWEEP_BLOCK + threadIdx.x;
@@ -189,9 +194,9 @@ __global__ __launch_bounds__(SWEEP_BLOCK* REDUCE_PARTS) void k_reduce(const Cons
     reduce_finish<M, R>(c, a, ms, T_mstep, b, m, v);
   }
 }
-template <class M, typename R>
-static int launch_reduce(const Consts<M, R>& c, const CellArgs<R>& a, const MstepArgs<R>& ms, const int T_mstep, void* stream) {
-  hipLaunchKernelGGL((k_reduce<M, R>), dim3((c.B + SWEEP_BLOCK - 1) / SWEEP_BLOCK), dim3(SWEEP_BLOCK, REDUCE_PARTS), 0,
+template <class M, typename R, class CA>
+static int launch_reduce(const Consts<M, R>& c, const CA& a, const MstepArgs<R>& ms, const int T_mstep, void* stream) {
+  hipLaunchKernelGGL((k_reduce<M, R, CA>), dim3((c.B + SWEEP_BLOCK - 1) / SWEEP_BLOCK), dim3(SWEEP_BLOCK, REDUCE_PARTS), 0,
                      (hipStream_t)stream, c, a, ms, T_mstep);
   return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
 }
@@ -353,10 +358,13 @@ template <class M> static size_t workspace_elems(int B, int T) {
 //                 lane's registers): every call runs the group kernels
 //   I2cProblem.group_lanes   0: the model's default (group kernels iff GROUP_ONLY); G = M::GROUP: ask for the group
 //                 kernels; anything else: I2C_ENOTSUP
-template <class M, typename R> struct Impl {
+//   S             storage type of the per-cell buffers: R, or float with R = double (I2C_F64_F32S: the cubature EM path of the
+//                 one-lane kernels only -- forward, backward, M-step, i2c_learn; everything else is I2C_ENOTSUP)
+template <class M, typename R, typename S = R> struct Impl {
   using C = Consts<M, R>;
+  static constexpr bool MIXED = sizeof(S) != sizeof(R);
   static constexpr int G = M::GROUP;
-  static constexpr bool HAS_GROUP = G > 0 && sizeof(R) == 8;
+  static constexpr bool HAS_GROUP = G > 0 && sizeof(R) == 8 && !MIXED;
   static constexpr bool LANE = !M::GROUP_ONLY;  // one-lane-per-trajectory kernels exist
 
   // 1: group kernels, 0: one lane per trajectory, < 0: error code
@@ -371,9 +379,35 @@ template <class M, typename R> struct Impl {
     return I2C_OK;
   }
 
+  // the sigma-point forward sweep of the one-lane kernels, for either storage type
+  static int forward_lane(const I2cProblem* p, const C& c, const FwdArgs<R, S>& a, void* stream) {
+    if constexpr (LANE) {
+#ifdef I2C_HOST_SIM
+      const int lanes = SWEEP_BLOCK;
+#else
+      const int lanes = sweep_lanes();
+#endif
+      const bool lean = c.rule_xu.unit && c.rule_x.unit && !c.z_per_cell && !a.alpha_cell && !a.prior_out;
+      if (lean) return launch(k_forward<M, R, true, false, S>, p->B, 1, lanes, stream, c, a, lanes);
+      return launch(k_forward<M, R, false, false, S>, p->B, 1, lanes, stream, c, a, lanes);
+    }
+    return I2C_ENOTSUP;
+  }
+
   static int forward(const I2cProblem* p, const void* prior, void* fwd, void* prior_out, int32_t* status,
                      void* stream) {
     const C c = make_consts<M, R>(p, 0.0, p->inference == I2C_INF_LINEARIZE ? p->expert_controller : 0);
+    if constexpr (MIXED) {  // fp64 arithmetic on fp32-stored messages: the cubature path of the one-lane kernels only
+      if (p->inference != I2C_INF_CUBATURE || use_group(p) != 0) return I2C_ENOTSUP;
+      FwdArgs<R, S> am{(const S*)prior, (S*)fwd, (S*)prior_out, (const R*)p->x0, (const R*)p->sig_x0,
+                       (const R*)p->z,  (const R*)p->alpha, (const R*)p->alpha_cell, p->feedforward, status};
+      return forward_lane(p, c, am, stream);
+    } else {
+      return forward_any(p, c, prior, fwd, prior_out, status, stream);
+    }
+  }
+  static int forward_any(const I2cProblem* p, const C& c, const void* prior, void* fwd, void* prior_out, int32_t* status,
+                         void* stream) {
     FwdArgs<R> a{(const R*)prior, (R*)fwd, (R*)prior_out, (const R*)p->x0, (const R*)p->sig_x0,
                  (const R*)p->z,  (const R*)p->alpha, (const R*)p->alpha_cell, p->feedforward, status};
     const int grp = use_group(p);
@@ -388,14 +422,7 @@ template <class M, typename R> struct Impl {
       if (p->inference == I2C_INF_LINEARIZE) return launch(k_forward_lin<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, a);
       if (p->inference == I2C_INF_GAUSS_HERMITE)
         return launch(k_forward<M, R, false, true>, p->B, 1, SWEEP_BLOCK, stream, c, a, SWEEP_BLOCK);
-#ifdef I2C_HOST_SIM
-      const int lanes = SWEEP_BLOCK;
-#else
-      const int lanes = sweep_lanes();
-#endif
-      const bool lean = c.rule_xu.unit && c.rule_x.unit && !c.z_per_cell && !a.alpha_cell && !a.prior_out;
-      if (lean) return launch(k_forward<M, R, true>, p->B, 1, lanes, stream, c, a, lanes);
-      return launch(k_forward<M, R, false>, p->B, 1, lanes, stream, c, a, lanes);
+      if constexpr (!MIXED) return forward_lane(p, c, a, stream);
     }
     return I2C_ENOTSUP;
   }
@@ -435,6 +462,17 @@ template <class M, typename R> struct Impl {
     const C c = make_consts<M, R>(p, fuse ? fuse->tol : 0.0, 0);
     MstepArgs<R> ms{(const R*)term_stats, fuse ? (R*)p->alpha : nullptr, fuse ? (R*)fuse->stats_out : nullptr,
                     fuse ? fuse->update : 0};
+    if constexpr (MIXED) {
+      if (p->inference != I2C_INF_CUBATURE || use_group(p) != 0) return I2C_ENOTSUP;
+      CellArgs<R, S> am{(const S*)fwd, (const S*)xm,   (const R*)p->z, (S*)post,  (S*)zpost,
+                        (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   (const R*)p->alpha};
+      return backward_lane(p, c, am, ms, fuse, stream);
+    } else {
+      return backward_any(p, c, ms, fwd, xm, post, zpost, cell_stats, term_stats, status, stream, fuse);
+    }
+  }
+  static int backward_any(const I2cProblem* p, const C& c, const MstepArgs<R>& ms, const void* fwd, void* xm, void* post,
+                          void* zpost, void* cell_stats, void* term_stats, int32_t* status, void* stream, MstepFuse* fuse) {
     CellArgs<R> a{(const R*)fwd, (const R*)xm,   (const R*)p->z, (R*)post,  (R*)zpost,
                   (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   (const R*)p->alpha};
     const int grp = use_group(p);
@@ -452,10 +490,18 @@ template <class M, typename R> struct Impl {
       }
       if (p->inference == I2C_INF_GAUSS_HERMITE)  // one schedule: the fused walk with the grid transform
         return launch(k_bwd_fused<M, R, true>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+      if constexpr (!MIXED) return backward_lane(p, c, a, ms, fuse, stream);
+    }
+    return I2C_ENOTSUP;
+  }
+  // the three schedules of the sigma-point backward sweep of the one-lane kernels, for either storage type
+  static int backward_lane(const I2cProblem* p, const C& c, const CellArgs<R, S>& a, const MstepArgs<R>& ms, MstepFuse* fuse,
+                           void* stream) {
+    if constexpr (LANE) {
       const int mode = pick_mode(p);
-      if (mode == I2C_BWD_FUSED) return launch(k_bwd_fused<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+      if (mode == I2C_BWD_FUSED) return launch(k_bwd_fused<M, R, false, S>, p->B, 1, SWEEP_BLOCK, stream, c, a);
       if (mode == I2C_BWD_CHUNKED) {
-        ChunkArgs<R> ch{a, nullptr, nullptr, nullptr, 0, 0};
+        ChunkArgs<R, S> ch{a, nullptr, nullptr, nullptr, 0, 0};
         chunk_geometry(p->B, p->T, &ch.n_chunks, &ch.chunk_len);
         constexpr int NX = M::NX;
         ch.comp = (R*)p->work;
@@ -463,19 +509,19 @@ template <class M, typename R> struct Impl {
         ch.part = ch.bnd + (size_t)ch.n_chunks * (NX + sym(NX)) * p->B;
         C cr = c;  // reduction over chunks instead of cells: same kernel, T := number of chunks
         cr.T = ch.n_chunks;
-        CellArgs<R> ared = a;
+        CellArgs<R, S> ared = a;
         ared.cell_stats = ch.part;
-        int rc = launch(k_chunk_compose<M, R>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
-        if (rc == I2C_OK) rc = launch(k_chunk_stitch<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, ch);
-        if (rc == I2C_OK) rc = launch(k_chunk_walk<M, R>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
+        int rc = launch(k_chunk_compose<M, R, S>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
+        if (rc == I2C_OK) rc = launch(k_chunk_stitch<M, R, S>, p->B, 1, SWEEP_BLOCK, stream, c, ch);
+        if (rc == I2C_OK) rc = launch(k_chunk_walk<M, R, S>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
         if (rc == I2C_OK) rc = launch_reduce<M, R>(cr, ared, ms, p->T, stream);
         if (fuse) fuse->done = true;
         return rc;
       }
-      if (!xm || !cell_stats) return I2C_EINVAL;  // two-pass needs both as workspace
-      ScanArgs<R> sc{(const R*)fwd, (R*)xm, (R*)p->temp, status};
-      int rc = launch(k_scan<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, sc);
-      if (rc == I2C_OK) rc = launch(k_cell<M, R>, p->B, p->T, CELL_BLOCK, stream, c, a);
+      if (!a.xm || !a.cell_stats) return I2C_EINVAL;  // two-pass needs both as workspace
+      ScanArgs<R, S> sc{a.fwd, const_cast<S*>(a.xm), (R*)p->temp, a.status};
+      int rc = launch(k_scan<M, R, S>, p->B, 1, SWEEP_BLOCK, stream, c, sc);
+      if (rc == I2C_OK) rc = launch(k_cell<M, R, S>, p->B, p->T, CELL_BLOCK, stream, c, a);
       if (rc == I2C_OK) rc = launch_reduce<M, R>(c, a, ms, p->T, stream);
       if (fuse) fuse->done = true;
       return rc;
@@ -485,6 +531,7 @@ template <class M, typename R> struct Impl {
 
   static int riccati(const I2cProblem* p, const void* prior_out, const void* fwd, const void* xm, void* post, void* ric,
                      int32_t* status, void* stream) {
+    if constexpr (MIXED) return I2C_ENOTSUP;
     if constexpr (LANE) {
       if (use_group(p) != 0) return I2C_ENOTSUP;
       const C c = make_consts<M, R>(p, 0.0, 0);
@@ -531,6 +578,7 @@ template <class M, typename R> struct Impl {
 
   static int ckf(const I2cProblem* p, const double* sig_zeta, const void* y, const void* u, void* mu, void* cov,
                  int32_t* status, void* stream) {
+    if constexpr (MIXED) return I2C_ENOTSUP;
     const C c = make_consts<M, R>(p, 0.0, 0);
     ZetaArg<M, R> z;
     for (int i = 0; i < sym(M::NY); ++i) z.v[i] = (R)sig_zeta[i];
@@ -547,6 +595,7 @@ template <class M, typename R> struct Impl {
   // One control step of the MPC loop enqueued by one call (i2c/policy/mpc.py:156-182): filter, n_iter x (forward,
   // backward, _update_priors), first action, horizon shift into the second set of buffers.
   static int mpc_step(const I2cProblem* p, const I2cMpcStep* m, void* stream) {
+    if constexpr (MIXED) return I2C_ENOTSUP;
     int rc = I2C_OK;
     if (m->do_filter) rc = ckf(p, m->sig_zeta, m->y, m->u, const_cast<void*>(p->x0), const_cast<void*>(p->sig_x0), m->status, stream);
     for (int it = 0; it < m->n_iter && rc == I2C_OK; ++it) {
@@ -565,6 +614,7 @@ template <class M, typename R> struct Impl {
   static int rollout(const I2cProblem* p, const void* post, int n_rollouts, int policy, const void* eps_x0,
                      const void* eps_x, const void* eps_u, void* xu, void* z, void* x_final, void* z_term,
                      void* stream) {
+    if constexpr (MIXED) return I2C_ENOTSUP;
     const C c = make_consts<M, R>(p, 0.0, 0);
     RolloutArgs<R> a{(const R*)post, (const R*)p->x0, (const R*)p->sig_x0, (const R*)eps_x0, (const R*)eps_x,
                      (const R*)eps_u, (R*)xu, (R*)z, (R*)x_final, (R*)z_term, n_rollouts, policy};
@@ -573,6 +623,7 @@ template <class M, typename R> struct Impl {
 
   static int propagate(const I2cProblem* p, const void* post, void* prop, void* prop_stats, int use_expert,
                        int32_t* status, void* stream) {
+    if constexpr (MIXED) return I2C_ENOTSUP;
     const C c = make_consts<M, R>(p, 0.0, use_expert);
     PropArgs<R> a{(const R*)post, (R*)prop, (R*)prop_stats, (const R*)p->x0, (const R*)p->sig_x0,
                   (const R*)p->z, p->feedforward, status};
@@ -609,8 +660,8 @@ template <class M> static void fill_dims(I2cDims* d) {
   d->group_only = M::GROUP_ONLY ? 1 : 0;
 }
 
-template <class M, typename R> const ModelOps* make_ops() {
-  using I = Impl<M, R>;
+template <class M, typename R, typename S = R> const ModelOps* make_ops() {
+  using I = Impl<M, R, S>;
   static const ModelOps ops = {&I::forward, &I::backward,  &I::mstep,        &I::learn,           &I::ckf,
                                &I::rollout, &I::propagate, &I::riccati,   &I::mpc_step,        &fill_dims<M>,
                                &workspace_elems<M>, &I::schedule};

@@ -1,5 +1,6 @@
 // One translation unit per (model, dtype): compiled with
-//   -DI2C_TU_MODEL=<struct in i2c_models.hpp> -DI2C_TU_REAL=<double|float> -DI2C_TU_OPS=<ops_<name>_<f64|f32>>
+//   -DI2C_TU_MODEL=<struct in i2c_models.hpp> -DI2C_TU_REAL=<double|float> -DI2C_TU_OPS=<ops_<name>_<f64|f32|f64s>>
+//   [-DI2C_TU_STORE=float]   storage type of the per-cell buffers (default: I2C_TU_REAL); f64s = double arithmetic, float storage
 // (see build.py). All kernels of the pair are instantiated here and nowhere else.
 #include "i2c_impl.hpp"
 
@@ -8,5 +9,8 @@
 #endif
 
 namespace i2c {
-const ModelOps* I2C_TU_OPS() { return make_ops<I2C_TU_MODEL, I2C_TU_REAL>(); }
+#ifndef I2C_TU_STORE
+#define I2C_TU_STORE I2C_TU_REAL
+#endif
+const ModelOps* I2C_TU_OPS() { return make_ops<I2C_TU_MODEL, I2C_TU_REAL, I2C_TU_STORE>(); }
 }  // namespace i2c

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _native
-from ._native import F32, F64, I2cProblem
+from ._native import F32, F64, F64_F32S, I2cProblem
 
 
 def sym_size(n):
@@ -54,7 +54,7 @@ class BatchedI2c:
                  mu_x_terminal=None, sig_x_terminal=None, quad=(1.0, 0.0, 0.0), x0=None, sig_x0=None,
                  z_traj=None, batch=None, dtype=torch.float64, device=None, lib=None, dtemp=1.0,
                  keep_zpost=True, keep_prior=False, keep_xm=True, backward_mode="auto", inference="cubature",
-                 gh_degree=None, group_lanes=0):
+                 gh_degree=None, group_lanes=0, storage_dtype=None, allow_inexact=False):
         self.lib = lib if lib is not None else _native.load_library()
         if device is None:
             device = "cpu" if self.lib.is_host_sim else "cuda"
@@ -64,8 +64,23 @@ class BatchedI2c:
                 f"library '{self.lib.build_info}' cannot run on device {self.device}: the HIP build needs a "
                 "GPU tensor device (there is no CPU fallback)"
             )
+        # Precision. dtype = ARITHMETIC type: float64 is the reference's arithmetic and the only parity-grade one.
+        #   storage_dtype=torch.float32 with dtype=torch.float64: the mixed mode I2C_F64_F32S -- fp64 arithmetic on fp32-STORED
+        #     per-cell buffers (post, fwd, xm, zpost, prior_out); half the HBM bytes, deviation from fp64 bounded
+        #     (tests/test_hip_precision.py); cubature EM path of the one-lane kernels only.
+        #   dtype=torch.float32: fp32 arithmetic. NOT parity-grade (the curvature terms of the sigma-point transform are
+        #     below fp32 resolution: O(1) deviation after a few EM iterations with status 0), so it has to be asked for
+        #     explicitly with allow_inexact=True (tolerance sweeps).
         assert dtype in (torch.float64, torch.float32)
+        if dtype == torch.float32 and not allow_inexact:
+            raise ValueError("dtype=torch.float32 runs the kernels in fp32 ARITHMETIC, which is not parity-grade (DESIGN.md section 4): "
+                             "pass allow_inexact=True for a tolerance sweep, or storage_dtype=torch.float32 with dtype=torch.float64 "
+                             "for fp32 storage with fp64 arithmetic")
+        if storage_dtype not in (None, dtype, torch.float32):
+            raise ValueError("storage_dtype must be None, the arithmetic dtype, or torch.float32")
         self.dtype = dtype
+        self.store_dtype = dtype if storage_dtype is None else storage_dtype
+        self.mixed = self.store_dtype != self.dtype
         self.sys = model
         self.model_id = int(model.model_id)
         dims = self.lib.query(self.model_id)
@@ -82,6 +97,8 @@ class BatchedI2c:
         if self.group_lanes not in (0, dims.group_lanes):
             raise ValueError(f"group_lanes={self.group_lanes}: this model's group kernels use {dims.group_lanes} lanes")
         self.uses_group_kernels = bool(self.group_lanes or dims.group_only)
+        if self.mixed and (self.uses_group_kernels or inference != "cubature"):
+            raise ValueError("fp32 storage (storage_dtype) is available for the cubature path of the one-lane kernels only")
 
         mu_u = np.asarray(mu_u, dtype=np.float64)
         if mu_u.ndim == 2:
@@ -154,9 +171,10 @@ class BatchedI2c:
             raise TypeError("sig_x_terminal given without mu_x_terminal (the reference crashes at i2c.py:558)")
         self.dtemp = float(dtemp)
 
-        dev, dt = self.device, self.dtype
+        dev, dt, st = self.device, self.dtype, self.store_dtype
         to = lambda a: torch.as_tensor(np.array(a, dtype=np.float64, order="C"), dtype=dt, device=dev)  # noqa: E731
         zeros = lambda *s: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+        zeros_s = lambda *s: torch.zeros(*s, dtype=st, device=dev)  # noqa: E731  (per-cell buffers: storage type)
         d = self.d
         # initial "posterior" = cell constructor state (i2c.py:95-100, 135-136)
         post = np.zeros((T, dims.e_post, B))
@@ -169,10 +187,10 @@ class BatchedI2c:
         o_k = d + sym_size(d) + nu * nx
         post[:, o_k: o_k + nu, :] = np.transpose(mu_u, (1, 2, 0))  # k = mu_u (i2c.py:136)
         post[:, o_k + nu:, :] = pack_sym_np(sig_u)[None, :, None]
-        self.post = to(post)
-        self.fwd = zeros(T, dims.e_fwd, B)
-        self.zpost = zeros(T, dims.e_zpost, B) if keep_zpost else None
-        self.prior_out = zeros(T, d + sym_size(d), B) if keep_prior else None
+        self.post = to(post).to(st)
+        self.fwd = zeros_s(T, dims.e_fwd, B)
+        self.zpost = zeros_s(T, dims.e_zpost, B) if keep_zpost else None
+        self.prior_out = zeros_s(T, d + sym_size(d), B) if keep_prior else None
         self.backward_mode = {"auto": _native.BWD_AUTO, "two_pass": _native.BWD_TWO_PASS, "fused": _native.BWD_FUSED,
                               "chunked": _native.BWD_CHUNKED}[backward_mode]
         mode = self.lib.i2c_backward_schedule(self.model_id, B, T, self.backward_mode)  # resolves "auto"
@@ -184,7 +202,7 @@ class BatchedI2c:
         self.backward_schedule = {_native.BWD_TWO_PASS: "two_pass", _native.BWD_FUSED: "fused", _native.BWD_CHUNKED: "chunked"}[mode]
         # the two-pass backward needs xm / cell_stats as workspace; the fused and chunked ones only write xm on request
         two_pass = mode == _native.BWD_TWO_PASS
-        self.xm = zeros(T, dims.e_xm, B) if (keep_xm or two_pass) else None
+        self.xm = zeros_s(T, dims.e_xm, B) if (keep_xm or two_pass) else None
         self.cell_stats = zeros(T, 2, B) if two_pass else None
         self.work = None
         if mode == _native.BWD_CHUNKED:
@@ -229,7 +247,7 @@ class BatchedI2c:
         p = I2cProblem()
         p.abi_version = _native.ABI_VERSION
         p.model_id = self.model_id
-        p.dtype = F64 if self.dtype == torch.float64 else F32
+        p.dtype = F64_F32S if self.mixed else (F64 if self.dtype == torch.float64 else F32)
         p.B, p.T = self.B, self.H
         p.has_Qf = int(self.has_Qf)
         p.has_x_terminal = int(self.has_x_terminal)

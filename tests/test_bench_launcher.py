@@ -1,0 +1,40 @@
+"""`python bench.py --gpus N` must start its own N workers (the driver's plain form): exercised here with N = 2 on CPU --
+gloo + the host simulation of the kernels (bench.py --test-hostsim, a test-only switch) -- so that the launcher, the
+rendezvous on 127.0.0.1, the max-over-ranks timing, the final all-gather and the strong-scaling legs are covered without
+a GPU. The numbers of this mode mean nothing; the JSON contract is what is checked."""
+import json
+import os
+import subprocess
+import sys
+
+import hostsim
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args):
+    hostsim.build()  # once, in the parent, so that the two workers do not race to build it
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on rank 0"
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks():
+    out = _run(["--gpus", "2", "--test-hostsim", "--batch", "6", "--horizon", "12", "--steps", "2", "--warmup", "1"])
+    assert out["n_gpus"] == 2 and out["rccl_world_size"] == 2 and out["scaling"] == "weak"
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True
+    assert out["config"]["batch_per_gpu"] == 6 and "global batch 12" in out["config"]["workload"]
+    assert out["value"] > 0 and out["final_allgather_ms"] is not None
+    assert out["strong_scaling"][0]["global_batch"] == 8 and out["strong_scaling"][0]["batch_per_gpu"] == 4
+    assert "TEST MODE" in out["data"]
+
+
+def test_bench_single_process_contract():
+    out = _run(["--test-hostsim", "--batch", "5", "--horizon", "10", "--steps", "2", "--warmup", "1", "--no-extra"])
+    assert out["n_gpus"] == 1 and out["final_allgather_ms"] is None and out["strong_scaling"] is None
+    for key in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "vs_baseline"):
+        assert key in out
+    assert out["dtype"] == "f64" and out["roofline"]["bound"] == "hbm" and out["roofline"]["peak"] == 8000.0

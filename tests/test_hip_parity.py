@@ -181,7 +181,7 @@ def test_hip_fp32_runs_and_tracks_fp64(lib):
     """fp32 variant (config 3's tolerance sweep): same problem in both precisions."""
     g = load_case("em_pendulum_T200")
     e64 = parity.engine_from_case(g, lib, "cuda", dtype=torch.float64)
-    e32 = parity.engine_from_case(g, lib, "cuda", dtype=torch.float32)
+    e32 = parity.engine_from_case(g, lib, "cuda", dtype=torch.float32, allow_inexact=True)
     for _ in range(3):
         e64.learn_msgs()
         e32.learn_msgs()
