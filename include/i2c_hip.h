@@ -84,7 +84,7 @@ enum {
 
 enum {
   I2C_OK = 0,
-  I2C_EINVAL = -1,   /* bad argument (null pointer, unknown model / dtype, B or T < 1) */
+  I2C_EINVAL = -1,   /* bad argument (null pointer, unknown model / dtype, B or T < 1, T > 65535) */
   I2C_ENOTSUP = -2,  /* combination not compiled in */
   I2C_ELAUNCH = -3   /* HIP launch error (hipGetLastError != hipSuccess) */
 };

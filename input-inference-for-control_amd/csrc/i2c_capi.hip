@@ -17,7 +17,7 @@ const i2c::ModelOps* find_ops(int model_id, int dtype) {
 
 int check_problem(const I2cProblem* p) {
   if (!p || p->abi_version != I2C_ABI_VERSION) return I2C_EINVAL;
-  if (p->B < 1 || p->T < 1) return I2C_EINVAL;
+  if (p->B < 1 || p->T < 1 || p->T > 65535) return I2C_EINVAL;  // status words keep t + 1 in 16 bits
   if (!p->x0 || !p->sig_x0 || !p->alpha || !p->feedforward) return I2C_EINVAL;
   if (p->has_x_terminal && !p->temp) return I2C_EINVAL;
   if (p->inference < I2C_INF_CUBATURE || p->inference > I2C_INF_GAUSS_HERMITE) return I2C_EINVAL;

@@ -54,7 +54,7 @@ class BatchedI2c:
                  mu_x_terminal=None, sig_x_terminal=None, quad=(1.0, 0.0, 0.0), x0=None, sig_x0=None,
                  z_traj=None, batch=None, dtype=torch.float64, device=None, lib=None, dtemp=1.0,
                  keep_zpost=True, keep_prior=False, keep_xm=True, backward_mode="auto", inference="cubature",
-                 gh_degree=None, group_lanes=0, storage_dtype=None, allow_inexact=False):
+                 gh_degree=None, group_lanes=0, storage_dtype=None, allow_inexact=False, keep_prior_joint=False):
         self.lib = lib if lib is not None else _native.load_library()
         if device is None:
             device = "cpu" if self.lib.is_host_sim else "cuda"
@@ -188,6 +188,13 @@ class BatchedI2c:
         post[:, o_k: o_k + nu, :] = np.transpose(mu_u, (1, 2, 0))  # k = mu_u (i2c.py:136)
         post[:, o_k + nu:, :] = pack_sym_np(sig_u)[None, :, None]
         self.post = to(post).to(st)
+        # The forward sweep reads `prior`, the backward sweep writes `post`. Normally they are ONE buffer (after
+        # _update_priors the prior IS the posterior, i2c.py:1210-1221, so the copy is free). keep_prior_joint=True keeps
+        # them apart until update_priors(): two forward/backward passes without _update_priors() in between then start
+        # from the same prior, as the reference's cells do (the drop-in I2cGraph asks for this; costs a second buffer).
+        self.keep_prior_joint = bool(keep_prior_joint)
+        self.prior = self.post
+        self._post_spare = torch.empty_like(self.post) if self.keep_prior_joint else None
         self.fwd = zeros_s(T, dims.e_fwd, B)
         self.zpost = zeros_s(T, dims.e_zpost, B) if keep_zpost else None
         self.prior_out = zeros_s(T, d + sym_size(d), B) if keep_prior else None
@@ -318,12 +325,14 @@ class BatchedI2c:
     def forward_sweep(self):
         """I2cGraph._forward_msgs (i2c.py:876-880)."""
         self._problem.expert_controller = int(bool(self.use_expert_controller))
-        rc = self.lib.i2c_forward_sweep(C.byref(self._problem), self._ptr(self.post), self._ptr(self.fwd),
+        rc = self.lib.i2c_forward_sweep(C.byref(self._problem), self._ptr(self.prior), self._ptr(self.fwd),
                                         self._ptr(self.prior_out), self._ptr(self.status), self._stream())
         self._check(rc, "i2c_forward_sweep")
 
     def backward_sweep(self):
         """I2cGraph._backward_msgs (i2c.py:882-886) + per-cell M-step statistics."""
+        if self.keep_prior_joint and self.post is self.prior:  # do not overwrite the prior of this sweep
+            self.post, self._post_spare = self._post_spare, None
         rc = self.lib.i2c_backward_sweep(C.byref(self._problem), self._ptr(self.fwd), self._ptr(self.xm),
                                          self._ptr(self.post), self._ptr(self.zpost), self._ptr(self.cell_stats),
                                          self._ptr(self.term_stats), self._ptr(self.status), self._stream())
@@ -367,10 +376,26 @@ class BatchedI2c:
         the posterior buffer as its prior; only the feed-forward -> feedback flags change."""
         if self.tau > 0:
             self.feedforward[: self.tau + 1] = 0
+        if self.prior is not self.post:  # keep_prior_joint: the posterior becomes the prior, the old prior buffer is free
+            self._post_spare, self.prior = self.prior, self.post
 
     def _alpha_from_propagation(self):
         """calculate_alpha(sum of propagated observation covariances) (i2c.py:901-904, 934-939)."""
         return self.prop_stats[0] / float(self.nz * self.H)
+
+    def alpha_mstep(self, update_alpha=True):
+        """compute_update_alpha (i2c.py:921-963) alone: alpha_hat from the backward sweep's statistics, the clamp, and --
+        with update_alpha -- the new temperature in every cell (update_xi). No cost bookkeeping, no prior update.
+        Returns (alpha_hat, alpha after the clamp) as (B,) tensors and appends them to alphas_desired / alphas."""
+        rc = self.lib.i2c_mstep(C.byref(self._problem), self._ptr(self.term_stats), self.alpha_update_tol,
+                                int(bool(update_alpha)), self._ptr(self.stats_out), self._stream())
+        self._check(rc, "i2c_mstep")
+        out = self.stats_out.clone()
+        self.alphas_desired.append(out[0])
+        self.alphas.append(out[1])
+        if update_alpha:
+            self._broadcast_alpha()
+        return out[0], out[1]
 
     def maximize(self, update_alpha=True):
         """I2cGraph._maximize (i2c.py:1004-1019): cost, prior update, temperature M-step."""
@@ -406,7 +431,10 @@ class BatchedI2c:
         """n_iters EM iterations enqueued from C++ with no host round trip (i2c_learn). Same results as
         calling learn_msgs() n_iters times; available when closed-loop propagation is off."""
         n_iters = int(n_iters)
-        if self._propagate or self.prior_out is not None or n_iters <= 0:
+        # The fused loop updates only alpha[b]; with per-cell temperatures (MPC) every cell has to take the new alpha each
+        # iteration (update_xi, i2c.py:961-981), which the stepwise path does through _broadcast_alpha(). Separate prior /
+        # posterior buffers (keep_prior_joint) also need the host-side swap of update_priors().
+        if self._propagate or self.prior_out is not None or n_iters <= 0 or self.alpha_cell is not None or self.keep_prior_joint:
             for _ in range(n_iters):
                 self.learn_msgs()
             return
@@ -457,7 +485,8 @@ class BatchedI2c:
         ny = self.dims.ny
         assert y.shape == (ny, self.B) and u.shape == (self.nu, self.B) and y.dtype == self.dtype
         zeta = (C.c_double * sym_size(ny))(*pack_sym_np(np.asarray(sig_zeta, np.float64)).reshape(-1))
-        rc = self.lib.i2c_ckf_filter(C.byref(self._problem), zeta, self._ptr(y.contiguous()), self._ptr(u.contiguous()),
+        y, u = y.contiguous(), u.contiguous()  # bound to locals: a temporary copy must outlive the launch
+        rc = self.lib.i2c_ckf_filter(C.byref(self._problem), zeta, self._ptr(y), self._ptr(u),
                                      self._ptr(mu), self._ptr(cov), self._ptr(self.status), self._stream())
         self._check(rc, "i2c_ckf_filter")
         return mu, cov
@@ -530,7 +559,10 @@ class BatchedI2c:
         rc = self.lib.i2c_mpc_step(C.byref(self._problem), C.byref(st), self._stream())
         self._check(rc, "i2c_mpc_step")
         # the shifted horizon becomes the current one
+        alias = self.prior is self.post
         self.post, nxt["post"] = nxt["post"], self.post
+        if alias:
+            self.prior = self.post
         self.feedforward, nxt["feedforward"] = nxt["feedforward"], self.feedforward
         if self.alpha_cell is not None:
             self.alpha_cell, nxt["alpha_cell"] = nxt["alpha_cell"], self.alpha_cell

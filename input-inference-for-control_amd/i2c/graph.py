@@ -132,7 +132,7 @@ class I2cGraph:
             sys, horizon, Q, R, Qf, alpha, alpha_update_tol, mu_u, sig_u, mu_x_terminal, sig_x_terminal,
             quad=inference.as_tuple() if isinstance(inference, CubatureQuadrature) else (1.0, 0.0, 0.0),
             x0=x0, sig_x0=sig_x0, z_traj=z_traj, batch=batch, dtype=dtype,
-            device=device, lib=lib, keep_zpost=True, keep_prior=True,
+            device=device, lib=lib, keep_zpost=True, keep_prior=True, keep_prior_joint=True,
             inference=("linearize" if isinstance(inference, Linearize) else
                        "gauss_hermite" if isinstance(inference, GaussHermiteQuadrature) else "cubature"),
             gh_degree=getattr(inference, "degree", None),
@@ -405,11 +405,9 @@ class I2cGraph:
             raise ValueError("Alpha is NaN")
 
     def compute_update_alpha(self, update_alpha):
-        """i2c.py:921-946 without the cost bookkeeping of _maximize."""
-        e = self.engine
-        n_cost, n_pf = len(e.costs_m), len(e.costs_pf)
-        e.maximize(update_alpha=bool(update_alpha))
-        del e.costs_m[n_cost:], e.costs_m_var[n_cost:], e.costs_pf[n_pf:]
+        """i2c.py:921-963: alpha_hat, the clamp, and (with update_alpha) the new temperature in every cell -- nothing else:
+        no cost bookkeeping, no _update_priors, no KL term (those belong to _maximize, i2c.py:1004-1019)."""
+        self.engine.alpha_mstep(update_alpha=bool(update_alpha))
 
     def learn_msgs(self):
         self._sync_initial_state()
@@ -536,21 +534,63 @@ class I2cGraph:
         np.save(os.path.join(res_dir, "u_plan.npy"), sq(mu[..., nx:]))
         np.save(os.path.join(res_dir, "z_plan.npy"), sq(mz))
 
+    _STATE_TENSORS = ("post", "alpha", "temp", "feedforward", "status", "x0", "sig_x0", "cell_init")
+    _STATE_OPTIONAL = ("z", "alpha_cell", "alpha_init")
+    _STATE_LISTS = ("alphas", "alphas_desired", "alphas_pf", "costs_m", "costs_m_var", "costs_pf", "costs_pf_var", "kl_terms")
+
     def state_dict(self):
-        """Tensors that define the solver state (replaces the reference's whole-object dill pickle)."""
+        """Everything a resumed EM or MPC run needs (replaces the reference's whole-object dill pickle, i2c.py:1384-1398):
+        posterior / prior state, temperatures (per trajectory and per cell), the belief x0 / sig_x0, per-cell targets,
+        mode flags, the moving terminal-cell index, tau, and the metric histories."""
         e = self.engine
-        return {"post": e.post.cpu(), "alpha": e.alpha.cpu(), "temp": e.temp.cpu(), "feedforward": e.feedforward.cpu(),
-                "status": e.status.cpu(), "em_iter": e.em_iter}
+        sd = {k: getattr(e, k).detach().cpu().clone() for k in self._STATE_TENSORS}
+        sd["prior"] = e.prior.detach().cpu().clone()
+        for k in self._STATE_OPTIONAL:
+            v = getattr(e, k)
+            sd[k] = None if v is None else v.detach().cpu().clone()
+        for k in self._STATE_LISTS:
+            sd[k] = [t.detach().cpu().clone() for t in getattr(e, k)]
+        sd.update(em_iter=e.em_iter, tau=e.tau, terminal_cell=e.terminal_cell, propagate=bool(e._propagate),
+                  use_expert_controller=bool(e.use_expert_controller), horizon=e.H, batch=e.B, model=self.sys.model_name)
+        return sd
 
     def load_state_dict(self, sd):
         e = self.engine
-        for k in ("post", "alpha", "temp", "feedforward", "status"):
+        if (sd["horizon"], sd["batch"], sd["model"]) != (e.H, e.B, self.sys.model_name):
+            raise ValueError("checkpoint is for another problem (model / horizon / batch)")
+        for k in self._STATE_TENSORS:
             getattr(e, k).copy_(sd[k])
-        e.em_iter = int(sd["em_iter"])
+        if e.prior is not e.post:
+            e._post_spare, e.prior = e.prior, e.post
+        if not torch.equal(sd["prior"], sd["post"]):  # saved between a sweep and its _update_priors()
+            e.post, e._post_spare = e._post_spare, None
+            e.post.copy_(sd["post"])
+            e.prior.copy_(sd["prior"])
+        if sd["alpha_cell"] is not None:
+            e.enable_per_cell_alpha()
+        if sd["z"] is not None and e.z is None:
+            e.set_targets(np.transpose(sd["z"].double().numpy(), (2, 0, 1)))
+        for k in self._STATE_OPTIONAL:
+            if sd[k] is not None:
+                getattr(e, k).copy_(sd[k])
+        for k in self._STATE_LISTS:
+            setattr(e, k, [t.to(e.device) for t in sd[k]])
+        e.em_iter, e.tau, e.terminal_cell = int(sd["em_iter"]), int(sd["tau"]), int(sd["terminal_cell"])
+        e._propagate, e.use_expert_controller = bool(sd["propagate"]), bool(sd["use_expert_controller"])
+        e.refresh_problem()
         self._invalidate()
 
     def save(self, path, name):
+        """i2c.py:1384-1390 (`i2c_{name}.pkl` there, a dill pickle of the whole graph): the solver state as tensors."""
         torch.save(self.state_dict(), os.path.join(path, f"i2c_{name}.pt"))
+
+    @classmethod
+    def load(cls, path, *args, **kwargs):
+        """Counterpart of the reference's I2cGraph.load (i2c.py:1392-1398). A dill pickle carries the constructor
+        arguments along; a tensor checkpoint does not, so they are passed again: I2cGraph.load(path, sys, horizon, ...)."""
+        g = cls(*args, **kwargs)
+        g.load_state_dict(torch.load(path, weights_only=False))
+        return g
 
     # figures are presentation, not part of the solver: keep runner scripts working
     def _no_plot(self, *args, **kwargs):

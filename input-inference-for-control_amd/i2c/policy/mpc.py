@@ -28,7 +28,8 @@ class MpcPolicy:
         self.model = i2c.sys
         self.n_iter = n_iter
         self.set_control(True)  # mpc.py:21-22
-        e.enable_per_cell_alpha()  # cell_init is copied NOW (mpc.py:26): appended cells carry today's sig_xi
+        e.enable_per_cell_alpha()  # cell_init is copied NOW (mpc.py:26): appended cells carry today's sig_xi ...
+        e.cell_init = e.post[0].clone()  # ... and today's cells[0] (deepcopy(i2c.cells[0]), mpc.py:26), not the constructor's
         self.z_traj = None if z_traj is None else np.asarray(z_traj, dtype=float)
         if self.z_traj is not None:
             zt = self.z_traj if self.z_traj.ndim == 3 else self.z_traj[None]
@@ -49,6 +50,8 @@ class MpcPolicy:
 
     def reset(self):
         e = self.engine
+        if e.prior is not e.post:  # separate prior / posterior buffers: fold them before restoring
+            e._post_spare, e.prior = e.prior, e.post
         for k, v in self._init_state.items():
             getattr(e, k).copy_(v)
         if self._init_z is not None:
