@@ -589,15 +589,18 @@ class BatchedI2c:
             self.z.copy_(zt)
 
     def rollout(self, n_rollouts=1, policy="linear", process_noise=True, action_noise=False, sample_x0=False,
-                generator=None, want=("xu", "z", "x_final", "z_term")):
+                generator=None, want=("xu", "z", "x_final", "z_term"), eps_x0=None, eps_x=None, eps_u=None):
         """Simulate the current controllers through the noisy model (env.batch_eval, i2c/env.py:93-103):
-        n_rollouts per trajectory, all B * n_rollouts in one launch. Returns a dict of (R, B, T, ...) tensors."""
+        n_rollouts per trajectory, all B * n_rollouts in one launch. Returns a dict of (R, B, T, ...) tensors.
+        The standard-normal disturbances are drawn here (torch.randn) unless given: eps_x0 [nx][N], eps_x [T][nx][N],
+        eps_u [T][nu][N] with N = n_rollouts * B, rollout n = r * B + b."""
         N, T, dev, dt = int(n_rollouts) * self.B, self.H, self.device, self.dtype
         code = {"linear": 0, "expert": 1, "expert_soft": 1, "expert_hard": 2}[policy]
         rnd = lambda *s: torch.randn(*s, dtype=dt, device=dev, generator=generator)  # noqa: E731
-        eps_x0 = rnd(self.nx, N) if sample_x0 else None
-        eps_x = rnd(T, self.nx, N) if process_noise else None
-        eps_u = rnd(T, self.nu, N) if action_noise else None
+        given = lambda t, shape: torch.as_tensor(t, dtype=dt, device=dev).reshape(shape).contiguous()  # noqa: E731
+        eps_x0 = given(eps_x0, (self.nx, N)) if eps_x0 is not None else (rnd(self.nx, N) if sample_x0 else None)
+        eps_x = given(eps_x, (T, self.nx, N)) if eps_x is not None else (rnd(T, self.nx, N) if process_noise else None)
+        eps_u = given(eps_u, (T, self.nu, N)) if eps_u is not None else (rnd(T, self.nu, N) if action_noise else None)
         out = {
             "xu": torch.empty(T, self.d, N, dtype=dt, device=dev) if "xu" in want else None,
             "z": torch.empty(T, self.nz, N, dtype=dt, device=dev) if "z" in want else None,

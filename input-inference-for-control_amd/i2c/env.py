@@ -70,7 +70,18 @@ class KnownSim:
         graph = getattr(policy, "source", None) or self._graph
         if graph is not None and getattr(policy, "device_policy", None) and _matches(policy, graph):
             return self._device_eval(graph, policy, n_eval, deterministic)
-        outs = [self.run(policy, deterministic) for _ in range(n_eval)]
+        if n_eval > 1:
+            # The reference farms these rollouts out to forked pool workers (env.py:96-100): each starts from a COPY of the
+            # parent's NumPy stream and the parent's own stream does not advance. Reproduced, so that what the caller draws
+            # afterwards (the final rollout saved as xu_real.npy, i2c_run.py:158) sees the same numbers as in the reference.
+            state = np.random.get_state()
+            outs = []
+            for _ in range(n_eval):
+                np.random.set_state(state)
+                outs.append(self.run(policy, deterministic))
+            np.random.set_state(state)
+        else:
+            outs = [self.run(policy, deterministic)]
         return tuple(list(col) for col in zip(*outs))
 
     def _device_eval(self, graph, policy, n_eval, deterministic):

@@ -549,6 +549,93 @@ def case_mpc_quad12():
     save("mpc_quad12_fb", out)
 
 
+def case_rollouts(T=60, n_em=4):
+    """Row f3: the reference's rollout / evaluation path on its own PendulumKnown simulator --
+    BaseSim.run (i2c/env.py:40-74) driven by TimeIndexedLinearGaussianPolicy / ExpertTimeIndexedLinearGaussianPolicy
+    (i2c/policy/linear.py:8-100) filled from an I2cGraph, and StochasticTrajectoryEvaluator.eval (i2c/utils.py:150-192).
+    Deterministic plant + deterministic policy runs are RNG-free. The stochastic run records every sample the reference draws
+    (numpy.random.multivariate_normal inside env.forward and the policy) and stores it STANDARDISED (eps = chol(cov)^-1
+    (sample - mean)), which is the form i2c_rollout takes its disturbances in."""
+    import i2c.env as ref_env
+    import i2c.policy.linear as ref_lin
+    from i2c.utils import StochasticTrajectoryEvaluator
+
+    rng = np.random.default_rng(21)
+    model = make_env_model("PendulumKnown", None)
+    Q, R = np.diag([1.0, 100.0, 1.0]), np.diag([2.0])
+    mu_u = 1e-2 * rng.normal(size=(T, 1))
+    sig_u = 2.0 * np.eye(1)
+    g = I2cGraph(model, T, Q, R, Q, 100.0, 0.0, mu_u, sig_u, None, None, CubatureQuadrature(1, 0, 0))
+    out = problem_inputs("PendulumKnown", model, T, Q, R, Q, 100.0, 0.0, mu_u, sig_u, None, None, (1, 0, 0), n_em=n_em)
+    for _ in range(n_em):
+        g.learn_msgs()
+    K, k, sigK = g.get_local_linear_policy()
+    Ke, ke, sKe, mue, lame = g.get_local_expert_linear_policy()
+    out.update({"K": K, "k": k, "sigK": sigK, "expert/K": Ke, "expert/k": ke, "expert/sigK": sKe, "expert/mu": mue, "expert/lam": lame})
+    env = ref_env.PendulumKnown(T)
+    lin = ref_lin.TimeIndexedLinearGaussianPolicy(sig_u, T, 1, 2)
+    lin.write(K, k, sigK)
+    pols = {"linear": lin}
+    for soft in (True, False):
+        pe = ref_lin.ExpertTimeIndexedLinearGaussianPolicy(sig_u, T, 1, 2, soft=soft)
+        pe.write(Ke, ke, sKe, mue, lame)
+        pols["expert_soft" if soft else "expert_hard"] = pe
+
+    def put(tag, res):
+        xt, yt, zt, z_term = res
+        out[tag + "/xu"], out[tag + "/dx"], out[tag + "/z"], out[tag + "/z_term"] = xt, yt, zt, np.asarray(z_term, float).reshape(-1)
+
+    env.deterministic = True
+    for name, pol in pols.items():
+        put("det/" + name, env.run(pol, deterministic=True))
+
+    # stochastic plant and stochastic policy, every draw recorded
+    draws = []
+    real_mvn = np.random.multivariate_normal
+
+    def recording_mvn(mean, cov, size=None, **kw):
+        smp = real_mvn(mean, cov, size, **kw)
+        draws.append((np.asarray(mean, float).reshape(-1), np.asarray(cov, float), np.asarray(smp, float).reshape(-1)))
+        return smp
+
+    env.deterministic = False
+    ref_env.mvn = recording_mvn
+    ref_lin.mvn = recording_mvn
+    z_runs, zt_runs = [], []
+    try:
+        for name in ("linear", "expert_soft"):
+            eps_x, eps_u = np.zeros((3, T, 2)), np.zeros((3, T, 1))
+            for rr in range(3):
+                np.random.seed(100 + rr)
+                del draws[:]
+                res = env.run(pols[name], deterministic=False)
+                put(f"sto/{name}/{rr}", res)
+                assert len(draws) == 2 * T  # per step: the policy's action sample, then the plant's disturbance
+                for t in range(T):
+                    mu_a, cov_a, smp_a = draws[2 * t]
+                    mu_p, cov_p, smp_p = draws[2 * t + 1]
+                    eps_u[rr, t] = np.linalg.solve(np.linalg.cholesky(cov_a), smp_a - mu_a)
+                    eps_x[rr, t] = np.linalg.solve(np.linalg.cholesky(cov_p), smp_p - mu_p)
+                if name == "linear":
+                    z_runs.append(res[2])
+                    zt_runs.append(res[3])
+            out[f"sto/{name}/eps_x"], out[f"sto/{name}/eps_u"] = eps_x, eps_u
+    finally:
+        ref_env.mvn = real_mvn
+        ref_lin.mvn = real_mvn
+        env.deterministic = False
+
+    # the evaluator of scripts/i2c_run.py:66-75, 104-106 on those rollouts against the plan
+    z_est, z_term_est = g.get_marginal_observed_trajectory()
+    ev = StochasticTrajectoryEvaluator(g.QR, g.Qf, g.z, g.z_term, g.Qf.shape[0])
+    ev.eval(z_runs, zt_runs, z_est, z_term_est)
+    ev.eval(z_runs[:2], zt_runs[:2], z_est, z_term_est)
+    out["eval/z_est"], out["eval/z_term_est"] = np.asarray(z_est, float), np.asarray(z_term_est, float)
+    for key in ("mu_actual_cost", "min_actual_cost", "max_actual_cost", "actual_cost_10", "actual_cost_90", "planned_cost"):
+        out["eval/" + key] = np.asarray(getattr(ev, key), float).reshape(-1)
+    save("rollouts_pendulum_T60", out)
+
+
 def case_i2c_run(config="pendulum_known_quad", name="run_pendulum_seed0"):
     """The reference's own runner, scripts/i2c_run.py:run(), on its shipped pendulum config (seed 0,
     N_INFERENCE cut to 6): what a user sees -- costs_m, alphas, the saved plan and the final policy."""
@@ -570,7 +657,8 @@ def case_i2c_run(config="pendulum_known_quad", name="run_pendulum_seed0"):
     runner.I2cGraph = capture
     with tempfile.TemporaryDirectory() as res_dir:
         runner.run(experiment, res_dir, None)
-        out = {k: np.load(os.path.join(res_dir, k + ".npy")) for k in ("xu_plan", "x_plan", "u_plan", "z_plan")}
+        out = {k: np.load(os.path.join(res_dir, k + ".npy")) for k in ("xu_plan", "x_plan", "u_plan", "z_plan",
+                                                                         "xu_real", "dx_real", "x_real", "u_real")}
     runner.I2cGraph = real_graph
     g = captured["i2c"]
     out["mu_u"] = np.asarray(experiment.INFERENCE.mu_u, float)
@@ -801,6 +889,7 @@ CASES = {
     "em_quad12": case_em_quad12,
     "em_quad12_pf": case_em_quad12_propagate,
     "mpc_quad12": case_mpc_quad12,
+    "rollouts": case_rollouts,
     "i2c_run": case_i2c_run,
     "i2c_run_lin": case_i2c_run_linearize,
     "gh_pendulum": case_gh_pendulum,

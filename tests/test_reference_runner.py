@@ -72,8 +72,13 @@ def test_reference_i2c_run_against_this_build(tmp_path, config, golden):
         # iterations and the planned actions are rounding noise (~1e-17) in the reference as well
         scale = np.abs(ref["xu_plan"]).max()
         assert np.abs(mine - ref[name]).max() <= 1e-7 * max(scale, np.abs(ref[name]).max()), name
-    for name in ("xu_real", "dx_real", "x_real", "u_real"):  # i2c_run.py:176-184
-        assert os.path.exists(os.path.join(tmp_path, name + ".npy"))
+    # i2c_run.py:158-160, 176-184: the final rollout of the linear policy through the NOISY simulator. The plant noise comes
+    # from NumPy's global stream in the parent process (seeded by the config module; the reference's evaluation rollouts
+    # run in pool workers, this build's on the device: neither advances it), so the contents are reproducible and compared
+    for name in ("xu_real", "dx_real", "x_real", "u_real"):
+        mine = np.load(os.path.join(tmp_path, name + ".npy"))
+        assert mine.shape == ref[name].shape, (name, mine.shape, ref[name].shape)
+        assert_close(mine, ref[name], 1e-6, name)
 
 
 SCRIPT_DRIVER = """

@@ -138,3 +138,87 @@ def test_env_batch_eval_uses_the_device_and_matches_host_protocol():
     z_est, z_term_est = i2c.get_marginal_observed_trajectory()
     ev.eval(zs, zts, z_est, z_term_est)
     assert ev.actual_cost_10[0] <= ev.mu_actual_cost[0] <= ev.actual_cost_90[0] or len(set(np.round(ev.mu_actual_cost, 6))) == 1
+
+
+# ---- pinned to the REFERENCE (tests/golden/rollouts_pendulum_T60.npz, oracle/gen_golden.py::case_rollouts): its BaseSim.run on
+# its own PendulumKnown simulator with its own policy classes filled from its I2cGraph, and its StochasticTrajectoryEvaluator --
+def _reference_rollout_case(lib, device):
+    g = load_case("rollouts_pendulum_T60")
+    eng = parity.engine_from_case(g, lib, device)
+    for _ in range(g.meta["n_em"]):
+        eng.learn_msgs()
+    K, k, sigK = (parity.np_(t)[0] for t in eng.local_linear_policy())
+    assert_close(K, g["K"], 1e-7, "controller the rollouts use")
+    return g, eng
+
+
+def _cmp(res, g, tag, r=0, tol=1e-7):
+    xu = res["xu"][r, 0].cpu().double().numpy()
+    xf = res["x_final"][r, 0].cpu().double().numpy()
+    assert_close(xu, g[tag + "/xu"], tol, tag + " xu")
+    assert_close(res["z"][r, 0].cpu().double().numpy(), g[tag + "/z"], tol, tag + " z")
+    assert_close(res["z_term"][r, 0].cpu().double().numpy(), g[tag + "/z_term"], tol, tag + " z_term")
+    x_all = np.concatenate((xu[:, :2], xf[None]), axis=0)
+    assert_close(x_all[1:] - x_all[:-1], g[tag + "/dx"], tol * 10, tag + " dx")
+
+
+def _rollouts_vs_reference(lib, device):
+    g, eng = _reference_rollout_case(lib, device)
+    for name in ("linear", "expert_soft", "expert_hard"):  # deterministic plant, deterministic policy: RNG-free
+        _cmp(eng.rollout(1, name, process_noise=False, action_noise=False), g, "det/" + name)
+    for name in ("linear", "expert_soft"):  # the reference's own noise draws, standardised, replayed as the kernel's eps
+        ex, eu = g[f"sto/{name}/eps_x"], g[f"sto/{name}/eps_u"]  # (3, T, nx), (3, T, nu)
+        res = eng.rollout(3, name, eps_x=np.ascontiguousarray(np.transpose(ex, (1, 2, 0))),
+                          eps_u=np.ascontiguousarray(np.transpose(eu, (1, 2, 0))))
+        for r in range(3):
+            _cmp(res, g, f"sto/{name}/{r}", r=r, tol=1e-6)
+
+
+def test_rollout_kernel_vs_reference_simulator_cpu():
+    _rollouts_vs_reference(hostsim.load(), "cpu")
+
+
+@pytest.mark.gpu
+def test_rollout_kernel_vs_reference_simulator_gpu():
+    _rollouts_vs_reference(None, "cuda")
+
+
+def test_host_protocol_and_evaluator_vs_reference():
+    """The mirrors a runner script touches -- env.run, the policy classes, StochasticTrajectoryEvaluator -- against the
+    reference's captured outputs (deterministic runs exactly; the evaluator on the reference's own stochastic rollouts)."""
+    from i2c.env import make_env
+    from i2c.policy.linear import ExpertTimeIndexedLinearGaussianPolicy, TimeIndexedLinearGaussianPolicy
+    from i2c.utils import StochasticTrajectoryEvaluator
+
+    g = load_case("rollouts_pendulum_T60")
+    T = g.meta["T"]
+
+    class Exp:
+        ENVIRONMENT, N_DURATION = "PendulumKnown", T
+
+    env = make_env(Exp)
+    env.deterministic = True
+    lin = TimeIndexedLinearGaussianPolicy(g["sig_u"], T, 1, 2)
+    lin.write(g["K"], g["k"], g["sigK"])
+    pols = {"linear": lin}
+    for soft in (True, False):
+        pe = ExpertTimeIndexedLinearGaussianPolicy(g["sig_u"], T, 1, 2, soft=soft)
+        pe.write(g["expert/K"], g["expert/k"], g["expert/sigK"], g["expert/mu"], g["expert/lam"])
+        pols["expert_soft" if soft else "expert_hard"] = pe
+    for name, pol in pols.items():
+        xt, yt, zt, z_term = env.run(pol, deterministic=True)
+        assert_close(xt, g[f"det/{name}/xu"], 1e-12, name + " xu")
+        assert_close(yt, g[f"det/{name}/dx"], 1e-10, name + " dx")
+        assert_close(zt, g[f"det/{name}/z"], 1e-12, name + " z")
+        assert_close(np.reshape(z_term, -1), g[f"det/{name}/z_term"], 1e-12, name + " z_term")
+    Q, R = g["Q"], g["R"]
+    QR = np.zeros((4, 4))
+    QR[:3, :3], QR[3:, 3:] = Q, R
+    zg = np.array([0.0, 1.0, 0.0, 0.0])  # PendulumKnown.zg (env_def.py:262-266): sin, cos, thd, u of the upright pendulum
+    ev = StochasticTrajectoryEvaluator(QR, g["Qf"], zg, zg[:3], 3)
+    zs = [g[f"sto/linear/{r}/z"] for r in range(3)]
+    zts = [g[f"sto/linear/{r}/z_term"].reshape(1, -1) for r in range(3)]
+    ev.eval(zs, zts, g["eval/z_est"], g["eval/z_term_est"])
+    ev.eval(zs[:2], zts[:2], g["eval/z_est"], g["eval/z_term_est"])
+    for key in ("mu_actual_cost", "min_actual_cost", "max_actual_cost", "actual_cost_10", "actual_cost_90", "planned_cost"):
+        assert_close(np.asarray(getattr(ev, key), float).reshape(-1), g["eval/" + key], 1e-12, "evaluator " + key)
