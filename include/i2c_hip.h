@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define I2C_ABI_VERSION 3
+#define I2C_ABI_VERSION 4
 
 #define I2C_MAX_NX 12
 #define I2C_MAX_NU 4
@@ -141,6 +141,11 @@ typedef struct I2cProblem {
                               model); I2cDims.group_lanes: run forward / backward / propagate / filter with that many lanes of
                               a wavefront per trajectory (fp64, cubature rule, diagonal cost weights, no terminal state prior;
                               the backward sweep then has one schedule, the fused walk); anything else: I2C_ENOTSUP            */
+  int32_t t0;              /* ring offset of the PERSISTENT per-cell buffers -- prior/post, z, alpha_cell, feedforward: cell t of the
+                              horizon lives in row (t0 + t) mod T. 0 outside the MPC loop; the receding-horizon shift (mpc.py:174-181)
+                              is "t0 += 1" plus one fresh row (i2c_mpc_step / i2c_shift_horizon). Buffers a sweep writes for its
+                              caller (fwd, xm, zpost, prior_out, prop, cell_stats) are indexed by the cell index t directly.          */
+  int32_t reserved1;
   /* CubatureQuadrature(alpha, beta, kappa): i2c/exp_types.py:31-49 */
   double quad_alpha, quad_beta, quad_kappa;
   double dtemp;            /* terminal-prior annealing rate (i2c.py:66,552)                    */
@@ -269,16 +274,15 @@ int i2c_mstep(const I2cProblem* p, const void* term_stats, double alpha_update_t
  *   if do_filter: i2c_ckf_filter on (p->x0, p->sig_x0) with measurement y and previous action u (mpc.py:125-145)
  *   n_iter x { i2c_forward_sweep; i2c_backward_sweep; _update_priors (cells <= tau to feedback mode) }
  *   action <- cells[0].mu_u0_m, sig_u0_m;  cells.pop(0); cells.append(deepcopy(cell_init))    (mpc.py:171-181)
- * The shift is out of place: the caller owns two sets of {post, alpha_cell, z, feedforward}; `*_next` receive the
- * shifted horizon and become p->... of the next step (p->terminal_cell moves on the host).
+ * The shift is in place: the persistent per-cell buffers are a ring (I2cProblem.t0); the step writes the appended cell over
+ * the row of the popped one, and the caller advances t0 by one (mod T) and moves terminal_cell before the next call.
  */
 typedef struct I2cMpcStep {
   int32_t do_filter, n_iter, tau, reserved0;
   double sig_zeta[I2C_SYM(I2C_MAX_NZ)]; /* packed measurement noise, ny x ny (sys.sig_zeta) */
   const void* y;            /* [ny][B] or NULL */
   const void* u;            /* [nu][B] or NULL: the action applied since the last step */
-  void* post;               /* [T][e_post][B] in/out: prior in, posterior of this step out */
-  void* post_next;          /* [T][e_post][B] out: the shifted horizon */
+  void* post;               /* [T][e_post][B] ring, in/out: prior in, posterior out, then the appended cell in row t0 */
   void* fwd;                /* [T][e_fwd][B] */
   void* xm;                 /* [T][e_xm][B] or NULL (as i2c_backward_sweep) */
   void* zpost;              /* optional */
@@ -286,14 +290,18 @@ typedef struct I2cMpcStep {
   void* term_stats;
   const void* cell_init;    /* [e_post][B]: the cell appended at the end of the horizon (I2cCell.__init__ state) */
   const void* alpha_init;   /* [B]: temperature the appended cell keeps (NULL iff p->alpha_cell is NULL) */
-  void* alpha_cell_next;    /* [T][B] (NULL iff p->alpha_cell is NULL) */
   const void* z_new;        /* [nz][B] target of the appended cell, or NULL: the previous last cell's */
-  void* z_next;             /* [T][nz][B] (NULL iff targets are not per cell) */
-  uint8_t* feedforward_next; /* [T] */
-  void* action;             /* [nu + SYM(nu)][B] out, or NULL */
+  void* action;             /* [nu + SYM(nu)][B] out, or NULL: cells[0].mu_u0_m, sig_u0_m before the shift */
   int32_t* status;          /* [B] */
 } I2cMpcStep;
 int i2c_mpc_step(const I2cProblem* p, const I2cMpcStep* step, void* stream);
+
+/* The receding-horizon shift alone: `cells.pop(0); cells.append(deepcopy(cell_init))` (mpc.py:174-181) on the ring of
+ * persistent per-cell buffers: copies cells[0]'s action moments to `action` (optional), then writes the fresh cell (cell_init,
+ * alpha_init, target z_new or the previous last cell's, feed-forward mode) over row t0 of post / p->alpha_cell / p->z /
+ * p->feedforward. The caller advances p->t0 afterwards. */
+int i2c_shift_horizon(const I2cProblem* p, void* post, const void* cell_init, const void* alpha_init, const void* z_new,
+                      void* action, void* stream);
 
 /*
  * Riccati-form backward messages after a Linearize forward/backward pass: replaces I2cGraph._backward_ricatti_msgs

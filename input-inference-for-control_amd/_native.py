@@ -9,7 +9,7 @@ without a GPU; nothing in the package ever looks for it.)
 import ctypes as C
 import os
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_NX, MAX_NU, MAX_NZ, MAX_PARAMS = 12, 4, 16, 16
 MAX_GH_DEGREE = 8
 
@@ -68,6 +68,8 @@ class I2cProblem(C.Structure):
         ("expert_controller", C.c_int32),
         ("gh_degree", C.c_int32),
         ("group_lanes", C.c_int32),
+        ("t0", C.c_int32),
+        ("reserved1", C.c_int32),
         ("quad_alpha", C.c_double),
         ("quad_beta", C.c_double),
         ("quad_kappa", C.c_double),
@@ -99,10 +101,10 @@ class I2cMpcStep(C.Structure):
     _fields_ = [
         ("do_filter", C.c_int32), ("n_iter", C.c_int32), ("tau", C.c_int32), ("reserved0", C.c_int32),
         ("sig_zeta", C.c_double * _sym(MAX_NZ)),
-        ("y", C.c_void_p), ("u", C.c_void_p), ("post", C.c_void_p), ("post_next", C.c_void_p), ("fwd", C.c_void_p),
+        ("y", C.c_void_p), ("u", C.c_void_p), ("post", C.c_void_p), ("fwd", C.c_void_p),
         ("xm", C.c_void_p), ("zpost", C.c_void_p), ("cell_stats", C.c_void_p), ("term_stats", C.c_void_p),
-        ("cell_init", C.c_void_p), ("alpha_init", C.c_void_p), ("alpha_cell_next", C.c_void_p), ("z_new", C.c_void_p),
-        ("z_next", C.c_void_p), ("feedforward_next", C.c_void_p), ("action", C.c_void_p), ("status", C.c_void_p),
+        ("cell_init", C.c_void_p), ("alpha_init", C.c_void_p), ("z_new", C.c_void_p),
+        ("action", C.c_void_p), ("status", C.c_void_p),
     ]
 
 
@@ -125,6 +127,7 @@ _SIGNATURES = {
     ),
     "i2c_riccati_sweep": (C.c_int, [C.POINTER(I2cProblem)] + [C.c_void_p] * 7),
     "i2c_mpc_step": (C.c_int, [C.POINTER(I2cProblem), C.POINTER(I2cMpcStep), C.c_void_p]),
+    "i2c_shift_horizon": (C.c_int, [C.POINTER(I2cProblem)] + [C.c_void_p] * 6),
     "i2c_rollout": (C.c_int, [C.POINTER(I2cProblem), C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8),
     "i2c_ckf_filter": (
         C.c_int,

@@ -22,6 +22,8 @@ int check_problem(const I2cProblem* p) {
   if (p->has_x_terminal && !p->temp) return I2C_EINVAL;
   if (p->inference < I2C_INF_CUBATURE || p->inference > I2C_INF_GAUSS_HERMITE) return I2C_EINVAL;
   if (p->inference == I2C_INF_GAUSS_HERMITE && (p->gh_degree < 1 || p->gh_degree > I2C_MAX_GH_DEGREE)) return I2C_EINVAL;
+  if (p->t0 < 0 || p->t0 >= p->T) return I2C_EINVAL;
+  if (p->t0 != 0 && p->inference != I2C_INF_CUBATURE) return I2C_ENOTSUP;  // the ring is an MPC (sigma-point) feature
   return I2C_OK;
 }
 
@@ -115,14 +117,17 @@ int i2c_riccati_sweep(const I2cProblem* p, const void* prior_out, const void* fw
 }
 
 int i2c_mpc_step(const I2cProblem* p, const I2cMpcStep* m, void* stream) {
-  if (!m || !m->post || !m->post_next || !m->fwd || !m->term_stats || !m->cell_init || !m->feedforward_next || !m->status ||
-      m->n_iter < 0)
-    return I2C_EINVAL;
+  if (!m || !m->post || !m->fwd || !m->term_stats || !m->cell_init || !m->status || m->n_iter < 0) return I2C_EINVAL;
   if (m->do_filter && (!m->y || !m->u)) return I2C_EINVAL;
-  if (p && ((p->alpha_cell != nullptr) != (m->alpha_cell_next != nullptr) || (p->alpha_cell && !m->alpha_init) ||
-            ((p->z != nullptr && p->z_per_cell) != (m->z_next != nullptr))))
-    return I2C_EINVAL;
+  if (p && p->alpha_cell && !m->alpha_init) return I2C_EINVAL;
   I2C_DISPATCH(p, mpc_step(p, m, stream));
+}
+
+int i2c_shift_horizon(const I2cProblem* p, void* post, const void* cell_init, const void* alpha_init, const void* z_new,
+                      void* action, void* stream) {
+  if (!post || !cell_init) return I2C_EINVAL;
+  if (p && p->alpha_cell && !alpha_init) return I2C_EINVAL;
+  I2C_DISPATCH(p, shift(p, post, cell_init, alpha_init, z_new, action, stream));
 }
 
 int i2c_ckf_filter(const I2cProblem* p, const double* sig_zeta, const void* y, const void* u, void* mu, void* cov,

@@ -42,6 +42,14 @@ template <class M, typename R> struct Consts {
   static constexpr int E_PROP = D + sym(D) + NX + sym(NX);
   static constexpr int E_TERM = 4 + NZT + sym(NZT);  // last row: plan-cost sum of the Linearize path
   int B, T;
+  // Ring offset of the PERSISTENT per-cell buffers (prior/post, z, alpha_cell, feedforward): cell t lives in row
+  // (t0 + t) mod T. 0 outside the MPC loop; the receding-horizon shift (mpc.py:174-181) advances it by one instead of
+  // moving every row. Scratch buffers of a sweep (fwd, xm, zpost, prior_out, prop, cell_stats) are indexed by t directly.
+  int t0;
+  I2C_HD inline int row(const int t) const {
+    const int r = t + t0;
+    return r >= T ? r - T : r;
+  }
   int has_Qf, has_x_terminal, z_per_cell, use_expert, terminal_cell, inference;
   int qr_diag, qf_diag;  // cost weights are diagonal: cheap closed forms in gaussian_cost
   Rule<R> rule_xu, rule_x;
@@ -509,17 +517,17 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R, ST
   R pri[C::E_PRI], zt[NZ];
   {
     const unsigned rb = rb0;
-    const Window w = make_window(a.prior, (unsigned long)C::E_POST * rb);
+    const Window w = make_window(a.prior + (unsigned long)(LEAN ? 0 : c.row(0)) * C::E_POST * B, (unsigned long)C::E_POST * rb);
 #pragma unroll
     for (int e = 0; e < C::E_PRI; ++e) pri[e] = (R)wld<ST_>(w, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo);
   }
 #pragma unroll
-  for (int k = 0; k < NZ; ++k) zt[k] = (!LEAN && c.z_per_cell) ? a.z[(long)k * B + b] : c.zg[k];
+  for (int k = 0; k < NZ; ++k) zt[k] = (!LEAN && c.z_per_cell) ? a.z[((long)c.row(0) * NZ + k) * B + b] : c.zg[k];
 
   // The feed-forward flag of a cell is a byte in global memory: loaded at the top of its own cell it is a dependent
   // vector load whose full latency (plus, vmcnt being shared, the acknowledgement of the previous cell's last stores)
   // is exposed EVERY cell. It is therefore fetched one cell ahead, together with the prior rows.
-  unsigned ff_cur = a.ff[0];
+  unsigned ff_cur = a.ff[LEAN ? 0 : c.row(0)];
   // Small models never factor the prior joint: its Cholesky factor is assembled from the factor Lx of the incoming
   // sig_x0_f (= chol(sig_x3_f) of the previous cell, already needed for the smoother gain) as
   //   L0 = [[Lx, 0], [K~ Lx, chol(sig_u|x)]],  sig_u|x = sig_u0_m - K~ sig_ux^T   (feed-forward: K~ = 0, sig_u|x = sig_u0_f),
@@ -546,7 +554,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R, ST
 #pragma unroll
   for (int k = 0; k < NZ; ++k) zt[k] = opaque(zt[k]);
   const R alpha_settled = opaque(alpha_traj);
-  R alpha_cur = opaque((!LEAN && a.alpha_cell) ? a.alpha_cell[b] : alpha_settled);  // per-cell temperature, fetched a cell ahead
+  R alpha_cur = opaque((!LEAN && a.alpha_cell) ? a.alpha_cell[(long)c.row(0) * B + b] : alpha_settled);  // per-cell temperature, fetched a cell ahead
   // Per-cell constants as VGPR values (small models): left as kernel arguments they sit in ~30 SGPRs for the whole
   // sweep, and the scalar file then spills (v_readlane) and re-materialises polynomial literals (s_mov) in every cell.
   // Only where the register file has room: the cartpole (21 + 10 doubles) already overflows into AGPRs and slows down.
@@ -564,6 +572,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R, ST
 
   for (int t = 0; t < T; ++t) {
     const int tn = t + 1 < T ? t + 1 : t;
+    const int tr = LEAN ? t : c.row(t), tnr = LEAN ? tn : c.row(tn);  // rows of the persistent buffers (ring, see Consts::t0)
     const unsigned rb = opaque_uniform(rb0);  // see opaque_uniform(): no hoisting of e * rb
     // Large models: an index the compiler cannot see through (always 0) makes the big constant tables of the kernel
     // argument (sig_xi0: 45 doubles for the double cartpole, sig_eta: 21) scalar LOADS next to their single use in each
@@ -577,11 +586,11 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R, ST
     // ~15 us cell rather than scratch traffic throughout.
     constexpr bool PREFETCH = C::D <= 5;
     if (!PREFETCH && t > 0) {
-      const Window w = make_window(a.prior + (unsigned long)t * C::E_POST * B, (unsigned long)C::E_POST * rb);
+      const Window w = make_window(a.prior + (unsigned long)tr * C::E_POST * B, (unsigned long)C::E_POST * rb);
 #pragma unroll
       for (int e = 0; e < C::E_PRI; ++e) pri[e] = (R)wld<ST_>(w, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo);
 #pragma unroll
-      for (int k = 0; k < NZ; ++k) zt[k] = (!LEAN && c.z_per_cell) ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
+      for (int k = 0; k < NZ; ++k) zt[k] = (!LEAN && c.z_per_cell) ? a.z[((long)tr * NZ + k) * B + b] : c.zg[k];
     }
 
     // per-cell temperature only in the MPC loop (stale sig_xi of appended cells); else the trajectory's
@@ -669,10 +678,10 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R, ST
       for (int e = 0; e < sym(D); ++e) wst(w, VOFF ? 0u : (D + e) * rb, VOFF ? voff[D + e] : bo, (ST_)S0[e]);
     }
 
-    ff_cur = a.ff[tn];  // the next cell's flag, a whole cell ahead of its use
-    if (!LEAN && a.alpha_cell) alpha_cur = a.alpha_cell[(long)tn * B + b];
+    ff_cur = a.ff[tnr];  // the next cell's flag, a whole cell ahead of its use
+    if (!LEAN && a.alpha_cell) alpha_cur = a.alpha_cell[(long)tnr * B + b];
     if (PREFETCH) {  // pri is dead from here on: refill it with the next cell's rows
-      const Window w = make_window(a.prior + (unsigned long)tn * C::E_POST * B, (unsigned long)C::E_POST * rb);
+      const Window w = make_window(a.prior + (unsigned long)tnr * C::E_POST * B, (unsigned long)C::E_POST * rb);
 #pragma unroll
       for (int e = 0; e < C::E_PRI; ++e) pri[e] = (R)wld<ST_>(w, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo);
     }
@@ -695,7 +704,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R, ST
     }
     if (!LEAN && PREFETCH && c.z_per_cell) {  // the target is consumed: fetch the next cell's
 #pragma unroll
-      for (int k = 0; k < NZ; ++k) zt[k] = a.z[((long)tn * NZ + k) * B + b];
+      for (int k = 0; k < NZ; ++k) zt[k] = a.z[((long)tnr * NZ + k) * B + b];
     }
     // mu0 / S0 now hold mu_xu1_f / sig_xu1_f
     const Window out = make_window(a.fwd + (unsigned long)t * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
@@ -1084,7 +1093,7 @@ I2C_FN void store_cell(const Consts<M, R>& c, const CellArgs<R, S_>& a, const in
   using C = Consts<M, R>;
   constexpr int NZ = C::NZ, D = C::D;
   const long B = c.B;
-  S_* out = a.post + ((long)t * C::E_POST) * B + b;
+  S_* out = a.post + ((long)c.row(t) * C::E_POST) * B + b;
 #pragma unroll
   for (int e = 0; e < D; ++e) out[(long)e * B] = (S_)mu[e];
 #pragma unroll
@@ -1133,7 +1142,7 @@ I2C_HD inline void backward_cell_body(const Consts<M, R>& c, const CellArgs<R, S
   for (int e = 0; e < D * NX; ++e) J[e] = in[(long)(O_J + e) * B];
   R zt[NZ];
 #pragma unroll
-  for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
+  for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k];
 
   R ctl[C::E_POST - D - sym(D)], mz[NZ], Sz[sym(NZ)], cm, cv;
   if (!cell_posterior<M, R>(c, zt, mu, S, J, dm, dS, ctl, mz, Sz, &cm, &cv)) set_status(a.status, b, 7, t);
@@ -1208,7 +1217,7 @@ I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R, 
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) dS[i] = S3m[i] - row[O_S3 + i];
 #pragma unroll
-    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
+    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k];
     R* mu = row;
     R* S = row + D;
     R ctl[C::E_POST - D - sym(D)], mz[NZ], Sz[sym(NZ)], cm, cv;
@@ -1427,7 +1436,7 @@ I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R, S_>
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) dS[i] = S3m[i] - row[O_S3 + i];
 #pragma unroll
-    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? ca.z[((long)t * NZ + k) * B + b] : c.zg[k];
+    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? ca.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k];
     R* mu = row;
     R* S = row + D;
     R ctl[C::E_POST - D - sym(D)], mz[NZ], Sz[sym(NZ)], cm, cv;
@@ -1518,14 +1527,14 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
   for (int i = 0; i < sym(NX); ++i) sig_x[i] = a.sig_x0[i * B + b];
   R pri[C::E_PRI];
 #pragma unroll
-  for (int e = 0; e < C::E_PRI; ++e) pri[e] = a.post[(long)e * B + b];
+  for (int e = 0; e < C::E_PRI; ++e) pri[e] = a.post[((long)c.row(0) * C::E_POST + e) * B + b];
   R sum_m = R(0), sum_v = R(0);
 
   for (int t = 0; t < T; ++t) {
     R nxt[C::E_PRI];
     const int tn = t + 1 < T ? t + 1 : t;
 #pragma unroll
-    for (int e = 0; e < C::E_PRI; ++e) nxt[e] = a.post[((long)tn * C::E_POST + e) * B + b];
+    for (int e = 0; e < C::E_PRI; ++e) nxt[e] = a.post[((long)c.row(tn) * C::E_POST + e) * B + b];
     const R* qmu = pri;
     const R* qsig = pri + D;
     const R* Kpost = pri + D + sym(D);
@@ -1533,7 +1542,7 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
     R mu0[D], S0[sym(D)], Kt[NU * NX], sig_u[sym(NU)];
 #pragma unroll
     for (int i = 0; i < NU * NX; ++i) Kt[i] = Kpost[i];
-    if (a.ff[t]) {  // i2c.py:155-157: action marginal, but the joint still carries K sig_x (i2c.py:173-179)
+    if (a.ff[c.row(t)]) {  // i2c.py:155-157: action marginal, but the joint still carries K sig_x (i2c.py:173-179)
 #pragma unroll
       for (int p = 0; p < NU; ++p)
 #pragma unroll
@@ -1575,7 +1584,7 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
     if (!chol<D>(L0, rinv)) set_status(a.status, b, 8, t);
     R zt[NZ], mz[NZ], Sz[sym(NZ)];
 #pragma unroll
-    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
+    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k];
     transform<GRID, M, ObsStruct<M>, D, NZ, false>(c.rule_xu, mu0, S0, L0, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
     R cm, cv;
     gaussian_cost<NZ>(c.QR, c.qr_diag != 0, mz, Sz, zt, &cm, &cv);
@@ -1727,7 +1736,7 @@ I2C_HD inline void rollout_body(const Consts<M, R>& c, const RolloutArgs<R>& a, 
   if (a.eps_x) chol<NX>(Le, rinv_e);
 
   for (int t = 0; t < T; ++t) {
-    const R* row = a.post + ((long)t * C::E_POST) * B + b;
+    const R* row = a.post + ((long)c.row(t) * C::E_POST) * B + b;
     R u[NU], Kc[NU * NX];
 #pragma unroll
     for (int e = 0; e < NU * NX; ++e) Kc[e] = row[(long)(D + sym(D) + e) * B];
@@ -1813,48 +1822,30 @@ I2C_HD inline void rollout_body(const Consts<M, R>& c, const RolloutArgs<R>& a, 
 // ------------------------------------------------------------------------------------------
 // Receding-horizon shift of the MPC loop (PartiallyObservedMpcPolicy.__call__, i2c/policy/mpc.py:171-181):
 //   u = cells[0].mu_u0_m;  cells.pop(0);  cells.append(deepcopy(cell_init)) with the next target.
-// Out of place (cell t of the new buffers = cell t+1 of the old ones, last cell = a fresh one), one lane per (t, b); the
-// first action and its covariance are copied out on the way. The fresh cell keeps the temperature `alpha_init` it was
-// copied with (see I2cProblem.alpha_cell).
+// The persistent per-cell buffers are a RING (Consts::t0): popping cell 0 and appending a cell is "advance t0 by one"
+// (done by the caller after this kernel) plus ONE fresh row, written here over the row cell 0 occupied -- one lane per
+// trajectory, after the first action and its covariance were copied out of that row. The fresh cell keeps the temperature
+// `alpha_init` it was copied with (see I2cProblem.alpha_cell) and is in feed-forward mode.
 // ------------------------------------------------------------------------------------------
 template <typename R> struct ShiftArgs {
-  const R* post;         // [T][E_POST][B]
-  R* post_next;          // [T][E_POST][B]
+  R* post;               // [T][E_POST][B]   ring
   const R* cell_init;    // [E_POST][B]
-  const R* alpha_cell;   // [T][B] or null
-  R* alpha_cell_next;    // [T][B] or null
+  R* alpha_cell;         // [T][B] ring, or null
   const R* alpha_init;   // [B] or null
-  const R* z;            // [T][NZ][B] or null
-  R* z_next;             // [T][NZ][B] or null
+  R* z;                  // [T][NZ][B] ring, or null
   const R* z_new;        // [NZ][B] or null: target of the appended cell (null: the previous last cell's)
-  const uint8_t* ff;     // [T]
-  uint8_t* ff_next;      // [T]
+  uint8_t* ff;           // [T] ring
   R* action;             // [NU + sym(NU)][B]: cells[0].mu_u0_m, sig_u0_m (packed) BEFORE the shift
 };
 
 template <class M, typename R>
-I2C_HD inline void mpc_shift_body(const Consts<M, R>& c, const ShiftArgs<R>& a, const int t, const int b) {
+I2C_HD inline void mpc_shift_body(const Consts<M, R>& c, const ShiftArgs<R>& a, const int b) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, D = C::D;
   const long B = c.B;
-  const int T = c.T;
-  const bool last = t == T - 1;
-  const R* src = last ? a.cell_init + b : a.post + ((long)(t + 1) * C::E_POST) * B + b;
-  R* dst = a.post_next + ((long)t * C::E_POST) * B + b;
-#pragma unroll
-  for (int e = 0; e < C::E_POST; ++e) dst[(long)e * B] = src[(long)e * B];
-  if (a.alpha_cell_next) a.alpha_cell_next[(long)t * B + b] = last ? a.alpha_init[b] : a.alpha_cell[(long)(t + 1) * B + b];
-  if (a.z_next) {
-#pragma unroll
-    for (int k = 0; k < NZ; ++k) {
-      const R v = !last ? a.z[((long)(t + 1) * NZ + k) * B + b]
-                        : (a.z_new ? a.z_new[(long)k * B + b] : a.z[((long)(T - 1) * NZ + k) * B + b]);
-      a.z_next[((long)t * NZ + k) * B + b] = v;
-    }
-  }
-  if (b == 0) a.ff_next[t] = last ? (uint8_t)1 : a.ff[t + 1];
-  if (t == 0 && a.action) {
-    const R* p0 = a.post + b;
+  const int r0 = c.row(0), rl = c.row(c.T - 1);  // rows of the first and of the last cell of the current horizon
+  R* p0 = a.post + ((long)r0 * C::E_POST) * B + b;
+  if (a.action) {
 #pragma unroll
     for (int i = 0; i < NU; ++i) a.action[(long)i * B + b] = p0[(long)(NX + i) * B];
 #pragma unroll
@@ -1862,6 +1853,15 @@ I2C_HD inline void mpc_shift_body(const Consts<M, R>& c, const ShiftArgs<R>& a, 
 #pragma unroll
       for (int q = 0; q <= p; ++q) a.action[(long)(NU + tri(p, q)) * B + b] = p0[(long)(D + tri(NX + p, NX + q)) * B];
   }
+#pragma unroll
+  for (int e = 0; e < C::E_POST; ++e) p0[(long)e * B] = a.cell_init[(long)e * B + b];
+  if (a.alpha_cell) a.alpha_cell[(long)r0 * B + b] = a.alpha_init[b];
+  if (a.z) {
+#pragma unroll
+    for (int k = 0; k < NZ; ++k)
+      a.z[((long)r0 * NZ + k) * B + b] = a.z_new ? a.z_new[(long)k * B + b] : a.z[((long)rl * NZ + k) * B + b];
+  }
+  if (b == 0) a.ff[r0] = (uint8_t)1;
 }
 
 }  // namespace i2c

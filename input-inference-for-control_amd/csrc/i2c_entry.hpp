@@ -27,6 +27,8 @@ struct ModelOps {
   void (*dims)(I2cDims*);
   size_t (*workspace_elems)(int B, int T);
   int (*schedule)(int B, int T, int requested);
+  int (*shift)(const I2cProblem*, void* post, const void* cell_init, const void* alpha_init, const void* z_new, void* action,
+               void* stream);
 };
 
 // defined by the translation units generated from i2c_model_tu.hip

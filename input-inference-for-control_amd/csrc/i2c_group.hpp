@@ -538,7 +538,8 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
     const bool is_u = r >= NX && r < D;
     const int ru = is_u ? r - NX : 0;
 
-    const GIO<R> pri = gio(a.prior + (unsigned long)t * C::E_POST * B, C::E_POST, rb, bo);
+    const int tr = c.row(t);  // row of the persistent buffers (ring, see Consts::t0)
+    const GIO<R> pri = gio(a.prior + (unsigned long)tr * C::E_POST * B, C::E_POST, rb, bo);
     const GIO<R> out = gio(a.fwd + (unsigned long)t * C::E_FWD * B, C::E_FWD, rb, bo);
     // every global load of the cell is issued here, together: one memory round trip per cell instead of three
     R pmu[D], prow[D], Krow[NX];
@@ -547,13 +548,13 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
     for (int j = 0; j < D; ++j) prow[j] = pri.ld(D + symidx(rd, trd, j));
 #pragma unroll
     for (int k = 0; k < NX; ++k) Krow[k] = pri.ld(O_K + ru * NX + k);
-    const R alpha = a.alpha_cell ? a.alpha_cell[(long)t * B + b] : alpha_traj;
+    const R alpha = a.alpha_cell ? a.alpha_cell[(long)tr * B + b] : alpha_traj;
     g_gather<D>(g, 0, pmu_own, pmu);
     int cell_bad = 0;
 
     // ---- 1. joint prior over (x, u) ---------------------------------------------------
     R mu0[D], s0[D];
-    if (a.ff[t] != 0) {  // feed-forward: independent action prior (i2c.py:355-360)
+    if (a.ff[tr] != 0) {  // feed-forward: independent action prior (i2c.py:355-360)
 #pragma unroll
       for (int i = 0; i < D; ++i) mu0[i] = i < NX ? mu_x[i] : pmu[i];
 #pragma unroll
@@ -603,7 +604,7 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
 #pragma unroll
       for (int l = 0; l < NZ; ++l) {
         szr[l] += alpha * kc.sig_xi0[rz * NZ + l];
-        mz[l] = (c.z_per_cell ? a.z[((long)t * NZ + l) * B + b] : c.zg[l]) - mz[l];  // the innovation
+        mz[l] = (c.z_per_cell ? a.z[((long)tr * NZ + l) * B + b] : c.zg[l]) - mz[l];  // the innovation
       }
       cell_bad = flag_stage(cell_bad, g_kalman<D, NZ>(g, mu0, s0, mz, szr, sxz, &mu1_own), 2);
     }
@@ -736,7 +737,7 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
     const int ru = is_u ? r - NX : 0;
 
     const GIO<R> fw = gio(a.fwd + (unsigned long)t * C::E_FWD * B, C::E_FWD, rb, bo);
-    const GIO<R> po = gio(a.post + (unsigned long)t * C::E_POST * B, C::E_POST, rb, bo);
+    const GIO<R> po = gio(a.post + (unsigned long)c.row(t) * C::E_POST * B, C::E_POST, rb, bo);
     R mu[D], S[D], m3f[NX], s3f[NX], Jr[NX];
     const R mu1_own = fw.ld(rd);
     g_gather<NX>(g, 1, fw.ld(O_MU3 + rx), m3f);
@@ -755,7 +756,7 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
     }
     R zt[NZ];
 #pragma unroll
-    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
+    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k];
 
     // RTS update of the joint (i2c.py:580-583): mu += J (m3m - m3f), S += J (S3m - S3f) J^T
     const auto dSm = g.mat(1), Jm = g.mat(2);
@@ -910,7 +911,7 @@ I2C_HD inline void propagate_group_body(const Consts<M, R>& c, const KC& kc, con
     const bool is_u = r >= NX && r < D;
     const int ru = is_u ? r - NX : 0;
 
-    const GIO<R> pri = gio(a.post + (unsigned long)t * C::E_POST * B, C::E_POST, rb, bo);
+    const GIO<R> pri = gio(a.post + (unsigned long)c.row(t) * C::E_POST * B, C::E_POST, rb, bo);
     const GIO<R> out = gio(a.prop + (unsigned long)t * C::E_PROP * B, C::E_PROP, rb, bo);
     R qmu[D], prow[D], Krow[NX];
     g_gather<D>(g, 0, pri.ld(rd), qmu);
@@ -918,7 +919,7 @@ I2C_HD inline void propagate_group_body(const Consts<M, R>& c, const KC& kc, con
     for (int j = 0; j < D; ++j) prow[j] = pri.ld(D + symidx(rd, trd, j));
 #pragma unroll
     for (int k = 0; k < NX; ++k) Krow[k] = pri.ld(O_K + ru * NX + k);
-    const bool ff = a.ff[t] != 0;
+    const bool ff = a.ff[c.row(t)] != 0;
     if (!ff && c.use_expert) {  // i2c.py:160-167
       R Sr[NX], rinvS[NX], q[NX];
 #pragma unroll
@@ -951,7 +952,7 @@ I2C_HD inline void propagate_group_body(const Consts<M, R>& c, const KC& kc, con
     if (!g_chol<D>(g, 0, L0, rinv0) && r == 0) set_status(a.status, b, 8, t);
     R zt[NZ], mz[NZ], szr[NZ], cm, cv;
 #pragma unroll
-    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
+    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k];
     if (OBS_ID && c.rule_xu.unit) {
 #pragma unroll
       for (int k = 0; k < NZ; ++k) {

@@ -135,7 +135,7 @@ I2C_KERNEL(SWEEP_BLOCK) k_ckf(I2C_LANE_PARAMS const Consts<M, R> c, const ZetaAr
 }
 template <class M, typename R> I2C_KERNEL(CELL_BLOCK) k_mpc_shift(I2C_LANE_PARAMS const Consts<M, R> c, const ShiftArgs<R> a) {
   const long b = I2C_LANE_X(CELL_BLOCK);
-  if (b < c.B) mpc_shift_body<M, R>(c, a, I2C_LANE_Y, (int)b);
+  if (b < c.B) mpc_shift_body<M, R>(c, a, (int)b);
 }
 template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_rollout(I2C_LANE_PARAMS const Consts<M, R> c, const RolloutArgs<R> a) {
   const long n = I2C_LANE_X(SWEEP_BLOCK);
@@ -297,6 +297,7 @@ template <class M, typename R> static Consts<M, R> make_consts(const I2cProblem*
   std::memset(&c, 0, sizeof(c));
   c.B = p->B;
   c.T = p->T;
+  c.t0 = p->t0;
   c.has_Qf = p->has_Qf && M::NZT > 0;
   c.has_x_terminal = p->has_x_terminal;
   c.z_per_cell = p->z_per_cell && p->z != nullptr;
@@ -387,7 +388,7 @@ template <class M, typename R, typename S = R> struct Impl {
 #else
       const int lanes = sweep_lanes();
 #endif
-      const bool lean = c.rule_xu.unit && c.rule_x.unit && !c.z_per_cell && !a.alpha_cell && !a.prior_out;
+      const bool lean = c.rule_xu.unit && c.rule_x.unit && !c.z_per_cell && !a.alpha_cell && !a.prior_out && c.t0 == 0;
       if (lean) return launch(k_forward<M, R, true, false, S>, p->B, 1, lanes, stream, c, a, lanes);
       return launch(k_forward<M, R, false, false, S>, p->B, 1, lanes, stream, c, a, lanes);
     }
@@ -551,8 +552,12 @@ template <class M, typename R, typename S = R> struct Impl {
 
   // _update_priors (i2c.py:1210-1213): cells with index <= tau switch to feedback mode
   static int to_feedback(const I2cProblem* p, int tau, void* stream) {
-    const size_t n = (size_t)(tau + 1 < p->T ? tau + 1 : p->T);
-    return clear_bytes(const_cast<uint8_t*>(p->feedforward), n, stream);
+    const int n = tau + 1 < p->T ? tau + 1 : p->T;  // cells 0 .. n-1 = ring rows t0 .. t0+n-1 (mod T): at most two spans
+    uint8_t* ff = const_cast<uint8_t*>(p->feedforward);
+    const int first = n < p->T - p->t0 ? n : p->T - p->t0;
+    int rc = clear_bytes(ff + p->t0, (size_t)first, stream);
+    if (rc == I2C_OK && n > first) rc = clear_bytes(ff, (size_t)(n - first), stream);
+    return rc;
   }
 
   static int learn(const I2cProblem* p, void* post, void* fwd, void* xm, void* zpost, void* cell_stats,
@@ -593,7 +598,8 @@ template <class M, typename R, typename S = R> struct Impl {
   }
 
   // One control step of the MPC loop enqueued by one call (i2c/policy/mpc.py:156-182): filter, n_iter x (forward,
-  // backward, _update_priors), first action, horizon shift into the second set of buffers.
+  // backward, _update_priors), first action, and the horizon shift: one fresh row written into the ring of per-cell buffers
+  // (the caller then advances I2cProblem.t0 by one and moves terminal_cell).
   static int mpc_step(const I2cProblem* p, const I2cMpcStep* m, void* stream) {
     if constexpr (MIXED) return I2C_ENOTSUP;
     int rc = I2C_OK;
@@ -604,11 +610,17 @@ template <class M, typename R, typename S = R> struct Impl {
       if (rc == I2C_OK && m->tau > 0) rc = to_feedback(p, m->tau, stream);
     }
     if (rc != I2C_OK) return rc;
+    return shift(p, m->post, m->cell_init, m->alpha_init, m->z_new, m->action, stream);
+  }
+  // the receding-horizon shift alone (BatchedI2c.shift_horizon, the step-by-step path of the policies)
+  static int shift(const I2cProblem* p, void* post, const void* cell_init, const void* alpha_init, const void* z_new, void* action,
+                   void* stream) {
+    if constexpr (MIXED) return I2C_ENOTSUP;
     const C c = make_consts<M, R>(p, 0.0, 0);
-    ShiftArgs<R> a{(const R*)m->post,       (R*)m->post_next, (const R*)m->cell_init, (const R*)p->alpha_cell, (R*)m->alpha_cell_next,
-                   (const R*)m->alpha_init, (const R*)p->z,   (R*)m->z_next,          (const R*)m->z_new,      p->feedforward,
-                   m->feedforward_next,     (R*)m->action};
-    return launch(k_mpc_shift<M, R>, p->B, p->T, CELL_BLOCK, stream, c, a);
+    ShiftArgs<R> a{(R*)post, (const R*)cell_init, (R*)const_cast<void*>(p->alpha_cell), (const R*)alpha_init,
+                   (R*)const_cast<void*>(p->z_per_cell ? p->z : nullptr), (const R*)z_new, const_cast<uint8_t*>(p->feedforward),
+                   (R*)action};
+    return launch(k_mpc_shift<M, R>, p->B, 1, CELL_BLOCK, stream, c, a);
   }
 
   static int rollout(const I2cProblem* p, const void* post, int n_rollouts, int policy, const void* eps_x0,
@@ -664,7 +676,7 @@ template <class M, typename R, typename S = R> const ModelOps* make_ops() {
   using I = Impl<M, R, S>;
   static const ModelOps ops = {&I::forward, &I::backward,  &I::mstep,        &I::learn,           &I::ckf,
                                &I::rollout, &I::propagate, &I::riccati,   &I::mpc_step,        &fill_dims<M>,
-                               &workspace_elems<M>, &I::schedule};
+                               &workspace_elems<M>, &I::schedule, &I::shift};
   return &ops;
 }
 

@@ -234,6 +234,9 @@ class BatchedI2c:
         self.zg = np.asarray(model.zg, np.float64).reshape(nz)
         self.zg_term = None if model.zg_term is None else np.asarray(model.zg_term, np.float64).reshape(-1)
 
+        # Ring offset of the persistent per-cell buffers (post / prior, z, alpha_cell, feedforward): cell t of the horizon
+        # lives in row (t0 + t) mod T (I2cProblem.t0). Only the MPC shift moves it; cells() / the getters undo it.
+        self.t0 = 0
         self.alpha_cell = None      # [T][B] per-cell temperature, only in the MPC loop (see enable_per_cell_alpha)
         self.alpha_init = None
         self.terminal_cell = T - 1  # cell whose forward pass applies the terminal cost update (i2c.py:82,822)
@@ -265,6 +268,7 @@ class BatchedI2c:
                        _native.INF_GAUSS_HERMITE if self.gauss_hermite else _native.INF_CUBATURE)
         p.gh_degree = self.gh_degree
         p.group_lanes = self.group_lanes
+        p.t0 = int(self.t0)
         if self.gauss_hermite:
             gx, gw = np.polynomial.hermite.hermgauss(self.gh_degree)  # exp_types.py:57
             for i in range(self.gh_degree):
@@ -375,7 +379,7 @@ class BatchedI2c:
         """I2cGraph._update_priors (i2c.py:1210-1221). The data copy is free: the forward sweep reads
         the posterior buffer as its prior; only the feed-forward -> feedback flags change."""
         if self.tau > 0:
-            self.feedforward[: self.tau + 1] = 0
+            self.feedforward[self.ring_rows(min(self.tau + 1, self.H))] = 0
         if self.prior is not self.post:  # keep_prior_joint: the posterior becomes the prior, the old prior buffer is free
             self._post_spare, self.prior = self.prior, self.post
 
@@ -499,7 +503,6 @@ class BatchedI2c:
         if self.alpha_cell is None:
             self.alpha_init = self.alpha.clone()
             self.alpha_cell = self.alpha.reshape(1, -1).repeat(self.H, 1).contiguous()
-            self._mpc_next = None
             self.refresh_problem()
 
     def _broadcast_alpha(self):
@@ -507,29 +510,48 @@ class BatchedI2c:
         if self.alpha_cell is not None:
             self.alpha_cell.copy_(self.alpha.reshape(1, -1).expand(self.H, -1))
 
-    def shift_horizon(self, z_new=None):
-        """Receding horizon (mpc.py:174-181): drop cell 0, append a fresh feed-forward cell whose target
-        is z_new ([nz][B] tensor) or, if None, the previous last cell's target. Buffers keep their address.
-        The `terminal_cell` flag stays with the cell it was set on (i2c.py:822), so it moves forward too."""
-        self.post.copy_(torch.roll(self.post, -1, 0))
-        self.post[-1] = self.cell_init
-        if self.alpha_cell is not None:
-            self.alpha_cell.copy_(torch.roll(self.alpha_cell, -1, 0))
-            self.alpha_cell[-1] = self.alpha_init
+    def ring_rows(self, n=None):
+        """Physical rows of cells 0..n-1 (default: the whole horizon) in the ring buffers, as an index tensor."""
+        n = self.H if n is None else n
+        return (torch.arange(n, device=self.device) + self.t0) % self.H
+
+    def cells(self, buf):
+        """A ring buffer ([T][...]) in cell order (a view when the ring has not moved)."""
+        return buf if self.t0 == 0 else torch.roll(buf, -self.t0, 0)
+
+    def _advance_ring(self):
+        self.t0 = (self.t0 + 1) % self.H
         if self.terminal_cell >= 0:
             self.terminal_cell -= 1
-            self._problem.terminal_cell = int(self.terminal_cell)
-        self.feedforward.copy_(torch.roll(self.feedforward, -1, 0))
-        self.feedforward[-1] = 1
-        if self.z is not None:
-            self.z.copy_(torch.roll(self.z, -1, 0))
-            self.z[-1] = self.z[-2] if z_new is None else z_new
+        self._problem.t0 = int(self.t0)
+        self._problem.terminal_cell = int(self.terminal_cell)
+
+    def shift_horizon(self, z_new=None, want_action=False):
+        """Receding horizon (mpc.py:174-181): drop cell 0, append a fresh feed-forward cell whose target is z_new ([nz][B]
+        tensor) or, if None, the previous last cell's. The per-cell buffers are a ring: the fresh cell is written over the
+        row of the dropped one (i2c_shift_horizon) and the ring offset advances -- nothing else moves. The `terminal_cell`
+        flag stays with the cell it was set on (i2c.py:822), so its index decreases. Returns the dropped cell's action
+        moments (mu_u (B, nu), sig_u packed (B, sym nu)) if want_action."""
+        assert self.prior is self.post, "shift_horizon() between a sweep and its update_priors()"
+        if want_action and getattr(self, "_mpc_action", None) is None:
+            self._mpc_action = torch.empty(self.nu + sym_size(self.nu), self.B, dtype=self.dtype, device=self.device)
+        if z_new is not None:
+            z_new = z_new.contiguous()
+        rc = self.lib.i2c_shift_horizon(C.byref(self._problem), self._ptr(self.post), self._ptr(self.cell_init),
+                                        self._ptr(self.alpha_init), self._ptr(z_new),
+                                        self._ptr(self._mpc_action) if want_action else None, self._stream())
+        self._check(rc, "i2c_shift_horizon")
+        self._advance_ring()
+        if want_action:
+            return self._mpc_action[: self.nu].T, self._mpc_action[self.nu:].T
 
     def mpc_step(self, n_iter, y=None, u=None, sig_zeta=None, z_new=None):
         """One control step of the MPC loop in one library call (i2c_mpc_step): optional filter step on the belief, n_iter
-        sweeps, first action, receding-horizon shift -- no host round trip, no torch ops. Returns (mu_u (B, nu),
-        sig_u packed (B, sym nu)) device tensors: the first planned action BEFORE the shift (cells[0].mu_u0_m, sig_u0_m).
-        Same numbers as ckf_filter + n_iter x (forward_backward, update_priors) + shift_horizon."""
+        sweeps, first action, receding-horizon shift -- no host round trip, no torch ops, no copy of the horizon (the per-cell
+        buffers are a ring). Returns (mu_u (B, nu), sig_u packed (B, sym nu)) device tensors: the first planned action BEFORE
+        the shift (cells[0].mu_u0_m, sig_u0_m). Same numbers as ckf_filter + n_iter x (forward_backward, update_priors) +
+        shift_horizon."""
+        assert self.prior is self.post, "mpc_step() between a sweep and its update_priors()"
         st = _native.I2cMpcStep()
         st.do_filter = int(y is not None)
         st.n_iter, st.tau = int(n_iter), int(self.tau)
@@ -540,50 +562,30 @@ class BatchedI2c:
                 st.sig_zeta[i] = float(v)
             y, u = y.contiguous(), u.contiguous()
             st.y, st.u = y.data_ptr(), u.data_ptr()
-        if getattr(self, "_mpc_next", None) is None:  # the second set of buffers of the out-of-place shift
-            self._mpc_next = {"post": torch.empty_like(self.post), "feedforward": torch.empty_like(self.feedforward),
-                              "alpha_cell": None if self.alpha_cell is None else torch.empty_like(self.alpha_cell),
-                              "z": None if self.z is None else torch.empty_like(self.z)}
+        if getattr(self, "_mpc_action", None) is None:
             self._mpc_action = torch.empty(self.nu + sym_size(self.nu), self.B, dtype=self.dtype, device=self.device)
-        nxt = self._mpc_next
-        st.post, st.post_next, st.fwd = self.post.data_ptr(), nxt["post"].data_ptr(), self.fwd.data_ptr()
+        st.post, st.fwd = self.post.data_ptr(), self.fwd.data_ptr()
         opt = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         st.xm, st.zpost, st.cell_stats, st.term_stats = opt(self.xm), opt(self.zpost), opt(self.cell_stats), self.term_stats.data_ptr()
-        st.cell_init = self.cell_init.data_ptr()
-        st.alpha_init, st.alpha_cell_next = opt(self.alpha_init), opt(nxt["alpha_cell"])
+        st.cell_init, st.alpha_init = self.cell_init.data_ptr(), opt(self.alpha_init)
         if z_new is not None:
             z_new = z_new.contiguous()
-        st.z_new, st.z_next = opt(z_new), opt(nxt["z"])
-        st.feedforward_next, st.action, st.status = nxt["feedforward"].data_ptr(), self._mpc_action.data_ptr(), self.status.data_ptr()
+        st.z_new = opt(z_new)
+        st.action, st.status = self._mpc_action.data_ptr(), self.status.data_ptr()
         self._problem.expert_controller = int(bool(self.use_expert_controller))
         rc = self.lib.i2c_mpc_step(C.byref(self._problem), C.byref(st), self._stream())
         self._check(rc, "i2c_mpc_step")
-        # the shifted horizon becomes the current one
-        alias = self.prior is self.post
-        self.post, nxt["post"] = nxt["post"], self.post
-        if alias:
-            self.prior = self.post
-        self.feedforward, nxt["feedforward"] = nxt["feedforward"], self.feedforward
-        if self.alpha_cell is not None:
-            self.alpha_cell, nxt["alpha_cell"] = nxt["alpha_cell"], self.alpha_cell
-        if self.z is not None:
-            self.z, nxt["z"] = nxt["z"], self.z
-        if self.terminal_cell >= 0:
-            self.terminal_cell -= 1
-        p = self._problem
-        p.terminal_cell = int(self.terminal_cell)
-        p.feedforward = self.feedforward.data_ptr()
-        p.alpha_cell = opt(self.alpha_cell)
-        p.z = opt(self.z)
+        self._advance_ring()
         return self._mpc_action[: self.nu].T, self._mpc_action[self.nu:].T
 
     def set_targets(self, z_traj):
         """Per-cell targets (mpc.py:29-31): z_traj (T, nz) or (B, T, nz)."""
         z = np.broadcast_to(np.asarray(z_traj, np.float64), (self.B, self.H, self.nz))
         zt = torch.as_tensor(np.array(np.transpose(z, (1, 2, 0)), order="C"), dtype=self.dtype, device=self.device)
+        if self.t0:
+            zt = torch.roll(zt, self.t0, 0)  # cell order -> ring rows
         if self.z is None:
-            self.z = zt
-            self._mpc_next = None
+            self.z = zt.contiguous()
             self.refresh_problem()
         else:
             self.z.copy_(zt)
@@ -657,6 +659,8 @@ class BatchedI2c:
 
     # ------------------------------------------------------------------ getters: (B, T, ...) tensors
     def _rows(self, buf, lo, n):
+        if buf is self.post or buf is self.prior:  # ring buffers: back to cell order
+            buf = self.cells(buf)
         return buf[:, lo: lo + n, :].permute(2, 0, 1)  # (B, T, n)
 
     def _sym_rows(self, buf, lo, n):

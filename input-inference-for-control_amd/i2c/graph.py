@@ -70,11 +70,13 @@ class I2cCell:
     # -- writable flags ---------------------------------------------------------------------
     @property
     def state_action_independence(self):
-        return bool(self._g.engine.feedforward[self.index].item())
+        e = self._g.engine
+        return bool(e.feedforward[(self.index + e.t0) % e.H].item())  # ring row of this cell
 
     @state_action_independence.setter
     def state_action_independence(self, value):
-        self._g.engine.feedforward[self.index] = 1 if value else 0
+        e = self._g.engine
+        e.feedforward[(self.index + e.t0) % e.H] = 1 if value else 0
 
     @property
     def use_expert_controller(self):
@@ -274,7 +276,7 @@ class I2cGraph:
         e = self.engine
         if e.z is None:
             return np.copy(self.z)
-        z = _np(e.z[t]).T  # (B, nz)
+        z = _np(e.z[(t + e.t0) % e.H]).T  # (B, nz); ring row of cell t
         return z[0].reshape(-1, 1) if self.B == 1 else z
 
     def _set_cell_target(self, t, value):
@@ -285,7 +287,7 @@ class I2cGraph:
             e.z = zg.reshape(1, -1, 1).repeat(self.H, 1, self.B).contiguous()
             e.refresh_problem()
         v = torch.as_tensor(np.asarray(value, dtype=float).reshape(-1, e.nz).T, dtype=e.dtype, device=e.device)
-        e.z[t] = v.expand(e.nz, self.B)
+        e.z[(t + e.t0) % e.H] = v.expand(e.nz, self.B)
 
     # ------------------------------------------------------------------ temperature
     @property
@@ -550,7 +552,7 @@ class I2cGraph:
             sd[k] = None if v is None else v.detach().cpu().clone()
         for k in self._STATE_LISTS:
             sd[k] = [t.detach().cpu().clone() for t in getattr(e, k)]
-        sd.update(em_iter=e.em_iter, tau=e.tau, terminal_cell=e.terminal_cell, propagate=bool(e._propagate),
+        sd.update(em_iter=e.em_iter, tau=e.tau, terminal_cell=e.terminal_cell, t0=e.t0, propagate=bool(e._propagate),
                   use_expert_controller=bool(e.use_expert_controller), horizon=e.H, batch=e.B, model=self.sys.model_name)
         return sd
 
@@ -575,7 +577,7 @@ class I2cGraph:
                 getattr(e, k).copy_(sd[k])
         for k in self._STATE_LISTS:
             setattr(e, k, [t.to(e.device) for t in sd[k]])
-        e.em_iter, e.tau, e.terminal_cell = int(sd["em_iter"]), int(sd["tau"]), int(sd["terminal_cell"])
+        e.em_iter, e.tau, e.terminal_cell, e.t0 = int(sd["em_iter"]), int(sd["tau"]), int(sd["terminal_cell"]), int(sd["t0"])
         e._propagate, e.use_expert_controller = bool(sd["propagate"]), bool(sd["use_expert_controller"])
         e.refresh_problem()
         self._invalidate()

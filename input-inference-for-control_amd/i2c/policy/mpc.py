@@ -29,7 +29,7 @@ class MpcPolicy:
         self.n_iter = n_iter
         self.set_control(True)  # mpc.py:21-22
         e.enable_per_cell_alpha()  # cell_init is copied NOW (mpc.py:26): appended cells carry today's sig_xi ...
-        e.cell_init = e.post[0].clone()  # ... and today's cells[0] (deepcopy(i2c.cells[0]), mpc.py:26), not the constructor's
+        e.cell_init = e.post[e.t0].clone()  # ... and today's cells[0] (deepcopy(i2c.cells[0]), mpc.py:26), not the constructor's
         self.z_traj = None if z_traj is None else np.asarray(z_traj, dtype=float)
         if self.z_traj is not None:
             zt = self.z_traj if self.z_traj.ndim == 3 else self.z_traj[None]
@@ -58,7 +58,8 @@ class MpcPolicy:
             e.z.copy_(self._init_z)
         e.status.zero_()
         e.terminal_cell = self._init_terminal
-        e._problem.terminal_cell = int(e.terminal_cell)
+        e.t0 = 0  # the snapshot was taken with the ring at its origin
+        e._problem.terminal_cell, e._problem.t0 = int(e.terminal_cell), 0
         self.xu_history, self.z_history = [], []
 
     def _squeeze(self, a, column=False):
@@ -91,11 +92,11 @@ class MpcPolicy:
         """cells[0].mu_u0_m (and sig_u0_m when sampling): only cell 0 of the posterior buffer is read back."""
         e = self.engine
         d, nx = e.d, e.nx
-        mu_u = _np(e.post[0, nx:d, :].T)  # (B, nu)
+        mu_u = _np(e.post[e.t0, nx:d, :].T)  # (B, nu); row t0 of the ring is cell 0
         if not deterministic:
             from .. import core
 
-            sig = core.engine.unpack_sym(e.post[0, d: d + d * (d + 1) // 2, :].T, d)  # (B, d, d), cell 0 only
+            sig = core.engine.unpack_sym(e.post[e.t0, d: d + d * (d + 1) // 2, :].T, d)  # (B, d, d), cell 0 only
             sig_u = _np(sig[:, nx:, nx:])
             mu_u = np.stack([np.random.multivariate_normal(m, s) for m, s in zip(mu_u, sig_u)])
         return mu_u

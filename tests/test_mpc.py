@@ -193,7 +193,7 @@ def _native_step_equals_stepwise(name, lib, device):
         for _ in range(meta["n_iter"]):
             ea.forward_backward()
             ea.update_priors()
-        mu_a = ea.post[0, ea.nx: ea.d, :].T.clone()
+        mu_a = ea.cells(ea.post)[0, ea.nx: ea.d, :].T.clone()
         ea.shift_horizon(z_new)
         # (b) one call
         mu_b, _ = eb.mpc_step(meta["n_iter"], yd if t > 0 else None, ud if t > 0 else None, pb.i2c.sys.sig_zeta, z_new=z_new)
@@ -202,7 +202,7 @@ def _native_step_equals_stepwise(name, lib, device):
             ta, tb = getattr(ea, key), getattr(eb, key)
             if ta is not None:
                 assert torch.equal(ta, tb), f"{name} step {t}: {key}"
-        assert ea.terminal_cell == eb.terminal_cell and nz == eb.nz
+        assert ea.terminal_cell == eb.terminal_cell and nz == eb.nz and ea.t0 == eb.t0 == (t + 1) % ea.H
 
 
 @pytest.mark.parametrize("name", ["mpc_pendulum_fb", "mpc_quadrotor_fb", "mpc_quad12_fb"])
