@@ -21,7 +21,11 @@ def per_kernel(d):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "i2c::" in r["Kernel_Name"]:
-            acc[r["Kernel_Name"].split("i2c::")[1].split("<")[0]].append(float(r["Counter_Value"]))
+            rest = r["Kernel_Name"].split("i2c::")[1]
+            name = rest.split("<")[0]
+            if name == "k_group":  # one kernel template for the four group sweeps: KIND is its first argument
+                name += "_" + {"0": "forward", "1": "backward", "2": "propagate", "3": "ckf"}.get(rest.split("<")[1].split(",")[0].strip(), "x")
+            acc[name].append(float(r["Counter_Value"]))
     return {k: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in acc.items()}  # steady-state half
 
 
