@@ -174,6 +174,9 @@ typedef struct I2cProblem {
   void* work;           /* optional device workspace of i2c_workspace_bytes() bytes for the chunked backward  */
   const uint8_t* feedforward; /* [T] bytes: 1 = cell in feed-forward mode
                                  (state_action_independence, i2c.py:132,355,1212-1213)            */
+  const uint8_t* expert;      /* optional [T] bytes (ring): per-cell use_expert_controller (i2c.py:143), read by the
+                                 closed-loop propagation (i2c.py:160) and the Linearize forward pass (i2c.py:259); NULL: every
+                                 cell takes the scalar flag (expert_controller / the argument of i2c_propagate)  */
 } I2cProblem;
 
 /*

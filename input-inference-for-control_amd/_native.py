@@ -94,6 +94,7 @@ class I2cProblem(C.Structure):
         ("temp", C.c_void_p),
         ("work", C.c_void_p),
         ("feedforward", C.c_void_p),
+        ("expert", C.c_void_p),
     ]
 
 

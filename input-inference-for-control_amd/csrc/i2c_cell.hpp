@@ -481,6 +481,7 @@ template <typename R, typename S = R> struct FwdArgs {
   const R* alpha_cell;  // [T][B] or null
   const uint8_t* ff;  // [T]
   int32_t* status;  // [B]
+  const uint8_t* expert;  // [T] ring or null: per-cell use_expert_controller (Linearize forward only, i2c.py:259-265)
 };
 
 // LEAN = the common case fixed at compile time (weights sum to 1, shared target, trajectory-level alpha, no
@@ -1512,6 +1513,7 @@ template <typename R> struct PropArgs {
   const R* z;
   const uint8_t* ff;
   int32_t* status;
+  const uint8_t* expert;  // [T] ring or null: per-cell use_expert_controller (i2c.py:143,160); null: Consts::use_expert
 };
 
 template <class M, typename R, bool GRID = false>
@@ -1549,7 +1551,7 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
         for (int q = 0; q <= p; ++q) sig_u[tri(p, q)] = qsig[tri(NX + p, NX + q)];
       joint_from_gain<NX, NU>(mu_x, sig_x, Kt, mu_x, qmu + NX, sig_u, mu0, S0);
     } else {
-      if (c.use_expert) {  // i2c.py:160-167
+      if (a.expert ? a.expert[c.row(t)] != 0 : c.use_expert != 0) {  // i2c.py:160-167
         R S[sym(NX)], delta[NX];
 #pragma unroll
         for (int i = 0; i < sym(NX); ++i) S[i] = qsig[i] + sig_x[i];

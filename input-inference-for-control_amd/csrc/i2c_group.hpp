@@ -920,7 +920,7 @@ I2C_HD inline void propagate_group_body(const Consts<M, R>& c, const KC& kc, con
 #pragma unroll
     for (int k = 0; k < NX; ++k) Krow[k] = pri.ld(O_K + ru * NX + k);
     const bool ff = a.ff[c.row(t)] != 0;
-    if (!ff && c.use_expert) {  // i2c.py:160-167
+    if (!ff && (a.expert ? a.expert[c.row(t)] != 0 : c.use_expert != 0)) {  // i2c.py:160-167
       R Sr[NX], rinvS[NX], q[NX];
 #pragma unroll
       for (int j = 0; j < NX; ++j) {

@@ -401,7 +401,7 @@ template <class M, typename R, typename S = R> struct Impl {
     if constexpr (MIXED) {  // fp64 arithmetic on fp32-stored messages: the cubature path of the one-lane kernels only
       if (p->inference != I2C_INF_CUBATURE || use_group(p) != 0) return I2C_ENOTSUP;
       FwdArgs<R, S> am{(const S*)prior, (S*)fwd, (S*)prior_out, (const R*)p->x0, (const R*)p->sig_x0,
-                       (const R*)p->z,  (const R*)p->alpha, (const R*)p->alpha_cell, p->feedforward, status};
+                       (const R*)p->z,  (const R*)p->alpha, (const R*)p->alpha_cell, p->feedforward, status, p->expert};
       return forward_lane(p, c, am, stream);
     } else {
       return forward_any(p, c, prior, fwd, prior_out, status, stream);
@@ -410,7 +410,7 @@ template <class M, typename R, typename S = R> struct Impl {
   static int forward_any(const I2cProblem* p, const C& c, const void* prior, void* fwd, void* prior_out, int32_t* status,
                          void* stream) {
     FwdArgs<R> a{(const R*)prior, (R*)fwd, (R*)prior_out, (const R*)p->x0, (const R*)p->sig_x0,
-                 (const R*)p->z,  (const R*)p->alpha, (const R*)p->alpha_cell, p->feedforward, status};
+                 (const R*)p->z,  (const R*)p->alpha, (const R*)p->alpha_cell, p->feedforward, status, p->expert};
     const int grp = use_group(p);
     if (grp < 0) return grp;
     if (grp) {
@@ -638,7 +638,7 @@ template <class M, typename R, typename S = R> struct Impl {
     if constexpr (MIXED) return I2C_ENOTSUP;
     const C c = make_consts<M, R>(p, 0.0, use_expert);
     PropArgs<R> a{(const R*)post, (R*)prop, (R*)prop_stats, (const R*)p->x0, (const R*)p->sig_x0,
-                  (const R*)p->z, p->feedforward, status};
+                  (const R*)p->z, p->feedforward, status, p->expert};
     const int grp = use_group(p);
     if (grp < 0) return grp;
     if (grp) {

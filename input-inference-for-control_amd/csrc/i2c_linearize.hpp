@@ -149,7 +149,7 @@ I2C_HD inline void forward_lin_body(const Consts<M, R>& c, const FwdArgs<R>& a, 
       for (int i = 0; i < sym(D); ++i) psig[i] = pri[(long)(D + i) * B];
 #pragma unroll
       for (int i = 0; i < NU * NX; ++i) Kt[i] = pri[(long)(D + sym(D) + i) * B];
-      if (c.use_expert) {
+      if (a.expert ? a.expert[t] != 0 : c.use_expert != 0) {
         R S[sym(NX)], delta[NX];
 #pragma unroll
         for (int i = 0; i < sym(NX); ++i) S[i] = psig[i] + sig_x[i];

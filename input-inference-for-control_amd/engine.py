@@ -244,6 +244,7 @@ class BatchedI2c:
         self.tau = T - 1  # i2c.py:833
         self._propagate = False
         self.use_expert_controller = True
+        self.expert_cells = None  # optional [T] uint8 ring: per-cell use_expert_controller (set_cell_expert)
         self.em_iter = 0
         # per-iteration metrics as device tensors (B,): no host sync inside the EM loop
         self.alphas = [self.alpha.clone()]
@@ -305,6 +306,7 @@ class BatchedI2c:
         p.temp = self.temp.data_ptr()
         p.work = self.work.data_ptr() if getattr(self, "work", None) is not None else None
         p.feedforward = self.feedforward.data_ptr()
+        p.expert = self.expert_cells.data_ptr() if self.expert_cells is not None else None
         return p
 
     def refresh_problem(self):
@@ -375,11 +377,28 @@ class BatchedI2c:
                                     self._ptr(self.status), self._stream())
         self._check(rc, "i2c_propagate")
 
+    def set_cell_expert(self, t, value):
+        """cells[t].use_expert_controller = value (i2c.py:143): a per-cell flag like the reference's, allocated on first use
+        (until then every cell follows `use_expert_controller`)."""
+        if self.expert_cells is None:
+            self.expert_cells = torch.full((self.H,), int(bool(self.use_expert_controller)), dtype=torch.uint8, device=self.device)
+            self._problem.expert = self.expert_cells.data_ptr()
+        self.expert_cells[(int(t) + self.t0) % self.H] = int(bool(value))
+
+    def cell_expert(self, t):
+        if self.expert_cells is None:
+            return bool(self.use_expert_controller)
+        return bool(self.expert_cells[(int(t) + self.t0) % self.H].item())
+
     def update_priors(self):
         """I2cGraph._update_priors (i2c.py:1210-1221). The data copy is free: the forward sweep reads
         the posterior buffer as its prior; only the feed-forward -> feedback flags change."""
         if self.tau > 0:
-            self.feedforward[self.ring_rows(min(self.tau + 1, self.H))] = 0
+            n = min(self.tau + 1, self.H)
+            if self.t0 == 0:
+                self.feedforward[:n] = 0  # one fill, no index arithmetic on the device
+            else:
+                self.feedforward[self.ring_rows(n)] = 0
         if self.prior is not self.post:  # keep_prior_joint: the posterior becomes the prior, the old prior buffer is free
             self._post_spare, self.prior = self.prior, self.post
 

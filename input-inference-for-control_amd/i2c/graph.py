@@ -80,12 +80,12 @@ class I2cCell:
 
     @property
     def use_expert_controller(self):
-        return self._g.engine.use_expert_controller
+        return self._g.engine.cell_expert(self.index)
 
     @use_expert_controller.setter
     def use_expert_controller(self, value):
         # the reference keeps the flag per cell but every script sets all cells alike
-        self._g.engine.use_expert_controller = bool(value)
+        self._g.engine.set_cell_expert(self.index, value)  # per cell, as in the reference (i2c.py:143)
 
     @property
     def z(self):

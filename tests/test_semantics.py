@@ -147,3 +147,34 @@ def test_horizon_beyond_status_word_is_refused():
                               lib=hostsim.load(), device="cpu", keep_zpost=False, keep_xm=False)
     with pytest.raises(RuntimeError, match="-1"):
         e.forward_sweep()
+
+
+def test_use_expert_controller_is_per_cell():
+    """cells[t].use_expert_controller (i2c.py:143) is a per-cell flag: the propagation scales the gain of exactly the cells
+    that have it set (i2c.py:160-167)."""
+    g = load_case("em_pendulum_T50_propagate")
+    lib = hostsim.load()
+    T = g.meta["T"]
+    runs = {}
+    for name in ("all_on", "all_off", "second_half_on"):
+        a = _graph(g, lib, "cpu")
+        a._propagate = True
+        for _ in range(2):
+            a._forward_backward_msgs()
+            a._update_priors()
+        if name == "all_on":
+            a.engine.use_expert_controller = True
+        elif name == "all_off":
+            for c in a.cells:
+                c.use_expert_controller = False
+        else:
+            for t, c in enumerate(a.cells):
+                c.use_expert_controller = t >= T // 2
+        a.propagate()
+        runs[name] = a.engine.prop.clone()
+        if name == "second_half_on":
+            assert not a.cells[0].use_expert_controller and a.cells[T - 1].use_expert_controller
+    h = T // 2
+    assert torch.equal(runs["second_half_on"][:h], runs["all_off"][:h])       # first half: unscaled gains
+    assert not torch.equal(runs["second_half_on"][h + 1:], runs["all_off"][h + 1:])  # then the scaling sets in
+    assert not torch.equal(runs["all_on"], runs["all_off"])
