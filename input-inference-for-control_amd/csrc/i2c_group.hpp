@@ -207,38 +207,55 @@ template <int N, typename R, int G> I2C_FN bool g_chol(const Grp<R, G>& g, const
 }
 
 // L y = b (forward substitution) for one or two right-hand sides per lane; L is in LDS matrix m, rinv replicated.
-// A scheduling fence per row keeps the live state at one row of L (an explicit one-row-ahead prefetch cost the d = 16
-// forward kernel 30 more live doubles and pushed it into scratch).
+// Row i + 1 of L is fetched while row i is consumed (the LDS latency of every row would otherwise be exposed to the lone
+// wave); a scheduling fence per row keeps the live state at two rows.
 template <int N, int NRHS, typename R, int G>
 I2C_FN void g_fsub(const Grp<R, G>& g, const int m, const R* rinv, R* b0, R* b1) {
   constexpr int LD = Grp<R, G>::LD;
   constexpr bool FENCE = N >= 6;
   const auto L = g.mat(m);
+  R lc[N], ln[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
+    if (i + 1 < N) {
+#pragma unroll
+      for (int k = 0; k <= i; ++k) ln[k] = L[(i + 1) * LD + k];
+    }
     R v0 = b0[i], v1 = NRHS > 1 ? b1[i] : R(0);
 #pragma unroll
     for (int k = 0; k < i; ++k) {
-      const R l = L[i * LD + k];
-      v0 -= l * b0[k];
-      if (NRHS > 1) v1 -= l * b1[k];
+      v0 -= lc[k] * b0[k];
+      if (NRHS > 1) v1 -= lc[k] * b1[k];
     }
     b0[i] = v0 * rinv[i];
     if (NRHS > 1) b1[i] = v1 * rinv[i];
+    if (i + 1 < N) {
+#pragma unroll
+      for (int k = 0; k <= i; ++k) lc[k] = ln[k];
+    }
     sched_fence<FENCE>();
   }
 }
-// L^T x = y (back substitution), one right-hand side per lane
+// L^T x = y (back substitution), one right-hand side per lane (column i - 1 of L fetched while column i is consumed)
 template <int N, typename R, int G> I2C_FN void g_bsub(const Grp<R, G>& g, const int m, const R* rinv, R* y) {
   constexpr int LD = Grp<R, G>::LD;
   constexpr bool FENCE = N >= 6;
   const auto L = g.mat(m);
+  R lc[N], ln[N];
 #pragma unroll
   for (int i = N - 1; i >= 0; --i) {
+    if (i > 0) {
+#pragma unroll
+      for (int k = i; k < N; ++k) ln[k] = L[k * LD + (i - 1)];
+    }
     R v = y[i];
 #pragma unroll
-    for (int k = i + 1; k < N; ++k) v -= L[k * LD + i] * y[k];
+    for (int k = i + 1; k < N; ++k) v -= lc[k] * y[k];
     y[i] = v * rinv[i];
+    if (i > 0) {
+#pragma unroll
+      for (int k = i; k < N; ++k) lc[k] = ln[k];
+    }
     sched_fence<FENCE>();
   }
 }
@@ -319,7 +336,7 @@ I2C_FN void g_transform(const Grp<R, G>& g, const int mL, const int mA, const in
   // matrix mL, which phase 1 left intact), so the live state is the three accumulator rows and one published pair.
   // Fully unrolled, this loop alone drove the d = 16 forward kernel 1.3 KB per lane into scratch.
   const auto Lr = Lm + r * LD;
-  constexpr int UF = DIN * DOUT >= 96 ? 1 : DIN;  // small models: the unrolled form fits and saves the loop overhead
+  constexpr int UF = DIN * DOUT >= 96 ? 2 : DIN;  // small models: fully unrolled; large: two points per trip (two LDS batches in flight)
 #pragma unroll UF
   for (int j = 0; j < DIN; ++j) {
     const R arc = Am[j * LD + r], drc = Dm[j * LD + r];  // junk for r >= DOUT: those lanes' Sy is never used
@@ -379,7 +396,7 @@ I2C_FN bool g_kalman(const Grp<R, G>& g, R* mu, R* S, R* q, R* Sz, R* Sxz, R* mu
   g_gather<DX>(g, 0, own, mu);  // its syncs also publish V
   // S_r -= V_r V^T as a ROLLED loop over the observation index: column k of V per step, the lane's own V_r[k] read back
   // from LDS, so that no register array is indexed by the loop variable
-  constexpr int UF = DX * DZ >= 96 ? 1 : DZ;
+  constexpr int UF = DX * DZ >= 96 ? 2 : DZ;
 #pragma unroll UF
   for (int k = 0; k < DZ; ++k) {
     const R vk = Vm[r * LD + k];
@@ -525,6 +542,30 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
 #pragma unroll
   for (int j = 0; j < NX; ++j) sx[j] = a.sig_x0[(long)symidx(rx, trx, j) * B + b];
 
+  // The prior rows of a cell do not depend on the recursion: they are fetched ONE CELL AHEAD (all global loads of a cell in
+  // one batch, issued right after the previous cell has consumed its own), so that the memory round trip is covered by a
+  // cell's worth of work instead of being exposed at the top of every cell -- where the registers allow: for d = 16 the
+  // 29 doubles in flight push both sweeps into scratch and cost more than the round trip (measured: forward 1.45 -> 1.50 ms,
+  // backward 0.62 -> 0.76 ms at B = 4096), so there the batch is loaded at the top of its own cell.
+  constexpr bool PREFETCH = D <= 8;
+  R nx_pmu_own, nx_prow[D], nx_Krow[NX], nx_alpha;
+  unsigned nx_ff;
+  auto fetch_prior = [&](const int tc, const unsigned rbx, const int rdx, const int trdx, const int rux) {
+    const int trc = c.row(tc);  // row of the persistent buffers (ring, see Consts::t0)
+    const GIO<R> pri = gio(a.prior + (unsigned long)trc * C::E_POST * B, C::E_POST, rbx, bo);
+    nx_pmu_own = pri.ld(rdx);
+#pragma unroll
+    for (int j = 0; j < D; ++j) nx_prow[j] = pri.ld(D + symidx(rdx, trdx, j));
+#pragma unroll
+    for (int k = 0; k < NX; ++k) nx_Krow[k] = pri.ld(O_K + rux * NX + k);
+    nx_alpha = a.alpha_cell ? a.alpha_cell[(long)trc * B + b] : alpha_traj;
+    nx_ff = a.ff[trc];
+  };
+  if (PREFETCH) {
+    const int r0 = g.r, rd0 = r0 < D ? r0 : D - 1;
+    fetch_prior(0, rb0, rd0, rd0 * (rd0 + 1) / 2, (r0 >= NX && r0 < D) ? r0 - NX : 0);
+  }
+
   for (int t = 0; t < T; ++t) {
     // Nothing that depends on the rank or on the row stride may be hoisted out of the time loop (the byte offsets of ~100
     // rows and the batch constants of "my" row would be pinned in registers for the whole sweep): the cell works on an
@@ -538,23 +579,22 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
     const bool is_u = r >= NX && r < D;
     const int ru = is_u ? r - NX : 0;
 
-    const int tr = c.row(t);  // row of the persistent buffers (ring, see Consts::t0)
-    const GIO<R> pri = gio(a.prior + (unsigned long)tr * C::E_POST * B, C::E_POST, rb, bo);
+    const int tr = c.row(t);
     const GIO<R> out = gio(a.fwd + (unsigned long)t * C::E_FWD * B, C::E_FWD, rb, bo);
-    // every global load of the cell is issued here, together: one memory round trip per cell instead of three
+    if (!PREFETCH) fetch_prior(t, rb, rd, trd, ru);  // nothing is carried across cells then
     R pmu[D], prow[D], Krow[NX];
-    const R pmu_own = pri.ld(rd);
+    const R pmu_own = nx_pmu_own, alpha = nx_alpha;
+    const unsigned ff_cur = nx_ff;
 #pragma unroll
-    for (int j = 0; j < D; ++j) prow[j] = pri.ld(D + symidx(rd, trd, j));
+    for (int j = 0; j < D; ++j) prow[j] = nx_prow[j];
 #pragma unroll
-    for (int k = 0; k < NX; ++k) Krow[k] = pri.ld(O_K + ru * NX + k);
-    const R alpha = a.alpha_cell ? a.alpha_cell[(long)tr * B + b] : alpha_traj;
+    for (int k = 0; k < NX; ++k) Krow[k] = nx_Krow[k];
     g_gather<D>(g, 0, pmu_own, pmu);
     int cell_bad = 0;
 
     // ---- 1. joint prior over (x, u) ---------------------------------------------------
     R mu0[D], s0[D];
-    if (a.ff[tr] != 0) {  // feed-forward: independent action prior (i2c.py:355-360)
+    if (ff_cur != 0) {  // feed-forward: independent action prior (i2c.py:355-360)
 #pragma unroll
       for (int i = 0; i < D; ++i) mu0[i] = i < NX ? mu_x[i] : pmu[i];
 #pragma unroll
@@ -576,6 +616,7 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
       for (int k = 0; k < NX; ++k) Krow[k] *= rho;
       g_joint<NX, NU>(g, mu_x, sx, Krow, prow, pmu, pmu + NX, true, false, true, mu0, s0);
     }
+    if (PREFETCH) fetch_prior(t + 1 < T ? t + 1 : t, rb, rd, trd, ru);  // this cell's rows are consumed: the next cell's, a cell ahead
     if (a.prior_out) {
       const GIO<R> po = gio(a.prior_out + (unsigned long)t * (D + sym(D)) * B, D + sym(D), rb, bo);
       if (r < D) po.st(r, g_sel<D>(mu0, r));
@@ -723,6 +764,21 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
   if (r == 0) a.term_stats[b] = trT;
 
   R sum_m = R(0), sum_v = R(0);
+  // the forward rows of a cell are fetched one cell ahead where the registers allow (see forward_group_body)
+  constexpr bool PREFETCH = D <= 8;
+  R nx_mu1_own, nx_m3f_own, nx_S[D], nx_s3f[NX], nx_Jr[NX];
+  auto fetch_fwd = [&](const int tc, const unsigned rbx, const int rdx, const int trdx, const int rxx, const int trxx) {
+    const GIO<R> fw = gio(a.fwd + (unsigned long)tc * C::E_FWD * B, C::E_FWD, rbx, bo);
+    nx_mu1_own = fw.ld(rdx);
+    nx_m3f_own = fw.ld(O_MU3 + rxx);
+#pragma unroll
+    for (int j = 0; j < D; ++j) nx_S[j] = fw.ld(D + symidx(rdx, trdx, j));
+#pragma unroll
+    for (int j = 0; j < NX; ++j) nx_s3f[j] = fw.ld(O_S3 + symidx(rxx, trxx, j));
+#pragma unroll
+    for (int l = 0; l < NX; ++l) nx_Jr[l] = fw.ld(O_J + rdx * NX + l);
+  };
+  if (PREFETCH) fetch_fwd(T - 1, rb0, rd, trd, rx, trx);
   for (int t = T - 1; t >= 0; --t) {
     // Nothing that depends on the rank or on the row stride may be hoisted out of the time loop (the byte offsets of ~100
     // rows and the batch constants of "my" row would be pinned in registers for the whole sweep): the cell works on an
@@ -736,17 +792,17 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
     const bool is_x = r < NX, is_u = r >= NX && r < D;
     const int ru = is_u ? r - NX : 0;
 
-    const GIO<R> fw = gio(a.fwd + (unsigned long)t * C::E_FWD * B, C::E_FWD, rb, bo);
     const GIO<R> po = gio(a.post + (unsigned long)c.row(t) * C::E_POST * B, C::E_POST, rb, bo);
+    if (!PREFETCH) fetch_fwd(t, rb, rd, trd, rx, trx);  // nothing is carried across cells then
     R mu[D], S[D], m3f[NX], s3f[NX], Jr[NX];
-    const R mu1_own = fw.ld(rd);
-    g_gather<NX>(g, 1, fw.ld(O_MU3 + rx), m3f);
+    const R mu1_own = nx_mu1_own;
+    g_gather<NX>(g, 1, nx_m3f_own, m3f);
 #pragma unroll
-    for (int j = 0; j < D; ++j) S[j] = fw.ld(D + symidx(rd, trd, j));
+    for (int j = 0; j < D; ++j) S[j] = nx_S[j];
 #pragma unroll
-    for (int j = 0; j < NX; ++j) s3f[j] = fw.ld(O_S3 + symidx(rx, trx, j));
+    for (int j = 0; j < NX; ++j) s3f[j] = nx_s3f[j];
 #pragma unroll
-    for (int l = 0; l < NX; ++l) Jr[l] = fw.ld(O_J + rd * NX + l);
+    for (int l = 0; l < NX; ++l) Jr[l] = nx_Jr[l];
     if (a.xm) {
       R* xo = const_cast<R*>(a.xm) + ((long)t * C::E_XM) * B + b;
       if (is_x) xo[(long)r * B] = g_sel<NX>(m3m, r);
@@ -777,7 +833,7 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
       R JD[NX];
 #pragma unroll
       for (int k = 0; k < NX; ++k) JD[k] = R(0);
-      constexpr int UF = D * NX >= 96 ? 1 : NX;
+      constexpr int UF = D * NX >= 96 ? 2 : NX;
 #pragma unroll UF
       for (int l = 0; l < NX; ++l) {
         const R jl = Jm[r * LD + l];
@@ -796,6 +852,7 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
         for (int j = 0; j < D; ++j) S[j] += jd * Jm[j * LD + k];
       }
     }
+    if (PREFETCH) fetch_fwd(t > 0 ? t - 1 : 0, rb, rd, trd, rx, trx);  // this cell's forward rows are consumed: the next cell's, a cell ahead
     R Lm[D], rinv[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) Lm[j] = S[j];
