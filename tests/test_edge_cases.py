@@ -183,3 +183,81 @@ def test_failure_isolation_other_inference_cpu(golden):
 @pytest.mark.parametrize("golden", ["lin_pendulum_T100", "gh3_pendulum_T40"])
 def test_failure_isolation_other_inference_gpu(golden):
     _check_failure_isolation(None, "cuda", golden)
+
+
+# ---- the same edge cases on the GROUP kernels (G lanes of a wavefront per trajectory) --------------------------------------
+def _short_quad12(T):
+    import json
+
+    g = load_case("em_quad12_T20")
+    return Case({**g, "meta": np.array(json.dumps(dict(g.meta, T=T))), "mu_u": g["mu_u"][:T]})
+
+
+def _check_group(lib, device, case, B, **kw):
+    x0, mu_u = parity.batched_inputs(case, B)
+    eng = parity.engine_from_case(case, lib, device, x0=x0, mu_u=mu_u, **kw)
+    assert eng.uses_group_kernels
+    o = oracle_from_case(Case({**case, "mu_u": mu_u}), x0=x0)
+    for it in range(3):
+        eng.learn_msgs()
+        o.learn_msgs()
+        mu, sig = eng.marginal_state_action()
+        assert_close(parity.np_(mu), o.mu_xu0_m, 1e-8, f"group B={B} it{it} mu")
+        assert_close(parity.np_(sig), o.sig_xu0_m, 1e-8, f"group B={B} it{it} sig")
+        assert_close(parity.np_(eng.alpha), o.alpha, 1e-8, f"group B={B} it{it} alpha")
+        assert_close(parity.np_(eng.costs_m[-1]), o.costs_m[-1], 1e-8, f"group B={B} it{it} cost")
+        assert_close(parity.np_(eng.costs_m_var[-1]), o.costs_m_var[-1], 1e-8, f"group B={B} it{it} cost variance")
+    assert eng.failures() == []
+
+
+@pytest.mark.parametrize("T,B", [(1, 1), (2, 3), (3, 5)])
+def test_group_kernels_short_horizons_cpu(T, B):
+    """Horizons of 1-3 cells (first cell = last cell, terminal update on the first cell) and batches that leave most of a
+    wavefront's groups empty, 12-state quadrotor (16 lanes per trajectory)."""
+    _check_group(hostsim.load(), "cpu", _short_quad12(T), B)
+
+
+def test_group_kernels_short_horizon_pendulum_cpu():
+    _check_group(hostsim.load(), "cpu", _short_case(2), 17, group_lanes=True)  # G = 4: 16 trajectories per wave + 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B", [(1, 1), (2, 3), (3, 5), (4, 67)])
+def test_group_kernels_short_horizons_gpu(T, B):
+    _check_group(None, "cuda", _short_quad12(T), B)
+
+
+@pytest.mark.gpu
+def test_group_kernels_short_horizon_pendulum_gpu():
+    _check_group(None, "cuda", _short_case(2), 1000, group_lanes=True)
+
+
+def _group_failure_isolation(lib, device):
+    """A covariance that is not positive definite in ONE trajectory: its status word names the first failing stage and
+    cell, its values go NaN, and the other trajectories of the same wavefront are bit-for-bit what they are without it."""
+    g = _short_quad12(6)
+    B = 6
+    x0, mu_u = parity.batched_inputs(g, B)
+    clean = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u)
+    bad = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u)
+    bad.sig_x0[0, 2] = -1.0  # sig_x0[0][0] of trajectory 2 (packed index 0): negative variance
+    for e in (clean, bad):
+        for _ in range(2):
+            e.learn_msgs()
+    f = bad.failures()
+    assert [b for b, _, _ in f] == [2] and f[0][2] == 0, f  # trajectory 2, first cell
+    keep = [0, 1, 3, 4, 5]
+    assert torch.equal(bad.post[:, :, keep], clean.post[:, :, keep])
+    assert torch.equal(bad.alpha[keep], clean.alpha[keep])
+    assert not torch.isfinite(bad.post[:, :, 2]).all()
+    with pytest.raises(np.linalg.LinAlgError):
+        bad.raise_on_failure()
+
+
+def test_group_kernels_failure_isolation_cpu():
+    _group_failure_isolation(hostsim.load(), "cpu")
+
+
+@pytest.mark.gpu
+def test_group_kernels_failure_isolation_gpu():
+    _group_failure_isolation(None, "cuda")
