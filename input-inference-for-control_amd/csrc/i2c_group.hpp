@@ -438,6 +438,16 @@ template <typename R> struct GIO {
   unsigned rb, bo;
   I2C_MEM R ld(const int e) const { return wld<R>(w, 0u, (unsigned)e * rb + bo); }
   I2C_MEM void st(const int e, const R v) const { wst(w, 0u, (unsigned)e * rb + bo, v); }
+  // Predicated store without touching EXEC: on the device a lane that must not store gets an offset beyond the window, and
+  // the buffer unit drops out-of-range stores (raw buffer, range-checked against num_records); one select instead of a
+  // compare + s_and_saveexec + s_or per store -- the packed-symmetric rows have ~60 such stores per cell.
+  I2C_MEM void st_if(const bool on, const int e, const R v) const {
+#ifdef I2C_HOST_SIM
+    if (on) wst(w, 0u, (unsigned)e * rb + bo, v);
+#else
+    wst(w, 0u, on ? (unsigned)e * rb + bo : 0x80000000u, v);
+#endif
+  }
 };
 template <typename R> I2C_FN GIO<R> gio(const R* base, const unsigned long elems, const unsigned rb, const unsigned bo) {
   return GIO<R>{make_window(base, elems * rb), rb, bo};
@@ -494,21 +504,27 @@ I2C_FN void g_joint(const Grp<R, G>& g, const R* mu_x, const R* sx, const R* Kro
     }
   }
   g.sync();
-  R su[D];
+  // The nu x nu action block: lane r < nu^2 forms entry (r / nu, r % nu) -- one entry per lane instead of every lane walking
+  // all of them (only the nu action lanes need the result; the walk was 14 % of the d = 16 forward cell's instructions).
+  static_assert(NU * NU <= G, "one action-block entry per lane");
+  {
+    const int ea = r < NU * NU ? r / NU : 0, ec = r < NU * NU ? r % NU : 0;
+    const int p = ea > ec ? ea : ec, q = ea > ec ? ec : ea;
+    R v = R(0);
 #pragma unroll
-  for (int j = 0; j < NX; ++j) su[j] = XC[j * LD + ru];
-#pragma unroll
-  for (int c = 0; c < NU; ++c) {
-    const int p = ru > c ? ru : c, q = ru > c ? c : ru;
-    R v = prow[NX + c];
-#pragma unroll (NX >= 8 ? 1 : NX)
-    for (int k = 0; k < NX; ++k) {  // rolled for the large models: nothing but LDS is indexed by k
+    for (int k = 0; k < NX; ++k) {
       const R ktq = Km[q * LD + k];
       if (sub_ux) v -= Km[p * LD + k] * Pm[q * LD + k];
       if (add_quad) v += XC[k * LD + NU + p] * ktq;
     }
-    su[NX + c] = v;
+    g.vec(3)[r] = v;  // slot 3 is not used by the gathers / sums around this call
   }
+  g.sync();
+  R su[D];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) su[j] = XC[j * LD + ru];
+#pragma unroll
+  for (int c = 0; c < NU; ++c) su[NX + c] = prow[NX + c] + g.vec(3)[ru * NU + c];
 #pragma unroll
   for (int j = 0; j < D; ++j) s0[j] = is_x ? (j < NX ? sx[j] : cr[j < NX ? 0 : j - NX]) : su[j];
 }
@@ -619,10 +635,10 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
     if (PREFETCH) fetch_prior(t + 1 < T ? t + 1 : t, rb, rd, trd, ru);  // this cell's rows are consumed: the next cell's, a cell ahead
     if (a.prior_out) {
       const GIO<R> po = gio(a.prior_out + (unsigned long)t * (D + sym(D)) * B, D + sym(D), rb, bo);
-      if (r < D) po.st(r, g_sel<D>(mu0, r));
+      po.st_if(r < D, r, g_sel<D>(mu0, r));
 #pragma unroll
       for (int j = 0; j < D; ++j)
-        if (r < D && j <= opaque_i(r)) po.st(D + trd + j, s0[j]);
+        po.st_if(r < D && j <= opaque_i(r), D + trd + j, s0[j]);
     }
 
     // ---- 2. cost "observation": measurement update on z (i2c.py:390-407) --------------
@@ -650,10 +666,10 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
       cell_bad = flag_stage(cell_bad, g_kalman<D, NZ>(g, mu0, s0, mz, szr, sxz, &mu1_own), 2);
     }
     // mu0 / s0 now hold mu_xu1_f / row r of sig_xu1_f
-    if (r < D) out.st(r, mu1_own);
+    out.st_if(r < D, r, mu1_own);
 #pragma unroll
     for (int j = 0; j < D; ++j)
-      if (r < D && j <= opaque_i(r)) out.st(D + trd + j, s0[j]);
+      out.st_if(r < D && j <= opaque_i(r), D + trd + j, s0[j]);
 
     // ---- 3. dynamics push-through (i2c.py:415-421) and smoother gain (i2c.py:423-425) --
     R L3[NX], rinv3[NX];
@@ -673,7 +689,7 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
       g_bsub<NX>(g, 0, rinv3, sxy);
 #pragma unroll
       for (int l = 0; l < NX; ++l)
-        if (r < D) out.st(O_J + rd * NX + l, sxy[l]);
+        out.st_if(r < D, O_J + rd * NX + l, sxy[l]);
     }
 
     // ---- 4. terminal cost observation on the flagged cell, after J (i2c.py:430-443) ----
@@ -696,10 +712,10 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
       cell_bad = flag_stage(cell_bad, g_kalman<NX, NT>(g, mu_x, sx, mzt, sztr, sxzt, &own), 5);
     }
     fail = fold_cell_failure(fail, cell_bad, t);
-    if (r < NX) out.st(O_MU3 + r, g_sel<NX>(mu_x, r));
+    out.st_if(r < NX, O_MU3 + r, g_sel<NX>(mu_x, r));
 #pragma unroll
     for (int j = 0; j < NX; ++j)
-      if (r < NX && j <= opaque_i(r)) out.st(O_S3 + trx + j, sx[j]);
+      out.st_if(r < NX && j <= opaque_i(r), O_S3 + trx + j, sx[j]);
   }
   if (r == 0 && fail != 0 && a.status[b] == 0) a.status[b] = fail;
 }
@@ -889,10 +905,10 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
     sum_m += cm;
     sum_v += cv;
 
-    if (r < D) po.st(r, mu_own);
+    po.st_if(r < D, r, mu_own);
 #pragma unroll
     for (int j = 0; j < D; ++j)
-      if (r < D && j <= opaque_i(r)) po.st(D + trd + j, S[j]);
+      po.st_if(r < D && j <= opaque_i(r), D + trd + j, S[j]);
     if (is_u) {
       R kk = mu_own;
 #pragma unroll
@@ -903,7 +919,7 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
       po.st(O_k + ru, kk);
 #pragma unroll
       for (int q = 0; q < NU; ++q)
-        if (q <= opaque_i(ru)) po.st(O_SK + ru * (ru + 1) / 2 + q, sigK[q]);
+        po.st_if(q <= opaque_i(ru), O_SK + ru * (ru + 1) / 2 + q, sigK[q]);
     }
     if (a.zpost) {
       R* zo = a.zpost + ((long)t * C::E_ZPOST) * B + b;
@@ -998,10 +1014,10 @@ I2C_HD inline void propagate_group_body(const Consts<M, R>& c, const KC& kc, con
 #pragma unroll
     for (int i = 0; i < NX; ++i) qx[i] = ff ? mu_x[i] : qmu[i];
     g_joint<NX, NU>(g, mu_x, sx, Krow, prow, qx, qmu + NX, false, !ff, !ff, mu0, s0);
-    if (r < D) out.st(r, g_sel<D>(mu0, r));
+    out.st_if(r < D, r, g_sel<D>(mu0, r));
 #pragma unroll
     for (int j = 0; j < D; ++j)
-      if (r < D && j <= opaque_i(r)) out.st(D + trd + j, s0[j]);
+      out.st_if(r < D && j <= opaque_i(r), D + trd + j, s0[j]);
 
     R L0[D], rinv0[D];
 #pragma unroll
@@ -1027,10 +1043,10 @@ I2C_HD inline void propagate_group_body(const Consts<M, R>& c, const KC& kc, con
     g_transform<M, DenseStruct<D>, D, NX, false>(g, 0, 1, 2, c.rule_xu, mu0, L0, DynamicsF<M, R>{c.params}, mu_x, sx, (R*)nullptr);
 #pragma unroll
     for (int l = 0; l < NX; ++l) sx[l] += c.rule_xu.W * kc.sig_eta[rx * NX + l];
-    if (r < NX) out.st(O_X3 + r, g_sel<NX>(mu_x, r));
+    out.st_if(r < NX, O_X3 + r, g_sel<NX>(mu_x, r));
 #pragma unroll
     for (int j = 0; j < NX; ++j)
-      if (r < NX && j <= opaque_i(r)) out.st(O_SX3 + trx + j, sx[j]);
+      out.st_if(r < NX && j <= opaque_i(r), O_SX3 + trx + j, sx[j]);
   }
   if (r == 0) {
     a.prop_stats[b] = sum_m;
