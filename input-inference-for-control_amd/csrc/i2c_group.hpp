@@ -190,7 +190,10 @@ template <int N, typename R, int G> I2C_FN bool g_chol(const Grp<R, G>& g, const
       const R l1 = (row[k + 1] - c0[k + 1] * t0) * r1;      // L[r][k+1]
       const R t1 = l1 * r1;
 #pragma unroll
-      for (int j = k + 2; j < N; ++j) row[j] -= t0 * c0[j] + t1 * c1[j];
+      for (int j = k + 2; j < N; ++j) {  // two fused multiply-adds (written as one expression it is mul + fma + add)
+        row[j] -= t0 * c0[j];
+        row[j] -= t1 * c1[j];
+      }
       row[k] = l0;
       row[k + 1] = l1;
     }
@@ -437,6 +440,7 @@ template <typename R> struct GIO {
   Window w;
   unsigned rb, bo;
   I2C_MEM R ld(const int e) const { return wld<R>(w, 0u, (unsigned)e * rb + bo); }
+  I2C_MEM R ldo(const unsigned byte_off) const { return wld<R>(w, 0u, byte_off); }  // offset precomputed by the caller
   I2C_MEM void st(const int e, const R v) const { wst(w, 0u, (unsigned)e * rb + bo, v); }
   // Predicated store without touching EXEC: on the device a lane that must not store gets an offset beyond the window, and
   // the buffer unit drops out-of-range stores (raw buffer, range-checked against num_records); one select instead of a
@@ -566,14 +570,25 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
   constexpr bool PREFETCH = D <= 8;
   R nx_pmu_own, nx_prow[D], nx_Krow[NX], nx_alpha;
   unsigned nx_ff;
-  auto fetch_prior = [&](const int tc, const unsigned rbx, const int rdx, const int trdx, const int rux) {
+  // byte offsets of this lane's prior rows inside a cell: the one piece of rank-dependent state that IS kept across the
+  // time loop (29 dwords; recomputing them costs ~5 instructions per load in every cell)
+  unsigned o_pmu, o_prow[D], o_K[NX];
+  {
+    const int r0 = g.r, rd0 = r0 < D ? r0 : D - 1, trd0 = rd0 * (rd0 + 1) / 2, ru0 = (r0 >= NX && r0 < D) ? r0 - NX : 0;
+    o_pmu = (unsigned)rd0 * rb0 + bo;
+#pragma unroll
+    for (int j = 0; j < D; ++j) o_prow[j] = (unsigned)(D + symidx(rd0, trd0, j)) * rb0 + bo;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) o_K[k] = (unsigned)(O_K + ru0 * NX + k) * rb0 + bo;
+  }
+  auto fetch_prior = [&](const int tc, const unsigned rbx, const int, const int, const int) {
     const int trc = c.row(tc);  // row of the persistent buffers (ring, see Consts::t0)
     const GIO<R> pri = gio(a.prior + (unsigned long)trc * C::E_POST * B, C::E_POST, rbx, bo);
-    nx_pmu_own = pri.ld(rdx);
+    nx_pmu_own = pri.ldo(o_pmu);
 #pragma unroll
-    for (int j = 0; j < D; ++j) nx_prow[j] = pri.ld(D + symidx(rdx, trdx, j));
+    for (int j = 0; j < D; ++j) nx_prow[j] = pri.ldo(o_prow[j]);
 #pragma unroll
-    for (int k = 0; k < NX; ++k) nx_Krow[k] = pri.ld(O_K + rux * NX + k);
+    for (int k = 0; k < NX; ++k) nx_Krow[k] = pri.ldo(o_K[k]);
     nx_alpha = a.alpha_cell ? a.alpha_cell[(long)trc * B + b] : alpha_traj;
     nx_ff = a.ff[trc];
   };
@@ -783,16 +798,26 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
   // the forward rows of a cell are fetched one cell ahead where the registers allow (see forward_group_body)
   constexpr bool PREFETCH = D <= 8;
   R nx_mu1_own, nx_m3f_own, nx_S[D], nx_s3f[NX], nx_Jr[NX];
-  auto fetch_fwd = [&](const int tc, const unsigned rbx, const int rdx, const int trdx, const int rxx, const int trxx) {
+  // byte offsets of this lane's forward rows inside a cell, kept across the time loop (see forward_group_body)
+  unsigned o_mu1, o_m3f, o_S[D], o_s3f[NX], o_J[NX];
+  o_mu1 = (unsigned)rd * rb0 + bo;
+  o_m3f = (unsigned)(O_MU3 + rx) * rb0 + bo;
+#pragma unroll
+  for (int j = 0; j < D; ++j) o_S[j] = (unsigned)(D + symidx(rd, trd, j)) * rb0 + bo;
+#pragma unroll
+  for (int j = 0; j < NX; ++j) o_s3f[j] = (unsigned)(O_S3 + symidx(rx, trx, j)) * rb0 + bo;
+#pragma unroll
+  for (int l = 0; l < NX; ++l) o_J[l] = (unsigned)(O_J + rd * NX + l) * rb0 + bo;
+  auto fetch_fwd = [&](const int tc, const unsigned rbx, const int, const int, const int, const int) {
     const GIO<R> fw = gio(a.fwd + (unsigned long)tc * C::E_FWD * B, C::E_FWD, rbx, bo);
-    nx_mu1_own = fw.ld(rdx);
-    nx_m3f_own = fw.ld(O_MU3 + rxx);
+    nx_mu1_own = fw.ldo(o_mu1);
+    nx_m3f_own = fw.ldo(o_m3f);
 #pragma unroll
-    for (int j = 0; j < D; ++j) nx_S[j] = fw.ld(D + symidx(rdx, trdx, j));
+    for (int j = 0; j < D; ++j) nx_S[j] = fw.ldo(o_S[j]);
 #pragma unroll
-    for (int j = 0; j < NX; ++j) nx_s3f[j] = fw.ld(O_S3 + symidx(rxx, trxx, j));
+    for (int j = 0; j < NX; ++j) nx_s3f[j] = fw.ldo(o_s3f[j]);
 #pragma unroll
-    for (int l = 0; l < NX; ++l) nx_Jr[l] = fw.ld(O_J + rdx * NX + l);
+    for (int l = 0; l < NX; ++l) nx_Jr[l] = fw.ldo(o_J[l]);
   };
   if (PREFETCH) fetch_fwd(T - 1, rb0, rd, trd, rx, trx);
   for (int t = T - 1; t >= 0; --t) {
