@@ -101,3 +101,63 @@ def test_config4_quadrotor_mpc_H50_B8192():
         u = np.clip(uB, 0.0, 30.0)
         y = model.measure(model.dynamics(np.hstack((pB.mu, u))))
     assert iB.engine.failures() == []
+
+
+def test_config4_quadrotor12_sweeps_H50_B8192_vs_oracle():
+    """BASELINE config 4 at nx = 12 (d = 16, group kernels): the EM sweeps at horizon 50 and 8192 trajectories, a subset
+    compared with the CPU oracle (the oracle is pinned to the reference solver on this model by em_quad12_T20 /
+    em_quad12_T12_propagate), planted duplicates bit-identical, and closed-loop propagation on the whole batch."""
+    g = load_case("em_quad12_T20")
+    T = 50
+    rng = np.random.default_rng(5)
+    mu_u = np.tile(g["mu_u"][:1], (T, 1)) + 1e-2 * rng.normal(size=(T, 4))
+    big = Case({**g, "meta": np.array(json.dumps(dict(g.meta, T=T))), "mu_u": mu_u})
+    eng = _subset_vs_oracle(big, 8192, 6, 3, 1e-6, plant=(4097, 8191))
+    assert eng.uses_group_kernels and eng.post.shape == (50, 214, 8192)
+    eng._propagate = True
+    eng.propagate()
+    assert eng.failures() == [] and torch.isfinite(eng.prop).all()
+    assert torch.equal(eng.prop[:, :, 0], eng.prop[:, :, 8191])
+
+
+def test_config4_quadrotor12_mpc_H50_B8192():
+    """... and the closed MPC loop with the cubature-KF state estimator on it: horizon 50, 8192 loops at once (one
+    i2c_mpc_step per control step: filter, sweeps, first action, ring shift), lane 0 against a single loop."""
+    from i2c.exp_types import CubatureQuadrature
+    from i2c.i2c import I2cGraph
+    from i2c.policy.mpc import PartiallyObservedMpcPolicy
+
+    g = load_case("mpc_quad12_fb")
+    H, B, steps = 50, 8192, 3
+    rng = np.random.default_rng(1)
+    model = parity.product_model(g)
+    model.sig_zeta = g["sig_zeta"]
+    mu_u = np.tile(g["mu_u"][:1], (H, 1))
+    z_traj = np.tile(g["z_traj"][:1], (H + steps + 1, 1))
+    z_traj[:, 0] += np.linspace(0, 0.5, H + steps + 1)
+    x0 = np.tile(g["x0"], (B, 1)) + 1e-3 * rng.normal(size=(B, 12))
+    x0[[4000, 8191]] = x0[0]
+
+    def make(batch, x0_):
+        i2c = I2cGraph(model, H, g["Q"], g["R"], g["Qf"], 1.0, 1.0, mu_u, g["sig_u"], None, None, CubatureQuadrature(1, 0, 0),
+                       batch=batch, x0=x0_, device="cuda")
+        i2c._propagate = True
+        pol = PartiallyObservedMpcPolicy(i2c, 2, g["sig_u"], np.copy(z_traj))
+        pol.set_control(feedforward=False)
+        i2c.calibrate_alpha()
+        pol.optimize(4)
+        return i2c, pol
+
+    iB, pB = make(B, x0)
+    i1, p1 = make(1, x0[:1])
+    y = model.measure(x0)
+    u = np.tile(0.25 * model.gravity, (B, 4))
+    for t in range(steps):
+        uB = pB(t, y, u)
+        u1 = p1(t, y[:1], u[:1])
+        assert uB.shape == (B, 4) and np.all(np.isfinite(uB))
+        assert_close(uB[0], u1[:, 0], 1e-9, f"lane 0 of the batch vs the single loop, step {t}")
+        assert np.array_equal(uB[0], uB[4000]) and np.array_equal(uB[0], uB[8191])
+        u = np.clip(uB, 0.0, model.force_mx)
+        y = model.measure(model.dynamics(np.hstack((pB.mu, u))))
+    assert iB.engine.failures() == [] and iB.engine.t0 == steps % H
