@@ -411,8 +411,14 @@ template <class M, typename R, typename S = R> struct Impl {
                          void* stream) {
     FwdArgs<R> a{(const R*)prior, (R*)fwd, (R*)prior_out, (const R*)p->x0, (const R*)p->sig_x0,
                  (const R*)p->z,  (const R*)p->alpha, (const R*)p->alpha_cell, p->feedforward, status, p->expert};
-    const int grp = use_group(p);
+    int grp = use_group(p);
     if (grp < 0) return grp;
+    // Hybrid default (measured, planar quadrotor d = 8 at B = 4096: forward 0.51 -> 0.40 ms, while its chunked lane backward
+    // stays the faster one): with no explicit request the FORWARD sweep of such a model runs on the group kernels as long
+    // as the batch leaves every group wave a SIMD of its own; the buffers are the same, so the backward schedules are unaffected
+    if constexpr (HAS_GROUP && M::GROUP_FORWARD_AUTO) {
+      if (grp == 0 && p->group_lanes == 0 && (long)p->B * G <= 64L * 1024 && group_supported(p, c) == I2C_OK) grp = 1;
+    }
     if (grp) {
       if constexpr (HAS_GROUP) {
         const int rc = group_supported(p, c);
