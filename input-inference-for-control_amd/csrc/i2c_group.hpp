@@ -80,7 +80,7 @@ template <typename R, int G> struct Grp {
 // Batch-wide constants a lane needs by ROW (runtime row index): unpacked, in LDS, filled once per workgroup.
 template <class M, typename R> struct GConst {
   static constexpr int NX = M::NX, NZ = M::NZ, NT = M::NZT > 0 ? M::NZT : 1, NY = M::NY;
-  R sig_xi0[NZ * NZ], sig_eta[NX * NX], sig_xiT0[NT * NT], sig_zeta[NY * NY];
+  R sig_xi0[NZ * NZ], sig_eta[NX * NX], sig_xiT0[NT * NT], sig_zeta[NY * NY], sig_x_term[NX * NX];
   R qr_d[NZ], qf_d[NT];
 };
 // `c` and `zeta` must be addressable memory (the host's structs; on the device the kernel-argument segment itself, see
@@ -92,6 +92,7 @@ I2C_FN void gconst_fill(DST& k, const Consts<M, R>* c, const R* zeta, const int 
   for (int e = tid; e < NX * NX; e += nthreads) k.sig_eta[e] = c->sig_eta[tri_any(e / NX, e % NX)];
   for (int e = tid; e < NT * NT; e += nthreads) k.sig_xiT0[e] = c->sig_xiT0[tri_any(e / NT, e % NT)];
   for (int e = tid; e < NY * NY; e += nthreads) k.sig_zeta[e] = zeta ? zeta[tri_any(e / NY, e % NY)] : R(0);
+  for (int e = tid; e < NX * NX; e += nthreads) k.sig_x_term[e] = c->sig_x_term[tri_any(e / NX, e % NX)];
   for (int e = tid; e < NZ; e += nthreads) k.qr_d[e] = c->QR[tri(e, e)];
   for (int e = tid; e < NT; e += nthreads) k.qf_d[e] = c->Qf[tri(e, e)];
 }
@@ -533,6 +534,93 @@ I2C_FN void g_joint(const Grp<R, G>& g, const R* mu_x, const R* sx, const R* Kro
   for (int j = 0; j < D; ++j) s0[j] = is_x ? (j < NX ? sx[j] : cr[j < NX ? 0 : j - NX]) : su[j];
 }
 
+// End of the chain with a terminal state prior (covariance control, i2c.py:548-559), rows distributed: the filtered terminal
+// state (m3f replicated, s3f = row r of sig_x3_f) is multiplied with the tempered prior N(mu_T, sig_T):
+//   St = temp sig_x3_f;  sig_x3_m = St - St (sig_T + St)^-1 St = St - W^T W, W = chol(sig_T + St)^-1 St;
+//   mu_x3_m = sig_x3_m (St^-1 mu_x3_f + sig_T^-1 mu_T).
+// In place: m3f / s3f become mu_x3_m / row r of sig_x3_m. Returns false if a factorisation fails. Uses LDS matrices 0, 1.
+template <class M, typename R, int G, class KC>
+I2C_FN bool g_end_of_chain(const Grp<R, G>& g, const Consts<M, R>& c, const KC& kc, const R tmp, R* m3, R* s3) {
+  constexpr int NX = M::NX, LD = Grp<R, G>::LD;
+  const int r = g.r, rx = r < NX ? r : NX - 1;
+  R St[NX], Ss[NX], sT[NX], rinv[NX];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    St[j] = tmp * s3[j];
+    sT[j] = kc.sig_x_term[rx * NX + j];
+    Ss[j] = sT[j] + St[j];
+  }
+  bool ok = g_chol<NX>(g, 0, Ss, rinv);
+  R w[NX];  // column r of W = C^-1 St (St is symmetric: its column r is this lane's row)
+#pragma unroll
+  for (int j = 0; j < NX; ++j) w[j] = St[j];
+  g_fsub<NX, 1>(g, 0, rinv, w, (R*)nullptr);
+  const auto Wm = g.mat(1);
+  g.sync();
+#pragma unroll
+  for (int k = 0; k < NX; ++k) Wm[r * LD + k] = w[k];
+  g.sync();
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    R v = St[j];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) v -= w[k] * Wm[j * LD + k];
+    s3[j] = v;
+  }
+  // rhs = St^-1 mu_x3_f + sig_T^-1 mu_T, every lane for itself (replicated vectors) against the two factors in LDS
+  R r1[NX], r2[NX], Lt[NX];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    Lt[j] = St[j];
+    r1[j] = m3[j];
+    r2[j] = c.mu_x_term[j];
+  }
+  ok = g_chol<NX>(g, 0, Lt, rinv) && ok;
+  g_fsub<NX, 1>(g, 0, rinv, r1, (R*)nullptr);
+  g_bsub<NX>(g, 0, rinv, r1);
+  ok = g_chol<NX>(g, 0, sT, rinv) && ok;
+  g_fsub<NX, 1>(g, 0, rinv, r2, (R*)nullptr);
+  g_bsub<NX>(g, 0, rinv, r2);
+  R own = R(0);
+#pragma unroll
+  for (int j = 0; j < NX; ++j) own += s3[j] * (r1[j] + r2[j]);
+  g_gather<NX>(g, 0, own, m3);
+  return ok;
+}
+
+// KL(N(mu, sig) || N(mu_T, sig_T)) of covariance control (i2c.py:1012-1019, mvn_kl_divergence :1223-1229) from the two Cholesky
+// factors, rows distributed (sx = row r of sig): log det ratio = 2 sum log(L2_ii / L1_ii), tr(sig_T^-1 sig) = ||L2^-1 L1||_F^2.
+template <class M, typename R, int G, class KC>
+I2C_FN R g_terminal_kl(const Grp<R, G>& g, const Consts<M, R>& c, const KC& kc, const R* mu, const R* sx, bool* ok) {
+  constexpr int NX = M::NX, LD = Grp<R, G>::LD;
+  const int r = g.r, rx = r < NX ? r : NX - 1;
+  R L1[NX], L2[NX], r1[NX], r2[NX];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    L1[j] = sx[j];
+    L2[j] = kc.sig_x_term[rx * NX + j];
+  }
+  *ok = g_chol<NX>(g, 0, L1, r1);
+  *ok = g_chol<NX>(g, 1, L2, r2) && *ok;
+  R logdet = R(0), dq[NX], col[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    logdet += r_log(r1[i]) - r_log(r2[i]);  // log(L2_ii) - log(L1_ii) with r = 1 / L_ii
+    dq[i] = c.mu_x_term[i] - mu[i];
+    col[i] = g.mat(0)[i * LD + rx];  // column r of L1 (zeros above the diagonal)
+  }
+  g_fsub<NX, 2>(g, 1, r2, col, dq);
+  R tr = R(0), maha = R(0);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    tr += col[i] * col[i];
+    maha += dq[i] * dq[i];
+  }
+  R trs, d0, d1;
+  g_sum3<NX>(g, r < NX ? tr : R(0), R(0), R(0), &trs, &d0, &d1);
+  return R(0.5) * (R(2) * logdet + trs + maha - R(NX));
+}
+
 // ------------------------------------------------------------------------------------------
 // Forward sweep (i2c.py:876-880 over :350-447): the group walks its trajectory through all T cells.
 // ------------------------------------------------------------------------------------------
@@ -738,7 +826,7 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
 // ------------------------------------------------------------------------------------------
 // Backward sweep (i2c.py:882-886 over :544-610), fused form: the group walks T-1..0 doing the whole cell -- RTS update of
 // the joint, posterior observation moments and their expected cost, controller from the factor of the posterior joint.
-// Terminal state prior (covariance control, i2c.py:548-559) is not available in the group form (the launcher refuses it).
+// With a terminal state prior (covariance control, i2c.py:548-559) the chain starts from its product with the filtered state.
 // ------------------------------------------------------------------------------------------
 template <class M, typename R, int G, class KC>
 I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, const CellArgs<R>& a, const int b,
@@ -767,6 +855,14 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
     g_gather<NX>(g, 0, fw.ld(O_MU3 + rx), m3m);
 #pragma unroll
     for (int j = 0; j < NX; ++j) s3m[j] = fw.ld(O_S3 + symidx(rx, trx, j));
+  }
+  if (c.has_x_terminal) {
+    const R tmp = a.temp[b];
+    const bool ok = g_end_of_chain<M, R, G>(g, c, kc, tmp, m3m, s3m);
+    if (r == 0) {
+      a.temp[b] = tmp + c.dtemp;  // every lane has read it (the gather inside is a group-wide synchronisation)
+      if (!ok) set_status(a.status, b, 6, T - 1);
+    }
   }
   // terminal observation statistics (i2c.py:567-570, 989-992): tr(Qf (errT errT^T + sig_z3_m))
   R trT = R(0);
@@ -1073,10 +1169,16 @@ I2C_HD inline void propagate_group_body(const Consts<M, R>& c, const KC& kc, con
     for (int j = 0; j < NX; ++j)
       out.st_if(r < NX && j <= opaque_i(r), O_SX3 + trx + j, sx[j]);
   }
+  R kl = R(0);
+  if (c.has_x_terminal) {
+    bool ok;
+    kl = g_terminal_kl<M, R, G>(g_in, c, kc, mu_x, sx, &ok);
+    if (!ok && g_in.r == 0) set_status(a.status, b, 8, T - 1);
+  }
   if (r == 0) {
     a.prop_stats[b] = sum_m;
     a.prop_stats[B + b] = sum_v;
-    a.prop_stats[2 * B + b] = R(0);  // KL to the terminal prior: covariance control is not available in the group form
+    a.prop_stats[2 * B + b] = kl;
   }
 }
 

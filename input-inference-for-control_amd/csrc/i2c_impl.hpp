@@ -373,9 +373,9 @@ template <class M, typename R, typename S = R> struct Impl {
     if (p->group_lanes == 0) return M::GROUP_ONLY ? (HAS_GROUP ? 1 : I2C_ENOTSUP) : 0;
     return (HAS_GROUP && p->group_lanes == G) ? 1 : I2C_ENOTSUP;
   }
-  // what the group form does not cover (yet): other inference rules, covariance control, non-diagonal cost weights
+  // what the group form does not cover: other inference rules, non-diagonal cost weights
   static int group_supported(const I2cProblem* p, const C& c) {
-    if (p->inference != I2C_INF_CUBATURE || p->has_x_terminal) return I2C_ENOTSUP;
+    if (p->inference != I2C_INF_CUBATURE) return I2C_ENOTSUP;
     if (!c.qr_diag || (c.has_Qf && !c.qf_diag)) return I2C_ENOTSUP;
     return I2C_OK;
   }

@@ -46,6 +46,7 @@ GROUP_GOLDEN = [
     ("em_linear_T60", 1e-8, 1e-7),
     ("em_pendulum_T50_propagate", 1e-8, 1e-7),
     ("em_quadrotor_T20", 1e-6, 1e-5),              # G = 8
+    ("em_covctrl_T100", 1e-7, 1e-6),               # covariance control: tempered terminal prior, propagation, KL
 ]
 
 

@@ -43,6 +43,7 @@ GROUP_GOLDEN = [
     ("em_linear_T60", 1e-9, 1e-8, None),
     ("em_pendulum_T50_propagate", 1e-9, 1e-8, None),  # propagation with the expert controller
     ("em_quadrotor_T20", 1e-7, 1e-6, None),           # G = 8, identity observation
+    ("em_covctrl_T100", 1e-8, 1e-7, 8),               # covariance control: tempered terminal prior, propagation, KL
 ]
 
 
@@ -57,11 +58,14 @@ def test_hostsim_group_kernels_batch_vs_oracle(lib):
 
 
 def test_group_kernels_refuse_what_they_do_not_cover(lib):
-    """Covariance control (terminal state prior), other inference rules and non-diagonal cost weights are not
-    available in the group form: the library says I2C_ENOTSUP instead of computing something else."""
-    from golden_util import load_case
+    """Non-diagonal cost weights (and the other inference rules) are not available in the group form: the library says
+    I2C_ENOTSUP instead of computing something else."""
+    import numpy as np
+    from golden_util import Case, load_case
 
-    eng = parity.engine_from_case(load_case("em_covctrl_T100"), lib, "cpu", group_lanes=True)
+    g = load_case("em_pendulum_T40_quad_general")
+    dense = Case({**g, "Q": np.array([[2.0, 0.3, -0.1], [0.3, 50.0, 0.4], [-0.1, 0.4, 1.5]])})
+    eng = parity.engine_from_case(dense, lib, "cpu", group_lanes=True)
     with pytest.raises(RuntimeError, match="-2"):
         eng.forward_sweep()
     with pytest.raises(ValueError):
