@@ -178,3 +178,27 @@ def test_use_expert_controller_is_per_cell():
     assert torch.equal(runs["second_half_on"][:h], runs["all_off"][:h])       # first half: unscaled gains
     assert not torch.equal(runs["second_half_on"][h + 1:], runs["all_off"][h + 1:])  # then the scaling sets in
     assert not torch.equal(runs["all_on"], runs["all_off"])
+
+
+def test_fused_learn_records_the_same_kl_history_as_stepwise():
+    """With a terminal state prior and closed-loop propagation OFF, the KL term of _maximize (i2c.py:1012-1019) is taken from
+    the last propagated terminal state, which does not change between iterations: learn(n) (one library call) and n x
+    learn_msgs() must append the same n values. (With propagation on, learn() runs the stepwise path itself.)"""
+    g = load_case("em_covctrl_T100")
+    lib = hostsim.load()
+    runs = []
+    for fused in (True, False):
+        e = parity.engine_from_case(g, lib, "cpu")
+        e._propagate = True
+        e.propagate()          # what calibrate_alpha / the scripts do once before the loop
+        e._propagate = False
+        if fused:
+            e.learn(3)
+        else:
+            for _ in range(3):
+                e.learn_msgs()
+        runs.append(e)
+    a, b = runs
+    assert len(a.kl_terms) == len(b.kl_terms) == 3
+    assert all(torch.equal(x, y) for x, y in zip(a.kl_terms, b.kl_terms))
+    assert torch.equal(a.post, b.post) and torch.equal(a.temp, b.temp)
