@@ -77,6 +77,14 @@ template <typename R, int G> struct Grp {
   }
 };
 
+// Diagnostic build only (-DI2C_GROUP_STAMPS, never in the shipped library): s_memtime stamps at the phase boundaries of the
+// forward cell, summed per phase and printed by trajectory 0 -- where a lone wave spends its cycles.
+#if defined(I2C_GROUP_STAMPS) && !defined(I2C_HOST_SIM)
+#define I2C_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += now_ - stamp_last; stamp_last = now_; } while (0)
+#else
+#define I2C_STAMP(i) do { } while (0)
+#endif
+
 // Batch-wide constants a lane needs by ROW (runtime row index): unpacked, in LDS, filled once per workgroup.
 template <class M, typename R> struct GConst {
   static constexpr int NX = M::NX, NZ = M::NZ, NT = M::NZT > 0 ? M::NZT : 1, NY = M::NY;
@@ -685,6 +693,9 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
     fetch_prior(0, rb0, rd0, rd0 * (rd0 + 1) / 2, (r0 >= NX && r0 < D) ? r0 - NX : 0);
   }
 
+#if defined(I2C_GROUP_STAMPS) && !defined(I2C_HOST_SIM)
+  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#endif
   for (int t = 0; t < T; ++t) {
     // Nothing that depends on the rank or on the row stride may be hoisted out of the time loop (the byte offsets of ~100
     // rows and the batch constants of "my" row would be pinned in registers for the whole sweep): the cell works on an
@@ -710,6 +721,7 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
     for (int k = 0; k < NX; ++k) Krow[k] = nx_Krow[k];
     g_gather<D>(g, 0, pmu_own, pmu);
     int cell_bad = 0;
+    I2C_STAMP(0);  // loads + gather of the prior mean
 
     // ---- 1. joint prior over (x, u) ---------------------------------------------------
     R mu0[D], s0[D];
@@ -735,6 +747,7 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
       for (int k = 0; k < NX; ++k) Krow[k] *= rho;
       g_joint<NX, NU>(g, mu_x, sx, Krow, prow, pmu, pmu + NX, true, false, true, mu0, s0);
     }
+    I2C_STAMP(1);  // joint prior
     if (PREFETCH) fetch_prior(t + 1 < T ? t + 1 : t, rb, rd, trd, ru);  // this cell's rows are consumed: the next cell's, a cell ahead
     if (a.prior_out) {
       const GIO<R> po = gio(a.prior_out + (unsigned long)t * (D + sym(D)) * B, D + sym(D), rb, bo);
@@ -768,6 +781,7 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
       }
       cell_bad = flag_stage(cell_bad, g_kalman<D, NZ>(g, mu0, s0, mz, szr, sxz, &mu1_own), 2);
     }
+    I2C_STAMP(2);  // cost observation update
     // mu0 / s0 now hold mu_xu1_f / row r of sig_xu1_f
     out.st_if(r < D, r, mu1_own);
 #pragma unroll
@@ -781,7 +795,9 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
 #pragma unroll
       for (int j = 0; j < D; ++j) L1[j] = s0[j];
       cell_bad = flag_stage(cell_bad, g_chol<D>(g, 0, L1, rinv1), 3);
+      I2C_STAMP(3);  // stores + chol(sig_xu1_f)
       g_transform<M, DenseStruct<D>, D, NX, true>(g, 0, 1, 2, c.rule_xu, mu0, L1, DynamicsF<M, R>{c.params}, mu_x, sx, sxy);
+      I2C_STAMP(4);  // dynamics transform
 #pragma unroll
       for (int l = 0; l < NX; ++l) {
         sx[l] += c.rule_xu.W * kc.sig_eta[rx * NX + l];  // sum_p w_p sig_eta (quadrature.py:57)
@@ -819,8 +835,14 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
 #pragma unroll
     for (int j = 0; j < NX; ++j)
       out.st_if(r < NX && j <= opaque_i(r), O_S3 + trx + j, sx[j]);
+    I2C_STAMP(5);  // chol(sig_x3_f), smoother gain, terminal update, stores
   }
-  if (r == 0 && fail != 0 && a.status[b] == 0) a.status[b] = fail;
+#if defined(I2C_GROUP_STAMPS) && !defined(I2C_HOST_SIM)
+  if (b == 0 && g_in.r == 0)
+    printf("group forward stamps (clocks per cell): loads %llu prior %llu observe %llu chol1 %llu dynamics %llu gain+stores %llu\n",
+           stamp_acc[0] / T, stamp_acc[1] / T, stamp_acc[2] / T, stamp_acc[3] / T, stamp_acc[4] / T, stamp_acc[5] / T);
+#endif
+  if (g_in.r == 0 && fail != 0 && a.status[b] == 0) a.status[b] = fail;
 }
 
 // ------------------------------------------------------------------------------------------
