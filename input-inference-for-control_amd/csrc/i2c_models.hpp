@@ -9,13 +9,19 @@
 #pragma once
 #include "i2c_linalg.hpp"
 
+#ifndef I2C_PENDULUM_GROUP
+#define I2C_PENDULUM_GROUP 4
+#endif
+
 namespace i2c {
 
 // PendulumKnown: i2c/env_def.py:233-309, step i2c/env_autograd.py:5-19
 struct Pendulum {
   static constexpr int ID = 0, NX = 2, NU = 1, NZ = 4, NZT = 3, NP = 0, NA = 1;
   static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
-  static constexpr int GROUP = 4;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
+  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled. I2C_PENDULUM_GROUP is an experiment knob
+  // (-DI2C_PENDULUM_GROUP=8 through I2C_HIPCC_EXTRA): the shipped build is 4, the widest group with a row for every lane but one.
+  static constexpr int GROUP = I2C_PENDULUM_GROUP;
   static constexpr bool GROUP_ONLY = false;
   static constexpr bool GROUP_FORWARD_AUTO = false;  // see Impl::forward_any (i2c_impl.hpp)
   I2C_HD static constexpr int ang(int) { return 0; }
