@@ -272,6 +272,38 @@ template <int N, typename R, int G> I2C_FN void g_bsub(const Grp<R, G>& g, const
   }
 }
 
+// Walk k = 0..K-1 doing apply(fetch(k)), where fetch only reads LDS into a small struct P and apply only consumes it.
+// PIPE: a ROLLED two-stage software pipeline -- the reads of step k + 1 are issued before step k is consumed, pinned there by
+// scheduling fences. Left to itself the compiler keeps one or two b128 reads in flight and waits on each in turn, and a lone
+// wave then pays the LDS latency a dozen times per step (measured on the 12-state quadrotor: forward 1.14 -> 1.08 ms from
+// the transform loop alone). Rolled, because no register array may be indexed by k at d = 16 (fully unrolled, the transform
+// loop alone drove the forward kernel 1.3 KB per lane into scratch). Small problems: fully unrolled, the compiler's schedule.
+template <int K, bool PIPE, class P, class Fetch, class Apply> I2C_FN void g_walk(const Fetch& fetch, const Apply& apply) {
+  if constexpr (PIPE && K % 2 == 0) {
+    P p0, p1;
+    fetch(0, p0);
+#pragma unroll 1
+    for (int k = 0; k < K; k += 2) {
+      fetch(k + 1, p1);
+      sched_fence<true>();
+      apply(p0);
+      sched_fence<true>();
+      fetch(k + 2 < K ? k + 2 : k + 1, p0);  // the last trip re-reads its own second step: no branch
+      sched_fence<true>();
+      apply(p1);
+      sched_fence<true>();
+    }
+  } else {
+    constexpr int UF = PIPE ? 2 : K;
+#pragma unroll UF
+    for (int k = 0; k < K; ++k) {
+      P p;
+      fetch(k, p);
+      apply(p);
+    }
+  }
+}
+
 template <class ST, int DOUT> constexpr bool st_identity() {
   for (int k = 0; k < DOUT; ++k)
     if (ST::lin(k) != k) return false;
@@ -344,29 +376,37 @@ I2C_FN void g_transform(const Grp<R, G>& g, const int mL, const int mA, const in
   R myb[DOUT];
 #pragma unroll
   for (int k = 0; k < DOUT; ++k) myb[k] = rule.W * (ST::lin(k) >= 0 ? m[ST::lin(k) >= 0 ? ST::lin(k) : 0] : y0[k]);
-  // A ROLLED loop over the points: no register array is indexed by j (the lane's own row of L is read back from LDS
-  // matrix mL, which phase 1 left intact), so the live state is the three accumulator rows and one published pair.
-  // Fully unrolled, this loop alone drove the d = 16 forward kernel 1.3 KB per lane into scratch.
+  // The walk over the points (g_walk): the lane's own row of L is read back from LDS matrix mL, which phase 1 left intact,
+  // so the live state is the three accumulator rows and the published pairs in flight.
   const auto Lr = Lm + r * LD;
-  constexpr int UF = DIN * DOUT >= 96 ? 2 : DIN;  // small models: fully unrolled; large: two points per trip (two LDS batches in flight)
-#pragma unroll UF
-  for (int j = 0; j < DIN; ++j) {
-    const R arc = Am[j * LD + r], drc = Dm[j * LD + r];  // junk for r >= DOUT: those lanes' Sy is never used
-    const R lj = CROSS ? Lr[j] : R(0);
-    Ar += arc;
+  // the LDS reads of one point: its published pair (rows j of mD / mA), this lane's own entries and L[r][j]
+  struct Pt {
+    R d[DOUT], a[DOUT], ar, dr, lj;
+  };
+  const auto fetch = [&](const int j, Pt& p) {
+    p.ar = Am[j * LD + r];  // junk for r >= DOUT: those lanes' Sy is never used
+    p.dr = Dm[j * LD + r];
+    p.lj = CROSS ? Lr[j] : R(0);
 #pragma unroll
     for (int l = 0; l < DOUT; ++l) {
-      const R dl = Dm[j * LD + l];
-      R acc = Sy[l] + drc * dl;
+      p.d[l] = Dm[j * LD + l];
+      p.a[l] = ST::lin(l) < 0 ? Am[j * LD + l] : R(0);
+    }
+  };
+  const auto accumulate = [&](const Pt& p) {
+    Ar += p.ar;
+#pragma unroll
+    for (int l = 0; l < DOUT; ++l) {
+      R acc = Sy[l] + p.dr * p.d[l];
       if (ST::lin(l) < 0) {
-        const R al = Am[j * LD + l];
-        A[l] += al;
-        acc += arc * al;
+        A[l] += p.a[l];
+        acc += p.ar * p.a[l];
       }
       Sy[l] = acc;
-      if (CROSS) Sxy[l] += lj * dl;
+      if (CROSS) Sxy[l] += p.lj * p.d[l];
     }
-  }
+  };
+  g_walk<DIN, (DIN * DOUT >= 96), Pt>(fetch, accumulate);
   const R hw = R(0.5) * rule.wi, w2 = rule.wi * rule.wi, cs = rule.wi * rule.sf;
 #pragma unroll
   for (int k = 0; k < DOUT; ++k) {
@@ -401,20 +441,27 @@ I2C_FN bool g_kalman(const Grp<R, G>& g, R* mu, R* S, R* q, R* Sz, R* Sxz, R* mu
   for (int k = 0; k < DZ; ++k) dmu += Sxz[k] * q[k];
   const R own = g_sel<DX>(mu, r) + dmu;
   *mu_own = own;
-  const auto Vm = g.mat(1);
+  // V is published TRANSPOSED (row k of the LDS matrix = column k of V): the update S_r -= V_r V^T then walks the
+  // observation index reading one contiguous row per step (b128 reads, half the LDS instructions of a column walk), the
+  // lane's own V_r[k] among them (g_walk).
+  const auto Vt = g.mat(1);
   g.sync();
 #pragma unroll
-  for (int k = 0; k < DZ; ++k) Vm[r * LD + k] = Sxz[k];
+  for (int k = 0; k < DZ; ++k) Vt[k * LD + r] = Sxz[k];
   g_gather<DX>(g, 0, own, mu);  // its syncs also publish V
-  // S_r -= V_r V^T as a ROLLED loop over the observation index: column k of V per step, the lane's own V_r[k] read back
-  // from LDS, so that no register array is indexed by the loop variable
-  constexpr int UF = DX * DZ >= 96 ? 2 : DZ;
-#pragma unroll UF
-  for (int k = 0; k < DZ; ++k) {
-    const R vk = Vm[r * LD + k];
+  struct Col {
+    R v[DX], own;
+  };
+  const auto fetch = [&](const int k, Col& c) {
+    c.own = Vt[k * LD + r];
 #pragma unroll
-    for (int j = 0; j < DX; ++j) S[j] -= vk * Vm[j * LD + k];
-  }
+    for (int j = 0; j < DX; ++j) c.v[j] = Vt[k * LD + j];
+  };
+  const auto apply = [&](const Col& c) {
+#pragma unroll
+    for (int j = 0; j < DX; ++j) S[j] -= c.own * c.v[j];
+  };
+  g_walk<DZ, (DX * DZ >= 96), Col>(fetch, apply);
   return ok;
 }
 
@@ -974,42 +1021,54 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
     for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k];
 
     // RTS update of the joint (i2c.py:580-583): mu += J (m3m - m3f), S += J (S3m - S3f) J^T
-    const auto dSm = g.mat(1), Jm = g.mat(2);
+    // J is published TRANSPOSED (row l of the LDS matrix = column l of J): both products then read contiguous rows.
+    const auto dSm = g.mat(1), Jt = g.mat(2);
     g.sync();
     if (is_x) {
 #pragma unroll
       for (int j = 0; j < NX; ++j) dSm[r * LD + j] = s3m[j] - s3f[j];
     }
-    if (r < D) {
 #pragma unroll
-      for (int l = 0; l < NX; ++l) Jm[r * LD + l] = Jr[l];
-    }
+    for (int l = 0; l < NX; ++l) Jt[l * LD + r] = Jr[l];  // lanes r >= D publish junk columns nobody reads
     R mu_own = mu1_own;
 #pragma unroll
     for (int l = 0; l < NX; ++l) mu_own += Jr[l] * (m3m[l] - m3f[l]);
     g_gather<D>(g, 0, mu_own, mu);  // its syncs also publish dS and J
-    {  // both products as ROLLED loops (see g_transform): JD = J_r dS, then S_r += JD J^T with JD_r parked in LDS
+    {  // both products as walks over the state index (g_walk): JD = J_r dS, then S_r += JD J^T with JD_r parked in LDS
       R JD[NX];
 #pragma unroll
       for (int k = 0; k < NX; ++k) JD[k] = R(0);
-      constexpr int UF = D * NX >= 96 ? 2 : NX;
-#pragma unroll UF
-      for (int l = 0; l < NX; ++l) {
-        const R jl = Jm[r * LD + l];
+      struct P1 {
+        R row[NX], own;
+      };
+      g_walk<NX, (D * NX >= 96), P1>(
+          [&](const int l, P1& p) {
+            p.own = Jt[l * LD + r];
 #pragma unroll
-        for (int k = 0; k < NX; ++k) JD[k] += jl * dSm[l * LD + k];
-      }
+            for (int k = 0; k < NX; ++k) p.row[k] = dSm[l * LD + k];
+          },
+          [&](const P1& p) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) JD[k] += p.own * p.row[k];
+          });
       const auto JDm = g.mat(0);  // free until the factorisation below
       g.sync();
 #pragma unroll
       for (int k = 0; k < NX; ++k) JDm[r * LD + k] = JD[k];
       g.sync();
-#pragma unroll UF
-      for (int k = 0; k < NX; ++k) {
-        const R jd = JDm[r * LD + k];
+      struct P2 {
+        R col[D], own;
+      };
+      g_walk<NX, (D * NX >= 96), P2>(
+          [&](const int k, P2& p) {
+            p.own = JDm[r * LD + k];
 #pragma unroll
-        for (int j = 0; j < D; ++j) S[j] += jd * Jm[j * LD + k];
-      }
+            for (int j = 0; j < D; ++j) p.col[j] = Jt[k * LD + j];
+          },
+          [&](const P2& p) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) S[j] += p.own * p.col[j];
+          });
     }
     if (PREFETCH) fetch_fwd(t > 0 ? t - 1 : 0, rb, rd, trd, rx, trx);  // this cell's forward rows are consumed: the next cell's, a cell ahead
     R Lm[D], rinv[D];
