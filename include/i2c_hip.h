@@ -74,8 +74,7 @@ enum {
 
 /* how i2c_backward_sweep is scheduled (results are identical up to summation order of the cost) */
 enum {
-  I2C_BWD_AUTO = 0,     /* resolved by i2c_backward_schedule(): chunked below I2C_BWD_FUSED_MIN_B trajectories; above, fused,
-                           except chunked for the double cartpole (its fused cell does not fit the registers) */
+  I2C_BWD_AUTO = 0,     /* resolved by i2c_backward_schedule(): chunked below I2C_BWD_FUSED_MIN_B trajectories, fused from there on */
   I2C_BWD_TWO_PASS = 1, /* sequential nx x nx scan + one lane per (t, b) + reduction                  */
   I2C_BWD_FUSED = 2,    /* one lane per trajectory does the whole cell: lowest HBM traffic            */
   I2C_BWD_CHUNKED = 3   /* the affine x-recursion composed per chunk of cells: sequential depth ~2T/NC; needs `work` */

@@ -514,16 +514,22 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R, ST
 #pragma unroll
     for (int e = 0; e < C::E_FWD; ++e) voff[e] = bo + (unsigned)e * rb0;
   }
-  // software prefetch of the next cell's prior rows: the loads do not depend on the recursion
+  // software prefetch of the next cell's prior rows: the loads do not depend on the recursion.
+  // Small models fetch the NEXT cell's prior rows right after a cell has consumed its own (below), straight into the same
+  // registers: a whole cell ahead of their use, no copies. For d >= 6 those d + s(d) + nu nx doubles would sit on top of a
+  // register peak that already fills the 512-VGPR file, so there EVERY cell (the first included: loaded here and skipped in
+  // the loop, the rows become loop-carried values that stay live through every cell to the back edge) loads its rows at the
+  // top of its own cell: one exposed HBM round trip (~1 us) per ~15 us cell rather than scratch traffic throughout.
+  constexpr bool PREFETCH = C::D <= 5;
   R pri[C::E_PRI], zt[NZ];
-  {
+  if (PREFETCH) {
     const unsigned rb = rb0;
     const Window w = make_window(a.prior + (unsigned long)(LEAN ? 0 : c.row(0)) * C::E_POST * B, (unsigned long)C::E_POST * rb);
 #pragma unroll
     for (int e = 0; e < C::E_PRI; ++e) pri[e] = (R)wld<ST_>(w, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo);
-  }
 #pragma unroll
-  for (int k = 0; k < NZ; ++k) zt[k] = (!LEAN && c.z_per_cell) ? a.z[((long)c.row(0) * NZ + k) * B + b] : c.zg[k];
+    for (int k = 0; k < NZ; ++k) zt[k] = (!LEAN && c.z_per_cell) ? a.z[((long)c.row(0) * NZ + k) * B + b] : c.zg[k];
+  }
 
   // The feed-forward flag of a cell is a byte in global memory: loaded at the top of its own cell it is a dependent
   // vector load whose full latency (plus, vmcnt being shared, the acknowledgement of the previous cell's last stores)
@@ -546,14 +552,16 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R, ST
   // Settle the loads issued so far: the waitcnt pass joins the loop-entry state with the back-edge state, and pending
   // loads on the entry path would put an `s_waitcnt vmcnt(0)` at the loop top that executes every cell (see below).
   ff_cur = opaque(ff_cur);
+  if (PREFETCH) {
 #pragma unroll
-  for (int e = 0; e < C::E_PRI; ++e) pri[e] = opaque(pri[e]);
+    for (int e = 0; e < C::E_PRI; ++e) pri[e] = opaque(pri[e]);
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) zt[k] = opaque(zt[k]);
+  }
 #pragma unroll
   for (int i = 0; i < NX; ++i) mu_x[i] = opaque(mu_x[i]);
 #pragma unroll
   for (int i = 0; i < sym(NX); ++i) sig_x[i] = opaque(sig_x[i]);
-#pragma unroll
-  for (int k = 0; k < NZ; ++k) zt[k] = opaque(zt[k]);
   const R alpha_settled = opaque(alpha_traj);
   R alpha_cur = opaque((!LEAN && a.alpha_cell) ? a.alpha_cell[(long)c.row(0) * B + b] : alpha_settled);  // per-cell temperature, fetched a cell ahead
   // Per-cell constants as VGPR values (small models): left as kernel arguments they sit in ~30 SGPRs for the whole
@@ -580,13 +588,7 @@ I2C_HD inline void forward_sweep_body(const Consts<M, R>& c, const FwdArgs<R, ST
     // cell; hoisted out of the time loop they occupy ~130 SGPRs and the scalar file spills through v_writelane /
     // v_readlane (540 of the 7 800 instructions of that kernel).
     const int kz = (C::D >= 6) ? (int)opaque_uniform(0u) : 0;
-    // Small models fetch the NEXT cell's prior rows right after this cell has consumed its own (below),
-    // straight into the same registers: a whole cell ahead of their use, no copies. For d >= 6 those
-    // d + s(d) + nu nx doubles would sit on top of a register peak that already fills the 512-VGPR file,
-    // so the rows are loaded at the top of their own cell instead: one exposed HBM round trip (~1 us) per
-    // ~15 us cell rather than scratch traffic throughout.
-    constexpr bool PREFETCH = C::D <= 5;
-    if (!PREFETCH && t > 0) {
+    if (!PREFETCH) {  // see PREFETCH above
       const Window w = make_window(a.prior + (unsigned long)tr * C::E_POST * B, (unsigned long)C::E_POST * rb);
 #pragma unroll
       for (int e = 0; e < C::E_PRI; ++e) pri[e] = (R)wld<ST_>(w, VOFF ? 0u : (e) * rb, VOFF ? voff[e] : bo);
@@ -1184,13 +1186,25 @@ I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R, 
 
   constexpr bool DOUBLE_BUFFER = C::D <= 5;  // see chunk_walk_body
   R row[C::E_FWD], nxt[DOUBLE_BUFFER ? C::E_FWD : 1];
+  R m3m[NX], S3m[sym(NX)];
   {
     const Window w = make_window(a.fwd + (unsigned long)(T - 1) * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
+    if (DOUBLE_BUFFER) {
 #pragma unroll
-    for (int e = 0; e < C::E_FWD; ++e) row[e] = (R)wld<S_>(w, e * rb, bo);
+      for (int e = 0; e < C::E_FWD; ++e) row[e] = (R)wld<S_>(w, e * rb, bo);
+      end_of_chain<M, R>(c, a.temp, b, row + O_MU3, row + O_S3, m3m, S3m, a.status);
+    } else {
+      // Only the filtered terminal state here: the loop below loads EVERY cell's row at the top of its own cell, the last
+      // one included. Loaded here and skipped there, the row becomes a loop-carried value and all 100+ doubles of it stay
+      // live through every cell to the back edge (that was the 452 B per lane of scratch of the d = 7 fused walk).
+      R m3f[NX], S3f[sym(NX)];
+#pragma unroll
+      for (int e = 0; e < NX; ++e) m3f[e] = (R)wld<S_>(w, (O_MU3 + e) * rb, bo);
+#pragma unroll
+      for (int e = 0; e < sym(NX); ++e) S3f[e] = (R)wld<S_>(w, (O_S3 + e) * rb, bo);
+      end_of_chain<M, R>(c, a.temp, b, m3f, S3f, m3m, S3m, a.status);
+    }
   }
-  R m3m[NX], S3m[sym(NX)];
-  end_of_chain<M, R>(c, a.temp, b, row + O_MU3, row + O_S3, m3m, S3m, a.status);
   terminal_obs_stats<M, R, GRID>(c, b, m3m, S3m, a.term_stats, a.status);
 
   R sum_m = R(0), sum_v = R(0);
@@ -1200,7 +1214,7 @@ I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R, 
       const Window w = make_window(a.fwd + (unsigned long)tp * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
       for (int e = 0; e < C::E_FWD; ++e) nxt[DOUBLE_BUFFER ? e : 0] = (R)wld<S_>(w, e * rb, bo);
-    } else if (t < T - 1) {
+    } else {
       const Window w = make_window(a.fwd + (unsigned long)t * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
       for (int e = 0; e < C::E_FWD; ++e) row[e] = (R)wld<S_>(w, e * rb, bo);
@@ -1527,16 +1541,21 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
   for (int i = 0; i < NX; ++i) mu_x[i] = a.x0[i * B + b];
 #pragma unroll
   for (int i = 0; i < sym(NX); ++i) sig_x[i] = a.sig_x0[i * B + b];
+  // the posterior rows of the next cell are fetched a cell ahead where a second set fits (see forward_sweep_body)
+  constexpr bool PREFETCH = C::D <= 5;
   R pri[C::E_PRI];
+  if (PREFETCH) {
 #pragma unroll
-  for (int e = 0; e < C::E_PRI; ++e) pri[e] = a.post[((long)c.row(0) * C::E_POST + e) * B + b];
+    for (int e = 0; e < C::E_PRI; ++e) pri[e] = a.post[((long)c.row(0) * C::E_POST + e) * B + b];
+  }
   R sum_m = R(0), sum_v = R(0);
 
   for (int t = 0; t < T; ++t) {
-    R nxt[C::E_PRI];
-    const int tn = t + 1 < T ? t + 1 : t;
+    R nxt[PREFETCH ? C::E_PRI : 1];
+    const int tn = PREFETCH ? (t + 1 < T ? t + 1 : t) : t;
 #pragma unroll
-    for (int e = 0; e < C::E_PRI; ++e) nxt[e] = a.post[((long)c.row(tn) * C::E_POST + e) * B + b];
+    for (int e = 0; e < C::E_PRI; ++e)
+      (PREFETCH ? nxt[PREFETCH ? e : 0] : pri[e]) = a.post[((long)c.row(tn) * C::E_POST + e) * B + b];
     const R* qmu = pri;
     const R* qsig = pri + D;
     const R* Kpost = pri + D + sym(D);
@@ -1600,8 +1619,10 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
     for (int e = 0; e < NX; ++e) out[(long)(D + sym(D) + e) * B] = mu_x[e];
 #pragma unroll
     for (int e = 0; e < sym(NX); ++e) out[(long)(D + sym(D) + NX + e) * B] = sig_x[e];
+    if (PREFETCH) {
 #pragma unroll
-    for (int e = 0; e < C::E_PRI; ++e) pri[e] = nxt[e];
+      for (int e = 0; e < C::E_PRI; ++e) pri[e] = nxt[PREFETCH ? e : 0];
+    }
   }
   a.prop_stats[b] = sum_m;
   a.prop_stats[B + b] = sum_v;

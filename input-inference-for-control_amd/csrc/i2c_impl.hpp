@@ -435,15 +435,13 @@ template <class M, typename R, typename S = R> struct Impl {
   }
 
   // Measured on MI355X (tools/bench_models.py): below ~32k trajectories the sequential depth decides -> chunked.
-  // Above, HBM traffic decides -> fused (264 instead of ~490 B/cell for the pendulum), except for the double cartpole,
-  // whose fused cell (d = 7, nz = 9 with four trigonometric outputs) still spills ~400 B/lane: its chunk walk does not,
-  // and stays the fastest schedule at every batch size (B = 32768: chunked 3.5, two-pass 5.8, fused 6.6 ms).
-  // Models that only have group kernels run the fused walk.
+  // Above, HBM traffic decides -> fused (264 instead of ~490 B/cell for the pendulum; double cartpole B = 32768: fused 2.45,
+  // chunked 3.31 ms; B = 16384: 2.25 against 1.76). Models that only have group kernels run the fused walk.
   static int schedule(int B, int T, int requested) {
     if (M::GROUP_ONLY) return I2C_BWD_FUSED;
     int mode = requested;
     if (mode == I2C_BWD_AUTO)
-      mode = B < I2C_BWD_FUSED_MIN_B ? I2C_BWD_CHUNKED : (M::FUSED_BACKWARD_FITS ? I2C_BWD_FUSED : I2C_BWD_CHUNKED);
+      mode = B < I2C_BWD_FUSED_MIN_B ? I2C_BWD_CHUNKED : I2C_BWD_FUSED;
     if (mode == I2C_BWD_CHUNKED && T < 8) mode = I2C_BWD_TWO_PASS;  // too short to chunk
     return mode;
   }

@@ -18,7 +18,6 @@ namespace i2c {
 // PendulumKnown: i2c/env_def.py:233-309, step i2c/env_autograd.py:5-19
 struct Pendulum {
   static constexpr int ID = 0, NX = 2, NU = 1, NZ = 4, NZT = 3, NP = 0, NA = 1;
-  static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
   // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled. I2C_PENDULUM_GROUP is an experiment knob
   // (-DI2C_PENDULUM_GROUP=8 through I2C_HIPCC_EXTRA): the shipped build is 4, the widest group with a row for every lane but one.
   static constexpr int GROUP = I2C_PENDULUM_GROUP;
@@ -64,7 +63,6 @@ struct Pendulum {
 // PendulumKnownActReg: i2c/env_def.py:312-346 (only the action is observed; no terminal observation)
 struct PendulumActReg {
   static constexpr int ID = 1, NX = 2, NU = 1, NZ = 1, NZT = 0, NP = 0, NA = 1;
-  static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
   static constexpr int GROUP = 4;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
   static constexpr bool GROUP_ONLY = false;
   static constexpr bool GROUP_FORWARD_AUTO = false;  // see Impl::forward_any (i2c_impl.hpp)
@@ -89,7 +87,6 @@ struct PendulumActReg {
 // CartpoleKnown: i2c/env_def.py:491-612, step i2c/env_autograd.py:25-54
 struct Cartpole {
   static constexpr int ID = 2, NX = 4, NU = 1, NZ = 6, NZT = 5, NP = 0, NA = 1;
-  static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
   static constexpr int GROUP = 8;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
   static constexpr bool GROUP_ONLY = false;
   static constexpr bool GROUP_FORWARD_AUTO = false;  // see Impl::forward_any (i2c_impl.hpp)
@@ -141,7 +138,6 @@ struct Cartpole {
 // DoubleCartpoleKnown: i2c/env_def.py:615-761, step i2c/env_autograd.py:60-167
 struct DoubleCartpole {
   static constexpr int ID = 3, NX = 6, NU = 1, NZ = 9, NZT = 8, NP = 0, NA = 2;
-  static constexpr bool FUSED_BACKWARD_FITS = false;  // see Impl::schedule (i2c_impl.hpp)
   static constexpr int GROUP = 16;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
   static constexpr bool GROUP_ONLY = false;
   static constexpr bool GROUP_FORWARD_AUTO = true;   // see Impl::forward_any (i2c_impl.hpp)
@@ -219,7 +215,6 @@ struct DoubleCartpole {
 // LinearKnown: i2c/env_def.py:139-191, i2c/model.py:226-246.  params = A (2x2 row-major), B (2), a (2)
 struct Linear {
   static constexpr int ID = 4, NX = 2, NU = 1, NZ = 3, NZT = 2, NP = 8, NA = 0;
-  static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
   static constexpr int GROUP = 4;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
   static constexpr bool GROUP_ONLY = false;
   static constexpr bool GROUP_FORWARD_AUTO = false;  // see Impl::forward_any (i2c_impl.hpp)
@@ -253,7 +248,6 @@ struct Linear {
 // LinearKnownMinimumEnergy: i2c/env_def.py:194-230 (only the action is observed; terminal = state)
 struct LinearMinEnergy {
   static constexpr int ID = 5, NX = 2, NU = 1, NZ = 1, NZT = 2, NP = 8, NA = 0;
-  static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
   static constexpr int GROUP = 0;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
   static constexpr bool GROUP_ONLY = false;
   static constexpr bool GROUP_FORWARD_AUTO = false;  // see Impl::forward_any (i2c_impl.hpp)
@@ -288,7 +282,6 @@ struct LinearMinEnergy {
 // params = {mass, inertia, u_max}.
 struct Quadrotor {
   static constexpr int ID = 6, NX = 6, NU = 2, NZ = 8, NZT = 6, NP = 3, NA = 1;
-  static constexpr bool FUSED_BACKWARD_FITS = true;  // see Impl::schedule (i2c_impl.hpp)
   static constexpr int GROUP = 8;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
   static constexpr bool GROUP_ONLY = false;
   static constexpr bool GROUP_FORWARD_AUTO = true;   // see Impl::forward_any (i2c_impl.hpp)
@@ -350,7 +343,6 @@ struct Quadrotor {
 // params = {mass, Ixx, Iyy, Izz, u_max}. d = 16: only the group kernels are compiled (GROUP_ONLY).
 struct Quadrotor12 {
   static constexpr int ID = 7, NX = 12, NU = 4, NZ = 16, NZT = 12, NP = 5, NA = 3;
-  static constexpr bool FUSED_BACKWARD_FITS = true;
   static constexpr int GROUP = 16;
   static constexpr bool GROUP_ONLY = true;
   static constexpr bool GROUP_FORWARD_AUTO = false;

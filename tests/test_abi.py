@@ -60,15 +60,15 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
 
 
 def test_backward_schedule_rule():
-    """I2C_BWD_AUTO: chunked below 32768 trajectories; above, fused, except chunked for the double cartpole; chunked
-    needs T >= 8; explicit requests are honoured; unknown models / modes give 0."""
+    """I2C_BWD_AUTO: chunked below 32768 trajectories, fused from there on; chunked needs T >= 8; explicit requests are
+    honoured; unknown models / modes give 0."""
     lib = pkg.load_library()
     N = pkg._native
     f = lib.i2c_backward_schedule
     assert f(0, 4096, 200, N.BWD_AUTO) == N.BWD_CHUNKED
     assert f(0, 32768, 200, N.BWD_AUTO) == N.BWD_FUSED
     assert f(2, 65536, 500, N.BWD_AUTO) == N.BWD_FUSED       # cartpole, d = 5
-    assert f(3, 32768, 300, N.BWD_AUTO) == N.BWD_CHUNKED     # double cartpole, d = 7: its fused cell spills
+    assert f(3, 32768, 300, N.BWD_AUTO) == N.BWD_FUSED       # double cartpole, d = 7 (its fused walk no longer spills)
     assert f(6, 32768, 50, N.BWD_AUTO) == N.BWD_FUSED        # quadrotor, d = 8: fits since the rows are single-buffered
     assert f(3, 4096, 300, N.BWD_AUTO) == N.BWD_CHUNKED
     assert f(0, 4096, 5, N.BWD_AUTO) == N.BWD_TWO_PASS
