@@ -137,9 +137,11 @@ typedef struct I2cProblem {
                               i2c.py:143,259-265); the cubature forward pass always scales it (i2c.py:366-375)      */
   int32_t gh_degree;       /* I2C_INF_GAUSS_HERMITE: 1 <= degree <= I2C_MAX_GH_DEGREE                               */
   int32_t group_lanes;     /* 0: the model's default kernels (one lane per trajectory; the group kernels for a group_only
-                              model); I2cDims.group_lanes: run forward / backward / propagate / filter with that many lanes of
+                              model; for the d >= 7 lane models the FORWARD sweep runs on the group kernels while B * G <= 65536);
+                              I2cDims.group_lanes: run forward / backward / propagate / filter with that many lanes of
                               a wavefront per trajectory (fp64, cubature rule, diagonal cost weights;
-                              the backward sweep then has one schedule, the fused walk); anything else: I2C_ENOTSUP            */
+                              the backward sweep then has one schedule, the fused walk); -1: one lane per trajectory for
+                              every sweep (I2C_ENOTSUP for a group_only model); anything else: I2C_ENOTSUP                     */
   int32_t t0;              /* ring offset of the PERSISTENT per-cell buffers -- prior/post, z, alpha_cell, feedforward: cell t of the
                               horizon lives in row (t0 + t) mod T. 0 outside the MPC loop; the receding-horizon shift (mpc.py:174-181)
                               is "t0 += 1" plus one fresh row (i2c_mpc_step / i2c_shift_horizon). Buffers a sweep writes for its

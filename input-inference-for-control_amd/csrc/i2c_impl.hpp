@@ -371,6 +371,7 @@ template <class M, typename R, typename S = R> struct Impl {
   // 1: group kernels, 0: one lane per trajectory, < 0: error code
   static int use_group(const I2cProblem* p) {
     if (p->group_lanes == 0) return M::GROUP_ONLY ? (HAS_GROUP ? 1 : I2C_ENOTSUP) : 0;
+    if (p->group_lanes == -1) return M::GROUP_ONLY ? I2C_ENOTSUP : 0;  // one lane per trajectory, no hybrid forward
     return (HAS_GROUP && p->group_lanes == G) ? 1 : I2C_ENOTSUP;
   }
   // what the group form does not cover: other inference rules, non-diagonal cost weights

@@ -90,13 +90,16 @@ class BatchedI2c:
         self.nx, self.nu, self.nz, self.nzt, self.d = nx, nu, nz, nzt, nx + nu
         self.H = T = int(horizon)
         # group kernels (csrc/i2c_group.hpp): `group_lanes` lanes of a wavefront per trajectory. 0 = the model's default
-        # (one lane per trajectory, except for models that only have group kernels); True = the model's group width.
+        # (one lane per trajectory, except for models that only have group kernels; the d >= 7 lane models run their
+        # FORWARD sweep on the group kernels at small batches); True = the model's group width; -1 = one lane per
+        # trajectory for every sweep.
         if group_lanes is True:
             group_lanes = dims.group_lanes
         self.group_lanes = int(group_lanes or 0)
-        if self.group_lanes not in (0, dims.group_lanes):
-            raise ValueError(f"group_lanes={self.group_lanes}: this model's group kernels use {dims.group_lanes} lanes")
-        self.uses_group_kernels = bool(self.group_lanes or dims.group_only)
+        if self.group_lanes not in (0, dims.group_lanes) and not (self.group_lanes == -1 and not dims.group_only):
+            raise ValueError(f"group_lanes={self.group_lanes}: this model's group kernels use {dims.group_lanes} lanes"
+                             + (" and it has no one-lane kernels" if dims.group_only else " (or -1: one lane per trajectory)"))
+        self.uses_group_kernels = bool(self.group_lanes > 0 or dims.group_only)
         if self.mixed and (self.uses_group_kernels or inference != "cubature"):
             raise ValueError("fp32 storage (storage_dtype) is available for the cubature path of the one-lane kernels only")
 

@@ -55,7 +55,15 @@ def test_hip_group_kernels_vs_reference_golden(lib, name, tol_d, tol_s):
     parity.check_against_golden(name, lib, "cuda", tol_d, tol_s, group_lanes=True)
 
 
-@pytest.mark.parametrize("name,B,group", [("em_quad12_T20", 203, 0), ("em_dcp_T60", 77, True), ("em_pendulum_T200", 1000, True)])
+# group_lanes = -1: one lane per trajectory for every sweep -- the d >= 7 models' default runs their forward sweep on the
+# group kernels at these batch sizes, so their one-lane forward kernels need their own golden runs
+@pytest.mark.parametrize("name,tol_d,tol_s", [("em_dcp_T60", 1e-6, 1e-5), ("em_quadrotor_T20", 1e-6, 1e-5)])
+def test_hip_lane_kernels_vs_reference_golden(lib, name, tol_d, tol_s):
+    parity.check_against_golden(name, lib, "cuda", tol_d, tol_s, group_lanes=-1)
+
+
+@pytest.mark.parametrize("name,B,group", [("em_quad12_T20", 203, 0), ("em_dcp_T60", 77, True), ("em_dcp_T60", 77, -1),
+                                          ("em_pendulum_T200", 1000, True)])
 def test_hip_group_kernels_batch_vs_oracle(lib, name, B, group):
     """Ragged batches (not a multiple of the 64 / G trajectories of a wavefront) against the batched oracle."""
     parity.check_batch_against_oracle(name, lib, "cuda", B, 3, tol=1e-6, group_lanes=group)

@@ -52,6 +52,19 @@ def test_hostsim_group_kernels_vs_reference_golden(lib, name, tol_d, tol_s, n_it
     parity.check_against_golden(name, lib, "cpu", tol_d, tol_s, n_iters=n_iters, group_lanes=True)
 
 
+# The d >= 7 models run their FORWARD sweep on the group kernels by default at small batches (the hybrid default), so the
+# goldens above no longer reach their one-lane forward kernels: group_lanes = -1 forces one lane per trajectory everywhere.
+LANE_GOLDEN = [
+    ("em_dcp_T60", 1e-7, 1e-6),
+    ("em_quadrotor_T20", 1e-7, 1e-6),
+]
+
+
+@pytest.mark.parametrize("name,tol_d,tol_s", LANE_GOLDEN)
+def test_hostsim_lane_kernels_vs_reference_golden(lib, name, tol_d, tol_s):
+    parity.check_against_golden(name, lib, "cpu", tol_d, tol_s, group_lanes=-1)
+
+
 def test_hostsim_group_kernels_batch_vs_oracle(lib):
     parity.check_batch_against_oracle("em_quad12_T20", lib, "cpu", 5, 3, tol=1e-7)
     parity.check_batch_against_oracle("em_dcp_T60", lib, "cpu", 3, 3, tol=1e-7, group_lanes=True)
@@ -70,6 +83,8 @@ def test_group_kernels_refuse_what_they_do_not_cover(lib):
         eng.forward_sweep()
     with pytest.raises(ValueError):
         parity.engine_from_case(load_case("em_pendulum_T200"), lib, "cpu", group_lanes=16)
+    with pytest.raises(ValueError):  # d = 16 has no one-lane kernels
+        parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu", group_lanes=-1)
 
 
 LINEARIZE = [
