@@ -219,30 +219,32 @@ def extra_config_legs(pkg, device, K=10):
 
     # config 4: quadrotor MPC + cubature-KF state estimation at nx = 12, horizon 50, B = 8192 closed loops: one control step
     # = filter + n_iter x (forward, backward, prior update) + first action + horizon shift, ONE library call (i2c_mpc_step)
+    # (B = 8192: the whole config on this GPU; B = 1024: one GPU's share of it when sharded over 8)
     m = make_env_model("Quadrotor12")
-    B, T, n_iter = 8192, 50, 1
-    Q, R = np.diag([10.0] * 3 + [1.0] * 3 + [0.1] * 6), 1e-2 * np.eye(4)
-    x0 = 1e-2 * rng.normal(size=(B, 12))
-    mu_u = 0.25 * m.gravity + 1e-2 * rng.normal(size=(B, T, 4))
-    eng = pkg.BatchedI2c(m, T, Q, R, Q / 10.0, 0.02, 1.0, mu_u, 1e-2 * np.eye(4), x0=x0, device=device, keep_zpost=False, keep_xm=False,
-                         z_traj=np.broadcast_to(np.concatenate((m.zg_term.reshape(-1), 0.25 * m.gravity * np.ones(4))), (T, 16)))
-    eng.tau = T - 1
-    eng.enable_per_cell_alpha()
-    sig_zeta = 1e-4 * np.eye(9)
-    y = torch.as_tensor(np.ascontiguousarray(m.measure(x0).T), dtype=torch.float64, device=device)
-    u = torch.as_tensor(np.ascontiguousarray(mu_u[:, 0, :].T), dtype=torch.float64, device=device)
-    for _ in range(2):
-        act, _ = eng.mpc_step(n_iter, y, u, sig_zeta)
-    sync(); t0 = time.perf_counter()
-    for _ in range(K):
-        act, _ = eng.mpc_step(n_iter, y, u, sig_zeta)
-    sync()
-    ms = (time.perf_counter() - t0) / K * 1e3
-    out["quadrotor12_mpc_H50_B8192"] = {"ms_per_control_step": ms, "closed_loop_steps_per_s": B / ms * 1e3, "em_iters_per_step": n_iter,
-                                        "value": B * T * n_iter / ms * 1e3, "unit": "timestep-messages/s",
-                                        "algorithmic_GBps": _gbps(eng, B, T * n_iter, ms), "kernels": "group (16 lanes per trajectory)",
-                                        "failed_trajectories": len(eng.failures())}
-    del eng
+    for B in (8192, 1024):
+        T, n_iter = 50, 1
+        Q, R = np.diag([10.0] * 3 + [1.0] * 3 + [0.1] * 6), 1e-2 * np.eye(4)
+        x0 = 1e-2 * rng.normal(size=(B, 12))
+        mu_u = 0.25 * m.gravity + 1e-2 * rng.normal(size=(B, T, 4))
+        eng = pkg.BatchedI2c(m, T, Q, R, Q / 10.0, 0.02, 1.0, mu_u, 1e-2 * np.eye(4), x0=x0, device=device, keep_zpost=False, keep_xm=False,
+                             z_traj=np.broadcast_to(np.concatenate((m.zg_term.reshape(-1), 0.25 * m.gravity * np.ones(4))), (T, 16)))
+        eng.tau = T - 1
+        eng.enable_per_cell_alpha()
+        sig_zeta = 1e-4 * np.eye(9)
+        y = torch.as_tensor(np.ascontiguousarray(m.measure(x0).T), dtype=torch.float64, device=device)
+        u = torch.as_tensor(np.ascontiguousarray(mu_u[:, 0, :].T), dtype=torch.float64, device=device)
+        for _ in range(2):
+            act, _ = eng.mpc_step(n_iter, y, u, sig_zeta)
+        sync(); t0 = time.perf_counter()
+        for _ in range(K):
+            act, _ = eng.mpc_step(n_iter, y, u, sig_zeta)
+        sync()
+        ms = (time.perf_counter() - t0) / K * 1e3
+        out["quadrotor12_mpc_H50_B%d" % B] = {"ms_per_control_step": ms, "closed_loop_steps_per_s": B / ms * 1e3, "em_iters_per_step": n_iter,
+                                              "value": B * T * n_iter / ms * 1e3, "unit": "timestep-messages/s",
+                                              "algorithmic_GBps": _gbps(eng, B, T * n_iter, ms), "kernels": "group (16 lanes per trajectory)",
+                                              "failed_trajectories": len(eng.failures())}
+        del eng
 
     # config 5: nonlinear covariance control (pendulum, action-only cost, annealed terminal prior, closed-loop propagation
     # and KL every iteration; scripts/experiments/pendulum_known_act_reg_quad.py:22-33), T=100, B=8192 = one GPU's share of 65536
