@@ -222,7 +222,7 @@ def extra_config_legs(pkg, device, K=10):
     # (B = 8192: the whole config on this GPU; B = 1024: one GPU's share of it when sharded over 8)
     m = make_env_model("Quadrotor12")
     for B in (8192, 1024):
-        T, n_iter = 50, 1
+        T, n_iter = 50, 2  # mpc_iter = 2 in the reference's script (scripts/mpc_state_est/mpc_quad.py:559)
         Q, R = np.diag([10.0] * 3 + [1.0] * 3 + [0.1] * 6), 1e-2 * np.eye(4)
         x0 = 1e-2 * rng.normal(size=(B, 12))
         mu_u = 0.25 * m.gravity + 1e-2 * rng.normal(size=(B, T, 4))
