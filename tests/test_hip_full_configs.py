@@ -50,6 +50,24 @@ def test_config3_double_cartpole_T300_B4096():
     _subset_vs_oracle(g, 4096, 16, 3, 1e-6, plant=(1000, 4095))
 
 
+def test_config3_double_cartpole_saturated_batch_lane_forward_fused_backward():
+    """The same model where the batch saturates the GPU: B = 32768 makes `auto` pick the one-lane forward sweep (B G > 65536)
+    and the fused backward walk (its row no longer loop-carried: no scratch) -- a subset against the oracle, planted
+    duplicates bit-identical, and the chunked schedule on the same inputs within rounding. T = 60 keeps it in seconds."""
+    g = load_case("em_dcp_T60")
+    eng = _subset_vs_oracle(g, 32768, 8, 2, 1e-6, plant=(20000, 32767))
+    assert eng.backward_schedule == "fused" and not eng.uses_group_kernels
+    x0, mu_u = parity.batched_inputs(g, 32768)
+    for b in (20000, 32767):
+        x0[b], mu_u[b] = x0[0], mu_u[0]
+    ch = parity.engine_from_case(g, None, "cuda", x0=x0, mu_u=mu_u, backward_mode="chunked")
+    for _ in range(2):
+        ch.learn_msgs()
+    assert ch.backward_schedule == "chunked"
+    assert_close(parity.np_(eng.post), parity.np_(ch.post), 1e-9, "fused vs chunked backward, B = 32768")
+    assert_close(parity.np_(eng.alpha), parity.np_(ch.alpha), 1e-9, "alpha, fused vs chunked")
+
+
 def test_config5_covariance_control_B65536():
     """Nonlinear covariance control, tempered terminal prior, closed-loop propagation; 65536 trajectories
     (the 8-GPU shape of BASELINE.json on one GPU), fused backward."""
