@@ -62,6 +62,24 @@ def test_hip_lane_kernels_vs_reference_golden(lib, name, tol_d, tol_s):
     parity.check_against_golden(name, lib, "cuda", tol_d, tol_s, group_lanes=-1)
 
 
+@pytest.mark.parametrize("name", ["em_dcp_T60", "em_quadrotor_T20"])
+def test_hip_kernel_families_agree_at_B4096(lib, name):
+    """The three ways to run a d >= 7 model -- the default (group forward + one-lane backward), group kernels throughout,
+    one lane per trajectory throughout -- on the same 4096 trajectories: the same posterior to rounding."""
+    g = load_case(name)
+    x0, mu_u = parity.batched_inputs(g, 4096)
+    engs = [parity.engine_from_case(g, lib, "cuda", x0=x0, mu_u=mu_u, group_lanes=gl) for gl in (0, True, -1)]
+    for e in engs:
+        for _ in range(3):
+            e.learn_msgs()
+        assert e.failures() == []
+    assert engs[1].uses_group_kernels and not engs[2].uses_group_kernels
+    ref = parity.np_(engs[2].post)
+    assert_close(parity.np_(engs[0].post), ref, 1e-8, name + ": hybrid default vs one lane per trajectory")
+    assert_close(parity.np_(engs[1].post), ref, 1e-8, name + ": group kernels vs one lane per trajectory")
+    assert_close(parity.np_(engs[1].alpha), parity.np_(engs[2].alpha), 1e-8, name + ": alpha")
+
+
 @pytest.mark.parametrize("name,B,group", [("em_quad12_T20", 203, 0), ("em_dcp_T60", 77, True), ("em_dcp_T60", 77, -1),
                                           ("em_pendulum_T200", 1000, True)])
 def test_hip_group_kernels_batch_vs_oracle(lib, name, B, group):
