@@ -137,15 +137,22 @@ def measured_traffic(B, T, dtype, kernel):
 
 
 def cpu_baseline(T):
-    """The oracle (NumPy restatement, batch-vectorised) timed on THIS host's cores, as a child process that
-    imports NumPy only (oracle/cpu_bench.py): one worker per core (capped at 32), a bounded sample."""
+    """The oracle (NumPy restatement) timed on THIS host's cores, as child processes that import NumPy only
+    (oracle/cpu_bench.py), one worker per core up to 128, bounded samples. Two shapes: batch-vectorised (the strongest CPU form
+    of this restatement: 512 trajectories per worker) and, as `reference_shaped`, the reference's own shape -- ONE trajectory per
+    process, a Python loop over the T cells."""
     import subprocess
 
-    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--horizon", str(T), "--batch", "512", "--iters", "10"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-    if r.returncode != 0:
-        raise RuntimeError("cpu baseline failed: " + r.stderr[-2000:])
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    def run(*extra):
+        cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--horizon", str(T)] + list(extra)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            raise RuntimeError("cpu baseline failed: " + r.stderr[-2000:])
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    out = run("--batch", "512", "--iters", "6")
+    out["reference_shaped"] = run("--batch", "1", "--iters", "5")
+    return out
 
 
 def launch_workers(n, argv):
@@ -158,6 +165,9 @@ def launch_workers(n, argv):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC; without it RCCL's buffer exchange
+    # between the rank processes fails with `hipIpcGetMemHandle: invalid argument`. It is exported on the boxes already; kept
+    # here so that a worker environment built from a scrubbed one still carries it.
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + argv
@@ -214,8 +224,34 @@ def extra_config_legs(pkg, device, K=10):
     ms = (time.perf_counter() - t0) / K * 1e3
     out["double_cartpole_T300_B4096"] = {"ms_per_step": ms, "value": B * T / ms * 1e3, "unit": "timestep-messages/s",
                                          "algorithmic_GBps": _gbps(eng, B, T, ms), "backward": eng.backward_schedule,
+                                         "forward_family": eng.forward_family, "backward_family": eng.backward_family,
                                          "failed_trajectories": len(eng.failures())}
     del eng
+
+    # the d >= 7 models at a batch that fills the chip (EM iteration = forward + backward + M-step, one i2c_learn call):
+    # double cartpole T=300 and the 12-state quadrotor T=50 at B = 32768
+    for tag, name, Tn, Bn in (("double_cartpole_T300_B32768", "DoubleCartpoleKnown", 300, 32768), ("quadrotor12_T50_B32768", "Quadrotor12", 50, 32768)):
+        m = make_env_model(name)
+        if name == "DoubleCartpoleKnown":
+            Qn, Rn, Qfn, a0, tol, su = Q, R, Q, 0.05, 0.99, np.eye(1)
+            mu_u = 1e-2 * rng.normal(size=(Bn, Tn, 1))
+            x0 = np.asarray(m.x0, float).reshape(1, -1) + 1e-3 * rng.normal(size=(Bn, m.dim_x))
+        else:
+            Qn, Rn = np.diag([10.0] * 3 + [1.0] * 3 + [0.1] * 6), 1e-2 * np.eye(4)
+            Qfn, a0, tol, su = Qn, 1.0, 0.5, 1e-2 * np.eye(4)
+            mu_u = 0.25 * m.gravity + 1e-2 * rng.normal(size=(Bn, Tn, 4))
+            x0 = 1e-2 * rng.normal(size=(Bn, 12))
+        eng = pkg.BatchedI2c(m, Tn, Qn, Rn, Qfn, a0, tol, mu_u, su, x0=x0, device=device, keep_zpost=False, keep_xm=False)
+        eng.learn(2)
+        Ks = max(K // 2, 3)
+        sync(); t0 = time.perf_counter(); eng.learn(Ks); sync()
+        ms = (time.perf_counter() - t0) / Ks * 1e3
+        gb = _gbps(eng, Bn, Tn, ms)
+        out[tag] = {"ms_per_step": ms, "value": Bn * Tn / ms * 1e3, "unit": "timestep-messages/s", "algorithmic_GBps": gb,
+                    "frac_of_hbm_peak": gb / HBM_PEAK_GBS, "forward_family": eng.forward_family, "backward_family": eng.backward_family,
+                    "backward": eng.backward_schedule, "failed_trajectories": len(eng.failures())}
+        del eng, mu_u, x0
+        torch.cuda.empty_cache()
 
     # config 4: quadrotor MPC + cubature-KF state estimation at nx = 12, horizon 50, B = 8192 closed loops: one control step
     # = filter + n_iter x (forward, backward, prior update) + first action + horizon shift, ONE library call (i2c_mpc_step)
@@ -242,7 +278,8 @@ def extra_config_legs(pkg, device, K=10):
         ms = (time.perf_counter() - t0) / K * 1e3
         out["quadrotor12_mpc_H50_B%d" % B] = {"ms_per_control_step": ms, "closed_loop_steps_per_s": B / ms * 1e3, "em_iters_per_step": n_iter,
                                               "value": B * T * n_iter / ms * 1e3, "unit": "timestep-messages/s",
-                                              "algorithmic_GBps": _gbps(eng, B, T * n_iter, ms), "kernels": "group (16 lanes per trajectory)",
+                                              "algorithmic_GBps": _gbps(eng, B, T * n_iter, ms),
+                                              "forward_family": eng.forward_family, "backward_family": eng.backward_family,
                                               "failed_trajectories": len(eng.failures())}
         del eng
 
@@ -280,6 +317,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturated", action="store_true", help="skip the extra B=131072 leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the legs of the other BASELINE configs and strong scaling")
+    ap.add_argument("--no-rccl", action="store_true", help="N = 1 only: do not create the single-rank RCCL group")
     ap.add_argument("--backward", default="auto", choices=["auto", "two_pass", "fused", "chunked"])
     ap.add_argument("--group-lanes", type=int, default=0, help="run the group kernels (lanes per trajectory) in the headline leg")
     ap.add_argument("--test-hostsim", action="store_true",
@@ -304,6 +342,7 @@ def main():
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
     dist = None
+    rccl_error = None
     if "RANK" in os.environ and "MASTER_ADDR" in os.environ:  # launched by torch.distributed.run (also with N = 1)
         import torch.distributed as dist
 
@@ -311,6 +350,23 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)  # RCCL on ROCm
+    elif args.gpus == 1 and not args.test_hostsim and not args.no_rccl:
+        # A plain `python bench.py` (how the driver runs N = 1): a single-rank RCCL group in this process, so that the job's one
+        # collective -- the all-gather of the final controllers -- runs through the same code path as N > 1 and the line
+        # carries its time. Nothing is re-executed; the group is created before any kernel of the benchmark runs.
+        import socket
+
+        import torch.distributed as dist
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        try:
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
+        except Exception as e:  # the measurement must not die with the collective library: say so in the line instead
+            rccl_error = f"{type(e).__name__}: {e}"
+            dist = None
 
     pkg = importlib.import_module(PKG)
     dtype = torch.float64
@@ -399,7 +455,9 @@ def main():
             "parallelism": f"batch-sharded x{world}, no collective in the EM loop",
             "kernels": "group, %d lanes per trajectory" % args.group_lanes if args.group_lanes else "one lane per trajectory",
         },
-        "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
+        "rccl_world_size": (dist.get_world_size() if dist is not None else None),
+        "rccl_backend": (dist.get_backend() if dist is not None else None),
+        "rccl_error": rccl_error,
         "kernel_ms": {"forward_sweep": fwd_ms, "backward_sweep": bwd_ms, "mstep": mst_ms},
         "backward": eng.backward_schedule,
         "ms_per_step_stepped_from_python": stepwise_s / K * 1e3,
@@ -419,7 +477,7 @@ def main():
             "whole_iteration_GBps": el["total"] * wbytes * B * T / (elapsed / K) / 1e9,
             "note": "instruction-issue-bound at B=4096 per GPU: 64 lone wavefronts (1024 SIMDs), each issuing ~88 % of its cycles "
                     "(profiles/r1_k_forward_sq_counters.json); spreading a trajectory over 4 lanes (group kernels) is SLOWER for "
-                    "this model (profiles/r2_pendulum_group_sq_counters.json); HBM-bound from B ~ 32768 (saturated_batch); "
+                    "this model (profiles/r2_pendulum_lane_vs_group_sq_counters.json); HBM-bound from B ~ 32768 (saturated_batch); "
                     "see DESIGN.md section 6",
         },
         "final_allgather_ms": allgather_ms,

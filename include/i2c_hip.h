@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define I2C_ABI_VERSION 4
+#define I2C_ABI_VERSION 5
 
 #define I2C_MAX_NX 12
 #define I2C_MAX_NU 4
@@ -58,7 +58,7 @@ enum {
 /* I2cProblem.dtype. I2C_F64: the reference's arithmetic, parity-grade. I2C_F64_F32S: fp64 ARITHMETIC on fp32-STORED per-cell
  * buffers (prior/post, fwd, xm, zpost, prior_out are float; everything per trajectory -- x0, sig_x0, z, alpha, alpha_cell, temp,
  * term_stats, cell_stats, stats, the chunk workspace -- stays double): half the HBM bytes of the sweeps; deviation from fp64
- * bounded (tests/test_hip_precision.py). Only the cubature EM path of the one-lane kernels (forward, backward, M-step,
+ * bounded (tests/test_precision.py). Only the cubature EM path of the one-lane kernels (forward, backward, M-step,
  * i2c_learn); other entry points return I2C_ENOTSUP. I2C_F32: fp32 arithmetic and storage -- NOT parity-grade (the sigma-point
  * curvature terms are below fp32 resolution; O(1) deviation after a few EM iterations): for tolerance sweeps only. */
 enum { I2C_F64 = 0, I2C_F32 = 1, I2C_F64_F32S = 2 };
@@ -80,6 +80,17 @@ enum {
   I2C_BWD_CHUNKED = 3   /* the affine x-recursion composed per chunk of cells: sequential depth ~2T/NC; needs `work` */
 };
 #define I2C_BWD_FUSED_MIN_B 32768
+
+/* kernel families (i2c_kernel_family): how the lanes of a wavefront are mapped onto trajectories */
+enum {
+  I2C_FAMILY_LANE = 1,  /* one trajectory per lane, every block in that lane's registers (d = nx + nu <= 8)              */
+  I2C_FAMILY_GROUP = 2, /* G = I2cDims.group_lanes lanes per trajectory, blocks row-distributed, exchanged through LDS  */
+  I2C_FAMILY_WAVE = 3   /* one wavefront per trajectory: 16 x 16 blocks in the MFMA accumulator layout (d = 16)          */
+};
+enum { I2C_SWEEP_FORWARD = 0, I2C_SWEEP_BACKWARD = 1, I2C_SWEEP_PROPAGATE = 2, I2C_SWEEP_FILTER = 3 };
+/* hybrid default of the d >= 7 lane models: their FORWARD sweep runs on the group kernels while B * G stays within this
+ * many lanes (every group wave then has a SIMD of its own: 1024 SIMDs x 64 lanes) */
+#define I2C_GROUP_FORWARD_MAX_LANES 65536
 
 enum {
   I2C_OK = 0,
@@ -114,6 +125,8 @@ typedef struct I2cDims {
   int32_t group_lanes;     /* G of the model's group kernels (G lanes of a wavefront per trajectory, blocks row-distributed
                               over the lanes and exchanged through LDS); 0: none compiled                                  */
   int32_t group_only;      /* 1: only the group kernels exist for this model (nx + nu > 8 does not fit one lane)           */
+  int32_t wave;            /* 1: the one-wavefront-per-trajectory kernels (I2C_FAMILY_WAVE) exist for this model;
+                              I2cProblem.group_lanes = 64 asks for them                                                    */
 } I2cDims;
 
 /*
@@ -129,7 +142,7 @@ typedef struct I2cProblem {
   int32_t has_Qf;          /* terminal cost observation (Qf given, i2c.py:787-793)             */
   int32_t has_x_terminal;  /* covariance control: terminal state prior (i2c.py:548-559)        */
   int32_t z_per_cell;      /* 0: target = zg for every cell; 1: device targets `z` [T][nz][B]  */
-  int32_t backward_mode;   /* I2C_BWD_AUTO | I2C_BWD_TWO_PASS | I2C_BWD_FUSED (see i2c_backward_sweep) */
+  int32_t backward_mode;   /* I2C_BWD_AUTO | I2C_BWD_TWO_PASS | I2C_BWD_FUSED | I2C_BWD_CHUNKED (see i2c_backward_sweep) */
   int32_t terminal_cell;   /* index of the cell whose FORWARD pass applies the terminal cost update (i2c.py:430-443;
                               `terminal_cell` flag, i2c.py:82,822); T-1 normally, moves with the MPC shift, -1: none */
   int32_t inference;       /* I2C_INF_CUBATURE | I2C_INF_LINEARIZE                                                  */
@@ -139,7 +152,7 @@ typedef struct I2cProblem {
   int32_t group_lanes;     /* 0: the model's default kernels (one lane per trajectory; the group kernels for a group_only
                               model; for the d >= 7 lane models the FORWARD sweep runs on the group kernels while B * G <= 65536);
                               I2cDims.group_lanes: run forward / backward / propagate / filter with that many lanes of
-                              a wavefront per trajectory (fp64, cubature rule, diagonal cost weights;
+                              a wavefront per trajectory (fp64, cubature rule;
                               the backward sweep then has one schedule, the fused walk); -1: one lane per trajectory for
                               every sweep (I2C_ENOTSUP for a group_only model); anything else: I2C_ENOTSUP                     */
   int32_t t0;              /* ring offset of the PERSISTENT per-cell buffers -- prior/post, z, alpha_cell, feedforward: cell t of the
@@ -211,6 +224,11 @@ size_t i2c_workspace_bytes(int model_id, int dtype, int B, int T);
  * fall-backs: chunked needs T >= 8). Callers size their buffers from the answer: two-pass needs xm and cell_stats,
  * chunked needs I2cProblem.work. Returns one of I2C_BWD_TWO_PASS / FUSED / CHUNKED, or 0 for an unknown model. */
 int i2c_backward_schedule(int model_id, int B, int T, int requested_mode);
+
+/* Which kernel family (I2C_FAMILY_*) will serve `sweep` (I2C_SWEEP_*) of problem p -- the one place that resolves
+ * I2cProblem.group_lanes, the models' defaults and the batch-size thresholds, so that callers and tests can see (and pin) what
+ * ran: the last bits of a result depend on the family. Returns a negative error code if that sweep would refuse the problem. */
+int i2c_kernel_family(const I2cProblem* p, int sweep);
 
 /* Library self-description: ABI version, and the gfx target it was compiled for. */
 int i2c_abi_version(void);

@@ -9,7 +9,7 @@ without a GPU; nothing in the package ever looks for it.)
 import ctypes as C
 import os
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_NX, MAX_NU, MAX_NZ, MAX_PARAMS = 12, 4, 16, 16
 MAX_GH_DEGREE = 8
 
@@ -21,6 +21,9 @@ def _sym(n):
 F64, F32, F64_F32S = 0, 1, 2  # I2cProblem.dtype (include/i2c_hip.h): F64_F32S = fp64 arithmetic on fp32-stored per-cell buffers
 BWD_AUTO, BWD_TWO_PASS, BWD_FUSED, BWD_CHUNKED = 0, 1, 2, 3
 INF_CUBATURE, INF_LINEARIZE, INF_GAUSS_HERMITE = 0, 1, 2
+FAMILY_LANE, FAMILY_GROUP, FAMILY_WAVE = 1, 2, 3  # i2c_kernel_family()
+FAMILY_NAMES = {FAMILY_LANE: "lane", FAMILY_GROUP: "group", FAMILY_WAVE: "wave"}
+SWEEP_FORWARD, SWEEP_BACKWARD, SWEEP_PROPAGATE, SWEEP_FILTER = 0, 1, 2, 3
 
 MODEL_IDS = {
     "PendulumKnown": 0,
@@ -49,7 +52,7 @@ FAIL_REASONS = {
 
 class I2cDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("nx", "nu", "nz", "nzt", "e_post", "e_fwd", "e_xm", "e_zpost", "e_prop", "n_params", "ny",
-                                          "group_lanes", "group_only")]
+                                          "group_lanes", "group_only", "wave")]
 
 
 class I2cProblem(C.Structure):
@@ -116,6 +119,7 @@ _SIGNATURES = {
     "i2c_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "i2c_backward_schedule": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "i2c_query": (C.c_int, [C.c_int, C.POINTER(I2cDims)]),
+    "i2c_kernel_family": (C.c_int, [C.POINTER(I2cProblem), C.c_int]),
     "i2c_forward_sweep": (C.c_int, [C.POINTER(I2cProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "i2c_backward_sweep": (
         C.c_int,

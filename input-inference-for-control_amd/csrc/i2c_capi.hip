@@ -23,7 +23,6 @@ int check_problem(const I2cProblem* p) {
   if (p->inference < I2C_INF_CUBATURE || p->inference > I2C_INF_GAUSS_HERMITE) return I2C_EINVAL;
   if (p->inference == I2C_INF_GAUSS_HERMITE && (p->gh_degree < 1 || p->gh_degree > I2C_MAX_GH_DEGREE)) return I2C_EINVAL;
   if (p->t0 < 0 || p->t0 >= p->T) return I2C_EINVAL;
-  if (p->t0 != 0 && p->inference != I2C_INF_CUBATURE) return I2C_ENOTSUP;  // the ring is an MPC (sigma-point) feature
   return I2C_OK;
 }
 
@@ -57,6 +56,11 @@ int i2c_backward_schedule(int model_id, int B, int T, int requested_mode) {
   if (B < 1 || T < 1 || requested_mode < I2C_BWD_AUTO || requested_mode > I2C_BWD_CHUNKED) return 0;
   const i2c::ModelOps* ops = find_ops(model_id, I2C_F64);
   return ops ? ops->schedule(B, T, requested_mode) : 0;
+}
+
+int i2c_kernel_family(const I2cProblem* p, int sweep) {
+  if (sweep < I2C_SWEEP_FORWARD || sweep > I2C_SWEEP_FILTER) return I2C_EINVAL;
+  I2C_DISPATCH(p, family(p, sweep));
 }
 
 size_t i2c_workspace_bytes(int model_id, int dtype, int B, int T) {

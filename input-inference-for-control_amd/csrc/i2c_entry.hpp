@@ -29,6 +29,7 @@ struct ModelOps {
   int (*schedule)(int B, int T, int requested);
   int (*shift)(const I2cProblem*, void* post, const void* cell_init, const void* alpha_init, const void* z_new, void* action,
                void* stream);
+  int (*family)(const I2cProblem*, int sweep);
 };
 
 // defined by the translation units generated from i2c_model_tu.hip

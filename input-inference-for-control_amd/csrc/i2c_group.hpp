@@ -89,6 +89,7 @@ template <typename R, int G> struct Grp {
 template <class M, typename R> struct GConst {
   static constexpr int NX = M::NX, NZ = M::NZ, NT = M::NZT > 0 ? M::NZT : 1, NY = M::NY;
   R sig_xi0[NZ * NZ], sig_eta[NX * NX], sig_xiT0[NT * NT], sig_zeta[NY * NY], sig_x_term[NX * NX];
+  R qr[NZ * NZ], qf[NT * NT];  // blkdiag(Q, R) and Qf unpacked (i2c.py:781-789 accepts any symmetric weight)
   R qr_d[NZ], qf_d[NT];
 };
 // `c` and `zeta` must be addressable memory (the host's structs; on the device the kernel-argument segment itself, see
@@ -101,6 +102,8 @@ I2C_FN void gconst_fill(DST& k, const Consts<M, R>* c, const R* zeta, const int 
   for (int e = tid; e < NT * NT; e += nthreads) k.sig_xiT0[e] = c->sig_xiT0[tri_any(e / NT, e % NT)];
   for (int e = tid; e < NY * NY; e += nthreads) k.sig_zeta[e] = zeta ? zeta[tri_any(e / NY, e % NY)] : R(0);
   for (int e = tid; e < NX * NX; e += nthreads) k.sig_x_term[e] = c->sig_x_term[tri_any(e / NX, e % NX)];
+  for (int e = tid; e < NZ * NZ; e += nthreads) k.qr[e] = c->QR[tri_any(e / NZ, e % NZ)];
+  for (int e = tid; e < NT * NT; e += nthreads) k.qf[e] = c->Qf[tri_any(e / NT, e % NT)];
   for (int e = tid; e < NZ; e += nthreads) k.qr_d[e] = c->QR[tri(e, e)];
   for (int e = tid; e < NT; e += nthreads) k.qf_d[e] = c->Qf[tri(e, e)];
 }
@@ -491,6 +494,51 @@ I2C_FN void g_cost(const Grp<R, G>& g, const WD wd, const R* mz, const R* Sz, co
   *v = R(2) * t2 + R(4) * qd;
 }
 
+// The same for ANY symmetric weight W (N x N, unpacked in LDS): lane r forms row r of P = Sz W and (W err)_r;
+//   m = sum_r [err_r (W err)_r + Sz_r . W_r],  tr((Sz W)^2) = sum_r sum_l P[r][l] P[l][r]  (P exchanged through LDS matrix
+//   1, column r read back),  err^T W Sz W err = sum_r (W err)_r (Sz_r . W err).
+// The lane kernels' gaussian_cost (i2c_cell.hpp) is the one-lane form of the same sums.
+template <int N, typename R, int G, class WM>
+I2C_FN void g_cost_full(const Grp<R, G>& g, const WM W, const R* mz, const R* Sz, const R* zt, R* m, R* v) {
+  constexpr int LD = Grp<R, G>::LD;
+  const int r = g.r, rc = r < N ? r : N - 1;
+  const bool on = r < N;
+  R err[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) err[i] = mz[i] - zt[i];
+  R werr_own = R(0), trSW = R(0);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const R w = W[rc * N + j];
+    werr_own += w * err[j];
+    trSW += Sz[j] * w;
+  }
+  R werr[N];
+  g_gather<N>(g, 0, werr_own, werr);
+  const auto Pm = g.mat(1);
+  R quad = R(0);
+#pragma unroll
+  for (int j = 0; j < N; ++j) quad += Sz[j] * werr[j];
+  quad *= werr_own;
+  g.sync();
+#pragma unroll 1
+  for (int l = 0; l < N; ++l) {  // row r of P = Sz W (W is symmetric: its column l is its row l)
+    R pv = R(0);
+#pragma unroll
+    for (int j = 0; j < N; ++j) pv += Sz[j] * W[l * N + j];
+    if (on) Pm[r * LD + l] = pv;  // lanes beyond the weight's dimension own no row
+  }
+  g.sync();
+  R tr2 = R(0);
+#pragma unroll
+  for (int l = 0; l < N; ++l) tr2 += Pm[rc * LD + l] * Pm[l * LD + rc];
+  const R er = g_sel<N>(err, r);
+  R mm, t2, qd;
+  g_sum3<N>(g, on ? er * werr_own + trSW : R(0), on ? tr2 : R(0), on ? quad : R(0), &mm, &t2, &qd);
+  *m = mm;
+  *v = R(2) * t2 + R(4) * qd;
+}
+
 // addressing of one [E][B] cell block of a device buffer for the lanes of trajectory b
 template <typename R> struct GIO {
   Window w;
@@ -505,7 +553,7 @@ template <typename R> struct GIO {
 #ifdef I2C_HOST_SIM
     if (on) wst(w, 0u, (unsigned)e * rb + bo, v);
 #else
-    wst(w, 0u, on ? (unsigned)e * rb + bo : 0x80000000u, v);
+    wst(w, 0u, on ? (unsigned)e * rb + bo : 0x80000000u, v);  // launch_group's callers refuse windows of 2 GiB and more (Impl::group_supported)
 #endif
   }
 };
@@ -897,7 +945,7 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
 // the joint, posterior observation moments and their expected cost, controller from the factor of the posterior joint.
 // With a terminal state prior (covariance control, i2c.py:548-559) the chain starts from its product with the filtered state.
 // ------------------------------------------------------------------------------------------
-template <class M, typename R, int G, class KC>
+template <class M, typename R, int G, bool FULLW, class KC>
 I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, const CellArgs<R>& a, const int b,
                                        const Grp<R, G>& g_in) {
   using C = Consts<M, R>;
@@ -951,7 +999,10 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
       g_transform<M, TermStruct<M>, NX, NT, false>(g, 0, 1, 2, c.rule_x, m3m, L3, ObserveTermF<M, R>{c.params}, mzt, sztr, (R*)nullptr);
     }
     R tv;
-    g_cost<NT>(g, kc.qf_d, mzt, sztr, c.zg_term, &trT, &tv);
+    // FULLW: the instantiation for non-diagonal weights (a compile-time variant: in one kernel the general form's live state
+    // pushed the d = 16 backward sweep into scratch)
+    if constexpr (FULLW) g_cost_full<NT>(g, kc.qf, mzt, sztr, c.zg_term, &trT, &tv);
+    else g_cost<NT>(g, kc.qf_d, mzt, sztr, c.zg_term, &trT, &tv);
     if (r < NT) a.term_stats[(long)(3 + r) * B + b] = g_sel<NT>(mzt, r);
 #pragma unroll
     for (int l = 0; l < NT; ++l)
@@ -1103,7 +1154,8 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
     } else {
       g_transform<M, ObsStruct<M>, D, NZ, false>(g, 0, 1, 2, c.rule_xu, mu, Lm, ObserveF<M, R>{c.params}, mz, szr, (R*)nullptr);
     }
-    g_cost<NZ>(g, kc.qr_d, mz, szr, zt, &cm, &cv);
+    if constexpr (FULLW) g_cost_full<NZ>(g, kc.qr, mz, szr, zt, &cm, &cv);
+    else g_cost<NZ>(g, kc.qr_d, mz, szr, zt, &cm, &cv);
     sum_m += cm;
     sum_v += cv;
 
@@ -1149,7 +1201,7 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
 // ------------------------------------------------------------------------------------------
 // Closed-loop propagation (i2c.py:150-199, 1247-1251) in the group form.
 // ------------------------------------------------------------------------------------------
-template <class M, typename R, int G, class KC>
+template <class M, typename R, int G, bool FULLW, class KC>
 I2C_HD inline void propagate_group_body(const Consts<M, R>& c, const KC& kc, const PropArgs<R>& a, const int b,
                                         const Grp<R, G>& g_in) {
   using C = Consts<M, R>;
@@ -1238,7 +1290,8 @@ I2C_HD inline void propagate_group_body(const Consts<M, R>& c, const KC& kc, con
       // writes LDS matrices 1 and 2 only: the factor in matrix 0 stays for the dynamics transform below
       g_transform<M, ObsStruct<M>, D, NZ, false>(g, 0, 1, 2, c.rule_xu, mu0, L0, ObserveF<M, R>{c.params}, mz, szr, (R*)nullptr);
     }
-    g_cost<NZ>(g, kc.qr_d, mz, szr, zt, &cm, &cv);
+    if constexpr (FULLW) g_cost_full<NZ>(g, kc.qr, mz, szr, zt, &cm, &cv);
+    else g_cost<NZ>(g, kc.qr_d, mz, szr, zt, &cm, &cv);
     sum_m += cm;
     sum_v += cv;
 

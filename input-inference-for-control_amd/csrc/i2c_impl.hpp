@@ -206,16 +206,17 @@ static int launch_reduce(const Consts<M, R>& c, const CA& a, const MstepArgs<R>&
 // KIND selects the sweep; the bodies share their argument plumbing. Device: one wave per workgroup, the batch constants
 // and every group's exchange region in LDS. Host simulation: the G lanes of a group are G threads.
 enum { GK_FORWARD = 0, GK_BACKWARD = 1, GK_PROPAGATE = 2, GK_CKF = 3 };
-template <int KIND, class M, typename R, int G, class KC, class A>
+// FULLW: non-diagonal cost weights (only the sweeps that price the cost, backward and propagate, have that variant)
+template <int KIND, class M, typename R, int G, bool FULLW, class KC, class A>
 I2C_FN void group_body(const Consts<M, R>& c, const KC& kc, const A& a, const int b, const Grp<R, G>& g) {
   if constexpr (KIND == GK_FORWARD) forward_group_body<M, R, G>(c, kc, a, b, g);
-  if constexpr (KIND == GK_BACKWARD) backward_group_body<M, R, G>(c, kc, a, b, g);
-  if constexpr (KIND == GK_PROPAGATE) propagate_group_body<M, R, G>(c, kc, a, b, g);
+  if constexpr (KIND == GK_BACKWARD) backward_group_body<M, R, G, FULLW>(c, kc, a, b, g);
+  if constexpr (KIND == GK_PROPAGATE) propagate_group_body<M, R, G, FULLW>(c, kc, a, b, g);
   if constexpr (KIND == GK_CKF) ckf_group_body<M, R, G>(c, kc, a, b, g);
 }
 #ifdef I2C_HOST_SIM
-template <int KIND, class M, typename R, int G, class A>
-static int launch_group(const Consts<M, R>& c, const ZetaArg<M, R>* zeta, const A& a, void*) {
+template <int KIND, class M, typename R, int G, bool FULLW, class A>
+static int launch_group_w(const Consts<M, R>& c, const ZetaArg<M, R>* zeta, const A& a, void*) {
   GConst<M, R> kc;
   gconst_fill<M, R>(kc, &c, zeta ? zeta->v : (const R*)nullptr, 0, 1);
   for (int b = 0; b < c.B; ++b) {
@@ -223,13 +224,13 @@ static int launch_group(const Consts<M, R>& c, const ZetaArg<M, R>* zeta, const 
     HostBarrier bar(G);
     std::vector<std::thread> lanes;
     for (int r = 0; r < G; ++r)
-      lanes.emplace_back([&, r] { group_body<KIND, M, R, G>(c, kc, a, b, Grp<R, G>{r, sh.data(), &bar}); });
+      lanes.emplace_back([&, r] { group_body<KIND, M, R, G, FULLW>(c, kc, a, b, Grp<R, G>{r, sh.data(), &bar}); });
     for (auto& th : lanes) th.join();
   }
   return I2C_OK;
 }
 #else
-template <int KIND, class M, typename R, int G, class A>
+template <int KIND, class M, typename R, int G, bool FULLW, class A>
 __global__ __launch_bounds__(SWEEP_BLOCK) void k_group(const Consts<M, R> c, const ZetaArg<M, R> zeta, const int has_zeta, const A a) {
   __shared__ GConst<M, R> kc;
   __shared__ R sh[(SWEEP_BLOCK / G) * Grp<R, G>::SIZE];
@@ -246,18 +247,27 @@ __global__ __launch_bounds__(SWEEP_BLOCK) void k_group(const Consts<M, R> c, con
   const long b = lane / G;
   if (b >= c.B) return;
   const Grp<R, G> g{(int)(threadIdx.x % G), (lds_ptr<R>)(sh + (threadIdx.x / G) * Grp<R, G>::SIZE)};
-  group_body<KIND, M, R, G>(c, kc, a, (int)b, g);
+  group_body<KIND, M, R, G, FULLW>(c, kc, a, (int)b, g);
 }
-template <int KIND, class M, typename R, int G, class A>
-static int launch_group(const Consts<M, R>& c, const ZetaArg<M, R>* zeta, const A& a, void* stream) {
+template <int KIND, class M, typename R, int G, bool FULLW, class A>
+static int launch_group_w(const Consts<M, R>& c, const ZetaArg<M, R>* zeta, const A& a, void* stream) {
   ZetaArg<M, R> z{};
   if (zeta) z = *zeta;
   const long lanes = (long)c.B * G;
-  hipLaunchKernelGGL((k_group<KIND, M, R, G, A>), dim3((unsigned)((lanes + SWEEP_BLOCK - 1) / SWEEP_BLOCK)), dim3(SWEEP_BLOCK), 0,
+  hipLaunchKernelGGL((k_group<KIND, M, R, G, FULLW, A>), dim3((unsigned)((lanes + SWEEP_BLOCK - 1) / SWEEP_BLOCK)), dim3(SWEEP_BLOCK), 0,
                      (hipStream_t)stream, c, z, zeta ? 1 : 0, a);
   return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
 }
 #endif
+
+template <int KIND, class M, typename R, int G, class A>
+static int launch_group(const Consts<M, R>& c, const ZetaArg<M, R>* zeta, const A& a, void* stream) {
+  if constexpr (KIND == GK_BACKWARD || KIND == GK_PROPAGATE) {
+    const bool fullw = !c.qr_diag || (KIND == GK_BACKWARD && c.has_Qf && !c.qf_diag);
+    if (fullw) return launch_group_w<KIND, M, R, G, true>(c, zeta, a, stream);
+  }
+  return launch_group_w<KIND, M, R, G, false>(c, zeta, a, stream);
+}
 
 template <typename R> static Rule<R> make_rule(const I2cProblem* p, int dim) {
   // CubatureQuadrature.weights, i2c/exp_types.py:40-49
@@ -374,11 +384,45 @@ template <class M, typename R, typename S = R> struct Impl {
     if (p->group_lanes == -1) return M::GROUP_ONLY ? I2C_ENOTSUP : 0;  // one lane per trajectory, no hybrid forward
     return (HAS_GROUP && p->group_lanes == G) ? 1 : I2C_ENOTSUP;
   }
-  // what the group form does not cover: other inference rules, non-diagonal cost weights
-  static int group_supported(const I2cProblem* p, const C& c) {
+  // what the group form does not cover: other inference rules; per-cell blocks beyond the 2 GiB the predicated stores of
+  // GIO::st_if park their masked-off lanes behind (the parked offset must stay out of the buffer window)
+  static int group_supported(const I2cProblem* p, const C&) {
     if (p->inference != I2C_INF_CUBATURE) return I2C_ENOTSUP;
-    if (!c.qr_diag || (c.has_Qf && !c.qf_diag)) return I2C_ENOTSUP;
+    constexpr long EMAX = C::E_FWD > C::E_POST ? (C::E_FWD > C::E_PROP ? C::E_FWD : C::E_PROP) : (C::E_POST > C::E_PROP ? C::E_POST : C::E_PROP);
+    if (EMAX * (long)p->B * (long)sizeof(R) >= (1L << 31)) return I2C_EINVAL;
     return I2C_OK;
+  }
+  // THE place that decides which kernel family serves a sweep (i2c_kernel_family() reports it): I2C_FAMILY_* or an error code.
+  //   explicit request (group_lanes = G or -1) -> that family or I2C_ENOTSUP;
+  //   default: the lane kernels, except (a) models that only have group kernels, (b) the hybrid default of the d >= 7 lane
+  //   models: the FORWARD sweep runs on the group kernels while the batch leaves every group wave a SIMD of its own
+  //   (measured, planar quadrotor d = 8 at B = 4096: forward 0.51 -> 0.40 ms, while its chunked lane backward stays the
+  //   faster one; the buffers of the families are the same, so the backward schedules are unaffected).
+  static int family(const I2cProblem* p, const C& c, const int sweep) {
+    if constexpr (MIXED) {  // fp64 arithmetic on fp32-stored messages: the cubature EM path of the one-lane kernels only
+      if (p->inference != I2C_INF_CUBATURE || use_group(p) != 0) return I2C_ENOTSUP;
+      if (sweep != I2C_SWEEP_FORWARD && sweep != I2C_SWEEP_BACKWARD) return I2C_ENOTSUP;
+      return LANE ? I2C_FAMILY_LANE : I2C_ENOTSUP;
+    }
+    int grp = use_group(p);
+    if (grp < 0) return grp;
+    if constexpr (HAS_GROUP && M::GROUP_FORWARD_AUTO) {
+      if (sweep == I2C_SWEEP_FORWARD && grp == 0 && p->group_lanes == 0 && (long)p->B * G <= I2C_GROUP_FORWARD_MAX_LANES &&
+          group_supported(p, c) == I2C_OK)
+        grp = 1;
+    }
+    if (grp) {
+      if constexpr (HAS_GROUP) {
+        const int rc = group_supported(p, c);
+        return rc != I2C_OK ? rc : I2C_FAMILY_GROUP;
+      }
+      return I2C_ENOTSUP;
+    }
+    return LANE ? I2C_FAMILY_LANE : I2C_ENOTSUP;
+  }
+  static int family_of(const I2cProblem* p, int sweep) {
+    const C c = make_consts<M, R>(p, 0.0, 0);
+    return family(p, c, sweep);
   }
 
   // the sigma-point forward sweep of the one-lane kernels, for either storage type
@@ -400,7 +444,8 @@ template <class M, typename R, typename S = R> struct Impl {
                      void* stream) {
     const C c = make_consts<M, R>(p, 0.0, p->inference == I2C_INF_LINEARIZE ? p->expert_controller : 0);
     if constexpr (MIXED) {  // fp64 arithmetic on fp32-stored messages: the cubature path of the one-lane kernels only
-      if (p->inference != I2C_INF_CUBATURE || use_group(p) != 0) return I2C_ENOTSUP;
+      const int fam = family(p, c, I2C_SWEEP_FORWARD);
+      if (fam < 0) return fam;
       FwdArgs<R, S> am{(const S*)prior, (S*)fwd, (S*)prior_out, (const R*)p->x0, (const R*)p->sig_x0,
                        (const R*)p->z,  (const R*)p->alpha, (const R*)p->alpha_cell, p->feedforward, status, p->expert};
       return forward_lane(p, c, am, stream);
@@ -412,19 +457,10 @@ template <class M, typename R, typename S = R> struct Impl {
                          void* stream) {
     FwdArgs<R> a{(const R*)prior, (R*)fwd, (R*)prior_out, (const R*)p->x0, (const R*)p->sig_x0,
                  (const R*)p->z,  (const R*)p->alpha, (const R*)p->alpha_cell, p->feedforward, status, p->expert};
-    int grp = use_group(p);
-    if (grp < 0) return grp;
-    // Hybrid default (measured, planar quadrotor d = 8 at B = 4096: forward 0.51 -> 0.40 ms, while its chunked lane backward
-    // stays the faster one): with no explicit request the FORWARD sweep of such a model runs on the group kernels as long
-    // as the batch leaves every group wave a SIMD of its own; the buffers are the same, so the backward schedules are unaffected
-    if constexpr (HAS_GROUP && M::GROUP_FORWARD_AUTO) {
-      if (grp == 0 && p->group_lanes == 0 && (long)p->B * G <= 64L * 1024 && group_supported(p, c) == I2C_OK) grp = 1;
-    }
-    if (grp) {
-      if constexpr (HAS_GROUP) {
-        const int rc = group_supported(p, c);
-        return rc != I2C_OK ? rc : launch_group<GK_FORWARD, M, R, G>(c, nullptr, a, stream);
-      }
+    const int fam = family(p, c, I2C_SWEEP_FORWARD);
+    if (fam < 0) return fam;
+    if (fam == I2C_FAMILY_GROUP) {
+      if constexpr (HAS_GROUP) return launch_group<GK_FORWARD, M, R, G>(c, nullptr, a, stream);
     }
     if constexpr (LANE) {
       if (p->inference == I2C_INF_LINEARIZE) return launch(k_forward_lin<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, a);
@@ -469,7 +505,8 @@ template <class M, typename R, typename S = R> struct Impl {
     MstepArgs<R> ms{(const R*)term_stats, fuse ? (R*)p->alpha : nullptr, fuse ? (R*)fuse->stats_out : nullptr,
                     fuse ? fuse->update : 0};
     if constexpr (MIXED) {
-      if (p->inference != I2C_INF_CUBATURE || use_group(p) != 0) return I2C_ENOTSUP;
+      const int fam = family(p, c, I2C_SWEEP_BACKWARD);
+      if (fam < 0) return fam;
       CellArgs<R, S> am{(const S*)fwd, (const S*)xm,   (const R*)p->z, (S*)post,  (S*)zpost,
                         (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   (const R*)p->alpha};
       return backward_lane(p, c, am, ms, fuse, stream);
@@ -481,13 +518,10 @@ template <class M, typename R, typename S = R> struct Impl {
                           void* zpost, void* cell_stats, void* term_stats, int32_t* status, void* stream, MstepFuse* fuse) {
     CellArgs<R> a{(const R*)fwd, (const R*)xm,   (const R*)p->z, (R*)post,  (R*)zpost,
                   (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   (const R*)p->alpha};
-    const int grp = use_group(p);
-    if (grp < 0) return grp;
-    if (grp) {  // one schedule: the group walks T-1..0 (the fused form); backward_mode is ignored
-      if constexpr (HAS_GROUP) {
-        const int rc = group_supported(p, c);
-        return rc != I2C_OK ? rc : launch_group<GK_BACKWARD, M, R, G>(c, nullptr, a, stream);
-      }
+    const int fam = family(p, c, I2C_SWEEP_BACKWARD);
+    if (fam < 0) return fam;
+    if (fam == I2C_FAMILY_GROUP) {  // one schedule: the group walks T-1..0 (the fused form); backward_mode is ignored
+      if constexpr (HAS_GROUP) return launch_group<GK_BACKWARD, M, R, G>(c, nullptr, a, stream);
     }
     if constexpr (LANE) {
       if (p->inference == I2C_INF_LINEARIZE) {  // one schedule: a lane per trajectory walks T-1..0
@@ -593,9 +627,9 @@ template <class M, typename R, typename S = R> struct Impl {
     ZetaArg<M, R> z;
     for (int i = 0; i < sym(M::NY); ++i) z.v[i] = (R)sig_zeta[i];
     CkfArgs<R> a{(const R*)y, (const R*)u, (R*)mu, (R*)cov, status};
-    const int grp = use_group(p);
-    if (grp < 0) return grp;
-    if (grp) {
+    const int fam = family(p, c, I2C_SWEEP_FILTER);  // also refuses what the family does not cover (a non-cubature rule)
+    if (fam < 0) return fam;
+    if (fam == I2C_FAMILY_GROUP) {
       if constexpr (HAS_GROUP) return launch_group<GK_CKF, M, R, G>(c, &z, a, stream);
     }
     if constexpr (LANE) return launch(k_ckf<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, z, a);
@@ -644,13 +678,10 @@ template <class M, typename R, typename S = R> struct Impl {
     const C c = make_consts<M, R>(p, 0.0, use_expert);
     PropArgs<R> a{(const R*)post, (R*)prop, (R*)prop_stats, (const R*)p->x0, (const R*)p->sig_x0,
                   (const R*)p->z, p->feedforward, status, p->expert};
-    const int grp = use_group(p);
-    if (grp < 0) return grp;
-    if (grp) {
-      if constexpr (HAS_GROUP) {
-        const int rc = group_supported(p, c);
-        return rc != I2C_OK ? rc : launch_group<GK_PROPAGATE, M, R, G>(c, nullptr, a, stream);
-      }
+    const int fam = family(p, c, I2C_SWEEP_PROPAGATE);
+    if (fam < 0) return fam;
+    if (fam == I2C_FAMILY_GROUP) {
+      if constexpr (HAS_GROUP) return launch_group<GK_PROPAGATE, M, R, G>(c, nullptr, a, stream);
     }
     if constexpr (LANE) {
       if (p->inference == I2C_INF_GAUSS_HERMITE) return launch(k_propagate<M, R, true>, p->B, 1, SWEEP_BLOCK, stream, c, a);
@@ -675,13 +706,14 @@ template <class M> static void fill_dims(I2cDims* d) {
   d->ny = M::NY;
   d->group_lanes = M::GROUP;
   d->group_only = M::GROUP_ONLY ? 1 : 0;
+  d->wave = 0;
 }
 
 template <class M, typename R, typename S = R> const ModelOps* make_ops() {
   using I = Impl<M, R, S>;
   static const ModelOps ops = {&I::forward, &I::backward,  &I::mstep,        &I::learn,           &I::ckf,
                                &I::rollout, &I::propagate, &I::riccati,   &I::mpc_step,        &fill_dims<M>,
-                               &workspace_elems<M>, &I::schedule, &I::shift};
+                               &workspace_elems<M>, &I::schedule, &I::shift, &I::family_of};
   return &ops;
 }
 

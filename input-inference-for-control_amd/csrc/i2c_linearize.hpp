@@ -122,16 +122,17 @@ I2C_HD inline void forward_lin_body(const Consts<M, R>& c, const FwdArgs<R>& a, 
   const R alpha_traj = a.alpha[b];
 
   for (int t = 0; t < T; ++t) {
-    const R* pri = a.prior + ((long)t * C::E_POST) * B + b;
+    const int tr = c.row(t);  // row of the persistent per-cell buffers (ring of the MPC loop, Consts::t0)
+    const R* pri = a.prior + ((long)tr * C::E_POST) * B + b;
     R* out = a.fwd + ((long)t * C::E_FWD) * B + b;
-    const R alpha = a.alpha_cell ? a.alpha_cell[(long)t * B + b] : alpha_traj;
+    const R alpha = a.alpha_cell ? a.alpha_cell[(long)tr * B + b] : alpha_traj;
     R zt[NZ];
 #pragma unroll
-    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
+    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)tr * NZ + k) * B + b] : c.zg[k];
 
     // ---- 1. joint prior over (x, u) (i2c.py:249-276) ----
     R mu0[D], S0[sym(D)];
-    if (a.ff[t]) {
+    if (a.ff[tr]) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) mu0[i] = mu_x[i];
 #pragma unroll
@@ -149,7 +150,7 @@ I2C_HD inline void forward_lin_body(const Consts<M, R>& c, const FwdArgs<R>& a, 
       for (int i = 0; i < sym(D); ++i) psig[i] = pri[(long)(D + i) * B];
 #pragma unroll
       for (int i = 0; i < NU * NX; ++i) Kt[i] = pri[(long)(D + sym(D) + i) * B];
-      if (a.expert ? a.expert[t] != 0 : c.use_expert != 0) {
+      if (a.expert ? a.expert[tr] != 0 : c.use_expert != 0) {
         R S[sym(NX)], delta[NX];
 #pragma unroll
         for (int i = 0; i < sym(NX); ++i) S[i] = psig[i] + sig_x[i];
@@ -302,7 +303,7 @@ I2C_HD inline void backward_lin_body(const Consts<M, R>& c, const CellArgs<R>& a
 #pragma unroll
     for (int e = 0; e < D * NX; ++e) J[e] = in[(long)(O_J + e) * B];
 #pragma unroll
-    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
+    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k];
 
     // RTS update, controller and the cubature cost of the posterior (shared with the sigma-point path)
     R ctl[C::E_POST - D - sym(D)], mzq[NZ], Szq[sym(NZ)], cm, cv;
@@ -431,7 +432,7 @@ I2C_HD inline void riccati_body(const Consts<M, R>& c, const RiccatiArgs<R>& a, 
   for (int t = T - 1; t >= 0; --t) {
     const R* pr = a.prior + ((long)t * (D + sym(D))) * B + b;
     const R* in = a.fwd + ((long)t * C::E_FWD) * B + b;
-    R* po = a.post + ((long)t * C::E_POST) * B + b;
+    R* po = a.post + ((long)c.row(t) * C::E_POST) * B + b;
     R mu0[D], S0[sym(D)], mu1[D], S1[sym(D)], m3f[NX], S3f[sym(NX)], zt[NZ];
 #pragma unroll
     for (int e = 0; e < D; ++e) {
@@ -448,7 +449,7 @@ I2C_HD inline void riccati_body(const Consts<M, R>& c, const RiccatiArgs<R>& a, 
 #pragma unroll
     for (int e = 0; e < sym(NX); ++e) S3f[e] = in[(long)(O_S3 + e) * B];
 #pragma unroll
-    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)t * NZ + k) * B + b] : c.zg[k];
+    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k];
 
     // lambda_x3_f, nu_x3_f (i2c.py:346)
     R tmpx[NX * NX], lam3f[NX * NX], nu3f[NX];

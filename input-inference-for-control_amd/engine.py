@@ -67,7 +67,7 @@ class BatchedI2c:
         # Precision. dtype = ARITHMETIC type: float64 is the reference's arithmetic and the only parity-grade one.
         #   storage_dtype=torch.float32 with dtype=torch.float64: the mixed mode I2C_F64_F32S -- fp64 arithmetic on fp32-STORED
         #     per-cell buffers (post, fwd, xm, zpost, prior_out); half the HBM bytes, deviation from fp64 bounded
-        #     (tests/test_hip_precision.py); cubature EM path of the one-lane kernels only.
+        #     (tests/test_precision.py); cubature EM path of the one-lane kernels only.
         #   dtype=torch.float32: fp32 arithmetic. NOT parity-grade (the curvature terms of the sigma-point transform are
         #     below fp32 resolution: O(1) deviation after a few EM iterations with status 0), so it has to be asked for
         #     explicitly with allow_inexact=True (tolerance sweeps).
@@ -311,6 +311,23 @@ class BatchedI2c:
         p.feedforward = self.feedforward.data_ptr()
         p.expert = self.expert_cells.data_ptr() if self.expert_cells is not None else None
         return p
+
+    def kernel_family(self, sweep="forward"):
+        """Which kernel family serves a sweep of THIS problem ("lane", "group" or "wave"): i2c_kernel_family(), the library's
+        single resolver of group_lanes, model defaults and batch thresholds. The last bits of a result depend on it."""
+        code = {"forward": _native.SWEEP_FORWARD, "backward": _native.SWEEP_BACKWARD, "propagate": _native.SWEEP_PROPAGATE,
+                "filter": _native.SWEEP_FILTER}[sweep]
+        rc = self.lib.i2c_kernel_family(C.byref(self._problem), code)
+        self._check(0 if rc > 0 else (rc or -1), "i2c_kernel_family")
+        return _native.FAMILY_NAMES[rc]
+
+    @property
+    def forward_family(self):
+        return self.kernel_family("forward")
+
+    @property
+    def backward_family(self):
+        return self.kernel_family("backward")
 
     def refresh_problem(self):
         """Rebuild the C problem descriptor after changing host-side constants / tensors."""

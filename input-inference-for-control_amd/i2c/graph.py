@@ -537,7 +537,7 @@ class I2cGraph:
         np.save(os.path.join(res_dir, "z_plan.npy"), sq(mz))
 
     _STATE_TENSORS = ("post", "alpha", "temp", "feedforward", "status", "x0", "sig_x0", "cell_init")
-    _STATE_OPTIONAL = ("z", "alpha_cell", "alpha_init")
+    _STATE_OPTIONAL = ("z", "alpha_cell", "alpha_init", "expert_cells")
     _STATE_LISTS = ("alphas", "alphas_desired", "alphas_pf", "costs_m", "costs_m_var", "costs_pf", "costs_pf_var", "kl_terms")
 
     def state_dict(self):
@@ -570,10 +570,12 @@ class I2cGraph:
             e.prior.copy_(sd["prior"])
         if sd["alpha_cell"] is not None:
             e.enable_per_cell_alpha()
+        if sd.get("expert_cells") is not None and e.expert_cells is None:
+            e.set_cell_expert(0, e.use_expert_controller)  # allocates the per-cell flags (and hands them to the library)
         if sd["z"] is not None and e.z is None:
             e.set_targets(np.transpose(sd["z"].double().numpy(), (2, 0, 1)))
         for k in self._STATE_OPTIONAL:
-            if sd[k] is not None:
+            if sd.get(k) is not None:
                 getattr(e, k).copy_(sd[k])
         for k in self._STATE_LISTS:
             setattr(e, k, [t.to(e.device) for t in sd[k]])

@@ -36,6 +36,7 @@ class MpcPolicy:
             e.set_targets(zt[:, : e.H])
         self._init_state = {k: getattr(e, k).clone() for k in ("post", "alpha", "alpha_cell", "feedforward", "x0", "sig_x0")}
         self._init_terminal = e.terminal_cell
+        self._init_t0 = e.t0  # the snapshot is in physical row order: it is only valid with the ring where it was taken
         self._init_z = None if e.z is None else e.z.clone()
         self.record_history = self.B == 1
         self.xu_history, self.z_history = [], []
@@ -58,8 +59,8 @@ class MpcPolicy:
             e.z.copy_(self._init_z)
         e.status.zero_()
         e.terminal_cell = self._init_terminal
-        e.t0 = 0  # the snapshot was taken with the ring at its origin
-        e._problem.terminal_cell, e._problem.t0 = int(e.terminal_cell), 0
+        e.t0 = self._init_t0  # rows were cloned in physical order, at this offset of the ring
+        e._problem.terminal_cell, e._problem.t0 = int(e.terminal_cell), int(e.t0)
         self.xu_history, self.z_history = [], []
 
     def _squeeze(self, a, column=False):

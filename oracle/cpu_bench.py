@@ -2,9 +2,11 @@
 
     python oracle/cpu_bench.py [--horizon 200] [--batch 512] [--iters 10] [--workers N]
 
-Each worker process runs the batch-vectorised NumPy oracle on its own `batch` pendulum trajectories
-(trajectories are independent, so W workers = W x the work); the rate is all cell-iterations divided by
-the wall time of the slowest worker. Prints one JSON line. Imports NumPy only (no torch, no GPU).
+Each worker process runs the NumPy oracle on its own `batch` pendulum trajectories (trajectories are independent, so
+W workers = W x the work); the rate is all cell-iterations divided by the wall time of the slowest worker.
+`--batch 512` (default) is the batch-vectorised form; `--batch 1` is the REFERENCE's shape: one trajectory per process, a
+Python loop over the T cells with NumPy calls on (d x d) arrays. Workers: one per core, up to 128 -- the count is
+in the line. Prints one JSON line. Imports NumPy only (no torch, no GPU).
 """
 import argparse
 import json
@@ -45,10 +47,10 @@ def main():
     ap.add_argument("--horizon", type=int, default=200)
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--workers", type=int, default=0, help="0 = one per core, capped at 32 (beyond that the NumPy workers only contend for memory bandwidth)")
+    ap.add_argument("--workers", type=int, default=0, help="0 = one per core, capped at 128")
     a = ap.parse_args()
     cores = os.cpu_count() or 1
-    W = a.workers if a.workers > 0 else min(cores, 32)
+    W = a.workers if a.workers > 0 else min(cores, 128)
     t0 = time.perf_counter()
     if W == 1:
         times = [_work((0, a.horizon, a.batch, a.iters))]
@@ -61,7 +63,8 @@ def main():
         "unit": "timestep-messages/s",
         "cores": W,
         "kind": "port",
-        "sample": f"oracle/i2c_numpy.py (batch-vectorised NumPy fp64), pendulum T={a.horizon}: {W} worker processes x {a.batch} "
+        "shape": "batch-vectorised" if a.batch > 1 else "reference-shaped: one trajectory per process, Python loop over the cells",
+        "sample": f"oracle/i2c_numpy.py ({'batch-vectorised ' if a.batch > 1 else ''}NumPy fp64), pendulum T={a.horizon}: {W} worker processes x {a.batch} "
                   f"trajectories x {a.iters} EM iterations after 1 warm-up; slowest worker {wall:.1f} s, whole leg "
                   f"{time.perf_counter() - t0:.1f} s on a host with {cores} cores",
         "single_worker_rate": a.batch * a.horizon * a.iters / min(times),

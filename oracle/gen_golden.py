@@ -516,6 +516,48 @@ def case_em_quad12_propagate(T=12, n_detail=2, n_total=4):
     save("em_quad12_T12_propagate", out)
 
 
+def _coupled(W, rng, strength=0.3):
+    """A symmetric positive-definite weight with off-diagonal entries: D^1/2 (I + s (A + A^T) / (2 |A|)) D^1/2."""
+    n = W.shape[0]
+    A = rng.normal(size=(n, n))
+    A = 0.5 * (A + A.T)
+    np.fill_diagonal(A, 0.0)
+    A *= strength / np.abs(np.linalg.eigvalsh(A)).max()
+    d = np.sqrt(np.diag(W))
+    return (np.eye(n) + A) * d[:, None] * d[None, :]
+
+
+def case_em_quad12_nondiag(T=12, n_detail=2, n_total=5):
+    """NON-DIAGONAL Q, R and Qf (i2c.py:781-789 takes any symmetric weight) on the 12-state quadrotor, with closed-loop
+    propagation (its cost statistics use the same weights): pins the general-weight cost of the multi-lane kernels."""
+    model = _reference_quad12()
+    rng = np.random.default_rng(15)
+    Q, R, Qf = _coupled(QUAD12_Q, rng), _coupled(QUAD12_R, rng), _coupled(QUAD12_Q / 5.0, rng)
+    mu_u = 0.25 * model.gravity * np.ones((T, 4)) + 1e-2 * rng.normal(size=(T, 4))
+    sig_u = 1e-2 * np.eye(4)
+    g = I2cGraph(model, T, Q, R, Qf, 1.0, 0.5, mu_u, sig_u, None, None, CubatureQuadrature(1, 0, 0))
+    g._propagate = True
+    out = problem_inputs("Quadrotor12", model, T, Q, R, Qf, 1.0, 0.5, mu_u, sig_u, None, None, (1, 0, 0), propagate=True)
+    run_em(g, n_detail, n_total, out, pre_propagate=True)
+    save("em_quad12_nondiag_T12", out)
+
+
+def case_em_dcp_nondiag(T=30, n_detail=2, n_total=6):
+    """Non-diagonal weights on the double cartpole (nz = 9 with sin / cos features): the general-weight cost with a
+    non-identity observation, for the lane and the group kernels."""
+    model = make_env_model("DoubleCartpoleKnown", None)
+    rng = np.random.default_rng(16)
+    sf = 1e-3
+    Q = _coupled(sf * np.diag([1.0, 1.0, 100.0, 1.0, 100.0, 10.0, 1.0, 1.0]), rng)
+    R = sf * np.diag([0.1])
+    Qf = _coupled(sf * np.diag([1.0, 1.0, 100.0, 1.0, 100.0, 10.0, 1.0, 1.0]), rng)
+    mu_u = 1e-2 * rng.normal(size=(T, 1))
+    g = I2cGraph(model, T, Q, R, Qf, 0.05, 0.99, mu_u, np.eye(1), None, None, CubatureQuadrature(1, 0, 0))
+    out = problem_inputs("DoubleCartpoleKnown", model, T, Q, R, Qf, 0.05, 0.99, mu_u, np.eye(1), None, None, (1, 0, 0))
+    run_em(g, n_detail, n_total, out)
+    save("em_dcp_nondiag_T30", out)
+
+
 def case_mpc_quad12():
     """mpc_quad.py:538-650 (i2c, feedback, low noise) on the 12-state quadrotor: tracking a moving position target."""
     from i2c.policy.mpc import PartiallyObservedMpcPolicy
@@ -889,6 +931,8 @@ CASES = {
     "em_quad12": case_em_quad12,
     "em_quad12_pf": case_em_quad12_propagate,
     "mpc_quad12": case_mpc_quad12,
+    "em_quad12_nondiag": case_em_quad12_nondiag,
+    "em_dcp_nondiag": case_em_dcp_nondiag,
     "rollouts": case_rollouts,
     "i2c_run": case_i2c_run,
     "i2c_run_lin": case_i2c_run_linearize,

@@ -35,6 +35,45 @@ def test_bench_self_launches_two_ranks():
 def test_bench_single_process_contract():
     out = _run(["--test-hostsim", "--batch", "5", "--horizon", "10", "--steps", "2", "--warmup", "1", "--no-extra"])
     assert out["n_gpus"] == 1 and out["final_allgather_ms"] is None and out["strong_scaling"] is None
+    assert out["rccl_world_size"] is None  # no process group in the host-simulation mode
     for key in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "vs_baseline"):
         assert key in out
     assert out["dtype"] == "f64" and out["roofline"]["bound"] == "hbm" and out["roofline"]["peak"] == 8000.0
+
+
+# ---- on the GPU box: the RCCL path of the N = 1 line (round-2 review: it had never been executed on hardware) ----------
+import socket  # noqa: E402
+
+import pytest  # noqa: E402
+
+_FAST = ["--steps", "2", "--warmup", "1", "--no-extra", "--no-saturated", "--no-cpu-baseline", "--batch", "256", "--horizon", "40"]
+
+
+def _child(cmd):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)  # a fresh child: nothing is re-executed
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_plain_single_gpu_line_carries_the_rccl_all_gather():
+    """`python bench.py` as the driver runs it at N = 1: a single-rank RCCL group in-process, the all-gather timed."""
+    out = _child([sys.executable, os.path.join(ROOT, "bench.py")] + _FAST)
+    assert out["rccl_error"] is None, out["rccl_error"]
+    assert out["rccl_world_size"] == 1 and out["rccl_backend"] == "nccl"
+    assert out["final_allgather_ms"] is not None and out["final_allgather_ms"] > 0
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["failed_trajectories"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_with_one_rank():
+    """The driver's N > 1 form with --nproc-per-node=1: rendezvous on 127.0.0.1, init_process_group("nccl"), all-gather."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = _child([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                  "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1"] + _FAST)
+    assert out["rccl_world_size"] == 1 and out["rccl_backend"] == "nccl" and out["final_allgather_ms"] > 0

@@ -29,6 +29,8 @@ GOLDEN = [
     ("em_quadrotor_T20", 1e-6, 1e-5),
     ("em_quad12_T20", 1e-6, 1e-5),            # 12-state quadrotor: group kernels only (d = 16)
     ("em_quad12_T12_propagate", 1e-6, 1e-5),
+    ("em_quad12_nondiag_T12", 1e-6, 1e-5),    # non-diagonal Q, R, Qf (i2c.py:781-789), with propagation
+    ("em_dcp_nondiag_T30", 1e-6, 1e-5),
 ]
 
 
@@ -47,6 +49,7 @@ GROUP_GOLDEN = [
     ("em_pendulum_T50_propagate", 1e-8, 1e-7),
     ("em_quadrotor_T20", 1e-6, 1e-5),              # G = 8
     ("em_covctrl_T100", 1e-7, 1e-6),               # covariance control: tempered terminal prior, propagation, KL
+    ("em_dcp_nondiag_T30", 1e-6, 1e-5),            # non-diagonal weights in the group form (g_cost_full)
 ]
 
 

@@ -24,6 +24,8 @@ GOLDEN = [
     ("em_quadrotor_T20", 1e-7, 1e-6),
     ("em_quad12_T20", 1e-7, 1e-6),            # group kernels only (d = 16)
     ("em_quad12_T12_propagate", 1e-7, 1e-6),
+    ("em_quad12_nondiag_T12", 1e-7, 1e-6),    # non-diagonal Q, R, Qf (i2c.py:781-789), with propagation
+    ("em_dcp_nondiag_T30", 1e-7, 1e-6),       # the same on a trigonometric observation (hybrid: group forward, lane backward)
 ]
 
 
@@ -44,6 +46,7 @@ GROUP_GOLDEN = [
     ("em_pendulum_T50_propagate", 1e-9, 1e-8, None),  # propagation with the expert controller
     ("em_quadrotor_T20", 1e-7, 1e-6, None),           # G = 8, identity observation
     ("em_covctrl_T100", 1e-8, 1e-7, 8),               # covariance control: tempered terminal prior, propagation, KL
+    ("em_dcp_nondiag_T30", 1e-7, 1e-6, None),         # non-diagonal weights: g_cost_full on nz = 9
 ]
 
 
@@ -56,6 +59,7 @@ def test_hostsim_group_kernels_vs_reference_golden(lib, name, tol_d, tol_s, n_it
 # goldens above no longer reach their one-lane forward kernels: group_lanes = -1 forces one lane per trajectory everywhere.
 LANE_GOLDEN = [
     ("em_dcp_T60", 1e-7, 1e-6),
+    ("em_dcp_nondiag_T30", 1e-7, 1e-6),
     ("em_quadrotor_T20", 1e-7, 1e-6),
 ]
 
@@ -71,20 +75,41 @@ def test_hostsim_group_kernels_batch_vs_oracle(lib):
 
 
 def test_group_kernels_refuse_what_they_do_not_cover(lib):
-    """Non-diagonal cost weights (and the other inference rules) are not available in the group form: the library says
-    I2C_ENOTSUP instead of computing something else."""
-    import numpy as np
-    from golden_util import Case, load_case
+    """The other inference rules are not available in the group form: the library says I2C_ENOTSUP instead of computing
+    something else. (Non-diagonal cost weights were refused until round 3: now covered, goldens em_*_nondiag_*.)"""
+    from golden_util import load_case
 
-    g = load_case("em_pendulum_T40_quad_general")
-    dense = Case({**g, "Q": np.array([[2.0, 0.3, -0.1], [0.3, 50.0, 0.4], [-0.1, 0.4, 1.5]])})
-    eng = parity.engine_from_case(dense, lib, "cpu", group_lanes=True)
+    eng = parity.engine_from_case(load_case("lin_pendulum_T100"), lib, "cpu", keep_xm=True)
+    eng._problem.group_lanes = 4  # behind the engine's own argument check
     with pytest.raises(RuntimeError, match="-2"):
         eng.forward_sweep()
     with pytest.raises(ValueError):
         parity.engine_from_case(load_case("em_pendulum_T200"), lib, "cpu", group_lanes=16)
     with pytest.raises(ValueError):  # d = 16 has no one-lane kernels
         parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu", group_lanes=-1)
+
+
+def test_group_kernels_dense_weights_match_lane_kernels(lib):
+    """A dense Q on the pendulum: the group form's general-weight cost (g_cost_full) against the lane kernels' gaussian_cost."""
+    import numpy as np
+    import torch
+    from golden_util import Case, load_case
+
+    g = load_case("em_pendulum_T40_quad_general")
+    dense = Case({**g, "Q": np.array([[2.0, 0.3, -0.1], [0.3, 50.0, 0.4], [-0.1, 0.4, 1.5]]),
+                  "Qf": np.array([[1.0, 0.2, 0.0], [0.2, 20.0, -0.3], [0.0, -0.3, 2.5]])})
+    runs = []
+    for gl in (0, True):
+        eng = parity.engine_from_case(dense, lib, "cpu", group_lanes=gl)
+        for _ in range(3):
+            eng.learn_msgs()
+        assert eng.failures() == []
+        runs.append(eng)
+    a, b = runs
+    assert (a.forward_family, b.forward_family) == ("lane", "group")
+    for x, y in zip(a.costs_m + a.costs_m_var + a.alphas, b.costs_m + b.costs_m_var + b.alphas):
+        assert torch.allclose(x, y, rtol=1e-10, atol=0)
+    assert torch.allclose(a.post, b.post, rtol=1e-9, atol=1e-12)
 
 
 LINEARIZE = [

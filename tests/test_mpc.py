@@ -214,3 +214,71 @@ def test_native_mpc_step_cpu(name):
 @pytest.mark.parametrize("name", ["mpc_pendulum_fb", "mpc_quadrotor_fb", "mpc_quad12_fb"])
 def test_native_mpc_step_gpu(name):
     _native_step_equals_stepwise(name, None, "cuda")
+
+
+def _ring_equals_unrolled(inference, lib, device):
+    """The receding-horizon ring (I2cProblem.t0) for EVERY inference rule: an engine whose horizon has been shifted k times
+    must give, bit for bit, the sweeps of an engine holding the same cells in cell order with the ring at its origin.
+    (The reference's MpcPolicy accepts any I2cGraph, mpc.py:16-33; round 2 refused t0 != 0 outside the cubature path.)"""
+    from i2c.exp_types import GaussHermiteQuadrature, Linearize
+    from i2c.model import make_env_model
+    from i2c.policy.mpc import MpcPolicy
+
+    rule = {"cubature": CubatureQuadrature(1, 0, 0), "gauss_hermite": GaussHermiteQuadrature(3), "linearize": Linearize()}[inference]
+    model = make_env_model("PendulumKnown")
+    T, B = 9, 3
+    rng = np.random.default_rng(5)
+    Q, R = np.diag([1.0, 100.0, 1.0]), np.diag([2.0])
+    mu_u = 1e-1 * rng.normal(size=(B, T, 1))
+    x0 = np.array([np.pi, 0.0]) + 1e-2 * rng.normal(size=(B, 2))
+    z_traj = np.tile(np.asarray(model.zg).reshape(1, -1), (T + 6, 1)) + 1e-2 * rng.normal(size=(T + 6, 4))
+
+    def graph():
+        g = I2cGraph(model, T, Q, R, Q, 100.0, 0.5, mu_u, 0.5 * np.eye(1), None, None, rule, lib=lib, device=device, batch=B)
+        g.engine.set_initial_state(x0, np.broadcast_to(1e-4 * np.eye(2), (B, 2, 2)))
+        return g
+
+    ga, gb = graph(), graph()
+    pa, pb = MpcPolicy(ga, 2, 0.5 * np.eye(1), z_traj), MpcPolicy(gb, 2, 0.5 * np.eye(1), z_traj)
+    pa.set_control(feedforward=False)
+    pb.set_control(feedforward=False)
+    ea, eb = ga.engine, gb.engine
+    ea.set_cell_expert(2, False)  # the per-cell expert flags ride on the ring too
+    eb.set_cell_expert(2, False)
+    for step in range(5):
+        # b := a in cell order, ring at the origin
+        for key in ("post", "z", "alpha_cell", "feedforward", "expert_cells"):
+            getattr(eb, key).copy_(ea.cells(getattr(ea, key)))
+        for key in ("x0", "sig_x0", "alpha", "temp"):
+            getattr(eb, key).copy_(getattr(ea, key))
+        eb.terminal_cell = ea.terminal_cell
+        eb._problem.terminal_cell = int(ea.terminal_cell)
+        assert eb.t0 == 0 and ea.t0 == step
+        for e in (ea, eb):
+            for _ in range(2):
+                e.forward_backward()
+                e.update_priors()
+        assert ea.failures() == [] and eb.failures() == []
+        assert torch.equal(ea.cells(ea.post), eb.post), f"{inference}: posterior after {step} shifts"
+        assert torch.equal(ea.fwd, eb.fwd), f"{inference}: forward messages after {step} shifts"
+        assert torch.equal(ea.term_stats, eb.term_stats)
+        ea.shift_horizon(pa._next_target(step))
+    # reset() returns to the snapshot, wherever the ring was when it was taken (a second policy on a moved ring)
+    pc = MpcPolicy(ga, 2, 0.5 * np.eye(1))
+    before = ea.cells(ea.post).clone()
+    t0 = ea.t0
+    assert t0 != 0
+    ea.forward_backward(); ea.update_priors(); ea.shift_horizon()
+    pc.reset()
+    assert ea.t0 == t0 and torch.equal(ea.cells(ea.post), before)
+
+
+@pytest.mark.parametrize("inference", ["cubature", "gauss_hermite", "linearize"])
+def test_mpc_ring_every_inference_cpu(inference):
+    _ring_equals_unrolled(inference, hostsim.load(), "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inference", ["cubature", "gauss_hermite", "linearize"])
+def test_mpc_ring_every_inference_gpu(inference):
+    _ring_equals_unrolled(inference, None, "cuda")

@@ -202,3 +202,50 @@ def test_fused_learn_records_the_same_kl_history_as_stepwise():
     assert len(a.kl_terms) == len(b.kl_terms) == 3
     assert all(torch.equal(x, y) for x, y in zip(a.kl_terms, b.kl_terms))
     assert torch.equal(a.post, b.post) and torch.equal(a.temp, b.temp)
+
+
+def test_checkpoint_carries_per_cell_expert_flags(tmp_path):
+    """cells[t].use_expert_controller set through set_cell_expert() survives save / load (round-2 advice)."""
+    g = load_case("em_pendulum_T50_propagate")
+    lib = hostsim.load()
+    a = _graph(g, lib, "cpu")
+    a._propagate = True
+    a.learn_msgs()
+    for t, c in enumerate(a.cells):
+        c.use_expert_controller = t % 3 == 0
+    a.save(str(tmp_path), "flags")
+    b = _graph(g, lib, "cpu")
+    assert b.engine.expert_cells is None
+    b.load_state_dict(torch.load(os.path.join(tmp_path, "i2c_flags.pt"), weights_only=False))
+    assert torch.equal(a.engine.expert_cells, b.engine.expert_cells)
+    a.propagate()
+    b.propagate()
+    assert torch.equal(a.engine.prop, b.engine.prop)
+
+
+def test_kernel_family_is_inspectable():
+    """i2c_kernel_family(): the one resolver of group_lanes, model defaults and the hybrid batch threshold (round-2 review:
+    the family that ran must be visible, like i2c_backward_schedule)."""
+    from i2c.model import make_env_model
+
+    lib = hostsim.load()
+
+    def eng(name, B, T=8, **kw):
+        m = make_env_model(name)
+        nz = m.dim_z
+        return parity.pkg.BatchedI2c(m, T, None, np.eye(nz), None, 1.0, 0.5, np.zeros((B, T, m.dim_u)), np.eye(m.dim_u),
+                                     lib=lib, device="cpu", keep_zpost=False, keep_xm=False, **kw)
+
+    assert eng("PendulumKnown", 4).forward_family == "lane"
+    assert eng("PendulumKnown", 4, group_lanes=True).forward_family == "group"
+    dcp = eng("DoubleCartpoleKnown", 4096)                   # hybrid default: group forward while B * G <= 65536 ...
+    assert (dcp.forward_family, dcp.backward_family) == ("group", "lane")
+    assert eng("DoubleCartpoleKnown", 4097).forward_family == "lane"   # ... and the lane kernels beyond
+    assert eng("DoubleCartpoleKnown", 64, group_lanes=-1).forward_family == "lane"
+    q = eng("Quadrotor12", 3)
+    assert q.forward_family in ("group", "wave") and q.kernel_family("filter") in ("group", "wave")
+    lin = eng("PendulumKnown", 4, inference="linearize", group_lanes=True)
+    with pytest.raises(RuntimeError, match="-2"):
+        lin.kernel_family("forward")
+    with pytest.raises(RuntimeError, match="-2"):  # the group filter no longer runs silently for a rule it does not cover
+        lin.kernel_family("filter")
