@@ -150,7 +150,10 @@ def cpu_baseline(T):
             raise RuntimeError("cpu baseline failed: " + r.stderr[-2000:])
         return json.loads(r.stdout.strip().splitlines()[-1])
 
-    out = run("--batch", "512", "--iters", "6")
+    cores = os.cpu_count() or 1
+    runs = [run("--batch", "512", "--iters", "4", "--workers", str(w)) for w in sorted({min(cores, 32), min(cores, 128)})]
+    out = dict(max(runs, key=lambda r: r["value"]))  # the strongest CPU form is the stated baseline
+    out["by_workers"] = {str(r["cores"]): r["value"] for r in runs}  # NumPy workers contend for memory bandwidth: more is not faster
     out["reference_shaped"] = run("--batch", "1", "--iters", "5")
     return out
 

@@ -91,6 +91,11 @@ enum { I2C_SWEEP_FORWARD = 0, I2C_SWEEP_BACKWARD = 1, I2C_SWEEP_PROPAGATE = 2, I
 /* hybrid default of the d >= 7 lane models: their FORWARD sweep runs on the group kernels while B * G stays within this
  * many lanes (every group wave then has a SIMD of its own: 1024 SIMDs x 64 lanes) */
 #define I2C_GROUP_FORWARD_MAX_LANES 65536
+/* default of the models that have wave kernels (I2cDims.wave): forward and backward sweeps run on them up to this batch (two
+ * wavefronts per SIMD: the wave form has the shorter dependent chain per cell and wins while the chip is not full; beyond, the
+ * group kernels amortise the serial factorisation work over four trajectories per wavefront and win). Measured on MI355X,
+ * 12-state quadrotor T = 50, forward + backward ms: B = 1024: 0.56 (wave) / 1.21 (group); 2048: 1.01 / 1.35; 4096: 2.19 / 1.66 */
+#define I2C_WAVE_MAX_BATCH 2048
 
 enum {
   I2C_OK = 0,
@@ -150,7 +155,10 @@ typedef struct I2cProblem {
                               i2c.py:143,259-265); the cubature forward pass always scales it (i2c.py:366-375)      */
   int32_t gh_degree;       /* I2C_INF_GAUSS_HERMITE: 1 <= degree <= I2C_MAX_GH_DEGREE                               */
   int32_t group_lanes;     /* 0: the model's default kernels (one lane per trajectory; the group kernels for a group_only
-                              model; for the d >= 7 lane models the FORWARD sweep runs on the group kernels while B * G <= 65536);
+                              model -- or its wave kernels, I2cDims.wave, while B <= I2C_WAVE_MAX_BATCH; for the d >= 7 lane models
+                              the FORWARD sweep runs on the group kernels while B * G <= 65536); 64: the wave kernels (one wavefront
+                              per trajectory: forward and backward sweeps, fp64 or I2C_F64_F32S, cubature rule with lam = 0, no
+                              terminal state prior; propagation and filter run the model's default);
                               I2cDims.group_lanes: run forward / backward / propagate / filter with that many lanes of
                               a wavefront per trajectory (fp64, cubature rule;
                               the backward sweep then has one schedule, the fused walk); -1: one lane per trajectory for

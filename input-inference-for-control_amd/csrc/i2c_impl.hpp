@@ -11,6 +11,7 @@
 #include "i2c_entry.hpp"
 #include "i2c_cell.hpp"
 #include "i2c_group.hpp"
+#include "i2c_wave.hpp"
 #include "i2c_linearize.hpp"
 
 #include <cmath>
@@ -260,6 +261,55 @@ static int launch_group_w(const Consts<M, R>& c, const ZetaArg<M, R>* zeta, cons
 }
 #endif
 
+// ---- wave kernels (i2c_wave.hpp): one wavefront per trajectory, four per workgroup ----------------------------------------------
+enum { WK_FORWARD = 0, WK_BACKWARD = 1 };
+constexpr int WAVES_PER_BLOCK = 4;
+template <int KIND, class M, typename R, typename S, class KC, class A>
+I2C_FN void wave_body(const Consts<M, R>& c, const KC& kc, const A& a, const int b, const Wave<R>& w) {
+  if constexpr (KIND == WK_FORWARD) forward_wave_body<M, R, S>(c, kc, a, b, w);
+  if constexpr (KIND == WK_BACKWARD) backward_wave_body<M, R, S>(c, kc, a, b, w);
+}
+#ifdef I2C_HOST_SIM
+template <int KIND, class M, typename R, typename S, class A>
+static int launch_wave(const Consts<M, R>& c, const A& a, void*) {
+  WConst<M, R> kc;
+  wconst_fill<M, R>(kc, &c, 0, 1);
+  for (int b = 0; b < c.B; ++b) {
+    std::vector<R> sh((size_t)WaveLds::SIZE, R(0)), xch(128, R(0));
+    HostBarrier bar(64);
+    std::vector<std::thread> lanes;
+    for (int l = 0; l < 64; ++l)
+      lanes.emplace_back([&, l] { wave_body<KIND, M, R, S>(c, kc, a, b, Wave<R>{l, l >> 4, l & 15, sh.data(), &bar, xch.data()}); });
+    for (auto& th : lanes) th.join();
+  }
+  return I2C_OK;
+}
+#else
+template <int KIND, class M, typename R, typename S, class A>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 2) void k_wave(const Consts<M, R> c, const A a) {
+  __shared__ WConst<M, R> kc;
+  __shared__ R sh[WAVES_PER_BLOCK * WaveLds::SIZE];
+  wconst_fill<M, R>(kc, (const Consts<M, R>*)__builtin_amdgcn_kernarg_segment_ptr(), (int)threadIdx.x, 64 * WAVES_PER_BLOCK);
+  __syncthreads();
+  // A wave reads ONE 8-byte element of every [B]-contiguous row: the 16 trajectories that share a 128-byte line of each row
+  // are mapped onto four workgroups of the SAME XCD (workgroups are dealt round-robin over the 8 XCDs, so blocks i and i + 8
+  // share an L2): every line is then fetched from HBM once per XCD instead of once per wave. Placement is a speed heuristic
+  // only -- any mapping computes the same result.
+  const unsigned i = blockIdx.x, x = i & 7u, r = (i >> 3) & 3u, g = i >> 5;
+  const long b = 16L * (g * 8u + x) + 4 * r + (threadIdx.x >> 6);
+  if (b >= c.B) return;
+  const int l = (int)(threadIdx.x & 63u);
+  const Wave<R> w{l, l >> 4, l & 15, (lds_ptr<R>)(sh + (threadIdx.x >> 6) * WaveLds::SIZE)};
+  wave_body<KIND, M, R, S>(c, kc, a, (int)b, w);
+}
+template <int KIND, class M, typename R, typename S, class A>
+static int launch_wave(const Consts<M, R>& c, const A& a, void* stream) {
+  const unsigned blocks = (unsigned)(((long)c.B + 127) / 128) * 32u;
+  hipLaunchKernelGGL((k_wave<KIND, M, R, S, A>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, (hipStream_t)stream, c, a);
+  return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
+}
+#endif
+
 template <int KIND, class M, typename R, int G, class A>
 static int launch_group(const Consts<M, R>& c, const ZetaArg<M, R>* zeta, const A& a, void* stream) {
   if constexpr (KIND == GK_BACKWARD || KIND == GK_PROPAGATE) {
@@ -377,10 +427,12 @@ template <class M, typename R, typename S = R> struct Impl {
   static constexpr int G = M::GROUP;
   static constexpr bool HAS_GROUP = G > 0 && sizeof(R) == 8 && !MIXED;
   static constexpr bool LANE = !M::GROUP_ONLY;  // one-lane-per-trajectory kernels exist
+  static constexpr bool HAS_WAVE = M::WAVE && sizeof(R) == 8;  // fp64 matrix instruction; the storage type S may be float
 
   // 1: group kernels, 0: one lane per trajectory, < 0: error code
   static int use_group(const I2cProblem* p) {
-    if (p->group_lanes == 0) return M::GROUP_ONLY ? (HAS_GROUP ? 1 : I2C_ENOTSUP) : 0;
+    if (p->group_lanes == 0 || (p->group_lanes == 64 && M::WAVE))  // 64: the wave kernels; their missing sweeps run the default
+      return M::GROUP_ONLY ? (HAS_GROUP ? 1 : I2C_ENOTSUP) : 0;
     if (p->group_lanes == -1) return M::GROUP_ONLY ? I2C_ENOTSUP : 0;  // one lane per trajectory, no hybrid forward
     return (HAS_GROUP && p->group_lanes == G) ? 1 : I2C_ENOTSUP;
   }
@@ -398,7 +450,24 @@ template <class M, typename R, typename S = R> struct Impl {
   //   models: the FORWARD sweep runs on the group kernels while the batch leaves every group wave a SIMD of its own
   //   (measured, planar quadrotor d = 8 at B = 4096: forward 0.51 -> 0.40 ms, while its chunked lane backward stays the
   //   faster one; the buffers of the families are the same, so the backward schedules are unaffected).
+  // what the wave form covers: the cubature rule with lam = 0 (every shipped config: unit weights, no weight on the centre;
+  // the centring of the pairwise sums relies on 2 d wi = 1), no terminal state prior, windows below 2 GiB (WIO::st_if)
+  static int wave_supported(const I2cProblem* p, const C& c) {
+    if (p->inference != I2C_INF_CUBATURE || c.has_x_terminal) return I2C_ENOTSUP;
+    if (!c.rule_xu.unit || !c.rule_x.unit || c.rule_xu.w0 != R(0) || c.rule_x.w0 != R(0)) return I2C_ENOTSUP;
+    constexpr long EMAX = C::E_FWD > C::E_POST ? C::E_FWD : C::E_POST;
+    if (EMAX * (long)p->B * (long)sizeof(S) >= (1L << 31)) return I2C_EINVAL;
+    return I2C_OK;
+  }
   static int family(const I2cProblem* p, const C& c, const int sweep) {
+    if constexpr (HAS_WAVE) {  // forward and backward sweeps: on request (group_lanes = 64) or as the model's default
+      if ((sweep == I2C_SWEEP_FORWARD || sweep == I2C_SWEEP_BACKWARD) &&
+          (p->group_lanes == 64 || (p->group_lanes == 0 && (p->B <= I2C_WAVE_MAX_BATCH || MIXED)))) {
+        const int rc = wave_supported(p, c);
+        if (rc == I2C_OK) return I2C_FAMILY_WAVE;
+        if (p->group_lanes == 64 || MIXED) return rc;
+      }
+    }
     if constexpr (MIXED) {  // fp64 arithmetic on fp32-stored messages: the cubature EM path of the one-lane kernels only
       if (p->inference != I2C_INF_CUBATURE || use_group(p) != 0) return I2C_ENOTSUP;
       if (sweep != I2C_SWEEP_FORWARD && sweep != I2C_SWEEP_BACKWARD) return I2C_ENOTSUP;
@@ -448,6 +517,9 @@ template <class M, typename R, typename S = R> struct Impl {
       if (fam < 0) return fam;
       FwdArgs<R, S> am{(const S*)prior, (S*)fwd, (S*)prior_out, (const R*)p->x0, (const R*)p->sig_x0,
                        (const R*)p->z,  (const R*)p->alpha, (const R*)p->alpha_cell, p->feedforward, status, p->expert};
+      if (fam == I2C_FAMILY_WAVE) {
+        if constexpr (HAS_WAVE) return launch_wave<WK_FORWARD, M, R, S>(c, am, stream);
+      }
       return forward_lane(p, c, am, stream);
     } else {
       return forward_any(p, c, prior, fwd, prior_out, status, stream);
@@ -459,6 +531,9 @@ template <class M, typename R, typename S = R> struct Impl {
                  (const R*)p->z,  (const R*)p->alpha, (const R*)p->alpha_cell, p->feedforward, status, p->expert};
     const int fam = family(p, c, I2C_SWEEP_FORWARD);
     if (fam < 0) return fam;
+    if (fam == I2C_FAMILY_WAVE) {
+      if constexpr (HAS_WAVE && !MIXED) return launch_wave<WK_FORWARD, M, R, R>(c, a, stream);
+    }
     if (fam == I2C_FAMILY_GROUP) {
       if constexpr (HAS_GROUP) return launch_group<GK_FORWARD, M, R, G>(c, nullptr, a, stream);
     }
@@ -509,6 +584,9 @@ template <class M, typename R, typename S = R> struct Impl {
       if (fam < 0) return fam;
       CellArgs<R, S> am{(const S*)fwd, (const S*)xm,   (const R*)p->z, (S*)post,  (S*)zpost,
                         (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   (const R*)p->alpha};
+      if (fam == I2C_FAMILY_WAVE) {
+        if constexpr (HAS_WAVE) return launch_wave<WK_BACKWARD, M, R, S>(c, am, stream);
+      }
       return backward_lane(p, c, am, ms, fuse, stream);
     } else {
       return backward_any(p, c, ms, fwd, xm, post, zpost, cell_stats, term_stats, status, stream, fuse);
@@ -520,6 +598,9 @@ template <class M, typename R, typename S = R> struct Impl {
                   (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   (const R*)p->alpha};
     const int fam = family(p, c, I2C_SWEEP_BACKWARD);
     if (fam < 0) return fam;
+    if (fam == I2C_FAMILY_WAVE) {  // one schedule: the wave walks T-1..0
+      if constexpr (HAS_WAVE && !MIXED) return launch_wave<WK_BACKWARD, M, R, R>(c, a, stream);
+    }
     if (fam == I2C_FAMILY_GROUP) {  // one schedule: the group walks T-1..0 (the fused form); backward_mode is ignored
       if constexpr (HAS_GROUP) return launch_group<GK_BACKWARD, M, R, G>(c, nullptr, a, stream);
     }
@@ -706,7 +787,7 @@ template <class M> static void fill_dims(I2cDims* d) {
   d->ny = M::NY;
   d->group_lanes = M::GROUP;
   d->group_only = M::GROUP_ONLY ? 1 : 0;
-  d->wave = 0;
+  d->wave = M::WAVE ? 1 : 0;
 }
 
 template <class M, typename R, typename S = R> const ModelOps* make_ops() {

@@ -23,6 +23,7 @@ struct Pendulum {
   static constexpr int GROUP = I2C_PENDULUM_GROUP;
   static constexpr bool GROUP_ONLY = false;
   static constexpr bool GROUP_FORWARD_AUTO = false;  // see Impl::forward_any (i2c_impl.hpp)
+  static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   I2C_HD static constexpr int ang(int) { return 0; }
   // z = [sin th, cos th, thd, u],  zT = [sin th, cos th, thd]
   I2C_HD static constexpr int obs_lin(int k) { return k < 2 ? -1 : k - 1; }
@@ -66,6 +67,7 @@ struct PendulumActReg {
   static constexpr int GROUP = 4;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
   static constexpr bool GROUP_ONLY = false;
   static constexpr bool GROUP_FORWARD_AUTO = false;  // see Impl::forward_any (i2c_impl.hpp)
+  static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int) { return 2; }  // z = [u]
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -90,6 +92,7 @@ struct Cartpole {
   static constexpr int GROUP = 8;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
   static constexpr bool GROUP_ONLY = false;
   static constexpr bool GROUP_FORWARD_AUTO = false;  // see Impl::forward_any (i2c_impl.hpp)
+  static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   I2C_HD static constexpr int ang(int) { return 1; }
   // z = [x, sin th, cos th, xd, thd, u],  zT = [x, sin th, cos th, xd, thd]
   I2C_HD static constexpr int obs_lin(int k) { return k == 0 ? 0 : (k < 3 ? -1 : k - 1); }
@@ -141,6 +144,7 @@ struct DoubleCartpole {
   static constexpr int GROUP = 16;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
   static constexpr bool GROUP_ONLY = false;
   static constexpr bool GROUP_FORWARD_AUTO = true;   // see Impl::forward_any (i2c_impl.hpp)
+  static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   I2C_HD static constexpr int ang(int a) { return a == 0 ? 1 : 2; }
   // z = [x, sin th1, cos th1, sin th2, cos th2, xd, th1d, th2d, u],  zT = z without u
   I2C_HD static constexpr int obs_lin(int k) { return k == 0 ? 0 : (k < 5 ? -1 : k - 2); }
@@ -218,6 +222,7 @@ struct Linear {
   static constexpr int GROUP = 4;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
   static constexpr bool GROUP_ONLY = false;
   static constexpr bool GROUP_FORWARD_AUTO = false;  // see Impl::forward_any (i2c_impl.hpp)
+  static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -251,6 +256,7 @@ struct LinearMinEnergy {
   static constexpr int GROUP = 0;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
   static constexpr bool GROUP_ONLY = false;
   static constexpr bool GROUP_FORWARD_AUTO = false;  // see Impl::forward_any (i2c_impl.hpp)
+  static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int) { return 2; }  // z = [u], zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -285,6 +291,7 @@ struct Quadrotor {
   static constexpr int GROUP = 8;  // lanes per trajectory of the group kernels (i2c_group.hpp); 0: none compiled
   static constexpr bool GROUP_ONLY = false;
   static constexpr bool GROUP_FORWARD_AUTO = true;   // see Impl::forward_any (i2c_impl.hpp)
+  static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   I2C_HD static constexpr int ang(int) { return 2; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -346,6 +353,7 @@ struct Quadrotor12 {
   static constexpr int GROUP = 16;
   static constexpr bool GROUP_ONLY = true;
   static constexpr bool GROUP_FORWARD_AUTO = false;
+  static constexpr bool WAVE = true;   // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   I2C_HD static constexpr int ang(int a) { return 3 + a; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }

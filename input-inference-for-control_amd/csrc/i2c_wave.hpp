@@ -1,0 +1,716 @@
+// One WAVEFRONT per trajectory: the cubature cells for models whose joint state-action dimension is exactly the width of the
+// fp64 matrix instruction of gfx950 (d = nx + nu = 16: the 12-state quadrotor).
+//
+//   * every 16 x 16 block of a cell lives in the ACCUMULATOR LAYOUT of v_mfma_f64_16x16x4_f64: lane l = 16 q + j holds column j,
+//     rows q, q + 4, q + 8, q + 12 (four fp64 registers per block). In that layout a block is at once the B operand of the
+//     instruction for each of its four row blocks and -- transposed -- the A operand, so  X^T Y  of two resident blocks is four
+//     matrix instructions with NO operand movement (w_tn). Symmetric blocks (covariances) are their own transpose: products
+//     with them are free of any layout change.
+//   * the factorisations are blocked (4 x 4 pivots): the diagonal block goes through LDS to every lane, which factors and
+//     inverts it in registers; the block row is scaled and the trailing matrix AND up to two right-hand sides are updated by
+//     matrix instructions (w_elim). The solves of a cell are right-hand sides of those eliminations -- there is no separate
+//     triangular-solve primitive, and only explicit products with  L^-1 R  are ever formed.
+//   * vectors live as "column form" (lane (q, j) holds element j, replicated over q) and are turned into "row form" (elements
+//     q + 4 v) through a 16-element LDS slot; sums over the four 16-lane rows use v_permlane32_swap / v_permlane16_swap.
+//   * the 2 d sigma points of a transform are evaluated by 32 lanes at once (lane p: + column p, lane 16 + p: - column p, lane 32:
+//     the centre), one model evaluation per lane.
+// The math is the reference's I2cCell (i2c/i2c.py:350-447, 544-610) and QuadratureInference (i2c/inference/quadrature.py:15-58)
+// in the centred pairwise form of sp_transform (i2c_cell.hpp); requirements on the model are static_asserted in the bodies.
+// HBM layout is the common [T][E][B] one: a wave touches one 8-byte element per row, so the launch maps 16 consecutive
+// trajectories (one 128-byte line of every row) onto workgroups of the SAME XCD (k_wave in i2c_impl.hpp).
+//
+// Host simulation (tests only): the 64 lanes are 64 threads; every cross-lane instruction is an exchange through a shared
+// buffer between two barriers.
+#pragma once
+#include "i2c_group.hpp"
+
+namespace i2c {
+
+constexpr int WLD = 17;  // row stride (elements) of a 16 x 16 block in LDS: column reads of 16 lanes hit 16 different bank pairs
+
+// LDS region of one wave (elements)
+struct WaveLds {
+  static constexpr int MAT = 16 * WLD;                 // one 16 x 16 block
+  static constexpr int O_MAT = 0;                      // block 0: sigma-point directions (rows of L^T)
+  static constexpr int YLD = 13;                       // row stride of the evaluation outputs (nx = 12 values per point)
+  static constexpr int O_Y = O_MAT + MAT;              // 33 rows: + points, - points, centre
+  static constexpr int NVEC = 6;
+  static constexpr int O_VEC = O_Y + 33 * YLD + 3;     // vector slots of 16
+  static constexpr int O_DG = O_VEC + NVEC * 16;       // 4 x 4 pivot block
+  static constexpr int O_DUMP = O_DG + 16;             // where masked-off lanes park their LDS stores (one slot per lane)
+  static constexpr int SIZE = O_DUMP + 64;
+};
+
+template <typename R> struct Wave {
+  int l, q, j;  // lane, its 16-lane row (l >> 4) and column (l & 15)
+  lds_ptr<R> sh;
+#ifdef I2C_HOST_SIM
+  HostBarrier* bar;
+  R* xch;  // 128 slots: operands of the emulated cross-lane instructions
+#endif
+  I2C_MEM lds_ptr<R> mat() const { return sh + WaveLds::O_MAT; }
+  I2C_MEM lds_ptr<R> ybuf() const { return sh + WaveLds::O_Y; }
+  I2C_MEM lds_ptr<R> vec(int i) const { return sh + WaveLds::O_VEC + i * 16; }
+  I2C_MEM lds_ptr<R> dg() const { return sh + WaveLds::O_DG; }
+  I2C_MEM int row(int v) const { return q + 4 * v; }  // matrix row of accumulator register v
+  // orders this wave's LDS writes before its later LDS reads (and earlier reads before later writes)
+  I2C_MEM void sync() const {
+#ifdef I2C_HOST_SIM
+    bar->wait();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
+  }
+};
+
+// a value every lane holds alike, made PROVABLY uniform (an SGPR): branches on it are scalar branches, not EXEC-masked regions
+I2C_FN int w_uniform(const int x) {
+#ifdef I2C_HOST_SIM
+  return x;
+#else
+  return __builtin_amdgcn_readfirstlane(x);
+#endif
+}
+
+// ---- the cross-lane instructions -------------------------------------------------------------------------------------------
+// acc (16 x 16, accumulator layout) += A (16 x 4) B (4 x 16): lane (q, i) supplies A[i][q], lane (q, j) supplies B[q][j]
+template <typename R> I2C_FN void w_mfma(const Wave<R>& w, const R a, const R b, R* acc) {
+#ifdef I2C_HOST_SIM
+  w.bar->wait();
+  w.xch[w.l] = a;
+  w.xch[64 + w.l] = b;
+  w.bar->wait();
+  for (int v = 0; v < 4; ++v) {
+    R s = acc[v];
+    for (int k = 0; k < 4; ++k) s = std::fma(w.xch[16 * k + w.row(v)], w.xch[64 + 16 * k + w.j], s);
+    acc[v] = s;
+  }
+#else
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  d4 c = {acc[0], acc[1], acc[2], acc[3]};
+  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  acc[0] = c[0];
+  acc[1] = c[1];
+  acc[2] = c[2];
+  acc[3] = c[3];
+#endif
+}
+// acc += X^T Y over the first KB row blocks of X and Y (both in the accumulator layout); NEG: acc -= X^T Y
+template <int KB, bool NEG = false, typename R> I2C_FN void w_tn(const Wave<R>& w, const R* x, const R* y, R* acc) {
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) w_mfma(w, NEG ? -x[kb] : x[kb], y[kb], acc);
+}
+// value held by lane K of the caller's 16-lane row (DPP row_newbcast)
+template <int K, typename R> I2C_FN R w_bcast(const Wave<R>& w, const R x) {
+#ifdef I2C_HOST_SIM
+  w.bar->wait();
+  w.xch[w.l] = x;
+  w.bar->wait();
+  return w.xch[(w.l & ~15) + K];
+#else
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+#endif
+}
+// sum over the four 16-lane rows (same column), result in every row: (r0 + r2) + (r1 + r3)
+template <typename R> I2C_FN R w_rowsum(const Wave<R>& w, const R x) {
+#ifdef I2C_HOST_SIM
+  w.bar->wait();
+  w.xch[w.l] = x;
+  w.bar->wait();
+  const int j = w.l & 15;
+  return (w.xch[j] + w.xch[32 + j]) + (w.xch[16 + j] + w.xch[48 + j]);
+#else
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  const auto l32 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto h32 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const double y = __hiloint2double(h32[0], l32[0]) + __hiloint2double(h32[1], l32[1]);
+  lo = __double2loint(y), hi = __double2hiint(y);
+  const auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(h16[0], l16[0]) + __hiloint2double(h16[1], l16[1]);
+#endif
+}
+// column form (lane (q, j): x[j]) -> row form (x[q + 4 v], v < NV) through vector slot `slot`
+template <int NV, typename R> I2C_FN void w_col2row(const Wave<R>& w, const int slot, const R xc, R* xr) {
+  const auto s = w.vec(slot);
+  w.sync();
+#ifdef I2C_HOST_SIM
+  if (w.q == 0)  // (lane-threads must not race; on the device the four rows store the same value to the same address)
+#endif
+    s[w.j] = xc;
+  w.sync();
+#pragma unroll
+  for (int v = 0; v < NV; ++v) xr[v] = s[w.row(v)];
+}
+// sum over all 64 lanes, in a fixed order, result in every lane
+template <typename R> I2C_FN R w_wavesum(const Wave<R>& w, const int slot, const R x) {
+  const R cs = w_rowsum(w, x);
+  const auto s = w.vec(slot);
+  w.sync();
+#ifdef I2C_HOST_SIM
+  if (w.q == 0)
+#endif
+    s[w.j] = cs;
+  w.sync();
+  R t = R(0);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t += s[k];
+  return t;
+}
+
+// Batch-wide constants by row, in LDS (one copy per workgroup): 16 x 16 row-major, zero-padded
+template <class M, typename R> struct WConst {
+  R xi[256], eta[256], xiT[256], qr[256], qf[256];  // sig_xi0, sig_eta, sig_xiT0, blkdiag(Q, R), Qf
+  R zg[16], zgT[16];
+};
+template <class M, typename R, class DST> I2C_FN void wconst_fill(DST& k, const Consts<M, R>* c, const int tid, const int nthreads) {
+  constexpr int NX = M::NX, NZ = M::NZ, NT = M::NZT > 0 ? M::NZT : 1;
+  for (int e = tid; e < 256; e += nthreads) {
+    const int i = e >> 4, j = e & 15;
+    k.xi[e] = (i < NZ && j < NZ) ? c->sig_xi0[tri_any(i, j)] : R(0);
+    k.eta[e] = (i < NX && j < NX) ? c->sig_eta[tri_any(i, j)] : R(0);
+    k.xiT[e] = (i < NT && j < NT) ? c->sig_xiT0[tri_any(i, j)] : R(0);
+    k.qr[e] = (i < NZ && j < NZ) ? c->QR[tri_any(i, j)] : R(0);
+    k.qf[e] = (i < NT && j < NT) ? c->Qf[tri_any(i, j)] : R(0);
+  }
+  for (int e = tid; e < 16; e += nthreads) {
+    k.zg[e] = e < NZ ? c->zg[e] : R(0);
+    k.zgT[e] = e < NT ? c->zg_term[e] : R(0);
+  }
+}
+// accumulator-layout registers of a constant block
+template <int NV, typename R, class P> I2C_FN void w_ldconst(const Wave<R>& w, const P m, R* x) {
+#pragma unroll
+  for (int v = 0; v < NV; ++v) x[v] = m[w.row(v) * 16 + w.j];
+}
+
+// ---- blocked Cholesky elimination --------------------------------------------------------------------------------------------
+// s: SPD matrix of dimension 4 NB (accumulator layout, consumed). On return lt = L^T (upper triangular, accumulator layout,
+// rows >= 4 NB zero) and, for each of the NRHS right-hand sides r (4 NB x 16), r = L^-1 r. Returns whether every pivot was
+// positive. Per 4 x 4 pivot block: the block goes through LDS to every lane, which factors it and inverts the factor in
+// registers (four dependent rsq chains: the serial core of the kernel); lane (q, i) then holds entry (i mod 4, q) of that inverse
+// as the A operand of the matrix instruction that scales block row kb of s and of every right-hand side, and the scaled block
+// row of s (= rows of L^T) is A and B operand of the rank-4 update of everything below.
+template <int NB, int NRHS, typename R> I2C_FN bool w_elim(const Wave<R>& w, R* s, R* r1, R* r2, R* lt) {
+  const auto dg = w.dg();
+  const int a = w.j & 3, cq = w.q, blk = w.j >> 2;
+  R last = R(0), mq[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) mq[k] = cq == k ? R(1) : R(0);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) lt[v] = R(0);
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    const bool inblk = blk == kb;
+    w.sync();
+    dg[inblk ? cq * 4 + a : 16 + w.l] = s[kb];  // entry (q, j mod 4) of the pivot block; the other lanes park their store
+    w.sync();
+    const R d00 = dg[0], d10 = dg[4], d11 = dg[5], d20 = dg[8], d21 = dg[9], d22 = dg[10];
+    const R d30 = dg[12], d31 = dg[13], d32 = dg[14], d33 = dg[15];
+    // 4 x 4 Cholesky (l) ...
+    const R i0 = r_rsqrt(d00);
+    const R l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
+    const R p1 = d11 - l10 * l10;
+    const R i1 = r_rsqrt(p1);
+    const R l21 = (d21 - l20 * l10) * i1, l31 = (d31 - l30 * l10) * i1;
+    const R p2 = d22 - l20 * l20 - l21 * l21;
+    const R i2 = r_rsqrt(p2);
+    const R l32 = (d32 - l30 * l20 - l31 * l21) * i2;
+    const R p3 = d33 - l30 * l30 - l31 * l31 - l32 * l32;
+    const R i3 = r_rsqrt(p3);
+    if (kb == NB - 1) last = p3;  // a failed pivot poisons everything after it (see chol(), i2c_linalg.hpp)
+    // ... and this lane's entry of its inverse: row a of L^-1 solves y^T L = e_a^T (back substitution; y_c = 0 for c > a
+    // falls out of the one-hot right-hand side, which is also zero outside block row kb), entry cq picked by a one-hot
+    // combination. Written without selects on purpose: with selects hipcc sinks the arithmetic into per-(a, cq) divergent
+    // branches, which a wavefront then executes one after the other.
+    const R e0 = (inblk && a == 0) ? R(1) : R(0), e1 = (inblk && a == 1) ? R(1) : R(0);
+    const R e2 = (inblk && a == 2) ? R(1) : R(0), e3 = (inblk && a == 3) ? R(1) : R(0);
+    const R y3 = e3 * i3;
+    const R y2 = (e2 - l32 * y3) * i2;
+    const R y1 = (e1 - l21 * y2 - l31 * y3) * i1;
+    const R y0 = (e0 - l10 * y1 - l20 * y2 - l30 * y3) * i0;
+    const R aw = (mq[0] * y0 + mq[1] * y1) + (mq[2] * y2 + mq[3] * y3);
+    // scale block row kb: rows of L^T (masked to the upper triangle: what is left of it is rounding noise) ...
+    R x[4] = {R(0), R(0), R(0), R(0)};
+    w_mfma(w, aw, s[kb], x);
+    const R ltk = (w.j >= 4 * kb + cq) ? x[kb] : R(0);
+    lt[kb] = ltk;
+    R x1 = R(0), x2 = R(0);
+    if (NRHS >= 1) {
+      R y[4] = {R(0), R(0), R(0), R(0)};
+      w_mfma(w, aw, r1[kb], y);
+      x1 = y[kb];
+    }
+    if (NRHS >= 2) {
+      R y[4] = {R(0), R(0), R(0), R(0)};
+      w_mfma(w, aw, r2[kb], y);
+      x2 = y[kb];
+    }
+    // ... and eliminate it from everything below
+    if (kb < NB - 1) {
+      w_mfma(w, -ltk, ltk, s);
+      if (NRHS >= 1) w_mfma(w, -ltk, x1, r1);
+      if (NRHS >= 2) w_mfma(w, -ltk, x2, r2);
+    }
+    if (NRHS >= 1) r1[kb] = x1;
+    if (NRHS >= 2) r2[kb] = x2;
+  }
+  return last > R(0);
+}
+
+// addressing of one [E][B] cell block for the lanes of a wave (storage type S, arithmetic type R)
+template <typename R, typename S> struct WIO {
+  Window w;
+  unsigned rb, bo;
+  I2C_MEM R ld(const int e) const { return (R)wld<S>(w, 0u, (unsigned)e * rb + bo); }
+  I2C_MEM void st(const int e, const R v) const { wst(w, 0u, (unsigned)e * rb + bo, (S)v); }
+  I2C_MEM void st_if(const bool on, const int e, const R v) const {
+#ifdef I2C_HOST_SIM
+    if (on) wst(w, 0u, (unsigned)e * rb + bo, (S)v);
+#else
+    wst(w, 0u, on ? (unsigned)e * rb + bo : 0x80000000u, (S)v);  // out of range: dropped by the buffer unit (see GIO::st_if)
+#endif
+  }
+};
+template <typename R, typename S> I2C_FN WIO<R, S> wio(const S* base, const unsigned long elems, const unsigned rb, const unsigned bo) {
+  return WIO<R, S>{make_window(base, elems * rb), rb, bo};
+}
+I2C_FN int w_symidx(const int i, const int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+// Kalman-style update of N(mu, s) of dimension N = 4 NB on an IDENTITY observation of it with noise alpha * xi and target zt
+// (i2c.py:394-403 with z a leading slice of the state):  with C = chol(s + alpha xi), U = C^-1 s:  s <- s - U^T U;  the mean uses
+// the posterior-covariance form of the same gain,  s (s + N)^-1 = s_new N^-1  (N^-1 = W / alpha, W = the cost weight):
+//   mu <- mu + s_new W (zt - mu) / alpha.
+// mu, zt, wd (diagonal of W) in column form; xi, wm (W when not diagonal) accumulator-layout constants.
+template <int NB, typename R, class P> I2C_FN bool w_kalman(const Wave<R>& w, const R alpha, const P xi_m, const P w_m, const bool w_diag,
+                                                             const R zt, R* mu, R* s) {
+  R sz[4], u[4], lt[4], xi[4];
+  w_ldconst<NB>(w, xi_m, xi);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    sz[v] = v < NB ? s[v] + alpha * xi[v] : R(0);
+    u[v] = v < NB ? s[v] : R(0);
+  }
+  const bool ok = w_elim<NB, 1>(w, sz, u, (R*)nullptr, lt);
+  w_tn<NB, true>(w, u, u, s);
+  const R r = zt - *mu;
+  R wr[4];
+  if (w_diag) {
+    const R wd = w_m[w.j * 16 + w.j];
+    w_col2row<NB>(w, 0, wd * r, wr);
+  } else {
+    R rr[4], wm[4];
+    w_col2row<NB>(w, 0, r, rr);
+    w_ldconst<NB>(w, w_m, wm);
+    R t = R(0);
+#pragma unroll
+    for (int v = 0; v < NB; ++v) t += wm[v] * rr[v];
+    w_col2row<NB>(w, 1, w_rowsum(w, t), wr);
+  }
+  R t = R(0);
+#pragma unroll
+  for (int v = 0; v < NB; ++v) t += s[v] * wr[v];
+  *mu += w_rowsum(w, t) * r_rcp(alpha);
+  return ok;
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward sweep (i2c.py:876-880 over :350-447)
+// ------------------------------------------------------------------------------------------
+template <class M, typename R, typename S, class KC>
+I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const FwdArgs<R, S>& a, const int b, const Wave<R>& w) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D, NBX = NX / 4;
+  static_assert(D == 16 && NX % 4 == 0 && NZ == D && (NZT == NX || NZT == 0), "wave kernels: d = 16, identity observations");
+  static_assert(st_identity<ObsStruct<M>, NZ>() && st_identity<TermStruct<M>, NZT>(), "wave kernels: identity observations");
+  constexpr int O_K = D + sym(D), O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  const int q = w.q, j = w.j;
+  const unsigned long B = c.B;
+  const int T = c.T;
+  const unsigned WS = sizeof(S), bo = (unsigned)b * WS, rb = (unsigned)(B * WS);
+  const bool jx = j < NX;
+  const int jxc = jx ? j : 0;
+  const R alpha_traj = a.alpha[b];
+  const Rule<R>& rule = c.rule_xu;
+  int fail = 0;
+
+  // state message carried along the chain: mean in column form, covariance in the accumulator layout (nx x nx, zero-padded)
+  R mx = jx ? a.x0[(long)jxc * B + b] : R(0);
+  R sx[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) sx[v] = (v < NBX && jx) ? a.sig_x0[(long)w_symidx(w.row(v) < NX ? w.row(v) : 0, jxc) * B + b] : R(0);
+
+  // The prior rows of a cell do not depend on the recursion: they are fetched ONE CELL AHEAD (issued once the current cell's
+  // have been consumed), so that the memory round trip hides behind a cell's worth of work.
+  R nx_pmu, nx_pj[4], nx_kt[4], nx_alpha, nx_zt;
+  int nx_ff;
+  auto fetch_prior = [&](const int tc) {
+    const int trc = c.row(tc);
+    const WIO<R, S> pri = wio<R, S>(a.prior + (unsigned long)trc * C::E_POST * B, C::E_POST, rb, bo);
+    nx_pmu = pri.ld(j);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) nx_pj[v] = pri.ld(D + w_symidx(w.row(v), j));
+#pragma unroll
+    for (int v = 0; v < 4; ++v) nx_kt[v] = v < NBX ? pri.ld(O_K + (jx ? 0 : j - NX) * NX + w.row(v)) : R(0);  // K^T columns (action lanes)
+    nx_alpha = a.alpha_cell ? a.alpha_cell[(long)trc * B + b] : alpha_traj;
+    nx_zt = c.z_per_cell ? a.z[((long)trc * NZ + j) * B + b] : kc.zg[j];
+    nx_ff = a.ff[trc];
+  };
+  fetch_prior(0);
+
+  for (int t = 0; t < T; ++t) {
+    const WIO<R, S> out = wio<R, S>(a.fwd + (unsigned long)t * C::E_FWD * B, C::E_FWD, rb, bo);
+    const R alpha = nx_alpha, zt = nx_zt, pmu = nx_pmu;
+    const bool ff = w_uniform(nx_ff) != 0;
+    R pj[4], kt[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      pj[v] = nx_pj[v];
+      kt[v] = nx_kt[v];
+    }
+    int cell_bad = 0;
+
+    // ---- 1. joint prior over (x, u) ---------------------------------------------------
+    R mu0, s0[4];
+    if (ff) {  // feed-forward: independent action prior (i2c.py:355-360)
+      mu0 = jx ? mx : pmu;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) s0[v] = (v < NBX) ? (jx ? sx[v] : R(0)) : (jx ? R(0) : pj[v]);
+    } else {  // feedback: condition the previous controller on the new state message (i2c.py:361-387)
+      // pdf ratio rho = exp(-delta^T (P_xx + sig_x)^-1 delta / 2): delta rides as column NX of the right-hand side
+      const R dl = jx ? mx - pmu : R(0);
+      R dr[4];
+      w_col2row<NBX>(w, 0, dl, dr);
+      R sm[4], rh[4], lt[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        sm[v] = (v < NBX && jx) ? pj[v] + sx[v] : R(0);
+        rh[v] = (v < NBX && j == NX) ? dr[v] : R(0);
+      }
+      cell_bad = flag_stage(cell_bad, w_elim<NBX, 1>(w, sm, rh, (R*)nullptr, lt), 0);
+      R ysq = R(0);
+#pragma unroll
+      for (int v = 0; v < NBX; ++v) ysq += rh[v] * rh[v];
+      const R maha = w_bcast<NX>(w, w_rowsum(w, ysq));
+      const R rho = r_exp(R(-0.5) * maha);
+      // F^T = [I | Kt^T] (nx x 16), Kt = rho K:  sig_0 = F sig_x F^T with (P_uu - Kt P_xu) added to the action block
+      R ft[4], m1[4] = {R(0), R(0), R(0), R(0)};
+#pragma unroll
+      for (int v = 0; v < 4; ++v) ft[v] = v < NBX ? (jx ? (w.row(v) == j ? R(1) : R(0)) : rho * kt[v]) : R(0);
+      w_tn<NBX>(w, sx, ft, m1);  // sig_x F^T
+      R kd = R(0);
+#pragma unroll
+      for (int v = 0; v < NBX; ++v) kd += ft[v] * dr[v];
+      kd = w_rowsum(w, kd);  // action lanes: Kt delta
+      mu0 = jx ? mx : pmu + kd;
+      R m1p[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        m1p[v] = (v < NBX && !jx) ? m1[v] - pj[v] : m1[v];
+        s0[v] = R(0);
+      }
+      w_tn<NBX>(w, ft, m1p, s0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        if (v < NBX) s0[v] = jx ? s0[v] : m1[v];  // state-action block: sig_x Kt^T itself
+        else s0[v] = jx ? s0[v] : s0[v] + pj[v];  // action block: P_uu - Kt P_xu + Kt sig_x Kt^T
+      }
+    }
+    fetch_prior(t + 1 < T ? t + 1 : t);  // this cell's rows are consumed: the next cell's, a cell ahead
+    if (a.prior_out) {
+      const WIO<R, S> po = wio<R, S>(a.prior_out + (unsigned long)t * (D + sym(D)) * B, D + sym(D), rb, bo);
+      po.st_if(q == 0, j, mu0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) po.st_if(w.row(v) >= j, D + w_symidx(w.row(v), j), s0[v]);
+    }
+
+    // ---- 2. cost "observation" z = (x, u): measurement update (i2c.py:390-407) ----------
+    cell_bad = flag_stage(cell_bad, w_kalman<4>(w, alpha, kc.xi, kc.qr, c.qr_diag != 0, zt, &mu0, s0), 2);
+    out.st_if(q == 0, j, mu0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) out.st_if(w.row(v) >= j, D + w_symidx(w.row(v), j), s0[v]);
+
+    // ---- 3. dynamics push-through (i2c.py:415-421) ---------------------------------------
+    R lt[4];
+    {
+      R tmp[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) tmp[v] = s0[v];
+      cell_bad = flag_stage(cell_bad, w_elim<4, 0>(w, tmp, (R*)nullptr, (R*)nullptr, lt), 3);
+    }
+    const auto Lt = w.mat();
+    const auto mv = w.vec(2);
+    w.sync();
+#pragma unroll
+    for (int v = 0; v < 4; ++v) Lt[w.row(v) * WLD + j] = lt[v];  // row p of L^T = direction of sigma-point pair p
+#ifdef I2C_HOST_SIM
+    if (q == 0)
+#endif
+      mv[j] = mu0;
+    w.sync();
+    {
+      // lane p: m + sf L[:, p]; lane 16 + p: m - sf L[:, p]; lanes >= 32: the centre (lane 32's copy is used)
+      const int p = w.l & 15;
+      const R sg = w.l < 16 ? rule.sf : (w.l < 32 ? -rule.sf : R(0));
+      R x[D], sn[M::NA > 0 ? M::NA : 1], cs[M::NA > 0 ? M::NA : 1], y[NX];
+#pragma unroll
+      for (int i = 0; i < D; ++i) x[i] = mv[i] + sg * Lt[p * WLD + i];
+#pragma unroll
+      for (int k = 0; k < M::NA; ++k) r_sincos(x[M::ang(k)], &sn[k], &cs[k]);
+      M::dynamics(c.params, x, sn, cs, y);
+      const auto Y = w.ybuf();
+      if (w.l <= 32) {  // lanes beyond the centre computed a copy of it
+#pragma unroll
+        for (int k = 0; k < NX; ++k) Y[w.l * WaveLds::YLD + k] = y[k];
+      }
+    }
+    w.sync();
+    // a_p = (y+ - y0) + (y- - y0), d_p = y+ - y-, in the accumulator layout (row = point pair, column = output)
+    R am[4], dm[4], y0;
+    {
+      const auto Y = w.ybuf();
+      y0 = opaque(Y[32 * WaveLds::YLD + jxc]);  // (opaque: an unconditional read, not an EXEC-masked one)
+      y0 = jx ? y0 : R(0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const R yp = Y[w.row(v) * WaveLds::YLD + jxc], ym = Y[(16 + w.row(v)) * WaveLds::YLD + jxc];
+        am[v] = jx ? (yp - y0) + (ym - y0) : R(0);
+        dm[v] = jx ? yp - ym : R(0);
+      }
+    }
+    const R asum = w_rowsum(w, (am[0] + am[1]) + (am[2] + am[3]));
+    mx = y0 + rule.wi * asum;  // mu_x3_f (column form)
+    // sig_y = wi/2 sum_p (a_p a_p^T + d_p d_p^T) - wi^2 A A^T: with 2 d wi = 1 the last term centres the a_p
+    R at[4], sy[4] = {R(0), R(0), R(0), R(0)}, sxy[4] = {R(0), R(0), R(0), R(0)};
+    const R amean = (R(2) * rule.wi) * asum;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) at[v] = jx ? am[v] - amean : R(0);
+    w_tn<4>(w, at, at, sy);
+    w_tn<4>(w, dm, dm, sy);
+    w_tn<4>(w, dm, lt, sxy);  // sig_xy^T = wi sf [d_p]^T L^T  (nx x 16)
+    {
+      R eta[4];
+      w_ldconst<NBX>(w, kc.eta, eta);
+      const R hw = R(0.5) * rule.wi, cw = rule.wi * rule.sf;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        sx[v] = v < NBX ? hw * sy[v] + eta[v] : R(0);
+        sxy[v] = v < NBX ? cw * sxy[v] : R(0);
+      }
+    }
+    // ---- smoother gain J = sig_xy sig_x3^-1 (i2c.py:423-425): J^T = W^T (W sig_xy^T), W = chol(sig_x3)^-1 ----
+    {
+      R tmp[4], w3[4], l3[4], jt[4] = {R(0), R(0), R(0), R(0)};
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        tmp[v] = sx[v];
+        w3[v] = (v < NBX && w.row(v) == j) ? R(1) : R(0);
+      }
+      cell_bad = flag_stage(cell_bad, w_elim<NBX, 2>(w, tmp, sxy, w3, l3), 4);
+      w_tn<NBX>(w, w3, sxy, jt);
+#pragma unroll
+      for (int v = 0; v < NBX; ++v) out.st(O_J + j * NX + w.row(v), jt[v]);
+    }
+    // ---- 4. terminal cost observation on the flagged cell, after J (i2c.py:430-443) ----
+    if (NZT > 0 && t == c.terminal_cell && c.has_Qf)  // (uniform: kernel arguments)
+      cell_bad = flag_stage(cell_bad, w_kalman<NBX>(w, alpha, kc.xiT, kc.qf, c.qf_diag != 0, kc.zgT[j], &mx, sx), 5);
+    fail = fold_cell_failure(fail, cell_bad, t);
+    out.st_if(q == 0 && jx, O_MU3 + jxc, mx);
+#pragma unroll
+    for (int v = 0; v < NBX; ++v) out.st_if(jx && w.row(v) >= j, O_S3 + w_symidx(w.row(v), jxc), sx[v]);
+  }
+  if (w.l == 0 && fail != 0 && a.status[b] == 0) a.status[b] = fail;
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward sweep (i2c.py:882-886 over :544-610), fused form: the wave walks T-1..0 doing the whole cell.
+// ------------------------------------------------------------------------------------------
+template <class M, typename R, typename S, class KC>
+I2C_HD inline void backward_wave_body(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>& a, const int b, const Wave<R>& w) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D, NBX = NX / 4, NT = C::NZT1;
+  static_assert(D == 16 && NX % 4 == 0 && NZ == D && (NZT == NX || NZT == 0), "wave kernels: d = 16, identity observations");
+  constexpr int O_K = D + sym(D), O_k = O_K + NU * NX, O_SK = O_k + NU;
+  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  const int q = w.q, j = w.j;
+  const unsigned long B = c.B;
+  const int T = c.T;
+  const unsigned WS = sizeof(S), bo = (unsigned)b * WS, rb = (unsigned)(B * WS);
+  const bool jx = j < NX;
+  const int jxc = jx ? j : 0, ju = jx ? 0 : j - NX;
+
+  // cost of N(m, s) about target zt under weight W (diag wd / full wm): this lane's share of
+  //   mean  err^T W err + tr(s W)   and   variance  2 tr((s W)^2) + 4 err^T W s W err      (i2c.py:1034-1043)
+  auto cost_share = [&](const bool diag, const auto wmat, const int NB, const R err, const R* s, R* pm, R* pv) {
+    R er[4], wm[4];
+    w_col2row<4>(w, 3, err, er);
+    w_ldconst<4>(w, wmat, wm);
+    if (diag) {
+      const R wd = wmat[j * 16 + j];
+      R m = R(0), t2 = R(0), qd = R(0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        if (v < NB) {
+          const R wrv = wmat[w.row(v) * 16 + w.row(v)];
+          m += (w.row(v) == j) ? wd * (err * err + s[v]) : R(0);
+          t2 += s[v] * s[v] * (wrv * wd);
+          qd += (wrv * er[v]) * s[v] * (wd * err);
+        }
+      }
+      *pm = m;
+      *pv = R(2) * t2 + R(4) * qd;
+    } else {
+      // P = s W, P^T = W s (matrix instructions); W err in column and row form
+      R p[4] = {R(0), R(0), R(0), R(0)}, pt[4] = {R(0), R(0), R(0), R(0)};
+      w_tn<4>(w, s, wm, p);
+      w_tn<4>(w, wm, s, pt);
+      R t = R(0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) t += wm[v] * er[v];
+      const R we = w_rowsum(w, t);
+      R wer[4];
+      w_col2row<4>(w, 4, we, wer);
+      R m = R(0), t2 = R(0), qd = R(0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        if (v < NB) {
+          m += er[v] * wm[v] * err + s[v] * wm[v];
+          t2 += p[v] * pt[v];
+          qd += wer[v] * s[v] * we;
+        }
+      }
+      *pm = m;
+      *pv = R(2) * t2 + R(4) * qd;
+    }
+  };
+
+  // end of the chain (i2c.py:546-564): the smoothed terminal state is the filtered one
+  R m3m, s3m[4];
+  {
+    const WIO<R, S> fw = wio<R, S>(a.fwd + (unsigned long)(T - 1) * C::E_FWD * B, C::E_FWD, rb, bo);
+    m3m = jx ? fw.ld(O_MU3 + jxc) : R(0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) s3m[v] = (v < NBX && jx) ? fw.ld(O_S3 + w_symidx(w.row(v) < NX ? w.row(v) : 0, jxc)) : R(0);
+  }
+  // terminal observation statistics (i2c.py:567-570, 989-992): tr(Qf (errT errT^T + sig_z3_m)), identity observation
+  R trT = R(0);
+  if (NZT > 0 && c.has_Qf) {
+    R pm, pv;
+    cost_share(c.qf_diag != 0, kc.qf, NBX, jx ? m3m - kc.zgT[jxc] : R(0), s3m, &pm, &pv);
+    trT = w_wavesum(w, 5, pm);
+    if (q == 0 && jx) a.term_stats[(long)(3 + jxc) * B + b] = m3m;
+#pragma unroll
+    for (int v = 0; v < NBX; ++v)
+      if (jx && w.row(v) >= j) a.term_stats[(long)(3 + NT + w_symidx(w.row(v), jxc)) * B + b] = s3m[v];
+  }
+  if (w.l == 0) a.term_stats[b] = trT;
+
+  R acc_m = R(0), acc_v = R(0);  // this lane's share of the cost sums over t (reduced once, after the walk)
+  // forward rows of a cell, fetched one cell ahead (see forward_wave_body)
+  R nx_mu, nx_m3f, nx_sg[4], nx_s3f[4], nx_jt[4], nx_zt;
+  auto fetch_fwd = [&](const int tc) {
+    const WIO<R, S> fw = wio<R, S>(a.fwd + (unsigned long)tc * C::E_FWD * B, C::E_FWD, rb, bo);
+    nx_mu = fw.ld(j);
+    nx_m3f = fw.ld(O_MU3 + jxc);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      nx_sg[v] = fw.ld(D + w_symidx(w.row(v), j));
+      nx_s3f[v] = v < NBX ? fw.ld(O_S3 + w_symidx(w.row(v) < NX ? w.row(v) : 0, jxc)) : R(0);
+      nx_jt[v] = v < NBX ? fw.ld(O_J + j * NX + (w.row(v) < NX ? w.row(v) : 0)) : R(0);  // J^T
+    }
+    nx_zt = c.z_per_cell ? a.z[((long)c.row(tc) * NZ + j) * B + b] : kc.zg[j];
+  };
+  fetch_fwd(T - 1);
+  for (int t = T - 1; t >= 0; --t) {
+    const int tr = c.row(t);
+    const WIO<R, S> po = wio<R, S>(a.post + (unsigned long)tr * C::E_POST * B, C::E_POST, rb, bo);
+    R mu = nx_mu, sg[4], s3f[4], jt[4];
+    const R m3f = jx ? nx_m3f : R(0), zt = nx_zt;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      sg[v] = nx_sg[v];
+      s3f[v] = jx ? nx_s3f[v] : R(0);
+      jt[v] = nx_jt[v];
+    }
+    fetch_fwd(t > 0 ? t - 1 : 0);
+    if (a.xm) {
+      S* xo = const_cast<S*>(a.xm) + ((long)t * C::E_XM) * B + b;
+      if (q == 0 && jx) xo[(long)jxc * B] = (S)m3m;
+#pragma unroll
+      for (int v = 0; v < NBX; ++v)
+        if (jx && w.row(v) >= j) xo[(long)(NX + w_symidx(w.row(v), jxc)) * B] = (S)s3m[v];
+    }
+    // RTS update of the joint (i2c.py:580-583): mu += J (m3m - m3f), sig += J (S3m - S3f) J^T
+    {
+      R dr[4], ds[4], p1[4] = {R(0), R(0), R(0), R(0)};
+      w_col2row<NBX>(w, 0, m3m - m3f, dr);
+      R tsum = R(0);
+#pragma unroll
+      for (int v = 0; v < NBX; ++v) tsum += jt[v] * dr[v];
+      mu += w_rowsum(w, tsum);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) ds[v] = v < NBX ? s3m[v] - s3f[v] : R(0);
+      w_tn<NBX>(w, ds, jt, p1);
+      w_tn<NBX>(w, jt, p1, sg);
+    }
+    // posterior observation moments = the joint itself (identity observation, i2c.py:594-596) and their expected cost
+    {
+      R pm, pv;
+      cost_share(c.qr_diag != 0, kc.qr, 4, mu - zt, sg, &pm, &pv);
+      acc_m += pm;
+      acc_v += pv;
+      if (a.cell_stats) {
+        const R cm = w_wavesum(w, 5, pm), cv = w_wavesum(w, 5, pv);
+        if (w.l == 0) {
+          a.cell_stats[((long)t * 2 + 0) * B + b] = cm;
+          a.cell_stats[((long)t * 2 + 1) * B + b] = cv;
+        }
+      }
+    }
+    // controller (i2c.py:600-608): with [W | Y] = chol(sig_xx)^-1 [I | sig_xu]:  K^T = W^T Y, sigK = sig_uu - Y^T Y
+    {
+      R sxx[4], rh[4], lt[4], g[4] = {R(0), R(0), R(0), R(0)}, mr[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        sxx[v] = (v < NBX && jx) ? sg[v] : R(0);
+        rh[v] = v < NBX ? (jx ? (w.row(v) == j ? R(1) : R(0)) : sg[v]) : R(0);
+      }
+      if (!w_elim<NBX, 1>(w, sxx, rh, (R*)nullptr, lt) && w.l == 0) set_status(a.status, b, 7, t);
+      w_tn<NBX>(w, rh, rh, g);
+      w_col2row<NBX>(w, 1, jx ? mu : R(0), mr);
+      R kx = R(0);
+#pragma unroll
+      for (int v = 0; v < NBX; ++v) {
+        po.st_if(!jx, O_K + ju * NX + (w.row(v) < NX ? w.row(v) : 0), g[v]);
+        kx += g[v] * mr[v];
+      }
+      kx = w_rowsum(w, kx);
+      po.st_if(!jx && q == 0, O_k + ju, mu - kx);
+      po.st_if(!jx && q >= ju, O_SK + q * (q + 1) / 2 + ju, sg[NBX] - g[NBX]);
+    }
+    po.st_if(q == 0, j, mu);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) po.st_if(w.row(v) >= j, D + w_symidx(w.row(v), j), sg[v]);
+    if (a.zpost) {
+      S* zo = a.zpost + ((long)t * C::E_ZPOST) * B + b;
+      if (q == 0) zo[(long)j * B] = (S)mu;
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (w.row(v) >= j) zo[(long)(NZ + w_symidx(w.row(v), j)) * B] = (S)sg[v];
+    }
+    m3m = jx ? mu : R(0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) s3m[v] = (v < NBX && jx) ? sg[v] : R(0);
+  }
+  const R sm = w_wavesum(w, 5, acc_m), sv = w_wavesum(w, 5, acc_v);
+  if (w.l == 0) {
+    a.term_stats[B + b] = sm;
+    a.term_stats[2 * B + b] = sv;
+  }
+}
+
+}  // namespace i2c

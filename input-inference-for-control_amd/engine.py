@@ -96,12 +96,19 @@ class BatchedI2c:
         if group_lanes is True:
             group_lanes = dims.group_lanes
         self.group_lanes = int(group_lanes or 0)
-        if self.group_lanes not in (0, dims.group_lanes) and not (self.group_lanes == -1 and not dims.group_only):
+        # 64 = the wave kernels (csrc/i2c_wave.hpp: one wavefront per trajectory, blocks in the fp64 matrix-instruction layout),
+        # for the models that have them (dims.wave): forward and backward sweeps; propagation and filter run the model's default
+        ok = self.group_lanes in (0, dims.group_lanes) or (self.group_lanes == -1 and not dims.group_only) or \
+            (self.group_lanes == 64 and dims.wave)
+        if not ok:
             raise ValueError(f"group_lanes={self.group_lanes}: this model's group kernels use {dims.group_lanes} lanes"
-                             + (" and it has no one-lane kernels" if dims.group_only else " (or -1: one lane per trajectory)"))
+                             + (" and it has no one-lane kernels" if dims.group_only else " (or -1: one lane per trajectory)")
+                             + (" (or 64: one wavefront per trajectory)" if dims.wave else ""))
         self.uses_group_kernels = bool(self.group_lanes > 0 or dims.group_only)
-        if self.mixed and (self.uses_group_kernels or inference != "cubature"):
-            raise ValueError("fp32 storage (storage_dtype) is available for the cubature path of the one-lane kernels only")
+        if self.mixed and inference != "cubature":
+            raise ValueError("fp32 storage (storage_dtype) is available for the cubature path only")
+        if self.mixed and self.uses_group_kernels and not (dims.wave and self.group_lanes in (0, 64)):
+            raise ValueError("fp32 storage (storage_dtype) is available for the one-lane kernels and the wave kernels only")
 
         mu_u = np.asarray(mu_u, dtype=np.float64)
         if mu_u.ndim == 2:

@@ -37,7 +37,7 @@ def engine_from_case(case, lib, device, dtype=torch.float64, x0=None, mu_u=None,
     eng = pkg.BatchedI2c(
         product_model(case), meta["T"], case.get("Q"), case["R"], case.get("Qf"), meta["alpha"], meta["tol"],
         case["mu_u"] if mu_u is None else mu_u, case["sig_u"], case.get("mu_x_term"), case.get("sig_x_term"),
-        quad=tuple(meta["quad"]), x0=x0, dtype=dtype, device=device, lib=lib, keep_prior=True,
+        quad=tuple(kw.pop("quad", meta["quad"])), x0=x0, dtype=dtype, device=device, lib=lib, keep_prior=True,
         inference=meta.get("inference", "cubature"), gh_degree=meta.get("gh_degree"), **kw,
     )
     if meta.get("propagate"):

@@ -65,6 +65,14 @@ def test_hip_lane_kernels_vs_reference_golden(lib, name, tol_d, tol_s):
     parity.check_against_golden(name, lib, "cuda", tol_d, tol_s, group_lanes=-1)
 
 
+# the 12-state quadrotor's two multi-lane forms: wave kernels (its default, 64) and group kernels (16)
+@pytest.mark.parametrize("name", ["em_quad12_T20", "em_quad12_T12_propagate", "em_quad12_nondiag_T12"])
+@pytest.mark.parametrize("lanes", [16, 64])
+def test_hip_quad12_both_families_vs_reference_golden(lib, name, lanes):
+    eng = parity.check_against_golden(name, lib, "cuda", 1e-6, 1e-5, group_lanes=lanes)
+    assert eng.forward_family == eng.backward_family == {16: "group", 64: "wave"}[lanes]
+
+
 @pytest.mark.parametrize("name", ["em_dcp_T60", "em_quadrotor_T20"])
 def test_hip_kernel_families_agree_at_B4096(lib, name):
     """The three ways to run a d >= 7 model -- the default (group forward + one-lane backward), group kernels throughout,
@@ -83,7 +91,7 @@ def test_hip_kernel_families_agree_at_B4096(lib, name):
     assert_close(parity.np_(engs[1].alpha), parity.np_(engs[2].alpha), 1e-8, name + ": alpha")
 
 
-@pytest.mark.parametrize("name,B,group", [("em_quad12_T20", 203, 0), ("em_dcp_T60", 77, True), ("em_dcp_T60", 77, -1),
+@pytest.mark.parametrize("name,B,group", [("em_quad12_T20", 203, 0), ("em_quad12_T20", 203, 16), ("em_dcp_T60", 77, True), ("em_dcp_T60", 77, -1),
                                           ("em_pendulum_T200", 1000, True)])
 def test_hip_group_kernels_batch_vs_oracle(lib, name, B, group):
     """Ragged batches (not a multiple of the 64 / G trajectories of a wavefront) against the batched oracle."""

@@ -1,7 +1,8 @@
 """Time one EM iteration (forward / backward / M-step) for any model:
-python tools/bench_models.py [model ...] [B ...] [two_pass|fused|chunked ...] [f64] [group] [lane]
+python tools/bench_models.py [model ...] [B ...] [two_pass|fused|chunked ...] [f64] [group] [lane] [wave]
 `group` runs the group kernels (G lanes per trajectory) as well where a model has both forms; `lane` forces one lane per
-trajectory for every sweep (the default runs the forward sweep of the d >= 7 models on the group kernels at small batches)."""
+trajectory for every sweep (the default runs the forward sweep of the d >= 7 models on the group kernels at small batches);
+`wave` runs the one-wavefront-per-trajectory kernels where a model has them (the 12-state quadrotor)."""
 import importlib
 import os
 import sys
@@ -49,7 +50,7 @@ def run(name, B, dtype, iters=10, mode="auto", group=0):
     el = (d.e_post - nu - nu * (nu + 1) // 2) + 2 * d.e_fwd + d.e_post
     tot = sum(ms)
     print(f"{name:22s} B={B:6d} T={T:3d} {str(dtype)[6:]:8s} fwd {ms[0]:8.3f} bwd {ms[1]:8.3f} mstep {ms[2]:6.3f} ms | "
-          f"[{eng.backward_schedule:8s}{' G=%d' % eng.dims.group_lanes if eng.uses_group_kernels else (' lane' if eng.group_lanes == -1 else ''):5s}] {B * T / tot * 1e3:10.3e} msg/s | {el * w * B * T / tot / 1e6:8.1f} GB/s | fails {len(eng.failures())}")
+          f"[{eng.backward_schedule:8s} {eng.forward_family:5s}/{eng.backward_family:5s}] {B * T / tot * 1e3:10.3e} msg/s | {el * w * B * T / tot / 1e6:8.1f} GB/s | fails {len(eng.failures())}")
 
 
 if __name__ == "__main__":
@@ -58,6 +59,8 @@ if __name__ == "__main__":
     modes = [a for a in sys.argv[1:] if a in ("auto", "two_pass", "fused", "chunked")] or ["auto"]
     dts = (torch.float64,) if "f64" in sys.argv[1:] else (torch.float64, torch.float32)
     groups = (0, True) if "group" in sys.argv[1:] else (0,)
+    if "wave" in sys.argv[1:]:
+        groups = groups + (64,)
     if "lane" in sys.argv[1:]:  # one lane per trajectory for every sweep (no group forward for the d >= 7 models)
         groups = (-1,) + groups[1:]
     for n in names:
@@ -65,8 +68,12 @@ if __name__ == "__main__":
             for dt in dts:
                 for m in modes:
                     for grp in groups:
-                        if grp is True and (dt != torch.float64 or n == "Quadrotor12" or m != modes[0]):
+                        if grp is True and (dt != torch.float64 or m != modes[0]):
                             continue
+                        if grp == 64 and (n != "Quadrotor12" or dt != torch.float64 or m != modes[0]):
+                            continue
+                        if grp == 0 and n == "Quadrotor12" and 64 in groups:
+                            continue  # the default IS the wave family where it applies
                         if grp == -1 and n == "Quadrotor12":
                             grp = 0
                         run(n, B, dt, mode=m, group=grp)

@@ -125,9 +125,9 @@ int main() {
   printf("layout: A lane(q,i)=A[i][q], B lane(q,j)=B[q][j], D reg v lane(q,j)=D[q+4v][j] : max |err| = %.3e  %s\n", err, err < 1e-14 ? "OK" : "MISMATCH");
 
   double* out; uint64_t* clk;
-  hipMalloc(&out, 64 * 8 * 1024); hipMalloc(&clk, 8 * 1024);
+  hipMalloc(&out, 64 * 8 * 4096); hipMalloc(&clk, 8 * 4096);
   const int n = 1000;
-  uint64_t h[1024];
+  static uint64_t h[4096];
   auto avg = [&](int blocks) { hipDeviceSynchronize(); hipMemcpy(h, clk, 8 * blocks, hipMemcpyDeviceToHost); double a = 0; for (int i = 0; i < blocks; ++i) a += double(h[i]); return a / blocks; };
   for (int blocks : {1, 1024}) {
     hipLaunchKernelGGL(k_time<1>, dim3(blocks), dim3(64), 0, 0, out, clk, n);
