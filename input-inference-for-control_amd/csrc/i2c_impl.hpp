@@ -264,14 +264,14 @@ static int launch_group_w(const Consts<M, R>& c, const ZetaArg<M, R>* zeta, cons
 // ---- wave kernels (i2c_wave.hpp): one wavefront per trajectory, four per workgroup ----------------------------------------------
 enum { WK_FORWARD = 0, WK_BACKWARD = 1 };
 constexpr int WAVES_PER_BLOCK = 4;
-template <int KIND, class M, typename R, typename S, class KC, class A>
+template <int KIND, class M, typename R, typename S, bool LIN, class KC, class A>
 I2C_FN void wave_body(const Consts<M, R>& c, const KC& kc, const A& a, const int b, const Wave<R>& w) {
-  if constexpr (KIND == WK_FORWARD) forward_wave_body<M, R, S>(c, kc, a, b, w);
-  if constexpr (KIND == WK_BACKWARD) backward_wave_body<M, R, S>(c, kc, a, b, w);
+  if constexpr (KIND == WK_FORWARD) forward_wave_body<M, R, S, LIN>(c, kc, a, b, w);
+  if constexpr (KIND == WK_BACKWARD) backward_wave_body<M, R, S, LIN>(c, kc, a, b, w);
 }
 #ifdef I2C_HOST_SIM
-template <int KIND, class M, typename R, typename S, class A>
-static int launch_wave(const Consts<M, R>& c, const A& a, void*) {
+template <int KIND, class M, typename R, typename S, bool LIN, class A>
+static int launch_wave_v(const Consts<M, R>& c, const A& a, void*) {
   WConst<M, R> kc;
   wconst_fill<M, R>(kc, &c, 0, 1);
   for (int b = 0; b < c.B; ++b) {
@@ -279,13 +279,13 @@ static int launch_wave(const Consts<M, R>& c, const A& a, void*) {
     HostBarrier bar(64);
     std::vector<std::thread> lanes;
     for (int l = 0; l < 64; ++l)
-      lanes.emplace_back([&, l] { wave_body<KIND, M, R, S>(c, kc, a, b, Wave<R>{l, l >> 4, l & 15, sh.data(), &bar, xch.data()}); });
+      lanes.emplace_back([&, l] { wave_body<KIND, M, R, S, LIN>(c, kc, a, b, Wave<R>{l, l >> 4, l & 15, sh.data(), &bar, xch.data()}); });
     for (auto& th : lanes) th.join();
   }
   return I2C_OK;
 }
 #else
-template <int KIND, class M, typename R, typename S, class A>
+template <int KIND, class M, typename R, typename S, bool LIN, class A>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 2) void k_wave(const Consts<M, R> c, const A a) {
   __shared__ WConst<M, R> kc;
   __shared__ R sh[WAVES_PER_BLOCK * WaveLds::SIZE];
@@ -300,15 +300,23 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 2) void k_wave(const Consts<M
   if (b >= c.B) return;
   const int l = (int)(threadIdx.x & 63u);
   const Wave<R> w{l, l >> 4, l & 15, (lds_ptr<R>)(sh + (threadIdx.x >> 6) * WaveLds::SIZE)};
-  wave_body<KIND, M, R, S>(c, kc, a, (int)b, w);
+  wave_body<KIND, M, R, S, LIN>(c, kc, a, (int)b, w);
 }
-template <int KIND, class M, typename R, typename S, class A>
-static int launch_wave(const Consts<M, R>& c, const A& a, void* stream) {
+template <int KIND, class M, typename R, typename S, bool LIN, class A>
+static int launch_wave_v(const Consts<M, R>& c, const A& a, void* stream) {
   const unsigned blocks = (unsigned)(((long)c.B + 127) / 128) * 32u;
-  hipLaunchKernelGGL((k_wave<KIND, M, R, S, A>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, (hipStream_t)stream, c, a);
+  hipLaunchKernelGGL((k_wave<KIND, M, R, S, LIN, A>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, (hipStream_t)stream, c, a);
   return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
 }
 #endif
+
+template <int KIND, class M, typename R, typename S, class A>
+static int launch_wave(const Consts<M, R>& c, const A& a, void* stream) {
+  if constexpr (sizeof(S) == sizeof(R) && M::NZT > 0) {  // the Linearize variant: fp64 storage, models with a terminal observation
+    if (c.inference == I2C_INF_LINEARIZE) return launch_wave_v<KIND, M, R, S, true>(c, a, stream);
+  }
+  return launch_wave_v<KIND, M, R, S, false>(c, a, stream);
+}
 
 template <int KIND, class M, typename R, int G, class A>
 static int launch_group(const Consts<M, R>& c, const ZetaArg<M, R>* zeta, const A& a, void* stream) {
@@ -453,7 +461,12 @@ template <class M, typename R, typename S = R> struct Impl {
   // what the wave form covers: the cubature rule with lam = 0 (every shipped config: unit weights, no weight on the centre;
   // the centring of the pairwise sums relies on 2 d wi = 1), no terminal state prior, windows below 2 GiB (WIO::st_if)
   static int wave_supported(const I2cProblem* p, const C& c) {
-    if (p->inference != I2C_INF_CUBATURE || c.has_x_terminal) return I2C_ENOTSUP;
+    if (p->inference == I2C_INF_LINEARIZE) {  // Linearize(): fp64 storage; needs a terminal observation like the lane form
+      if (MIXED) return I2C_ENOTSUP;
+      if (M::NZT == 0) return I2C_EINVAL;
+    } else if (p->inference != I2C_INF_CUBATURE || c.has_x_terminal) {
+      return I2C_ENOTSUP;
+    }
     if (!c.rule_xu.unit || !c.rule_x.unit || c.rule_xu.w0 != R(0) || c.rule_x.w0 != R(0)) return I2C_ENOTSUP;
     constexpr long EMAX = C::E_FWD > C::E_POST ? C::E_FWD : C::E_POST;
     if (EMAX * (long)p->B * (long)sizeof(S) >= (1L << 31)) return I2C_EINVAL;
@@ -462,7 +475,8 @@ template <class M, typename R, typename S = R> struct Impl {
   static int family(const I2cProblem* p, const C& c, const int sweep) {
     if constexpr (HAS_WAVE) {  // forward and backward sweeps: on request (group_lanes = 64) or as the model's default
       if ((sweep == I2C_SWEEP_FORWARD || sweep == I2C_SWEEP_BACKWARD) &&
-          (p->group_lanes == 64 || (p->group_lanes == 0 && (p->B <= I2C_WAVE_MAX_BATCH || MIXED)))) {
+          (p->group_lanes == 64 ||
+           (p->group_lanes == 0 && (p->B <= I2C_WAVE_MAX_BATCH || MIXED || p->inference == I2C_INF_LINEARIZE)))) {
         const int rc = wave_supported(p, c);
         if (rc == I2C_OK) return I2C_FAMILY_WAVE;
         if (p->group_lanes == 64 || MIXED) return rc;

@@ -6,7 +6,7 @@
 //     instruction for each of its four row blocks and -- transposed -- the A operand, so  X^T Y  of two resident blocks is four
 //     matrix instructions with NO operand movement (w_tn). Symmetric blocks (covariances) are their own transpose: products
 //     with them are free of any layout change.
-//   * the factorisations are blocked (4 x 4 pivots): the diagonal block goes through LDS to every lane, which factors and
+//   * the factorisations are blocked (4 x 4 pivots): the diagonal block goes to every lane (v_readlane), which factors and
 //     inverts it in registers; the block row is scaled and the trailing matrix AND up to two right-hand sides are updated by
 //     matrix instructions (w_elim). The solves of a cell are right-hand sides of those eliminations -- there is no separate
 //     triangular-solve primitive, and only explicit products with  L^-1 R  are ever formed.
@@ -23,6 +23,7 @@
 // buffer between two barriers.
 #pragma once
 #include "i2c_group.hpp"
+#include "i2c_linearize.hpp"
 
 namespace i2c {
 
@@ -36,9 +37,7 @@ struct WaveLds {
   static constexpr int O_Y = O_MAT + MAT;              // 33 rows: + points, - points, centre
   static constexpr int NVEC = 6;
   static constexpr int O_VEC = O_Y + 33 * YLD + 3;     // vector slots of 16
-  static constexpr int O_DG = O_VEC + NVEC * 16;       // 4 x 4 pivot block
-  static constexpr int O_DUMP = O_DG + 16;             // where masked-off lanes park their LDS stores (one slot per lane)
-  static constexpr int SIZE = O_DUMP + 64;
+  static constexpr int SIZE = O_VEC + NVEC * 16;
 };
 
 template <typename R> struct Wave {
@@ -51,7 +50,6 @@ template <typename R> struct Wave {
   I2C_MEM lds_ptr<R> mat() const { return sh + WaveLds::O_MAT; }
   I2C_MEM lds_ptr<R> ybuf() const { return sh + WaveLds::O_Y; }
   I2C_MEM lds_ptr<R> vec(int i) const { return sh + WaveLds::O_VEC + i * 16; }
-  I2C_MEM lds_ptr<R> dg() const { return sh + WaveLds::O_DG; }
   I2C_MEM int row(int v) const { return q + 4 * v; }  // matrix row of accumulator register v
   // orders this wave's LDS writes before its later LDS reads (and earlier reads before later writes)
   I2C_MEM void sync() const {
@@ -134,6 +132,27 @@ template <typename R> I2C_FN R w_rowsum(const Wave<R>& w, const R x) {
   return __hiloint2double(h16[0], l16[0]) + __hiloint2double(h16[1], l16[1]);
 #endif
 }
+// The 4 x 4 pivot block of row block KB of a symmetric matrix, to every lane: x = accumulator register KB, whose entry (a, b) of
+// the block sits in lane (a, 4 KB + b). Ten v_readlane pairs into scalar registers: no LDS round trip, and the block is
+// provably wave-uniform for everything computed from it. d = {d00, d10, d11, d20, d21, d22, d30, d31, d32, d33}.
+template <int KB, typename R> I2C_FN void w_pivot_block(const Wave<R>& w, const R x, R* d) {
+#ifdef I2C_HOST_SIM
+  w.bar->wait();
+  w.xch[w.l] = x;
+  w.bar->wait();
+  int n = 0;
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b <= a; ++b) d[n++] = w.xch[16 * a + 4 * KB + b];
+#else
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  int n = 0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b)
+      d[n++] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * a + 4 * KB + b), __builtin_amdgcn_readlane(lo, 16 * a + 4 * KB + b));
+#endif
+}
 // column form (lane (q, j): x[j]) -> row form (x[q + 4 v], v < NV) through vector slot `slot`
 template <int NV, typename R> I2C_FN void w_col2row(const Wave<R>& w, const int slot, const R xc, R* xr) {
   const auto s = w.vec(slot);
@@ -164,8 +183,8 @@ template <typename R> I2C_FN R w_wavesum(const Wave<R>& w, const int slot, const
 
 // Batch-wide constants by row, in LDS (one copy per workgroup): 16 x 16 row-major, zero-padded
 template <class M, typename R> struct WConst {
-  R xi[256], eta[256], xiT[256], qr[256], qf[256];  // sig_xi0, sig_eta, sig_xiT0, blkdiag(Q, R), Qf
-  R zg[16], zgT[16];
+  R xi[256], eta[256], xiT[256], qr[256], qf[256], sxT[256];  // sig_xi0, sig_eta, sig_xiT0, blkdiag(Q, R), Qf, sig_x_terminal
+  R zg[16], zgT[16], mxT[16];
 };
 template <class M, typename R, class DST> I2C_FN void wconst_fill(DST& k, const Consts<M, R>* c, const int tid, const int nthreads) {
   constexpr int NX = M::NX, NZ = M::NZ, NT = M::NZT > 0 ? M::NZT : 1;
@@ -176,10 +195,12 @@ template <class M, typename R, class DST> I2C_FN void wconst_fill(DST& k, const 
     k.xiT[e] = (i < NT && j < NT) ? c->sig_xiT0[tri_any(i, j)] : R(0);
     k.qr[e] = (i < NZ && j < NZ) ? c->QR[tri_any(i, j)] : R(0);
     k.qf[e] = (i < NT && j < NT) ? c->Qf[tri_any(i, j)] : R(0);
+    k.sxT[e] = (i < NX && j < NX) ? c->sig_x_term[tri_any(i, j)] : R(0);
   }
   for (int e = tid; e < 16; e += nthreads) {
     k.zg[e] = e < NZ ? c->zg[e] : R(0);
     k.zgT[e] = e < NT ? c->zg_term[e] : R(0);
+    k.mxT[e] = e < NX ? c->mu_x_term[e] : R(0);
   }
 }
 // accumulator-layout registers of a constant block
@@ -191,74 +212,73 @@ template <int NV, typename R, class P> I2C_FN void w_ldconst(const Wave<R>& w, c
 // ---- blocked Cholesky elimination --------------------------------------------------------------------------------------------
 // s: SPD matrix of dimension 4 NB (accumulator layout, consumed). On return lt = L^T (upper triangular, accumulator layout,
 // rows >= 4 NB zero) and, for each of the NRHS right-hand sides r (4 NB x 16), r = L^-1 r. Returns whether every pivot was
-// positive. Per 4 x 4 pivot block: the block goes through LDS to every lane, which factors it and inverts the factor in
+// positive. Per 4 x 4 pivot block: the block goes to every lane (w_pivot_block), which factors it and inverts the factor in
 // registers (four dependent rsq chains: the serial core of the kernel); lane (q, i) then holds entry (i mod 4, q) of that inverse
 // as the A operand of the matrix instruction that scales block row kb of s and of every right-hand side, and the scaled block
 // row of s (= rows of L^T) is A and B operand of the rank-4 update of everything below.
+template <int KB, int NB, int NRHS, typename R>
+I2C_FN void w_elim_step(const Wave<R>& w, R* s, R* r1, R* r2, R* lt, const R* mq, R* last) {
+  const int a = w.j & 3, cq = w.q;
+  const bool inblk = (w.j >> 2) == KB;
+  R d[10];
+  w_pivot_block<KB>(w, s[KB], d);
+  const R d00 = d[0], d10 = d[1], d11 = d[2], d20 = d[3], d21 = d[4], d22 = d[5], d30 = d[6], d31 = d[7], d32 = d[8], d33 = d[9];
+  // 4 x 4 Cholesky (l) ...
+  const R i0 = r_rsqrt(d00);
+  const R l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
+  const R p1 = d11 - l10 * l10;
+  const R i1 = r_rsqrt(p1);
+  const R l21 = (d21 - l20 * l10) * i1, l31 = (d31 - l30 * l10) * i1;
+  const R p2 = d22 - l20 * l20 - l21 * l21;
+  const R i2 = r_rsqrt(p2);
+  const R l32 = (d32 - l30 * l20 - l31 * l21) * i2;
+  const R p3 = d33 - l30 * l30 - l31 * l31 - l32 * l32;
+  const R i3 = r_rsqrt(p3);
+  if (KB == NB - 1) *last = p3;  // a failed pivot poisons everything after it (see chol(), i2c_linalg.hpp)
+  // ... and this lane's entry of its inverse: row a of L^-1 solves y^T L = e_a^T (back substitution; y_c = 0 for c > a
+  // falls out of the one-hot right-hand side, which is also zero outside block row KB), entry cq picked by a one-hot
+  // combination. Written without selects on purpose: with selects hipcc sinks the arithmetic into per-(a, cq) divergent
+  // branches, which a wavefront then executes one after the other.
+  const R e0 = (inblk && a == 0) ? R(1) : R(0), e1 = (inblk && a == 1) ? R(1) : R(0);
+  const R e2 = (inblk && a == 2) ? R(1) : R(0), e3 = (inblk && a == 3) ? R(1) : R(0);
+  const R y3 = e3 * i3;
+  const R y2 = (e2 - l32 * y3) * i2;
+  const R y1 = (e1 - l21 * y2 - l31 * y3) * i1;
+  const R y0 = (e0 - l10 * y1 - l20 * y2 - l30 * y3) * i0;
+  const R aw = (mq[0] * y0 + mq[1] * y1) + (mq[2] * y2 + mq[3] * y3);
+  // scale block row KB: rows of L^T (masked to the upper triangle: what is left of it is rounding noise) ...
+  R x[4] = {R(0), R(0), R(0), R(0)};
+  w_mfma(w, aw, s[KB], x);
+  const R ltk = (w.j >= 4 * KB + cq) ? x[KB] : R(0);
+  lt[KB] = ltk;
+  R x1 = R(0), x2 = R(0);
+  if (NRHS >= 1) {
+    R y[4] = {R(0), R(0), R(0), R(0)};
+    w_mfma(w, aw, r1[KB], y);
+    x1 = y[KB];
+  }
+  if (NRHS >= 2) {
+    R y[4] = {R(0), R(0), R(0), R(0)};
+    w_mfma(w, aw, r2[KB], y);
+    x2 = y[KB];
+  }
+  // ... and eliminate it from everything below
+  if (KB < NB - 1) {
+    w_mfma(w, -ltk, ltk, s);
+    if (NRHS >= 1) w_mfma(w, -ltk, x1, r1);
+    if (NRHS >= 2) w_mfma(w, -ltk, x2, r2);
+  }
+  if (NRHS >= 1) r1[KB] = x1;
+  if (NRHS >= 2) r2[KB] = x2;
+  if constexpr (KB + 1 < NB) w_elim_step<KB + 1, NB, NRHS>(w, s, r1, r2, lt, mq, last);
+}
 template <int NB, int NRHS, typename R> I2C_FN bool w_elim(const Wave<R>& w, R* s, R* r1, R* r2, R* lt) {
-  const auto dg = w.dg();
-  const int a = w.j & 3, cq = w.q, blk = w.j >> 2;
   R last = R(0), mq[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) mq[k] = cq == k ? R(1) : R(0);
+  for (int k = 0; k < 4; ++k) mq[k] = w.q == k ? R(1) : R(0);
 #pragma unroll
   for (int v = 0; v < 4; ++v) lt[v] = R(0);
-#pragma unroll
-  for (int kb = 0; kb < NB; ++kb) {
-    const bool inblk = blk == kb;
-    w.sync();
-    dg[inblk ? cq * 4 + a : 16 + w.l] = s[kb];  // entry (q, j mod 4) of the pivot block; the other lanes park their store
-    w.sync();
-    const R d00 = dg[0], d10 = dg[4], d11 = dg[5], d20 = dg[8], d21 = dg[9], d22 = dg[10];
-    const R d30 = dg[12], d31 = dg[13], d32 = dg[14], d33 = dg[15];
-    // 4 x 4 Cholesky (l) ...
-    const R i0 = r_rsqrt(d00);
-    const R l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
-    const R p1 = d11 - l10 * l10;
-    const R i1 = r_rsqrt(p1);
-    const R l21 = (d21 - l20 * l10) * i1, l31 = (d31 - l30 * l10) * i1;
-    const R p2 = d22 - l20 * l20 - l21 * l21;
-    const R i2 = r_rsqrt(p2);
-    const R l32 = (d32 - l30 * l20 - l31 * l21) * i2;
-    const R p3 = d33 - l30 * l30 - l31 * l31 - l32 * l32;
-    const R i3 = r_rsqrt(p3);
-    if (kb == NB - 1) last = p3;  // a failed pivot poisons everything after it (see chol(), i2c_linalg.hpp)
-    // ... and this lane's entry of its inverse: row a of L^-1 solves y^T L = e_a^T (back substitution; y_c = 0 for c > a
-    // falls out of the one-hot right-hand side, which is also zero outside block row kb), entry cq picked by a one-hot
-    // combination. Written without selects on purpose: with selects hipcc sinks the arithmetic into per-(a, cq) divergent
-    // branches, which a wavefront then executes one after the other.
-    const R e0 = (inblk && a == 0) ? R(1) : R(0), e1 = (inblk && a == 1) ? R(1) : R(0);
-    const R e2 = (inblk && a == 2) ? R(1) : R(0), e3 = (inblk && a == 3) ? R(1) : R(0);
-    const R y3 = e3 * i3;
-    const R y2 = (e2 - l32 * y3) * i2;
-    const R y1 = (e1 - l21 * y2 - l31 * y3) * i1;
-    const R y0 = (e0 - l10 * y1 - l20 * y2 - l30 * y3) * i0;
-    const R aw = (mq[0] * y0 + mq[1] * y1) + (mq[2] * y2 + mq[3] * y3);
-    // scale block row kb: rows of L^T (masked to the upper triangle: what is left of it is rounding noise) ...
-    R x[4] = {R(0), R(0), R(0), R(0)};
-    w_mfma(w, aw, s[kb], x);
-    const R ltk = (w.j >= 4 * kb + cq) ? x[kb] : R(0);
-    lt[kb] = ltk;
-    R x1 = R(0), x2 = R(0);
-    if (NRHS >= 1) {
-      R y[4] = {R(0), R(0), R(0), R(0)};
-      w_mfma(w, aw, r1[kb], y);
-      x1 = y[kb];
-    }
-    if (NRHS >= 2) {
-      R y[4] = {R(0), R(0), R(0), R(0)};
-      w_mfma(w, aw, r2[kb], y);
-      x2 = y[kb];
-    }
-    // ... and eliminate it from everything below
-    if (kb < NB - 1) {
-      w_mfma(w, -ltk, ltk, s);
-      if (NRHS >= 1) w_mfma(w, -ltk, x1, r1);
-      if (NRHS >= 2) w_mfma(w, -ltk, x2, r2);
-    }
-    if (NRHS >= 1) r1[kb] = x1;
-    if (NRHS >= 2) r2[kb] = x2;
-  }
+  w_elim_step<0, NB, NRHS>(w, s, r1, r2, lt, mq, &last);
   return last > R(0);
 }
 
@@ -321,7 +341,10 @@ template <int NB, typename R, class P> I2C_FN bool w_kalman(const Wave<R>& w, co
 // ------------------------------------------------------------------------------------------
 // Forward sweep (i2c.py:876-880 over :350-447)
 // ------------------------------------------------------------------------------------------
-template <class M, typename R, typename S, class KC>
+// LIN: Linearize() inference (i2c.py:244-348): the same cell with the dynamics push-through replaced by value + Jacobian (one
+// forward-mode pass per input direction, lane p carrying the tangent e_p), the pdf-ratio scaling of the gain only with the
+// expert controller (:259-265), and no terminal update here (it happens at the end of the backward chain, :475-491).
+template <class M, typename R, typename S, bool LIN, class KC>
 I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const FwdArgs<R, S>& a, const int b, const Wave<R>& w) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D, NBX = NX / 4;
@@ -347,7 +370,7 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
   // The prior rows of a cell do not depend on the recursion: they are fetched ONE CELL AHEAD (issued once the current cell's
   // have been consumed), so that the memory round trip hides behind a cell's worth of work.
   R nx_pmu, nx_pj[4], nx_kt[4], nx_alpha, nx_zt;
-  int nx_ff;
+  int nx_ff, nx_ex;
   auto fetch_prior = [&](const int tc) {
     const int trc = c.row(tc);
     const WIO<R, S> pri = wio<R, S>(a.prior + (unsigned long)trc * C::E_POST * B, C::E_POST, rb, bo);
@@ -359,13 +382,14 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
     nx_alpha = a.alpha_cell ? a.alpha_cell[(long)trc * B + b] : alpha_traj;
     nx_zt = c.z_per_cell ? a.z[((long)trc * NZ + j) * B + b] : kc.zg[j];
     nx_ff = a.ff[trc];
+    nx_ex = LIN ? (a.expert ? (int)a.expert[trc] : c.use_expert) : 1;  // the sigma-point cell always scales the gain (i2c.py:366-375)
   };
   fetch_prior(0);
 
   for (int t = 0; t < T; ++t) {
     const WIO<R, S> out = wio<R, S>(a.fwd + (unsigned long)t * C::E_FWD * B, C::E_FWD, rb, bo);
     const R alpha = nx_alpha, zt = nx_zt, pmu = nx_pmu;
-    const bool ff = w_uniform(nx_ff) != 0;
+    const bool ff = w_uniform(nx_ff) != 0, scale_gain = w_uniform(nx_ex) != 0;
     R pj[4], kt[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -385,18 +409,21 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
       const R dl = jx ? mx - pmu : R(0);
       R dr[4];
       w_col2row<NBX>(w, 0, dl, dr);
-      R sm[4], rh[4], lt[4];
+      R rho = R(1);
+      if (scale_gain) {
+        R sm[4], rh[4], lt[4];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        sm[v] = (v < NBX && jx) ? pj[v] + sx[v] : R(0);
-        rh[v] = (v < NBX && j == NX) ? dr[v] : R(0);
+        for (int v = 0; v < 4; ++v) {
+          sm[v] = (v < NBX && jx) ? pj[v] + sx[v] : R(0);
+          rh[v] = (v < NBX && j == NX) ? dr[v] : R(0);
+        }
+        cell_bad = flag_stage(cell_bad, w_elim<NBX, 1>(w, sm, rh, (R*)nullptr, lt), 0);
+        R ysq = R(0);
+#pragma unroll
+        for (int v = 0; v < NBX; ++v) ysq += rh[v] * rh[v];
+        const R maha = w_bcast<NX>(w, w_rowsum(w, ysq));
+        rho = r_exp(R(-0.5) * maha);
       }
-      cell_bad = flag_stage(cell_bad, w_elim<NBX, 1>(w, sm, rh, (R*)nullptr, lt), 0);
-      R ysq = R(0);
-#pragma unroll
-      for (int v = 0; v < NBX; ++v) ysq += rh[v] * rh[v];
-      const R maha = w_bcast<NX>(w, w_rowsum(w, ysq));
-      const R rho = r_exp(R(-0.5) * maha);
       // F^T = [I | Kt^T] (nx x 16), Kt = rho K:  sig_0 = F sig_x F^T with (P_uu - Kt P_xu) added to the action block
       R ft[4], m1[4] = {R(0), R(0), R(0), R(0)};
 #pragma unroll
@@ -434,72 +461,131 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
 #pragma unroll
     for (int v = 0; v < 4; ++v) out.st_if(w.row(v) >= j, D + w_symidx(w.row(v), j), s0[v]);
 
-    // ---- 3. dynamics push-through (i2c.py:415-421) ---------------------------------------
-    R lt[4];
-    {
-      R tmp[4];
+    // ---- 3. dynamics push-through (i2c.py:415-421; Linearize: :321-341) ----------------------
+    R sxy[4] = {R(0), R(0), R(0), R(0)};  // sig_xy^T (nx x 16)
+    if constexpr (!LIN) {
+      R lt[4];
+      {
+        R tmp[4];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) tmp[v] = s0[v];
-      cell_bad = flag_stage(cell_bad, w_elim<4, 0>(w, tmp, (R*)nullptr, (R*)nullptr, lt), 3);
-    }
-    const auto Lt = w.mat();
-    const auto mv = w.vec(2);
-    w.sync();
+        for (int v = 0; v < 4; ++v) tmp[v] = s0[v];
+        cell_bad = flag_stage(cell_bad, w_elim<4, 0>(w, tmp, (R*)nullptr, (R*)nullptr, lt), 3);
+      }
+      const auto Lt = w.mat();
+      const auto mv = w.vec(2);
+      w.sync();
 #pragma unroll
-    for (int v = 0; v < 4; ++v) Lt[w.row(v) * WLD + j] = lt[v];  // row p of L^T = direction of sigma-point pair p
+      for (int v = 0; v < 4; ++v) Lt[w.row(v) * WLD + j] = lt[v];  // row p of L^T = direction of sigma-point pair p
 #ifdef I2C_HOST_SIM
-    if (q == 0)
+      if (q == 0)
 #endif
-      mv[j] = mu0;
-    w.sync();
-    {
-      // lane p: m + sf L[:, p]; lane 16 + p: m - sf L[:, p]; lanes >= 32: the centre (lane 32's copy is used)
-      const int p = w.l & 15;
-      const R sg = w.l < 16 ? rule.sf : (w.l < 32 ? -rule.sf : R(0));
-      R x[D], sn[M::NA > 0 ? M::NA : 1], cs[M::NA > 0 ? M::NA : 1], y[NX];
+        mv[j] = mu0;
+      w.sync();
+      {
+        // lane p: m + sf L[:, p]; lane 16 + p: m - sf L[:, p]; lanes >= 32: the centre (lane 32's copy is used)
+        const int p = w.l & 15;
+        const R sg = w.l < 16 ? rule.sf : (w.l < 32 ? -rule.sf : R(0));
+        R x[D], sn[M::NA > 0 ? M::NA : 1], cs[M::NA > 0 ? M::NA : 1], y[NX];
 #pragma unroll
-      for (int i = 0; i < D; ++i) x[i] = mv[i] + sg * Lt[p * WLD + i];
+        for (int i = 0; i < D; ++i) x[i] = mv[i] + sg * Lt[p * WLD + i];
 #pragma unroll
-      for (int k = 0; k < M::NA; ++k) r_sincos(x[M::ang(k)], &sn[k], &cs[k]);
-      M::dynamics(c.params, x, sn, cs, y);
-      const auto Y = w.ybuf();
-      if (w.l <= 32) {  // lanes beyond the centre computed a copy of it
+        for (int k = 0; k < M::NA; ++k) r_sincos(x[M::ang(k)], &sn[k], &cs[k]);
+        M::dynamics(c.params, x, sn, cs, y);
+        const auto Y = w.ybuf();
+        if (w.l <= 32) {  // lanes beyond the centre computed a copy of it
 #pragma unroll
-        for (int k = 0; k < NX; ++k) Y[w.l * WaveLds::YLD + k] = y[k];
+          for (int k = 0; k < NX; ++k) Y[w.l * WaveLds::YLD + k] = y[k];
+        }
       }
-    }
-    w.sync();
-    // a_p = (y+ - y0) + (y- - y0), d_p = y+ - y-, in the accumulator layout (row = point pair, column = output)
-    R am[4], dm[4], y0;
-    {
-      const auto Y = w.ybuf();
-      y0 = opaque(Y[32 * WaveLds::YLD + jxc]);  // (opaque: an unconditional read, not an EXEC-masked one)
-      y0 = jx ? y0 : R(0);
+      w.sync();
+      // a_p = (y+ - y0) + (y- - y0), d_p = y+ - y-, in the accumulator layout (row = point pair, column = output)
+      R am[4], dm[4], y0;
+      {
+        const auto Y = w.ybuf();
+        y0 = opaque(Y[32 * WaveLds::YLD + jxc]);  // (opaque: an unconditional read, not an EXEC-masked one)
+        y0 = jx ? y0 : R(0);
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const R yp = Y[w.row(v) * WaveLds::YLD + jxc], ym = Y[(16 + w.row(v)) * WaveLds::YLD + jxc];
-        am[v] = jx ? (yp - y0) + (ym - y0) : R(0);
-        dm[v] = jx ? yp - ym : R(0);
+        for (int v = 0; v < 4; ++v) {
+          const R yp = Y[w.row(v) * WaveLds::YLD + jxc], ym = Y[(16 + w.row(v)) * WaveLds::YLD + jxc];
+          am[v] = jx ? (yp - y0) + (ym - y0) : R(0);
+          dm[v] = jx ? yp - ym : R(0);
+        }
       }
-    }
-    const R asum = w_rowsum(w, (am[0] + am[1]) + (am[2] + am[3]));
-    mx = y0 + rule.wi * asum;  // mu_x3_f (column form)
-    // sig_y = wi/2 sum_p (a_p a_p^T + d_p d_p^T) - wi^2 A A^T: with 2 d wi = 1 the last term centres the a_p
-    R at[4], sy[4] = {R(0), R(0), R(0), R(0)}, sxy[4] = {R(0), R(0), R(0), R(0)};
-    const R amean = (R(2) * rule.wi) * asum;
+      const R asum = w_rowsum(w, (am[0] + am[1]) + (am[2] + am[3]));
+      mx = y0 + rule.wi * asum;  // mu_x3_f (column form)
+      // sig_y = wi/2 sum_p (a_p a_p^T + d_p d_p^T) - wi^2 A A^T: with 2 d wi = 1 the last term centres the a_p
+      R at[4], sy[4] = {R(0), R(0), R(0), R(0)};
+      const R amean = (R(2) * rule.wi) * asum;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) at[v] = jx ? am[v] - amean : R(0);
-    w_tn<4>(w, at, at, sy);
-    w_tn<4>(w, dm, dm, sy);
-    w_tn<4>(w, dm, lt, sxy);  // sig_xy^T = wi sf [d_p]^T L^T  (nx x 16)
-    {
+      for (int v = 0; v < 4; ++v) at[v] = jx ? am[v] - amean : R(0);
+      w_tn<4>(w, at, at, sy);
+      w_tn<4>(w, dm, dm, sy);
+      w_tn<4>(w, dm, lt, sxy);  // sig_xy^T = wi sf [d_p]^T L^T  (nx x 16)
+      {
+        R eta[4];
+        w_ldconst<NBX>(w, kc.eta, eta);
+        const R hw = R(0.5) * rule.wi, cw = rule.wi * rule.sf;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          sx[v] = v < NBX ? hw * sy[v] + eta[v] : R(0);
+          sxy[v] = v < NBX ? cw * sxy[v] : R(0);
+        }
+      }
+    } else {
+      // value and Jacobian A = d f / d [x; u] at the updated mean: lane p differentiates along input p (single-tangent dual
+      // numbers through the SAME model functor), A^T lands in the accumulator layout (row = input, column = output)
+      const auto mv = w.vec(2);
+      w.sync();
+#ifdef I2C_HOST_SIM
+      if (q == 0)
+#endif
+        mv[j] = mu0;
+      w.sync();
+      {
+        constexpr int NA1 = M::NA > 0 ? M::NA : 1, NP1 = M::NP > 0 ? M::NP : 1;
+        const int p = w.l & 15;
+        Dual<R> pd[NP1], x[D], sn[NA1], cs[NA1], y[NX];
+#pragma unroll
+        for (int i = 0; i < M::NP; ++i) pd[i] = Dual<R>(c.params[i]);
+#pragma unroll
+        for (int i = 0; i < D; ++i) x[i] = Dual<R>(mv[i], i == p ? R(1) : R(0));
+#pragma unroll
+        for (int k = 0; k < M::NA; ++k) {
+          R s0v, c0v;
+          r_sincos(x[M::ang(k)].v, &s0v, &c0v);
+          const R seed = M::ang(k) == p ? R(1) : R(0);
+          sn[k] = Dual<R>(s0v, seed * c0v);
+          cs[k] = Dual<R>(c0v, -seed * s0v);
+        }
+        M::dynamics(pd, x, sn, cs, y);
+        const auto Y = w.ybuf();
+        if (w.l <= 16) {  // lanes 0..15: their column of A; lane 16 (a copy of lane 0's evaluation): the value f(mu)
+          const int yrow = w.l < 16 ? w.l : 32;
+#pragma unroll
+          for (int k = 0; k < NX; ++k) Y[yrow * WaveLds::YLD + k] = w.l < 16 ? y[k].d : y[k].v;
+        }
+      }
+      w.sync();
+      R at[4], pm[4] = {R(0), R(0), R(0), R(0)}, sy[4] = {R(0), R(0), R(0), R(0)};
+      {
+        const auto Y = w.ybuf();
+        const R y0 = opaque(Y[32 * WaveLds::YLD + jxc]);
+        mx = jx ? y0 : R(0);  // mu_x3_f = f(mu_xu1_f)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const R av = opaque(Y[w.row(v) * WaveLds::YLD + jxc]);
+          at[v] = jx ? av : R(0);
+        }
+      }
+      w_tn<4>(w, at, s0, sxy);  // A sig_1   = sig_xy^T
+      w_tn<4>(w, s0, at, pm);   // sig_1 A^T = sig_xy
+      w_tn<4>(w, at, pm, sy);   // A sig_1 A^T
       R eta[4];
       w_ldconst<NBX>(w, kc.eta, eta);
-      const R hw = R(0.5) * rule.wi, cw = rule.wi * rule.sf;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        sx[v] = v < NBX ? hw * sy[v] + eta[v] : R(0);
-        sxy[v] = v < NBX ? cw * sxy[v] : R(0);
+        sx[v] = v < NBX ? sy[v] + eta[v] : R(0);
+        sxy[v] = v < NBX ? sxy[v] : R(0);
       }
     }
     // ---- smoother gain J = sig_xy sig_x3^-1 (i2c.py:423-425): J^T = W^T (W sig_xy^T), W = chol(sig_x3)^-1 ----
@@ -516,7 +602,7 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
       for (int v = 0; v < NBX; ++v) out.st(O_J + j * NX + w.row(v), jt[v]);
     }
     // ---- 4. terminal cost observation on the flagged cell, after J (i2c.py:430-443) ----
-    if (NZT > 0 && t == c.terminal_cell && c.has_Qf)  // (uniform: kernel arguments)
+    if (!LIN && NZT > 0 && t == c.terminal_cell && c.has_Qf)  // (uniform: kernel arguments)
       cell_bad = flag_stage(cell_bad, w_kalman<NBX>(w, alpha, kc.xiT, kc.qf, c.qf_diag != 0, kc.zgT[j], &mx, sx), 5);
     fail = fold_cell_failure(fail, cell_bad, t);
     out.st_if(q == 0 && jx, O_MU3 + jxc, mx);
@@ -529,7 +615,12 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
 // ------------------------------------------------------------------------------------------
 // Backward sweep (i2c.py:882-886 over :544-610), fused form: the wave walks T-1..0 doing the whole cell.
 // ------------------------------------------------------------------------------------------
-template <class M, typename R, typename S, class KC>
+// LIN: Linearize() inference (i2c.py:449-542): at the end of the chain a terminal state prior PINS the smoothed terminal state
+// (:453-472), otherwise the terminal cost observation is applied there (:475-491, with sig_xi_terminal kept in sig_z3_m); per
+// cell the alpha statistic uses the linearised marginal observation WITHOUT state-action cross terms (:537-540) while the plan
+// cost is priced with the cubature transform of the full joint (i2c.py:841-844, 1034-1053).
+// term_stats rows: 0 = terminal trace, 1 = sum_t alpha statistic, 2 = sum_t cost variance, last = sum_t plan-cost mean (LIN).
+template <class M, typename R, typename S, bool LIN, class KC>
 I2C_HD inline void backward_wave_body(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>& a, const int b, const Wave<R>& w) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D, NBX = NX / 4, NT = C::NZT1;
@@ -596,20 +687,35 @@ I2C_HD inline void backward_wave_body(const Consts<M, R>& c, const KC& kc, const
 #pragma unroll
     for (int v = 0; v < 4; ++v) s3m[v] = (v < NBX && jx) ? fw.ld(O_S3 + w_symidx(w.row(v) < NX ? w.row(v) : 0, jxc)) : R(0);
   }
+  R xiT[4] = {R(0), R(0), R(0), R(0)};  // Linearize: the sig_xi_terminal that stays in sig_z3_m (i2c.py:460, 488, 497)
+  if (LIN) {
+    if (c.has_x_terminal) {
+      m3m = jx ? kc.mxT[jxc] : R(0);
+      w_ldconst<NBX>(w, kc.sxT, s3m);
+    } else if (NZT > 0 && c.has_Qf) {
+      const R alpha = a.alpha[b];
+      if (!w_kalman<NBX>(w, alpha, kc.xiT, kc.qf, c.qf_diag != 0, kc.zgT[j], &m3m, s3m) && w.l == 0) set_status(a.status, b, 6, T - 1);
+      w_ldconst<NBX>(w, kc.xiT, xiT);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) xiT[v] *= alpha;
+    }
+  }
   // terminal observation statistics (i2c.py:567-570, 989-992): tr(Qf (errT errT^T + sig_z3_m)), identity observation
   R trT = R(0);
   if (NZT > 0 && c.has_Qf) {
-    R pm, pv;
-    cost_share(c.qf_diag != 0, kc.qf, NBX, jx ? m3m - kc.zgT[jxc] : R(0), s3m, &pm, &pv);
+    R pm, pv, szt[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) szt[v] = s3m[v] + xiT[v];
+    cost_share(c.qf_diag != 0, kc.qf, NBX, jx ? m3m - kc.zgT[jxc] : R(0), szt, &pm, &pv);
     trT = w_wavesum(w, 5, pm);
     if (q == 0 && jx) a.term_stats[(long)(3 + jxc) * B + b] = m3m;
 #pragma unroll
     for (int v = 0; v < NBX; ++v)
-      if (jx && w.row(v) >= j) a.term_stats[(long)(3 + NT + w_symidx(w.row(v), jxc)) * B + b] = s3m[v];
+      if (jx && w.row(v) >= j) a.term_stats[(long)(3 + NT + w_symidx(w.row(v), jxc)) * B + b] = szt[v];
   }
   if (w.l == 0) a.term_stats[b] = trT;
 
-  R acc_m = R(0), acc_v = R(0);  // this lane's share of the cost sums over t (reduced once, after the walk)
+  R acc_m = R(0), acc_v = R(0), acc_a = R(0);  // this lane's share of the cost sums over t (reduced once, after the walk)
   // forward rows of a cell, fetched one cell ahead (see forward_wave_body)
   R nx_mu, nx_m3f, nx_sg[4], nx_s3f[4], nx_jt[4], nx_zt;
   auto fetch_fwd = [&](const int tc) {
@@ -663,6 +769,13 @@ I2C_HD inline void backward_wave_body(const Consts<M, R>& c, const KC& kc, const
       cost_share(c.qr_diag != 0, kc.qr, 4, mu - zt, sg, &pm, &pv);
       acc_m += pm;
       acc_v += pv;
+      if (LIN) {  // alpha statistic: the linearised marginal observation, block-diagonal in (x, u) (i2c.py:537-540)
+        R sbd[4], pa, pva;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) sbd[v] = ((w.row(v) < NX) == jx) ? sg[v] : R(0);
+        cost_share(c.qr_diag != 0, kc.qr, 4, mu - zt, sbd, &pa, &pva);
+        acc_a += pa;
+      }
       if (a.cell_stats) {
         const R cm = w_wavesum(w, 5, pm), cv = w_wavesum(w, 5, pv);
         if (w.l == 0) {
@@ -699,17 +812,18 @@ I2C_HD inline void backward_wave_body(const Consts<M, R>& c, const KC& kc, const
       S* zo = a.zpost + ((long)t * C::E_ZPOST) * B + b;
       if (q == 0) zo[(long)j * B] = (S)mu;
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
-        if (w.row(v) >= j) zo[(long)(NZ + w_symidx(w.row(v), j)) * B] = (S)sg[v];
+      for (int v = 0; v < 4; ++v)  // (Linearize: the linearised marginal observation has no state-action cross terms)
+        if (w.row(v) >= j) zo[(long)(NZ + w_symidx(w.row(v), j)) * B] = (S)((LIN && (w.row(v) < NX) != jx) ? R(0) : sg[v]);
     }
     m3m = jx ? mu : R(0);
 #pragma unroll
     for (int v = 0; v < 4; ++v) s3m[v] = (v < NBX && jx) ? sg[v] : R(0);
   }
-  const R sm = w_wavesum(w, 5, acc_m), sv = w_wavesum(w, 5, acc_v);
+  const R sm = w_wavesum(w, 5, acc_m), sv = w_wavesum(w, 5, acc_v), sa = LIN ? w_wavesum(w, 5, acc_a) : sm;
   if (w.l == 0) {
-    a.term_stats[B + b] = sm;
+    a.term_stats[B + b] = sa;
     a.term_stats[2 * B + b] = sv;
+    if (LIN) a.term_stats[(long)(C::E_TERM - 1) * B + b] = sm;
   }
 }
 

@@ -483,6 +483,20 @@ def _reference_quad12():
         def measure(x):
             return q.measure(x)
 
+        # Linearize() hooks (i2c.py:278-285, 321-323, 475-478): identity observations; the dynamics Jacobian through the
+        # same stand-in for autograd.jacobian as the reference's own models get here (oracle/ref_shim.py)
+        def dydxu(self, xu):
+            import autograd
+
+            return autograd.jacobian(self.dynamics)(xu).reshape((self.dim_x, self.dim_xu))
+
+        def observe_linearize(self, xu):
+            z = self.observe(xu).T
+            return z, np.eye(16)[:, :12], np.zeros((16, 1)), np.eye(16)[:, 12:]
+
+        def observe_terminal_linearize(self, x):
+            return self.observe_terminal(x.T).T, np.eye(12), np.zeros((12, 1))
+
     return Quad12Analytic()
 
 
@@ -881,6 +895,21 @@ def case_lin_double_cartpole():
 
 
 
+def case_lin_quad12(T=20, n_detail=2, n_total=6):
+    """Linearize() on the build-defined 12-state quadrotor (d = 16) through the reference's own I2cGraph."""
+    from i2c.exp_types import Linearize
+
+    model = _reference_quad12()
+    rng = np.random.default_rng(17)
+    mu_u = 0.25 * model.gravity * np.ones((T, 4)) + 1e-2 * rng.normal(size=(T, 4))
+    sig_u = 1e-2 * np.eye(4)
+    g = I2cGraph(model, T, QUAD12_Q, QUAD12_R, QUAD12_Q, 1.0, 0.5, mu_u, sig_u, None, None, Linearize())
+    out = problem_inputs("Quadrotor12", model, T, QUAD12_Q, QUAD12_R, QUAD12_Q, 1.0, 0.5, mu_u, sig_u, None, None, (1, 0, 0),
+                         inference="linearize", jacobian="complex-step stand-in for autograd.jacobian (oracle/ref_shim.py)")
+    run_em_linearize(g, n_detail, n_total, out)
+    save("lin_quad12_T20", out)
+
+
 def case_gh_pendulum(T=40, degree=3, n_detail=2, n_total=8):
     """GaussHermiteQuadrature(degree) as the inference method (exp_types.py:52-68): 27 points per joint transform, 9 for
     the terminal one. No reference script ships such a config; hyper-parameters of pendulum_known_quad.py."""
@@ -944,6 +973,7 @@ CASES = {
     "lin_pendulum": case_lin_pendulum,
     "lin_cartpole": case_lin_cartpole,
     "lin_dcp": case_lin_double_cartpole,
+    "lin_quad12": case_lin_quad12,
 }
 
 if __name__ == "__main__":

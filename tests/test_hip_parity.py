@@ -104,6 +104,7 @@ LINEARIZE = [
     ("lin_pendulum_T100", 1e-7, 1e-5),
     ("lin_cartpole_T100", 1e-6, 1e-5),
     ("lin_dcp_T80", 1e-6, 1e-5),
+    ("lin_quad12_T20", 1e-6, 1e-5),  # d = 16: wave kernels, Linearize variant
 ]
 
 

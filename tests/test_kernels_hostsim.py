@@ -144,6 +144,7 @@ LINEARIZE = [
     ("lin_pendulum_T100", 1e-8, 1e-6),
     ("lin_cartpole_T100", 1e-7, 1e-6),
     ("lin_dcp_T80", 1e-7, 1e-6),
+    ("lin_quad12_T20", 1e-7, 1e-6),  # d = 16: the wave kernels' Linearize variant (dual-number Jacobian, one input per lane)
 ]
 
 
@@ -165,7 +166,7 @@ def test_hostsim_gauss_hermite_batch_vs_oracle(lib):
     parity.check_batch_against_oracle("gh3_pendulum_T40", lib, "cpu", 5, 3, tol=1e-7)
 
 
-@pytest.mark.parametrize("name,B,iters", [("lin_pendulum_T100", 6, 4), ("lin_dcp_T80", 3, 3)])
+@pytest.mark.parametrize("name,B,iters", [("lin_pendulum_T100", 6, 4), ("lin_dcp_T80", 3, 3), ("lin_quad12_T20", 3, 3)])
 def test_hostsim_linearize_batch_vs_oracle(lib, name, B, iters):
     parity.check_batch_against_oracle(name, lib, "cpu", B, iters, tol=1e-7)
 

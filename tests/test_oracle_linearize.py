@@ -59,6 +59,7 @@ def run_and_check(name, tol_detail, tol_summary):
     ("lin_pendulum_T100", 1e-8, 1e-6),
     ("lin_cartpole_T100", 1e-8, 1e-6),
     ("lin_dcp_T80", 1e-7, 1e-6),
+    ("lin_quad12_T20", 1e-8, 1e-6),  # 12-state quadrotor (d = 16): the reference's I2cGraph on the build-defined model
 ])
 def test_linearize_em(name, td, ts):
     run_and_check(name, td, ts)

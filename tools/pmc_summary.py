@@ -23,7 +23,7 @@ def per_kernel(d):
         if "i2c::" in r["Kernel_Name"]:
             rest = r["Kernel_Name"].split("i2c::")[1]
             name = rest.split("<")[0]
-            if name == "k_group":  # one kernel template for the four group sweeps: KIND is its first argument
+            if name in ("k_group", "k_wave"):  # one kernel template per family: the sweep (KIND) is its first argument
                 name += "_" + {"0": "forward", "1": "backward", "2": "propagate", "3": "ckf"}.get(rest.split("<")[1].split(",")[0].strip(), "x")
             acc[name].append(float(r["Counter_Value"]))
     return {k: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in acc.items()}  # steady-state half
