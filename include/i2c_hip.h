@@ -91,11 +91,9 @@ enum { I2C_SWEEP_FORWARD = 0, I2C_SWEEP_BACKWARD = 1, I2C_SWEEP_PROPAGATE = 2, I
 /* hybrid default of the d >= 7 lane models: their FORWARD sweep runs on the group kernels while B * G stays within this
  * many lanes (every group wave then has a SIMD of its own: 1024 SIMDs x 64 lanes) */
 #define I2C_GROUP_FORWARD_MAX_LANES 65536
-/* default of the models that have wave kernels (I2cDims.wave): forward and backward sweeps run on them up to this batch (two
- * wavefronts per SIMD: the wave form has the shorter dependent chain per cell and wins while the chip is not full; beyond, the
- * group kernels amortise the serial factorisation work over four trajectories per wavefront and win). Measured on MI355X,
- * 12-state quadrotor T = 50, forward + backward ms: B = 1024: 0.56 (wave) / 1.21 (group); 2048: 1.01 / 1.35; 4096: 2.19 / 1.66 */
-#define I2C_WAVE_MAX_BATCH 2048
+/* The models that have wave kernels (I2cDims.wave) run their forward and backward sweeps on them by default at EVERY batch size
+ * (measured on MI355X, 12-state quadrotor T = 50, forward + backward ms, wave / group: B = 1024: 0.48 / 1.21; 2048: 0.85 / 1.35;
+ * 4096: 1.67 / 1.66; 8192: 3.29 / 3.29; 32768: 13.3 / 16.0): one family for all batches keeps results independent of B. */
 
 enum {
   I2C_OK = 0,
@@ -155,7 +153,7 @@ typedef struct I2cProblem {
                               i2c.py:143,259-265); the cubature forward pass always scales it (i2c.py:366-375)      */
   int32_t gh_degree;       /* I2C_INF_GAUSS_HERMITE: 1 <= degree <= I2C_MAX_GH_DEGREE                               */
   int32_t group_lanes;     /* 0: the model's default kernels (one lane per trajectory; the group kernels for a group_only
-                              model -- or its wave kernels, I2cDims.wave, while B <= I2C_WAVE_MAX_BATCH; for the d >= 7 lane models
+                              model -- or its wave kernels, I2cDims.wave, wherever they apply; for the d >= 7 lane models
                               the FORWARD sweep runs on the group kernels while B * G <= 65536); 64: the wave kernels (one wavefront
                               per trajectory: forward and backward sweeps, fp64 or I2C_F64_F32S, cubature rule with lam = 0, no
                               terminal state prior; propagation and filter run the model's default);
@@ -216,6 +214,9 @@ typedef struct I2cProblem {
  * Forward-message buffer, [T][e_fwd][B]; per cell:
  *   mu_xu1_f[d] | sig_xu1_f[SYM(d)] | mu_x3_f[nx] | sig_x3_f[SYM(nx)] | J_dyn[d*nx] (row-major)
  * (the quantities I2cCell keeps for the backward pass, i2c.py:402-428).
+ * The buffer is scratch between the forward sweep that writes it and the backward sweep that reads it, and its layout belongs
+ * to the kernel family that runs them (i2c_kernel_family): [T][e_fwd][B] for I2C_FAMILY_LANE and I2C_FAMILY_GROUP,
+ * trajectory-major [T][B][e_fwd] for I2C_FAMILY_WAVE (a wavefront reads one cell of one trajectory: contiguous). Same size.
  */
 
 /* Smoothed next-state buffer [T][e_xm][B]: mu_x3_m[nx] | sig_x3_m[SYM(nx)] (i2c.py:546-576). */

@@ -262,26 +262,29 @@ static int launch_group_w(const Consts<M, R>& c, const ZetaArg<M, R>* zeta, cons
 #endif
 
 // ---- wave kernels (i2c_wave.hpp): one wavefront per trajectory, four per workgroup ----------------------------------------------
-enum { WK_FORWARD = 0, WK_BACKWARD = 1 };
+enum { WK_FORWARD = 0, WK_BACKWARD = 1, WK_SCAN = 2, WK_CELL = 3 };
 constexpr int WAVES_PER_BLOCK = 4;
 template <int KIND, class M, typename R, typename S, bool LIN, class KC, class A>
-I2C_FN void wave_body(const Consts<M, R>& c, const KC& kc, const A& a, const int b, const Wave<R>& w) {
+I2C_FN void wave_body(const Consts<M, R>& c, const KC& kc, const A& a, const int t, const int b, const Wave<R>& w) {
   if constexpr (KIND == WK_FORWARD) forward_wave_body<M, R, S, LIN>(c, kc, a, b, w);
   if constexpr (KIND == WK_BACKWARD) backward_wave_body<M, R, S, LIN>(c, kc, a, b, w);
+  if constexpr (KIND == WK_SCAN) backward_wave_scan_body<M, R, S>(c, kc, a, b, w);
+  if constexpr (KIND == WK_CELL) backward_wave_cell_body<M, R, S>(c, kc, a, t, b, w);  // one wave per (t, b)
 }
 #ifdef I2C_HOST_SIM
 template <int KIND, class M, typename R, typename S, bool LIN, class A>
 static int launch_wave_v(const Consts<M, R>& c, const A& a, void*) {
   WConst<M, R> kc;
   wconst_fill<M, R>(kc, &c, 0, 1);
-  for (int b = 0; b < c.B; ++b) {
-    std::vector<R> sh((size_t)WaveLds::SIZE, R(0)), xch(128, R(0));
-    HostBarrier bar(64);
-    std::vector<std::thread> lanes;
-    for (int l = 0; l < 64; ++l)
-      lanes.emplace_back([&, l] { wave_body<KIND, M, R, S, LIN>(c, kc, a, b, Wave<R>{l, l >> 4, l & 15, sh.data(), &bar, xch.data()}); });
-    for (auto& th : lanes) th.join();
-  }
+  for (int t = 0; t < (KIND == WK_CELL ? c.T : 1); ++t)
+    for (int b = 0; b < c.B; ++b) {
+      std::vector<R> sh((size_t)WaveLds::SIZE, R(0)), xch(128, R(0));
+      HostBarrier bar(64);
+      std::vector<std::thread> lanes;
+      for (int l = 0; l < 64; ++l)
+        lanes.emplace_back([&, l, t, b] { wave_body<KIND, M, R, S, LIN>(c, kc, a, t, b, Wave<R>{l, l >> 4, l & 15, sh.data(), &bar, xch.data()}); });
+      for (auto& th : lanes) th.join();
+    }
   return I2C_OK;
 }
 #else
@@ -300,19 +303,21 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 2) void k_wave(const Consts<M
   if (b >= c.B) return;
   const int l = (int)(threadIdx.x & 63u);
   const Wave<R> w{l, l >> 4, l & 15, (lds_ptr<R>)(sh + (threadIdx.x >> 6) * WaveLds::SIZE)};
-  wave_body<KIND, M, R, S, LIN>(c, kc, a, (int)b, w);
+  wave_body<KIND, M, R, S, LIN>(c, kc, a, (int)blockIdx.y, (int)b, w);
 }
 template <int KIND, class M, typename R, typename S, bool LIN, class A>
 static int launch_wave_v(const Consts<M, R>& c, const A& a, void* stream) {
   const unsigned blocks = (unsigned)(((long)c.B + 127) / 128) * 32u;
-  hipLaunchKernelGGL((k_wave<KIND, M, R, S, LIN, A>), dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, (hipStream_t)stream, c, a);
+  hipLaunchKernelGGL((k_wave<KIND, M, R, S, LIN, A>), dim3(blocks, KIND == WK_CELL ? (unsigned)c.T : 1u), dim3(64 * WAVES_PER_BLOCK), 0,
+                     (hipStream_t)stream, c, a);
   return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
 }
 #endif
 
 template <int KIND, class M, typename R, typename S, class A>
 static int launch_wave(const Consts<M, R>& c, const A& a, void* stream) {
-  if constexpr (sizeof(S) == sizeof(R) && M::NZT > 0) {  // the Linearize variant: fp64 storage, models with a terminal observation
+  if constexpr (sizeof(S) == sizeof(R) && M::NZT > 0 && (KIND == WK_FORWARD || KIND == WK_BACKWARD)) {
+    // the Linearize variant: fp64 storage, models with a terminal observation, one backward schedule
     if (c.inference == I2C_INF_LINEARIZE) return launch_wave_v<KIND, M, R, S, true>(c, a, stream);
   }
   return launch_wave_v<KIND, M, R, S, false>(c, a, stream);
@@ -475,8 +480,7 @@ template <class M, typename R, typename S = R> struct Impl {
   static int family(const I2cProblem* p, const C& c, const int sweep) {
     if constexpr (HAS_WAVE) {  // forward and backward sweeps: on request (group_lanes = 64) or as the model's default
       if ((sweep == I2C_SWEEP_FORWARD || sweep == I2C_SWEEP_BACKWARD) &&
-          (p->group_lanes == 64 ||
-           (p->group_lanes == 0 && (p->B <= I2C_WAVE_MAX_BATCH || MIXED || p->inference == I2C_INF_LINEARIZE)))) {
+          (p->group_lanes == 64 || p->group_lanes == 0)) {
         const int rc = wave_supported(p, c);
         if (rc == I2C_OK) return I2C_FAMILY_WAVE;
         if (p->group_lanes == 64 || MIXED) return rc;
@@ -564,6 +568,14 @@ template <class M, typename R, typename S = R> struct Impl {
   // Above, HBM traffic decides -> fused (264 instead of ~490 B/cell for the pendulum; double cartpole B = 32768: fused 2.45,
   // chunked 3.31 ms; B = 16384: 2.25 against 1.76). Models that only have group kernels run the fused walk.
   static int schedule(int B, int T, int requested) {
+    if (M::WAVE && M::GROUP_ONLY) {
+      // wave kernels: the fused walk, or on request the two-pass schedule (scan + one wave per (t, b) cell). Measured on MI355X
+      // (12-state quadrotor, T = 50): the two-pass form is SLOWER at every batch -- B = 256: 0.179 against 0.162 ms, B = 1024:
+      // 0.347 against 0.184 ms -- because with T times as many waves in flight the sweep is bound by the vector-memory
+      // pipeline: a wave's load touches one 8-byte element in each of 64 different [B]-contiguous rows (64 cache lines per
+      // instruction), which a lone wave per SIMD hides behind its dependent arithmetic and 50 waves per SIMD do not.
+      return requested == I2C_BWD_TWO_PASS ? I2C_BWD_TWO_PASS : I2C_BWD_FUSED;
+    }
     if (M::GROUP_ONLY) return I2C_BWD_FUSED;
     int mode = requested;
     if (mode == I2C_BWD_AUTO)
@@ -598,13 +610,27 @@ template <class M, typename R, typename S = R> struct Impl {
       if (fam < 0) return fam;
       CellArgs<R, S> am{(const S*)fwd, (const S*)xm,   (const R*)p->z, (S*)post,  (S*)zpost,
                         (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   (const R*)p->alpha};
-      if (fam == I2C_FAMILY_WAVE) {
-        if constexpr (HAS_WAVE) return launch_wave<WK_BACKWARD, M, R, S>(c, am, stream);
-      }
+      if (fam == I2C_FAMILY_WAVE) return backward_wave(p, c, am, ms, fuse, stream);
       return backward_lane(p, c, am, ms, fuse, stream);
     } else {
       return backward_any(p, c, ms, fwd, xm, post, zpost, cell_stats, term_stats, status, stream, fuse);
     }
+  }
+  // the wave family's backward sweep: two-pass (scan, one wave per cell, reduction -- with the M-step riding on it in
+  // i2c_learn) when that schedule is asked for / the default and its workspaces exist; the fused walk otherwise
+  template <class CA>
+  static int backward_wave(const I2cProblem* p, const C& c, const CA& a, const MstepArgs<R>& ms, MstepFuse* fuse, void* stream) {
+    if constexpr (HAS_WAVE) {
+      const bool two_pass = schedule(p->B, p->T, p->backward_mode) == I2C_BWD_TWO_PASS && a.xm && a.cell_stats &&
+                            p->inference == I2C_INF_CUBATURE;
+      if (!two_pass) return launch_wave<WK_BACKWARD, M, R, S>(c, a, stream);
+      int rc = launch_wave<WK_SCAN, M, R, S>(c, a, stream);
+      if (rc == I2C_OK) rc = launch_wave<WK_CELL, M, R, S>(c, a, stream);
+      if (rc == I2C_OK) rc = launch_reduce<M, R>(c, a, ms, p->T, stream);
+      if (fuse) fuse->done = true;
+      return rc;
+    }
+    return I2C_ENOTSUP;
   }
   static int backward_any(const I2cProblem* p, const C& c, const MstepArgs<R>& ms, const void* fwd, void* xm, void* post,
                           void* zpost, void* cell_stats, void* term_stats, int32_t* status, void* stream, MstepFuse* fuse) {
@@ -612,8 +638,8 @@ template <class M, typename R, typename S = R> struct Impl {
                   (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   (const R*)p->alpha};
     const int fam = family(p, c, I2C_SWEEP_BACKWARD);
     if (fam < 0) return fam;
-    if (fam == I2C_FAMILY_WAVE) {  // one schedule: the wave walks T-1..0
-      if constexpr (HAS_WAVE && !MIXED) return launch_wave<WK_BACKWARD, M, R, R>(c, a, stream);
+    if (fam == I2C_FAMILY_WAVE) {
+      if constexpr (!MIXED) return backward_wave(p, c, a, ms, fuse, stream);
     }
     if (fam == I2C_FAMILY_GROUP) {  // one schedule: the group walks T-1..0 (the fused form); backward_mode is ignored
       if constexpr (HAS_GROUP) return launch_group<GK_BACKWARD, M, R, G>(c, nullptr, a, stream);

@@ -299,6 +299,14 @@ template <typename R, typename S> struct WIO {
 template <typename R, typename S> I2C_FN WIO<R, S> wio(const S* base, const unsigned long elems, const unsigned rb, const unsigned bo) {
   return WIO<R, S>{make_window(base, elems * rb), rb, bo};
 }
+// The forward-message buffer of the WAVE family is trajectory-major, [T][B][e_fwd]: the e_fwd elements of one cell of one
+// trajectory are contiguous, so a wave's load of 64 elements touches 4 - 8 cache lines instead of 64 (with the common
+// [T][e][B] layout every lane of a wave hits a different [B]-contiguous row: the vector-memory pipeline, ~0.5 line requests per
+// clock and CU, bounded the backward sweep already at one wave per SIMD -- B = 1024: 0.184 ms). The buffer is private to the
+// family that writes it (forward sweep) and reads it (backward sweep); callers go through i2c_kernel_family().
+template <typename R, typename S> I2C_FN WIO<R, S> w_fwd_cell(const S* fwd, const int e_fwd, const unsigned long B, const int t, const int b) {
+  return wio<R, S>(fwd + ((unsigned long)t * B + (unsigned long)b) * (unsigned long)e_fwd, (unsigned long)e_fwd, (unsigned)sizeof(S), 0u);
+}
 I2C_FN int w_symidx(const int i, const int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
 // Kalman-style update of N(mu, s) of dimension N = 4 NB on an IDENTITY observation of it with noise alpha * xi and target zt
@@ -387,7 +395,7 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
   fetch_prior(0);
 
   for (int t = 0; t < T; ++t) {
-    const WIO<R, S> out = wio<R, S>(a.fwd + (unsigned long)t * C::E_FWD * B, C::E_FWD, rb, bo);
+    const WIO<R, S> out = w_fwd_cell<R, S>(a.fwd, C::E_FWD, B, t, b);
     const R alpha = nx_alpha, zt = nx_zt, pmu = nx_pmu;
     const bool ff = w_uniform(nx_ff) != 0, scale_gain = w_uniform(nx_ex) != 0;
     R pj[4], kt[4];
@@ -613,79 +621,89 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
 }
 
 // ------------------------------------------------------------------------------------------
-// Backward sweep (i2c.py:882-886 over :544-610), fused form: the wave walks T-1..0 doing the whole cell.
-// ------------------------------------------------------------------------------------------
+// Backward sweep (i2c.py:882-886 over :544-610). Two schedules of the same cell arithmetic:
+//   fused    -- one wave walks T-1..0 doing the whole cell (one launch; the choice once the chip is full);
+//   two-pass -- only the nx x nx marginal recursion is sequential (backward_wave_scan_body: six matrix instructions per
+//               cell), everything else of a cell -- joint update, expected cost, controller -- is independent given the
+//               smoothed next state, so a second launch runs ONE WAVE PER (t, b) CELL (backward_wave_cell_body): T times the
+//               parallelism of the walk, which is what a batch of ~1000 trajectories needs to fill the chip; the per-cell
+//               cost terms are summed over t by the lane kernels' k_reduce in a fixed order.
 // LIN: Linearize() inference (i2c.py:449-542): at the end of the chain a terminal state prior PINS the smoothed terminal state
 // (:453-472), otherwise the terminal cost observation is applied there (:475-491, with sig_xi_terminal kept in sig_z3_m); per
 // cell the alpha statistic uses the linearised marginal observation WITHOUT state-action cross terms (:537-540) while the plan
-// cost is priced with the cubature transform of the full joint (i2c.py:841-844, 1034-1053).
+// cost is priced with the cubature transform of the full joint (i2c.py:841-844, 1034-1053). One schedule (fused).
 // term_stats rows: 0 = terminal trace, 1 = sum_t alpha statistic, 2 = sum_t cost variance, last = sum_t plan-cost mean (LIN).
+// ------------------------------------------------------------------------------------------
+// cost of N(m, s) about a target under weight W (16 x 16 row-major in LDS; diag: only its diagonal): this lane's share of
+//   mean  err^T W err + tr(s W)   and   variance  2 tr((s W)^2) + 4 err^T W s W err      (i2c.py:1034-1043)
+template <typename R, class P>
+I2C_FN void w_cost_share(const Wave<R>& w, const bool diag, const P wmat, const int NB, const R err, const R* s, R* pm, R* pv) {
+  const int j = w.j;
+  R er[4], wm[4];
+  w_col2row<4>(w, 3, err, er);
+  w_ldconst<4>(w, wmat, wm);
+  if (diag) {
+    const R wd = wmat[j * 16 + j];
+    R m = R(0), t2 = R(0), qd = R(0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if (v < NB) {
+        const R wrv = wmat[w.row(v) * 16 + w.row(v)];
+        m += (w.row(v) == j) ? wd * (err * err + s[v]) : R(0);
+        t2 += s[v] * s[v] * (wrv * wd);
+        qd += (wrv * er[v]) * s[v] * (wd * err);
+      }
+    }
+    *pm = m;
+    *pv = R(2) * t2 + R(4) * qd;
+  } else {
+    // P = s W, P^T = W s (matrix instructions); W err in column and row form
+    R p[4] = {R(0), R(0), R(0), R(0)}, pt[4] = {R(0), R(0), R(0), R(0)};
+    w_tn<4>(w, s, wm, p);
+    w_tn<4>(w, wm, s, pt);
+    R t = R(0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) t += wm[v] * er[v];
+    const R we = w_rowsum(w, t);
+    R wer[4];
+    w_col2row<4>(w, 4, we, wer);
+    R m = R(0), t2 = R(0), qd = R(0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if (v < NB) {
+        m += er[v] * wm[v] * err + s[v] * wm[v];
+        t2 += p[v] * pt[v];
+        qd += wer[v] * s[v] * we;
+      }
+    }
+    *pm = m;
+    *pv = R(2) * t2 + R(4) * qd;
+  }
+}
+
+// End of the chain (i2c.py:546-572): the smoothed terminal state (m3m column form, s3m accumulator layout) and the terminal
+// observation statistics (term_stats rows 0, 3..).
 template <class M, typename R, typename S, bool LIN, class KC>
-I2C_HD inline void backward_wave_body(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>& a, const int b, const Wave<R>& w) {
+I2C_FN void w_end_of_chain(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>& a, const int b, const Wave<R>& w, R* m3m_out, R* s3m) {
   using C = Consts<M, R>;
-  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D, NBX = NX / 4, NT = C::NZT1;
-  static_assert(D == 16 && NX % 4 == 0 && NZ == D && (NZT == NX || NZT == 0), "wave kernels: d = 16, identity observations");
-  constexpr int O_K = D + sym(D), O_k = O_K + NU * NX, O_SK = O_k + NU;
-  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  constexpr int NX = C::NX, NZT = C::NZT, D = C::D, NBX = NX / 4, NT = C::NZT1;
+  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX;
   const int q = w.q, j = w.j;
   const unsigned long B = c.B;
   const int T = c.T;
   const unsigned WS = sizeof(S), bo = (unsigned)b * WS, rb = (unsigned)(B * WS);
   const bool jx = j < NX;
-  const int jxc = jx ? j : 0, ju = jx ? 0 : j - NX;
-
-  // cost of N(m, s) about target zt under weight W (diag wd / full wm): this lane's share of
-  //   mean  err^T W err + tr(s W)   and   variance  2 tr((s W)^2) + 4 err^T W s W err      (i2c.py:1034-1043)
-  auto cost_share = [&](const bool diag, const auto wmat, const int NB, const R err, const R* s, R* pm, R* pv) {
-    R er[4], wm[4];
-    w_col2row<4>(w, 3, err, er);
-    w_ldconst<4>(w, wmat, wm);
-    if (diag) {
-      const R wd = wmat[j * 16 + j];
-      R m = R(0), t2 = R(0), qd = R(0);
+  const int jxc = jx ? j : 0;
+  R m3m;
+  {  // the smoothed terminal state is the filtered one (i2c.py:563-564)
+    const WIO<R, S> fw = w_fwd_cell<R, S>(a.fwd, C::E_FWD, B, T - 1, b);
+    const R mv = fw.ld(O_MU3 + jxc);
+    m3m = jx ? mv : R(0);
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        if (v < NB) {
-          const R wrv = wmat[w.row(v) * 16 + w.row(v)];
-          m += (w.row(v) == j) ? wd * (err * err + s[v]) : R(0);
-          t2 += s[v] * s[v] * (wrv * wd);
-          qd += (wrv * er[v]) * s[v] * (wd * err);
-        }
-      }
-      *pm = m;
-      *pv = R(2) * t2 + R(4) * qd;
-    } else {
-      // P = s W, P^T = W s (matrix instructions); W err in column and row form
-      R p[4] = {R(0), R(0), R(0), R(0)}, pt[4] = {R(0), R(0), R(0), R(0)};
-      w_tn<4>(w, s, wm, p);
-      w_tn<4>(w, wm, s, pt);
-      R t = R(0);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) t += wm[v] * er[v];
-      const R we = w_rowsum(w, t);
-      R wer[4];
-      w_col2row<4>(w, 4, we, wer);
-      R m = R(0), t2 = R(0), qd = R(0);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        if (v < NB) {
-          m += er[v] * wm[v] * err + s[v] * wm[v];
-          t2 += p[v] * pt[v];
-          qd += wer[v] * s[v] * we;
-        }
-      }
-      *pm = m;
-      *pv = R(2) * t2 + R(4) * qd;
+    for (int v = 0; v < 4; ++v) {
+      const R sv = v < NBX ? fw.ld(O_S3 + w_symidx(w.row(v) < NX ? w.row(v) : 0, jxc)) : R(0);
+      s3m[v] = (v < NBX && jx) ? sv : R(0);
     }
-  };
-
-  // end of the chain (i2c.py:546-564): the smoothed terminal state is the filtered one
-  R m3m, s3m[4];
-  {
-    const WIO<R, S> fw = wio<R, S>(a.fwd + (unsigned long)(T - 1) * C::E_FWD * B, C::E_FWD, rb, bo);
-    m3m = jx ? fw.ld(O_MU3 + jxc) : R(0);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) s3m[v] = (v < NBX && jx) ? fw.ld(O_S3 + w_symidx(w.row(v) < NX ? w.row(v) : 0, jxc)) : R(0);
   }
   R xiT[4] = {R(0), R(0), R(0), R(0)};  // Linearize: the sig_xi_terminal that stays in sig_z3_m (i2c.py:460, 488, 497)
   if (LIN) {
@@ -706,7 +724,7 @@ I2C_HD inline void backward_wave_body(const Consts<M, R>& c, const KC& kc, const
     R pm, pv, szt[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) szt[v] = s3m[v] + xiT[v];
-    cost_share(c.qf_diag != 0, kc.qf, NBX, jx ? m3m - kc.zgT[jxc] : R(0), szt, &pm, &pv);
+    w_cost_share(w, c.qf_diag != 0, kc.qf, NBX, jx ? m3m - kc.zgT[jxc] : R(0), szt, &pm, &pv);
     trT = w_wavesum(w, 5, pm);
     if (q == 0 && jx) a.term_stats[(long)(3 + jxc) * B + b] = m3m;
 #pragma unroll
@@ -714,106 +732,153 @@ I2C_HD inline void backward_wave_body(const Consts<M, R>& c, const KC& kc, const
       if (jx && w.row(v) >= j) a.term_stats[(long)(3 + NT + w_symidx(w.row(v), jxc)) * B + b] = szt[v];
   }
   if (w.l == 0) a.term_stats[b] = trT;
+  *m3m_out = m3m;
+}
 
+// The forward rows of one cell as a backward cell needs them (filled from HBM; a prefetch buffer in the fused walk)
+template <typename R> struct WFwdRow {
+  R mu, m3f, sg[4], s3f[4], jt[4], zt;
+};
+template <class M, typename R, typename S, class KC>
+I2C_FN void w_fetch_fwd(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>& a, const int b, const Wave<R>& w, const int tc, WFwdRow<R>& f) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NZ = C::NZ, D = C::D, NBX = NX / 4;
+  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  const unsigned long B = c.B;
+  const unsigned WS = sizeof(S), bo = (unsigned)b * WS, rb = (unsigned)(B * WS);
+  const int j = w.j, jxc = j < NX ? j : 0;
+  const WIO<R, S> fw = w_fwd_cell<R, S>(a.fwd, C::E_FWD, B, tc, b);
+  f.mu = fw.ld(j);
+  f.m3f = fw.ld(O_MU3 + jxc);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    f.sg[v] = fw.ld(D + w_symidx(w.row(v), j));
+    f.s3f[v] = v < NBX ? fw.ld(O_S3 + w_symidx(w.row(v) < NX ? w.row(v) : 0, jxc)) : R(0);
+    f.jt[v] = v < NBX ? fw.ld(O_J + j * NX + (w.row(v) < NX ? w.row(v) : 0)) : R(0);  // J^T
+  }
+  f.zt = c.z_per_cell ? a.z[((long)c.row(tc) * NZ + j) * B + b] : kc.zg[j];
+}
+
+// One backward cell (i2c.py:574-608) given its forward rows and the smoothed next state (m3m column form, s3m accumulator
+// layout): RTS update of the joint, expected cost of the posterior observation (this lane's shares: pm, pv; pa = the
+// Linearize alpha statistic), controller, stores. On return mu / sg hold the posterior joint.
+template <class M, typename R, typename S, bool LIN, class KC>
+I2C_FN void w_bwd_cell(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>& a, const int b, const Wave<R>& w, const int t,
+                       const WFwdRow<R>& f, const R m3m, const R* s3m, R* mu_out, R* sg, R* pm, R* pv, R* pa) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, D = C::D, NBX = NX / 4;
+  constexpr int O_K = D + sym(D), O_k = O_K + NU * NX, O_SK = O_k + NU;
+  const int q = w.q, j = w.j;
+  const unsigned long B = c.B;
+  const unsigned WS = sizeof(S), bo = (unsigned)b * WS, rb = (unsigned)(B * WS);
+  const bool jx = j < NX;
+  const int jxc = jx ? j : 0, ju = jx ? 0 : j - NX;
+  const WIO<R, S> po = wio<R, S>(a.post + (unsigned long)c.row(t) * C::E_POST * B, C::E_POST, rb, bo);
+  R mu = f.mu, jt[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    sg[v] = f.sg[v];
+    jt[v] = f.jt[v];
+  }
+  // RTS update of the joint (i2c.py:580-583): mu += J (m3m - m3f), sig += J (S3m - S3f) J^T
+  {
+    R dr[4], ds[4], p1[4] = {R(0), R(0), R(0), R(0)};
+    w_col2row<NBX>(w, 0, m3m - (jx ? f.m3f : R(0)), dr);
+    R tsum = R(0);
+#pragma unroll
+    for (int v = 0; v < NBX; ++v) tsum += jt[v] * dr[v];
+    mu += w_rowsum(w, tsum);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) ds[v] = (v < NBX && jx) ? s3m[v] - f.s3f[v] : R(0);
+    w_tn<NBX>(w, ds, jt, p1);
+    w_tn<NBX>(w, jt, p1, sg);
+  }
+  // posterior observation moments = the joint itself (identity observation, i2c.py:594-596) and their expected cost
+  w_cost_share(w, c.qr_diag != 0, kc.qr, 4, mu - f.zt, sg, pm, pv);
+  *pa = R(0);
+  if (LIN) {  // alpha statistic: the linearised marginal observation, block-diagonal in (x, u) (i2c.py:537-540)
+    R sbd[4], pva;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) sbd[v] = ((w.row(v) < NX) == jx) ? sg[v] : R(0);
+    w_cost_share(w, c.qr_diag != 0, kc.qr, 4, mu - f.zt, sbd, pa, &pva);
+  }
+  // controller (i2c.py:600-608): with [W | Y] = chol(sig_xx)^-1 [I | sig_xu]:  K^T = W^T Y, sigK = sig_uu - Y^T Y
+  {
+    R sxx[4], rh[4], lt[4], g[4] = {R(0), R(0), R(0), R(0)}, mr[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      sxx[v] = (v < NBX && jx) ? sg[v] : R(0);
+      rh[v] = v < NBX ? (jx ? (w.row(v) == j ? R(1) : R(0)) : sg[v]) : R(0);
+    }
+    if (!w_elim<NBX, 1>(w, sxx, rh, (R*)nullptr, lt) && w.l == 0) set_status(a.status, b, 7, t);
+    w_tn<NBX>(w, rh, rh, g);
+    w_col2row<NBX>(w, 1, jx ? mu : R(0), mr);
+    R kx = R(0);
+#pragma unroll
+    for (int v = 0; v < NBX; ++v) {
+      po.st_if(!jx, O_K + ju * NX + (w.row(v) < NX ? w.row(v) : 0), g[v]);
+      kx += g[v] * mr[v];
+    }
+    kx = w_rowsum(w, kx);
+    po.st_if(!jx && q == 0, O_k + ju, mu - kx);
+    po.st_if(!jx && q >= ju, O_SK + q * (q + 1) / 2 + ju, sg[NBX] - g[NBX]);
+  }
+  po.st_if(q == 0, j, mu);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) po.st_if(w.row(v) >= j, D + w_symidx(w.row(v), j), sg[v]);
+  if (a.zpost) {
+    S* zo = a.zpost + ((long)t * C::E_ZPOST) * B + b;
+    if (q == 0) zo[(long)j * B] = (S)mu;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)  // (Linearize: the linearised marginal observation has no state-action cross terms)
+      if (w.row(v) >= j) zo[(long)(NZ + w_symidx(w.row(v), j)) * B] = (S)((LIN && (w.row(v) < NX) != jx) ? R(0) : sg[v]);
+  }
+  *mu_out = mu;
+}
+template <class M, typename R, typename S> I2C_FN void w_store_xm(const Consts<M, R>& c, const CellArgs<R, S>& a, const int b, const Wave<R>& w,
+                                                                   const int t, const R m3m, const R* s3m) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NBX = NX / 4;
+  const long B = c.B;
+  const int j = w.j;
+  const bool jx = j < NX;
+  const int jxc = jx ? j : 0;
+  S* xo = const_cast<S*>(a.xm) + ((long)t * C::E_XM) * B + b;
+  if (w.q == 0 && jx) xo[(long)jxc * B] = (S)m3m;
+#pragma unroll
+  for (int v = 0; v < NBX; ++v)
+    if (jx && w.row(v) >= j) xo[(long)(NX + w_symidx(w.row(v), jxc)) * B] = (S)s3m[v];
+}
+
+// fused schedule: the wave walks T-1..0 doing the whole cell
+template <class M, typename R, typename S, bool LIN, class KC>
+I2C_HD inline void backward_wave_body(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>& a, const int b, const Wave<R>& w) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NZ = C::NZ, NZT = C::NZT, D = C::D, NBX = NX / 4;
+  static_assert(D == 16 && NX % 4 == 0 && NZ == D && (NZT == NX || NZT == 0), "wave kernels: d = 16, identity observations");
+  const unsigned long B = c.B;
+  const int T = c.T;
+  const bool jx = w.j < NX;
+  R m3m, s3m[4];
+  w_end_of_chain<M, R, S, LIN>(c, kc, a, b, w, &m3m, s3m);
   R acc_m = R(0), acc_v = R(0), acc_a = R(0);  // this lane's share of the cost sums over t (reduced once, after the walk)
-  // forward rows of a cell, fetched one cell ahead (see forward_wave_body)
-  R nx_mu, nx_m3f, nx_sg[4], nx_s3f[4], nx_jt[4], nx_zt;
-  auto fetch_fwd = [&](const int tc) {
-    const WIO<R, S> fw = wio<R, S>(a.fwd + (unsigned long)tc * C::E_FWD * B, C::E_FWD, rb, bo);
-    nx_mu = fw.ld(j);
-    nx_m3f = fw.ld(O_MU3 + jxc);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      nx_sg[v] = fw.ld(D + w_symidx(w.row(v), j));
-      nx_s3f[v] = v < NBX ? fw.ld(O_S3 + w_symidx(w.row(v) < NX ? w.row(v) : 0, jxc)) : R(0);
-      nx_jt[v] = v < NBX ? fw.ld(O_J + j * NX + (w.row(v) < NX ? w.row(v) : 0)) : R(0);  // J^T
-    }
-    nx_zt = c.z_per_cell ? a.z[((long)c.row(tc) * NZ + j) * B + b] : kc.zg[j];
-  };
-  fetch_fwd(T - 1);
+  WFwdRow<R> nx;  // forward rows of a cell, fetched one cell ahead (see forward_wave_body)
+  w_fetch_fwd<M, R, S>(c, kc, a, b, w, T - 1, nx);
   for (int t = T - 1; t >= 0; --t) {
-    const int tr = c.row(t);
-    const WIO<R, S> po = wio<R, S>(a.post + (unsigned long)tr * C::E_POST * B, C::E_POST, rb, bo);
-    R mu = nx_mu, sg[4], s3f[4], jt[4];
-    const R m3f = jx ? nx_m3f : R(0), zt = nx_zt;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      sg[v] = nx_sg[v];
-      s3f[v] = jx ? nx_s3f[v] : R(0);
-      jt[v] = nx_jt[v];
-    }
-    fetch_fwd(t > 0 ? t - 1 : 0);
-    if (a.xm) {
-      S* xo = const_cast<S*>(a.xm) + ((long)t * C::E_XM) * B + b;
-      if (q == 0 && jx) xo[(long)jxc * B] = (S)m3m;
-#pragma unroll
-      for (int v = 0; v < NBX; ++v)
-        if (jx && w.row(v) >= j) xo[(long)(NX + w_symidx(w.row(v), jxc)) * B] = (S)s3m[v];
-    }
-    // RTS update of the joint (i2c.py:580-583): mu += J (m3m - m3f), sig += J (S3m - S3f) J^T
-    {
-      R dr[4], ds[4], p1[4] = {R(0), R(0), R(0), R(0)};
-      w_col2row<NBX>(w, 0, m3m - m3f, dr);
-      R tsum = R(0);
-#pragma unroll
-      for (int v = 0; v < NBX; ++v) tsum += jt[v] * dr[v];
-      mu += w_rowsum(w, tsum);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) ds[v] = v < NBX ? s3m[v] - s3f[v] : R(0);
-      w_tn<NBX>(w, ds, jt, p1);
-      w_tn<NBX>(w, jt, p1, sg);
-    }
-    // posterior observation moments = the joint itself (identity observation, i2c.py:594-596) and their expected cost
-    {
-      R pm, pv;
-      cost_share(c.qr_diag != 0, kc.qr, 4, mu - zt, sg, &pm, &pv);
-      acc_m += pm;
-      acc_v += pv;
-      if (LIN) {  // alpha statistic: the linearised marginal observation, block-diagonal in (x, u) (i2c.py:537-540)
-        R sbd[4], pa, pva;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) sbd[v] = ((w.row(v) < NX) == jx) ? sg[v] : R(0);
-        cost_share(c.qr_diag != 0, kc.qr, 4, mu - zt, sbd, &pa, &pva);
-        acc_a += pa;
+    const WFwdRow<R> f = nx;
+    w_fetch_fwd<M, R, S>(c, kc, a, b, w, t > 0 ? t - 1 : 0, nx);
+    if (a.xm) w_store_xm<M, R, S>(c, a, b, w, t, m3m, s3m);
+    R mu, sg[4], pm, pv, pa;
+    w_bwd_cell<M, R, S, LIN>(c, kc, a, b, w, t, f, m3m, s3m, &mu, sg, &pm, &pv, &pa);
+    acc_m += pm;
+    acc_v += pv;
+    acc_a += pa;
+    if (a.cell_stats) {
+      const R cm = w_wavesum(w, 5, pm), cv = w_wavesum(w, 5, pv);
+      if (w.l == 0) {
+        a.cell_stats[((long)t * 2 + 0) * B + b] = cm;
+        a.cell_stats[((long)t * 2 + 1) * B + b] = cv;
       }
-      if (a.cell_stats) {
-        const R cm = w_wavesum(w, 5, pm), cv = w_wavesum(w, 5, pv);
-        if (w.l == 0) {
-          a.cell_stats[((long)t * 2 + 0) * B + b] = cm;
-          a.cell_stats[((long)t * 2 + 1) * B + b] = cv;
-        }
-      }
-    }
-    // controller (i2c.py:600-608): with [W | Y] = chol(sig_xx)^-1 [I | sig_xu]:  K^T = W^T Y, sigK = sig_uu - Y^T Y
-    {
-      R sxx[4], rh[4], lt[4], g[4] = {R(0), R(0), R(0), R(0)}, mr[4];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        sxx[v] = (v < NBX && jx) ? sg[v] : R(0);
-        rh[v] = v < NBX ? (jx ? (w.row(v) == j ? R(1) : R(0)) : sg[v]) : R(0);
-      }
-      if (!w_elim<NBX, 1>(w, sxx, rh, (R*)nullptr, lt) && w.l == 0) set_status(a.status, b, 7, t);
-      w_tn<NBX>(w, rh, rh, g);
-      w_col2row<NBX>(w, 1, jx ? mu : R(0), mr);
-      R kx = R(0);
-#pragma unroll
-      for (int v = 0; v < NBX; ++v) {
-        po.st_if(!jx, O_K + ju * NX + (w.row(v) < NX ? w.row(v) : 0), g[v]);
-        kx += g[v] * mr[v];
-      }
-      kx = w_rowsum(w, kx);
-      po.st_if(!jx && q == 0, O_k + ju, mu - kx);
-      po.st_if(!jx && q >= ju, O_SK + q * (q + 1) / 2 + ju, sg[NBX] - g[NBX]);
-    }
-    po.st_if(q == 0, j, mu);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) po.st_if(w.row(v) >= j, D + w_symidx(w.row(v), j), sg[v]);
-    if (a.zpost) {
-      S* zo = a.zpost + ((long)t * C::E_ZPOST) * B + b;
-      if (q == 0) zo[(long)j * B] = (S)mu;
-#pragma unroll
-      for (int v = 0; v < 4; ++v)  // (Linearize: the linearised marginal observation has no state-action cross terms)
-        if (w.row(v) >= j) zo[(long)(NZ + w_symidx(w.row(v), j)) * B] = (S)((LIN && (w.row(v) < NX) != jx) ? R(0) : sg[v]);
     }
     m3m = jx ? mu : R(0);
 #pragma unroll
@@ -824,6 +889,73 @@ I2C_HD inline void backward_wave_body(const Consts<M, R>& c, const KC& kc, const
     a.term_stats[B + b] = sa;
     a.term_stats[2 * B + b] = sv;
     if (LIN) a.term_stats[(long)(C::E_TERM - 1) * B + b] = sm;
+  }
+}
+
+// two-pass schedule, pass 1: the sequential part alone -- the x-marginal of the RTS recursion (i2c.py:580-583 restricted to the
+// state block; it is all cell t-1 needs from cell t). Writes xm[t] = (mu_x3_m, sig_x3_m) for every cell.
+template <class M, typename R, typename S, class KC>
+I2C_HD inline void backward_wave_scan_body(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>& a, const int b, const Wave<R>& w) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, D = C::D, NBX = NX / 4;
+  const int T = c.T;
+  const bool jx = w.j < NX;
+  R m3m, s3m[4];
+  w_end_of_chain<M, R, S, false>(c, kc, a, b, w, &m3m, s3m);
+  WFwdRow<R> nx;
+  w_fetch_fwd<M, R, S>(c, kc, a, b, w, T - 1, nx);
+  for (int t = T - 1; t >= 0; --t) {
+    const WFwdRow<R> f = nx;
+    w_fetch_fwd<M, R, S>(c, kc, a, b, w, t > 0 ? t - 1 : 0, nx);
+    w_store_xm<M, R, S>(c, a, b, w, t, m3m, s3m);
+    if (t == 0) break;
+    R dr[4], ds[4], jt[4], sg[4], p1[4] = {R(0), R(0), R(0), R(0)};
+    w_col2row<NBX>(w, 0, m3m - (jx ? f.m3f : R(0)), dr);
+    R tsum = R(0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      jt[v] = f.jt[v];
+      sg[v] = f.sg[v];
+      ds[v] = (v < NBX && jx) ? s3m[v] - f.s3f[v] : R(0);
+      tsum += v < NBX ? jt[v] * dr[v] : R(0);
+    }
+    const R mu = f.mu + w_rowsum(w, tsum);
+    w_tn<NBX>(w, ds, jt, p1);
+    w_tn<NBX>(w, jt, p1, sg);
+    m3m = jx ? mu : R(0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) s3m[v] = (v < NBX && jx) ? sg[v] : R(0);
+  }
+}
+// two-pass schedule, pass 2: one wave per (t, b) cell; its cost terms go to cell_stats[t] (summed over t by k_reduce)
+template <class M, typename R, typename S, class KC>
+I2C_HD inline void backward_wave_cell_body(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>& a, const int t, const int b,
+                                           const Wave<R>& w) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NBX = NX / 4;
+  const long B = c.B;
+  const int j = w.j;
+  const bool jx = j < NX;
+  const int jxc = jx ? j : 0;
+  WFwdRow<R> f;
+  w_fetch_fwd<M, R, S>(c, kc, a, b, w, t, f);
+  R m3m, s3m[4];
+  {
+    const S* xi = a.xm + ((long)t * C::E_XM) * B + b;
+    const R mv = (R)xi[(long)jxc * B];
+    m3m = jx ? mv : R(0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const R sv = v < NBX ? (R)xi[(long)(NX + w_symidx(w.row(v) < NX ? w.row(v) : 0, jxc)) * B] : R(0);
+      s3m[v] = (v < NBX && jx) ? sv : R(0);
+    }
+  }
+  R mu, sg[4], pm, pv, pa;
+  w_bwd_cell<M, R, S, false>(c, kc, a, b, w, t, f, m3m, s3m, &mu, sg, &pm, &pv, &pa);
+  const R cm = w_wavesum(w, 5, pm), cv = w_wavesum(w, 5, pv);
+  if (w.l == 0) {
+    a.cell_stats[((long)t * 2 + 0) * B + b] = cm;
+    a.cell_stats[((long)t * 2 + 1) * B + b] = cv;
   }
 }
 

@@ -213,8 +213,11 @@ class BatchedI2c:
         mode = self.lib.i2c_backward_schedule(self.model_id, B, T, self.backward_mode)  # resolves "auto"
         if mode not in (_native.BWD_TWO_PASS, _native.BWD_FUSED, _native.BWD_CHUNKED):
             raise RuntimeError("i2c_backward_schedule() returned %d" % mode)
-        if self.linearize or self.gauss_hermite or self.uses_group_kernels:
+        wave_ok = bool(dims.wave) and self.group_lanes in (0, 64) and not (self.linearize or self.gauss_hermite)
+        if self.linearize or self.gauss_hermite or (self.uses_group_kernels and not wave_ok):
             mode = _native.BWD_FUSED  # one backward schedule: a lane (or a group of lanes) per trajectory walks T-1..0
+        elif wave_ok and mode == _native.BWD_CHUNKED:
+            mode = _native.BWD_FUSED  # the wave kernels have the fused walk and the two-pass schedule
         self.fused_backward = mode == _native.BWD_FUSED
         self.backward_schedule = {_native.BWD_TWO_PASS: "two_pass", _native.BWD_FUSED: "fused", _native.BWD_CHUNKED: "chunked"}[mode]
         # the two-pass backward needs xm / cell_stats as workspace; the fused and chunked ones only write xm on request
@@ -262,6 +265,15 @@ class BatchedI2c:
         self.alphas_pf = [self.alpha.clone()]
         self.costs_m, self.costs_m_var, self.costs_pf, self.costs_pf_var, self.kl_terms = [], [], [], [], []
         self._problem = self._make_problem()
+        # The forward-message buffer is private to the kernel family that writes and reads it: the wave kernels keep it
+        # trajectory-major, [T][B][e_fwd] (include/i2c_hip.h); forward_messages() reads it through a view either way.
+        try:
+            self.fwd_trajectory_major = self.kernel_family("forward") == "wave"
+        except RuntimeError:  # a problem the library refuses: the sweeps report it (same code) when they are called
+            self.fwd_trajectory_major = False
+        if self.fwd_trajectory_major:
+            assert self.kernel_family("backward") == "wave"
+            self.fwd = self.fwd.reshape(T, B, dims.e_fwd)
 
     # ------------------------------------------------------------------ C-ABI plumbing
     def _make_problem(self):
@@ -727,12 +739,13 @@ class BatchedI2c:
     def forward_messages(self):
         d, nx = self.d, self.nx
         o = d + sym_size(d)
+        fwd = self.fwd.permute(0, 2, 1) if self.fwd_trajectory_major else self.fwd  # [T][e_fwd][B] either way
         return dict(
-            mu_xu1_f=self._rows(self.fwd, 0, d),
-            sig_xu1_f=self._sym_rows(self.fwd, d, d),
-            mu_x3_f=self._rows(self.fwd, o, nx),
-            sig_x3_f=self._sym_rows(self.fwd, o + nx, nx),
-            J_dyn=self._rows(self.fwd, o + nx + sym_size(nx), d * nx).reshape(self.B, self.H, d, nx),
+            mu_xu1_f=self._rows(fwd, 0, d),
+            sig_xu1_f=self._sym_rows(fwd, d, d),
+            mu_x3_f=self._rows(fwd, o, nx),
+            sig_x3_f=self._sym_rows(fwd, o + nx, nx),
+            J_dyn=self._rows(fwd, o + nx + sym_size(nx), d * nx).reshape(self.B, self.H, d, nx),
         )
 
     def smoothed_next_state(self):

@@ -19,11 +19,11 @@ def _with(g, **meta_over):
     return Case({**g, "meta": np.array(json.dumps(dict(g.meta, **meta_over)))})
 
 
-def _subset_vs_oracle(g, B, n_sub, iters, tol, mode="auto", plant=(), pre_propagate=False):
+def _subset_vs_oracle(g, B, n_sub, iters, tol, mode="auto", plant=(), pre_propagate=False, **kw):
     x0, mu_u = parity.batched_inputs(g, B)
     for b in plant:  # duplicates of trajectory 0 far apart in the batch
         x0[b], mu_u[b] = x0[0], mu_u[0]
-    eng = parity.engine_from_case(g, None, "cuda", x0=x0, mu_u=mu_u, backward_mode=mode)
+    eng = parity.engine_from_case(g, None, "cuda", x0=x0, mu_u=mu_u, backward_mode=mode, **kw)
     o = oracle_from_case(Case({**g, "mu_u": mu_u[:n_sub]}), x0=x0[:n_sub])
     if pre_propagate:
         eng.propagate()
@@ -94,7 +94,7 @@ def test_config4_quadrotor_mpc_H50_B8192():
     z_traj = np.tile(g["z_traj"][:1], (H + steps + 1, 1))
     z_traj[:, 0] += np.linspace(0, 1.0, H + steps + 1)
     x0 = np.tile(g["x0"], (B, 1)) + 1e-3 * rng.normal(size=(B, 6))
-    x0[[4000, 8191]] = x0[0]
+    x0[[B // 2 - 96, B - 1]] = x0[0]
 
     def make(batch, x0_):
         i2c = I2cGraph(model, H, g["Q"], g["R"], g["Qf"], 1.0, 1.0, mu_u, g["sig_u"], None, None, CubatureQuadrature(1, 0, 0),
@@ -121,32 +121,37 @@ def test_config4_quadrotor_mpc_H50_B8192():
     assert iB.engine.failures() == []
 
 
-def test_config4_quadrotor12_sweeps_H50_B8192_vs_oracle():
-    """BASELINE config 4 at nx = 12 (d = 16, group kernels): the EM sweeps at horizon 50 and 8192 trajectories, a subset
-    compared with the CPU oracle (the oracle is pinned to the reference solver on this model by em_quad12_T20 /
-    em_quad12_T12_propagate), planted duplicates bit-identical, and closed-loop propagation on the whole batch."""
+@pytest.mark.parametrize("lanes,B", [(0, 8192), (16, 8192), (0, 1024)])
+def test_config4_quadrotor12_sweeps_H50_vs_oracle(lanes, B):
+    """BASELINE config 4 at nx = 12 (d = 16): the EM sweeps at horizon 50 and 8192 trajectories (the whole config on one GPU)
+    or 1024 (one GPU's share of it) on the wave kernels (the default) and the group kernels, a subset compared with the CPU
+    oracle (the oracle is pinned to the reference solver on this model by em_quad12_T20 / em_quad12_T12_propagate), planted
+    duplicates bit-identical, and closed-loop propagation on the whole batch."""
     g = load_case("em_quad12_T20")
     T = 50
     rng = np.random.default_rng(5)
     mu_u = np.tile(g["mu_u"][:1], (T, 1)) + 1e-2 * rng.normal(size=(T, 4))
     big = Case({**g, "meta": np.array(json.dumps(dict(g.meta, T=T))), "mu_u": mu_u})
-    eng = _subset_vs_oracle(big, 8192, 6, 3, 1e-6, plant=(4097, 8191))
-    assert eng.uses_group_kernels and eng.post.shape == (50, 214, 8192)
+    eng = _subset_vs_oracle(big, B, 6, 3, 1e-6, plant=(B // 2 + 1, B - 1), group_lanes=lanes)
+    assert eng.forward_family == eng.backward_family == ("group" if lanes == 16 else "wave") and eng.post.shape == (50, 214, B)
     eng._propagate = True
     eng.propagate()
     assert eng.failures() == [] and torch.isfinite(eng.prop).all()
-    assert torch.equal(eng.prop[:, :, 0], eng.prop[:, :, 8191])
+    assert torch.equal(eng.prop[:, :, 0], eng.prop[:, :, B - 1])
 
 
-def test_config4_quadrotor12_mpc_H50_B8192():
-    """... and the closed MPC loop with the cubature-KF state estimator on it: horizon 50, 8192 loops at once (one
-    i2c_mpc_step per control step: filter, sweeps, first action, ring shift), lane 0 against a single loop."""
+@pytest.mark.parametrize("B", [8192, 1024])
+def test_config4_quadrotor12_mpc_H50(B):
+    """... and the closed MPC loop with the cubature-KF state estimator on it: horizon 50, 8192 loops at once (or one GPU's
+    share, 1024; one i2c_mpc_step per control step: filter, sweeps, first action, ring shift), lane 0 against a single loop.
+    NB a property check of the batched loop against the B = 1 loop of the SAME kernels (wave sweeps, group filter); the oracle
+    comparisons of this config are the sweeps above and the reference's own MPC replay mpc_quad12_fb (tests/test_mpc.py)."""
     from i2c.exp_types import CubatureQuadrature
     from i2c.i2c import I2cGraph
     from i2c.policy.mpc import PartiallyObservedMpcPolicy
 
     g = load_case("mpc_quad12_fb")
-    H, B, steps = 50, 8192, 3
+    H, steps = 50, 3
     rng = np.random.default_rng(1)
     model = parity.product_model(g)
     model.sig_zeta = g["sig_zeta"]
@@ -154,7 +159,7 @@ def test_config4_quadrotor12_mpc_H50_B8192():
     z_traj = np.tile(g["z_traj"][:1], (H + steps + 1, 1))
     z_traj[:, 0] += np.linspace(0, 0.5, H + steps + 1)
     x0 = np.tile(g["x0"], (B, 1)) + 1e-3 * rng.normal(size=(B, 12))
-    x0[[4000, 8191]] = x0[0]
+    x0[[B // 2 - 96, B - 1]] = x0[0]
 
     def make(batch, x0_):
         i2c = I2cGraph(model, H, g["Q"], g["R"], g["Qf"], 1.0, 1.0, mu_u, g["sig_u"], None, None, CubatureQuadrature(1, 0, 0),
@@ -175,7 +180,7 @@ def test_config4_quadrotor12_mpc_H50_B8192():
         u1 = p1(t, y[:1], u[:1])
         assert uB.shape == (B, 4) and np.all(np.isfinite(uB))
         assert_close(uB[0], u1[:, 0], 1e-9, f"lane 0 of the batch vs the single loop, step {t}")
-        assert np.array_equal(uB[0], uB[4000]) and np.array_equal(uB[0], uB[8191])
+        assert np.array_equal(uB[0], uB[B // 2 - 96]) and np.array_equal(uB[0], uB[B - 1])
         u = np.clip(uB, 0.0, model.force_mx)
         y = model.measure(model.dynamics(np.hstack((pB.mu, u))))
     assert iB.engine.failures() == [] and iB.engine.t0 == steps % H

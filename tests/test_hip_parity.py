@@ -73,6 +73,33 @@ def test_hip_quad12_both_families_vs_reference_golden(lib, name, lanes):
     assert eng.forward_family == eng.backward_family == {16: "group", 64: "wave"}[lanes]
 
 
+@pytest.mark.parametrize("mode", ["fused", "two_pass"])
+def test_hip_wave_backward_schedules_vs_reference_golden(lib, mode):
+    eng = parity.check_against_golden("em_quad12_T20", lib, "cuda", 1e-6, 1e-5, group_lanes=64, backward_mode=mode)
+    assert eng.backward_schedule == mode and eng.backward_family == "wave"
+
+
+def test_hip_wave_fused_learn_matches_stepwise(lib):
+    """i2c_learn (one library call per EM run) against stepping the same iterations from Python, both wave schedules (in the
+    two-pass one the M-step rides on the reduction kernel)."""
+    g = load_case("em_quad12_T20")
+    x0, mu_u = parity.batched_inputs(g, 37)
+    for mode in ("fused", "two_pass"):
+        engs = []
+        for fused in (True, False):
+            e = parity.pkg.BatchedI2c(parity.product_model(g), g.meta["T"], g["Q"], g["R"], g["Qf"], g.meta["alpha"], g.meta["tol"],
+                                      mu_u, g["sig_u"], x0=x0, device="cuda", lib=lib, keep_zpost=False, keep_xm=False,
+                                      backward_mode=mode)
+            if fused:
+                e.learn(3)
+            else:
+                for _ in range(3):
+                    e.learn_msgs()
+            assert e.failures() == [] and e.backward_family == "wave" and e.backward_schedule == mode
+            engs.append(e)
+        assert torch.equal(engs[0].post, engs[1].post) and torch.equal(engs[0].alpha, engs[1].alpha)
+
+
 @pytest.mark.parametrize("name", ["em_dcp_T60", "em_quadrotor_T20"])
 def test_hip_kernel_families_agree_at_B4096(lib, name):
     """The three ways to run a d >= 7 model -- the default (group forward + one-lane backward), group kernels throughout,

@@ -77,11 +77,19 @@ def test_hostsim_quad12_both_families_vs_reference_golden(lib, name, lanes):
     assert eng.forward_family == eng.backward_family == {16: "group", 64: "wave"}[lanes]
 
 
+@pytest.mark.parametrize("mode", ["fused", "two_pass"])
+def test_hostsim_wave_backward_schedules_vs_reference_golden(lib, mode):
+    """The wave family's two backward schedules -- the fused walk, and the sequential nx x nx scan + one wave per (t, b) cell +
+    reduction (on request only: measured slower on the device, see Impl::schedule) -- against the same golden run."""
+    eng = parity.check_against_golden("em_quad12_T20", lib, "cpu", 1e-7, 1e-6, n_iters=4, group_lanes=64, backward_mode=mode)
+    assert eng.backward_schedule == mode and eng.backward_family == "wave"
+
+
 def test_hostsim_wave_kernels_are_the_quad12_default(lib):
     from golden_util import load_case
 
     eng = parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu")
-    assert (eng.forward_family, eng.backward_family) == ("wave", "wave")
+    assert (eng.forward_family, eng.backward_family, eng.backward_schedule) == ("wave", "wave", "fused")
     assert eng.kernel_family("propagate") == "group" and eng.kernel_family("filter") == "group"  # sweeps the wave form lacks
     general = parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu", quad=(1.2, 0.44, 0.5))
     assert general.forward_family == "group"  # weights with lam != 0: not covered by the wave form, the group kernels take over
