@@ -37,7 +37,9 @@ struct WaveLds {
   static constexpr int O_Y = O_MAT + MAT;              // 33 rows: + points, - points, centre
   static constexpr int NVEC = 6;
   static constexpr int O_VEC = O_Y + 33 * YLD + 3;     // vector slots of 16
-  static constexpr int SIZE = O_VEC + NVEC * 16;
+  static constexpr int O_DG = O_VEC + NVEC * 16;       // 4 x 4 pivot block (w_pivot_block through LDS)
+  static constexpr int O_DUMP = O_DG + 16;             // where masked-off lanes park that store (one slot per lane)
+  static constexpr int SIZE = O_DUMP + 64;
 };
 
 template <typename R> struct Wave {
@@ -133,9 +135,14 @@ template <typename R> I2C_FN R w_rowsum(const Wave<R>& w, const R x) {
 #endif
 }
 // The 4 x 4 pivot block of row block KB of a symmetric matrix, to every lane: x = accumulator register KB, whose entry (a, b) of
-// the block sits in lane (a, 4 KB + b). Ten v_readlane pairs into scalar registers: no LDS round trip, and the block is
-// provably wave-uniform for everything computed from it. d = {d00, d10, d11, d20, d21, d22, d30, d31, d32, d33}.
-template <int KB, typename R> I2C_FN void w_pivot_block(const Wave<R>& w, const R x, R* d) {
+// the block sits in lane (a, 4 KB + b). d = {d00, d10, d11, d20, d21, d22, d30, d31, d32, d33}. Two ways (PL), fixed per kernel:
+//   v_readlane: ten pairs into scalar registers -- no round trip to wait for, 20 issue slots. The forward sweep's choice: a
+//               lone wave (B <= 1024) gains 4 % (0.382 -> 0.365 ms), a full chip neither gains nor loses (1.13 ms at B = 4096);
+//   LDS:        the 16 lanes that hold the block store it, every lane reads it back (1 + 6 instructions and a round trip).
+//               The backward sweep's choice: -10 ... -14 % once waves share a SIMD (B = 8192: 1.12 -> 0.96 ms), level below.
+// (A per-launch switch between the two inside one kernel was measured and dropped: the extra branch and registers cost the
+// forward sweep 6 - 10 % at every batch size.)
+template <int KB, bool PL, typename R> I2C_FN void w_pivot_block(const Wave<R>& w, const R x, R* d) {
 #ifdef I2C_HOST_SIM
   w.bar->wait();
   w.xch[w.l] = x;
@@ -144,13 +151,23 @@ template <int KB, typename R> I2C_FN void w_pivot_block(const Wave<R>& w, const 
   for (int a = 0; a < 4; ++a)
     for (int b = 0; b <= a; ++b) d[n++] = w.xch[16 * a + 4 * KB + b];
 #else
-  const int lo = __double2loint(x), hi = __double2hiint(x);
-  int n = 0;
+  if constexpr (PL) {
+    const auto dg = w.sh + WaveLds::O_DG;
+    const bool inblk = (w.j >> 2) == KB;
+    w.sync();
+    dg[inblk ? w.q * 4 + (w.j & 3) : 16 + w.l] = x;  // the other lanes park their store
+    w.sync();
+    d[0] = dg[0], d[1] = dg[4], d[2] = dg[5], d[3] = dg[8], d[4] = dg[9], d[5] = dg[10];
+    d[6] = dg[12], d[7] = dg[13], d[8] = dg[14], d[9] = dg[15];
+  } else {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    int n = 0;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b <= a; ++b)
-      d[n++] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * a + 4 * KB + b), __builtin_amdgcn_readlane(lo, 16 * a + 4 * KB + b));
+      for (int b = 0; b <= a; ++b)
+        d[n++] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * a + 4 * KB + b), __builtin_amdgcn_readlane(lo, 16 * a + 4 * KB + b));
+  }
 #endif
 }
 // column form (lane (q, j): x[j]) -> row form (x[q + 4 v], v < NV) through vector slot `slot`
@@ -216,12 +233,12 @@ template <int NV, typename R, class P> I2C_FN void w_ldconst(const Wave<R>& w, c
 // registers (four dependent rsq chains: the serial core of the kernel); lane (q, i) then holds entry (i mod 4, q) of that inverse
 // as the A operand of the matrix instruction that scales block row kb of s and of every right-hand side, and the scaled block
 // row of s (= rows of L^T) is A and B operand of the rank-4 update of everything below.
-template <int KB, int NB, int NRHS, typename R>
+template <int KB, int NB, int NRHS, bool PL, typename R>
 I2C_FN void w_elim_step(const Wave<R>& w, R* s, R* r1, R* r2, R* lt, const R* mq, R* last) {
   const int a = w.j & 3, cq = w.q;
   const bool inblk = (w.j >> 2) == KB;
   R d[10];
-  w_pivot_block<KB>(w, s[KB], d);
+  w_pivot_block<KB, PL>(w, s[KB], d);
   const R d00 = d[0], d10 = d[1], d11 = d[2], d20 = d[3], d21 = d[4], d22 = d[5], d30 = d[6], d31 = d[7], d32 = d[8], d33 = d[9];
   // 4 x 4 Cholesky (l) ...
   const R i0 = r_rsqrt(d00);
@@ -270,15 +287,15 @@ I2C_FN void w_elim_step(const Wave<R>& w, R* s, R* r1, R* r2, R* lt, const R* mq
   }
   if (NRHS >= 1) r1[KB] = x1;
   if (NRHS >= 2) r2[KB] = x2;
-  if constexpr (KB + 1 < NB) w_elim_step<KB + 1, NB, NRHS>(w, s, r1, r2, lt, mq, last);
+  if constexpr (KB + 1 < NB) w_elim_step<KB + 1, NB, NRHS, PL>(w, s, r1, r2, lt, mq, last);
 }
-template <int NB, int NRHS, typename R> I2C_FN bool w_elim(const Wave<R>& w, R* s, R* r1, R* r2, R* lt) {
+template <int NB, int NRHS, bool PL = false, typename R> I2C_FN bool w_elim(const Wave<R>& w, R* s, R* r1, R* r2, R* lt) {
   R last = R(0), mq[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) mq[k] = w.q == k ? R(1) : R(0);
 #pragma unroll
   for (int v = 0; v < 4; ++v) lt[v] = R(0);
-  w_elim_step<0, NB, NRHS>(w, s, r1, r2, lt, mq, &last);
+  w_elim_step<0, NB, NRHS, PL>(w, s, r1, r2, lt, mq, &last);
   return last > R(0);
 }
 
@@ -314,7 +331,7 @@ I2C_FN int w_symidx(const int i, const int j) { return i >= j ? i * (i + 1) / 2 
 // the posterior-covariance form of the same gain,  s (s + N)^-1 = s_new N^-1  (N^-1 = W / alpha, W = the cost weight):
 //   mu <- mu + s_new W (zt - mu) / alpha.
 // mu, zt, wd (diagonal of W) in column form; xi, wm (W when not diagonal) accumulator-layout constants.
-template <int NB, typename R, class P> I2C_FN bool w_kalman(const Wave<R>& w, const R alpha, const P xi_m, const P w_m, const bool w_diag,
+template <int NB, bool PL = false, typename R, class P> I2C_FN bool w_kalman(const Wave<R>& w, const R alpha, const P xi_m, const P w_m, const bool w_diag,
                                                              const R zt, R* mu, R* s) {
   R sz[4], u[4], lt[4], xi[4];
   w_ldconst<NB>(w, xi_m, xi);
@@ -323,7 +340,7 @@ template <int NB, typename R, class P> I2C_FN bool w_kalman(const Wave<R>& w, co
     sz[v] = v < NB ? s[v] + alpha * xi[v] : R(0);
     u[v] = v < NB ? s[v] : R(0);
   }
-  const bool ok = w_elim<NB, 1>(w, sz, u, (R*)nullptr, lt);
+  const bool ok = w_elim<NB, 1, PL>(w, sz, u, (R*)nullptr, lt);
   w_tn<NB, true>(w, u, u, s);
   const R r = zt - *mu;
   R wr[4];
@@ -712,7 +729,7 @@ I2C_FN void w_end_of_chain(const Consts<M, R>& c, const KC& kc, const CellArgs<R
       w_ldconst<NBX>(w, kc.sxT, s3m);
     } else if (NZT > 0 && c.has_Qf) {
       const R alpha = a.alpha[b];
-      if (!w_kalman<NBX>(w, alpha, kc.xiT, kc.qf, c.qf_diag != 0, kc.zgT[j], &m3m, s3m) && w.l == 0) set_status(a.status, b, 6, T - 1);
+      if (!w_kalman<NBX, true>(w, alpha, kc.xiT, kc.qf, c.qf_diag != 0, kc.zgT[j], &m3m, s3m) && w.l == 0) set_status(a.status, b, 6, T - 1);
       w_ldconst<NBX>(w, kc.xiT, xiT);
 #pragma unroll
       for (int v = 0; v < 4; ++v) xiT[v] *= alpha;
@@ -810,7 +827,7 @@ I2C_FN void w_bwd_cell(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>
       sxx[v] = (v < NBX && jx) ? sg[v] : R(0);
       rh[v] = v < NBX ? (jx ? (w.row(v) == j ? R(1) : R(0)) : sg[v]) : R(0);
     }
-    if (!w_elim<NBX, 1>(w, sxx, rh, (R*)nullptr, lt) && w.l == 0) set_status(a.status, b, 7, t);
+    if (!w_elim<NBX, 1, true>(w, sxx, rh, (R*)nullptr, lt) && w.l == 0) set_status(a.status, b, 7, t);
     w_tn<NBX>(w, rh, rh, g);
     w_col2row<NBX>(w, 1, jx ? mu : R(0), mr);
     R kx = R(0);
