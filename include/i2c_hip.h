@@ -165,7 +165,10 @@ typedef struct I2cProblem {
                               horizon lives in row (t0 + t) mod T. 0 outside the MPC loop; the receding-horizon shift (mpc.py:174-181)
                               is "t0 += 1" plus one fresh row (i2c_mpc_step / i2c_shift_horizon). Buffers a sweep writes for its
                               caller (fwd, xm, zpost, prior_out, prop, cell_stats) are indexed by the cell index t directly.          */
-  int32_t reserved1;
+  int32_t post_layout;     /* layout of the posterior / prior buffers (`prior`, `post`, I2cMpcStep.post): 0 = [T][e_post][B] (every
+                              model); 1 = trajectory-major [T][B][e_post] -- the e_post elements of one cell of one trajectory are
+                              contiguous -- accepted by the models with wave kernels (I2cDims.wave), whose every kernel then
+                              reads / writes a cell of a trajectory as a few cache lines instead of e_post scattered elements   */
   /* CubatureQuadrature(alpha, beta, kappa): i2c/exp_types.py:31-49 */
   double quad_alpha, quad_beta, quad_kappa;
   double dtemp;            /* terminal-prior annealing rate (i2c.py:66,552)                    */

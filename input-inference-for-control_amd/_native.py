@@ -72,7 +72,7 @@ class I2cProblem(C.Structure):
         ("gh_degree", C.c_int32),
         ("group_lanes", C.c_int32),
         ("t0", C.c_int32),
-        ("reserved1", C.c_int32),
+        ("post_layout", C.c_int32),
         ("quad_alpha", C.c_double),
         ("quad_beta", C.c_double),
         ("quad_kappa", C.c_double),

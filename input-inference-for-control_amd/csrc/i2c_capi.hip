@@ -23,6 +23,14 @@ int check_problem(const I2cProblem* p) {
   if (p->inference < I2C_INF_CUBATURE || p->inference > I2C_INF_GAUSS_HERMITE) return I2C_EINVAL;
   if (p->inference == I2C_INF_GAUSS_HERMITE && (p->gh_degree < 1 || p->gh_degree > I2C_MAX_GH_DEGREE)) return I2C_EINVAL;
   if (p->t0 < 0 || p->t0 >= p->T) return I2C_EINVAL;
+  if (p->post_layout != 0 && p->post_layout != 1) return I2C_EINVAL;
+  if (p->post_layout == 1) {  // trajectory-major posterior: only the models whose every kernel knows it
+    I2cDims d;
+    const i2c::ModelOps* ops = find_ops(p->model_id, I2C_F64);
+    if (!ops) return I2C_EINVAL;
+    ops->dims(&d);
+    if (!d.wave) return I2C_ENOTSUP;
+  }
   return I2C_OK;
 }
 

@@ -52,6 +52,10 @@ template <class M, typename R> struct Consts {
   }
   int has_Qf, has_x_terminal, z_per_cell, use_expert, terminal_cell, inference;
   int qr_diag, qf_diag;  // cost weights are diagonal: cheap closed forms in gaussian_cost
+  int post_tm;           // posterior / prior buffers are trajectory-major, [T][B][E_POST] (I2cProblem.post_layout; wave-capable models)
+  // element e of trajectory b inside one cell block of the posterior / prior buffer: stride of e and offset of b
+  I2C_HD inline long post_es() const { return post_tm ? 1L : (long)B; }
+  I2C_HD inline long post_bo(const int b) const { return post_tm ? (long)b * E_POST : (long)b; }
   Rule<R> rule_xu, rule_x;
   R dtemp, tol;
   R sig_eta_w[sym(NX)];  // W(d) * sig_eta, W = sum of the d-dimensional rule's weights
@@ -1759,14 +1763,15 @@ I2C_HD inline void rollout_body(const Consts<M, R>& c, const RolloutArgs<R>& a, 
   if (a.eps_x) chol<NX>(Le, rinv_e);
 
   for (int t = 0; t < T; ++t) {
-    const R* row = a.post + ((long)c.row(t) * C::E_POST) * B + b;
+    const long es = c.post_es();
+    const R* row = a.post + ((long)c.row(t) * C::E_POST) * B + c.post_bo(b);
     R u[NU], Kc[NU * NX];
 #pragma unroll
-    for (int e = 0; e < NU * NX; ++e) Kc[e] = row[(long)(D + sym(D) + e) * B];
+    for (int e = 0; e < NU * NX; ++e) Kc[e] = row[(long)(D + sym(D) + e) * es];
     if (a.policy == 0) {  // u = K x + k
 #pragma unroll
       for (int p = 0; p < NU; ++p) {
-        R v = row[(long)(C::E_PRI + p) * B];
+        R v = row[(long)(C::E_PRI + p) * es];
 #pragma unroll
         for (int k = 0; k < NX; ++k) v += Kc[p * NX + k] * x[k];
         u[p] = v;
@@ -1774,9 +1779,9 @@ I2C_HD inline void rollout_body(const Consts<M, R>& c, const RolloutArgs<R>& a, 
     } else {  // u = mu_u + w K (x - mu_x), w = exp(-maha/2) (soft) or [maha/2 < 3] (hard); lam = sig_x^{-1}
       R dlt[NX], q[NX], S[sym(NX)], rinv[NX];
 #pragma unroll
-      for (int k = 0; k < NX; ++k) q[k] = dlt[k] = x[k] - row[(long)k * B];
+      for (int k = 0; k < NX; ++k) q[k] = dlt[k] = x[k] - row[(long)k * es];
 #pragma unroll
-      for (int k = 0; k < sym(NX); ++k) S[k] = row[(long)(D + k) * B];
+      for (int k = 0; k < sym(NX); ++k) S[k] = row[(long)(D + k) * es];
       chol<NX>(S, rinv);
       fsub<NX>(S, rinv, q);
       R half = R(0);
@@ -1789,13 +1794,13 @@ I2C_HD inline void rollout_body(const Consts<M, R>& c, const RolloutArgs<R>& a, 
         R v = R(0);
 #pragma unroll
         for (int k = 0; k < NX; ++k) v += Kc[p * NX + k] * dlt[k];
-        u[p] = row[(long)(NX + p) * B] + w * v;
+        u[p] = row[(long)(NX + p) * es] + w * v;
       }
     }
     if (a.eps_u) {  // u += chol(sigK) eps
       R Lk[sym(NU)], rk[NU];
 #pragma unroll
-      for (int k = 0; k < sym(NU); ++k) Lk[k] = row[(long)(C::E_PRI + NU + k) * B];
+      for (int k = 0; k < sym(NU); ++k) Lk[k] = row[(long)(C::E_PRI + NU + k) * es];
       chol<NU>(Lk, rk);
 #pragma unroll
       for (int p = 0; p < NU; ++p)
@@ -1867,17 +1872,18 @@ I2C_HD inline void mpc_shift_body(const Consts<M, R>& c, const ShiftArgs<R>& a, 
   constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, D = C::D;
   const long B = c.B;
   const int r0 = c.row(0), rl = c.row(c.T - 1);  // rows of the first and of the last cell of the current horizon
-  R* p0 = a.post + ((long)r0 * C::E_POST) * B + b;
+  const long es = c.post_es();
+  R* p0 = a.post + ((long)r0 * C::E_POST) * B + c.post_bo(b);
   if (a.action) {
 #pragma unroll
-    for (int i = 0; i < NU; ++i) a.action[(long)i * B + b] = p0[(long)(NX + i) * B];
+    for (int i = 0; i < NU; ++i) a.action[(long)i * B + b] = p0[(long)(NX + i) * es];
 #pragma unroll
     for (int p = 0; p < NU; ++p)
 #pragma unroll
-      for (int q = 0; q <= p; ++q) a.action[(long)(NU + tri(p, q)) * B + b] = p0[(long)(D + tri(NX + p, NX + q)) * B];
+      for (int q = 0; q <= p; ++q) a.action[(long)(NU + tri(p, q)) * B + b] = p0[(long)(D + tri(NX + p, NX + q)) * es];
   }
 #pragma unroll
-  for (int e = 0; e < C::E_POST; ++e) p0[(long)e * B] = a.cell_init[(long)e * B + b];
+  for (int e = 0; e < C::E_POST; ++e) p0[(long)e * es] = a.cell_init[(long)e * B + b];
   if (a.alpha_cell) a.alpha_cell[(long)r0 * B + b] = a.alpha_init[b];
   if (a.z) {
 #pragma unroll

@@ -560,6 +560,11 @@ template <typename R> struct GIO {
 template <typename R> I2C_FN GIO<R> gio(const R* base, const unsigned long elems, const unsigned rb, const unsigned bo) {
   return GIO<R>{make_window(base, elems * rb), rb, bo};
 }
+// a cell block of the posterior / prior buffer: [E][B] or, trajectory-major (Consts::post_tm), [B][E] -- the same E * B elements,
+// element e of trajectory b at byte e * rbp + bop with (rbp, bop) = (B W, b W) or (W, b E W)
+template <typename R> I2C_FN GIO<R> gio_post(const R* base, const unsigned long elems, const unsigned long B, const unsigned rbp, const unsigned bop) {
+  return GIO<R>{make_window(base, elems * B * sizeof(R)), rbp, bop};
+}
 
 // Joint over (x, u) from a state message (mu_x replicated, sx = row r of sig_x for the state lanes) and a controller
 // row block (i2c.py:361-387 forward feedback prior with Kt = rho K; i2c.py:158-179 propagation):
@@ -741,6 +746,7 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
   const unsigned long B = c.B;
   const int T = c.T;
   const unsigned W = sizeof(R), bo = (unsigned)b * W, rb0 = (unsigned)(B * W);
+  const unsigned rbp = c.post_tm ? W : rb0, bop = c.post_tm ? (unsigned)b * C::E_POST * W : bo;  // prior buffer (gio_post)
   const int rx = r < NX ? r : NX - 1, rd = r < D ? r : D - 1, rz = r < NZ ? r : NZ - 1, rt = r < NT ? r : NT - 1;
   const int trx = rx * (rx + 1) / 2, trd = rd * (rd + 1) / 2;
   const bool is_u = r >= NX && r < D;
@@ -766,15 +772,15 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
   unsigned o_pmu, o_prow[D], o_K[NX];
   {
     const int r0 = g.r, rd0 = r0 < D ? r0 : D - 1, trd0 = rd0 * (rd0 + 1) / 2, ru0 = (r0 >= NX && r0 < D) ? r0 - NX : 0;
-    o_pmu = (unsigned)rd0 * rb0 + bo;
+    o_pmu = (unsigned)rd0 * rbp + bop;
 #pragma unroll
-    for (int j = 0; j < D; ++j) o_prow[j] = (unsigned)(D + symidx(rd0, trd0, j)) * rb0 + bo;
+    for (int j = 0; j < D; ++j) o_prow[j] = (unsigned)(D + symidx(rd0, trd0, j)) * rbp + bop;
 #pragma unroll
-    for (int k = 0; k < NX; ++k) o_K[k] = (unsigned)(O_K + ru0 * NX + k) * rb0 + bo;
+    for (int k = 0; k < NX; ++k) o_K[k] = (unsigned)(O_K + ru0 * NX + k) * rbp + bop;
   }
   auto fetch_prior = [&](const int tc, const unsigned rbx, const int, const int, const int) {
     const int trc = c.row(tc);  // row of the persistent buffers (ring, see Consts::t0)
-    const GIO<R> pri = gio(a.prior + (unsigned long)trc * C::E_POST * B, C::E_POST, rbx, bo);
+    const GIO<R> pri = gio_post(a.prior + (unsigned long)trc * C::E_POST * B, C::E_POST, B, rbx, bop);
     nx_pmu_own = pri.ldo(o_pmu);
 #pragma unroll
     for (int j = 0; j < D; ++j) nx_prow[j] = pri.ldo(o_prow[j]);
@@ -1049,7 +1055,8 @@ I2C_HD inline void backward_group_body(const Consts<M, R>& c, const KC& kc, cons
     const bool is_x = r < NX, is_u = r >= NX && r < D;
     const int ru = is_u ? r - NX : 0;
 
-    const GIO<R> po = gio(a.post + (unsigned long)c.row(t) * C::E_POST * B, C::E_POST, rb, bo);
+    const GIO<R> po = gio_post(a.post + (unsigned long)c.row(t) * C::E_POST * B, C::E_POST, B, c.post_tm ? W : rb,
+                               c.post_tm ? (unsigned)b * C::E_POST * W : bo);
     if (!PREFETCH) fetch_fwd(t, rb, rd, trd, rx, trx);  // nothing is carried across cells then
     R mu[D], S[D], m3f[NX], s3f[NX], Jr[NX];
     const R mu1_own = nx_mu1_own;
@@ -1238,7 +1245,8 @@ I2C_HD inline void propagate_group_body(const Consts<M, R>& c, const KC& kc, con
     const bool is_u = r >= NX && r < D;
     const int ru = is_u ? r - NX : 0;
 
-    const GIO<R> pri = gio(a.post + (unsigned long)c.row(t) * C::E_POST * B, C::E_POST, rb, bo);
+    const GIO<R> pri = gio_post(a.post + (unsigned long)c.row(t) * C::E_POST * B, C::E_POST, B, c.post_tm ? W : rb,
+                                c.post_tm ? (unsigned)b * C::E_POST * W : bo);
     const GIO<R> out = gio(a.prop + (unsigned long)t * C::E_PROP * B, C::E_PROP, rb, bo);
     R qmu[D], prow[D], Krow[NX];
     g_gather<D>(g, 0, pri.ld(rd), qmu);

@@ -262,11 +262,12 @@ static int launch_group_w(const Consts<M, R>& c, const ZetaArg<M, R>* zeta, cons
 #endif
 
 // ---- wave kernels (i2c_wave.hpp): one wavefront per trajectory, four per workgroup ----------------------------------------------
-enum { WK_FORWARD = 0, WK_BACKWARD = 1, WK_SCAN = 2, WK_CELL = 3 };
+enum { WK_FORWARD = 0, WK_BACKWARD = 1, WK_SCAN = 2, WK_CELL = 3, WK_FORWARD_PL = 4 };  // _PL: pivot blocks through LDS
 constexpr int WAVES_PER_BLOCK = 4;
 template <int KIND, class M, typename R, typename S, bool LIN, class KC, class A>
 I2C_FN void wave_body(const Consts<M, R>& c, const KC& kc, const A& a, const int t, const int b, const Wave<R>& w) {
-  if constexpr (KIND == WK_FORWARD) forward_wave_body<M, R, S, LIN>(c, kc, a, b, w);
+  if constexpr (KIND == WK_FORWARD) forward_wave_body<M, R, S, LIN, false>(c, kc, a, b, w);
+  if constexpr (KIND == WK_FORWARD_PL) forward_wave_body<M, R, S, LIN, true>(c, kc, a, b, w);
   if constexpr (KIND == WK_BACKWARD) backward_wave_body<M, R, S, LIN>(c, kc, a, b, w);
   if constexpr (KIND == WK_SCAN) backward_wave_scan_body<M, R, S>(c, kc, a, b, w);
   if constexpr (KIND == WK_CELL) backward_wave_cell_body<M, R, S>(c, kc, a, t, b, w);  // one wave per (t, b)
@@ -316,6 +317,9 @@ static int launch_wave_v(const Consts<M, R>& c, const A& a, void* stream) {
 
 template <int KIND, class M, typename R, typename S, class A>
 static int launch_wave(const Consts<M, R>& c, const A& a, void* stream) {
+  if constexpr (KIND == WK_FORWARD) {  // batches whose waves share a SIMD: the variant with the pivot blocks through LDS
+    if (c.B > 1024 && c.inference != I2C_INF_LINEARIZE) return launch_wave_v<WK_FORWARD_PL, M, R, S, false>(c, a, stream);
+  }
   if constexpr (sizeof(S) == sizeof(R) && M::NZT > 0 && (KIND == WK_FORWARD || KIND == WK_BACKWARD)) {
     // the Linearize variant: fp64 storage, models with a terminal observation, one backward schedule
     if (c.inference == I2C_INF_LINEARIZE) return launch_wave_v<KIND, M, R, S, true>(c, a, stream);
@@ -377,6 +381,7 @@ template <class M, typename R> static Consts<M, R> make_consts(const I2cProblem*
   c.use_expert = use_expert;
   c.terminal_cell = p->terminal_cell;
   c.inference = p->inference;
+  c.post_tm = (p->post_layout == 1 && M::WAVE) ? 1 : 0;
   auto is_diag = [](const double* W, int n) {
     for (int i = 0; i < n; ++i)
       for (int j = 0; j < i; ++j)

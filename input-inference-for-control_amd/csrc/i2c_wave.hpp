@@ -135,12 +135,14 @@ template <typename R> I2C_FN R w_rowsum(const Wave<R>& w, const R x) {
 #endif
 }
 // The 4 x 4 pivot block of row block KB of a symmetric matrix, to every lane: x = accumulator register KB, whose entry (a, b) of
-// the block sits in lane (a, 4 KB + b). d = {d00, d10, d11, d20, d21, d22, d30, d31, d32, d33}. Two ways (PL), fixed per kernel:
-//   v_readlane: ten pairs into scalar registers -- no round trip to wait for, 20 issue slots. The forward sweep's choice: a
-//               lone wave (B <= 1024) gains 4 % (0.382 -> 0.365 ms), a full chip neither gains nor loses (1.13 ms at B = 4096);
-//   LDS:        the 16 lanes that hold the block store it, every lane reads it back (1 + 6 instructions and a round trip).
-//               The backward sweep's choice: -10 ... -14 % once waves share a SIMD (B = 8192: 1.12 -> 0.96 ms), level below.
-// (A per-launch switch between the two inside one kernel was measured and dropped: the extra branch and registers cost the
+// the block sits in lane (a, 4 KB + b). d = {d00, d10, d11, d20, d21, d22, d30, d31, d32, d33}. Two ways (PL), a compile-time
+// choice per kernel instantiation:
+//   v_readlane: ten pairs into scalar registers -- no round trip to wait for, 20 issue slots: the forward sweep while every
+//               wave has a SIMD to itself (B <= 1024: 0.382 -> 0.365 ms);
+//   LDS:        the 16 lanes that hold the block store it, every lane reads it back (1 + 6 instructions and a round trip that
+//               other waves of the SIMD fill): the backward sweep, and the forward sweep of larger batches (the readlanes are
+//               17 % of a forward cell's vector instructions, and a full chip is issue-bound).
+// (A RUN-TIME switch between the two inside one kernel was measured and dropped: the extra branch and registers cost the
 // forward sweep 6 - 10 % at every batch size.)
 template <int KB, bool PL, typename R> I2C_FN void w_pivot_block(const Wave<R>& w, const R x, R* d) {
 #ifdef I2C_HOST_SIM
@@ -324,6 +326,13 @@ template <typename R, typename S> I2C_FN WIO<R, S> wio(const S* base, const unsi
 template <typename R, typename S> I2C_FN WIO<R, S> w_fwd_cell(const S* fwd, const int e_fwd, const unsigned long B, const int t, const int b) {
   return wio<R, S>(fwd + ((unsigned long)t * B + (unsigned long)b) * (unsigned long)e_fwd, (unsigned long)e_fwd, (unsigned)sizeof(S), 0u);
 }
+// one cell of the posterior / prior buffer for trajectory b: [T][E][B], or trajectory-major [T][B][E] (Consts::post_tm)
+template <typename R, typename S>
+I2C_FN WIO<R, S> w_post_cell(const S* post, const int e_post, const unsigned long B, const int row, const int b, const bool tm) {
+  const S* cell = post + (unsigned long)row * (unsigned long)e_post * B;
+  if (tm) return wio<R, S>(cell + (unsigned long)b * (unsigned long)e_post, (unsigned long)e_post, (unsigned)sizeof(S), 0u);
+  return wio<R, S>(cell, (unsigned long)e_post, (unsigned)(B * sizeof(S)), (unsigned)(b * sizeof(S)));
+}
 I2C_FN int w_symidx(const int i, const int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
 // Kalman-style update of N(mu, s) of dimension N = 4 NB on an IDENTITY observation of it with noise alpha * xi and target zt
@@ -369,7 +378,9 @@ template <int NB, bool PL = false, typename R, class P> I2C_FN bool w_kalman(con
 // LIN: Linearize() inference (i2c.py:244-348): the same cell with the dynamics push-through replaced by value + Jacobian (one
 // forward-mode pass per input direction, lane p carrying the tangent e_p), the pdf-ratio scaling of the gain only with the
 // expert controller (:259-265), and no terminal update here (it happens at the end of the backward chain, :475-491).
-template <class M, typename R, typename S, bool LIN, class KC>
+// PL: the pivot blocks of the eliminations go through LDS instead of v_readlane (w_pivot_block): the variant for batches
+// whose waves share a SIMD.
+template <class M, typename R, typename S, bool LIN, bool PL, class KC>
 I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const FwdArgs<R, S>& a, const int b, const Wave<R>& w) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D, NBX = NX / 4;
@@ -398,7 +409,7 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
   int nx_ff, nx_ex;
   auto fetch_prior = [&](const int tc) {
     const int trc = c.row(tc);
-    const WIO<R, S> pri = wio<R, S>(a.prior + (unsigned long)trc * C::E_POST * B, C::E_POST, rb, bo);
+    const WIO<R, S> pri = w_post_cell<R, S>(a.prior, C::E_POST, B, trc, b, c.post_tm != 0);
     nx_pmu = pri.ld(j);
 #pragma unroll
     for (int v = 0; v < 4; ++v) nx_pj[v] = pri.ld(D + w_symidx(w.row(v), j));
@@ -442,7 +453,7 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
           sm[v] = (v < NBX && jx) ? pj[v] + sx[v] : R(0);
           rh[v] = (v < NBX && j == NX) ? dr[v] : R(0);
         }
-        cell_bad = flag_stage(cell_bad, w_elim<NBX, 1>(w, sm, rh, (R*)nullptr, lt), 0);
+        cell_bad = flag_stage(cell_bad, w_elim<NBX, 1, PL>(w, sm, rh, (R*)nullptr, lt), 0);
         R ysq = R(0);
 #pragma unroll
         for (int v = 0; v < NBX; ++v) ysq += rh[v] * rh[v];
@@ -481,7 +492,7 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
     }
 
     // ---- 2. cost "observation" z = (x, u): measurement update (i2c.py:390-407) ----------
-    cell_bad = flag_stage(cell_bad, w_kalman<4>(w, alpha, kc.xi, kc.qr, c.qr_diag != 0, zt, &mu0, s0), 2);
+    cell_bad = flag_stage(cell_bad, w_kalman<4, PL>(w, alpha, kc.xi, kc.qr, c.qr_diag != 0, zt, &mu0, s0), 2);
     out.st_if(q == 0, j, mu0);
 #pragma unroll
     for (int v = 0; v < 4; ++v) out.st_if(w.row(v) >= j, D + w_symidx(w.row(v), j), s0[v]);
@@ -494,7 +505,7 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
         R tmp[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) tmp[v] = s0[v];
-        cell_bad = flag_stage(cell_bad, w_elim<4, 0>(w, tmp, (R*)nullptr, (R*)nullptr, lt), 3);
+        cell_bad = flag_stage(cell_bad, w_elim<4, 0, PL>(w, tmp, (R*)nullptr, (R*)nullptr, lt), 3);
       }
       const auto Lt = w.mat();
       const auto mv = w.vec(2);
@@ -621,14 +632,14 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
         tmp[v] = sx[v];
         w3[v] = (v < NBX && w.row(v) == j) ? R(1) : R(0);
       }
-      cell_bad = flag_stage(cell_bad, w_elim<NBX, 2>(w, tmp, sxy, w3, l3), 4);
+      cell_bad = flag_stage(cell_bad, w_elim<NBX, 2, PL>(w, tmp, sxy, w3, l3), 4);
       w_tn<NBX>(w, w3, sxy, jt);
 #pragma unroll
       for (int v = 0; v < NBX; ++v) out.st(O_J + j * NX + w.row(v), jt[v]);
     }
     // ---- 4. terminal cost observation on the flagged cell, after J (i2c.py:430-443) ----
     if (!LIN && NZT > 0 && t == c.terminal_cell && c.has_Qf)  // (uniform: kernel arguments)
-      cell_bad = flag_stage(cell_bad, w_kalman<NBX>(w, alpha, kc.xiT, kc.qf, c.qf_diag != 0, kc.zgT[j], &mx, sx), 5);
+      cell_bad = flag_stage(cell_bad, w_kalman<NBX, PL>(w, alpha, kc.xiT, kc.qf, c.qf_diag != 0, kc.zgT[j], &mx, sx), 5);
     fail = fold_cell_failure(fail, cell_bad, t);
     out.st_if(q == 0 && jx, O_MU3 + jxc, mx);
 #pragma unroll
@@ -790,7 +801,7 @@ I2C_FN void w_bwd_cell(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>
   const unsigned WS = sizeof(S), bo = (unsigned)b * WS, rb = (unsigned)(B * WS);
   const bool jx = j < NX;
   const int jxc = jx ? j : 0, ju = jx ? 0 : j - NX;
-  const WIO<R, S> po = wio<R, S>(a.post + (unsigned long)c.row(t) * C::E_POST * B, C::E_POST, rb, bo);
+  const WIO<R, S> po = w_post_cell<R, S>(a.post, C::E_POST, B, c.row(t), b, c.post_tm != 0);
   R mu = f.mu, jt[4];
 #pragma unroll
   for (int v = 0; v < 4; ++v) {

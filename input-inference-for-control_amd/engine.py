@@ -9,6 +9,7 @@ Device layout (see include/i2c_hip.h): every per-cell buffer is ``[T][E][B]`` wi
 trajectory index innermost, symmetric matrices packed (lower, row-major).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -197,7 +198,14 @@ class BatchedI2c:
         o_k = d + sym_size(d) + nu * nx
         post[:, o_k: o_k + nu, :] = np.transpose(mu_u, (1, 2, 0))  # k = mu_u (i2c.py:136)
         post[:, o_k + nu:, :] = pack_sym_np(sig_u)[None, :, None]
+        # Layout of the posterior / prior buffers (I2cProblem.post_layout): logically always [T][e_post][B]; for the models with
+        # wave kernels the STORAGE is trajectory-major, [T][B][e_post] (a cell of a trajectory is contiguous: a wavefront, which
+        # works on one trajectory, reads it as a few cache lines), and self.post is a permuted view of it, so every index
+        # expression in this file and its callers is layout-blind; only the library (data_ptr) sees the difference.
+        self.post_layout = int(os.environ.get("I2C_POST_LAYOUT", "1" if dims.wave else "0")) if dims.wave else 0
         self.post = to(post).to(st)
+        if self.post_layout == 1:
+            self.post = self.post.permute(0, 2, 1).contiguous().permute(0, 2, 1)
         # The forward sweep reads `prior`, the backward sweep writes `post`. Normally they are ONE buffer (after
         # _update_priors the prior IS the posterior, i2c.py:1210-1221, so the copy is free). keep_prior_joint=True keeps
         # them apart until update_priors(): two forward/backward passes without _update_priors() in between then start
@@ -253,7 +261,7 @@ class BatchedI2c:
         self.alpha_cell = None      # [T][B] per-cell temperature, only in the MPC loop (see enable_per_cell_alpha)
         self.alpha_init = None
         self.terminal_cell = T - 1  # cell whose forward pass applies the terminal cost update (i2c.py:82,822)
-        self.cell_init = self.post[0].clone()  # a fresh cell (I2cCell.__init__), appended by shift_horizon()
+        self.cell_init = self.post[0].contiguous().clone()  # a fresh cell (I2cCell.__init__), appended by shift_horizon(); [e_post][B]
         self.tau = T - 1  # i2c.py:833
         self._propagate = False
         self.use_expert_controller = True
@@ -292,6 +300,7 @@ class BatchedI2c:
         p.gh_degree = self.gh_degree
         p.group_lanes = self.group_lanes
         p.t0 = int(self.t0)
+        p.post_layout = int(self.post_layout)
         if self.gauss_hermite:
             gx, gw = np.polynomial.hermite.hermgauss(self.gh_degree)  # exp_types.py:57
             for i in range(self.gh_degree):

@@ -270,3 +270,9 @@ def test_hip_fused_em_loop_matches_stepwise(lib):
     torch.cuda.synchronize()
     assert torch.equal(a.post, b.post) and torch.equal(a.alpha, b.alpha) and torch.equal(a.feedforward, b.feedforward)
     assert torch.equal(torch.stack(a.costs_m), torch.stack(b.costs_m))
+
+
+def test_hip_post_layout_is_transparent(lib, monkeypatch):
+    from test_kernels_hostsim import _post_layout_is_transparent
+
+    _post_layout_is_transparent(lib, "cuda", monkeypatch)

@@ -232,3 +232,40 @@ def test_hostsim_fused_em_loop_matches_stepwise(lib):
     assert b.em_iter == 5 and len(b.alphas) == 6 and len(b.costs_m) == 5
     assert torch.equal(torch.stack(a.costs_m), torch.stack(b.costs_m))
     assert torch.equal(torch.stack(a.alphas), torch.stack(b.alphas))
+
+
+def _post_layout_is_transparent(lib, device, monkeypatch):
+    """The posterior / prior buffers of the wave-capable models are stored trajectory-major (I2cProblem.post_layout = 1); the
+    standard [T][e][B] layout stays available (I2C_POST_LAYOUT=0). Same arithmetic, different addressing: EM iterations on both
+    kernel families, closed-loop propagation, the MPC step with its ring shift, and policy rollouts must agree bit for bit."""
+    import numpy as np
+    import torch
+    from golden_util import load_case
+
+    g = load_case("em_quad12_T12_propagate")
+    x0, mu_u = parity.batched_inputs(g, 5)
+    runs = {}
+    for layout in ("1", "0"):
+        monkeypatch.setenv("I2C_POST_LAYOUT", layout)
+        for lanes in (0, 16):
+            e = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u, group_lanes=lanes)
+            assert e.post_layout == int(layout) and e.post.shape == (g.meta["T"], e.dims.e_post, 5)
+            assert e.post.stride()[1] == (1 if layout == "1" else 5)
+            e.propagate()
+            for _ in range(3):
+                e.learn_msgs()
+            e.enable_per_cell_alpha()
+            sig_zeta = 1e-4 * np.eye(9)
+            y = torch.as_tensor(np.ascontiguousarray(parity.product_model(g).measure(x0).T), dtype=torch.float64, device=device)
+            u = torch.as_tensor(np.ascontiguousarray(mu_u[:, 0, :].T), dtype=torch.float64, device=device)
+            act = [e.mpc_step(2, y, u, sig_zeta)[0].clone() for _ in range(2)]
+            roll = e.rollout(2, "expert_soft", process_noise=False)
+            assert e.failures() == []
+            runs[(layout, lanes)] = (e.post.clone(), e.prop.clone(), torch.stack(act), roll["xu"].clone(), e.alpha.clone())
+    for lanes in (0, 16):
+        for a, b in zip(runs[("1", lanes)], runs[("0", lanes)]):
+            assert torch.equal(a, b)
+
+
+def test_hostsim_post_layout_is_transparent(lib, monkeypatch):
+    _post_layout_is_transparent(lib, "cpu", monkeypatch)
