@@ -441,22 +441,21 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
 #pragma unroll
       for (int v = 0; v < 4; ++v) s0[v] = (v < NBX) ? (jx ? sx[v] : R(0)) : (jx ? R(0) : pj[v]);
     } else {  // feedback: condition the previous controller on the new state message (i2c.py:361-387)
-      // pdf ratio rho = exp(-delta^T (P_xx + sig_x)^-1 delta / 2): delta rides as column NX of the right-hand side
+      // pdf ratio rho = exp(-delta^T (P_xx + sig_x)^-1 delta / 2): delta rides as column NX of the nx x nx matrix ITSELF (its tile
+      // has 16 columns): the scaling and the rank-4 updates of the elimination treat that column like any other, so
+      // y = L^-1 delta comes out as column NX of L^T with no right-hand-side instructions at all
       const R dl = jx ? mx - pmu : R(0);
       R dr[4];
       w_col2row<NBX>(w, 0, dl, dr);
       R rho = R(1);
       if (scale_gain) {
-        R sm[4], rh[4], lt[4];
+        R sm[4], lt[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          sm[v] = (v < NBX && jx) ? pj[v] + sx[v] : R(0);
-          rh[v] = (v < NBX && j == NX) ? dr[v] : R(0);
-        }
-        cell_bad = flag_stage(cell_bad, w_elim<NBX, 1, PL>(w, sm, rh, (R*)nullptr, lt), 0);
+        for (int v = 0; v < 4; ++v) sm[v] = v < NBX ? (jx ? pj[v] + sx[v] : (j == NX ? dr[v] : R(0))) : R(0);
+        cell_bad = flag_stage(cell_bad, w_elim<NBX, 0, PL>(w, sm, (R*)nullptr, (R*)nullptr, lt), 0);
         R ysq = R(0);
 #pragma unroll
-        for (int v = 0; v < NBX; ++v) ysq += rh[v] * rh[v];
+        for (int v = 0; v < NBX; ++v) ysq += j == NX ? lt[v] * lt[v] : R(0);
         const R maha = w_bcast<NX>(w, w_rowsum(w, ysq));
         rho = r_exp(R(-0.5) * maha);
       }
