@@ -125,9 +125,8 @@ def algorithmic_elements(d, nx, nu):
 
 def measured_traffic(B, T, dtype, kernel):
     """HBM bytes per launch from the committed PMC passes (tools/pmc_summary.py), if one matches."""
-    path = os.path.join(ROOT, "profiles", f"r2_B{B}_pmc_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", f"r1_B{B}_pmc_traffic.json")
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_B{B}_pmc_traffic.json") for r in (3, 2, 1)) if os.path.exists(q)),
+                os.path.join(ROOT, "profiles", f"r1_B{B}_pmc_traffic.json"))
     if not os.path.exists(path):
         return None
     d = json.load(open(path))
@@ -474,7 +473,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": measured_traffic(B, T, args.dtype, "k_forward"),
             "traffic_note": "bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                            "(FETCH_SIZE x2, gfx950 correction; profiles/r2_B*_pmc_traffic.json); algorithmic = "
+                            "(FETCH_SIZE x2, gfx950 correction; profiles/r3_B*_pmc_traffic.json); algorithmic = "
                             + str(fwd_bytes),
             "algorithmic_bytes_per_cell": {k: v * wbytes for k, v in el.items()},
             "whole_iteration_GBps": el["total"] * wbytes * B * T / (elapsed / K) / 1e9,
