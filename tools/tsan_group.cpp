@@ -1,14 +1,15 @@
-// ThreadSanitizer driver for the GROUP kernels' host simulation (tests only): the G lanes of a group run as G threads with a
-// barrier wherever the device code has its LDS fence, so a missing fence shows up here as a data race on the group's
-// exchange region. Drives forward, backward, propagation and the filter step of the 12-state quadrotor (16 lanes per
-// trajectory) through the C ABI on a tiny problem. Built and run by tools/tsan_group.sh.
+// ThreadSanitizer driver for the multi-lane kernels' host simulation (tests only): the G lanes of a group -- or the 64 lanes of a
+// wave kernel's wavefront -- run as threads with a barrier wherever the device code has its LDS fence or a cross-lane
+// instruction, so a missing fence shows up here as a data race on the exchange region. Drives forward, backward, propagation and
+// the filter step of the 12-state quadrotor through the C ABI on a tiny problem: group kernels (16 lanes per trajectory), wave
+// kernels (cubature), wave kernels (Linearize). Built and run by tools/tsan_group.sh.
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <vector>
 #include "../include/i2c_hip.h"
 
-int main() {
+static int run(const int group_lanes, const int inference) {
   I2cDims d;
   if (i2c_query(I2C_MODEL_QUADROTOR12, &d) != I2C_OK) return 2;
   const int B = 3, T = 4, nx = d.nx, nu = d.nu, nz = d.nz, D = nx + nu;
@@ -21,7 +22,8 @@ int main() {
   p.T = T;
   p.has_Qf = 1;
   p.terminal_cell = T - 1;
-  p.inference = I2C_INF_CUBATURE;
+  p.inference = inference;
+  p.group_lanes = group_lanes;
   p.quad_alpha = 1.0;
   p.dtemp = 1.0;
   auto diag = [](double* packed, int n, double v) {
@@ -62,13 +64,22 @@ int main() {
     rc = i2c_forward_sweep(&p, post.data(), fwd.data(), nullptr, status.data(), nullptr);
     if (!rc) rc = i2c_backward_sweep(&p, fwd.data(), nullptr, post.data(), nullptr, nullptr, term.data(), status.data(), nullptr);
     if (!rc) rc = i2c_mstep(&p, term.data(), 0.5, 1, stats.data(), nullptr);
-    if (!rc) rc = i2c_propagate(&p, post.data(), prop.data(), pstat.data(), 1, status.data(), nullptr);
+    if (!rc && inference == I2C_INF_CUBATURE) rc = i2c_propagate(&p, post.data(), prop.data(), pstat.data(), 1, status.data(), nullptr);
   }
   std::vector<double> zeta(d.ny * (d.ny + 1) / 2, 0.0), y(d.ny * B, 0.01), u(nu * B, 2.45);
   for (int i = 0; i < d.ny; ++i) zeta[i * (i + 1) / 2 + i] = 1e-4;
-  if (!rc) rc = i2c_ckf_filter(&p, zeta.data(), y.data(), u.data(), x0.data(), sx0.data(), status.data(), nullptr);
+  if (!rc && inference == I2C_INF_CUBATURE) rc = i2c_ckf_filter(&p, zeta.data(), y.data(), u.data(), x0.data(), sx0.data(), status.data(), nullptr);
   bool finite = true;
   for (double v : post) finite = finite && std::isfinite(v);
-  std::printf("rc %d status %d %d %d finite %d cost %.6f\n", rc, status[0], status[1], status[2], (int)finite, stats[2 * B]);
+  std::printf("lanes %2d inference %d family fwd %d bwd %d: rc %d status %d %d %d finite %d cost %.6f\n", group_lanes, inference,
+              i2c_kernel_family(&p, I2C_SWEEP_FORWARD), i2c_kernel_family(&p, I2C_SWEEP_BACKWARD), rc, status[0], status[1], status[2],
+              (int)finite, stats[2 * B]);
   return (rc == 0 && finite && status[0] == 0) ? 0 : 1;
+}
+
+int main() {
+  int bad = run(16, I2C_INF_CUBATURE);
+  bad += run(64, I2C_INF_CUBATURE);
+  bad += run(64, I2C_INF_LINEARIZE);
+  return bad;
 }
