@@ -185,7 +185,8 @@ def test_failure_isolation_other_inference_gpu(golden):
     _check_failure_isolation(None, "cuda", golden)
 
 
-# ---- the same edge cases on the GROUP kernels (G lanes of a wavefront per trajectory) --------------------------------------
+# ---- the same edge cases on the multi-lane kernels: the 12-state quadrotor's WAVE kernels (its default: lanes = 0 / 64, one
+# wavefront per trajectory) and GROUP kernels (lanes = 16) --------------------------------------------------------------------
 def _short_quad12(T):
     import json
 
@@ -210,11 +211,12 @@ def _check_group(lib, device, case, B, **kw):
     assert eng.failures() == []
 
 
+@pytest.mark.parametrize("lanes", [0, 16])
 @pytest.mark.parametrize("T,B", [(1, 1), (2, 3), (3, 5)])
-def test_group_kernels_short_horizons_cpu(T, B):
+def test_group_kernels_short_horizons_cpu(T, B, lanes):
     """Horizons of 1-3 cells (first cell = last cell, terminal update on the first cell) and batches that leave most of a
-    wavefront's groups empty, 12-state quadrotor (16 lanes per trajectory)."""
-    _check_group(hostsim.load(), "cpu", _short_quad12(T), B)
+    wavefront's groups / a workgroup's waves empty, 12-state quadrotor: wave kernels and group kernels."""
+    _check_group(hostsim.load(), "cpu", _short_quad12(T), B, group_lanes=lanes)
 
 
 def test_group_kernels_short_horizon_pendulum_cpu():
@@ -222,9 +224,10 @@ def test_group_kernels_short_horizon_pendulum_cpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("T,B", [(1, 1), (2, 3), (3, 5), (4, 67)])
-def test_group_kernels_short_horizons_gpu(T, B):
-    _check_group(None, "cuda", _short_quad12(T), B)
+@pytest.mark.parametrize("lanes", [0, 16])
+@pytest.mark.parametrize("T,B", [(1, 1), (2, 3), (3, 5), (4, 67), (2, 131)])
+def test_group_kernels_short_horizons_gpu(T, B, lanes):
+    _check_group(None, "cuda", _short_quad12(T), B, group_lanes=lanes)
 
 
 @pytest.mark.gpu
@@ -232,14 +235,14 @@ def test_group_kernels_short_horizon_pendulum_gpu():
     _check_group(None, "cuda", _short_case(2), 1000, group_lanes=True)
 
 
-def _group_failure_isolation(lib, device):
+def _group_failure_isolation(lib, device, lanes=0):
     """A covariance that is not positive definite in ONE trajectory: its status word names the first failing stage and
     cell, its values go NaN, and the other trajectories of the same wavefront are bit-for-bit what they are without it."""
     g = _short_quad12(6)
     B = 6
     x0, mu_u = parity.batched_inputs(g, B)
-    clean = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u)
-    bad = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u)
+    clean = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u, group_lanes=lanes)
+    bad = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u, group_lanes=lanes)
     bad.sig_x0[0, 2] = -1.0  # sig_x0[0][0] of trajectory 2 (packed index 0): negative variance
     for e in (clean, bad):
         for _ in range(2):
@@ -254,10 +257,12 @@ def _group_failure_isolation(lib, device):
         bad.raise_on_failure()
 
 
-def test_group_kernels_failure_isolation_cpu():
-    _group_failure_isolation(hostsim.load(), "cpu")
+@pytest.mark.parametrize("lanes", [0, 16])
+def test_group_kernels_failure_isolation_cpu(lanes):
+    _group_failure_isolation(hostsim.load(), "cpu", lanes)
 
 
 @pytest.mark.gpu
-def test_group_kernels_failure_isolation_gpu():
-    _group_failure_isolation(None, "cuda")
+@pytest.mark.parametrize("lanes", [0, 16])
+def test_group_kernels_failure_isolation_gpu(lanes):
+    _group_failure_isolation(None, "cuda", lanes)

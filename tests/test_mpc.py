@@ -15,22 +15,22 @@ from i2c.i2c import I2cGraph
 from i2c.policy.mpc import PartiallyObservedMpcPolicy
 
 
-def _policy(g, lib, device, batch=None):
+def _policy(g, lib, device, batch=None, group_lanes=0):
     meta = g.meta
     model = parity.product_model(g)
     model.sig_zeta = g["sig_zeta"]
     i2c = I2cGraph(model, meta["T"], g.get("Q"), g["R"], g.get("Qf"), meta["alpha"], meta["tol"], g["mu_u"], g["sig_u"],
-                   None, None, CubatureQuadrature(*meta["quad"]), lib=lib, device=device, batch=batch)
+                   None, None, CubatureQuadrature(*meta["quad"]), lib=lib, device=device, batch=batch, group_lanes=group_lanes)
     i2c._propagate = True
     pol = PartiallyObservedMpcPolicy(i2c, meta["n_iter"], g["sig_u"], np.copy(g["z_traj"]))
     pol.set_control(feedforward=meta["feedforward"])
     return model, i2c, pol
 
 
-def _replay(name, lib, device, tol):
+def _replay(name, lib, device, tol, group_lanes=0):
     g = load_case(name)
     meta = g.meta
-    model, i2c, pol = _policy(g, lib, device)
+    model, i2c, pol = _policy(g, lib, device, group_lanes=group_lanes)
     i2c.calibrate_alpha()
     assert_close(i2c.alpha, g["alpha_cal1"], tol, "first alpha calibration")
     pol.optimize(meta["warm"], model.x0, model.sig_x0)
@@ -60,6 +60,18 @@ def test_mpc_replay_cpu(name):
 @pytest.mark.parametrize("name", ["mpc_pendulum_ff", "mpc_pendulum_fb", "mpc_quadrotor_fb", "mpc_quad12_fb"])
 def test_mpc_replay_gpu(name):
     _replay(name, None, "cuda", 1e-6)
+
+
+# mpc_quad12_fb above runs the 12-state quadrotor's default, the wave kernels; the same replay on its group kernels
+def test_mpc_replay_quad12_group_kernels_cpu():
+    pol = _replay("mpc_quad12_fb", hostsim.load(), "cpu", 1e-7, group_lanes=16)
+    assert pol.engine.forward_family == "group"
+
+
+@pytest.mark.gpu
+def test_mpc_replay_quad12_group_kernels_gpu():
+    pol = _replay("mpc_quad12_fb", None, "cuda", 1e-6, group_lanes=16)
+    assert pol.engine.forward_family == "group"
 
 
 def _ckf_oracle(model, rule_w, mu, cov, u, y, sig_zeta):
