@@ -51,7 +51,7 @@ enum {
   I2C_MODEL_LINEAR = 4,           /* LinearKnown           env_def.py:139-191, model.py:226-246       */
   I2C_MODEL_LINEAR_MINENERGY = 5, /* LinearKnownMinimumEnergy env_def.py:194-230                      */
   I2C_MODEL_QUADROTOR = 6,        /* build-defined planar quadrotor (Box2D physics is not reproducible) */
-  I2C_MODEL_QUADROTOR12 = 7,      /* build-defined 12-state / 4-rotor quadrotor (BASELINE config 4: nx = 12); group kernels only */
+  I2C_MODEL_QUADROTOR12 = 7,      /* build-defined 12-state / 4-rotor quadrotor (BASELINE config 4: nx = 12); wave + group kernels */
   I2C_NUM_MODELS = 8
 };
 
@@ -127,7 +127,7 @@ typedef struct I2cDims {
   int32_t ny;              /* dim_y of sys.measure (state estimator of the MPC loop)         */
   int32_t group_lanes;     /* G of the model's group kernels (G lanes of a wavefront per trajectory, blocks row-distributed
                               over the lanes and exchanged through LDS); 0: none compiled                                  */
-  int32_t group_only;      /* 1: only the group kernels exist for this model (nx + nu > 8 does not fit one lane)           */
+  int32_t group_only;      /* 1: no one-lane-per-trajectory kernels exist for this model (nx + nu > 8 does not fit one lane)  */
   int32_t wave;            /* 1: the one-wavefront-per-trajectory kernels (I2C_FAMILY_WAVE) exist for this model;
                               I2cProblem.group_lanes = 64 asks for them                                                    */
 } I2cDims;

@@ -433,12 +433,14 @@ template <class M> static size_t workspace_elems(int B, int T) {
 // ---- per-(model, dtype) entry points ------------------------------------------------------
 // Which kernels serve a call:
 //   M::GROUP      lanes per trajectory of the model's group kernels (0: none compiled); fp64 only
+//   M::WAVE       the wave kernels (i2c_wave.hpp: one wavefront per trajectory) exist for this model: its default for the forward and
+//                 backward sweeps wherever they apply (Impl::wave_supported); I2cProblem.group_lanes = 64 asks for them
 //   M::GROUP_ONLY the one-lane-per-trajectory kernels are NOT compiled for this model (d = nx + nu > 8 does not fit one
-//                 lane's registers): every call runs the group kernels
-//   I2cProblem.group_lanes   0: the model's default (group kernels iff GROUP_ONLY); G = M::GROUP: ask for the group
-//                 kernels; anything else: I2C_ENOTSUP
+//                 lane's registers): every call runs the wave or the group kernels
+//   I2cProblem.group_lanes   0: the model's default (Impl::family); G = M::GROUP: ask for the group kernels; 64: the wave kernels;
+//                 -1: one lane per trajectory; anything else: I2C_ENOTSUP
 //   S             storage type of the per-cell buffers: R, or float with R = double (I2C_F64_F32S: the cubature EM path of the
-//                 one-lane kernels only -- forward, backward, M-step, i2c_learn; everything else is I2C_ENOTSUP)
+//                 one-lane and the wave kernels -- forward, backward, M-step, i2c_learn; everything else is I2C_ENOTSUP)
 template <class M, typename R, typename S = R> struct Impl {
   using C = Consts<M, R>;
   static constexpr bool MIXED = sizeof(S) != sizeof(R);

@@ -347,7 +347,8 @@ struct Quadrotor {
 // kq (f1 - f2 + f3 - f4). Integrator as the planar model (Box2D's order for a free body): velocities first
 // (semi-implicit Euler, angular damping as 1 / (1 + dt c)), then positions and Euler angles with the NEW velocities.
 // observe = identity on (x, u), observe_terminal = identity on x, measure = [p | angles | body rates].
-// params = {mass, Ixx, Iyy, Izz, u_max}. d = 16: only the group kernels are compiled (GROUP_ONLY).
+// params = {mass, Ixx, Iyy, Izz, u_max}. d = 16: no one-lane kernels (GROUP_ONLY); the native tile of the fp64 matrix instruction,
+// so the forward / backward sweeps have the wave form (WAVE, i2c_wave.hpp) next to the group form.
 struct Quadrotor12 {
   static constexpr int ID = 7, NX = 12, NU = 4, NZ = 16, NZT = 12, NP = 5, NA = 3;
   static constexpr int GROUP = 16;

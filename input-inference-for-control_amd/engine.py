@@ -5,8 +5,9 @@ independent trajectories of one model and horizon, optimised by the same EM iter
 (learn_msgs, i2c.py:1238-1245). The EM loop lives here in Python; every sweep is one call into
 ``libi2c_hip.so``. PyTorch is plumbing only: it owns the HBM buffers and the stream.
 
-Device layout (see include/i2c_hip.h): every per-cell buffer is ``[T][E][B]`` with the
-trajectory index innermost, symmetric matrices packed (lower, row-major).
+Device layout (see include/i2c_hip.h): every per-cell buffer is logically ``[T][E][B]``, symmetric matrices packed
+(lower, row-major). Physically the trajectory index is innermost -- except for the models with wave kernels, whose
+posterior / prior and forward-message buffers are trajectory-major (``[T][B][E]``) behind permuted views.
 """
 import ctypes as C
 import os
@@ -105,7 +106,7 @@ class BatchedI2c:
             raise ValueError(f"group_lanes={self.group_lanes}: this model's group kernels use {dims.group_lanes} lanes"
                              + (" and it has no one-lane kernels" if dims.group_only else " (or -1: one lane per trajectory)")
                              + (" (or 64: one wavefront per trajectory)" if dims.wave else ""))
-        self.uses_group_kernels = bool(self.group_lanes > 0 or dims.group_only)
+        self.uses_group_kernels = bool(self.group_lanes > 0 or dims.group_only)  # a multi-lane family (group or wave) serves the sweeps
         if self.mixed and inference != "cubature":
             raise ValueError("fp32 storage (storage_dtype) is available for the cubature path only")
         if self.mixed and self.uses_group_kernels and not (dims.wave and self.group_lanes in (0, 64)):

@@ -409,7 +409,8 @@ class PlanarQuadrotor(KnownModel):
 
 class Quadrotor12(KnownModel):
     """Build-defined 12-state, 4-rotor quadrotor (BASELINE config 4: nx = 12) with the plugin interface of the reference's
-    QuadrotorDef (scripts/mpc_state_est/mpc_quad.py:219-383); see csrc/i2c_models.hpp. Runs on the group kernels only."""
+    QuadrotorDef (scripts/mpc_state_est/mpc_quad.py:219-383); see csrc/i2c_models.hpp. d = 16: no one-lane kernels; the sweeps run on the wave kernels (one wavefront per
+    trajectory, csrc/i2c_wave.hpp), propagation and the filter on the group kernels."""
 
     name = "3D Quadrotor"
     model_name = "Quadrotor12"
