@@ -24,7 +24,9 @@ def per_kernel(d):
             rest = r["Kernel_Name"].split("i2c::")[1]
             name = rest.split("<")[0]
             if name in ("k_group", "k_wave"):  # one kernel template per family: the sweep (KIND) is its first argument
-                name += "_" + {"0": "forward", "1": "backward", "2": "propagate", "3": "ckf"}.get(rest.split("<")[1].split(",")[0].strip(), "x")
+                kinds = {"0": "forward", "1": "backward", "2": "propagate", "3": "ckf"} if name == "k_group" else \
+                    {"0": "forward", "1": "backward", "2": "scan", "3": "cell", "4": "forward"}  # 4: forward, pivot blocks through LDS
+                name += "_" + kinds.get(rest.split("<")[1].split(",")[0].strip(), "x")
             acc[name].append(float(r["Counter_Value"]))
     return {k: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in acc.items()}  # steady-state half
 
