@@ -314,6 +314,34 @@ template <int N, typename R> I2C_FN bool chol(R* a, R* rinv) {
   return ok;
 }
 
+// The same for a symmetric NON-SINGULAR matrix that need not be positive definite: a = L Sigma L^T with Sigma = diag(sgn),
+// sgn[j] = +-1 the sign of pivot j (unpivoted, so a vanishing leading minor fails like a singular matrix does). fsub / bsub
+// apply to the L it returns. Returns false on a zero or NaN pivot.
+template <int N, typename R> I2C_FN bool chol_signed(R* a, R* rinv, R* sgn) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    R s = a[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= sgn[k] * a[tri(j, k)] * a[tri(j, k)];
+    const R g = s < R(0) ? R(-1) : R(1);
+    sgn[j] = g;
+    s *= g;
+    if (j == N - 1) ok = s > R(0);
+    const R r = r_rsqrt(s);
+    rinv[j] = r;
+    a[tri(j, j)] = s * r;
+#pragma unroll
+    for (int i = j + 1; i < N; ++i) {
+      R v = a[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= sgn[k] * a[tri(i, k)] * a[tri(j, k)];
+      a[tri(i, j)] = v * r * g;
+    }
+  }
+  return ok;
+}
+
 // Solve L y = b in place (forward substitution); `stride` lets b be a row of a row-major matrix.
 template <int N, typename R> I2C_FN void fsub(const R* L, const R* rinv, R* b) {
 #pragma unroll

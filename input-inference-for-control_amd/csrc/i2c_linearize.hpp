@@ -254,6 +254,47 @@ I2C_HD inline void backward_lin_body(const Consts<M, R>& c, const CellArgs<R>& a
 #pragma unroll
   for (int i = 0; i < sym(NT); ++i) xiT[i] = R(0);
   if (c.has_x_terminal) {
+    if (NZT > 0 && c.has_Qf) {
+      // the back-calculated sig_xi_terminal (the Lagrange multiplier of the pinned covariance, i2c.py:455-462): with
+      // Szx = E S3f and MP = Szx Szx^T,  sig_z = MP (Szx (S3f - S_T) Szx^T)^-1 MP  and  sig_xi_terminal = sig_z - E S3f E^T
+      // (the middle factor is symmetric but in general indefinite: chol_signed)
+      R mzt[NT], Szt[sym(NT)], Sxzt[NX * NT], E[NT * NX], W[NX * NT], mid[sym(NT)], rinv[NT], sgn[NT], Y[NT * NT];
+      lin_transform<M, FN_OBSERVE_TERMINAL, NX, NT, R>(c.params, m3m, S3m, mzt, Szt, Sxzt, E);
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+          R v = R(0);
+#pragma unroll
+          for (int l = 0; l < NX; ++l) v += (S3m[tri_any(i, l)] - c.sig_x_term[tri_any(i, l)]) * Sxzt[l * NT + k];
+          W[i * NT + k] = v;
+        }
+#pragma unroll
+      for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int l = 0; l < NT; ++l) {
+          R vm = R(0), vp = R(0);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+            vm += Sxzt[i * NT + k] * W[i * NT + l];
+            vp += Sxzt[i * NT + k] * Sxzt[i * NT + l];
+          }
+          if (l <= k) mid[tri(k, l)] = vm;
+          Y[l * NT + k] = vp;  // row l = column l of the symmetric MP
+        }
+      if (!chol_signed<NT>(mid, rinv, sgn)) set_status(a.status, b, 6, T - 1);
+#pragma unroll
+      for (int l = 0; l < NT; ++l) fsub<NT>(mid, rinv, &Y[l * NT]);  // row l <- L^-1 MP[:, l]
+#pragma unroll
+      for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int l = 0; l <= k; ++l) {
+          R v = R(0);
+#pragma unroll
+          for (int r = 0; r < NT; ++r) v += sgn[r] * Y[k * NT + r] * Y[l * NT + r];
+          xiT[tri(k, l)] = v - Szt[tri(k, l)];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NX; ++i) m3m[i] = c.mu_x_term[i];
 #pragma unroll

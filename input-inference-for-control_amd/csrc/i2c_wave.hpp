@@ -235,24 +235,49 @@ template <int NV, typename R, class P> I2C_FN void w_ldconst(const Wave<R>& w, c
 // registers (four dependent rsq chains: the serial core of the kernel); lane (q, i) then holds entry (i mod 4, q) of that inverse
 // as the A operand of the matrix instruction that scales block row kb of s and of every right-hand side, and the scaled block
 // row of s (= rows of L^T) is A and B operand of the rank-4 update of everything below.
-template <int KB, int NB, int NRHS, bool PL, typename R>
-I2C_FN void w_elim_step(const Wave<R>& w, R* s, R* r1, R* r2, R* lt, const R* mq, R* last) {
+// SIGNED: the matrix is symmetric and non-singular but not necessarily positive definite; the factorisation is L Sigma L^T with
+// Sigma = diag(+-1) (a Cholesky factorisation that carries the sign of each pivot), sgn receives Sigma in accumulator layout
+// (register v, lane (q, .): the sign of row 4 v + q) and the right-hand sides return L^-1 r as before, so that
+// r^T s^-1 r = (L^-1 r)^T Sigma (L^-1 r). Used once per sweep (the Linearize covariance-control multiplier); lt is not produced.
+template <int KB, int NB, int NRHS, bool PL, bool SIGNED = false, typename R>
+I2C_FN void w_elim_step(const Wave<R>& w, R* s, R* r1, R* r2, R* lt, const R* mq, R* last, R* sgn = nullptr) {
   const int a = w.j & 3, cq = w.q;
   const bool inblk = (w.j >> 2) == KB;
   R d[10];
   w_pivot_block<KB, PL>(w, s[KB], d);
   const R d00 = d[0], d10 = d[1], d11 = d[2], d20 = d[3], d21 = d[4], d22 = d[5], d30 = d[6], d31 = d[7], d32 = d[8], d33 = d[9];
   // 4 x 4 Cholesky (l) ...
-  const R i0 = r_rsqrt(d00);
-  const R l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
-  const R p1 = d11 - l10 * l10;
-  const R i1 = r_rsqrt(p1);
-  const R l21 = (d21 - l20 * l10) * i1, l31 = (d31 - l30 * l10) * i1;
-  const R p2 = d22 - l20 * l20 - l21 * l21;
-  const R i2 = r_rsqrt(p2);
-  const R l32 = (d32 - l30 * l20 - l31 * l21) * i2;
-  const R p3 = d33 - l30 * l30 - l31 * l31 - l32 * l32;
-  const R i3 = r_rsqrt(p3);
+  R i0, i1, i2, i3, l10, l20, l30, l21, l31, l32, p3, sq = R(1);
+  if constexpr (!SIGNED) {
+    i0 = r_rsqrt(d00);
+    l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
+    const R p1 = d11 - l10 * l10;
+    i1 = r_rsqrt(p1);
+    l21 = (d21 - l20 * l10) * i1, l31 = (d31 - l30 * l10) * i1;
+    const R p2 = d22 - l20 * l20 - l21 * l21;
+    i2 = r_rsqrt(p2);
+    l32 = (d32 - l30 * l20 - l31 * l21) * i2;
+    p3 = d33 - l30 * l30 - l31 * l31 - l32 * l32;
+    i3 = r_rsqrt(p3);
+  } else {
+    const R g0 = d00 < R(0) ? R(-1) : R(1);
+    i0 = r_rsqrt(g0 * d00);
+    l10 = d10 * i0 * g0, l20 = d20 * i0 * g0, l30 = d30 * i0 * g0;
+    const R p1 = d11 - g0 * l10 * l10;
+    const R g1 = p1 < R(0) ? R(-1) : R(1);
+    i1 = r_rsqrt(g1 * p1);
+    l21 = (d21 - g0 * l20 * l10) * i1 * g1, l31 = (d31 - g0 * l30 * l10) * i1 * g1;
+    const R p2 = d22 - g0 * l20 * l20 - g1 * l21 * l21;
+    const R g2 = p2 < R(0) ? R(-1) : R(1);
+    i2 = r_rsqrt(g2 * p2);
+    l32 = (d32 - g0 * l30 * l20 - g1 * l31 * l21) * i2 * g2;
+    p3 = d33 - g0 * l30 * l30 - g1 * l31 * l31 - g2 * l32 * l32;
+    const R g3 = p3 < R(0) ? R(-1) : R(1);
+    i3 = r_rsqrt(g3 * p3);
+    sq = (mq[0] * g0 + mq[1] * g1) + (mq[2] * g2 + mq[3] * g3);
+    sgn[KB] = sq;
+    p3 = p3 * p3;  // the caller tests `> 0`: a zero (or NaN) pivot fails, a negative one does not
+  }
   if (KB == NB - 1) *last = p3;  // a failed pivot poisons everything after it (see chol(), i2c_linalg.hpp)
   // ... and this lane's entry of its inverse: row a of L^-1 solves y^T L = e_a^T (back substitution; y_c = 0 for c > a
   // falls out of the one-hot right-hand side, which is also zero outside block row KB), entry cq picked by a one-hot
@@ -283,13 +308,25 @@ I2C_FN void w_elim_step(const Wave<R>& w, R* s, R* r1, R* r2, R* lt, const R* mq
   }
   // ... and eliminate it from everything below
   if (KB < NB - 1) {
-    w_mfma(w, -ltk, ltk, s);
-    if (NRHS >= 1) w_mfma(w, -ltk, x1, r1);
-    if (NRHS >= 2) w_mfma(w, -ltk, x2, r2);
+    const R nl = SIGNED ? -ltk * sq : -ltk;
+    w_mfma(w, nl, ltk, s);
+    if (NRHS >= 1) w_mfma(w, nl, x1, r1);
+    if (NRHS >= 2) w_mfma(w, nl, x2, r2);
   }
   if (NRHS >= 1) r1[KB] = x1;
   if (NRHS >= 2) r2[KB] = x2;
-  if constexpr (KB + 1 < NB) w_elim_step<KB + 1, NB, NRHS, PL>(w, s, r1, r2, lt, mq, last);
+  if constexpr (KB + 1 < NB) w_elim_step<KB + 1, NB, NRHS, PL, SIGNED>(w, s, r1, r2, lt, mq, last, sgn);
+}
+// r <- L^-1 r for a symmetric non-singular s = L Sigma L^T (see w_elim_step); sgn <- Sigma, rows >= 4 NB get +1
+template <int NB, bool PL = false, typename R> I2C_FN bool w_elim_signed(const Wave<R>& w, R* s, R* r, R* sgn) {
+  R last = R(0), mq[4], lt[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    mq[k] = w.q == k ? R(1) : R(0);
+    sgn[k] = R(1);
+  }
+  w_elim_step<0, NB, 1, PL, true>(w, s, r, (R*)nullptr, lt, mq, &last, sgn);
+  return last > R(0);
 }
 template <int NB, int NRHS, bool PL = false, typename R> I2C_FN bool w_elim(const Wave<R>& w, R* s, R* r1, R* r2, R* lt) {
   R last = R(0), mq[4];
@@ -735,8 +772,28 @@ I2C_FN void w_end_of_chain(const Consts<M, R>& c, const KC& kc, const CellArgs<R
   R xiT[4] = {R(0), R(0), R(0), R(0)};  // Linearize: the sig_xi_terminal that stays in sig_z3_m (i2c.py:460, 488, 497)
   if (LIN) {
     if (c.has_x_terminal) {
+      R sxT[4];
+      w_ldconst<NBX>(w, kc.sxT, sxT);
+      if (NZT > 0 && c.has_Qf) {
+        // the back-calculated sig_xi_terminal (the Lagrange multiplier of the pinned covariance, i2c.py:455-462); with the
+        // identity observation sig_z = S3f (S3f - S_T)^-1 S3f and sig_xi_terminal = sig_z - S3f
+        // (S3f - S_T is symmetric but in general indefinite: the target may be tighter in some directions and looser in others)
+        R ds[4], y[4], ys[4], sg[4], g[4] = {R(0), R(0), R(0), R(0)};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          ds[v] = (v < NBX && jx) ? s3m[v] - sxT[v] : R(0);
+          y[v] = s3m[v];
+        }
+        if (!w_elim_signed<NBX, true>(w, ds, y, sg) && w.l == 0) set_status(a.status, b, 6, T - 1);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) ys[v] = sg[v] * y[v];
+        w_tn<NBX>(w, ys, y, g);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) xiT[v] = g[v] - s3m[v];
+      }
       m3m = jx ? kc.mxT[jxc] : R(0);
-      w_ldconst<NBX>(w, kc.sxT, s3m);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) s3m[v] = sxT[v];
     } else if (NZT > 0 && c.has_Qf) {
       const R alpha = a.alpha[b];
       if (!w_kalman<NBX, true>(w, alpha, kc.xiT, kc.qf, c.qf_diag != 0, kc.zgT[j], &m3m, s3m) && w.l == 0) set_status(a.status, b, 6, T - 1);

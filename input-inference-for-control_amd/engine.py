@@ -180,7 +180,8 @@ class BatchedI2c:
         self.sig_x_terminal = None if sig_x_terminal is None else np.asarray(sig_x_terminal, np.float64)
         self.has_x_terminal = self.sig_x_terminal is not None
         if self.has_x_terminal and self.mu_x_terminal is None:
-            raise TypeError("sig_x_terminal given without mu_x_terminal (the reference crashes at i2c.py:558)")
+            raise TypeError("sig_x_terminal given without mu_x_terminal: the reference's cubature rule crashes on it (i2c.py:558) and the "
+                            "mean its Linearize rule back-calculates (i2c.py:464-470) is not implemented here")
         self.dtemp = float(dtemp)
 
         dev, dt, st = self.device, self.dtype, self.store_dtype

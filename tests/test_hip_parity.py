@@ -276,3 +276,10 @@ def test_hip_post_layout_is_transparent(lib, monkeypatch):
     from test_kernels_hostsim import _post_layout_is_transparent
 
     _post_layout_is_transparent(lib, "cuda", monkeypatch)
+
+
+@pytest.mark.parametrize("name,T,mu_T,sig_T,family", __import__("test_kernels_hostsim").TERMINAL_PRIOR)
+def test_hip_terminal_prior_with_terminal_cost_vs_oracle(lib, name, T, mu_T, sig_T, family):
+    from test_kernels_hostsim import _terminal_prior_with_terminal_cost
+
+    _terminal_prior_with_terminal_cost(lib, "cuda", name, T, mu_T, sig_T, family, 1e-6)

@@ -2,6 +2,7 @@
 and driven through the same C ABI + engine as on the GPU, against the golden vectors of the
 real reference and against the batched CPU oracle. The GPU twins of these tests are in
 tests/test_hip_parity.py."""
+import numpy as np
 import pytest
 
 import hostsim
@@ -269,3 +270,57 @@ def _post_layout_is_transparent(lib, device, monkeypatch):
 
 def test_hostsim_post_layout_is_transparent(lib, monkeypatch):
     _post_layout_is_transparent(lib, "cpu", monkeypatch)
+
+
+def _terminal_prior_with_terminal_cost(lib, device, name, T, mu_T, sig_T, family, tol):
+    """Covariance control (a terminal state prior, i2c.py:548-559 / 453-472) TOGETHER with a terminal cost, against the batched
+    oracle. Under the cubature rule the wave form does not cover it and the group kernels take over (tempered product at the end
+    of the chain); under Linearize() the smoothed terminal state is pinned to the prior and sig_z3_m carries the back-calculated
+    sig_xi_terminal (i2c.py:455-462, 499-501), which reaches alpha through the terminal statistic (:989-992)."""
+    import json
+
+    import numpy as np
+    from golden_util import Case, assert_close, load_case, oracle_from_case
+
+    g = load_case(name)
+    assert "Qf" in g
+    meta = dict(g.meta, T=T)
+    case = Case({**g, "meta": np.array(json.dumps(meta)), "mu_u": g["mu_u"][:T], "mu_x_term": np.asarray(mu_T, float),
+                 "sig_x_term": np.asarray(sig_T, float)})
+    x0, mu_u = parity.batched_inputs(case, 3)
+    eng = parity.engine_from_case(case, lib, device, x0=x0, mu_u=mu_u)
+    assert eng.forward_family == family
+    o = oracle_from_case(Case({**case, "mu_u": mu_u}), x0=x0)
+    for it in range(2):  # (the back-calculation amplifies rounding-level differences of sig_x3_f by cond(S3f - S_T)^2: two sweeps)
+        eng.learn_msgs()
+        o.learn_msgs()
+        if meta.get("inference") == "linearize" and eng.nzt == eng.nx:
+            # the kernel's multiplier from the kernel's OWN filtered terminal covariance (identity observation, i2c.py:455-462)
+            S3f = parity.np_(eng.forward_messages()["sig_x3_f"])[:, T - 1]
+            dS = S3f - case["sig_x_term"]
+            if it == 1:  # neither tighter nor looser than the filtered covariance: the multiplier is indefinite
+                assert np.linalg.eigvalsh(dS[0]).min() < 0 < np.linalg.eigvalsh(dS[0]).max()
+            want = case["sig_x_term"] + S3f @ np.linalg.inv(dS) @ S3f - S3f
+            assert_close(parity.np_(eng.terminal_observed_marginal()[1]), want, 1e-9 * np.linalg.cond(dS).max() ** 2,
+                         f"{name} terminal prior it{it}: sig_z3_m from the kernel's own sig_x3_f")
+        mu, sig = eng.marginal_state_action()
+        assert_close(parity.np_(mu), o.mu_xu0_m, tol, f"{name} terminal prior it{it}: mu")
+        assert_close(parity.np_(sig), o.sig_xu0_m, tol, f"{name} terminal prior it{it}: sig")
+        mzt, szt = eng.terminal_observed_marginal()
+        assert_close(parity.np_(mzt), o.mu_z3_m, tol, f"{name} terminal prior it{it}: mu_z3_m")
+        assert_close(parity.np_(szt), o.sig_z3_m, tol * 10, f"{name} terminal prior it{it}: sig_z3_m")
+        assert_close(parity.np_(eng.alpha), o.alpha, tol * 10, f"{name} terminal prior it{it}: alpha")
+    assert eng.failures() == []
+
+
+Q12_TERM = ([0.3, -0.2, 0.5] + [0.0] * 9, np.diag([1e-2] * 3 + [1e-1] * 9))
+TERMINAL_PRIOR = [
+    ("em_quad12_T20", 8, *Q12_TERM, "group"),
+    ("lin_quad12_T20", 8, *Q12_TERM, "wave"),
+    ("lin_linear_T60", 30, [1.0, 0.5], [[1e-3, 2e-4], [2e-4, 50.0]], "lane"),
+]
+
+
+@pytest.mark.parametrize("name,T,mu_T,sig_T,family", TERMINAL_PRIOR)
+def test_hostsim_terminal_prior_with_terminal_cost_vs_oracle(lib, name, T, mu_T, sig_T, family):
+    _terminal_prior_with_terminal_cost(lib, "cpu", name, T, mu_T, sig_T, family, 1e-7)
