@@ -1,0 +1,95 @@
+"""Feature matrix: every model / inference rule crossed with the optional parts of the problem (terminal cost on / off,
+covariance control, propagation, expert controller on / off, an alpha-update tolerance, general cubature weights), the batched
+engine against the batched CPU oracle on identical inputs. Each golden case pins ONE combination against the real reference;
+this file checks that the kernels and the (pinned) oracle agree on the combinations no shipped script exercises -- the round-3
+find: Linearize() + covariance control + a terminal cost dropped the back-calculated sig_xi_terminal (i2c.py:455-462).
+
+Left out because the REFERENCE fails on them: Linearize() without a terminal cost on a model whose terminal observation is not
+the state (i2c.py:497 adds a dim_x identity to a dim_zt matrix), and Linearize() covariance control when dim_zt > dim_x (the
+back-calculation inverts a rank-deficient matrix, i2c.py:459)."""
+import json
+
+import numpy as np
+import pytest
+
+import hostsim
+import parity
+from golden_util import Case, load_case, oracle_from_case, rel_err
+
+BASES = [("em_pendulum_T200", 10), ("lin_pendulum_T100", 10), ("em_linear_T60", 10), ("lin_linear_T60", 10), ("gh4_linear_T30", 8),
+         ("em_cartpole_T100", 8), ("lin_cartpole_T100", 8), ("em_dcp_T60", 6), ("lin_dcp_T80", 6), ("em_quadrotor_T20", 6),
+         ("em_quad12_T20", 5), ("lin_quad12_T20", 5)]
+VARIANTS = ["no_terminal_cost", "terminal_prior", "terminal_prior_only", "propagate", "expert", "no_expert", "alpha_tol", "general_weights"]
+IDENTITY_TERMINAL = {"LinearKnown", "Quadrotor12"}  # terminal observation = the state
+
+
+def make_case(name, T, variant):
+    g = load_case(name)
+    meta = dict(g.meta, T=T)
+    lin = meta.get("inference") == "linearize"
+    d = {k: g[k] for k in g}
+    nx = g["x0"].shape[0]
+    prior = {"mu_x_term": 0.1 * np.ones(nx), "sig_x_term": 1e-2 * np.eye(nx) + 1e-3 * np.ones((nx, nx))}
+    if variant == "no_terminal_cost":
+        if lin and meta["model"] not in IDENTITY_TERMINAL:
+            return None
+        d.pop("Qf", None)
+    elif variant == "terminal_prior":
+        if lin and meta["model"] not in IDENTITY_TERMINAL:
+            return None
+        d.update(prior)
+    elif variant == "terminal_prior_only":
+        if lin and meta["model"] not in IDENTITY_TERMINAL:
+            return None
+        d.pop("Qf", None)
+        d.update(prior)
+    elif variant == "propagate":
+        if name == "lin_quad12_T20":
+            return None  # no propagation kernel for Linearize() at d = 16 (I2C_ENOTSUP)
+        meta["propagate"] = True
+    elif variant == "expert":
+        meta["use_expert_controller"] = True
+    elif variant == "no_expert":
+        meta["use_expert_controller"] = False
+    elif variant == "alpha_tol":
+        meta["tol"] = 1.0
+    elif variant == "general_weights":
+        if meta.get("inference", "cubature") != "cubature":
+            return None
+        meta["quad"] = [1.2, 0.44, 0.5]
+    d["meta"] = np.array(json.dumps(meta))
+    d["mu_u"] = g["mu_u"][:T]
+    return Case(d)
+
+
+def run_matrix_entry(lib, device, name, T, variant, tol):
+    case = make_case(name, T, variant)
+    if case is None:
+        pytest.skip("the reference fails on this combination (module docstring)")
+    x0, mu_u = parity.batched_inputs(case, 2)
+    eng = parity.engine_from_case(case, lib, device, x0=x0, mu_u=mu_u)
+    o = oracle_from_case(Case({**case, "mu_u": mu_u}), x0=x0)
+    if case.meta.get("propagate"):
+        eng.propagate()
+        o.propagate()
+    for it in range(2):
+        eng.learn_msgs()
+        o.learn_msgs()
+        mu, sig = eng.marginal_state_action()
+        K, k, sigK = eng.local_linear_policy()
+        for what, a, b in (("mu", mu, o.mu_xu0_m), ("sig", sig, o.sig_xu0_m), ("K", K, o.K), ("k", k, o.k), ("sigK", sigK, o.sigK),
+                           ("alpha", eng.alpha, o.alpha)):
+            e = rel_err(parity.np_(a), b)
+            assert np.isfinite(e) and e <= tol, f"{name} / {variant} it{it} {what}: {e:.2e} > {tol:.0e}"
+    assert eng.failures() == []
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return hostsim.load()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("name,T", BASES)
+def test_hostsim_feature_matrix_vs_oracle(lib, name, T, variant):
+    run_matrix_entry(lib, "cpu", name, T, variant, 1e-7)

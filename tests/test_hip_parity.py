@@ -283,3 +283,11 @@ def test_hip_terminal_prior_with_terminal_cost_vs_oracle(lib, name, T, mu_T, sig
     from test_kernels_hostsim import _terminal_prior_with_terminal_cost
 
     _terminal_prior_with_terminal_cost(lib, "cuda", name, T, mu_T, sig_T, family, 1e-6)
+
+
+@pytest.mark.parametrize("variant", __import__("test_feature_matrix").VARIANTS)
+@pytest.mark.parametrize("name,T", __import__("test_feature_matrix").BASES)
+def test_hip_feature_matrix_vs_oracle(lib, name, T, variant):
+    from test_feature_matrix import run_matrix_entry
+
+    run_matrix_entry(lib, "cuda", name, T, variant, 1e-6)

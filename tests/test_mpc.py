@@ -228,7 +228,7 @@ def test_native_mpc_step_gpu(name):
     _native_step_equals_stepwise(name, None, "cuda")
 
 
-def _ring_equals_unrolled(inference, lib, device):
+def _ring_equals_unrolled(inference, lib, device, golden=None, family="lane"):
     """The receding-horizon ring (I2cProblem.t0) for EVERY inference rule: an engine whose horizon has been shifted k times
     must give, bit for bit, the sweeps of an engine holding the same cells in cell order with the ring at its origin.
     (The reference's MpcPolicy accepts any I2cGraph, mpc.py:16-33; round 2 refused t0 != 0 outside the cubature path.)"""
@@ -237,21 +237,32 @@ def _ring_equals_unrolled(inference, lib, device):
     from i2c.policy.mpc import MpcPolicy
 
     rule = {"cubature": CubatureQuadrature(1, 0, 0), "gauss_hermite": GaussHermiteQuadrature(3), "linearize": Linearize()}[inference]
-    model = make_env_model("PendulumKnown")
     T, B = 9, 3
     rng = np.random.default_rng(5)
-    Q, R = np.diag([1.0, 100.0, 1.0]), np.diag([2.0])
-    mu_u = 1e-1 * rng.normal(size=(B, T, 1))
-    x0 = np.array([np.pi, 0.0]) + 1e-2 * rng.normal(size=(B, 2))
-    z_traj = np.tile(np.asarray(model.zg).reshape(1, -1), (T + 6, 1)) + 1e-2 * rng.normal(size=(T + 6, 4))
+    if golden is None:
+        model = make_env_model("PendulumKnown")
+        Q, R, Qf, alpha = np.diag([1.0, 100.0, 1.0]), np.diag([2.0]), np.diag([1.0, 100.0, 1.0]), 100.0
+        x0 = np.array([np.pi, 0.0])
+    else:  # the wider models (group / wave kernel families): cost weights and start state of a golden case
+        from golden_util import load_case
+
+        c = load_case(golden)
+        model = make_env_model(c.meta["model"])
+        Q, R, Qf, alpha, x0 = c["Q"], c["R"], c["Qf"], c.meta["alpha"], c["x0"]
+    nx, nu, nz = model.dim_x, model.dim_u, model.dim_z
+    mu_u = 1e-1 * rng.normal(size=(B, T, nu))
+    x0 = x0 + 1e-2 * rng.normal(size=(B, nx))
+    z_traj = np.tile(np.asarray(model.zg).reshape(1, -1), (T + 6, 1)) + 1e-2 * rng.normal(size=(T + 6, nz))
+    sig_u = 0.5 * np.eye(nu)
 
     def graph():
-        g = I2cGraph(model, T, Q, R, Q, 100.0, 0.5, mu_u, 0.5 * np.eye(1), None, None, rule, lib=lib, device=device, batch=B)
-        g.engine.set_initial_state(x0, np.broadcast_to(1e-4 * np.eye(2), (B, 2, 2)))
+        g = I2cGraph(model, T, Q, R, Qf, alpha, 0.5, mu_u, sig_u, None, None, rule, lib=lib, device=device, batch=B)
+        g.engine.set_initial_state(x0, np.broadcast_to(1e-4 * np.eye(nx), (B, nx, nx)))
         return g
 
     ga, gb = graph(), graph()
-    pa, pb = MpcPolicy(ga, 2, 0.5 * np.eye(1), z_traj), MpcPolicy(gb, 2, 0.5 * np.eye(1), z_traj)
+    assert ga.engine.forward_family == family
+    pa, pb = MpcPolicy(ga, 2, sig_u, z_traj), MpcPolicy(gb, 2, sig_u, z_traj)
     pa.set_control(feedforward=False)
     pb.set_control(feedforward=False)
     ea, eb = ga.engine, gb.engine
@@ -276,7 +287,7 @@ def _ring_equals_unrolled(inference, lib, device):
         assert torch.equal(ea.term_stats, eb.term_stats)
         ea.shift_horizon(pa._next_target(step))
     # reset() returns to the snapshot, wherever the ring was when it was taken (a second policy on a moved ring)
-    pc = MpcPolicy(ga, 2, 0.5 * np.eye(1))
+    pc = MpcPolicy(ga, 2, sig_u)
     before = ea.cells(ea.post).clone()
     t0 = ea.t0
     assert t0 != 0
@@ -294,3 +305,19 @@ def test_mpc_ring_every_inference_cpu(inference):
 @pytest.mark.parametrize("inference", ["cubature", "gauss_hermite", "linearize"])
 def test_mpc_ring_every_inference_gpu(inference):
     _ring_equals_unrolled(inference, None, "cuda")
+
+
+RING_WIDE = [("cubature", "em_dcp_T60", "group"), ("cubature", "em_quad12_T20", "wave"), ("linearize", "lin_quad12_T20", "wave"),
+             ("linearize", "lin_dcp_T80", "lane")]
+
+
+@pytest.mark.parametrize("inference,golden,family", RING_WIDE)
+def test_mpc_ring_wide_models_cpu(inference, golden, family):
+    """The same for the models served by the group and wave kernel families (and their Linearize variants)."""
+    _ring_equals_unrolled(inference, hostsim.load(), "cpu", golden, family)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inference,golden,family", RING_WIDE)
+def test_mpc_ring_wide_models_gpu(inference, golden, family):
+    _ring_equals_unrolled(inference, None, "cuda", golden, family)
