@@ -458,8 +458,9 @@ template <class M, typename R, typename S = R> struct Impl {
   }
   // what the group form does not cover: other inference rules; per-cell blocks beyond the 2 GiB the predicated stores of
   // GIO::st_if park their masked-off lanes behind (the parked offset must stay out of the buffer window)
-  static int group_supported(const I2cProblem* p, const C&) {
-    if (p->inference != I2C_INF_CUBATURE) return I2C_ENOTSUP;
+  // (closed-loop propagation under Linearize() IS the unit cubature rule: i2c.py:109-115)
+  static int group_supported(const I2cProblem* p, const C&, const int sweep) {
+    if (p->inference != I2C_INF_CUBATURE && !(p->inference == I2C_INF_LINEARIZE && sweep == I2C_SWEEP_PROPAGATE)) return I2C_ENOTSUP;
     constexpr long EMAX = C::E_FWD > C::E_POST ? (C::E_FWD > C::E_PROP ? C::E_FWD : C::E_PROP) : (C::E_POST > C::E_PROP ? C::E_POST : C::E_PROP);
     if (EMAX * (long)p->B * (long)sizeof(R) >= (1L << 31)) return I2C_EINVAL;
     return I2C_OK;
@@ -502,21 +503,29 @@ template <class M, typename R, typename S = R> struct Impl {
     if (grp < 0) return grp;
     if constexpr (HAS_GROUP && M::GROUP_FORWARD_AUTO) {
       if (sweep == I2C_SWEEP_FORWARD && grp == 0 && p->group_lanes == 0 && (long)p->B * G <= I2C_GROUP_FORWARD_MAX_LANES &&
-          group_supported(p, c) == I2C_OK)
+          group_supported(p, c, sweep) == I2C_OK)
         grp = 1;
     }
     if (grp) {
       if constexpr (HAS_GROUP) {
-        const int rc = group_supported(p, c);
+        const int rc = group_supported(p, c, sweep);
         return rc != I2C_OK ? rc : I2C_FAMILY_GROUP;
       }
       return I2C_ENOTSUP;
     }
     return LANE ? I2C_FAMILY_LANE : I2C_ENOTSUP;
   }
+  // The state estimator's rule is fixed, whatever the graph infers with: CubatureQuadrature(1, 0, 0) (mpc.py:121-123)
+  static I2cProblem filter_problem(const I2cProblem* p) {
+    I2cProblem q = *p;
+    q.inference = I2C_INF_CUBATURE;
+    q.quad_alpha = 1.0, q.quad_beta = 0.0, q.quad_kappa = 0.0;
+    return q;
+  }
   static int family_of(const I2cProblem* p, int sweep) {
-    const C c = make_consts<M, R>(p, 0.0, 0);
-    return family(p, c, sweep);
+    const I2cProblem q = sweep == I2C_SWEEP_FILTER ? filter_problem(p) : *p;
+    const C c = make_consts<M, R>(&q, 0.0, 0);
+    return family(&q, c, sweep);
   }
 
   // the sigma-point forward sweep of the one-lane kernels, for either storage type
@@ -751,11 +760,13 @@ template <class M, typename R, typename S = R> struct Impl {
   static int ckf(const I2cProblem* p, const double* sig_zeta, const void* y, const void* u, void* mu, void* cov,
                  int32_t* status, void* stream) {
     if constexpr (MIXED) return I2C_ENOTSUP;
+    const I2cProblem q = filter_problem(p);
+    p = &q;
     const C c = make_consts<M, R>(p, 0.0, 0);
     ZetaArg<M, R> z;
     for (int i = 0; i < sym(M::NY); ++i) z.v[i] = (R)sig_zeta[i];
     CkfArgs<R> a{(const R*)y, (const R*)u, (R*)mu, (R*)cov, status};
-    const int fam = family(p, c, I2C_SWEEP_FILTER);  // also refuses what the family does not cover (a non-cubature rule)
+    const int fam = family(p, c, I2C_SWEEP_FILTER);
     if (fam < 0) return fam;
     if (fam == I2C_FAMILY_GROUP) {
       if constexpr (HAS_GROUP) return launch_group<GK_CKF, M, R, G>(c, &z, a, stream);

@@ -44,8 +44,6 @@ def make_case(name, T, variant):
         d.pop("Qf", None)
         d.update(prior)
     elif variant == "propagate":
-        if name == "lin_quad12_T20":
-            return None  # no propagation kernel for Linearize() at d = 16 (I2C_ENOTSUP)
         meta["propagate"] = True
     elif variant == "expert":
         meta["use_expert_controller"] = True

@@ -15,12 +15,13 @@ from i2c.i2c import I2cGraph
 from i2c.policy.mpc import PartiallyObservedMpcPolicy
 
 
-def _policy(g, lib, device, batch=None, group_lanes=0):
+def _policy(g, lib, device, batch=None, group_lanes=0, rule=None):
     meta = g.meta
     model = parity.product_model(g)
     model.sig_zeta = g["sig_zeta"]
     i2c = I2cGraph(model, meta["T"], g.get("Q"), g["R"], g.get("Qf"), meta["alpha"], meta["tol"], g["mu_u"], g["sig_u"],
-                   None, None, CubatureQuadrature(*meta["quad"]), lib=lib, device=device, batch=batch, group_lanes=group_lanes)
+                   None, None, CubatureQuadrature(*meta["quad"]) if rule is None else rule, lib=lib, device=device, batch=batch,
+                   group_lanes=group_lanes)
     i2c._propagate = True
     pol = PartiallyObservedMpcPolicy(i2c, meta["n_iter"], g["sig_u"], np.copy(g["z_traj"]))
     pol.set_control(feedforward=meta["feedforward"])
@@ -91,8 +92,9 @@ def _ckf_oracle(model, rule_w, mu, cov, u, y, sig_zeta):
     return mu_f + np.einsum("bij,bj->bi", K, y - mu_y), sig_f - K @ sig_y @ np.swapaxes(K, -1, -2)
 
 
-def _ckf_batch(lib, device, model_name, B=37):
-    """The filter kernel on a ragged batch of random beliefs against the oracle restatement."""
+def _ckf_batch(lib, device, model_name, B=37, rule=None):
+    """The filter kernel on a ragged batch of random beliefs against the oracle restatement. `rule`: the graph's inference --
+    the filter's own rule is CubatureQuadrature(1, 0, 0) whatever the graph infers with (mpc.py:121-123)."""
     from oracle.models_numpy import make_model
 
     g = load_case({"PlanarQuadrotor": "mpc_quadrotor_fb", "Quadrotor12": "mpc_quad12_fb"}.get(model_name, "mpc_pendulum_ff"))
@@ -106,7 +108,7 @@ def _ckf_batch(lib, device, model_name, B=37):
     u = rng.normal(size=(B, nu)) + (om.u_max / 4 if hasattr(om, "u_max") else 0.0)
     sig_zeta = np.diag(10.0 ** rng.uniform(-5, -2, size=ny))
     y = om.measure(mu) + 0.01 * rng.normal(size=(B, ny))
-    _, i2c, pol = _policy(g, lib, device, batch=B)
+    _, i2c, pol = _policy(g, lib, device, batch=B, rule=rule)
     i2c.sys.sig_zeta = sig_zeta
     i2c.engine.set_initial_state(mu, cov)
     pol.filter(y, u)
@@ -125,6 +127,28 @@ def test_ckf_batch_cpu(model_name):
 @pytest.mark.parametrize("model_name", ["PendulumKnown", "PlanarQuadrotor", "Quadrotor12"])
 def test_ckf_batch_gpu(model_name):
     _ckf_batch(None, "cuda", model_name)
+
+
+def _graph_rules():
+    from i2c.exp_types import GaussHermiteQuadrature, Linearize
+
+    return {"general_weights": CubatureQuadrature(1.2, 0.44, 0.5), "linearize": Linearize(), "gauss_hermite": GaussHermiteQuadrature(3)}
+
+
+CKF_RULES = [("PendulumKnown", "general_weights"), ("PendulumKnown", "linearize"), ("PendulumKnown", "gauss_hermite"),
+             ("Quadrotor12", "general_weights"), ("Quadrotor12", "linearize")]
+
+
+@pytest.mark.parametrize("model_name,rule", CKF_RULES)
+def test_ckf_rule_is_fixed_cpu(model_name, rule):
+    """The estimator under a graph that infers with another rule (group kernels for the 12-state quadrotor)."""
+    _ckf_batch(hostsim.load(), "cpu", model_name, B=5, rule=_graph_rules()[rule])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_name,rule", CKF_RULES)
+def test_ckf_rule_is_fixed_gpu(model_name, rule):
+    _ckf_batch(None, "cuda", model_name, B=5, rule=_graph_rules()[rule])
 
 
 def _batched_loop_matches_single(lib, device):

@@ -247,5 +247,10 @@ def test_kernel_family_is_inspectable():
     lin = eng("PendulumKnown", 4, inference="linearize", group_lanes=True)
     with pytest.raises(RuntimeError, match="-2"):
         lin.kernel_family("forward")
-    with pytest.raises(RuntimeError, match="-2"):  # the group filter no longer runs silently for a rule it does not cover
-        lin.kernel_family("filter")
+    # the estimator and the closed-loop propagation of a Linearize() graph ARE the unit cubature rule (mpc.py:121-123,
+    # i2c.py:109-115): the group kernels serve them; a Gauss-Hermite graph propagates with its own grid, which they do not cover
+    assert lin.kernel_family("filter") == "group" and lin.kernel_family("propagate") == "group"
+    gh = eng("PendulumKnown", 4, inference="gauss_hermite", gh_degree=3, group_lanes=True)
+    assert gh.kernel_family("filter") == "group"
+    with pytest.raises(RuntimeError, match="-2"):
+        gh.kernel_family("propagate")
