@@ -315,7 +315,7 @@ def _mpc_loop(policy, model, steps, out, rng, plant_noise=True):
     out["xu_plan_last"] = np.asarray(policy.xu_history[-1], float)[:, :, 0]
 
 
-def case_mpc_pendulum(feedforward, name):
+def case_mpc_pendulum(feedforward, name, quad=(1, 0, 0)):
     """PartiallyObservedMpcPolicy (i2c/policy/mpc.py:113-182) on the pendulum with a stand-in
     measurement model y = observe_terminal(x) + N(0, sig_zeta) (the reference defines `measure`
     only for its Box2D quadrotor). Protocol of mpc_quad.py:624-650: calibrate_alpha, warm start,
@@ -333,11 +333,11 @@ def case_mpc_pendulum(feedforward, name):
     sig_u = 2.0 * np.eye(1)
     z_traj = np.tile(np.asarray(model.zg, float).reshape(1, -1), (steps + H, 1))
     z_traj[:, 2] = 0.3 * np.sin(np.linspace(0, 3, steps + H))  # a moving velocity target
-    g = I2cGraph(model, H, Q, R, Q, 10.0, 1.0, mu_u, sig_u, None, None, CubatureQuadrature(1, 0, 0))
+    g = I2cGraph(model, H, Q, R, Q, 10.0, 1.0, mu_u, sig_u, None, None, CubatureQuadrature(*quad))
     g._propagate = True
     policy = PartiallyObservedMpcPolicy(g, n_iter, sig_u, np.copy(z_traj))
     policy.set_control(feedforward=feedforward)
-    out = problem_inputs("PendulumKnown", model, H, Q, R, Q, 10.0, 1.0, mu_u, sig_u, None, None, (1, 0, 0),
+    out = problem_inputs("PendulumKnown", model, H, Q, R, Q, 10.0, 1.0, mu_u, sig_u, None, None, quad,
                          feedforward=bool(feedforward), steps=steps, n_iter=n_iter, warm=warm)
     out["z_traj"], out["sig_zeta"] = z_traj, model.sig_zeta
     g.calibrate_alpha()
@@ -355,6 +355,12 @@ def case_mpc_pendulum_ff():
 
 def case_mpc_pendulum_fb():
     case_mpc_pendulum(False, "mpc_pendulum_fb")
+
+
+def case_mpc_pendulum_general_weights():
+    """The graph infers with general cubature weights; the policy's state estimator keeps CubatureQuadrature(1, 0, 0)
+    (mpc.py:121-123)."""
+    case_mpc_pendulum(False, "mpc_pendulum_fb_general", quad=(1.2, 0.44, 0.5))
 
 
 def _reference_quadrotor():
@@ -855,6 +861,25 @@ def case_lin_covariance_control(n_detail=2):
     save("lin_covctrl_T50", out)
 
 
+def case_lin_covctrl_terminal_cost(T=30, n_detail=2, n_total=6, noise=1e-4):
+    """Linearize() with covariance control AND a terminal cost: the one combination in which the back-calculated
+    sig_xi_terminal of i2c.py:455-462 reaches a result (sig_z3_m :499-501 -> alpha :989-992). The terminal covariance is
+    tighter than the filtered one in one direction and looser in the other, so the multiplier is indefinite."""
+    from i2c.exp_types import Linearize
+
+    mu_u = np.zeros((T, 1))
+    Q, R = np.diag([10.0, 10.0]), np.diag([1.0])
+    mu_T, sig_T = np.array([[1.0], [0.5]]), np.array([[1e-3, 2e-4], [2e-4, 50.0]])
+    model = make_env_model("LinearKnown", None)
+    model.sig_x0 = noise * np.eye(2)
+    model.sig_eta = noise * np.eye(2)
+    g = I2cGraph(model, T, Q, R, Q, 1e2, 0.0, mu_u, 1e2 * np.eye(1), mu_T, sig_T, Linearize())
+    out = problem_inputs("LinearKnown", model, T, Q, R, Q, 1e2, 0.0, mu_u, 1e2 * np.eye(1), mu_T, sig_T, (1, 0, 0),
+                         noise=noise, inference="linearize")
+    run_em_linearize(g, n_detail, n_total, out)
+    save("lin_covctrl_qf_T30", out)
+
+
 def _case_lin_nonlinear(env, T, Q, R, Qf, alpha, tol, mu_u, sig_u, n_detail, n_total, name):
     from i2c.exp_types import Linearize
 
@@ -955,6 +980,7 @@ CASES = {
     "models": case_models,
     "mpc_ff": case_mpc_pendulum_ff,
     "mpc_fb": case_mpc_pendulum_fb,
+    "mpc_fb_general": case_mpc_pendulum_general_weights,
     "em_quad": case_em_quadrotor,
     "mpc_quad": case_mpc_quadrotor,
     "em_quad12": case_em_quad12,
@@ -970,6 +996,7 @@ CASES = {
     "lin_linear": case_lin_linear,
     "lin_lqr": case_lin_lqr_compare,
     "lin_covctrl": case_lin_covariance_control,
+    "lin_covctrl_qf": case_lin_covctrl_terminal_cost,
     "lin_pendulum": case_lin_pendulum,
     "lin_cartpole": case_lin_cartpole,
     "lin_dcp": case_lin_double_cartpole,

@@ -128,6 +128,7 @@ def test_hip_group_kernels_batch_vs_oracle(lib, name, B, group):
 LINEARIZE = [
     ("lin_linear_T60", 1e-7, 1e-6),
     ("lin_covctrl_T50", 1e-7, 1e-6),
+    ("lin_covctrl_qf_T30", 1e-7, 1e-6),  # + a terminal cost: the back-calculated sig_xi_terminal (i2c.py:455-462)
     ("lin_pendulum_T100", 1e-7, 1e-5),
     ("lin_cartpole_T100", 1e-6, 1e-5),
     ("lin_dcp_T80", 1e-6, 1e-5),

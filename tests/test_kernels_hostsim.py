@@ -150,6 +150,7 @@ def test_group_kernels_dense_weights_match_lane_kernels(lib):
 LINEARIZE = [
     ("lin_linear_T60", 1e-8, 1e-7),
     ("lin_covctrl_T50", 1e-8, 1e-7),
+    ("lin_covctrl_qf_T30", 1e-8, 1e-7),  # + a terminal cost: the back-calculated sig_xi_terminal (i2c.py:455-462)
     ("lin_pendulum_T100", 1e-8, 1e-6),
     ("lin_cartpole_T100", 1e-7, 1e-6),
     ("lin_dcp_T80", 1e-7, 1e-6),
