@@ -612,6 +612,12 @@ template <class M, typename R, typename S = R> struct Impl {
     void* stats_out;
     bool done;
   };
+  // Linearize() applies the terminal cost at the END of the chain, with the temperature of the cell that sits there
+  // (i2c.py:475-491: the cell's own sig_xi_terminal). A receding-horizon loop appends cells that keep the temperature they were
+  // copied with (I2cProblem.alpha_cell), so after the first shift that is not the graph's alpha.
+  static const R* terminal_alpha(const I2cProblem* p, const C& c) {
+    return p->alpha_cell ? (const R*)p->alpha_cell + (long)c.row(p->T - 1) * (long)p->B : (const R*)p->alpha;
+  }
   static int backward(const I2cProblem* p, const void* fwd, void* xm, void* post, void* zpost, void* cell_stats,
                       void* term_stats, int32_t* status, void* stream) {
     return backward_impl(p, fwd, xm, post, zpost, cell_stats, term_stats, status, stream, nullptr);
@@ -625,7 +631,7 @@ template <class M, typename R, typename S = R> struct Impl {
       const int fam = family(p, c, I2C_SWEEP_BACKWARD);
       if (fam < 0) return fam;
       CellArgs<R, S> am{(const S*)fwd, (const S*)xm,   (const R*)p->z, (S*)post,  (S*)zpost,
-                        (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   (const R*)p->alpha};
+                        (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   terminal_alpha(p, c)};
       if (fam == I2C_FAMILY_WAVE) return backward_wave(p, c, am, ms, fuse, stream);
       return backward_lane(p, c, am, ms, fuse, stream);
     } else {
@@ -651,7 +657,7 @@ template <class M, typename R, typename S = R> struct Impl {
   static int backward_any(const I2cProblem* p, const C& c, const MstepArgs<R>& ms, const void* fwd, void* xm, void* post,
                           void* zpost, void* cell_stats, void* term_stats, int32_t* status, void* stream, MstepFuse* fuse) {
     CellArgs<R> a{(const R*)fwd, (const R*)xm,   (const R*)p->z, (R*)post,  (R*)zpost,
-                  (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   (const R*)p->alpha};
+                  (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   terminal_alpha(p, c)};
     const int fam = family(p, c, I2C_SWEEP_BACKWARD);
     if (fam < 0) return fam;
     if (fam == I2C_FAMILY_WAVE) {

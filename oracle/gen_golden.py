@@ -207,6 +207,22 @@ def case_covariance_control(T=100, n_detail=3, n_total=30):
     save("em_covctrl_T100", out)
 
 
+def case_covariance_control_terminal_cost(T=40, n_detail=3, n_total=8):
+    """Covariance control (tempered terminal prior, i2c.py:548-559) on a graph that ALSO has a terminal cost: the terminal
+    observation statistics (:565-570) come from the pinned smoothed state; expert controller on; KL terms (:1012-1019)."""
+    np.random.seed(3)
+    mu_u = 1e-2 * np.random.randn(T, 1)
+    Q, R, Qf = np.diag([1, 100.0, 1]), np.diag([2.0]), np.diag([1, 100.0, 1])
+    mu_xt, sig_xt = np.array([0.5, 0.0]), np.array([[2e-3, 5e-4], [5e-4, 1e-2]])
+    model = make_env_model("PendulumKnown", None)
+    g = I2cGraph(model, T, Q, R, Qf, 100.0, 0.5, mu_u, 2.0 * np.eye(1), mu_xt, sig_xt, CubatureQuadrature(1, 0, 0))
+    g._propagate = True
+    out = problem_inputs("PendulumKnown", model, T, Q, R, Qf, 100.0, 0.5, mu_u, 2.0 * np.eye(1), mu_xt, sig_xt, (1, 0, 0),
+                         propagate=True, use_expert_controller=True, seed=3)
+    run_em(g, n_detail, n_total, out, pre_propagate=True)
+    save("em_covctrl_qf_T40", out)
+
+
 def case_propagate_expert(T=50, n_detail=3, n_total=5):
     """Closed-loop propagation with the expert (pdf-ratio scaled) controller, i2c.py:160-165,
     plus calibrate_alpha (i2c.py:895-911) before the EM loop, as mpc_quad.py:624-630 does."""
@@ -315,7 +331,7 @@ def _mpc_loop(policy, model, steps, out, rng, plant_noise=True):
     out["xu_plan_last"] = np.asarray(policy.xu_history[-1], float)[:, :, 0]
 
 
-def case_mpc_pendulum(feedforward, name, quad=(1, 0, 0)):
+def case_mpc_pendulum(feedforward, name, quad=(1, 0, 0), rule=None, **meta):
     """PartiallyObservedMpcPolicy (i2c/policy/mpc.py:113-182) on the pendulum with a stand-in
     measurement model y = observe_terminal(x) + N(0, sig_zeta) (the reference defines `measure`
     only for its Box2D quadrotor). Protocol of mpc_quad.py:624-650: calibrate_alpha, warm start,
@@ -333,12 +349,12 @@ def case_mpc_pendulum(feedforward, name, quad=(1, 0, 0)):
     sig_u = 2.0 * np.eye(1)
     z_traj = np.tile(np.asarray(model.zg, float).reshape(1, -1), (steps + H, 1))
     z_traj[:, 2] = 0.3 * np.sin(np.linspace(0, 3, steps + H))  # a moving velocity target
-    g = I2cGraph(model, H, Q, R, Q, 10.0, 1.0, mu_u, sig_u, None, None, CubatureQuadrature(*quad))
+    g = I2cGraph(model, H, Q, R, Q, 10.0, 1.0, mu_u, sig_u, None, None, CubatureQuadrature(*quad) if rule is None else rule)
     g._propagate = True
     policy = PartiallyObservedMpcPolicy(g, n_iter, sig_u, np.copy(z_traj))
     policy.set_control(feedforward=feedforward)
     out = problem_inputs("PendulumKnown", model, H, Q, R, Q, 10.0, 1.0, mu_u, sig_u, None, None, quad,
-                         feedforward=bool(feedforward), steps=steps, n_iter=n_iter, warm=warm)
+                         feedforward=bool(feedforward), steps=steps, n_iter=n_iter, warm=warm, **meta)
     out["z_traj"], out["sig_zeta"] = z_traj, model.sig_zeta
     g.calibrate_alpha()
     out["alpha_cal1"] = np.array(g.alpha)
@@ -361,6 +377,17 @@ def case_mpc_pendulum_general_weights():
     """The graph infers with general cubature weights; the policy's state estimator keeps CubatureQuadrature(1, 0, 0)
     (mpc.py:121-123)."""
     case_mpc_pendulum(False, "mpc_pendulum_fb_general", quad=(1.2, 0.44, 0.5))
+
+
+def case_mpc_pendulum_linearize():
+    """MpcPolicy accepts any I2cGraph (mpc.py:16-33): the loop on a Linearize() graph (filter: unit cubature rule)."""
+    from i2c.exp_types import Linearize
+
+    case_mpc_pendulum(False, "mpc_pendulum_fb_lin", rule=Linearize(), inference="linearize", jacobian="complex-step stand-in (oracle/ref_shim.py)")
+
+
+def case_mpc_pendulum_gauss_hermite():
+    case_mpc_pendulum(False, "mpc_pendulum_fb_gh3", rule=GaussHermiteQuadrature(3), inference="gauss_hermite", gh_degree=3)
 
 
 def _reference_quadrotor():
@@ -950,6 +977,42 @@ def case_gh_pendulum(T=40, degree=3, n_detail=2, n_total=8):
     save(f"gh{degree}_pendulum_T{T}", out)
 
 
+def case_gh_covariance_control(T=100, degree=3, n_detail=2, n_total=30):
+    """Covariance control (tempered terminal prior + KL term) under GaussHermiteQuadrature(3), propagation with the grid.
+    (A small random initial action sequence: with mu_u = 0 the observed mean is rounding noise around zero.)"""
+    np.random.seed(8)
+    mu_u = 1e-2 * np.random.randn(T, 1)
+    R = np.diag([1.0])
+    mu_xt, sig_xt = np.array([0.0, 0.0]), np.diag([1e-3, 1e-3])
+    model = make_env_model("PendulumKnownActReg", None)
+    g = I2cGraph(model, T, None, R, None, 300.0, 1.0, mu_u, 0.5 * np.eye(1), mu_xt, sig_xt, GaussHermiteQuadrature(degree))
+    for c in g.cells:
+        c.use_expert_controller = False
+    g._propagate = True
+    out = problem_inputs("PendulumKnownActReg", model, T, None, R, None, 300.0, 1.0, mu_u, 0.5 * np.eye(1), mu_xt, sig_xt, (1, 0, 0),
+                         propagate=True, use_expert_controller=False, inference="gauss_hermite", gh_degree=degree)
+    run_em(g, n_detail, n_total, out, pre_propagate=True)
+    save(f"gh{degree}_covctrl_T{T}", out)
+
+
+def case_lin_pendulum_propagate(T=40, n_detail=2, n_total=8):
+    """Linearize() on the pendulum WITH closed-loop propagation (unit cubature rule, i2c.py:109-115) and the expert
+    controller in both the forward messages (:259-265) and the propagation (:160-167)."""
+    from i2c.exp_types import Linearize
+
+    np.random.seed(6)
+    mu_u = 1e-1 * np.random.randn(T, 1)
+    Q, R, Qf = np.diag([1, 100.0, 1]), np.diag([1.0]), np.diag([1, 100.0, 1])
+    model = make_env_model("PendulumKnown", None)
+    g = I2cGraph(model, T, Q, R, Qf, 100.0, 0.99, mu_u, 0.2 * np.eye(1), None, None, Linearize())
+    g._propagate = True
+    out = problem_inputs("PendulumKnown", model, T, Q, R, Qf, 100.0, 0.99, mu_u, 0.2 * np.eye(1), None, None, (1, 0, 0), seed=6,
+                         inference="linearize", propagate=True, use_expert_controller=True,
+                         jacobian="complex-step stand-in for autograd.jacobian (oracle/ref_shim.py)")
+    run_em_linearize(g, n_detail, n_total, out, pre_propagate=True)
+    save("lin_pendulum_T40_propagate", out)
+
+
 def case_gh_linear(T=30, degree=4, n_detail=2, n_total=6, noise=1e-4):
     """Gauss-Hermite degree 4 on LinearKnown (non-degenerate noise): 64 points per joint transform."""
     mu_u = np.zeros((T, 1))
@@ -975,12 +1038,15 @@ CASES = {
     "cartpole": case_cartpole,
     "linear": case_linear,
     "covctrl": case_covariance_control,
+    "covctrl_qf": case_covariance_control_terminal_cost,
     "propagate": case_propagate_expert,
     "quadrature": case_quadrature,
     "models": case_models,
     "mpc_ff": case_mpc_pendulum_ff,
     "mpc_fb": case_mpc_pendulum_fb,
     "mpc_fb_general": case_mpc_pendulum_general_weights,
+    "mpc_fb_lin": case_mpc_pendulum_linearize,
+    "mpc_fb_gh": case_mpc_pendulum_gauss_hermite,
     "em_quad": case_em_quadrotor,
     "mpc_quad": case_mpc_quadrotor,
     "em_quad12": case_em_quad12,
@@ -993,6 +1059,8 @@ CASES = {
     "i2c_run_lin": case_i2c_run_linearize,
     "gh_pendulum": case_gh_pendulum,
     "gh_linear": case_gh_linear,
+    "gh_covctrl": case_gh_covariance_control,
+    "lin_pendulum_pf": case_lin_pendulum_propagate,
     "lin_linear": case_lin_linear,
     "lin_lqr": case_lin_lqr_compare,
     "lin_covctrl": case_lin_covariance_control,

@@ -25,6 +25,7 @@ GOLDEN = [
     ("em_cartpole_T100", 1e-6, 1e-5),
     ("em_linear_T60", 1e-8, 1e-7),
     ("em_covctrl_T100", 1e-7, 1e-6),
+    ("em_covctrl_qf_T40", 1e-7, 1e-6),
     ("em_pendulum_T50_propagate", 1e-8, 1e-7),
     ("em_quadrotor_T20", 1e-6, 1e-5),
     ("em_quad12_T20", 1e-6, 1e-5),            # 12-state quadrotor: group kernels only (d = 16)
@@ -49,6 +50,7 @@ GROUP_GOLDEN = [
     ("em_pendulum_T50_propagate", 1e-8, 1e-7),
     ("em_quadrotor_T20", 1e-6, 1e-5),              # G = 8
     ("em_covctrl_T100", 1e-7, 1e-6),               # covariance control: tempered terminal prior, propagation, KL
+    ("em_covctrl_qf_T40", 1e-7, 1e-6),
     ("em_dcp_nondiag_T30", 1e-6, 1e-5),            # non-diagonal weights in the group form (g_cost_full)
 ]
 
@@ -130,6 +132,7 @@ LINEARIZE = [
     ("lin_covctrl_T50", 1e-7, 1e-6),
     ("lin_covctrl_qf_T30", 1e-7, 1e-6),  # + a terminal cost: the back-calculated sig_xi_terminal (i2c.py:455-462)
     ("lin_pendulum_T100", 1e-7, 1e-5),
+    ("lin_pendulum_T40_propagate", 1e-7, 1e-5),
     ("lin_cartpole_T100", 1e-6, 1e-5),
     ("lin_dcp_T80", 1e-6, 1e-5),
     ("lin_quad12_T20", 1e-6, 1e-5),  # d = 16: wave kernels, Linearize variant
@@ -142,7 +145,7 @@ def test_hip_linearize_vs_reference_golden(lib, name, tol_d, tol_s):
     parity.check_against_golden(name, lib, "cuda", tol_d, tol_s)
 
 
-@pytest.mark.parametrize("name", ["gh3_pendulum_T40", "gh4_linear_T30"])
+@pytest.mark.parametrize("name", ["gh3_pendulum_T40", "gh4_linear_T30", "gh3_covctrl_T100"])
 def test_hip_gauss_hermite_vs_reference_golden(lib, name):
     """GaussHermiteQuadrature(degree) inference on the device (tensor-grid transform) against the reference's runs."""
     parity.check_against_golden(name, lib, "cuda", 1e-7, 1e-6)

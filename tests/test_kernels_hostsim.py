@@ -21,6 +21,7 @@ GOLDEN = [
     ("em_cartpole_T100", 1e-7, 1e-6),
     ("em_linear_T60", 1e-9, 1e-8),
     ("em_covctrl_T100", 1e-8, 1e-7),
+    ("em_covctrl_qf_T40", 1e-8, 1e-7),        # covariance control + terminal cost + expert controller
     ("em_pendulum_T50_propagate", 1e-9, 1e-8),
     ("em_quadrotor_T20", 1e-7, 1e-6),
     ("em_quad12_T20", 1e-7, 1e-6),            # group kernels only (d = 16)
@@ -47,6 +48,7 @@ GROUP_GOLDEN = [
     ("em_pendulum_T50_propagate", 1e-9, 1e-8, None),  # propagation with the expert controller
     ("em_quadrotor_T20", 1e-7, 1e-6, None),           # G = 8, identity observation
     ("em_covctrl_T100", 1e-8, 1e-7, 8),               # covariance control: tempered terminal prior, propagation, KL
+    ("em_covctrl_qf_T40", 1e-8, 1e-7, None),
     ("em_dcp_nondiag_T30", 1e-7, 1e-6, None),         # non-diagonal weights: g_cost_full on nz = 9
 ]
 
@@ -152,6 +154,7 @@ LINEARIZE = [
     ("lin_covctrl_T50", 1e-8, 1e-7),
     ("lin_covctrl_qf_T30", 1e-8, 1e-7),  # + a terminal cost: the back-calculated sig_xi_terminal (i2c.py:455-462)
     ("lin_pendulum_T100", 1e-8, 1e-6),
+    ("lin_pendulum_T40_propagate", 1e-8, 1e-6),  # + closed-loop propagation (unit cubature rule), expert controller
     ("lin_cartpole_T100", 1e-7, 1e-6),
     ("lin_dcp_T80", 1e-7, 1e-6),
     ("lin_quad12_T20", 1e-7, 1e-6),  # d = 16: the wave kernels' Linearize variant (dual-number Jacobian, one input per lane)
@@ -165,7 +168,7 @@ def test_hostsim_linearize_vs_reference_golden(lib, name, tol_d, tol_s):
     parity.check_against_golden(name, lib, "cpu", tol_d, tol_s)
 
 
-@pytest.mark.parametrize("name", ["gh3_pendulum_T40", "gh4_linear_T30"])
+@pytest.mark.parametrize("name", ["gh3_pendulum_T40", "gh4_linear_T30", "gh3_covctrl_T100"])
 def test_hostsim_gauss_hermite_vs_reference_golden(lib, name):
     """GaussHermiteQuadrature(degree) inference (exp_types.py:52-68): tensor-grid transform in the forward, backward
     and propagation kernels, against the reference's captured runs."""

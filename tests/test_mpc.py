@@ -15,12 +15,20 @@ from i2c.i2c import I2cGraph
 from i2c.policy.mpc import PartiallyObservedMpcPolicy
 
 
+def _rule_of(meta):
+    from i2c.exp_types import GaussHermiteQuadrature, Linearize
+
+    kind = meta.get("inference", "cubature")
+    return {"cubature": lambda: CubatureQuadrature(*meta["quad"]), "linearize": Linearize,
+            "gauss_hermite": lambda: GaussHermiteQuadrature(meta.get("gh_degree", 3))}[kind]()
+
+
 def _policy(g, lib, device, batch=None, group_lanes=0, rule=None):
     meta = g.meta
     model = parity.product_model(g)
     model.sig_zeta = g["sig_zeta"]
     i2c = I2cGraph(model, meta["T"], g.get("Q"), g["R"], g.get("Qf"), meta["alpha"], meta["tol"], g["mu_u"], g["sig_u"],
-                   None, None, CubatureQuadrature(*meta["quad"]) if rule is None else rule, lib=lib, device=device, batch=batch,
+                   None, None, _rule_of(meta) if rule is None else rule, lib=lib, device=device, batch=batch,
                    group_lanes=group_lanes)
     i2c._propagate = True
     pol = PartiallyObservedMpcPolicy(i2c, meta["n_iter"], g["sig_u"], np.copy(g["z_traj"]))
@@ -52,13 +60,15 @@ def _replay(name, lib, device, tol, group_lanes=0):
     return pol
 
 
-@pytest.mark.parametrize("name", ["mpc_pendulum_ff", "mpc_pendulum_fb", "mpc_pendulum_fb_general", "mpc_quadrotor_fb", "mpc_quad12_fb"])
+@pytest.mark.parametrize("name", ["mpc_pendulum_ff", "mpc_pendulum_fb", "mpc_pendulum_fb_general", "mpc_pendulum_fb_lin", "mpc_pendulum_fb_gh3",
+                                  "mpc_quadrotor_fb", "mpc_quad12_fb"])
 def test_mpc_replay_cpu(name):
     _replay(name, hostsim.load(), "cpu", 1e-7)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["mpc_pendulum_ff", "mpc_pendulum_fb", "mpc_pendulum_fb_general", "mpc_quadrotor_fb", "mpc_quad12_fb"])
+@pytest.mark.parametrize("name", ["mpc_pendulum_ff", "mpc_pendulum_fb", "mpc_pendulum_fb_general", "mpc_pendulum_fb_lin", "mpc_pendulum_fb_gh3",
+                                  "mpc_quadrotor_fb", "mpc_quad12_fb"])
 def test_mpc_replay_gpu(name):
     _replay(name, None, "cuda", 1e-6)
 
@@ -241,13 +251,13 @@ def _native_step_equals_stepwise(name, lib, device):
         assert ea.terminal_cell == eb.terminal_cell and nz == eb.nz and ea.t0 == eb.t0 == (t + 1) % ea.H
 
 
-@pytest.mark.parametrize("name", ["mpc_pendulum_fb", "mpc_quadrotor_fb", "mpc_quad12_fb"])
+@pytest.mark.parametrize("name", ["mpc_pendulum_fb", "mpc_pendulum_fb_lin", "mpc_pendulum_fb_gh3", "mpc_quadrotor_fb", "mpc_quad12_fb"])
 def test_native_mpc_step_cpu(name):
     _native_step_equals_stepwise(name, hostsim.load(), "cpu")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["mpc_pendulum_fb", "mpc_quadrotor_fb", "mpc_quad12_fb"])
+@pytest.mark.parametrize("name", ["mpc_pendulum_fb", "mpc_pendulum_fb_lin", "mpc_pendulum_fb_gh3", "mpc_quadrotor_fb", "mpc_quad12_fb"])
 def test_native_mpc_step_gpu(name):
     _native_step_equals_stepwise(name, None, "cuda")
 

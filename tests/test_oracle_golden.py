@@ -140,6 +140,11 @@ def test_em_covariance_control_T100():
     _run_and_check("em_covctrl_T100", 1e-8, 1e-7)
 
 
+def test_em_covariance_control_with_terminal_cost():
+    """Tempered terminal prior on a graph that also has a terminal cost, expert controller on (i2c.py:548-570)."""
+    _run_and_check("em_covctrl_qf_T40", 1e-8, 1e-7)
+
+
 def test_em_quadrotor_T20():
     """Build-defined analytic quadrotor fed to the REAL reference solver (dynamics unpinned, solver pinned)."""
     _run_and_check("em_quadrotor_T20", 1e-8, 1e-7)
@@ -174,7 +179,7 @@ def test_em_long_runs(name, n):
     _run_and_check(name, 1e-8, 1e-6, n_iters=n)
 
 
-@pytest.mark.parametrize("name", ["gh3_pendulum_T40", "gh4_linear_T30"])
+@pytest.mark.parametrize("name", ["gh3_pendulum_T40", "gh4_linear_T30", "gh3_covctrl_T100"])
 def test_em_gauss_hermite(name):
     """GaussHermiteQuadrature(degree) as the inference rule (exp_types.py:52-68), with closed-loop propagation."""
     _run_and_check(name, 1e-8, 1e-7)

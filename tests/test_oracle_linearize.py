@@ -58,6 +58,7 @@ def run_and_check(name, tol_detail, tol_summary):
     ("lin_covctrl_T50", 1e-8, 1e-7),
     ("lin_covctrl_qf_T30", 1e-8, 1e-7),  # + a terminal cost: the back-calculated sig_xi_terminal (i2c.py:455-462)
     ("lin_pendulum_T100", 1e-8, 1e-6),
+    ("lin_pendulum_T40_propagate", 1e-8, 1e-6),  # + closed-loop propagation, expert controller
     ("lin_cartpole_T100", 1e-8, 1e-6),
     ("lin_dcp_T80", 1e-7, 1e-6),
     ("lin_quad12_T20", 1e-8, 1e-6),  # 12-state quadrotor (d = 16): the reference's I2cGraph on the build-defined model
