@@ -386,8 +386,30 @@ def case_mpc_pendulum_linearize():
     case_mpc_pendulum(False, "mpc_pendulum_fb_lin", rule=Linearize(), inference="linearize", jacobian="complex-step stand-in (oracle/ref_shim.py)")
 
 
+def case_mpc_pendulum_linearize_ff():
+    from i2c.exp_types import Linearize
+
+    case_mpc_pendulum(True, "mpc_pendulum_ff_lin", rule=Linearize(), inference="linearize", jacobian="complex-step stand-in (oracle/ref_shim.py)")
+
+
 def case_mpc_pendulum_gauss_hermite():
     case_mpc_pendulum(False, "mpc_pendulum_fb_gh3", rule=GaussHermiteQuadrature(3), inference="gauss_hermite", gh_degree=3)
+
+
+def case_pendulum_tau(T=30, tau=7, n_detail=4, n_total=8):
+    """A feedback horizon in the middle: _update_priors flips the cells with index <= tau (i2c.py:1210-1213), the rest stay
+    feed-forward."""
+    np.random.seed(9)
+    mu_u = 1e-2 * np.random.randn(T, 1)
+    Q, R, Qf = np.diag([1, 100.0, 1]), np.diag([2.0]), np.diag([1, 100.0, 1])
+    model = make_env_model("PendulumKnown", None)
+    g = I2cGraph(model, T, Q, R, Qf, 100.0, 0.0, mu_u, 2.0 * np.eye(1), None, None, CubatureQuadrature(1, 0, 0))
+    g.tau = tau
+    out = problem_inputs("PendulumKnown", model, T, Q, R, Qf, 100.0, 0.0, mu_u, 2.0 * np.eye(1), None, None, (1, 0, 0), seed=9,
+                         tau=tau)
+    run_em(g, n_detail, n_total, out)
+    out["feedforward_final"] = np.array([bool(c.state_action_independence) for c in g.cells])
+    save(f"em_pendulum_T{T}_tau{tau}", out)
 
 
 def _reference_quadrotor():
@@ -1045,8 +1067,10 @@ CASES = {
     "mpc_ff": case_mpc_pendulum_ff,
     "mpc_fb": case_mpc_pendulum_fb,
     "mpc_fb_general": case_mpc_pendulum_general_weights,
+    "pendulum_tau": case_pendulum_tau,
     "mpc_fb_lin": case_mpc_pendulum_linearize,
     "mpc_fb_gh": case_mpc_pendulum_gauss_hermite,
+    "mpc_ff_lin": case_mpc_pendulum_linearize_ff,
     "em_quad": case_em_quadrotor,
     "mpc_quad": case_mpc_quadrotor,
     "em_quad12": case_em_quad12,

@@ -68,6 +68,8 @@ def oracle_from_case(case, **over):
         o._propagate = True
     if "use_expert_controller" in meta:
         o.use_expert_controller = bool(meta["use_expert_controller"])
+    if "tau" in meta:
+        o.tau = int(meta["tau"])
     return o
 
 

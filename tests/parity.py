@@ -44,6 +44,8 @@ def engine_from_case(case, lib, device, dtype=torch.float64, x0=None, mu_u=None,
         eng._propagate = True
     if "use_expert_controller" in meta:
         eng.use_expert_controller = bool(meta["use_expert_controller"])
+    if "tau" in meta:
+        eng.tau = int(meta["tau"])
     return eng
 
 

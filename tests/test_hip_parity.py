@@ -27,6 +27,7 @@ GOLDEN = [
     ("em_covctrl_T100", 1e-7, 1e-6),
     ("em_covctrl_qf_T40", 1e-7, 1e-6),
     ("em_pendulum_T50_propagate", 1e-8, 1e-7),
+    ("em_pendulum_T30_tau7", 1e-8, 1e-7),
     ("em_quadrotor_T20", 1e-6, 1e-5),
     ("em_quad12_T20", 1e-6, 1e-5),            # 12-state quadrotor: group kernels only (d = 16)
     ("em_quad12_T12_propagate", 1e-6, 1e-5),

@@ -23,6 +23,7 @@ GOLDEN = [
     ("em_covctrl_T100", 1e-8, 1e-7),
     ("em_covctrl_qf_T40", 1e-8, 1e-7),        # covariance control + terminal cost + expert controller
     ("em_pendulum_T50_propagate", 1e-9, 1e-8),
+    ("em_pendulum_T30_tau7", 1e-9, 1e-8),     # feedback horizon in the middle (i2c.py:1210-1213)
     ("em_quadrotor_T20", 1e-7, 1e-6),
     ("em_quad12_T20", 1e-7, 1e-6),            # group kernels only (d = 16)
     ("em_quad12_T12_propagate", 1e-7, 1e-6),

@@ -169,6 +169,11 @@ def test_em_propagate_expert_T50():
     _run_and_check("em_pendulum_T50_propagate", 1e-9, 1e-8)
 
 
+def test_em_feedback_horizon_tau():
+    """tau in the middle of the horizon: cells 0..tau turn feedback, the rest stay feed-forward (i2c.py:1210-1213)."""
+    _run_and_check("em_pendulum_T30_tau7", 1e-9, 1e-8)
+
+
 @pytest.mark.parametrize("name,n", [("em_pendulum_T200_run200", 200), ("em_dcp_T300_run20", 20), ("em_pendulum_T200_seed1_run60", 60),
                                     ("em_pendulum_T200_seed2_run60", 24), ("em_dcp_T300_run50", 50)])
 def test_em_long_runs(name, n):
