@@ -331,7 +331,7 @@ def _mpc_loop(policy, model, steps, out, rng, plant_noise=True):
     out["xu_plan_last"] = np.asarray(policy.xu_history[-1], float)[:, :, 0]
 
 
-def case_mpc_pendulum(feedforward, name, quad=(1, 0, 0), rule=None, **meta):
+def case_mpc_pendulum(feedforward, name, quad=(1, 0, 0), rule=None, z_rows=None, **meta):
     """PartiallyObservedMpcPolicy (i2c/policy/mpc.py:113-182) on the pendulum with a stand-in
     measurement model y = observe_terminal(x) + N(0, sig_zeta) (the reference defines `measure`
     only for its Box2D quadrotor). Protocol of mpc_quad.py:624-650: calibrate_alpha, warm start,
@@ -347,8 +347,9 @@ def case_mpc_pendulum(feedforward, name, quad=(1, 0, 0), rule=None, **meta):
     Q, R = np.diag([1, 100.0, 1]), np.diag([2.0])
     mu_u = 0.1 * rng.normal(size=(H, 1))
     sig_u = 2.0 * np.eye(1)
-    z_traj = np.tile(np.asarray(model.zg, float).reshape(1, -1), (steps + H, 1))
-    z_traj[:, 2] = 0.3 * np.sin(np.linspace(0, 3, steps + H))  # a moving velocity target
+    z_rows = steps + H if z_rows is None else z_rows
+    z_traj = np.tile(np.asarray(model.zg, float).reshape(1, -1), (z_rows, 1))
+    z_traj[:, 2] = 0.3 * np.sin(np.linspace(0, 3, z_rows))  # a moving velocity target
     g = I2cGraph(model, H, Q, R, Q, 10.0, 1.0, mu_u, sig_u, None, None, CubatureQuadrature(*quad) if rule is None else rule)
     g._propagate = True
     policy = PartiallyObservedMpcPolicy(g, n_iter, sig_u, np.copy(z_traj))
@@ -390,6 +391,12 @@ def case_mpc_pendulum_linearize_ff():
     from i2c.exp_types import Linearize
 
     case_mpc_pendulum(True, "mpc_pendulum_ff_lin", rule=Linearize(), inference="linearize", jacobian="complex-step stand-in (oracle/ref_shim.py)")
+
+
+def case_mpc_pendulum_short_targets():
+    """The target trajectory runs out during the loop: the appended cell then takes the target of the cell before it
+    (mpc.py:75-78)."""
+    case_mpc_pendulum(False, "mpc_pendulum_fb_short_targets", z_rows=22)
 
 
 def case_mpc_pendulum_gauss_hermite():
@@ -1070,6 +1077,7 @@ CASES = {
     "pendulum_tau": case_pendulum_tau,
     "mpc_fb_lin": case_mpc_pendulum_linearize,
     "mpc_fb_gh": case_mpc_pendulum_gauss_hermite,
+    "mpc_fb_short": case_mpc_pendulum_short_targets,
     "mpc_ff_lin": case_mpc_pendulum_linearize_ff,
     "em_quad": case_em_quadrotor,
     "mpc_quad": case_mpc_quadrotor,
