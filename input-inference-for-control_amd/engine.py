@@ -204,7 +204,10 @@ class BatchedI2c:
         # wave kernels the STORAGE is trajectory-major, [T][B][e_post] (a cell of a trajectory is contiguous: a wavefront, which
         # works on one trajectory, reads it as a few cache lines), and self.post is a permuted view of it, so every index
         # expression in this file and its callers is layout-blind; only the library (data_ptr) sees the difference.
-        self.post_layout = int(os.environ.get("I2C_POST_LAYOUT", "1" if dims.wave else "0")) if dims.wave else 0
+        layout = os.environ.get("I2C_POST_LAYOUT", "1")  # measurement knob (profiles/r3_quad12_post_layout_ab.txt)
+        if layout not in ("0", "1"):
+            raise ValueError(f"I2C_POST_LAYOUT={layout!r}: 0 ([T][e][B]) or 1 (trajectory-major, models with wave kernels)")
+        self.post_layout = int(layout) if dims.wave else 0
         self.post = to(post).to(st)
         if self.post_layout == 1:
             self.post = self.post.permute(0, 2, 1).contiguous().permute(0, 2, 1)

@@ -634,7 +634,7 @@ def case_em_dcp_nondiag(T=30, n_detail=2, n_total=6):
     save("em_dcp_nondiag_T30", out)
 
 
-def case_mpc_quad12():
+def case_mpc_quad12(rule=None, name="mpc_quad12_fb", **meta):
     """mpc_quad.py:538-650 (i2c, feedback, low noise) on the 12-state quadrotor: tracking a moving position target."""
     from i2c.policy.mpc import PartiallyObservedMpcPolicy
 
@@ -651,12 +651,12 @@ def case_mpc_quad12():
     Qf = Q / 10.0
     mu_u = 0.25 * model.gravity * np.ones((H, 4))
     sig_u = 1e-2 * np.eye(4)
-    g = I2cGraph(model, H, Q, R, Qf, 1.0, 1.0, mu_u, sig_u, None, None, CubatureQuadrature(1, 0, 0))
+    g = I2cGraph(model, H, Q, R, Qf, 1.0, 1.0, mu_u, sig_u, None, None, CubatureQuadrature(1, 0, 0) if rule is None else rule)
     g._propagate = True
     policy = PartiallyObservedMpcPolicy(g, n_iter, sig_u, np.copy(z_traj))
     policy.set_control(feedforward=False)
     out = problem_inputs("Quadrotor12", model, H, Q, R, Qf, 1.0, 1.0, mu_u, sig_u, None, None, (1, 0, 0),
-                         feedforward=False, steps=steps, n_iter=n_iter, warm=warm)
+                         feedforward=False, steps=steps, n_iter=n_iter, warm=warm, **meta)
     out["z_traj"], out["sig_zeta"] = z_traj, model.sig_zeta
     g.calibrate_alpha()
     out["alpha_cal1"] = np.array(g.alpha)
@@ -664,7 +664,15 @@ def case_mpc_quad12():
     g.calibrate_alpha()
     out["alpha_cal2"] = np.array(g.alpha)
     _mpc_loop(policy, model, steps, out, rng)
-    save("mpc_quad12_fb", out)
+    save(name, out)
+
+
+def case_mpc_quad12_linearize():
+    """The same loop on a Linearize() graph: the wave kernels' Linearize variant on the ring, the terminal cost at the end of the
+    chain with the appended cell's own temperature."""
+    from i2c.exp_types import Linearize
+
+    case_mpc_quad12(Linearize(), "mpc_quad12_fb_lin", inference="linearize", jacobian="complex-step stand-in (oracle/ref_shim.py)")
 
 
 def case_rollouts(T=60, n_em=4):
@@ -1084,6 +1092,7 @@ CASES = {
     "em_quad12": case_em_quad12,
     "em_quad12_pf": case_em_quad12_propagate,
     "mpc_quad12": case_mpc_quad12,
+    "mpc_quad12_lin": case_mpc_quad12_linearize,
     "em_quad12_nondiag": case_em_quad12_nondiag,
     "em_dcp_nondiag": case_em_dcp_nondiag,
     "rollouts": case_rollouts,
