@@ -192,7 +192,8 @@ typedef struct I2cProblem {
   void* alpha;          /* [B] temperature; read by the sweeps, updated in place by i2c_mstep    */
   const void* alpha_cell; /* optional [T][B]: per-cell temperature used INSTEAD of alpha[b] for sig_xi /
                              sig_xi_terminal of cell t. NULL normally; the MPC loop needs it because a cell
-                             appended by deepcopy(cell_init) keeps its stale sig_xi (mpc.py:175, i2c.py:976-981) */
+                             appended by deepcopy(cell_init) keeps its stale sig_xi (mpc.py:175, i2c.py:976-981). Linearize()
+                             applies the terminal cost at the END of the chain: with the last cell's entry (i2c.py:475-491) */
   void* temp;           /* [B] terminal-prior temperature (i2c.py:147,552) or NULL               */
   void* work;           /* optional device workspace of i2c_workspace_bytes() bytes for the chunked backward  */
   const uint8_t* feedforward; /* [T] bytes: 1 = cell in feed-forward mode
