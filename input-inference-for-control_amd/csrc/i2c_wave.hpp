@@ -246,7 +246,9 @@ I2C_FN void w_elim_step(const Wave<R>& w, R* s, R* r1, R* r2, R* lt, const R* mq
   R d[10];
   w_pivot_block<KB, PL>(w, s[KB], d);
   const R d00 = d[0], d10 = d[1], d11 = d[2], d20 = d[3], d21 = d[4], d22 = d[5], d30 = d[6], d31 = d[7], d32 = d[8], d33 = d[9];
-  // 4 x 4 Cholesky (l) ...
+  // 4 x 4 Cholesky (l), column by column. (Measured and dropped: two levels of 2 x 2 blocks, whose two rsq chains per level are
+  // independent -- half the dependent depth for 5 more instructions: SLOWER at every batch size, B = 256: 0.333 -> 0.343 ms,
+  // B = 8192: 2.07 -> 2.11 ms, profiles/r3_quad12_pivot_2x2_ab.txt. Even the lone wave is bound by instruction count here.)
   R i0, i1, i2, i3, l10, l20, l30, l21, l31, l32, p3, sq = R(1);
   if constexpr (!SIGNED) {
     i0 = r_rsqrt(d00);
