@@ -15,5 +15,5 @@ m.compile_all("g++", flags, sys.argv[1] + "/obj", sys.argv[1] + "/libi2c_hostsim
 PY
 I2C_HOSTSIM_LIB="$OUT/libi2c_hostsim.so" LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)" \
   ASAN_OPTIONS=detect_leaks=0 python -m pytest tests/test_kernels_hostsim.py tests/test_edge_cases.py tests/test_mpc.py \
-  tests/test_rollout.py tests/test_lqr_known_answer.py tests/test_facade.py tests/test_dist_gloo.py -q -m "not gpu" 2>&1 | tee "$OUT/report.txt" | tail -3
+  tests/test_feature_matrix.py tests/test_rollout.py tests/test_lqr_known_answer.py tests/test_facade.py tests/test_dist_gloo.py -q -m "not gpu" 2>&1 | tee "$OUT/report.txt" | tail -3
 echo "sanitizer reports: $(grep -c 'runtime error\|AddressSanitizer' "$OUT/report.txt" || true)"
