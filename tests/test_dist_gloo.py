@@ -7,6 +7,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -22,12 +23,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, B, iters, out_dir):
+def _worker(rank, world, port, B, iters, out_dir, golden="em_pendulum_T40_quad_general"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         pkg = importlib.import_module("input-inference-for-control_amd")
-        g = load_case("em_pendulum_T40_quad_general")
+        g = load_case(golden)
         x0, mu_u = parity.batched_inputs(g, B)
         lo, hi = pkg.dist.shard_range(B, rank, world)
         eng = parity.engine_from_case(g, hostsim.load(), "cpu", x0=x0[lo:hi], mu_u=mu_u[lo:hi])
@@ -56,15 +57,17 @@ def test_shard_range_covers_batch():
         assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_gloo_matches_single_process(tmp_path):
+@pytest.mark.parametrize("golden,B", [("em_pendulum_T40_quad_general", 11), ("em_quad12_T20", 5)])
+def test_two_rank_gloo_matches_single_process(tmp_path, golden, B):
+    """(the 12-state quadrotor: wave kernels, trajectory-major posterior storage behind the same views)"""
     hostsim.build()  # build once in the parent so the workers do not race
-    B, iters, world = 11, 3, 2  # ragged shards: 6 + 5
+    iters, world = 3, 2  # ragged shards: 6 + 5, 3 + 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, B, iters, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, B, iters, str(tmp_path), golden), nprocs=world, join=True)
     got = np.load(os.path.join(tmp_path, "gathered.npz"))
 
     pkg = importlib.import_module("input-inference-for-control_amd")
-    g = load_case("em_pendulum_T40_quad_general")
+    g = load_case(golden)
     x0, mu_u = parity.batched_inputs(g, B)
     eng = parity.engine_from_case(g, hostsim.load(), "cpu", x0=x0, mu_u=mu_u)
     for _ in range(iters):

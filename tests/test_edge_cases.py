@@ -139,7 +139,8 @@ def _check_inference(lib, device, golden, T, B):
 
 
 INFERENCE_EDGE = [("lin_pendulum_T100", 1, 1), ("lin_pendulum_T100", 2, 67), ("lin_cartpole_T100", 3, 5),
-                  ("gh3_pendulum_T40", 1, 3), ("gh3_pendulum_T40", 4, 66)]
+                  ("gh3_pendulum_T40", 1, 3), ("gh3_pendulum_T40", 4, 66),
+                  ("lin_quad12_T20", 1, 1), ("lin_quad12_T20", 2, 5)]  # the wave kernels' Linearize variant
 
 
 @pytest.mark.parametrize("golden,T,B", INFERENCE_EDGE)
@@ -174,13 +175,13 @@ def _check_failure_isolation(lib, device, golden):
     assert not np.all(np.isfinite(b[2]))
 
 
-@pytest.mark.parametrize("golden", ["lin_pendulum_T100", "gh3_pendulum_T40"])
+@pytest.mark.parametrize("golden", ["lin_pendulum_T100", "gh3_pendulum_T40", "lin_quad12_T20"])
 def test_failure_isolation_other_inference_cpu(golden):
     _check_failure_isolation(hostsim.load(), "cpu", golden)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("golden", ["lin_pendulum_T100", "gh3_pendulum_T40"])
+@pytest.mark.parametrize("golden", ["lin_pendulum_T100", "gh3_pendulum_T40", "lin_quad12_T20"])
 def test_failure_isolation_other_inference_gpu(golden):
     _check_failure_isolation(None, "cuda", golden)
 
