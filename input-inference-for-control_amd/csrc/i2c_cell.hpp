@@ -954,7 +954,7 @@ I2C_FN R terminal_obs_stats(const Consts<M, R>& c, const int b, const R* m3m, co
 // Out: mu/S = mu_xu0_m / sig_xu0_m, ctl = [K | k | sigK], mz/Sz, cost mean / variance.
 template <class M, typename R, bool GRID = false>
 I2C_FN bool cell_posterior(const Consts<M, R>& c, const R* zt, R* mu, R* S, const R* J, const R* dm, const R* dS,
-                           R* ctl, R* mz, R* Sz, R* cm, R* cv) {
+                           R* ctl, R* mz, R* Sz, R* cm, R* cv, const PolyTab<R>* tab = nullptr) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, D = C::D;
 #pragma unroll
@@ -969,7 +969,7 @@ I2C_FN bool cell_posterior(const Consts<M, R>& c, const R* zt, R* mu, R* S, cons
 #pragma unroll
   for (int e = 0; e < sym(D); ++e) Lm[e] = S[e];
   const bool ok = chol<D>(Lm, rinv);
-  transform<GRID, M, ObsStruct<M>, D, NZ, false>(c.rule_xu, mu, S, Lm, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
+  transform<GRID, M, ObsStruct<M>, D, NZ, false>(c.rule_xu, mu, S, Lm, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr, tab);
   gaussian_cost<NZ>(c.QR, c.qr_diag != 0, mz, Sz, zt, cm, cv);
 #pragma unroll
   for (int p = 0; p < NU; ++p) {
@@ -1081,6 +1081,9 @@ I2C_HD inline void backward_scan_body(const Consts<M, R>& c, const ScanArgs<R, S
   }
 }
 
+#ifndef I2C_WALK_VOFF
+#define I2C_WALK_VOFF 1
+#endif
 template <typename R, typename S = R> struct CellArgs {
   const S* fwd;      // [T][E_FWD][B]
   const S* xm;       // [T][E_XM][B]   (two-pass: input; fused: optional output)
@@ -1094,12 +1097,37 @@ template <typename R, typename S = R> struct CellArgs {
   const R* alpha;    // [B] (Linearize backward only: terminal cost update at the end of the chain)
 };
 
+// voff (small models, see forward_sweep_body): the lane's byte offset of row e, bo + e * rb, as VGPR values -- the stores then go
+// through one buffer window per cell and need no scalar address arithmetic (5 - 6 scalar instructions per row otherwise, and
+// the lone wave of the small-batch regime pays 4 clocks for each of them).
 template <class M, typename R, typename S_>
 I2C_FN void store_cell(const Consts<M, R>& c, const CellArgs<R, S_>& a, const int t, const int b, const R* mu, const R* S,
-                       const R* ctl, const R* mz, const R* Sz, const R cm, const R cv) {
+                       const R* ctl, const R* mz, const R* Sz, const R cm, const R cv, const unsigned* voff = nullptr) {
   using C = Consts<M, R>;
   constexpr int NZ = C::NZ, D = C::D;
   const long B = c.B;
+  if (voff) {
+    const unsigned rb = (unsigned)(B * sizeof(S_));
+    const Window wp = make_window(a.post + (unsigned long)c.row(t) * C::E_POST * B, (unsigned long)C::E_POST * rb);
+#pragma unroll
+    for (int e = 0; e < D; ++e) wst(wp, 0u, voff[e], (S_)mu[e]);
+#pragma unroll
+    for (int e = 0; e < sym(D); ++e) wst(wp, 0u, voff[D + e], (S_)S[e]);
+#pragma unroll
+    for (int e = 0; e < C::E_POST - D - sym(D); ++e) wst(wp, 0u, voff[D + sym(D) + e], (S_)ctl[e]);
+    if (a.zpost) {
+      const Window wz = make_window(a.zpost + (unsigned long)t * C::E_ZPOST * B, (unsigned long)C::E_ZPOST * rb);
+#pragma unroll
+      for (int k = 0; k < NZ; ++k) wst(wz, 0u, voff[k], (S_)mz[k]);
+#pragma unroll
+      for (int k = 0; k < sym(NZ); ++k) wst(wz, 0u, voff[NZ + k], (S_)Sz[k]);
+    }
+    if (a.cell_stats) {
+      a.cell_stats[((long)t * 2 + 0) * B + b] = cm;
+      a.cell_stats[((long)t * 2 + 1) * B + b] = cv;
+    }
+    return;
+  }
   S_* out = a.post + ((long)c.row(t) * C::E_POST) * B + b;
 #pragma unroll
   for (int e = 0; e < D; ++e) out[(long)e * B] = (S_)mu[e];
@@ -1428,11 +1456,22 @@ I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R, S_>
   // row is 100+ doubles, two of them overflow the register file into scratch and the walk then waits on scratch traffic
   // 80 % of the time (SQ counters); there the row is loaded at the top of its own cell.
   constexpr bool DOUBLE_BUFFER = C::D <= 5;
+  // per-row byte offsets as VGPR values (small models; see forward_sweep_body and store_cell)
+  constexpr bool VOFF = I2C_WALK_VOFF && C::D <= 5;
+  constexpr int NOFF = C::E_FWD > C::E_POST ? (C::E_FWD > C::E_ZPOST ? C::E_FWD : C::E_ZPOST) : (C::E_POST > C::E_ZPOST ? C::E_POST : C::E_ZPOST);
+  unsigned voff[VOFF ? NOFF : 1];
+  if (VOFF) {
+#pragma unroll
+    for (int e = 0; e < NOFF; ++e) voff[e] = bo + (unsigned)e * rb;
+  }
+  PolyTab<R> ptab;  // sincos coefficients as VGPR values (24 literal moves per cell otherwise), same condition
+  if (VOFF) poly_tab_init(ptab);
+  const PolyTab<R>* const tab = VOFF ? &ptab : nullptr;
   R row[C::E_FWD], nxt[DOUBLE_BUFFER ? C::E_FWD : 1];
   if (DOUBLE_BUFFER) {
     const Window w = make_window(ca.fwd + (unsigned long)(t_hi - 1) * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
-    for (int e = 0; e < C::E_FWD; ++e) row[e] = (R)wld<S_>(w, e * rb, bo);
+    for (int e = 0; e < C::E_FWD; ++e) row[e] = (R)wld<S_>(w, VOFF ? 0u : e * rb, VOFF ? voff[e] : bo);
   }
   R sum_m = R(0), sum_v = R(0);
   for (int t = t_hi - 1; t >= t_lo; --t) {
@@ -1440,7 +1479,8 @@ I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R, S_>
       const int tp = DOUBLE_BUFFER ? (t > t_lo ? t - 1 : t_lo) : t;
       const Window w = make_window(ca.fwd + (unsigned long)tp * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
-      for (int e = 0; e < C::E_FWD; ++e) (DOUBLE_BUFFER ? nxt[DOUBLE_BUFFER ? e : 0] : row[e]) = (R)wld<S_>(w, e * rb, bo);
+      for (int e = 0; e < C::E_FWD; ++e)
+        (DOUBLE_BUFFER ? nxt[DOUBLE_BUFFER ? e : 0] : row[e]) = (R)wld<S_>(w, VOFF ? 0u : e * rb, VOFF ? voff[e] : bo);
     }
     if (ca.xm) {
       S_* xo = const_cast<S_*>(ca.xm) + ((long)t * C::E_XM) * B + b;
@@ -1454,13 +1494,20 @@ I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R, S_>
     for (int i = 0; i < NX; ++i) dm[i] = m3m[i] - row[O_MU3 + i];
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) dS[i] = S3m[i] - row[O_S3 + i];
+    if (VOFF && c.z_per_cell) {  // (NZ <= E_FWD: the row offsets cover it; R-typed rows: 8 / sizeof(S_) scales them)
+      static_assert(NZ <= NOFF, "row offsets");
+      const Window wz = make_window(ca.z + (unsigned long)c.row(t) * NZ * B, (unsigned long)NZ * B * sizeof(R));
 #pragma unroll
-    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? ca.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k];
+      for (int k = 0; k < NZ; ++k) zt[k] = wld<R>(wz, 0u, voff[k] * (unsigned)(sizeof(R) / W));
+    } else {
+#pragma unroll
+      for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? ca.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k];
+    }
     R* mu = row;
     R* S = row + D;
     R ctl[C::E_POST - D - sym(D)], mz[NZ], Sz[sym(NZ)], cm, cv;
-    if (!cell_posterior<M, R>(c, zt, mu, S, row + O_J, dm, dS, ctl, mz, Sz, &cm, &cv)) set_status(ca.status, b, 7, t);
-    store_cell<M, R, S_>(c, ca, t, b, mu, S, ctl, mz, Sz, cm, cv);
+    if (!cell_posterior<M, R>(c, zt, mu, S, row + O_J, dm, dS, ctl, mz, Sz, &cm, &cv, tab)) set_status(ca.status, b, 7, t);
+    store_cell<M, R, S_>(c, ca, t, b, mu, S, ctl, mz, Sz, cm, cv, VOFF ? voff : nullptr);
     sum_m += cm;
     sum_v += cv;
 #pragma unroll
