@@ -1434,7 +1434,11 @@ I2C_HD inline void chunk_stitch_body(const Consts<M, R>& c, const ChunkArgs<R, S
   }
 }
 
-template <class M, typename R, typename S_ = R>
+// LEANW: the common case fixed at compile time (no smoothed-state / observed-marginal / per-cell-cost outputs, one shared target):
+// with the optional stores behind run-time branches the compiler cannot count the memory operations between the row prefetch and
+// its use, so its s_waitcnt at the top of a cell also waits for the PREVIOUS cell's stores to be acknowledged (vmcnt is one
+// in-order counter) -- 41 % of the walk's cycles (profiles/r3_pendulum_B4096_chunked_sq_summary.txt).
+template <class M, typename R, typename S_ = R, bool LEANW = false>
 I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R, S_>& a, const int ch, const int b) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NZ = C::NZ, D = C::D;
@@ -1443,7 +1447,9 @@ I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R, S_>
   const unsigned long B = c.B;
   const unsigned bo = (unsigned)b * W, rb = (unsigned)(B * W);
   const int t_lo = ch * a.chunk_len, t_hi = (t_lo + a.chunk_len < c.T) ? t_lo + a.chunk_len : c.T;
-  const CellArgs<R, S_>& ca = a.cell;
+  CellArgs<R, S_> ca = a.cell;
+  if (LEANW) ca.xm = nullptr, ca.zpost = nullptr, ca.cell_stats = nullptr;
+  const bool z_per_cell = LEANW ? false : c.z_per_cell != 0;
   R m3m[NX], S3m[sym(NX)];
   {
     const R* bi = a.bnd + ((long)ch * C::E_XM) * B + b;
@@ -1472,6 +1478,13 @@ I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R, S_>
     const Window w = make_window(ca.fwd + (unsigned long)(t_hi - 1) * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
     for (int e = 0; e < C::E_FWD; ++e) row[e] = (R)wld<S_>(w, VOFF ? 0u : e * rb, VOFF ? voff[e] : bo);
+    // settle them before the loop: the waitcnt pass joins the loop-entry state with the back-edge state, and loads still pending
+    // on the entry path (youngest operations there, but older than a cell's stores on the back edge) make it wait for
+    // vmcnt(0) -- the previous cell's stores -- at the top of EVERY cell (see forward_sweep_body)
+    if (LEANW) {
+#pragma unroll
+      for (int e = 0; e < C::E_FWD; ++e) row[e] = opaque(row[e]);
+    }
   }
   R sum_m = R(0), sum_v = R(0);
   for (int t = t_hi - 1; t >= t_lo; --t) {
@@ -1494,14 +1507,14 @@ I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R, S_>
     for (int i = 0; i < NX; ++i) dm[i] = m3m[i] - row[O_MU3 + i];
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) dS[i] = S3m[i] - row[O_S3 + i];
-    if (VOFF && c.z_per_cell) {  // (NZ <= E_FWD: the row offsets cover it; R-typed rows: 8 / sizeof(S_) scales them)
+    if (VOFF && z_per_cell) {  // (NZ <= E_FWD: the row offsets cover it; R-typed rows: 8 / sizeof(S_) scales them)
       static_assert(NZ <= NOFF, "row offsets");
       const Window wz = make_window(ca.z + (unsigned long)c.row(t) * NZ * B, (unsigned long)NZ * B * sizeof(R));
 #pragma unroll
       for (int k = 0; k < NZ; ++k) zt[k] = wld<R>(wz, 0u, voff[k] * (unsigned)(sizeof(R) / W));
     } else {
 #pragma unroll
-      for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? ca.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k];
+      for (int k = 0; k < NZ; ++k) zt[k] = z_per_cell ? ca.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k];
     }
     R* mu = row;
     R* S = row + D;

@@ -112,10 +112,13 @@ I2C_KERNEL(SWEEP_BLOCK) k_chunk_stitch(I2C_LANE_PARAMS const Consts<M, R> c, con
   const long b = I2C_LANE_X(SWEEP_BLOCK);
   if (b < c.B) chunk_stitch_body<M, R, S>(c, a, (int)b);
 }
-template <class M, typename R, typename S = R>
+#ifndef I2C_WALK_LEAN
+#define I2C_WALK_LEAN 1
+#endif
+template <class M, typename R, typename S = R, bool LEANW = false>
 I2C_KERNEL(SWEEP_BLOCK) k_chunk_walk(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, S> a) {
   const long b = I2C_LANE_X(SWEEP_BLOCK);
-  if (b < c.B) chunk_walk_body<M, R, S>(c, a, I2C_LANE_Y, (int)b);
+  if (b < c.B) chunk_walk_body<M, R, S, LEANW>(c, a, I2C_LANE_Y, (int)b);
 }
 template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_mstep(I2C_LANE_PARAMS const Consts<M, R> c, const MstepArgs<R> a) {
   const long b = I2C_LANE_X(SWEEP_BLOCK);
@@ -696,7 +699,11 @@ template <class M, typename R, typename S = R> struct Impl {
         ared.cell_stats = ch.part;
         int rc = launch(k_chunk_compose<M, R, S>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
         if (rc == I2C_OK) rc = launch(k_chunk_stitch<M, R, S>, p->B, 1, SWEEP_BLOCK, stream, c, ch);
-        if (rc == I2C_OK) rc = launch(k_chunk_walk<M, R, S>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
+        if (rc == I2C_OK) {
+          const bool lean = I2C_WALK_LEAN && !a.xm && !a.zpost && !a.cell_stats && !c.z_per_cell;  // see chunk_walk_body
+          rc = lean ? launch(k_chunk_walk<M, R, S, true>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch)
+                    : launch(k_chunk_walk<M, R, S>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
+        }
         if (rc == I2C_OK) rc = launch_reduce<M, R>(cr, ared, ms, p->T, stream);
         if (fuse) fuse->done = true;
         return rc;
