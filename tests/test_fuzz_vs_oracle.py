@@ -1,0 +1,84 @@
+"""Randomised differential test: random problems (model, inference rule, horizon, batch, cost weights -- diagonal or coupled --,
+temperature, update tolerance, feedback horizon, propagation, expert controller) through the batched engine and through the CPU
+oracle. Complements tests/test_feature_matrix.py (one option at a time) with combinations; the seeds are fixed."""
+import json
+
+import numpy as np
+import pytest
+
+import hostsim
+import parity
+from golden_util import Case, load_case, oracle_from_case
+
+BASES = ["em_pendulum_T200", "lin_pendulum_T100", "em_linear_T60", "lin_linear_T60", "em_cartpole_T100", "lin_cartpole_T100",
+         "em_dcp_T60", "em_quadrotor_T20", "em_quad12_T20", "lin_quad12_T20", "gh3_pendulum_T40"]
+
+
+def _spd(rng, n, lo, hi, coupled):
+    d = 10.0 ** rng.uniform(np.log10(lo), np.log10(hi), size=n)
+    if not coupled:
+        return np.diag(d)
+    q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    m = q @ np.diag(d) @ q.T
+    return 0.5 * (m + m.T)
+
+
+def random_case(rng):
+    name = BASES[rng.integers(len(BASES))]
+    g = load_case(name)
+    meta = dict(g.meta)
+    T, B = int(rng.integers(2, 12)), int(rng.integers(1, 5))
+    d = {k: g[k] for k in g}
+    nu = g["R"].shape[0]
+    coupled = bool(rng.integers(2))
+    if "Q" in g:
+        d["Q"] = _spd(rng, g["Q"].shape[0], 0.1, 100, coupled) * (np.abs(g["Q"]).max() / 100)
+    d["R"] = _spd(rng, nu, 0.1, 10, coupled and nu > 1) * np.abs(g["R"]).max()
+    if "Qf" in g and rng.integers(3) > 0:
+        d["Qf"] = _spd(rng, g["Qf"].shape[0], 0.1, 100, coupled) * (np.abs(g["Qf"]).max() / 100)
+    elif "Qf" in g and meta.get("inference") != "linearize":  # (Linearize without a terminal cost: the reference fails, see
+        d.pop("Qf")                                            #  test_feature_matrix.py)
+    meta.update(T=T, alpha=float(meta["alpha"] * 10 ** rng.uniform(-1, 1)), tol=float(rng.choice([0.0, 0.5, 0.99, 1.0])))
+    if rng.integers(2):
+        meta["propagate"] = True
+    if rng.integers(2):
+        meta["use_expert_controller"] = bool(rng.integers(2))
+    if rng.integers(2):
+        meta["tau"] = int(rng.integers(0, T + 1))
+    d["meta"] = np.array(json.dumps(meta))
+    d["mu_u"] = g["mu_u"][:T] * (1 + 0.3 * rng.normal(size=(T, nu))) + 1e-3 * rng.normal(size=(T, nu))
+    d["sig_u"] = g["sig_u"] * 10 ** rng.uniform(-0.5, 0.5)
+    return name, Case(d), B, int(rng.integers(1 << 30)), float(10 ** rng.uniform(-3, -1))
+
+
+def run_random_case(lib, device, seed, tol):
+    rng = np.random.default_rng(seed)
+    name, case, B, seed_b, x0_scale = random_case(rng)
+    x0, mu_u = parity.batched_inputs(case, B, seed=seed_b, x0_scale=x0_scale)
+    eng = parity.engine_from_case(case, lib, device, x0=x0, mu_u=mu_u)
+    o = oracle_from_case(Case({**case, "mu_u": mu_u}), x0=x0)
+    if case.meta.get("propagate"):
+        eng.propagate()
+        o.propagate()
+    for it in range(3):
+        eng.learn_msgs()
+        o.learn_msgs()
+        mu, sig = eng.marginal_state_action()
+        K, k, sigK = eng.local_linear_policy()
+        for what, a, b in (("mu", mu, o.mu_xu0_m), ("sig", sig, o.sig_xu0_m), ("K", K, o.K), ("k", k, o.k), ("sigK", sigK, o.sigK),
+                           ("alpha", eng.alpha, o.alpha), ("cost", eng.costs_m[-1], o.costs_m[-1])):
+            a, b = parity.np_(a), np.asarray(b, float)
+            err = np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-9)  # (the floor: gains that are zero up to rounding)
+            assert np.isfinite(err) and err <= tol, f"seed {seed} ({name}, {case.meta}) it{it} {what}: {err:.2e}"
+    assert eng.failures() == [], f"seed {seed} ({name})"
+
+
+@pytest.mark.parametrize("seed", range(100, 130))
+def test_hostsim_random_problems_vs_oracle(seed):
+    run_random_case(hostsim.load(), "cpu", seed, 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(100, 130))
+def test_hip_random_problems_vs_oracle(seed):
+    run_random_case(parity.pkg.load_library(), "cuda", seed, 1e-5)
