@@ -129,7 +129,7 @@ if __name__ == "__main__":
     for i in range(n):
         try:
             res.append(one(rng, i))
-        except Exception as e:  # the reference itself raises on some combinations (see tests/test_feature_matrix.py)
+        except Exception as e:  # (so far always the reference: a covariance that is not positive definite, quadrature.py:18)
             print(f"{i:3d} reference / oracle raised {type(e).__name__}: {str(e)[:120]}", flush=True)
     w = max(res) if res else (0.0, "")
     print(f"seed {seed}: {len(res)} of {n} cases compared, worst {w[0]:.2e} ({w[1]})")
