@@ -331,30 +331,35 @@ def _mpc_loop(policy, model, steps, out, rng, plant_noise=True):
     out["xu_plan_last"] = np.asarray(policy.xu_history[-1], float)[:, :, 0]
 
 
-def case_mpc_pendulum(feedforward, name, quad=(1, 0, 0), rule=None, z_rows=None, **meta):
+def case_mpc_pendulum(feedforward, name, quad=(1, 0, 0), rule=None, z_rows=None, hyper=None, **meta):
     """PartiallyObservedMpcPolicy (i2c/policy/mpc.py:113-182) on the pendulum with a stand-in
     measurement model y = observe_terminal(x) + N(0, sig_zeta) (the reference defines `measure`
     only for its Box2D quadrotor). Protocol of mpc_quad.py:624-650: calibrate_alpha, warm start,
     calibrate_alpha, then the closed loop with per-cell targets."""
     from i2c.policy.mpc import PartiallyObservedMpcPolicy
 
-    H, steps, n_iter, warm = 10, 25, 2, 8
-    rng = np.random.default_rng(5)
+    hp = dict(H=10, steps=25, n_iter=2, warm=8, seed=5, Q=np.diag([1, 100.0, 1]), R=np.diag([2.0]), Qf=None, alpha=10.0, sig_u=2.0,
+              sig_zeta=np.diag([1e-4, 1e-4, 1e-3]), amp=0.3)
+    hp.update(hyper or {})
+    H, steps, n_iter, warm = hp["H"], hp["steps"], hp["n_iter"], hp["warm"]
+    rng = np.random.default_rng(hp["seed"])
     model = make_env_model("PendulumKnown", None)
-    model.sig_zeta = np.diag([1e-4, 1e-4, 1e-3])
+    model.sig_zeta = hp["sig_zeta"]
     model.measure = lambda x: model.observe_terminal(x)
     model.dim_y = 3
-    Q, R = np.diag([1, 100.0, 1]), np.diag([2.0])
+    Q, R = hp["Q"], hp["R"]
+    Qf = Q if hp["Qf"] is None else hp["Qf"]
+    alpha0 = hp["alpha"]
     mu_u = 0.1 * rng.normal(size=(H, 1))
-    sig_u = 2.0 * np.eye(1)
+    sig_u = hp["sig_u"] * np.eye(1)
     z_rows = steps + H if z_rows is None else z_rows
     z_traj = np.tile(np.asarray(model.zg, float).reshape(1, -1), (z_rows, 1))
-    z_traj[:, 2] = 0.3 * np.sin(np.linspace(0, 3, z_rows))  # a moving velocity target
-    g = I2cGraph(model, H, Q, R, Q, 10.0, 1.0, mu_u, sig_u, None, None, CubatureQuadrature(*quad) if rule is None else rule)
+    z_traj[:, 2] = hp["amp"] * np.sin(np.linspace(0, 3, z_rows))  # a moving velocity target
+    g = I2cGraph(model, H, Q, R, Qf, alpha0, 1.0, mu_u, sig_u, None, None, CubatureQuadrature(*quad) if rule is None else rule)
     g._propagate = True
     policy = PartiallyObservedMpcPolicy(g, n_iter, sig_u, np.copy(z_traj))
     policy.set_control(feedforward=feedforward)
-    out = problem_inputs("PendulumKnown", model, H, Q, R, Q, 10.0, 1.0, mu_u, sig_u, None, None, quad,
+    out = problem_inputs("PendulumKnown", model, H, Q, R, Qf, alpha0, 1.0, mu_u, sig_u, None, None, quad,
                          feedforward=bool(feedforward), steps=steps, n_iter=n_iter, warm=warm, **meta)
     out["z_traj"], out["sig_zeta"] = z_traj, model.sig_zeta
     g.calibrate_alpha()
@@ -397,6 +402,29 @@ def case_mpc_pendulum_short_targets():
     """The target trajectory runs out during the loop: the appended cell then takes the target of the cell before it
     (mpc.py:75-78)."""
     case_mpc_pendulum(False, "mpc_pendulum_fb_short_targets", z_rows=22)
+
+
+def case_mpc_pendulum_random():
+    """Six MPC loops with random hyper-parameters (horizon, sweeps per step, cost weights incl. coupled ones, temperature, action
+    prior, measurement noise, target amplitude) over the inference rules and both control modes."""
+    from i2c.exp_types import Linearize
+
+    rng = np.random.default_rng(2024)
+    kinds = [("cubature", None, {}), ("general", None, {}), ("linearize", Linearize, dict(inference="linearize")),
+             ("gh3", lambda: GaussHermiteQuadrature(3), dict(inference="gauss_hermite", gh_degree=3)),
+             ("linearize", Linearize, dict(inference="linearize")), ("cubature", None, {})]
+    for n, (kind, mk, meta) in enumerate(kinds):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        q = np.eye(3) + 0.15 * (q - np.eye(3))
+        Q = q @ np.diag([1, 100.0, 1] * 10 ** rng.uniform(-0.4, 0.4, size=3)) @ q.T
+        Q = 0.5 * (Q + Q.T)
+        hyper = dict(H=int(rng.integers(4, 9)), steps=int(rng.integers(8, 14)), n_iter=int(rng.integers(1, 4)), warm=int(rng.integers(2, 6)),
+                     seed=int(rng.integers(1 << 20)), Q=Q if n % 2 else np.diag(np.diag(Q)), R=np.diag([2.0 * 10 ** rng.uniform(-0.3, 0.3)]),
+                     Qf=np.diag(np.diag(Q)) * 10 ** rng.uniform(-0.5, 0.5), alpha=float(10 ** rng.uniform(0.5, 1.5)),
+                     sig_u=float(10 ** rng.uniform(-0.2, 0.5)), sig_zeta=np.diag(10.0 ** rng.uniform(-5, -3, size=3)),
+                     amp=float(rng.uniform(0.1, 0.5)))
+        case_mpc_pendulum(bool(n == 5), f"mpc_pendulum_random{n}", quad=(1.2, 0.44, 0.5) if kind == "general" else (1, 0, 0),
+                          rule=None if mk is None else mk(), hyper=hyper, **meta)
 
 
 def case_mpc_pendulum_gauss_hermite():
@@ -1086,6 +1114,7 @@ CASES = {
     "mpc_fb_lin": case_mpc_pendulum_linearize,
     "mpc_fb_gh": case_mpc_pendulum_gauss_hermite,
     "mpc_fb_short": case_mpc_pendulum_short_targets,
+    "mpc_random": case_mpc_pendulum_random,
     "mpc_ff_lin": case_mpc_pendulum_linearize_ff,
     "em_quad": case_em_quadrotor,
     "mpc_quad": case_mpc_quadrotor,

@@ -61,7 +61,8 @@ def _replay(name, lib, device, tol, group_lanes=0):
 
 
 @pytest.mark.parametrize("name", ["mpc_pendulum_ff", "mpc_pendulum_fb", "mpc_pendulum_fb_general", "mpc_pendulum_fb_lin", "mpc_pendulum_ff_lin", "mpc_pendulum_fb_gh3",
-                                  "mpc_pendulum_fb_short_targets",
+                                  "mpc_pendulum_fb_short_targets", "mpc_pendulum_random0", "mpc_pendulum_random1", "mpc_pendulum_random2",
+                                  "mpc_pendulum_random3", "mpc_pendulum_random4", "mpc_pendulum_random5",
                                   "mpc_quadrotor_fb", "mpc_quad12_fb", "mpc_quad12_fb_lin"])
 def test_mpc_replay_cpu(name):
     _replay(name, hostsim.load(), "cpu", 1e-7)
@@ -69,7 +70,8 @@ def test_mpc_replay_cpu(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["mpc_pendulum_ff", "mpc_pendulum_fb", "mpc_pendulum_fb_general", "mpc_pendulum_fb_lin", "mpc_pendulum_ff_lin", "mpc_pendulum_fb_gh3",
-                                  "mpc_pendulum_fb_short_targets",
+                                  "mpc_pendulum_fb_short_targets", "mpc_pendulum_random0", "mpc_pendulum_random1", "mpc_pendulum_random2",
+                                  "mpc_pendulum_random3", "mpc_pendulum_random4", "mpc_pendulum_random5",
                                   "mpc_quadrotor_fb", "mpc_quad12_fb", "mpc_quad12_fb_lin"])
 def test_mpc_replay_gpu(name):
     _replay(name, None, "cuda", 1e-6)
