@@ -323,7 +323,8 @@ typedef struct I2cMpcStep {
   void* zpost;              /* optional */
   void* cell_stats;         /* as i2c_backward_sweep */
   void* term_stats;
-  const void* cell_init;    /* [e_post][B]: the cell appended at the end of the horizon (I2cCell.__init__ state) */
+  const void* cell_init;    /* one cell block in the layout of `post` ([e_post][B]; [B][e_post] with post_layout = 1): the cell
+                               appended at the end of the horizon (I2cCell.__init__ state), written by a block copy */
   const void* alpha_init;   /* [B]: temperature the appended cell keeps (NULL iff p->alpha_cell is NULL) */
   const void* z_new;        /* [nz][B] target of the appended cell, or NULL: the previous last cell's */
   void* action;             /* [nu + SYM(nu)][B] out, or NULL: cells[0].mu_u0_m, sig_u0_m before the shift */

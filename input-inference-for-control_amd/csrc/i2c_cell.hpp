@@ -1933,7 +1933,7 @@ I2C_HD inline void mpc_shift_body(const Consts<M, R>& c, const ShiftArgs<R>& a, 
   const long B = c.B;
   const int r0 = c.row(0), rl = c.row(c.T - 1);  // rows of the first and of the last cell of the current horizon
   const long es = c.post_es();
-  R* p0 = a.post + ((long)r0 * C::E_POST) * B + c.post_bo(b);
+  const R* p0 = a.post + ((long)r0 * C::E_POST) * B + c.post_bo(b);
   if (a.action) {
 #pragma unroll
     for (int i = 0; i < NU; ++i) a.action[(long)i * B + b] = p0[(long)(NX + i) * es];
@@ -1942,8 +1942,7 @@ I2C_HD inline void mpc_shift_body(const Consts<M, R>& c, const ShiftArgs<R>& a, 
 #pragma unroll
       for (int q = 0; q <= p; ++q) a.action[(long)(NU + tri(p, q)) * B + b] = p0[(long)(D + tri(NX + p, NX + q)) * es];
   }
-#pragma unroll
-  for (int e = 0; e < C::E_POST; ++e) p0[(long)e * es] = a.cell_init[(long)e * B + b];
+  // (the fresh cell itself -- cell_init, one cell block in the layout of `post` -- is a plain block copy: Impl::shift)
   if (a.alpha_cell) a.alpha_cell[(long)r0 * B + b] = a.alpha_init[b];
   if (a.z) {
 #pragma unroll

@@ -45,6 +45,10 @@ static int clear_bytes(void* p, size_t n, void*) {
   std::memset(p, 0, n);
   return I2C_OK;
 }
+static int copy_bytes(void* dst, const void* src, size_t n, void*) {
+  std::memcpy(dst, src, n);
+  return I2C_OK;
+}
 #else
 #define I2C_KERNEL(BLOCK) __global__ __launch_bounds__(BLOCK) void
 #define I2C_LANE_PARAMS
@@ -67,6 +71,9 @@ static int launch(K kernel, const long n, const int ny, const int block, void* s
 }
 static int clear_bytes(void* p, size_t n, void* stream) {
   return hipMemsetAsync(p, 0, n, (hipStream_t)stream) == hipSuccess ? I2C_OK : I2C_ELAUNCH;
+}
+static int copy_bytes(void* dst, const void* src, size_t n, void* stream) {
+  return hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? I2C_OK : I2C_ELAUNCH;
 }
 #endif
 
@@ -798,7 +805,7 @@ template <class M, typename R, typename S = R> struct Impl {
     for (int it = 0; it < m->n_iter && rc == I2C_OK; ++it) {
       rc = forward(p, m->post, m->fwd, nullptr, m->status, stream);
       if (rc == I2C_OK) rc = backward(p, m->fwd, m->xm, m->post, m->zpost, m->cell_stats, m->term_stats, m->status, stream);
-      if (rc == I2C_OK && m->tau > 0) rc = to_feedback(p, m->tau, stream);
+      if (rc == I2C_OK && m->tau > 0 && it == 0) rc = to_feedback(p, m->tau, stream);  // (idempotent within a step: _update_priors)
     }
     if (rc != I2C_OK) return rc;
     return shift(p, m->post, m->cell_init, m->alpha_init, m->z_new, m->action, stream);
@@ -811,7 +818,13 @@ template <class M, typename R, typename S = R> struct Impl {
     ShiftArgs<R> a{(R*)post, (const R*)cell_init, (R*)const_cast<void*>(p->alpha_cell), (const R*)alpha_init,
                    (R*)const_cast<void*>(p->z_per_cell ? p->z : nullptr), (const R*)z_new, const_cast<uint8_t*>(p->feedforward),
                    (R*)action};
-    return launch(k_mpc_shift<M, R>, p->B, 1, CELL_BLOCK, stream, c, a);
+    // the per-trajectory part (first action out, temperature, target, mode flag of the fresh cell), then the fresh cell: one
+    // contiguous block copy (a lane-per-trajectory loop over the e_post elements took 111 us at B = 1024 for the 12-state
+    // quadrotor: 230 dependent partial-line stores per lane -- a tenth of the control step)
+    int rc = launch(k_mpc_shift<M, R>, p->B, 1, CELL_BLOCK, stream, c, a);
+    if (rc == I2C_OK)
+      rc = copy_bytes((R*)post + (size_t)c.row(0) * C::E_POST * p->B, cell_init, (size_t)C::E_POST * p->B * sizeof(R), stream);
+    return rc;
   }
 
   static int rollout(const I2cProblem* p, const void* post, int n_rollouts, int policy, const void* eps_x0,

@@ -266,7 +266,7 @@ class BatchedI2c:
         self.alpha_cell = None      # [T][B] per-cell temperature, only in the MPC loop (see enable_per_cell_alpha)
         self.alpha_init = None
         self.terminal_cell = T - 1  # cell whose forward pass applies the terminal cost update (i2c.py:82,822)
-        self.cell_init = self.post[0].contiguous().clone()  # a fresh cell (I2cCell.__init__), appended by shift_horizon(); [e_post][B]
+        self.cell_init = self.post[0].clone()  # a fresh cell (I2cCell.__init__), appended by shift_horizon(): one cell block in the layout of post
         self.tau = T - 1  # i2c.py:833
         self._propagate = False
         self.use_expert_controller = True

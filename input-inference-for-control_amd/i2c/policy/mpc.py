@@ -29,7 +29,7 @@ class MpcPolicy:
         self.n_iter = n_iter
         self.set_control(True)  # mpc.py:21-22
         e.enable_per_cell_alpha()  # cell_init is copied NOW (mpc.py:26): appended cells carry today's sig_xi ...
-        e.cell_init = e.post[e.t0].contiguous().clone()  # ... and today's cells[0] (deepcopy(i2c.cells[0]), mpc.py:26), not the constructor's
+        e.cell_init = e.post[e.t0].clone()  # ... and today's cells[0] (deepcopy(i2c.cells[0]), mpc.py:26), not the constructor's
         self.z_traj = None if z_traj is None else np.asarray(z_traj, dtype=float)
         if self.z_traj is not None:
             zt = self.z_traj if self.z_traj.ndim == 3 else self.z_traj[None]
