@@ -1612,11 +1612,46 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
 #pragma unroll
     for (int e = 0; e < C::E_PRI; ++e) pri[e] = a.post[((long)c.row(0) * C::E_POST + e) * B + b];
   }
+  // The mode and expert flags of a cell are bytes in global memory: loaded at the top of their own cell they are dependent
+  // loads whose full latency -- plus, vmcnt being one in-order counter, the acknowledgement of the previous cell's stores and
+  // the arrival of the rows just requested -- is exposed EVERY cell (see forward_sweep_body). Fetched one cell ahead, and
+  // everything settled before the loop (a load pending on the loop-entry path makes the waitcnt pass wait for vmcnt(0) at the top).
+  unsigned ff_cur = a.ff[c.row(0)], ex_cur = a.expert ? (unsigned)a.expert[c.row(0)] : (unsigned)(c.use_expert != 0);
+  ff_cur = opaque(ff_cur);
+  ex_cur = opaque(ex_cur);
+  if (PREFETCH) {
+#pragma unroll
+    for (int e = 0; e < C::E_PRI; ++e) pri[e] = opaque(pri[e]);
+  }
+#pragma unroll
+  for (int i = 0; i < NX; ++i) mu_x[i] = opaque(mu_x[i]);
+#pragma unroll
+  for (int i = 0; i < sym(NX); ++i) sig_x[i] = opaque(sig_x[i]);
+  // The per-cell target too: a load behind a run-time branch in the middle of the cell leaves an s_waitcnt vmcnt(0) at the join,
+  // which every cell pays with the acknowledgement of the stores it has just issued. Small models: fetched a cell ahead and
+  // WITHOUT a branch (when there are no per-cell targets the loads read the trajectory's x0 row and are discarded).
+  constexpr bool ZPRE = PREFETCH && NZ <= NX * 4;
+  R zt_cur[ZPRE ? NZ : 1];
+  auto fetch_z = [&](const int row, R* zt) {
+    const R* src = c.z_per_cell ? a.z + ((long)row * NZ) * B + b : a.x0 + b;
+    const long st = c.z_per_cell ? B : 0;
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) {
+      const R v = src[(long)k * st];
+      zt[k] = c.z_per_cell ? v : c.zg[k];
+    }
+  };
+  if (ZPRE) {
+    fetch_z(c.row(0), zt_cur);
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) zt_cur[k] = opaque(zt_cur[k]);
+  }
   R sum_m = R(0), sum_v = R(0);
 
   for (int t = 0; t < T; ++t) {
     R nxt[PREFETCH ? C::E_PRI : 1];
-    const int tn = PREFETCH ? (t + 1 < T ? t + 1 : t) : t;
+    const int tn1 = t + 1 < T ? t + 1 : t;  // the next cell (flags), and where a second set of rows fits also its rows
+    const int tn = PREFETCH ? tn1 : t;
 #pragma unroll
     for (int e = 0; e < C::E_PRI; ++e)
       (PREFETCH ? nxt[PREFETCH ? e : 0] : pri[e]) = a.post[((long)c.row(tn) * C::E_POST + e) * B + b];
@@ -1627,14 +1662,19 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
     R mu0[D], S0[sym(D)], Kt[NU * NX], sig_u[sym(NU)];
 #pragma unroll
     for (int i = 0; i < NU * NX; ++i) Kt[i] = Kpost[i];
-    if (a.ff[c.row(t)]) {  // i2c.py:155-157: action marginal, but the joint still carries K sig_x (i2c.py:173-179)
+    const unsigned ff_now = ff_cur, ex_now = ex_cur;
+    R zt_nxt[ZPRE ? NZ : 1];
+    if (ZPRE) fetch_z(c.row(tn1), zt_nxt);
+    ff_cur = a.ff[c.row(tn1)];  // the next cell's flags, a whole cell ahead of their use
+    if (a.expert) ex_cur = a.expert[c.row(tn1)];
+    if (ff_now) {  // i2c.py:155-157: action marginal, but the joint still carries K sig_x (i2c.py:173-179)
 #pragma unroll
       for (int p = 0; p < NU; ++p)
 #pragma unroll
         for (int q = 0; q <= p; ++q) sig_u[tri(p, q)] = qsig[tri(NX + p, NX + q)];
       joint_from_gain<NX, NU>(mu_x, sig_x, Kt, mu_x, qmu + NX, sig_u, mu0, S0);
     } else {
-      if (a.expert ? a.expert[c.row(t)] != 0 : c.use_expert != 0) {  // i2c.py:160-167
+      if (ex_now != 0) {  // i2c.py:160-167
         R S[sym(NX)], delta[NX];
 #pragma unroll
         for (int i = 0; i < sym(NX); ++i) S[i] = qsig[i] + sig_x[i];
@@ -1669,7 +1709,7 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
     if (!chol<D>(L0, rinv)) set_status(a.status, b, 8, t);
     R zt[NZ], mz[NZ], Sz[sym(NZ)];
 #pragma unroll
-    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k];
+    for (int k = 0; k < NZ; ++k) zt[k] = ZPRE ? zt_cur[ZPRE ? k : 0] : (c.z_per_cell ? a.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k]);
     transform<GRID, M, ObsStruct<M>, D, NZ, false>(c.rule_xu, mu0, S0, L0, ObserveF<M, R>{c.params}, mz, Sz, (R*)nullptr);
     R cm, cv;
     gaussian_cost<NZ>(c.QR, c.qr_diag != 0, mz, Sz, zt, &cm, &cv);
@@ -1683,6 +1723,10 @@ I2C_HD inline void propagate_body(const Consts<M, R>& c, const PropArgs<R>& a, c
     for (int e = 0; e < NX; ++e) out[(long)(D + sym(D) + e) * B] = mu_x[e];
 #pragma unroll
     for (int e = 0; e < sym(NX); ++e) out[(long)(D + sym(D) + NX + e) * B] = sig_x[e];
+    if (ZPRE) {
+#pragma unroll
+      for (int k = 0; k < NZ; ++k) zt_cur[k] = zt_nxt[ZPRE ? k : 0];
+    }
     if (PREFETCH) {
 #pragma unroll
       for (int e = 0; e < C::E_PRI; ++e) pri[e] = nxt[PREFETCH ? e : 0];

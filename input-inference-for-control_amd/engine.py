@@ -481,10 +481,12 @@ class BatchedI2c:
         out = self.stats_out.clone()
         self.costs_m.append(out[2])
         self.costs_m_var.append(out[3])
+        ps = None
         if self._propagate:
-            self.costs_pf.append(self.prop_stats[0].clone())
-            self.costs_pf_var.append(self.prop_stats[1].clone())
-            self.alphas_pf.append(self._alpha_from_propagation())
+            ps = self.prop_stats.clone()  # ONE copy per iteration (cost mean, cost variance, terminal KL): the rows below are views
+            self.costs_pf.append(ps[0])
+            self.costs_pf_var.append(ps[1])
+            self.alphas_pf.append(ps[0] / float(self.nz * self.H))  # = _alpha_from_propagation()
         else:
             self.costs_pf.append(torch.full_like(out[2], -1.0))  # i2c.py:1065
         self.update_priors()
@@ -493,7 +495,7 @@ class BatchedI2c:
         if update_alpha:
             self._broadcast_alpha()
         if self.has_x_terminal:
-            self.kl_terms.append(self._terminal_kl())
+            self.kl_terms.append(ps[2].to(torch.float64) if (ps is not None and self.prop is not None) else self._terminal_kl())
 
     def learn_msgs(self):
         """One EM iteration (I2cGraph.learn_msgs, i2c.py:1238-1245)."""
