@@ -217,6 +217,7 @@ template <typename R> I2C_FN R wld(const Window& w, unsigned row_off, unsigned l
 template <typename R> I2C_FN void wst(const Window& w, unsigned row_off, unsigned lane_off, R v) {
   *reinterpret_cast<R*>(w.p + row_off + lane_off) = v;
 }
+I2C_FN unsigned wld_u8(const Window& w, unsigned off) { return *reinterpret_cast<const unsigned char*>(w.p + off); }
 #else
 struct Window {
   __amdgpu_buffer_rsrc_t r;
@@ -241,6 +242,9 @@ template <typename R> I2C_FN R wld(const Window& w, unsigned row_off, unsigned l
     return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b32(w.r, lane_off, uniform_u32(row_off), 0));
   }
 }
+// one byte through the buffer path (a global_load_ubyte next to buffer stores makes the waitcnt pass wait for vmcnt(0): it does
+// not count on FLAT-encoded and MUBUF operations returning in order with each other)
+I2C_FN unsigned wld_u8(const Window& w, unsigned off) { return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(w.r, off, 0, 0); }
 I2C_FN void wst(const Window& w, unsigned row_off, unsigned lane_off, double v) {
   typedef unsigned v2u __attribute__((ext_vector_type(2)));
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), w.r, lane_off, uniform_u32(row_off), 0);

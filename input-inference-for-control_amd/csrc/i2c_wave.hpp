@@ -446,6 +446,9 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
   // have been consumed), so that the memory round trip hides behind a cell's worth of work.
   R nx_pmu, nx_pj[4], nx_kt[4], nx_alpha, nx_zt;
   int nx_ff, nx_ex;
+  const Window ffw = make_window(a.ff, (unsigned long)T), exw = make_window(a.expert ? a.expert : a.ff, (unsigned long)T);
+  const Window alw = make_window(a.alpha_cell ? a.alpha_cell : a.alpha, (a.alpha_cell ? (unsigned long)T : 1ul) * B * sizeof(R));
+  const Window zw = make_window(c.z_per_cell ? a.z : a.x0, (c.z_per_cell ? (unsigned long)T * NZ : 1ul) * B * sizeof(R));  // (x0 row 0: a valid dummy)
   auto fetch_prior = [&](const int tc) {
     const int trc = c.row(tc);
     const WIO<R, S> pri = w_post_cell<R, S>(a.prior, C::E_POST, B, trc, b, c.post_tm != 0);
@@ -454,16 +457,30 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
     for (int v = 0; v < 4; ++v) nx_pj[v] = pri.ld(D + w_symidx(w.row(v), j));
 #pragma unroll
     for (int v = 0; v < 4; ++v) nx_kt[v] = v < NBX ? pri.ld(O_K + (jx ? 0 : j - NX) * NX + w.row(v)) : R(0);  // K^T columns (action lanes)
-    nx_alpha = a.alpha_cell ? a.alpha_cell[(long)trc * B + b] : alpha_traj;
-    nx_zt = c.z_per_cell ? a.z[((long)trc * NZ + j) * B + b] : kc.zg[j];
-    nx_ff = a.ff[trc];
-    nx_ex = LIN ? (a.expert ? (int)a.expert[trc] : c.use_expert) : 1;  // the sigma-point cell always scales the gain (i2c.py:366-375)
+    // (buffer loads without branches: a flat load -- global or LDS, picked at run time -- or a global load behind a branch
+    //  among buffer stores makes the waitcnt pass wait for vmcnt(0), i.e. for the acknowledgement of the cell's own stores)
+    nx_alpha = wld<R>(alw, 0u, a.alpha_cell ? (unsigned)(((unsigned long)trc * B + b) * sizeof(R)) : (unsigned)(b * sizeof(R)));
+    // (the per-cell target or a discarded dummy; the choice is made when the value is USED, a cell later: selecting it here would
+    //  wait for the load right after issuing it)
+    nx_zt = wld<R>(zw, 0u, c.z_per_cell ? (unsigned)((((unsigned long)trc * NZ + j) * B + b) * sizeof(R)) : (unsigned)(b * sizeof(R)));
+    nx_ff = (int)wld_u8(ffw, (unsigned)trc);
+    nx_ex = LIN ? (a.expert ? (int)wld_u8(exw, (unsigned)trc) : c.use_expert) : 1;  // the sigma-point cell always scales the gain (i2c.py:366-375)
   };
   fetch_prior(0);
+  // settled before the loop: with loads pending on the loop-entry path the waitcnt pass merges their queue positions with the
+  // back edge's (where a cell's stores are younger than its prefetch) and waits for vmcnt(0) -- the acknowledgement of the previous
+  // cell's stores -- at the top of EVERY cell (see forward_sweep_body)
+  nx_pmu = opaque(nx_pmu), nx_alpha = opaque(nx_alpha), nx_zt = opaque(nx_zt);
+  nx_ff = (int)opaque((unsigned)nx_ff), nx_ex = (int)opaque((unsigned)nx_ex);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) nx_pj[v] = opaque(nx_pj[v]), nx_kt[v] = opaque(nx_kt[v]);
+  mx = opaque(mx);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) sx[v] = opaque(sx[v]);
 
   for (int t = 0; t < T; ++t) {
     const WIO<R, S> out = w_fwd_cell<R, S>(a.fwd, C::E_FWD, B, t, b);
-    const R alpha = nx_alpha, zt = nx_zt, pmu = nx_pmu;
+    const R alpha = nx_alpha, zt = c.z_per_cell ? nx_zt : kc.zg[j], pmu = nx_pmu;
     const bool ff = w_uniform(nx_ff) != 0, scale_gain = w_uniform(nx_ex) != 0;
     R pj[4], kt[4];
 #pragma unroll
@@ -842,7 +859,11 @@ I2C_FN void w_fetch_fwd(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S
     f.s3f[v] = v < NBX ? fw.ld(O_S3 + w_symidx(w.row(v) < NX ? w.row(v) : 0, jxc)) : R(0);
     f.jt[v] = v < NBX ? fw.ld(O_J + j * NX + (w.row(v) < NX ? w.row(v) : 0)) : R(0);  // J^T
   }
-  f.zt = c.z_per_cell ? a.z[((long)c.row(tc) * NZ + j) * B + b] : kc.zg[j];
+  {  // the per-cell target or a discarded dummy, through the buffer path and without a branch (see forward_wave_body); the choice
+     // is made where the value is used (w_bwd_cell)
+    const Window zw = make_window(c.z_per_cell ? a.z : a.term_stats, (c.z_per_cell ? (unsigned long)c.T * NZ : 1ul) * B * sizeof(R));
+    f.zt = wld<R>(zw, 0u, c.z_per_cell ? (unsigned)((((unsigned long)c.row(tc) * NZ + j) * B + b) * sizeof(R)) : (unsigned)(b * sizeof(R)));
+  }
 }
 
 // One backward cell (i2c.py:574-608) given its forward rows and the smoothed next state (m3m column form, s3m accumulator
@@ -880,13 +901,14 @@ I2C_FN void w_bwd_cell(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>
     w_tn<NBX>(w, jt, p1, sg);
   }
   // posterior observation moments = the joint itself (identity observation, i2c.py:594-596) and their expected cost
-  w_cost_share(w, c.qr_diag != 0, kc.qr, 4, mu - f.zt, sg, pm, pv);
+  const R ztv = c.z_per_cell ? f.zt : kc.zg[j];
+  w_cost_share(w, c.qr_diag != 0, kc.qr, 4, mu - ztv, sg, pm, pv);
   *pa = R(0);
   if (LIN) {  // alpha statistic: the linearised marginal observation, block-diagonal in (x, u) (i2c.py:537-540)
     R sbd[4], pva;
 #pragma unroll
     for (int v = 0; v < 4; ++v) sbd[v] = ((w.row(v) < NX) == jx) ? sg[v] : R(0);
-    w_cost_share(w, c.qr_diag != 0, kc.qr, 4, mu - f.zt, sbd, pa, &pva);
+    w_cost_share(w, c.qr_diag != 0, kc.qr, 4, mu - ztv, sbd, pa, &pva);
   }
   // controller (i2c.py:600-608): with [W | Y] = chol(sig_xx)^-1 [I | sig_xu]:  K^T = W^T Y, sigK = sig_uu - Y^T Y
   {
@@ -950,6 +972,13 @@ I2C_HD inline void backward_wave_body(const Consts<M, R>& c, const KC& kc, const
   R acc_m = R(0), acc_v = R(0), acc_a = R(0);  // this lane's share of the cost sums over t (reduced once, after the walk)
   WFwdRow<R> nx;  // forward rows of a cell, fetched one cell ahead (see forward_wave_body)
   w_fetch_fwd<M, R, S>(c, kc, a, b, w, T - 1, nx);
+  // settled before the loop (see forward_wave_body: loads pending on the loop-entry path cost a vmcnt(0) in every cell)
+  nx.mu = opaque(nx.mu), nx.m3f = opaque(nx.m3f), nx.zt = opaque(nx.zt);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) nx.sg[v] = opaque(nx.sg[v]), nx.s3f[v] = opaque(nx.s3f[v]), nx.jt[v] = opaque(nx.jt[v]);
+  m3m = opaque(m3m);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) s3m[v] = opaque(s3m[v]);
   for (int t = T - 1; t >= 0; --t) {
     const WFwdRow<R> f = nx;
     w_fetch_fwd<M, R, S>(c, kc, a, b, w, t > 0 ? t - 1 : 0, nx);
