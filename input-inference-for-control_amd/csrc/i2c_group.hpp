@@ -732,7 +732,12 @@ I2C_FN R g_terminal_kl(const Grp<R, G>& g, const Consts<M, R>& c, const KC& kc, 
 // ------------------------------------------------------------------------------------------
 // Forward sweep (i2c.py:876-880 over :350-447): the group walks its trajectory through all T cells.
 // ------------------------------------------------------------------------------------------
-template <class M, typename R, int G, class KC>
+// LEANG: the common case fixed at compile time (one shared target, the trajectory's temperature, no joint-prior output, ring at
+// its origin). With the per-cell target behind a run-time branch in the MIDDLE of the cell, the s_waitcnt at the join waits for
+// vmcnt(0) in every cell -- the rows just prefetched and the acknowledgement of the stores just issued -- whether or not the
+// branch is taken (see propagate_body); the generic variant keeps that, both variants fetch flags and temperature through the
+// buffer path and settle the first prefetch before the loop.
+template <class M, typename R, int G, bool LEANG = false, class KC>
 I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const FwdArgs<R>& a, const int b,
                                       const Grp<R, G>& g_in) {
   using C = Consts<M, R>;
@@ -753,6 +758,11 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
   const int ru = is_u ? r - NX : 0;
   const R alpha_traj = a.alpha[b];
   int fail = 0;
+  const bool z_per_cell = LEANG ? false : c.z_per_cell != 0;
+  const R* const alpha_cell = LEANG ? nullptr : a.alpha_cell;
+  R* const prior_out = LEANG ? nullptr : a.prior_out;
+  const Window ffw = make_window(a.ff, (unsigned long)T);
+  const Window alw = make_window(alpha_cell ? alpha_cell : a.alpha, (alpha_cell ? (unsigned long)T : 1ul) * B * W);
 
   R mu_x[NX], sx[NX];
   g_gather<NX>(g, 0, a.x0[(long)rx * B + b], mu_x);
@@ -786,12 +796,20 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
     for (int j = 0; j < D; ++j) nx_prow[j] = pri.ldo(o_prow[j]);
 #pragma unroll
     for (int k = 0; k < NX; ++k) nx_Krow[k] = pri.ldo(o_K[k]);
-    nx_alpha = a.alpha_cell ? a.alpha_cell[(long)trc * B + b] : alpha_traj;
-    nx_ff = a.ff[trc];
+    nx_alpha = LEANG ? alpha_traj : wld<R>(alw, 0u, alpha_cell ? (unsigned)(((unsigned long)trc * B + b) * W) : bo);
+    nx_ff = wld_u8(ffw, (unsigned)trc);
   };
   if (PREFETCH) {
     const int r0 = g.r, rd0 = r0 < D ? r0 : D - 1;
     fetch_prior(0, rb0, rd0, rd0 * (rd0 + 1) / 2, (r0 >= NX && r0 < D) ? r0 - NX : 0);
+    // settled before the loop: loads pending on the loop-entry path cost an s_waitcnt vmcnt(0) at the top of every cell
+    nx_pmu_own = opaque(nx_pmu_own), nx_alpha = opaque(nx_alpha), nx_ff = opaque(nx_ff);
+#pragma unroll
+    for (int j = 0; j < D; ++j) nx_prow[j] = opaque(nx_prow[j]);
+#pragma unroll
+    for (int k = 0; k < NX; ++k) nx_Krow[k] = opaque(nx_Krow[k]);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) mu_x[j] = opaque(mu_x[j]), sx[j] = opaque(sx[j]);
   }
 
 #if defined(I2C_GROUP_STAMPS) && !defined(I2C_HOST_SIM)
@@ -850,8 +868,8 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
     }
     I2C_STAMP(1);  // joint prior
     if (PREFETCH) fetch_prior(t + 1 < T ? t + 1 : t, rb, rd, trd, ru);  // this cell's rows are consumed: the next cell's, a cell ahead
-    if (a.prior_out) {
-      const GIO<R> po = gio(a.prior_out + (unsigned long)t * (D + sym(D)) * B, D + sym(D), rb, bo);
+    if (prior_out) {
+      const GIO<R> po = gio(prior_out + (unsigned long)t * (D + sym(D)) * B, D + sym(D), rb, bo);
       po.st_if(r < D, r, g_sel<D>(mu0, r));
 #pragma unroll
       for (int j = 0; j < D; ++j)
@@ -878,7 +896,7 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
 #pragma unroll
       for (int l = 0; l < NZ; ++l) {
         szr[l] += alpha * kc.sig_xi0[rz * NZ + l];
-        mz[l] = (c.z_per_cell ? a.z[((long)tr * NZ + l) * B + b] : c.zg[l]) - mz[l];  // the innovation
+        mz[l] = (z_per_cell ? a.z[((long)tr * NZ + l) * B + b] : c.zg[l]) - mz[l];  // the innovation
       }
       cell_bad = flag_stage(cell_bad, g_kalman<D, NZ>(g, mu0, s0, mz, szr, sxz, &mu1_own), 2);
     }

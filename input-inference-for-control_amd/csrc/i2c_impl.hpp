@@ -220,7 +220,7 @@ enum { GK_FORWARD = 0, GK_BACKWARD = 1, GK_PROPAGATE = 2, GK_CKF = 3 };
 // FULLW: non-diagonal cost weights (only the sweeps that price the cost, backward and propagate, have that variant)
 template <int KIND, class M, typename R, int G, bool FULLW, class KC, class A>
 I2C_FN void group_body(const Consts<M, R>& c, const KC& kc, const A& a, const int b, const Grp<R, G>& g) {
-  if constexpr (KIND == GK_FORWARD) forward_group_body<M, R, G>(c, kc, a, b, g);
+  if constexpr (KIND == GK_FORWARD) forward_group_body<M, R, G, FULLW>(c, kc, a, b, g);  // (FULLW: the lean variant here)
   if constexpr (KIND == GK_BACKWARD) backward_group_body<M, R, G, FULLW>(c, kc, a, b, g);
   if constexpr (KIND == GK_PROPAGATE) propagate_group_body<M, R, G, FULLW>(c, kc, a, b, g);
   if constexpr (KIND == GK_CKF) ckf_group_body<M, R, G>(c, kc, a, b, g);
@@ -342,6 +342,9 @@ static int launch_group(const Consts<M, R>& c, const ZetaArg<M, R>* zeta, const 
   if constexpr (KIND == GK_BACKWARD || KIND == GK_PROPAGATE) {
     const bool fullw = !c.qr_diag || (KIND == GK_BACKWARD && c.has_Qf && !c.qf_diag);
     if (fullw) return launch_group_w<KIND, M, R, G, true>(c, zeta, a, stream);
+  }
+  if constexpr (KIND == GK_FORWARD) {  // the compile-time lean variant (forward_group_body)
+    if (!c.z_per_cell && !a.alpha_cell && !a.prior_out && c.t0 == 0) return launch_group_w<KIND, M, R, G, true>(c, zeta, a, stream);
   }
   return launch_group_w<KIND, M, R, G, false>(c, zeta, a, stream);
 }
