@@ -464,7 +464,7 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
     //  wait for the load right after issuing it)
     nx_zt = wld<R>(zw, 0u, c.z_per_cell ? (unsigned)((((unsigned long)trc * NZ + j) * B + b) * sizeof(R)) : (unsigned)(b * sizeof(R)));
     nx_ff = (int)wld_u8(ffw, (unsigned)trc);
-    nx_ex = LIN ? (a.expert ? (int)wld_u8(exw, (unsigned)trc) : c.use_expert) : 1;  // the sigma-point cell always scales the gain (i2c.py:366-375)
+    nx_ex = LIN ? (int)wld_u8(exw, (unsigned)trc) : 1;  // (Linearize: the per-cell flag or a discarded dummy, picked where it is used)
   };
   fetch_prior(0);
   // settled before the loop: with loads pending on the loop-entry path the waitcnt pass merges their queue positions with the
@@ -481,7 +481,8 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
   for (int t = 0; t < T; ++t) {
     const WIO<R, S> out = w_fwd_cell<R, S>(a.fwd, C::E_FWD, B, t, b);
     const R alpha = nx_alpha, zt = c.z_per_cell ? nx_zt : kc.zg[j], pmu = nx_pmu;
-    const bool ff = w_uniform(nx_ff) != 0, scale_gain = w_uniform(nx_ex) != 0;
+    // the sigma-point cell always scales the gain (i2c.py:366-375); Linearize: per-cell or graph-wide flag (i2c.py:259-265)
+    const bool ff = w_uniform(nx_ff) != 0, scale_gain = LIN ? (a.expert ? w_uniform(nx_ex) != 0 : c.use_expert != 0) : true;
     R pj[4], kt[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
