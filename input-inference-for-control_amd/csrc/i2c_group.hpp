@@ -775,8 +775,9 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
   // 29 doubles in flight push both sweeps into scratch and cost more than the round trip (measured: forward 1.45 -> 1.50 ms,
   // backward 0.62 -> 0.76 ms at B = 4096), so there the batch is loaded at the top of its own cell.
   constexpr bool PREFETCH = D <= 8;
-  R nx_pmu_own, nx_prow[D], nx_Krow[NX], nx_alpha;
+  R nx_pmu_own, nx_prow[D], nx_Krow[NX], nx_alpha, nx_zt[LEANG ? 1 : NZ];  // (nx_zt: per-cell targets, generic variant only)
   unsigned nx_ff;
+  const Window zw = make_window(z_per_cell ? a.z : a.x0, (z_per_cell ? (unsigned long)T * NZ : 1ul) * B * W);
   // byte offsets of this lane's prior rows inside a cell: the one piece of rank-dependent state that IS kept across the
   // time loop (29 dwords; recomputing them costs ~5 instructions per load in every cell)
   unsigned o_pmu, o_prow[D], o_K[NX];
@@ -798,6 +799,10 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
     for (int k = 0; k < NX; ++k) nx_Krow[k] = pri.ldo(o_K[k]);
     nx_alpha = LEANG ? alpha_traj : wld<R>(alw, 0u, alpha_cell ? (unsigned)(((unsigned long)trc * B + b) * W) : bo);
     nx_ff = wld_u8(ffw, (unsigned)trc);
+    if (!LEANG && z_per_cell) {  // with the rows, a cell ahead: a load behind this branch in MID-cell costs a vmcnt(0) at its join
+#pragma unroll
+      for (int l = 0; l < NZ; ++l) nx_zt[LEANG ? 0 : l] = wld<R>(zw, 0u, (unsigned)((((unsigned long)trc * NZ + l) * B + b) * W));
+    }
   };
   if (PREFETCH) {
     const int r0 = g.r, rd0 = r0 < D ? r0 : D - 1;
@@ -834,6 +839,11 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
     R pmu[D], prow[D], Krow[NX];
     const R pmu_own = nx_pmu_own, alpha = nx_alpha;
     const unsigned ff_cur = nx_ff;
+    R zt_cur[LEANG ? 1 : NZ];
+    if (!LEANG) {
+#pragma unroll
+      for (int l = 0; l < NZ; ++l) zt_cur[l] = nx_zt[l];
+    }
 #pragma unroll
     for (int j = 0; j < D; ++j) prow[j] = nx_prow[j];
 #pragma unroll
@@ -896,7 +906,7 @@ I2C_HD inline void forward_group_body(const Consts<M, R>& c, const KC& kc, const
 #pragma unroll
       for (int l = 0; l < NZ; ++l) {
         szr[l] += alpha * kc.sig_xi0[rz * NZ + l];
-        mz[l] = (z_per_cell ? a.z[((long)tr * NZ + l) * B + b] : c.zg[l]) - mz[l];  // the innovation
+        mz[l] = ((!LEANG && z_per_cell) ? zt_cur[LEANG ? 0 : l] : c.zg[l]) - mz[l];  // the innovation
       }
       cell_bad = flag_stage(cell_bad, g_kalman<D, NZ>(g, mu0, s0, mz, szr, sxz, &mu1_own), 2);
     }
