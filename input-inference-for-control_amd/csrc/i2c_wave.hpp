@@ -862,7 +862,8 @@ I2C_FN void w_fetch_fwd(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S
   }
   {  // the per-cell target or a discarded dummy, through the buffer path and without a branch (see forward_wave_body); the choice
      // is made where the value is used (w_bwd_cell)
-    const Window zw = make_window(c.z_per_cell ? a.z : a.term_stats, (c.z_per_cell ? (unsigned long)c.T * NZ : 1ul) * B * sizeof(R));
+    // (the dummy: the first B doubles of the forward-message buffer, which this sweep only reads)
+    const Window zw = make_window(c.z_per_cell ? (const void*)a.z : (const void*)a.fwd, (c.z_per_cell ? (unsigned long)c.T * NZ : 1ul) * B * sizeof(R));
     f.zt = wld<R>(zw, 0u, c.z_per_cell ? (unsigned)((((unsigned long)c.row(tc) * NZ + j) * B + b) * sizeof(R)) : (unsigned)(b * sizeof(R)));
   }
 }
