@@ -322,9 +322,42 @@ I2C_HD inline void backward_lin_body(const Consts<M, R>& c, const CellArgs<R>& a
   }
   a.term_stats[b] = trT;
 
+  // The forward rows (and the per-cell target) of a cell are fetched one cell ahead where a second set of registers fits
+  // (see chunk_walk_body / propagate_body: loaded at the top of their own cell, their round trip -- and, vmcnt being one in-order
+  // counter, the acknowledgement of the previous cell's stores -- is exposed in every cell; a target behind a branch in mid-cell
+  // costs a vmcnt(0) at its join). The first set is settled before the loop.
+  constexpr bool PRE = C::D <= 5;
+  R row[PRE ? C::E_FWD : 1], zt_cur[PRE ? NZ : 1];
+  auto fetch_z = [&](const int r, R* zt) {  // branch-free: without per-cell targets the loads re-read fwd and are discarded
+    const R* src = c.z_per_cell ? a.z + ((long)r * NZ) * B + b : a.fwd + b;
+    const long st = c.z_per_cell ? B : 0;
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) {
+      const R v = src[(long)k * st];
+      zt[k] = c.z_per_cell ? v : c.zg[k];
+    }
+  };
+  if (PRE) {
+    const R* in0 = a.fwd + ((long)(T - 1) * C::E_FWD) * B + b;
+#pragma unroll
+    for (int e = 0; e < C::E_FWD; ++e) row[e] = opaque(in0[(long)e * B]);
+    fetch_z(c.row(T - 1), zt_cur);
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) zt_cur[k] = opaque(zt_cur[k]);
+  }
   R sum_a = R(0), sum_m = R(0), sum_v = R(0);
   for (int t = T - 1; t >= 0; --t) {
+    R cur[PRE ? C::E_FWD : 1], nxt[PRE ? C::E_FWD : 1], zt_nxt[PRE ? NZ : 1];
+    if (PRE) {
+#pragma unroll
+      for (int e = 0; e < C::E_FWD; ++e) cur[e] = row[e];
+      const R* inn = a.fwd + ((long)(t > 0 ? t - 1 : 0) * C::E_FWD) * B + b;
+#pragma unroll
+      for (int e = 0; e < C::E_FWD; ++e) nxt[e] = inn[(long)e * B];
+      fetch_z(c.row(t > 0 ? t - 1 : 0), zt_nxt);
+    }
     const R* in = a.fwd + ((long)t * C::E_FWD) * B + b;
+    auto ld = [&](const int e) { return PRE ? cur[PRE ? e : 0] : in[(long)e * B]; };
     if (a.xm) {
       R* xo = const_cast<R*>(a.xm) + ((long)t * C::E_XM) * B + b;
 #pragma unroll
@@ -334,17 +367,17 @@ I2C_HD inline void backward_lin_body(const Consts<M, R>& c, const CellArgs<R>& a
     }
     R mu[D], S[sym(D)], J[D * NX], dm[NX], dS[sym(NX)], zt[NZ];
 #pragma unroll
-    for (int e = 0; e < D; ++e) mu[e] = in[(long)e * B];
+    for (int e = 0; e < D; ++e) mu[e] = ld(e);
 #pragma unroll
-    for (int e = 0; e < sym(D); ++e) S[e] = in[(long)(D + e) * B];
+    for (int e = 0; e < sym(D); ++e) S[e] = ld(D + e);
 #pragma unroll
-    for (int e = 0; e < NX; ++e) dm[e] = m3m[e] - in[(long)(O_MU3 + e) * B];
+    for (int e = 0; e < NX; ++e) dm[e] = m3m[e] - ld(O_MU3 + e);
 #pragma unroll
-    for (int e = 0; e < sym(NX); ++e) dS[e] = S3m[e] - in[(long)(O_S3 + e) * B];
+    for (int e = 0; e < sym(NX); ++e) dS[e] = S3m[e] - ld(O_S3 + e);
 #pragma unroll
-    for (int e = 0; e < D * NX; ++e) J[e] = in[(long)(O_J + e) * B];
+    for (int e = 0; e < D * NX; ++e) J[e] = ld(O_J + e);
 #pragma unroll
-    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k];
+    for (int k = 0; k < NZ; ++k) zt[k] = PRE ? zt_cur[PRE ? k : 0] : (c.z_per_cell ? a.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k]);
 
     // RTS update, controller and the cubature cost of the posterior (shared with the sigma-point path)
     R ctl[C::E_POST - D - sym(D)], mzq[NZ], Szq[sym(NZ)], cm, cv;
@@ -375,6 +408,12 @@ I2C_HD inline void backward_lin_body(const Consts<M, R>& c, const CellArgs<R>& a
     for (int i = 0; i < NX; ++i) m3m[i] = mu[i];
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) S3m[i] = S[i];
+    if (PRE) {
+#pragma unroll
+      for (int e = 0; e < C::E_FWD; ++e) row[e] = nxt[e];
+#pragma unroll
+      for (int k = 0; k < NZ; ++k) zt_cur[k] = zt_nxt[k];
+    }
   }
   a.term_stats[B + b] = sum_a;
   a.term_stats[2 * B + b] = sum_v;
