@@ -120,37 +120,77 @@ I2C_HD inline void forward_lin_body(const Consts<M, R>& c, const FwdArgs<R>& a, 
 #pragma unroll
   for (int i = 0; i < sym(NX); ++i) sig_x[i] = a.sig_x0[(long)i * B + b];
   const R alpha_traj = a.alpha[b];
+  // Small models: everything a cell reads that does not depend on the recursion -- its prior rows, temperature, target, mode and
+  // expert flags -- is fetched ONE CELL AHEAD, without branches (a discarded dummy where an option is off, the choice made where
+  // the value is used), and the first set is settled before the loop (see propagate_body / DESIGN.md "Waits on memory").
+  constexpr bool PRE = C::D <= 5;
+  struct Pre {
+    R pri[PRE ? C::E_PRI : 1], zt[PRE ? NZ : 1], alpha;
+    unsigned ff, ex;
+  } nx;
+  auto fetch = [&](const int row, Pre& f) {
+    const R* pr = a.prior + ((long)row * C::E_POST) * B + b;
+#pragma unroll
+    for (int e = 0; e < C::E_PRI; ++e) f.pri[e] = pr[(long)e * B];
+    f.alpha = (a.alpha_cell ? a.alpha_cell + (long)row * B : a.alpha)[b];
+    const R* zs = c.z_per_cell ? a.z + ((long)row * NZ) * B + b : a.x0 + b;
+    const long zst = c.z_per_cell ? B : 0;
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) f.zt[k] = zs[(long)k * zst];
+    f.ff = a.ff[row];
+    f.ex = (a.expert ? a.expert : a.ff)[row];
+  };
+  if (PRE) {
+    fetch(c.row(0), nx);
+#pragma unroll
+    for (int e = 0; e < C::E_PRI; ++e) nx.pri[e] = opaque(nx.pri[e]);
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) nx.zt[k] = opaque(nx.zt[k]);
+    nx.alpha = opaque(nx.alpha), nx.ff = opaque(nx.ff), nx.ex = opaque(nx.ex);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) mu_x[i] = opaque(mu_x[i]);
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) sig_x[i] = opaque(sig_x[i]);
+  }
 
   for (int t = 0; t < T; ++t) {
     const int tr = c.row(t);  // row of the persistent per-cell buffers (ring of the MPC loop, Consts::t0)
-    const R* pri = a.prior + ((long)tr * C::E_POST) * B + b;
+    const R* pri_g = a.prior + ((long)tr * C::E_POST) * B + b;
     R* out = a.fwd + ((long)t * C::E_FWD) * B + b;
-    const R alpha = a.alpha_cell ? a.alpha_cell[(long)tr * B + b] : alpha_traj;
+    Pre cur;
+    if (PRE) {
+      cur = nx;
+      fetch(c.row(t + 1 < T ? t + 1 : t), nx);
+    }
+    auto pri = [&](const int e) { return PRE ? cur.pri[PRE ? e : 0] : pri_g[(long)e * B]; };
+    const R alpha = PRE ? cur.alpha : (a.alpha_cell ? a.alpha_cell[(long)tr * B + b] : alpha_traj);
+    const bool ff_now = PRE ? cur.ff != 0 : a.ff[tr] != 0;
+    const bool ex_now = a.expert ? (PRE ? cur.ex != 0 : a.expert[tr] != 0) : c.use_expert != 0;
     R zt[NZ];
 #pragma unroll
-    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)tr * NZ + k) * B + b] : c.zg[k];
+    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? (PRE ? cur.zt[PRE ? k : 0] : a.z[((long)tr * NZ + k) * B + b]) : c.zg[k];
 
     // ---- 1. joint prior over (x, u) (i2c.py:249-276) ----
     R mu0[D], S0[sym(D)];
-    if (a.ff[tr]) {
+    if (ff_now) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) mu0[i] = mu_x[i];
 #pragma unroll
-      for (int i = NX; i < D; ++i) mu0[i] = pri[(long)i * B];
+      for (int i = NX; i < D; ++i) mu0[i] = pri(i);
 #pragma unroll
       for (int i = 0; i < D; ++i)
 #pragma unroll
         for (int j = 0; j <= i; ++j)
-          S0[tri(i, j)] = (i < NX) ? sig_x[tri(i, j)] : (j >= NX ? pri[(long)(D + tri(i, j)) * B] : R(0));
+          S0[tri(i, j)] = (i < NX) ? sig_x[tri(i, j)] : (j >= NX ? pri(D + tri(i, j)) : R(0));
     } else {
       R pmu[D], psig[sym(D)], Kt[NU * NX];
 #pragma unroll
-      for (int i = 0; i < D; ++i) pmu[i] = pri[(long)i * B];
+      for (int i = 0; i < D; ++i) pmu[i] = pri(i);
 #pragma unroll
-      for (int i = 0; i < sym(D); ++i) psig[i] = pri[(long)(D + i) * B];
+      for (int i = 0; i < sym(D); ++i) psig[i] = pri(D + i);
 #pragma unroll
-      for (int i = 0; i < NU * NX; ++i) Kt[i] = pri[(long)(D + sym(D) + i) * B];
-      if (a.expert ? a.expert[tr] != 0 : c.use_expert != 0) {
+      for (int i = 0; i < NU * NX; ++i) Kt[i] = pri(D + sym(D) + i);
+      if (ex_now) {
         R S[sym(NX)], delta[NX];
 #pragma unroll
         for (int i = 0; i < sym(NX); ++i) S[i] = psig[i] + sig_x[i];
