@@ -1206,8 +1206,12 @@ I2C_FN void reduce_partial(const Consts<M, R>& c, const R* cell_stats, const int
 // the whole cell; each forward row is read once and the cost sums stay in registers, so the pass
 // moves E_FWD + E_POST elements per cell instead of the two-pass form's ~2x that.
 // ------------------------------------------------------------------------------------------
-template <class M, typename R, bool GRID = false, typename S_ = R>
-I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R, S_>& a, const int b) {
+// LEANW: as in chunk_walk_body (no optional outputs, one shared target: a compile-time count of the memory operations of a cell).
+template <class M, typename R, bool GRID = false, typename S_ = R, bool LEANW = false>
+I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R, S_>& a_in, const int b) {
+  CellArgs<R, S_> a = a_in;
+  if (LEANW) a.xm = nullptr, a.zpost = nullptr, a.cell_stats = nullptr;
+  const bool z_per_cell = LEANW ? false : c.z_per_cell != 0;
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NZ = C::NZ, D = C::D;
   constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
@@ -1217,13 +1221,27 @@ I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R, 
   const unsigned bo = (unsigned)b * W, rb = (unsigned)(B * W);
 
   constexpr bool DOUBLE_BUFFER = C::D <= 5;  // see chunk_walk_body
+  constexpr bool VOFF = LEANW && !GRID && C::D <= 5;  // row offsets in VGPRs, sincos table in registers (chunk_walk_body)
+  constexpr int NOFF = C::E_FWD > C::E_POST ? C::E_FWD : C::E_POST;
+  unsigned voff[VOFF ? NOFF : 1];
+  if (VOFF) {
+#pragma unroll
+    for (int e = 0; e < NOFF; ++e) voff[e] = bo + (unsigned)e * rb;
+  }
+  PolyTab<R> ptab;
+  if (VOFF) poly_tab_init(ptab);
+  const PolyTab<R>* const tab = VOFF ? &ptab : nullptr;
   R row[C::E_FWD], nxt[DOUBLE_BUFFER ? C::E_FWD : 1];
   R m3m[NX], S3m[sym(NX)];
   {
     const Window w = make_window(a.fwd + (unsigned long)(T - 1) * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
     if (DOUBLE_BUFFER) {
 #pragma unroll
-      for (int e = 0; e < C::E_FWD; ++e) row[e] = (R)wld<S_>(w, e * rb, bo);
+      for (int e = 0; e < C::E_FWD; ++e) row[e] = (R)wld<S_>(w, VOFF ? 0u : e * rb, VOFF ? voff[e] : bo);
+      if (LEANW) {  // settled before the loop (chunk_walk_body)
+#pragma unroll
+        for (int e = 0; e < C::E_FWD; ++e) row[e] = opaque(row[e]);
+      }
       end_of_chain<M, R>(c, a.temp, b, row + O_MU3, row + O_S3, m3m, S3m, a.status);
     } else {
       // Only the filtered terminal state here: the loop below loads EVERY cell's row at the top of its own cell, the last
@@ -1245,7 +1263,7 @@ I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R, 
       const int tp = t > 0 ? t - 1 : 0;
       const Window w = make_window(a.fwd + (unsigned long)tp * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
-      for (int e = 0; e < C::E_FWD; ++e) nxt[DOUBLE_BUFFER ? e : 0] = (R)wld<S_>(w, e * rb, bo);
+      for (int e = 0; e < C::E_FWD; ++e) nxt[DOUBLE_BUFFER ? e : 0] = (R)wld<S_>(w, VOFF ? 0u : e * rb, VOFF ? voff[e] : bo);
     } else {
       const Window w = make_window(a.fwd + (unsigned long)t * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
 #pragma unroll
@@ -1264,12 +1282,12 @@ I2C_HD inline void backward_fused_body(const Consts<M, R>& c, const CellArgs<R, 
 #pragma unroll
     for (int i = 0; i < sym(NX); ++i) dS[i] = S3m[i] - row[O_S3 + i];
 #pragma unroll
-    for (int k = 0; k < NZ; ++k) zt[k] = c.z_per_cell ? a.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k];
+    for (int k = 0; k < NZ; ++k) zt[k] = z_per_cell ? a.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k];
     R* mu = row;
     R* S = row + D;
     R ctl[C::E_POST - D - sym(D)], mz[NZ], Sz[sym(NZ)], cm, cv;
-    if (!cell_posterior<M, R, GRID>(c, zt, mu, S, row + O_J, dm, dS, ctl, mz, Sz, &cm, &cv)) set_status(a.status, b, 7, t);
-    store_cell<M, R, S_>(c, a, t, b, mu, S, ctl, mz, Sz, cm, cv);
+    if (!cell_posterior<M, R, GRID>(c, zt, mu, S, row + O_J, dm, dS, ctl, mz, Sz, &cm, &cv, tab)) set_status(a.status, b, 7, t);
+    store_cell<M, R, S_>(c, a, t, b, mu, S, ctl, mz, Sz, cm, cv, VOFF ? voff : nullptr);
     sum_m += cm;
     sum_v += cv;
 #pragma unroll

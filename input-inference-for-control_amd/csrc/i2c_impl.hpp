@@ -104,10 +104,10 @@ I2C_KERNEL(CELL_BLOCK) k_cell(I2C_LANE_PARAMS const Consts<M, R> c, const CellAr
   const long b = I2C_LANE_X(CELL_BLOCK);
   if (b < c.B) backward_cell_body<M, R, S>(c, a, I2C_LANE_Y, (int)b);
 }
-template <class M, typename R, bool GRID = false, typename S = R>
+template <class M, typename R, bool GRID = false, typename S = R, bool LEANW = false>
 I2C_KERNEL(SWEEP_BLOCK) k_bwd_fused(I2C_LANE_PARAMS const Consts<M, R> c, const CellArgs<R, S> a) {
   const long b = I2C_LANE_X(SWEEP_BLOCK);
-  if (b < c.B) backward_fused_body<M, R, GRID, S>(c, a, (int)b);
+  if (b < c.B) backward_fused_body<M, R, GRID, S, LEANW>(c, a, (int)b);
 }
 template <class M, typename R, typename S = R>
 I2C_KERNEL(SWEEP_BLOCK) k_chunk_compose(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, S> a) {
@@ -695,7 +695,11 @@ template <class M, typename R, typename S = R> struct Impl {
                            void* stream) {
     if constexpr (LANE) {
       const int mode = pick_mode(p);
-      if (mode == I2C_BWD_FUSED) return launch(k_bwd_fused<M, R, false, S>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+      if (mode == I2C_BWD_FUSED) {
+        const bool lean = I2C_WALK_LEAN && !a.xm && !a.zpost && !a.cell_stats && !c.z_per_cell;  // see chunk_walk_body
+        return lean ? launch(k_bwd_fused<M, R, false, S, true>, p->B, 1, SWEEP_BLOCK, stream, c, a)
+                    : launch(k_bwd_fused<M, R, false, S>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+      }
       if (mode == I2C_BWD_CHUNKED) {
         ChunkArgs<R, S> ch{a, nullptr, nullptr, nullptr, 0, 0};
         chunk_geometry(p->B, p->T, &ch.n_chunks, &ch.chunk_len);
