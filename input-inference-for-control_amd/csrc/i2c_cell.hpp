@@ -1316,7 +1316,7 @@ template <typename R, typename S_ = R> struct ChunkArgs {
   CellArgs<R, S_> cell;  // fwd, xm (optional out), z, post, zpost, cell_stats (optional out), term_stats, temp, status
   R* comp;           // [NC][NX + NX*NX + sym(NX)][B]  composite maps
   R* bnd;            // [NC][NX + sym(NX)][B]          smoothed state entering each chunk
-  R* part;           // [NC][2][B]                     per-chunk cost sums
+  R* part;           // [NC][2][B]                     per-chunk cost sums ([NC][3][B] in the Linearize form)
   int n_chunks, chunk_len;
 };
 

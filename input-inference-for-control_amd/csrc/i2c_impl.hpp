@@ -127,6 +127,19 @@ I2C_KERNEL(SWEEP_BLOCK) k_chunk_walk(I2C_LANE_PARAMS const Consts<M, R> c, const
   const long b = I2C_LANE_X(SWEEP_BLOCK);
   if (b < c.B) chunk_walk_body<M, R, S, LEANW>(c, a, I2C_LANE_Y, (int)b);
 }
+template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_chunk_stitch_lin(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, R> a) {
+  const long b = I2C_LANE_X(SWEEP_BLOCK);
+  if (b < c.B) chunk_stitch_lin_body<M, R>(c, a, (int)b);
+}
+template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_chunk_walk_lin(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, R> a) {
+  const long b = I2C_LANE_X(SWEEP_BLOCK);
+  if (b < c.B) chunk_walk_lin_body<M, R>(c, a, I2C_LANE_Y, (int)b);
+}
+template <class M, typename R>
+I2C_KERNEL(SWEEP_BLOCK) k_chunk_reduce_lin(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, R> a, const MstepArgs<R> ms) {
+  const long b = I2C_LANE_X(SWEEP_BLOCK);
+  if (b < c.B) chunk_reduce_lin_body<M, R>(c, a, ms, (int)b);
+}
 template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_mstep(I2C_LANE_PARAMS const Consts<M, R> c, const MstepArgs<R> a) {
   const long b = I2C_LANE_X(SWEEP_BLOCK);
   if (b < c.B) mstep_body<M, R>(c, a, (int)b);
@@ -440,7 +453,7 @@ template <class M> static size_t workspace_elems(int B, int T) {
   int nc, len;
   chunk_geometry(B, T, &nc, &len);
   constexpr int NX = M::NX;
-  return (size_t)nc * (size_t)B * (size_t)((NX + NX * NX + sym(NX)) + (NX + sym(NX)) + 2);
+  return (size_t)nc * (size_t)B * (size_t)((NX + NX * NX + sym(NX)) + (NX + sym(NX)) + 3);  // (3: the Linearize form's partial sums)
 }
 
 // ---- per-(model, dtype) entry points ------------------------------------------------------
@@ -680,8 +693,24 @@ template <class M, typename R, typename S = R> struct Impl {
       if constexpr (HAS_GROUP) return launch_group<GK_BACKWARD, M, R, G>(c, nullptr, a, stream);
     }
     if constexpr (LANE) {
-      if (p->inference == I2C_INF_LINEARIZE) {  // one schedule: a lane per trajectory walks T-1..0
+      if (p->inference == I2C_INF_LINEARIZE) {  // a lane per trajectory walks T-1..0, or (small batches) the chunked form
         if (M::NZT == 0) return I2C_EINVAL;     // no terminal observation: the reference fails at i2c.py:500-501
+        if constexpr (!MIXED) {
+          if (pick_mode(p) == I2C_BWD_CHUNKED) {  // (pick_mode: asked for or the default below I2C_BWD_FUSED_MIN_B, with a workspace)
+            ChunkArgs<R, R> ch{a, nullptr, nullptr, nullptr, 0, 0};
+            chunk_geometry(p->B, p->T, &ch.n_chunks, &ch.chunk_len);
+            constexpr int NX = M::NX;
+            ch.comp = (R*)p->work;
+            ch.bnd = ch.comp + (size_t)ch.n_chunks * (NX + NX * NX + sym(NX)) * p->B;
+            ch.part = ch.bnd + (size_t)ch.n_chunks * (NX + sym(NX)) * p->B;
+            int rc = launch(k_chunk_compose<M, R, R>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
+            if (rc == I2C_OK) rc = launch(k_chunk_stitch_lin<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, ch);
+            if (rc == I2C_OK) rc = launch(k_chunk_walk_lin<M, R>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
+            if (rc == I2C_OK) rc = launch(k_chunk_reduce_lin<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, ch, ms);
+            if (fuse) fuse->done = true;
+            return rc;
+          }
+        }
         return launch(k_bwd_lin<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, a);
       }
       if (p->inference == I2C_INF_GAUSS_HERMITE)  // one schedule: the fused walk with the grid transform

@@ -272,16 +272,17 @@ I2C_HD inline void forward_lin_body(const Consts<M, R>& c, const FwdArgs<R>& a, 
 // plan cost is evaluated with the graph's cubature transform (i2c.py:841-844, 1034-1053).
 // term_stats rows: 0 = terminal trace, 1 = sum_t alpha statistic, 2 = sum_t cost variance, last = sum_t cost mean.
 // ------------------------------------------------------------------------------------------
+// End of the chain of the Linearize backward sweep (i2c.py:453-501): the smoothed terminal state (m3m, S3m) -- pinned by a terminal
+// state prior, or updated by the terminal cost observation, or the filtered one -- and the terminal observation statistics
+// (term_stats rows 0, 3..).
 template <class M, typename R>
-I2C_HD inline void backward_lin_body(const Consts<M, R>& c, const CellArgs<R>& a, const int b) {
+I2C_FN void lin_end_of_chain(const Consts<M, R>& c, const CellArgs<R>& a, const int b, R* m3m, R* S3m) {
   using C = Consts<M, R>;
-  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, D = C::D, NZT = C::NZT, NT = C::NZT1;
-  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  constexpr int NX = C::NX, D = C::D, NZT = C::NZT, NT = C::NZT1;
+  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX;
   const long B = c.B;
   const int T = c.T;
   const R alpha = a.alpha[b];
-
-  R m3m[NX], S3m[sym(NX)];
   {
     const R* in = a.fwd + ((long)(T - 1) * C::E_FWD) * B + b;
 #pragma unroll
@@ -362,6 +363,83 @@ I2C_HD inline void backward_lin_body(const Consts<M, R>& c, const CellArgs<R>& a
   }
   a.term_stats[b] = trT;
 
+}
+
+// One cell of the Linearize backward sweep (i2c.py:503-542) given its forward row `ld(e)`, its target zt and the smoothed next
+// state, which it replaces by this cell's; adds the cell's alpha statistic, plan cost and cost variance to the sums.
+template <class M, typename R, class LD>
+I2C_FN void lin_backward_cell(const Consts<M, R>& c, const CellArgs<R>& a, const int t, const int b, const LD& ld, const R* zt_in,
+                              R* m3m, R* S3m, R& sum_a, R& sum_m, R& sum_v) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NZ = C::NZ, D = C::D;
+  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  const long B = c.B;
+  {
+    if (a.xm) {
+      R* xo = const_cast<R*>(a.xm) + ((long)t * C::E_XM) * B + b;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xo[(long)i * B] = m3m[i];
+#pragma unroll
+      for (int i = 0; i < sym(NX); ++i) xo[(long)(NX + i) * B] = S3m[i];
+    }
+    R mu[D], S[sym(D)], J[D * NX], dm[NX], dS[sym(NX)], zt[NZ];
+#pragma unroll
+    for (int e = 0; e < D; ++e) mu[e] = ld(e);
+#pragma unroll
+    for (int e = 0; e < sym(D); ++e) S[e] = ld(D + e);
+#pragma unroll
+    for (int e = 0; e < NX; ++e) dm[e] = m3m[e] - ld(O_MU3 + e);
+#pragma unroll
+    for (int e = 0; e < sym(NX); ++e) dS[e] = S3m[e] - ld(O_S3 + e);
+#pragma unroll
+    for (int e = 0; e < D * NX; ++e) J[e] = ld(O_J + e);
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) zt[k] = zt_in[k];
+
+    // RTS update, controller and the cubature cost of the posterior (shared with the sigma-point path)
+    R ctl[C::E_POST - D - sym(D)], mzq[NZ], Szq[sym(NZ)], cm, cv;
+    if (!cell_posterior<M, R>(c, zt, mu, S, J, dm, dS, ctl, mzq, Szq, &cm, &cv)) set_status(a.status, b, 7, t);
+
+    // linearised marginal observation (i2c.py:537-540): block-diagonal use of the posterior covariance
+    R mz[NZ], Sz[sym(NZ)], CD[NZ * D];
+    value_and_jacobian<M, FN_OBSERVE, D, NZ, R>(c.params, mu, mz, CD);
+#pragma unroll
+    for (int k = 0; k < NZ; ++k)
+#pragma unroll
+      for (int l = 0; l <= k; ++l) {
+        R v = R(0);
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+          for (int j = 0; j < D; ++j)
+            if ((i < NX) == (j < NX)) v += CD[k * D + i] * S[tri_any(i, j)] * CD[l * D + j];
+        Sz[tri(k, l)] = v;
+      }
+    R ca, cva;
+    gaussian_cost<NZ>(c.QR, c.qr_diag != 0, mz, Sz, zt, &ca, &cva);
+    store_cell<M, R>(c, a, t, b, mu, S, ctl, mz, Sz, cm, cv);
+    sum_a += ca;
+    sum_m += cm;
+    sum_v += cv;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) m3m[i] = mu[i];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) S3m[i] = S[i];
+  }
+}
+
+template <class M, typename R>
+I2C_HD inline void backward_lin_body(const Consts<M, R>& c, const CellArgs<R>& a, const int b) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, D = C::D, NZT = C::NZT, NT = C::NZT1;
+  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  const long B = c.B;
+  const int T = c.T;
+  const R alpha = a.alpha[b];
+
+  R m3m[NX], S3m[sym(NX)];
+  lin_end_of_chain<M, R>(c, a, b, m3m, S3m);
+
   // The forward rows (and the per-cell target) of a cell are fetched one cell ahead where a second set of registers fits
   // (see chunk_walk_body / propagate_body: loaded at the top of their own cell, their round trip -- and, vmcnt being one in-order
   // counter, the acknowledgement of the previous cell's stores -- is exposed in every cell; a target behind a branch in mid-cell
@@ -398,56 +476,10 @@ I2C_HD inline void backward_lin_body(const Consts<M, R>& c, const CellArgs<R>& a
     }
     const R* in = a.fwd + ((long)t * C::E_FWD) * B + b;
     auto ld = [&](const int e) { return PRE ? cur[PRE ? e : 0] : in[(long)e * B]; };
-    if (a.xm) {
-      R* xo = const_cast<R*>(a.xm) + ((long)t * C::E_XM) * B + b;
+    R ztc[NZ];
 #pragma unroll
-      for (int i = 0; i < NX; ++i) xo[(long)i * B] = m3m[i];
-#pragma unroll
-      for (int i = 0; i < sym(NX); ++i) xo[(long)(NX + i) * B] = S3m[i];
-    }
-    R mu[D], S[sym(D)], J[D * NX], dm[NX], dS[sym(NX)], zt[NZ];
-#pragma unroll
-    for (int e = 0; e < D; ++e) mu[e] = ld(e);
-#pragma unroll
-    for (int e = 0; e < sym(D); ++e) S[e] = ld(D + e);
-#pragma unroll
-    for (int e = 0; e < NX; ++e) dm[e] = m3m[e] - ld(O_MU3 + e);
-#pragma unroll
-    for (int e = 0; e < sym(NX); ++e) dS[e] = S3m[e] - ld(O_S3 + e);
-#pragma unroll
-    for (int e = 0; e < D * NX; ++e) J[e] = ld(O_J + e);
-#pragma unroll
-    for (int k = 0; k < NZ; ++k) zt[k] = PRE ? zt_cur[PRE ? k : 0] : (c.z_per_cell ? a.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k]);
-
-    // RTS update, controller and the cubature cost of the posterior (shared with the sigma-point path)
-    R ctl[C::E_POST - D - sym(D)], mzq[NZ], Szq[sym(NZ)], cm, cv;
-    if (!cell_posterior<M, R>(c, zt, mu, S, J, dm, dS, ctl, mzq, Szq, &cm, &cv)) set_status(a.status, b, 7, t);
-
-    // linearised marginal observation (i2c.py:537-540): block-diagonal use of the posterior covariance
-    R mz[NZ], Sz[sym(NZ)], CD[NZ * D];
-    value_and_jacobian<M, FN_OBSERVE, D, NZ, R>(c.params, mu, mz, CD);
-#pragma unroll
-    for (int k = 0; k < NZ; ++k)
-#pragma unroll
-      for (int l = 0; l <= k; ++l) {
-        R v = R(0);
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-          for (int j = 0; j < D; ++j)
-            if ((i < NX) == (j < NX)) v += CD[k * D + i] * S[tri_any(i, j)] * CD[l * D + j];
-        Sz[tri(k, l)] = v;
-      }
-    R ca, cva;
-    gaussian_cost<NZ>(c.QR, c.qr_diag != 0, mz, Sz, zt, &ca, &cva);
-    store_cell<M, R>(c, a, t, b, mu, S, ctl, mz, Sz, cm, cv);
-    sum_a += ca;
-    sum_m += cm;
-    sum_v += cv;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) m3m[i] = mu[i];
-#pragma unroll
-    for (int i = 0; i < sym(NX); ++i) S3m[i] = S[i];
+    for (int k = 0; k < NZ; ++k) ztc[k] = PRE ? zt_cur[PRE ? k : 0] : (c.z_per_cell ? a.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k]);
+    lin_backward_cell<M, R>(c, a, t, b, ld, ztc, m3m, S3m, sum_a, sum_m, sum_v);
     if (PRE) {
 #pragma unroll
       for (int e = 0; e < C::E_FWD; ++e) row[e] = nxt[e];
@@ -458,6 +490,130 @@ I2C_HD inline void backward_lin_body(const Consts<M, R>& c, const CellArgs<R>& a
   a.term_stats[B + b] = sum_a;
   a.term_stats[2 * B + b] = sum_v;
   a.term_stats[(long)(C::E_TERM - 1) * B + b] = sum_m;
+}
+
+// ------------------------------------------------------------------------------------------
+// CHUNKED form of the Linearize backward sweep (small batches; see chunk_compose_body in i2c_cell.hpp): the x-marginal recursion
+// is the same affine map as in the sigma-point path, so the composites of the chunks come from the SAME k_chunk_compose; the
+// stitch starts from the Linearize end of the chain, the walk does the Linearize cell and keeps three partial sums per chunk
+// (alpha statistic, plan cost, cost variance), which one lane per trajectory adds up in chunk order (with the M-step riding on it
+// inside i2c_learn). Sequential depth T / NC + NC instead of T.
+// ------------------------------------------------------------------------------------------
+template <class M, typename R>
+I2C_HD inline void chunk_stitch_lin_body(const Consts<M, R>& c, const ChunkArgs<R, R>& a, const int b) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, EC = NX + NX * NX + sym(NX);
+  const long B = c.B;
+  R m[NX], S[sym(NX)];
+  lin_end_of_chain<M, R>(c, a.cell, b, m, S);
+  for (int ch = a.n_chunks - 1; ch >= 0; --ch) {
+    const R* cp = a.comp + ((long)ch * EC) * B + b;
+    R av[NX], G[NX * NX], Cc[sym(NX)];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) av[i] = cp[(long)i * B];
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) G[i] = cp[(long)(NX + i) * B];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) Cc[i] = cp[(long)(NX + NX * NX + i) * B];
+    R* bo = a.bnd + ((long)ch * C::E_XM) * B + b;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) bo[(long)i * B] = m[i];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) bo[(long)(NX + i) * B] = S[i];
+    R mn[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      R v = av[i];
+#pragma unroll
+      for (int k = 0; k < NX; ++k) v += G[i * NX + k] * m[k];
+      mn[i] = v;
+    }
+    add_JDJt<NX, NX>(G, S, Cc);  // C + G S G^T
+#pragma unroll
+    for (int i = 0; i < NX; ++i) m[i] = mn[i];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) S[i] = Cc[i];
+  }
+}
+
+template <class M, typename R>
+I2C_HD inline void chunk_walk_lin_body(const Consts<M, R>& c, const ChunkArgs<R, R>& a, const int ch, const int b) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NZ = C::NZ;
+  const long B = c.B;
+  const int t_lo = ch * a.chunk_len, t_hi = (t_lo + a.chunk_len < c.T) ? t_lo + a.chunk_len : c.T;
+  const CellArgs<R>& ca = a.cell;
+  R m3m[NX], S3m[sym(NX)];
+  {
+    const R* bi = a.bnd + ((long)ch * C::E_XM) * B + b;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) m3m[i] = bi[(long)i * B];
+#pragma unroll
+    for (int i = 0; i < sym(NX); ++i) S3m[i] = bi[(long)(NX + i) * B];
+  }
+  constexpr bool PRE = C::D <= 5;  // rows and target a cell ahead (see backward_lin_body)
+  R row[PRE ? C::E_FWD : 1], zt_cur[PRE ? NZ : 1];
+  auto fetch_z = [&](const int r, R* zt) {
+    const R* src = c.z_per_cell ? ca.z + ((long)r * NZ) * B + b : ca.fwd + b;
+    const long st = c.z_per_cell ? B : 0;
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) {
+      const R v = src[(long)k * st];
+      zt[k] = c.z_per_cell ? v : c.zg[k];
+    }
+  };
+  if (PRE) {
+    const R* in0 = ca.fwd + ((long)(t_hi - 1) * C::E_FWD) * B + b;
+#pragma unroll
+    for (int e = 0; e < C::E_FWD; ++e) row[e] = opaque(in0[(long)e * B]);
+    fetch_z(c.row(t_hi - 1), zt_cur);
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) zt_cur[k] = opaque(zt_cur[k]);
+  }
+  R sum_a = R(0), sum_m = R(0), sum_v = R(0);
+  for (int t = t_hi - 1; t >= t_lo; --t) {
+    R cur[PRE ? C::E_FWD : 1], nxt[PRE ? C::E_FWD : 1], zt_nxt[PRE ? NZ : 1];
+    if (PRE) {
+#pragma unroll
+      for (int e = 0; e < C::E_FWD; ++e) cur[e] = row[e];
+      const R* inn = ca.fwd + ((long)(t > t_lo ? t - 1 : t_lo) * C::E_FWD) * B + b;
+#pragma unroll
+      for (int e = 0; e < C::E_FWD; ++e) nxt[e] = inn[(long)e * B];
+      fetch_z(c.row(t > t_lo ? t - 1 : t_lo), zt_nxt);
+    }
+    const R* in = ca.fwd + ((long)t * C::E_FWD) * B + b;
+    auto ld = [&](const int e) { return PRE ? cur[PRE ? e : 0] : in[(long)e * B]; };
+    R ztc[NZ];
+#pragma unroll
+    for (int k = 0; k < NZ; ++k) ztc[k] = PRE ? zt_cur[PRE ? k : 0] : (c.z_per_cell ? ca.z[((long)c.row(t) * NZ + k) * B + b] : c.zg[k]);
+    lin_backward_cell<M, R>(c, ca, t, b, ld, ztc, m3m, S3m, sum_a, sum_m, sum_v);
+    if (PRE) {
+#pragma unroll
+      for (int e = 0; e < C::E_FWD; ++e) row[e] = nxt[e];
+#pragma unroll
+      for (int k = 0; k < NZ; ++k) zt_cur[k] = zt_nxt[k];
+    }
+  }
+  a.part[((long)ch * 3 + 0) * B + b] = sum_a;
+  a.part[((long)ch * 3 + 1) * B + b] = sum_m;
+  a.part[((long)ch * 3 + 2) * B + b] = sum_v;
+}
+
+// the three sums over the chunks, in chunk order (high t first, as the sequential walk adds them), and the M-step if asked for
+template <class M, typename R>
+I2C_HD inline void chunk_reduce_lin_body(const Consts<M, R>& c, const ChunkArgs<R, R>& a, const MstepArgs<R>& ms, const int b) {
+  using C = Consts<M, R>;
+  const long B = c.B;
+  R sa = R(0), sm = R(0), sv = R(0);
+  for (int ch = a.n_chunks - 1; ch >= 0; --ch) {
+    sa += a.part[((long)ch * 3 + 0) * B + b];
+    sm += a.part[((long)ch * 3 + 1) * B + b];
+    sv += a.part[((long)ch * 3 + 2) * B + b];
+  }
+  a.cell.term_stats[B + b] = sa;
+  a.cell.term_stats[2 * B + b] = sv;
+  a.cell.term_stats[(long)(C::E_TERM - 1) * B + b] = sm;
+  if (ms.alpha) mstep_body<M, R>(c, ms, b);
 }
 
 // ------------------------------------------------------------------------------------------

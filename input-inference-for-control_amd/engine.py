@@ -227,7 +227,10 @@ class BatchedI2c:
         if mode not in (_native.BWD_TWO_PASS, _native.BWD_FUSED, _native.BWD_CHUNKED):
             raise RuntimeError("i2c_backward_schedule() returned %d" % mode)
         wave_ok = bool(dims.wave) and self.group_lanes in (0, 64) and not (self.linearize or self.gauss_hermite)
-        if self.linearize or self.gauss_hermite or (self.uses_group_kernels and not wave_ok):
+        lin_chunked = self.linearize and not self.uses_group_kernels and not self.mixed and mode == _native.BWD_CHUNKED
+        if lin_chunked:
+            pass  # Linearize on the one-lane kernels: the sequential walk or, at small batches, its chunked form
+        elif self.linearize or self.gauss_hermite or (self.uses_group_kernels and not wave_ok):
             mode = _native.BWD_FUSED  # one backward schedule: a lane (or a group of lanes) per trajectory walks T-1..0
         elif wave_ok and mode == _native.BWD_CHUNKED:
             mode = _native.BWD_FUSED  # the wave kernels have the fused walk and the two-pass schedule

@@ -296,3 +296,10 @@ def test_hip_feature_matrix_vs_oracle(lib, name, T, variant):
     from test_feature_matrix import run_matrix_entry
 
     run_matrix_entry(lib, "cuda", name, T, variant, 1e-6)
+
+
+@pytest.mark.parametrize("name", ["lin_pendulum_T100", "lin_cartpole_T100", "lin_dcp_T80", "lin_covctrl_qf_T30"])
+def test_hip_linearize_chunked_backward_equals_sequential(lib, name):
+    from test_kernels_hostsim import _linearize_chunked_equals_sequential
+
+    _linearize_chunked_equals_sequential(lib, "cuda", name, 1e-8)

@@ -3,10 +3,12 @@ and driven through the same C ABI + engine as on the GPU, against the golden vec
 real reference and against the batched CPU oracle. The GPU twins of these tests are in
 tests/test_hip_parity.py."""
 import numpy as np
+import torch
 import pytest
 
 import hostsim
 import parity
+from golden_util import load_case
 
 
 @pytest.fixture(scope="module")
@@ -329,3 +331,33 @@ TERMINAL_PRIOR = [
 @pytest.mark.parametrize("name,T,mu_T,sig_T,family", TERMINAL_PRIOR)
 def test_hostsim_terminal_prior_with_terminal_cost_vs_oracle(lib, name, T, mu_T, sig_T, family):
     _terminal_prior_with_terminal_cost(lib, "cpu", name, T, mu_T, sig_T, family, 1e-7)
+
+
+def _linearize_chunked_equals_sequential(lib, device, name, rtol):
+    """The chunked form of the Linearize backward sweep (the default of small batches) against the sequential walk."""
+    g = load_case(name)
+    runs = []
+    for mode in ("fused", "chunked"):
+        eng = parity.engine_from_case(g, lib, device, backward_mode=mode)
+        assert eng.backward_schedule == mode
+        for _ in range(4):
+            eng.learn_msgs()
+        assert eng.failures() == []
+        runs.append(eng)
+    a, b = runs
+    from golden_util import rel_err  # (max-norm relative: the composites are applied in another order, rounding differs)
+
+    for x, y in zip(a.costs_m + a.costs_m_var + a.alphas, b.costs_m + b.costs_m_var + b.alphas):
+        assert rel_err(parity.np_(x), parity.np_(y)) <= rtol
+    mu_a, sig_a = a.marginal_state_action()
+    mu_b, sig_b = b.marginal_state_action()
+    assert rel_err(parity.np_(mu_a), parity.np_(mu_b)) <= rtol and rel_err(parity.np_(sig_a), parity.np_(sig_b)) <= rtol
+    for x, y in zip(a.local_linear_policy(), b.local_linear_policy()):
+        assert rel_err(parity.np_(x), parity.np_(y)) <= rtol * 10
+    assert rel_err(parity.np_(a.term_stats), parity.np_(b.term_stats)) <= rtol
+    assert parity.engine_from_case(g, lib, device).backward_schedule == "chunked"  # ... and it is the default here
+
+
+@pytest.mark.parametrize("name", ["lin_pendulum_T100", "lin_cartpole_T100", "lin_dcp_T80", "lin_covctrl_qf_T30"])
+def test_hostsim_linearize_chunked_backward_equals_sequential(lib, name):
+    _linearize_chunked_equals_sequential(lib, "cpu", name, 1e-9)
