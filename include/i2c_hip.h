@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define I2C_ABI_VERSION 5
+#define I2C_ABI_VERSION 6
 
 #define I2C_MAX_NX 12
 #define I2C_MAX_NU 4
@@ -85,7 +85,9 @@ enum {
 enum {
   I2C_FAMILY_LANE = 1,  /* one trajectory per lane, every block in that lane's registers (d = nx + nu <= 8)              */
   I2C_FAMILY_GROUP = 2, /* G = I2cDims.group_lanes lanes per trajectory, blocks row-distributed, exchanged through LDS  */
-  I2C_FAMILY_WAVE = 3   /* one wavefront per trajectory: 16 x 16 blocks in the MFMA accumulator layout (d = 16)          */
+  I2C_FAMILY_WAVE = 3,  /* one wavefront per trajectory: 16 x 16 blocks in the MFMA accumulator layout (d = 16)          */
+  I2C_FAMILY_QUAD = 4   /* four trajectories per wavefront: 4 x 4 blocks on v_mfma_f64_4x4x4_4b_f64, one element per lane
+                           (d <= 8; forward sweep)                                                                        */
 };
 enum { I2C_SWEEP_FORWARD = 0, I2C_SWEEP_BACKWARD = 1, I2C_SWEEP_PROPAGATE = 2, I2C_SWEEP_FILTER = 3 };
 /* hybrid default of the d >= 7 lane models: their FORWARD sweep runs on the group kernels while B * G stays within this
@@ -130,6 +132,8 @@ typedef struct I2cDims {
   int32_t group_only;      /* 1: no one-lane-per-trajectory kernels exist for this model (nx + nu > 8 does not fit one lane)  */
   int32_t wave;            /* 1: the one-wavefront-per-trajectory kernels (I2C_FAMILY_WAVE) exist for this model;
                               I2cProblem.group_lanes = 64 asks for them                                                    */
+  int32_t quad;            /* 1: the four-trajectories-per-wavefront forward kernel (I2C_FAMILY_QUAD) exists for this model;
+                              I2cProblem.group_lanes = 64 asks for it                                                      */
 } I2cDims;
 
 /*

@@ -9,7 +9,7 @@ without a GPU; nothing in the package ever looks for it.)
 import ctypes as C
 import os
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_NX, MAX_NU, MAX_NZ, MAX_PARAMS = 12, 4, 16, 16
 MAX_GH_DEGREE = 8
 
@@ -21,8 +21,8 @@ def _sym(n):
 F64, F32, F64_F32S = 0, 1, 2  # I2cProblem.dtype (include/i2c_hip.h): F64_F32S = fp64 arithmetic on fp32-stored per-cell buffers
 BWD_AUTO, BWD_TWO_PASS, BWD_FUSED, BWD_CHUNKED = 0, 1, 2, 3
 INF_CUBATURE, INF_LINEARIZE, INF_GAUSS_HERMITE = 0, 1, 2
-FAMILY_LANE, FAMILY_GROUP, FAMILY_WAVE = 1, 2, 3  # i2c_kernel_family()
-FAMILY_NAMES = {FAMILY_LANE: "lane", FAMILY_GROUP: "group", FAMILY_WAVE: "wave"}
+FAMILY_LANE, FAMILY_GROUP, FAMILY_WAVE, FAMILY_QUAD = 1, 2, 3, 4  # i2c_kernel_family()
+FAMILY_NAMES = {FAMILY_LANE: "lane", FAMILY_GROUP: "group", FAMILY_WAVE: "wave", FAMILY_QUAD: "quad"}
 SWEEP_FORWARD, SWEEP_BACKWARD, SWEEP_PROPAGATE, SWEEP_FILTER = 0, 1, 2, 3
 
 MODEL_IDS = {
@@ -52,7 +52,7 @@ FAIL_REASONS = {
 
 class I2cDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("nx", "nu", "nz", "nzt", "e_post", "e_fwd", "e_xm", "e_zpost", "e_prop", "n_params", "ny",
-                                          "group_lanes", "group_only", "wave")]
+                                          "group_lanes", "group_only", "wave", "quad")]
 
 
 class I2cProblem(C.Structure):

@@ -12,6 +12,7 @@
 #include "i2c_cell.hpp"
 #include "i2c_group.hpp"
 #include "i2c_wave.hpp"
+#include "i2c_quad.hpp"
 #include "i2c_linearize.hpp"
 
 #include <cmath>
@@ -338,6 +339,52 @@ static int launch_wave_v(const Consts<M, R>& c, const A& a, void* stream) {
 }
 #endif
 
+// ---- quad kernels (i2c_quad.hpp): four trajectories per wavefront, one wavefront per workgroup ------------------------------------
+#ifdef I2C_HOST_SIM
+template <class M, typename R, typename S, class A>
+static int launch_quad_forward(const Consts<M, R>& c, const A& a, void*) {
+  WConst<M, R> kc;
+  wconst_fill<M, R>(kc, &c, 0, 1);
+  for (int b0 = 0; b0 < c.B; b0 += 4) {
+    std::vector<R> sh((size_t)4 * QuadLds::SIZE, R(0)), xch(128, R(0));
+    HostBarrier bar(64);
+    std::vector<std::thread> lanes;
+    for (int l = 0; l < 64; ++l)
+      lanes.emplace_back([&, l, b0] {
+        const int g = (l >> 2) & 3, b = b0 + g;
+        const bool live = b < c.B;
+        forward_quad_body<M, R, S>(c, kc, a, live ? b : c.B - 1, live, Quad<R>{l, l >> 4, g, l & 3, sh.data() + g * QuadLds::SIZE, &bar, xch.data()});
+      });
+    for (auto& th : lanes) th.join();
+  }
+  return I2C_OK;
+}
+#else
+template <class M, typename R, typename S, class A>
+__global__ __launch_bounds__(64, 2) void k_quad_forward(const Consts<M, R> c, const A a) {
+  __shared__ WConst<M, R> kc;
+  __shared__ R sh[4 * QuadLds::SIZE];
+  wconst_fill<M, R>(kc, (const Consts<M, R>*)__builtin_amdgcn_kernarg_segment_ptr(), (int)threadIdx.x, 64);
+  __syncthreads();
+  // A wave reads four consecutive trajectories (32 bytes) of every [B]-contiguous row: the four waves that share a 128-byte line
+  // of each row are mapped onto workgroups of the SAME XCD (workgroups are dealt round-robin over the 8 XCDs, so blocks i and
+  // i + 8 share an L2). Placement is a speed heuristic only -- any mapping computes the same result.
+  const unsigned i = blockIdx.x, x = i & 7u, rr = (i >> 3) & 3u, gg = i >> 5;
+  const int l = (int)threadIdx.x, g = (l >> 2) & 3;
+  const long b = 16L * (gg * 8u + x) + 4 * rr + g;
+  if (16L * (gg * 8u + x) + 4 * rr >= c.B) return;  // (wave-uniform: no trajectory in this wave)
+  const bool live = b < c.B;
+  const Quad<R> q{l, l >> 4, g, l & 3, (lds_ptr<R>)(sh + g * QuadLds::SIZE)};
+  forward_quad_body<M, R, S>(c, kc, a, (int)(live ? b : c.B - 1), live, q);
+}
+template <class M, typename R, typename S, class A>
+static int launch_quad_forward(const Consts<M, R>& c, const A& a, void* stream) {
+  const unsigned blocks = (unsigned)(((long)c.B + 127) / 128) * 32u;
+  hipLaunchKernelGGL((k_quad_forward<M, R, S, A>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, c, a);
+  return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
+}
+#endif
+
 template <int KIND, class M, typename R, typename S, class A>
 static int launch_wave(const Consts<M, R>& c, const A& a, void* stream) {
   if constexpr (KIND == WK_FORWARD) {  // batches whose waves share a SIMD: the variant with the pivot blocks through LDS
@@ -474,10 +521,11 @@ template <class M, typename R, typename S = R> struct Impl {
   static constexpr bool HAS_GROUP = G > 0 && sizeof(R) == 8 && !MIXED;
   static constexpr bool LANE = !M::GROUP_ONLY;  // one-lane-per-trajectory kernels exist
   static constexpr bool HAS_WAVE = M::WAVE && sizeof(R) == 8;  // fp64 matrix instruction; the storage type S may be float
+  static constexpr bool HAS_QUAD = M::QUAD && sizeof(R) == 8 && !MIXED;  // fp64 matrix instruction (i2c_quad.hpp): forward sweep
 
   // 1: group kernels, 0: one lane per trajectory, < 0: error code
   static int use_group(const I2cProblem* p) {
-    if (p->group_lanes == 0 || (p->group_lanes == 64 && M::WAVE))  // 64: the wave kernels; their missing sweeps run the default
+    if (p->group_lanes == 0 || (p->group_lanes == 64 && (M::WAVE || M::QUAD)))  // 64: the wave / quad kernels; their missing sweeps run the default
       return M::GROUP_ONLY ? (HAS_GROUP ? 1 : I2C_ENOTSUP) : 0;
     if (p->group_lanes == -1) return M::GROUP_ONLY ? I2C_ENOTSUP : 0;  // one lane per trajectory, no hybrid forward
     return (HAS_GROUP && p->group_lanes == G) ? 1 : I2C_ENOTSUP;
@@ -511,7 +559,24 @@ template <class M, typename R, typename S = R> struct Impl {
     if (EMAX * (long)p->B * (long)sizeof(S) >= (1L << 31)) return I2C_EINVAL;
     return I2C_OK;
   }
+  // what the quad form (forward sweep) covers: the cubature rule with lam = 0 (unit weights, no weight on the centre: the centring
+  // of the pairwise sums relies on 2 d wi = 1, and the d = 8 models evaluate no centre point at all), windows below 2 GiB
+  static int quad_supported(const I2cProblem* p, const C& c) {
+    if (p->inference != I2C_INF_CUBATURE) return I2C_ENOTSUP;
+    if (!c.rule_xu.unit || !c.rule_x.unit || c.rule_xu.w0 != R(0) || c.rule_x.w0 != R(0)) return I2C_ENOTSUP;
+    constexpr long EMAX = C::E_FWD > C::E_POST ? C::E_FWD : C::E_POST;
+    if (EMAX * (long)p->B * (long)sizeof(S) >= (1L << 31)) return I2C_EINVAL;
+    if (c.z_per_cell && (long)p->T * C::NZ * (long)p->B * (long)sizeof(R) >= (1L << 32)) return I2C_EINVAL;
+    if (p->alpha_cell && (long)p->T * (long)p->B * (long)sizeof(R) >= (1L << 32)) return I2C_EINVAL;
+    return I2C_OK;
+  }
   static int family(const I2cProblem* p, const C& c, const int sweep) {
+    if constexpr (HAS_QUAD) {  // forward sweep: on request (group_lanes = 64)
+      if (sweep == I2C_SWEEP_FORWARD && p->group_lanes == 64) {
+        const int rc = quad_supported(p, c);
+        return rc == I2C_OK ? I2C_FAMILY_QUAD : rc;
+      }
+    }
     if constexpr (HAS_WAVE) {  // forward and backward sweeps: on request (group_lanes = 64) or as the model's default
       if ((sweep == I2C_SWEEP_FORWARD || sweep == I2C_SWEEP_BACKWARD) &&
           (p->group_lanes == 64 || p->group_lanes == 0)) {
@@ -593,6 +658,9 @@ template <class M, typename R, typename S = R> struct Impl {
     if (fam < 0) return fam;
     if (fam == I2C_FAMILY_WAVE) {
       if constexpr (HAS_WAVE && !MIXED) return launch_wave<WK_FORWARD, M, R, R>(c, a, stream);
+    }
+    if (fam == I2C_FAMILY_QUAD) {
+      if constexpr (HAS_QUAD) return launch_quad_forward<M, R, R>(c, a, stream);
     }
     if (fam == I2C_FAMILY_GROUP) {
       if constexpr (HAS_GROUP) return launch_group<GK_FORWARD, M, R, G>(c, nullptr, a, stream);
@@ -908,6 +976,7 @@ template <class M> static void fill_dims(I2cDims* d) {
   d->group_lanes = M::GROUP;
   d->group_only = M::GROUP_ONLY ? 1 : 0;
   d->wave = M::WAVE ? 1 : 0;
+  d->quad = M::QUAD ? 1 : 0;
 }
 
 template <class M, typename R, typename S = R> const ModelOps* make_ops() {

@@ -1,0 +1,779 @@
+// FOUR trajectories per wavefront on the small fp64 matrix instruction of gfx950: the forward cubature cell for the models with
+// d = nx + nu <= 8 (pendulum ... double cartpole, planar quadrotor), whatever their observation function.
+//
+//   v_mfma_f64_4x4x4_4b_f64 multiplies four independent 4 x 4 blocks at once. Block g lives in lanes {16 k + 4 g + m}: lane
+//   l = 16 r + 4 g + c holds element (r, c) of block g -- as result / accumulator and as B operand; as A operand the same lane
+//   supplies A[c][r], i.e. a resident block is multiplied TRANSPOSED from the left (probed, not assumed:
+//   tools/micro/mfma_f64_4x4.hip, profiles/r4_micro_mfma_f64_4x4.txt). So:
+//   * trajectory g of a wave owns block g; every matrix of its cell is cut into 4 x 4 blocks, one fp64 register per block, one
+//     element per lane (an 8 x 8 joint covariance = 4 registers, the double cartpole's 9 x 9 observation covariance = 9);
+//   * X^T Y of two resident block matrices is one instruction per (k, i, j) block triple with NO operand movement, for four
+//     trajectories at once (q_tn), at ~16 clocks of issue -- an 8 x 8 x 8 product of four trajectories in 8 instructions.
+//     Everything is arranged so that only X^T Y forms occur (as in i2c_wave.hpp); a block transpose, a column sum, a
+//     column-form -> row-form change of a vector are each ONE instruction against a constant block (identity / ones);
+//   * factorisations are blocked with 4 x 4 pivots: the pivot block goes through 16 doubles of LDS to the sixteen lanes of its
+//     trajectory, which factor and invert it in registers (compile-time shorter for a partly filled last block: the 9th
+//     observation of the double cartpole is a scalar pivot); scaling and elimination of the block row, the trailing matrix and
+//     any number of right-hand-side block columns are matrix instructions. Solves are right-hand sides of eliminations;
+//   * the 2 d (+ 1) sigma points of a transform are evaluated ONE PER LANE by the sixteen lanes of a trajectory (lane p < 8:
+//     m + sf L[:, p], lane 8 + p: m - sf L[:, p], a spare lane: the centre) through the model functors of i2c_models.hpp --
+//     general observation functions included; directions and results change layout through the trajectory's LDS region.
+// The math is the reference's I2cCell._forward_msgs_quadrature (i2c/i2c.py:350-447) and QuadratureInference
+// (i2c/inference/quadrature.py:15-58) in the centred pairwise form of sp_transform (i2c_cell.hpp). Buffers are the common
+// [T][E][B] ones, so the backward schedules of the lane kernels consume what this sweep writes.
+//
+// Host simulation (tests only): the 64 lanes are 64 threads; every cross-lane instruction is an exchange through a shared
+// buffer between two barriers.
+#pragma once
+#include "i2c_wave.hpp"
+
+namespace i2c {
+
+// LDS region of one trajectory (elements)
+struct QuadLds {
+  static constexpr int LDL = 10;               // row stride of the sigma-point directions: 8 rows (pairs) of <= 8 inputs
+  static constexpr int O_L = 0;
+  static constexpr int YLD = 12;               // row stride of the evaluation outputs: 16 rows (points) of <= 12 outputs
+  static constexpr int O_Y = O_L + 8 * LDL;
+  static constexpr int O_MV = O_Y + 16 * YLD;  // the mean the points are built around (8)
+  static constexpr int O_DG = O_MV + 8;        // 4 x 4 pivot block
+  static constexpr int SIZE = O_DG + 16 + 2;   // (= 10 mod 32 elements: the four regions of a wave start on different banks)
+};
+
+// Diagnostic build only (-DI2C_QUAD_STAMPS, never in the shipped library): s_memtime stamps at the phase boundaries of the forward
+// cell, summed per phase and printed by trajectory 0 -- where a lone wave spends its cycles.
+#if defined(I2C_QUAD_STAMPS) && !defined(I2C_HOST_SIM)
+#define I2C_QSTAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += now_ - stamp_last; stamp_last = now_; } while (0)
+#else
+#define I2C_QSTAMP(i) do { } while (0)
+#endif
+
+template <typename R> struct Quad {
+  int l, r, g, c;  // lane; block row (l >> 4), trajectory slot ((l >> 2) & 3), block column (l & 3)
+  lds_ptr<R> sh;   // this trajectory's LDS region
+#ifdef I2C_HOST_SIM
+  HostBarrier* bar;
+  R* xch;  // 128 slots: operands of the emulated cross-lane instructions
+#endif
+  I2C_MEM int p() const { return 4 * r + c; }  // lane index inside the trajectory: which sigma point it evaluates
+  I2C_MEM void sync() const {
+#ifdef I2C_HOST_SIM
+    bar->wait();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
+  }
+};
+
+// ---- the cross-lane instructions -------------------------------------------------------------------------------------------
+// acc (block) += A B per trajectory: lane (r, c) supplies A[c][r] and B[r][c] and holds acc[r][c]
+template <typename R> I2C_FN void q_mfma(const Quad<R>& q, const R a, const R b, R& acc) {
+#ifdef I2C_HOST_SIM
+  q.bar->wait();
+  q.xch[q.l] = a;
+  q.xch[64 + q.l] = b;
+  q.bar->wait();
+  R s = acc;
+  for (int k = 0; k < 4; ++k) s = std::fma(q.xch[16 * k + 4 * q.g + q.r], q.xch[64 + 16 * k + 4 * q.g + q.c], s);
+  acc = s;
+#else
+  acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc, 0, 0, 0);
+#endif
+}
+// acc[NI][NJ] += X^T Y for block matrices X[NK][NI], Y[NK][NJ] (row-major arrays of block registers); NEG: -=.
+// UPPER: only the blocks i <= j (symmetric results whose lower blocks nobody reads); YUP: Y is block upper triangular.
+template <int NK, int NI, int NJ, bool NEG = false, bool UPPER = false, bool YUP = false, typename R>
+I2C_FN void q_tn(const Quad<R>& q, const R* x, const R* y, R* acc) {
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (UPPER && i > j) continue;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        if (YUP && k > j) continue;
+        q_mfma(q, NEG ? -x[k * NI + i] : x[k * NI + i], y[k * NJ + j], acc[i * NJ + j]);
+      }
+    }
+}
+// block transpose
+template <typename R> I2C_FN R q_tr(const Quad<R>& q, const R x) {
+  R t = R(0);
+  q_mfma(q, x, q.r == q.c ? R(1) : R(0), t);
+  return t;
+}
+// sum over the four rows of a block, in every row
+template <typename R> I2C_FN R q_colsum(const Quad<R>& q, const R x) {
+  R t = R(0);
+  q_mfma(q, R(1), x, t);
+  return t;
+}
+// value held by column K of the caller's block row (DPP quad_perm)
+template <int K, typename R> I2C_FN R q_bcq(const Quad<R>& q, const R x) {
+#ifdef I2C_HOST_SIM
+  q.bar->wait();
+  q.xch[q.l] = x;
+  q.bar->wait();
+  return q.xch[(q.l & ~3) + K];
+#else
+  constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+#endif
+}
+// sum over the four columns of a block row, in every column
+template <typename R> I2C_FN R q_rowsum(const Quad<R>& q, const R x) {
+#ifdef I2C_HOST_SIM
+  q.bar->wait();
+  q.xch[q.l] = x;
+  q.bar->wait();
+  const int b = q.l & ~3;
+  return (q.xch[b] + q.xch[b + 1]) + (q.xch[b + 2] + q.xch[b + 3]);
+#else
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  const double y = x + __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false));  // [1,0,3,2]
+  lo = __double2loint(y), hi = __double2hiint(y);
+  return y + __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false));  // [2,3,0,1]
+#endif
+}
+
+// Batch-wide constants by (row, column), in LDS, one copy per workgroup: WConst of i2c_wave.hpp (16 x 16 row-major, zero-padded)
+template <typename R, class P> I2C_FN R q_ldc(const Quad<R>& q, const P m, const int I, const int J) { return m[(4 * I + q.r) * 16 + 4 * J + q.c]; }
+template <typename R, class P> I2C_FN R q_ldv(const Quad<R>& q, const P v, const int J) { return v[4 * J + q.c]; }  // column form
+
+// ---- blocked Cholesky elimination --------------------------------------------------------------------------------------------
+// s: SPD matrix of dimension N in NB x NB blocks, of which the UPPER blocks are read (consumed). On return lt = L^T (upper blocks;
+// the others are left alone) and each right-hand side block matrix r1 [NB][NC1], r2 [NB][NC2] is replaced by L^-1 r. Returns
+// whether every pivot was positive. Rows / columns >= N of s and of the right-hand sides must be zero (no identity padding: the
+// pivot algebra of a partly filled block is compiled for its NL live rows).
+template <int K, int NB, int N, int NC1, int NC2, typename R>
+I2C_FN void q_elim_step(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* last) {
+  constexpr int NL = (N - 4 * K) >= 4 ? 4 : (N - 4 * K);
+  static_assert(NL >= 1, "empty pivot block");
+  const auto dg = q.sh + QuadLds::O_DG;
+  q.sync();
+  dg[4 * q.r + q.c] = s[K * NB + K];
+  q.sync();
+  // 4 x 4 Cholesky of the pivot block (l), column by column; rows >= NL are identity rows
+  const R d00 = dg[0];
+  const R i0 = r_rsqrt(d00);
+  R pl = d00, i1 = R(1), i2 = R(1), i3 = R(1);
+  R l10 = R(0), l20 = R(0), l21 = R(0), l30 = R(0), l31 = R(0), l32 = R(0);
+  if constexpr (NL > 1) {
+    const R d10 = dg[4], d11 = dg[5];
+    l10 = d10 * i0;
+    pl = d11 - l10 * l10;
+    i1 = r_rsqrt(pl);
+  }
+  if constexpr (NL > 2) {
+    const R d20 = dg[8], d21 = dg[9], d22 = dg[10];
+    l20 = d20 * i0;
+    l21 = (d21 - l20 * l10) * i1;
+    pl = d22 - l20 * l20 - l21 * l21;
+    i2 = r_rsqrt(pl);
+  }
+  if constexpr (NL > 3) {
+    const R d30 = dg[12], d31 = dg[13], d32 = dg[14], d33 = dg[15];
+    l30 = d30 * i0;
+    l31 = (d31 - l30 * l10) * i1;
+    l32 = (d32 - l30 * l20 - l31 * l21) * i2;
+    pl = d33 - l30 * l30 - l31 * l31 - l32 * l32;
+    i3 = r_rsqrt(pl);
+  }
+  if (K == NB - 1) *last = pl;  // a failed pivot poisons everything after it (see chol(), i2c_linalg.hpp)
+  // this lane's entry of the inverse of l as the A operand: lane (r, c) supplies A[c][r] = (l^-1)[c][r]. Row a of l^-1 solves
+  // y^T l = e_a^T (back substitution; y_k = 0 for k > a falls out of the one-hot right-hand side); entry r picked by a one-hot
+  // combination (written without selects: see w_elim_step, i2c_wave.hpp)
+  const int a = q.c, cq = q.r;
+  const R e0 = a == 0 ? R(1) : R(0), e1 = a == 1 ? R(1) : R(0), e2 = a == 2 ? R(1) : R(0), e3 = a == 3 ? R(1) : R(0);
+  const R y3 = e3 * i3;
+  const R y2 = (e2 - l32 * y3) * i2;
+  const R y1 = (e1 - l21 * y2 - l31 * y3) * i1;
+  const R y0 = (e0 - l10 * y1 - l20 * y2 - l30 * y3) * i0;
+  const R m0 = cq == 0 ? R(1) : R(0), m1 = cq == 1 ? R(1) : R(0), m2 = cq == 2 ? R(1) : R(0), m3 = cq == 3 ? R(1) : R(0);
+  const R aw = (m0 * y0 + m1 * y1) + (m2 * y2 + m3 * y3);
+  // scale block row K: rows of L^T (the diagonal block masked to its upper triangle: what is left of it is rounding noise) ...
+#pragma unroll
+  for (int j = K; j < NB; ++j) {
+    R x = R(0);
+    q_mfma(q, aw, s[K * NB + j], x);
+    lt[K * NB + j] = (j > K || q.c >= q.r) ? x : R(0);
+  }
+#pragma unroll
+  for (int j = 0; j < NC1; ++j) {
+    R x = R(0);
+    q_mfma(q, aw, r1[K * NC1 + j], x);
+    r1[K * NC1 + j] = x;
+  }
+#pragma unroll
+  for (int j = 0; j < NC2; ++j) {
+    R x = R(0);
+    q_mfma(q, aw, r2[K * NC2 + j], x);
+    r2[K * NC2 + j] = x;
+  }
+  // ... and eliminate it from everything below
+#pragma unroll
+  for (int i = K + 1; i < NB; ++i) {
+    const R nl = -lt[K * NB + i];
+#pragma unroll
+    for (int j = i; j < NB; ++j) q_mfma(q, nl, lt[K * NB + j], s[i * NB + j]);
+#pragma unroll
+    for (int j = 0; j < NC1; ++j) q_mfma(q, nl, r1[K * NC1 + j], r1[i * NC1 + j]);
+#pragma unroll
+    for (int j = 0; j < NC2; ++j) q_mfma(q, nl, r2[K * NC2 + j], r2[i * NC2 + j]);
+  }
+  if constexpr (K + 1 < NB) q_elim_step<K + 1, NB, N, NC1, NC2>(q, s, r1, r2, lt, last);
+}
+template <int N, int NC1, int NC2, typename R> I2C_FN bool q_elim(const Quad<R>& q, R* s, R* r1, R* r2, R* lt) {
+  R last = R(0);
+  q_elim_step<0, (N + 3) / 4, N, NC1, NC2>(q, s, r1, r2, lt, &last);
+  return last > R(0);
+}
+
+// ---- sigma points ------------------------------------------------------------------------------------------------------------
+// The points m +/- sf L[:, p] of a DIN-dimensional rule through f, one evaluation per lane of the trajectory (lane p < 8: +,
+// lane 8 + p: -; pairs >= DIN have a zero direction: they evaluate the centre, and row 7 is used as such). Results as pairwise
+// sums and differences about a reference value yc, in blocks [pair][output]:  am = (y+ - yc) + (y- - yc),  dm = y+ - y-.
+// yc = the centre value for DIN < 8. For DIN = 8 all sixteen lanes carry points; with no weight on the centre (the only rules
+// this family serves) the moments do not depend on the reference value, and yc = the midpoint of pair 0 stands in.
+//   muc: mean, column form [NBI]; lt: L^T, upper blocks [NBI][NBI]
+template <class M, int DIN, int NOUT, class F, typename R>
+I2C_FN void q_points(const Quad<R>& q, const R sf, const R* muc, const R* lt, const F& f, R* am, R* dm, R* yc) {
+  constexpr int NBI = (DIN + 3) / 4, NBO = (NOUT + 3) / 4;
+  constexpr int NA1 = M::NA > 0 ? M::NA : 1;
+  static_assert(DIN <= 8 && NOUT <= QuadLds::YLD, "quad kernels: d <= 8, <= 12 outputs");
+  const auto Lr = q.sh + QuadLds::O_L, Y = q.sh + QuadLds::O_Y, mv = q.sh + QuadLds::O_MV;
+  q.sync();
+#pragma unroll
+  for (int i = 0; i < NBI; ++i)
+#pragma unroll
+    for (int j = 0; j < NBI; ++j) Lr[(4 * i + q.r) * QuadLds::LDL + 4 * j + q.c] = j >= i ? lt[i * NBI + j] : R(0);
+#ifdef I2C_HOST_SIM
+  if (q.r == 0)  // (lane-threads must not race; on the device the four rows store the same value to the same address)
+#endif
+  {
+#pragma unroll
+    for (int j = 0; j < NBI; ++j) mv[4 * j + q.c] = muc[j];
+  }
+  q.sync();
+  {
+    const int p = q.p(), pp = p & 7;
+    const bool pt = pp < DIN;  // pairs beyond the input dimension evaluate the centre (their rows may not even be written)
+    const R sg = pt ? (p < 8 ? sf : -sf) : R(0);
+    const int lrow = (pt ? pp : 0) * QuadLds::LDL;
+    R x[DIN], sn[NA1], cs[NA1], y[NOUT];
+#pragma unroll
+    for (int i = 0; i < DIN; ++i) x[i] = mv[i] + sg * Lr[lrow + i];
+#pragma unroll
+    for (int k = 0; k < M::NA; ++k) r_sincos(x[M::ang(k)], &sn[k], &cs[k]);
+    f(x, sn, cs, y);
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) Y[p * QuadLds::YLD + k] = y[k];
+  }
+  q.sync();
+#pragma unroll
+  for (int j = 0; j < NBO; ++j) {
+    const int col = 4 * j + q.c;
+    const bool cv = col < NOUT;
+    const int cc = cv ? col : 0;
+    R y0;
+    if constexpr (DIN < 8) {
+      y0 = Y[7 * QuadLds::YLD + cc];
+    } else {
+      y0 = R(0.5) * (Y[cc] + Y[8 * QuadLds::YLD + cc]);
+    }
+    yc[j] = cv ? y0 : R(0);
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) {
+      const int row = 4 * i + q.r;
+      const R yp = Y[row * QuadLds::YLD + cc], ym = Y[(8 + row) * QuadLds::YLD + cc];
+      const bool v = cv && row < DIN;
+      am[i * NBO + j] = v ? (yp - y0) + (ym - y0) : R(0);
+      dm[i * NBO + j] = v ? yp - ym : R(0);
+    }
+  }
+}
+// Moments from the pairwise sums / differences (quadrature.py:34-44 in the form of sp_transform): mean (column form), the
+// centred sums (am is overwritten), and sy [NBO][NBO] upper blocks = wi/2 (am^T am + dm^T dm) (+ nothing: the caller adds noise)
+template <int DIN, int NOUT, typename R>
+I2C_FN void q_moments(const Quad<R>& q, const R wi, R* am, const R* dm, const R* yc, R* myc, R* sy) {
+  constexpr int NBI = (DIN + 3) / 4, NBO = (NOUT + 3) / 4;
+  const R hw = R(0.5) * wi;
+#pragma unroll
+  for (int j = 0; j < NBO; ++j) {
+    R t = am[j];
+#pragma unroll
+    for (int i = 1; i < NBI; ++i) t += am[i * NBO + j];
+    const R asum = q_colsum(q, t);
+    myc[j] = yc[j] + wi * asum;
+    // sig_y = wi/2 sum_p (a_p a_p^T + d_p d_p^T) - wi^2 A A^T: with 2 d wi = 1 the last term centres the a_p
+    const R amean = (R(2) * wi) * asum;
+    const int col = 4 * j + q.c;
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) am[i * NBO + j] = (col < NOUT && 4 * i + q.r < DIN) ? am[i * NBO + j] - amean : R(0);
+  }
+#pragma unroll
+  for (int k = 0; k < NBO * NBO; ++k) sy[k] = R(0);
+  q_tn<NBI, NBO, NBO, false, true>(q, am, am, sy);
+  q_tn<NBI, NBO, NBO, false, true>(q, dm, dm, sy);
+#pragma unroll
+  for (int k = 0; k < NBO * NBO; ++k) sy[k] *= hw;
+}
+
+// ---- Kalman-style updates ------------------------------------------------------------------------------------------------------
+// Update of N(mu, s) (dimension N; mu column form [NB], s upper blocks [NB][NB]) on an observation with predicted mean mzc
+// (column form [NBZ]), covariance sz INCLUDING its noise (upper blocks, consumed), cross-covariance szx = cov(z, x) [NBZ][NB]
+// and target ztc:  with C = chol(sz), [U | q] = C^-1 [szx | zt - mz]:  s <- s - U^T U,  mu <- mu + U^T q   (i2c.py:398-403).
+// The innovation rides as one more column of the right-hand side -- the spare column N of the last block column when N is not
+// a multiple of 4, a block column of its own otherwise -- so the mean update is a by-product of the same instructions.
+template <int N, int NZ, typename R> I2C_FN bool q_kalman(const Quad<R>& q, R* muc, R* s, const R* mzc, R* sz, const R* szx, const R* ztc) {
+  constexpr int NB = (N + 3) / 4, NBZ = (NZ + 3) / 4;
+  constexpr bool SPARE = N % 4 != 0;
+  constexpr int NC = SPARE ? NB : NB + 1, QC = SPARE ? N % 4 : 0;  // right-hand side block columns; the innovation's column in the last
+  R u[NBZ * NC], lt[NBZ * NBZ];
+#pragma unroll
+  for (int k = 0; k < NBZ; ++k) {
+    const R rr = q_tr(q, ztc[k] - mzc[k]);  // row form
+#pragma unroll
+    for (int j = 0; j < NB; ++j) u[k * NC + j] = szx[k * NB + j];
+    if constexpr (SPARE) {
+      u[k * NC + NB - 1] = q.c == QC ? rr : u[k * NC + NB - 1];
+    } else {
+      u[k * NC + NC - 1] = q.c == QC ? rr : R(0);
+    }
+  }
+  const bool ok = q_elim<NZ, NC, 0>(q, sz, u, (R*)nullptr, lt);
+  R inc[NB];  // -(U^T q), row form in column QC
+  if constexpr (SPARE) {
+    q_tn<NBZ, NB, NB, true, true>(q, u, u, s);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      inc[i] = s[i * NB + NB - 1];
+      s[i * NB + NB - 1] = q.c == QC ? R(0) : s[i * NB + NB - 1];  // (s had zeros there; the last block also gets -|q|^2 at (N, N))
+    }
+  } else {
+    R un[NBZ * NB], e[NB];
+#pragma unroll
+    for (int k = 0; k < NBZ; ++k)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) un[k * NB + j] = u[k * NC + j];
+    q_tn<NBZ, NB, NB, true, true>(q, un, un, s);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      e[i] = R(0);
+#pragma unroll
+      for (int k = 0; k < NBZ; ++k) q_mfma(q, -u[k * NC + i], u[k * NC + NC - 1], e[i]);
+      inc[i] = e[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const R ir = q_bcq<QC>(q, inc[i]);                                  // row form, every column
+    const R ic = q_tr(q, (4 * i + q.r < N) ? ir : R(0));                // column form
+    muc[i] -= ic;
+  }
+  return ok;
+}
+// The same update on an IDENTITY observation of the state itself with noise alpha * xi and target zt (i2c.py:394-403 with z = the
+// state):  with C = chol(s + alpha xi), U = C^-1 s:  s <- s - U^T U;  the mean uses the posterior-covariance form of the same gain,
+// s (s + N)^-1 = s_new N^-1  (N^-1 = W / alpha, W = the cost weight):  mu <- mu + s_new W (zt - mu) / alpha   (see w_kalman).
+// s: FULL blocks in, full blocks out. xi_m, w_m: 16 x 16 row-major constants in LDS.
+template <int N, typename R, class P>
+I2C_FN bool q_kalman_identity(const Quad<R>& q, const R alpha, const P xi_m, const P w_m, const bool w_diag, const R* ztc, R* muc, R* s) {
+  constexpr int NB = (N + 3) / 4;
+  R sz[NB * NB], u[NB * NB], lt[NB * NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      sz[i * NB + j] = s[i * NB + j] + alpha * q_ldc(q, xi_m, i, j);
+      u[i * NB + j] = s[i * NB + j];
+    }
+  const bool ok = q_elim<N, NB, 0>(q, sz, u, (R*)nullptr, lt);
+  q_tn<NB, NB, NB, true>(q, u, u, s);
+  // wr = W (zt - mu), row form
+  R wr[NB];
+  if (w_diag) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) wr[j] = q_tr(q, w_m[(4 * j + q.c) * 16 + 4 * j + q.c] * (ztc[j] - muc[j]));
+  } else {
+    R rr[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rr[j] = q_tr(q, ztc[j] - muc[j]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {  // (W r)[i], W symmetric: sum_k W[k][i] r[k]
+      wr[i] = R(0);
+#pragma unroll
+      for (int k = 0; k < NB; ++k) q_mfma(q, q_ldc(q, w_m, k, i), rr[k], wr[i]);
+    }
+  }
+  const R ia = r_rcp(alpha);
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {  // (s wr)[i] = sum_k s[k][i] wr[k] (s symmetric), row form; back to column form
+    R t = R(0);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) q_mfma(q, s[k * NB + i], wr[k], t);
+    muc[i] += q_tr(q, t) * ia;
+  }
+  return ok;
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward sweep (i2c.py:876-880 over :350-447)
+// ------------------------------------------------------------------------------------------
+// `live`: trajectory slot b holds a real trajectory (the last wave of a batch that is not a multiple of four repeats its last
+// one in the spare slots: every lane of a wave takes part in the matrix instructions; nothing is stored for them)
+template <class M, typename R, typename S, class KC>
+I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const FwdArgs<R, S>& a, const int b, const bool live, const Quad<R>& q) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D, NT = C::NZT1;
+  constexpr int NBX = (NX + 3) / 4, NBD = (D + 3) / 4, NBZ = (NZ + 3) / 4, NBT = (NT + 3) / 4;
+  static_assert(D <= 8 && NZ <= 12 && NZT <= 12, "quad kernels: d <= 8, at most 12 observations");
+  constexpr bool OBS_ID = st_identity<ObsStruct<M>, NZ>() && NZ == D;
+  constexpr bool TERM_ID = NZT > 0 && st_identity<TermStruct<M>, NT>() && NT == NX;
+  static_assert(OBS_ID || D % 4 != 0, "quad kernels: a general observation needs a spare column in the joint's last block");
+  constexpr int O_K = D + sym(D), O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  const int r = q.r, cc = q.c;
+  const unsigned long B = c.B;
+  const int T = c.T;
+  const unsigned WS = sizeof(S), bo = (unsigned)b * WS, rb = (unsigned)(B * WS);
+  const Rule<R>& rule = c.rule_xu;
+  int fail = 0;
+  auto xrow = [&](const int i) { return 4 * i + r; };  // matrix row / column of this lane in block row i / block column j
+  auto xcol = [&](const int j) { return 4 * j + cc; };
+
+  // state message carried along the chain: mean in column form, covariance in FULL blocks (nx x nx, zero-padded)
+  R mx[NBX], sx[NBX * NBX];
+#pragma unroll
+  for (int j = 0; j < NBX; ++j) {
+    const int col = xcol(j);
+    const R v = a.x0[(long)(col < NX ? col : 0) * B + b];
+    mx[j] = col < NX ? v : R(0);
+#pragma unroll
+    for (int i = 0; i < NBX; ++i) {
+      const int row = xrow(i);
+      const bool in = row < NX && col < NX;
+      const R sv = a.sig_x0[(long)w_symidx(in ? row : 0, in ? col : 0) * B + b];
+      sx[i * NBX + j] = in ? sv : R(0);
+    }
+  }
+
+  // The prior rows of a cell do not depend on the recursion: they are fetched ONE CELL AHEAD (see forward_wave_body)
+  R nx_pmu[NBD], nx_pj[NBD * NBD], nx_kt[NBX * NBD], nx_alpha, nx_zt[NBZ];
+  int nx_ff;
+  const Window ffw = make_window(a.ff, (unsigned long)T);
+  const Window alw = make_window(a.alpha_cell ? a.alpha_cell : a.alpha, (a.alpha_cell ? (unsigned long)T : 1ul) * B * sizeof(R));
+  const Window zw = make_window(c.z_per_cell ? a.z : a.x0, (c.z_per_cell ? (unsigned long)T * NZ : 1ul) * B * sizeof(R));  // (x0 row 0: a valid dummy)
+  auto fetch_prior = [&](const int tc) {
+    const int trc = c.row(tc);
+    const WIO<R, S> pri = wio<R, S>(a.prior + (unsigned long)trc * C::E_POST * B, (unsigned long)C::E_POST, rb, bo);
+#pragma unroll
+    for (int j = 0; j < NBD; ++j) {
+      const int col = xcol(j);
+      nx_pmu[j] = pri.ld(col < D ? col : 0);
+#pragma unroll
+      for (int i = 0; i < NBD; ++i) {
+        const int row = xrow(i);
+        const bool in = row < D && col < D;
+        nx_pj[i * NBD + j] = pri.ld(D + w_symidx(in ? row : 0, in ? col : 0));
+      }
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) {  // F^T = [I | K^T]: row = state index, column = joint index; the action columns hold K^T
+        const int row = xrow(i);
+        const bool in = row < NX && col >= NX && col < D;
+        nx_kt[i * NBD + j] = (4 * j + 3 >= NX) ? pri.ld(O_K + (in ? col - NX : 0) * NX + (in ? row : 0)) : R(0);
+      }
+    }
+    nx_alpha = wld<R>(alw, 0u, a.alpha_cell ? (unsigned)(((unsigned long)trc * B + b) * sizeof(R)) : (unsigned)(b * sizeof(R)));
+#pragma unroll
+    for (int j = 0; j < NBZ; ++j) {
+      const int col = xcol(j);
+      nx_zt[j] = wld<R>(zw, 0u, c.z_per_cell ? (unsigned)((((unsigned long)trc * NZ + (col < NZ ? col : 0)) * B + b) * sizeof(R)) : (unsigned)(b * sizeof(R)));
+    }
+    nx_ff = (int)wld_u8(ffw, (unsigned)trc);
+  };
+  fetch_prior(0);
+  // settled before the loop (see forward_wave_body: loads pending on the loop-entry path cost a vmcnt(0) in every cell)
+  nx_alpha = opaque(nx_alpha);
+  nx_ff = (int)opaque((unsigned)nx_ff);
+#pragma unroll
+  for (int k = 0; k < NBD; ++k) nx_pmu[k] = opaque(nx_pmu[k]);
+#pragma unroll
+  for (int k = 0; k < NBD * NBD; ++k) nx_pj[k] = opaque(nx_pj[k]);
+#pragma unroll
+  for (int k = 0; k < NBX * NBD; ++k) nx_kt[k] = opaque(nx_kt[k]);
+#pragma unroll
+  for (int k = 0; k < NBZ; ++k) nx_zt[k] = opaque(nx_zt[k]);
+#pragma unroll
+  for (int k = 0; k < NBX; ++k) mx[k] = opaque(mx[k]);
+#pragma unroll
+  for (int k = 0; k < NBX * NBX; ++k) sx[k] = opaque(sx[k]);
+
+#if defined(I2C_QUAD_STAMPS) && !defined(I2C_HOST_SIM)
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#endif
+  for (int t = 0; t < T; ++t) {
+    const WIO<R, S> out = wio<R, S>(a.fwd + (unsigned long)t * C::E_FWD * B, (unsigned long)C::E_FWD, rb, bo);
+    const R alpha = nx_alpha;
+    const bool ff = w_uniform(nx_ff) != 0;
+    R pmu[NBD], pj[NBD * NBD], kt[NBX * NBD], zt[NBZ];
+#pragma unroll
+    for (int k = 0; k < NBD; ++k) pmu[k] = nx_pmu[k];
+#pragma unroll
+    for (int k = 0; k < NBD * NBD; ++k) pj[k] = nx_pj[k];
+#pragma unroll
+    for (int k = 0; k < NBX * NBD; ++k) kt[k] = nx_kt[k];
+#pragma unroll
+    for (int j = 0; j < NBZ; ++j) zt[j] = xcol(j) < NZ ? (c.z_per_cell ? nx_zt[j] : q_ldv(q, kc.zg, j)) : R(0);
+    int cell_bad = 0;
+
+    // ---- 1. joint prior over (x, u): mean column form, covariance UPPER blocks -------------
+    R mu0[NBD], s0[NBD * NBD];
+    if (ff) {  // feed-forward: independent action prior (i2c.py:355-360)
+#pragma unroll
+      for (int j = 0; j < NBD; ++j) {
+        const int col = xcol(j);
+        mu0[j] = col < NX ? (j < NBX ? mx[j < NBX ? j : 0] : R(0)) : (col < D ? pmu[j] : R(0));
+#pragma unroll
+        for (int i = 0; i < NBD; ++i) {
+          const int row = xrow(i);
+          const bool xx = row < NX && col < NX, uu = row >= NX && row < D && col >= NX && col < D;
+          const R sxv = (i < NBX && j < NBX) ? sx[(i < NBX ? i : 0) * NBX + (j < NBX ? j : 0)] : R(0);
+          s0[i * NBD + j] = xx ? sxv : (uu ? pj[i * NBD + j] : R(0));
+        }
+      }
+    } else {  // feedback: condition the previous controller on the new state message (i2c.py:361-387)
+      // pdf ratio rho = exp(-delta^T (P_xx + sig_x)^-1 delta / 2): y = L^-1 delta is a right-hand side of the factorisation of the
+      // nx x nx sum -- riding as its spare column nx when nx is not a multiple of 4
+      R dl[NBX], dr[NBX];
+#pragma unroll
+      for (int j = 0; j < NBX; ++j) {
+        dl[j] = xcol(j) < NX ? mx[j] - pmu[j] : R(0);
+        dr[j] = q_tr(q, dl[j]);  // row form
+      }
+      R rho;
+      {
+        constexpr bool SPARE = NX % 4 != 0;
+        constexpr int NCR = SPARE ? 0 : 1, QC = SPARE ? NX % 4 : 0;
+        R sm[NBX * NBX], lt[NBX * NBX], rhs[NBX];
+#pragma unroll
+        for (int i = 0; i < NBX; ++i) {
+#pragma unroll
+          for (int j = 0; j < NBX; ++j) {
+            const bool xx = xrow(i) < NX && xcol(j) < NX;
+            sm[i * NBX + j] = xx ? pj[i * NBD + j] + sx[i * NBX + j] : R(0);
+          }
+          if constexpr (SPARE) sm[i * NBX + NBX - 1] = (cc == QC && xrow(i) < NX) ? dr[i] : sm[i * NBX + NBX - 1];
+          rhs[i] = (cc == QC && xrow(i) < NX) ? dr[i] : R(0);
+        }
+        cell_bad = flag_stage(cell_bad, q_elim<NX, NCR, 0>(q, sm, rhs, (R*)nullptr, lt), 0);
+        R ysq = R(0);
+#pragma unroll
+        for (int i = 0; i < NBX; ++i) {
+          const R yv = SPARE ? lt[i * NBX + NBX - 1] : rhs[i];
+          ysq += (cc == QC && xrow(i) < NX) ? yv * yv : R(0);
+        }
+        const R maha = q_bcq<QC>(q, q_colsum(q, ysq));
+        rho = r_exp(R(-0.5) * maha);
+      }
+      // F^T = [I | Kt^T] (nx x d), Kt = rho K:  sig_0 = F sig_x F^T with (P_uu - Kt P_xu) added to the action block
+      R ft[NBX * NBD], m1[NBX * NBD], m1p[NBX * NBD];
+#pragma unroll
+      for (int i = 0; i < NBX; ++i)
+#pragma unroll
+        for (int j = 0; j < NBD; ++j) {
+          const int row = xrow(i), col = xcol(j);
+          ft[i * NBD + j] = col < NX ? (row == col ? R(1) : R(0)) : ((col < D && row < NX) ? rho * kt[i * NBD + j] : R(0));
+          m1[i * NBD + j] = R(0);
+        }
+      q_tn<NBX, NBX, NBD>(q, sx, ft, m1);  // sig_x F^T (sig_x symmetric)
+#pragma unroll
+      for (int j = 0; j < NBD; ++j) {  // action columns: Kt delta
+        R t = R(0);
+#pragma unroll
+        for (int i = 0; i < NBX; ++i) t += ft[i * NBD + j] * dr[i];
+        const R kd = q_colsum(q, t);
+        const int col = xcol(j);
+        mu0[j] = col < NX ? (j < NBX ? mx[j < NBX ? j : 0] : R(0)) : (col < D ? pmu[j] + kd : R(0));
+      }
+#pragma unroll
+      for (int i = 0; i < NBX; ++i)
+#pragma unroll
+        for (int j = 0; j < NBD; ++j) {
+          const bool xu = xrow(i) < NX && xcol(j) >= NX && xcol(j) < D;
+          m1p[i * NBD + j] = xu ? m1[i * NBD + j] - pj[i * NBD + j] : m1[i * NBD + j];
+        }
+#pragma unroll
+      for (int k = 0; k < NBD * NBD; ++k) s0[k] = R(0);
+      q_tn<NBX, NBD, NBD, false, true>(q, ft, m1p, s0);
+#pragma unroll
+      for (int i = 0; i < NBD; ++i)
+#pragma unroll
+        for (int j = i; j < NBD; ++j) {
+          const int row = xrow(i), col = xcol(j);
+          const bool xrw = row < NX, urw = row >= NX && row < D, ucl = col >= NX && col < D;
+          const R m1v = i < NBX ? m1[(i < NBX ? i : 0) * NBD + j] : R(0);
+          // state rows, action columns: sig_x Kt^T itself; action block: P_uu - Kt P_xu + Kt sig_x Kt^T
+          s0[i * NBD + j] = (xrw && ucl) ? m1v : ((urw && ucl) ? s0[i * NBD + j] + pj[i * NBD + j] : s0[i * NBD + j]);
+        }
+    }
+    I2C_QSTAMP(0);  // joint prior
+    fetch_prior(t + 1 < T ? t + 1 : t);  // this cell's rows are consumed: the next cell's, a cell ahead
+    if (a.prior_out) {
+      const WIO<R, S> po = wio<R, S>(a.prior_out + (unsigned long)t * (D + sym(D)) * B, (unsigned long)(D + sym(D)), rb, bo);
+#pragma unroll
+      for (int j = 0; j < NBD; ++j) {
+        po.st_if(live && r == 0 && xcol(j) < D, xcol(j), mu0[j]);
+#pragma unroll
+        for (int i = 0; i <= j; ++i) po.st_if(live && xrow(i) <= xcol(j) && xcol(j) < D, D + w_symidx(xrow(i), xcol(j) < D ? xcol(j) : 0), s0[i * NBD + j]);
+      }
+    }
+
+    // ---- 2. cost "observation": measurement update on z (i2c.py:390-407) ----------------
+    if constexpr (OBS_ID) {
+      R sf_[NBD * NBD];  // full blocks for the identity form
+#pragma unroll
+      for (int i = 0; i < NBD; ++i)
+#pragma unroll
+        for (int j = 0; j < NBD; ++j) sf_[i * NBD + j] = j >= i ? s0[i * NBD + j] : q_tr(q, s0[j * NBD + i]);
+      cell_bad = flag_stage(cell_bad, q_kalman_identity<D>(q, alpha, kc.xi, kc.qr, c.qr_diag != 0, zt, mu0, sf_), 2);
+#pragma unroll
+      for (int k = 0; k < NBD * NBD; ++k) s0[k] = sf_[k];
+    } else {
+      R lt[NBD * NBD];
+      {
+        R tmp[NBD * NBD];
+#pragma unroll
+        for (int k = 0; k < NBD * NBD; ++k) tmp[k] = s0[k];
+        cell_bad = flag_stage(cell_bad, q_elim<D, 0, 0>(q, tmp, (R*)nullptr, (R*)nullptr, lt), 1);
+      }
+      I2C_QSTAMP(1);  // chol(prior joint)
+      R am[NBD * NBZ], dm[NBD * NBZ], yc[NBZ], mz[NBZ], sz[NBZ * NBZ], szx[NBZ * NBD];
+      q_points<M, D, NZ>(q, rule.sf, mu0, lt, ObserveF<M, R>{c.params}, am, dm, yc);
+      I2C_QSTAMP(2);  // observation points
+      q_moments<D, NZ>(q, rule.wi, am, dm, yc, mz, sz);
+#pragma unroll
+      for (int i = 0; i < NBZ; ++i)
+#pragma unroll
+        for (int j = i; j < NBZ; ++j) sz[i * NBZ + j] += alpha * q_ldc(q, kc.xi, i, j);
+      // cov(z, xu) = wi sf [d_p]^T L^T
+#pragma unroll
+      for (int k = 0; k < NBZ * NBD; ++k) szx[k] = R(0);
+      q_tn<NBD, NBZ, NBD, false, false, true>(q, dm, lt, szx);
+      const R cw = rule.wi * rule.sf;
+#pragma unroll
+      for (int k = 0; k < NBZ * NBD; ++k) szx[k] *= cw;
+      I2C_QSTAMP(3);  // observation moments
+      cell_bad = flag_stage(cell_bad, q_kalman<D, NZ>(q, mu0, s0, mz, sz, szx, zt), 2);
+    }
+    I2C_QSTAMP(4);  // Kalman-style update
+#pragma unroll
+    for (int j = 0; j < NBD; ++j) {
+      out.st_if(live && r == 0 && xcol(j) < D, xcol(j), mu0[j]);
+#pragma unroll
+      for (int i = 0; i <= j; ++i) out.st_if(live && xrow(i) <= xcol(j) && xcol(j) < D, D + w_symidx(xrow(i), xcol(j) < D ? xcol(j) : 0), s0[i * NBD + j]);
+    }
+
+    // ---- 3. dynamics push-through (i2c.py:415-421) ----------------------------------------
+    R sxy[NBX * NBD];  // sig_xy^T (nx x d)
+    {
+      R lt[NBD * NBD];
+      {
+        R tmp[NBD * NBD];
+#pragma unroll
+        for (int k = 0; k < NBD * NBD; ++k) tmp[k] = s0[k];
+        cell_bad = flag_stage(cell_bad, q_elim<D, 0, 0>(q, tmp, (R*)nullptr, (R*)nullptr, lt), 3);
+      }
+      I2C_QSTAMP(5);  // stores + chol(updated joint)
+      R am[NBD * NBX], dm[NBD * NBX], yc[NBX], sy[NBX * NBX];
+      q_points<M, D, NX>(q, rule.sf, mu0, lt, DynamicsF<M, R>{c.params}, am, dm, yc);
+      I2C_QSTAMP(6);  // dynamics points
+      q_moments<D, NX>(q, rule.wi, am, dm, yc, mx, sy);
+#pragma unroll
+      for (int i = 0; i < NBX; ++i)
+#pragma unroll
+        for (int j = 0; j < NBX; ++j) sx[i * NBX + j] = j >= i ? sy[i * NBX + j] + q_ldc(q, kc.eta, i, j) : R(0);
+#pragma unroll
+      for (int k = 0; k < NBX * NBD; ++k) sxy[k] = R(0);
+      q_tn<NBD, NBX, NBD, false, false, true>(q, dm, lt, sxy);  // sig_xy^T = wi sf [d_p]^T L^T
+      const R cw = rule.wi * rule.sf;
+#pragma unroll
+      for (int k = 0; k < NBX * NBD; ++k) sxy[k] *= cw;
+    }
+    // ---- smoother gain J = sig_xy sig_x3^-1 (i2c.py:423-425): J^T = W^T (W sig_xy^T), W = chol(sig_x3)^-1 ----
+    R l3[NBX * NBX];
+    {
+      R tmp[NBX * NBX], w3[NBX * NBX], jt[NBX * NBD];
+#pragma unroll
+      for (int i = 0; i < NBX; ++i)
+#pragma unroll
+        for (int j = 0; j < NBX; ++j) {
+          tmp[i * NBX + j] = sx[i * NBX + j];
+          w3[i * NBX + j] = (i == j && r == cc && xrow(i) < NX) ? R(1) : R(0);
+        }
+      cell_bad = flag_stage(cell_bad, q_elim<NX, NBD, NBX>(q, tmp, sxy, w3, l3), 4);
+#pragma unroll
+      for (int k = 0; k < NBX * NBD; ++k) jt[k] = R(0);
+      q_tn<NBX, NBX, NBD>(q, w3, sxy, jt);
+#pragma unroll
+      for (int i = 0; i < NBX; ++i)
+#pragma unroll
+        for (int j = 0; j < NBD; ++j) {
+          const bool in = xrow(i) < NX && xcol(j) < D;
+          out.st_if(live && in, O_J + (in ? xcol(j) : 0) * NX + (in ? xrow(i) : 0), jt[i * NBD + j]);
+        }
+    }
+    // the lower blocks of sig_x3 (the next cell multiplies with the full matrix)
+#pragma unroll
+    for (int i = 0; i < NBX; ++i)
+#pragma unroll
+      for (int j = 0; j < i; ++j) sx[i * NBX + j] = q_tr(q, sx[j * NBX + i]);
+    // ---- 4. terminal cost observation on the flagged cell, after J (i2c.py:430-443) ----
+    if (NZT > 0 && t == c.terminal_cell && c.has_Qf) {  // (uniform: kernel arguments)
+      R ztT[NBT];
+#pragma unroll
+      for (int j = 0; j < NBT; ++j) ztT[j] = q_ldv(q, kc.zgT, j);
+      if constexpr (TERM_ID) {
+        cell_bad = flag_stage(cell_bad, q_kalman_identity<NX>(q, alpha, kc.xiT, kc.qf, c.qf_diag != 0, ztT, mx, sx), 5);
+      } else if constexpr (NZT > 0) {
+        R am[NBX * NBT], dm[NBX * NBT], yc[NBT], mz[NBT], sz[NBT * NBT], szx[NBT * NBX];
+        q_points<M, NX, NT>(q, c.rule_x.sf, mx, l3, ObserveTermF<M, R>{c.params}, am, dm, yc);
+        q_moments<NX, NT>(q, c.rule_x.wi, am, dm, yc, mz, sz);
+#pragma unroll
+        for (int i = 0; i < NBT; ++i)
+#pragma unroll
+          for (int j = i; j < NBT; ++j) sz[i * NBT + j] += alpha * q_ldc(q, kc.xiT, i, j);
+#pragma unroll
+        for (int k = 0; k < NBT * NBX; ++k) szx[k] = R(0);
+        q_tn<NBX, NBT, NBX, false, false, true>(q, dm, l3, szx);
+        const R cw = c.rule_x.wi * c.rule_x.sf;
+#pragma unroll
+        for (int k = 0; k < NBT * NBX; ++k) szx[k] *= cw;
+        cell_bad = flag_stage(cell_bad, q_kalman<NX, NT>(q, mx, sx, mz, sz, szx, ztT), 5);
+#pragma unroll
+        for (int i = 0; i < NBX; ++i)
+#pragma unroll
+          for (int j = 0; j < i; ++j) sx[i * NBX + j] = q_tr(q, sx[j * NBX + i]);
+      }
+    }
+    fail = fold_cell_failure(fail, cell_bad, t);
+#pragma unroll
+    for (int j = 0; j < NBX; ++j) {
+      out.st_if(live && r == 0 && xcol(j) < NX, O_MU3 + (xcol(j) < NX ? xcol(j) : 0), mx[j]);
+#pragma unroll
+      for (int i = 0; i <= j; ++i) out.st_if(live && xrow(i) <= xcol(j) && xcol(j) < NX, O_S3 + w_symidx(xrow(i), xcol(j) < NX ? xcol(j) : 0), sx[i * NBX + j]);
+    }
+    I2C_QSTAMP(7);  // dynamics moments, smoother gain, terminal update, stores
+  }
+#if defined(I2C_QUAD_STAMPS) && !defined(I2C_HOST_SIM)
+  if (b == 0 && q.l == 0)
+    printf("quad forward, clocks per cell: prior %llu | chol0 %llu | obs points %llu | obs moments %llu | kalman %llu | stores+chol1 %llu | dyn points %llu | moments+gain+stores %llu\n",
+           stamp_acc[0] / T, stamp_acc[1] / T, stamp_acc[2] / T, stamp_acc[3] / T, stamp_acc[4] / T, stamp_acc[5] / T, stamp_acc[6] / T, stamp_acc[7] / T);
+#endif
+  if (live && q.p() == 0 && fail != 0 && a.status[b] == 0) a.status[b] = fail;
+}
+
+}  // namespace i2c

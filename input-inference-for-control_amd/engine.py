@@ -101,12 +101,16 @@ class BatchedI2c:
         # 64 = the wave kernels (csrc/i2c_wave.hpp: one wavefront per trajectory, blocks in the fp64 matrix-instruction layout),
         # for the models that have them (dims.wave): forward and backward sweeps; propagation and filter run the model's default
         ok = self.group_lanes in (0, dims.group_lanes) or (self.group_lanes == -1 and not dims.group_only) or \
-            (self.group_lanes == 64 and dims.wave)
+            (self.group_lanes == 64 and (dims.wave or dims.quad))
         if not ok:
             raise ValueError(f"group_lanes={self.group_lanes}: this model's group kernels use {dims.group_lanes} lanes"
                              + (" and it has no one-lane kernels" if dims.group_only else " (or -1: one lane per trajectory)")
-                             + (" (or 64: one wavefront per trajectory)" if dims.wave else ""))
-        self.uses_group_kernels = bool(self.group_lanes > 0 or dims.group_only)  # a multi-lane family (group or wave) serves the sweeps
+                             + (" (or 64: one wavefront per trajectory)" if dims.wave else "")
+                             + (" (or 64: four trajectories per wavefront, forward sweep)" if dims.quad else ""))
+        # 64 on a model with the quad kernel (csrc/i2c_quad.hpp: four trajectories per wavefront on the 4 x 4 x 4 fp64 matrix
+        # instruction): the FORWARD sweep runs on it, every other sweep on the model's default kernels
+        self.quad_requested = bool(self.group_lanes == 64 and dims.quad and not dims.wave)
+        self.uses_group_kernels = bool((self.group_lanes > 0 and not self.quad_requested) or dims.group_only)  # a multi-lane family (group or wave) serves the sweeps
         if self.mixed and inference != "cubature":
             raise ValueError("fp32 storage (storage_dtype) is available for the cubature path only")
         if self.mixed and self.uses_group_kernels and not (dims.wave and self.group_lanes in (0, 64)):

@@ -103,6 +103,28 @@ def test_hip_wave_fused_learn_matches_stepwise(lib):
         assert torch.equal(engs[0].post, engs[1].post) and torch.equal(engs[0].alpha, engs[1].alpha)
 
 
+# The quad forward kernel (csrc/i2c_quad.hpp, group_lanes = 64 on the d <= 8 models) against the reference's golden vectors,
+# including the long free runs (200 EM iterations of the pendulum, 20 / 50 of the double cartpole at T = 300)
+QUAD_GOLDEN = [("em_pendulum_T200", 1e-8, 1e-7), ("em_pendulum_T200_run200", 1e-6, 1e-5), ("em_dcp_T60", 1e-6, 1e-5),
+               ("em_dcp_T300_run20", 1e-6, 1e-5), ("em_dcp_T300_run50", 1e-6, 1e-5), ("em_dcp_nondiag_T30", 1e-6, 1e-5),
+               ("em_cartpole_T100", 1e-6, 1e-5), ("em_linear_T60", 1e-8, 1e-7), ("em_quadrotor_T20", 1e-6, 1e-5),
+               ("em_pendulum_T30_tau7", 1e-8, 1e-7), ("em_covctrl_T100", 1e-7, 1e-6), ("em_covctrl_qf_T40", 1e-7, 1e-6)]
+
+
+@pytest.mark.parametrize("name,tol_d,tol_s", QUAD_GOLDEN)
+def test_hip_quad_forward_vs_reference_golden(lib, name, tol_d, tol_s):
+    eng = parity.check_against_golden(name, lib, "cuda", tol_d, tol_s, group_lanes=64)
+    assert eng.forward_family == "quad" and eng.backward_family == "lane"
+
+
+@pytest.mark.parametrize("name,B", [("em_dcp_T60", 77), ("em_pendulum_T200", 1001), ("em_quadrotor_T20", 203), ("em_cartpole_T100", 130)])
+def test_hip_quad_forward_batch_vs_oracle(lib, name, B):
+    """Ragged batches (not a multiple of the four trajectories of a wavefront, nor of the 16 that share a cache line) against
+    the batched oracle."""
+    eng, _ = parity.check_batch_against_oracle(name, lib, "cuda", B, 3, tol=1e-6, group_lanes=64)
+    assert eng.forward_family == "quad"
+
+
 @pytest.mark.parametrize("name", ["em_dcp_T60", "em_quadrotor_T20"])
 def test_hip_kernel_families_agree_at_B4096(lib, name):
     """The three ways to run a d >= 7 model -- the default (group forward + one-lane backward), group kernels throughout,

@@ -103,6 +103,46 @@ def test_hostsim_wave_kernels_are_the_quad12_default(lib):
         parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu", quad=(1.2, 0.44, 0.5), group_lanes=64).forward_sweep()
 
 
+# The QUAD forward kernel (csrc/i2c_quad.hpp: four trajectories per wavefront, 4 x 4 blocks on the small fp64 matrix instruction,
+# one sigma point per lane through the model functors -- general observation functions included) on every d <= 8 model, with the
+# lane kernels' backward schedules behind it: the same golden vectors. group_lanes = 64 asks for it. The host simulation runs the
+# 64 lanes of a wave as 64 threads and emulates the matrix / DPP instructions.
+QUAD_GOLDEN = [
+    ("em_pendulum_T200", 1e-9, 1e-8, 8),       # 1 block everywhere; trigonometric observation; terminal update through sin / cos
+    ("em_dcp_T60", 1e-7, 1e-6, None),          # d = 7 (2 blocks), nz = 9 (3 blocks, the last one a scalar pivot)
+    ("em_dcp_nondiag_T30", 1e-7, 1e-6, None),  # non-diagonal weights (the forward sweep only sees sig_xi = alpha inv(QR))
+    ("em_cartpole_T100", 1e-7, 1e-6, None),    # nx = 4: the pdf-ratio solve has no spare column, the innovation none at the terminal update
+    ("em_linear_T60", 1e-9, 1e-8, None),       # identity observation, d = 3
+    ("em_quadrotor_T20", 1e-7, 1e-6, None),    # identity observation, d = 8: sixteen points, no centre evaluation
+    ("em_pendulum_T30_tau7", 1e-9, 1e-8, None),  # feed-forward and feedback cells in one sweep
+    ("em_covctrl_T100", 1e-8, 1e-7, 8),        # nz = 1 (only the action is observed), no terminal observation; covariance control behind it
+    ("em_covctrl_qf_T40", 1e-8, 1e-7, None),
+]
+
+
+@pytest.mark.parametrize("name,tol_d,tol_s,n_iters", QUAD_GOLDEN)
+def test_hostsim_quad_forward_vs_reference_golden(lib, name, tol_d, tol_s, n_iters):
+    eng = parity.check_against_golden(name, lib, "cpu", tol_d, tol_s, n_iters=n_iters, group_lanes=64)
+    assert eng.forward_family == "quad" and eng.backward_family == "lane"
+
+
+@pytest.mark.parametrize("name,B", [("em_dcp_T60", 6), ("em_pendulum_T200", 9), ("em_quadrotor_T20", 5), ("em_cartpole_T100", 3)])
+def test_hostsim_quad_forward_batch_vs_oracle(lib, name, B):
+    """Ragged batches (not a multiple of the four trajectories of a wavefront: the spare slots repeat the last trajectory and
+    store nothing) against the batched oracle."""
+    eng, _ = parity.check_batch_against_oracle(name, lib, "cpu", B, 2, tol=1e-7, group_lanes=64)
+    assert eng.forward_family == "quad"
+
+
+def test_quad_forward_refuses_what_it_does_not_cover(lib):
+    """General cubature weights (a weight on the centre point) and the other inference rules are not in the quad form: the
+    library says I2C_ENOTSUP when it is asked for explicitly."""
+    with pytest.raises(RuntimeError, match="-2"):
+        parity.engine_from_case(load_case("em_pendulum_T40_quad_general"), lib, "cpu", group_lanes=64).forward_sweep()
+    with pytest.raises(ValueError):  # d = 16 has the wave kernels under 64; models without either refuse it
+        parity.engine_from_case(load_case("em_pendulum_T200"), lib, "cpu", group_lanes=32)
+
+
 @pytest.mark.parametrize("name,tol_d,tol_s", LANE_GOLDEN)
 def test_hostsim_lane_kernels_vs_reference_golden(lib, name, tol_d, tol_s):
     parity.check_against_golden(name, lib, "cpu", tol_d, tol_s, group_lanes=-1)

@@ -77,6 +77,23 @@ def test_mpc_replay_gpu(name):
     _replay(name, None, "cuda", 1e-6)
 
 
+# the reference's MPC loops with the forward sweeps on the quad kernel (csrc/i2c_quad.hpp: per-cell targets and temperatures,
+# the ring of per-cell buffers, a terminal cell that sits mid-horizon after the first shift)
+@pytest.mark.parametrize("name", ["mpc_pendulum_ff", "mpc_pendulum_fb", "mpc_pendulum_fb_short_targets", "mpc_pendulum_random0",
+                                  "mpc_pendulum_random5", "mpc_quadrotor_fb"])
+def test_mpc_replay_quad_forward_cpu(name):
+    pol = _replay(name, hostsim.load(), "cpu", 1e-7, group_lanes=64)
+    assert pol.engine.forward_family == "quad"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mpc_pendulum_ff", "mpc_pendulum_fb", "mpc_pendulum_fb_short_targets", "mpc_pendulum_random0",
+                                  "mpc_pendulum_random5", "mpc_quadrotor_fb"])
+def test_mpc_replay_quad_forward_gpu(name):
+    pol = _replay(name, None, "cuda", 1e-6, group_lanes=64)
+    assert pol.engine.forward_family == "quad"
+
+
 # mpc_quad12_fb above runs the 12-state quadrotor's default, the wave kernels; the same replay on its group kernels
 def test_mpc_replay_quad12_group_kernels_cpu():
     pol = _replay("mpc_quad12_fb", hostsim.load(), "cpu", 1e-7, group_lanes=16)

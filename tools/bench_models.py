@@ -2,7 +2,8 @@
 python tools/bench_models.py [model ...] [B ...] [two_pass|fused|chunked ...] [f64] [group] [lane] [wave]
 `group` runs the group kernels (G lanes per trajectory) as well where a model has both forms; `lane` forces one lane per
 trajectory for every sweep (the default runs the forward sweep of the d >= 7 models on the group kernels at small batches);
-`wave` runs the one-wavefront-per-trajectory kernels where a model has them (the 12-state quadrotor)."""
+`wave` runs the matrix-instruction kernels where a model has them (group_lanes = 64: one wavefront per trajectory for the 12-state
+quadrotor, four trajectories per wavefront -- forward sweep -- for the d <= 8 models)."""
 import importlib
 import os
 import sys
@@ -71,8 +72,8 @@ if __name__ == "__main__":
                     for grp in groups:
                         if grp is True and (dt != torch.float64 or m != modes[0]):
                             continue
-                        if grp == 64 and (n != "Quadrotor12" or dt != torch.float64 or m != modes[0]):
-                            continue
+                        if grp == 64 and (dt != torch.float64 or m != modes[0]):
+                            continue  # (64: the wave kernels of the 12-state quadrotor, the quad forward kernel of the d <= 8 models)
                         if grp == 0 and n == "Quadrotor12" and 64 in groups:
                             continue  # the default IS the wave family where it applies
                         if grp == -1 and n == "Quadrotor12":
