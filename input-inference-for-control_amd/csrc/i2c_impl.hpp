@@ -571,10 +571,11 @@ template <class M, typename R, typename S = R> struct Impl {
     return I2C_OK;
   }
   static int family(const I2cProblem* p, const C& c, const int sweep) {
-    if constexpr (HAS_QUAD) {  // forward sweep: on request (group_lanes = 64)
-      if (sweep == I2C_SWEEP_FORWARD && p->group_lanes == 64) {
+    if constexpr (HAS_QUAD) {  // forward sweep: on request (group_lanes = 64), or the model's default for small batches
+      if (sweep == I2C_SWEEP_FORWARD && (p->group_lanes == 64 || (p->group_lanes == 0 && p->B <= M::QUAD_FORWARD_MAX_B))) {
         const int rc = quad_supported(p, c);
-        return rc == I2C_OK ? I2C_FAMILY_QUAD : rc;
+        if (rc == I2C_OK) return I2C_FAMILY_QUAD;
+        if (p->group_lanes == 64) return rc;
       }
     }
     if constexpr (HAS_WAVE) {  // forward and backward sweeps: on request (group_lanes = 64) or as the model's default

@@ -25,6 +25,7 @@ struct Pendulum {
   static constexpr bool GROUP_FORWARD_AUTO = false;  // see Impl::forward_any (i2c_impl.hpp)
   static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
+  static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   I2C_HD static constexpr int ang(int) { return 0; }
   // z = [sin th, cos th, thd, u],  zT = [sin th, cos th, thd]
   I2C_HD static constexpr int obs_lin(int k) { return k < 2 ? -1 : k - 1; }
@@ -70,6 +71,7 @@ struct PendulumActReg {
   static constexpr bool GROUP_FORWARD_AUTO = false;  // see Impl::forward_any (i2c_impl.hpp)
   static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
+  static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int) { return 2; }  // z = [u]
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -96,6 +98,7 @@ struct Cartpole {
   static constexpr bool GROUP_FORWARD_AUTO = false;  // see Impl::forward_any (i2c_impl.hpp)
   static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
+  static constexpr int QUAD_FORWARD_MAX_B = 4096;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   I2C_HD static constexpr int ang(int) { return 1; }
   // z = [x, sin th, cos th, xd, thd, u],  zT = [x, sin th, cos th, xd, thd]
   I2C_HD static constexpr int obs_lin(int k) { return k == 0 ? 0 : (k < 3 ? -1 : k - 1); }
@@ -149,6 +152,7 @@ struct DoubleCartpole {
   static constexpr bool GROUP_FORWARD_AUTO = true;   // see Impl::forward_any (i2c_impl.hpp)
   static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
+  static constexpr int QUAD_FORWARD_MAX_B = 8192;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   I2C_HD static constexpr int ang(int a) { return a == 0 ? 1 : 2; }
   // z = [x, sin th1, cos th1, sin th2, cos th2, xd, th1d, th2d, u],  zT = z without u
   I2C_HD static constexpr int obs_lin(int k) { return k == 0 ? 0 : (k < 5 ? -1 : k - 2); }
@@ -228,6 +232,7 @@ struct Linear {
   static constexpr bool GROUP_FORWARD_AUTO = false;  // see Impl::forward_any (i2c_impl.hpp)
   static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
+  static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -263,6 +268,7 @@ struct LinearMinEnergy {
   static constexpr bool GROUP_FORWARD_AUTO = false;  // see Impl::forward_any (i2c_impl.hpp)
   static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
+  static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int) { return 2; }  // z = [u], zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -299,6 +305,7 @@ struct Quadrotor {
   static constexpr bool GROUP_FORWARD_AUTO = true;   // see Impl::forward_any (i2c_impl.hpp)
   static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
+  static constexpr int QUAD_FORWARD_MAX_B = 8192;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   I2C_HD static constexpr int ang(int) { return 2; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -363,6 +370,7 @@ struct Quadrotor12 {
   static constexpr bool GROUP_FORWARD_AUTO = false;
   static constexpr bool WAVE = true;   // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   static constexpr bool QUAD = false;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
+  static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   I2C_HD static constexpr int ang(int a) { return 3 + a; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }

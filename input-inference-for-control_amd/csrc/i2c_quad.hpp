@@ -37,7 +37,8 @@ struct QuadLds {
   static constexpr int O_Y = O_L + 8 * LDL;
   static constexpr int O_MV = O_Y + 16 * YLD;  // the mean the points are built around (8)
   static constexpr int O_DG = O_MV + 8;        // 4 x 4 pivot block
-  static constexpr int SIZE = O_DG + 16 + 2;   // (= 10 mod 32 elements: the four regions of a wave start on different banks)
+  static constexpr int O_DG2 = O_DG + 16;      // ... of the second elimination of a pair (q_elim2)
+  static constexpr int SIZE = O_DG2 + 16 + 2;  // (= 26 mod 32 elements: the four regions of a wave start on different banks)
 };
 
 // Diagnostic build only (-DI2C_QUAD_STAMPS, never in the shipped library): s_memtime stamps at the phase boundaries of the forward
@@ -149,14 +150,12 @@ template <typename R, class P> I2C_FN R q_ldv(const Quad<R>& q, const P v, const
 // the others are left alone) and each right-hand side block matrix r1 [NB][NC1], r2 [NB][NC2] is replaced by L^-1 r. Returns
 // whether every pivot was positive. Rows / columns >= N of s and of the right-hand sides must be zero (no identity padding: the
 // pivot algebra of a partly filled block is compiled for its NL live rows).
-template <int K, int NB, int N, int NC1, int NC2, typename R>
-I2C_FN void q_elim_step(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* last) {
-  constexpr int NL = (N - 4 * K) >= 4 ? 4 : (N - 4 * K);
-  static_assert(NL >= 1, "empty pivot block");
-  const auto dg = q.sh + QuadLds::O_DG;
-  q.sync();
-  dg[4 * q.r + q.c] = s[K * NB + K];
-  q.sync();
+// One pivot step = (a) the 4 x 4 pivot block through LDS to the sixteen lanes of its trajectory, (b) every lane factors it and
+// forms ITS entry of the inverse factor, (c) matrix instructions scale block row K and eliminate it from everything below.
+// q_elim2 runs two independent eliminations in lockstep: one LDS round trip per pair of pivot blocks, and two independent
+// instruction streams for the scheduler to interleave (a lone wave per SIMD has nothing else to hide its latencies behind).
+template <int NL, typename R, class P> I2C_FN void q_pivot_algebra(const Quad<R>& q, const P dg, R* aw_out, R* pl_out) {
+  static_assert(NL >= 1 && NL <= 4, "pivot block");
   // 4 x 4 Cholesky of the pivot block (l), column by column; rows >= NL are identity rows
   const R d00 = dg[0];
   const R i0 = r_rsqrt(d00);
@@ -183,19 +182,26 @@ I2C_FN void q_elim_step(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* last) {
     pl = d33 - l30 * l30 - l31 * l31 - l32 * l32;
     i3 = r_rsqrt(pl);
   }
-  if (K == NB - 1) *last = pl;  // a failed pivot poisons everything after it (see chol(), i2c_linalg.hpp)
+  *pl_out = pl;  // (the last pivot: a failed one poisons everything after it, see chol(), i2c_linalg.hpp)
   // this lane's entry of the inverse of l as the A operand: lane (r, c) supplies A[c][r] = (l^-1)[c][r]. Row a of l^-1 solves
   // y^T l = e_a^T (back substitution; y_k = 0 for k > a falls out of the one-hot right-hand side); entry r picked by a one-hot
   // combination (written without selects: see w_elim_step, i2c_wave.hpp)
   const int a = q.c, cq = q.r;
   const R e0 = a == 0 ? R(1) : R(0), e1 = a == 1 ? R(1) : R(0), e2 = a == 2 ? R(1) : R(0), e3 = a == 3 ? R(1) : R(0);
-  const R y3 = e3 * i3;
-  const R y2 = (e2 - l32 * y3) * i2;
-  const R y1 = (e1 - l21 * y2 - l31 * y3) * i1;
-  const R y0 = (e0 - l10 * y1 - l20 * y2 - l30 * y3) * i0;
   const R m0 = cq == 0 ? R(1) : R(0), m1 = cq == 1 ? R(1) : R(0), m2 = cq == 2 ? R(1) : R(0), m3 = cq == 3 ? R(1) : R(0);
-  const R aw = (m0 * y0 + m1 * y1) + (m2 * y2 + m3 * y3);
-  // scale block row K: rows of L^T (the diagonal block masked to its upper triangle: what is left of it is rounding noise) ...
+  if constexpr (NL == 1) {
+    *aw_out = (e0 * m0) * i0 + (e1 * m1 + e2 * m2 + e3 * m3);
+  } else {
+    const R y3 = e3 * i3;
+    const R y2 = (e2 - l32 * y3) * i2;
+    const R y1 = (e1 - l21 * y2 - l31 * y3) * i1;
+    const R y0 = (e0 - l10 * y1 - l20 * y2 - l30 * y3) * i0;
+    *aw_out = (m0 * y0 + m1 * y1) + (m2 * y2 + m3 * y3);
+  }
+}
+// scale block row K by the inverse pivot factor (aw) and eliminate it from everything below
+template <int K, int NB, int NC1, int NC2, typename R> I2C_FN void q_elim_apply(const Quad<R>& q, const R aw, R* s, R* r1, R* r2, R* lt) {
+  // rows of L^T (the diagonal block masked to its upper triangle: what is left of it is rounding noise) ...
 #pragma unroll
   for (int j = K; j < NB; ++j) {
     R x = R(0);
@@ -214,7 +220,7 @@ I2C_FN void q_elim_step(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* last) {
     q_mfma(q, aw, r2[K * NC2 + j], x);
     r2[K * NC2 + j] = x;
   }
-  // ... and eliminate it from everything below
+  // ... and the elimination
 #pragma unroll
   for (int i = K + 1; i < NB; ++i) {
     const R nl = -lt[K * NB + i];
@@ -225,12 +231,48 @@ I2C_FN void q_elim_step(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* last) {
 #pragma unroll
     for (int j = 0; j < NC2; ++j) q_mfma(q, nl, r2[K * NC2 + j], r2[i * NC2 + j]);
   }
+}
+template <int K, int NB, int N, int NC1, int NC2, typename R>
+I2C_FN void q_elim_step(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* last) {
+  constexpr int NL = (N - 4 * K) >= 4 ? 4 : (N - 4 * K);
+  const auto dg = q.sh + QuadLds::O_DG;
+  q.sync();
+  dg[4 * q.r + q.c] = s[K * NB + K];
+  q.sync();
+  R aw, pl;
+  q_pivot_algebra<NL>(q, dg, &aw, &pl);
+  if (K == NB - 1) *last = pl;
+  q_elim_apply<K, NB, NC1, NC2>(q, aw, s, r1, r2, lt);
   if constexpr (K + 1 < NB) q_elim_step<K + 1, NB, N, NC1, NC2>(q, s, r1, r2, lt, last);
 }
 template <int N, int NC1, int NC2, typename R> I2C_FN bool q_elim(const Quad<R>& q, R* s, R* r1, R* r2, R* lt) {
   R last = R(0);
   q_elim_step<0, (N + 3) / 4, N, NC1, NC2>(q, s, r1, r2, lt, &last);
   return last > R(0);
+}
+// two eliminations of the same dimension in lockstep: (sa; ra1, ra2) -> lta and (sb; rb1) -> ltb
+template <int K, int NB, int N, int NA1, int NA2, int NB1, typename R>
+I2C_FN void q_elim2_step(const Quad<R>& q, R* sa, R* ra1, R* ra2, R* lta, R* lasta, R* sb, R* rb1, R* ltb, R* lastb) {
+  constexpr int NL = (N - 4 * K) >= 4 ? 4 : (N - 4 * K);
+  const auto dga = q.sh + QuadLds::O_DG, dgb = q.sh + QuadLds::O_DG2;
+  q.sync();
+  dga[4 * q.r + q.c] = sa[K * NB + K];
+  dgb[4 * q.r + q.c] = sb[K * NB + K];
+  q.sync();
+  R awa, pla, awb, plb;
+  q_pivot_algebra<NL>(q, dga, &awa, &pla);
+  q_pivot_algebra<NL>(q, dgb, &awb, &plb);
+  if (K == NB - 1) *lasta = pla, *lastb = plb;
+  q_elim_apply<K, NB, NA1, NA2>(q, awa, sa, ra1, ra2, lta);
+  q_elim_apply<K, NB, NB1, 0>(q, awb, sb, rb1, (R*)nullptr, ltb);
+  if constexpr (K + 1 < NB) q_elim2_step<K + 1, NB, N, NA1, NA2, NB1>(q, sa, ra1, ra2, lta, lasta, sb, rb1, ltb, lastb);
+}
+template <int N, int NA1, int NA2, int NB1, typename R>
+I2C_FN void q_elim2(const Quad<R>& q, R* sa, R* ra1, R* ra2, R* lta, bool* oka, R* sb, R* rb1, R* ltb, bool* okb) {
+  R lasta = R(0), lastb = R(0);
+  q_elim2_step<0, (N + 3) / 4, N, NA1, NA2, NB1>(q, sa, ra1, ra2, lta, &lasta, sb, rb1, ltb, &lastb);
+  *oka = lasta > R(0);
+  *okb = lastb > R(0);
 }
 
 // ---- sigma points ------------------------------------------------------------------------------------------------------------
@@ -239,6 +281,8 @@ template <int N, int NC1, int NC2, typename R> I2C_FN bool q_elim(const Quad<R>&
 // sums and differences about a reference value yc, in blocks [pair][output]:  am = (y+ - yc) + (y- - yc),  dm = y+ - y-.
 // yc = the centre value for DIN < 8. For DIN = 8 all sixteen lanes carry points; with no weight on the centre (the only rules
 // this family serves) the moments do not depend on the reference value, and yc = the midpoint of pair 0 stands in.
+// No masks: a pair beyond the input dimension IS a centre evaluation (its sum and difference vanish exactly), and the output
+// columns beyond NOUT are written as zeros by every lane.
 //   muc: mean, column form [NBI]; lt: L^T, upper blocks [NBI][NBI]
 template <class M, int DIN, int NOUT, class F, typename R>
 I2C_FN void q_points(const Quad<R>& q, const R sf, const R* muc, const R* lt, const F& f, R* am, R* dm, R* yc) {
@@ -271,28 +315,25 @@ I2C_FN void q_points(const Quad<R>& q, const R sf, const R* muc, const R* lt, co
     for (int k = 0; k < M::NA; ++k) r_sincos(x[M::ang(k)], &sn[k], &cs[k]);
     f(x, sn, cs, y);
 #pragma unroll
-    for (int k = 0; k < NOUT; ++k) Y[p * QuadLds::YLD + k] = y[k];
+    for (int k = 0; k < 4 * NBO; ++k) Y[p * QuadLds::YLD + k] = k < NOUT ? y[k < NOUT ? k : 0] : R(0);
   }
   q.sync();
 #pragma unroll
   for (int j = 0; j < NBO; ++j) {
     const int col = 4 * j + q.c;
-    const bool cv = col < NOUT;
-    const int cc = cv ? col : 0;
     R y0;
     if constexpr (DIN < 8) {
-      y0 = Y[7 * QuadLds::YLD + cc];
+      y0 = Y[7 * QuadLds::YLD + col];
     } else {
-      y0 = R(0.5) * (Y[cc] + Y[8 * QuadLds::YLD + cc]);
+      y0 = R(0.5) * (Y[col] + Y[8 * QuadLds::YLD + col]);
     }
-    yc[j] = cv ? y0 : R(0);
+    yc[j] = y0;
 #pragma unroll
     for (int i = 0; i < NBI; ++i) {
       const int row = 4 * i + q.r;
-      const R yp = Y[row * QuadLds::YLD + cc], ym = Y[(8 + row) * QuadLds::YLD + cc];
-      const bool v = cv && row < DIN;
-      am[i * NBO + j] = v ? (yp - y0) + (ym - y0) : R(0);
-      dm[i * NBO + j] = v ? yp - ym : R(0);
+      const R yp = Y[row * QuadLds::YLD + col], ym = Y[(8 + row) * QuadLds::YLD + col];
+      am[i * NBO + j] = (yp - y0) + (ym - y0);
+      dm[i * NBO + j] = yp - ym;
     }
   }
 }
@@ -302,6 +343,7 @@ template <int DIN, int NOUT, typename R>
 I2C_FN void q_moments(const Quad<R>& q, const R wi, R* am, const R* dm, const R* yc, R* myc, R* sy) {
   constexpr int NBI = (DIN + 3) / 4, NBO = (NOUT + 3) / 4;
   const R hw = R(0.5) * wi;
+  const R rm = (4 * (NBI - 1) + q.r < DIN) ? R(1) : R(0);  // live pairs of the last pair block
 #pragma unroll
   for (int j = 0; j < NBO; ++j) {
     R t = am[j];
@@ -311,9 +353,8 @@ I2C_FN void q_moments(const Quad<R>& q, const R wi, R* am, const R* dm, const R*
     myc[j] = yc[j] + wi * asum;
     // sig_y = wi/2 sum_p (a_p a_p^T + d_p d_p^T) - wi^2 A A^T: with 2 d wi = 1 the last term centres the a_p
     const R amean = (R(2) * wi) * asum;
-    const int col = 4 * j + q.c;
 #pragma unroll
-    for (int i = 0; i < NBI; ++i) am[i * NBO + j] = (col < NOUT && 4 * i + q.r < DIN) ? am[i * NBO + j] - amean : R(0);
+    for (int i = 0; i < NBI; ++i) am[i * NBO + j] = (i < NBI - 1 || DIN % 4 == 0) ? am[i * NBO + j] - amean : am[i * NBO + j] - amean * rm;
   }
 #pragma unroll
   for (int k = 0; k < NBO * NBO; ++k) sy[k] = R(0);
@@ -424,6 +465,14 @@ I2C_FN bool q_kalman_identity(const Quad<R>& q, const R alpha, const P xi_m, con
 // ------------------------------------------------------------------------------------------
 // Forward sweep (i2c.py:876-880 over :350-447)
 // ------------------------------------------------------------------------------------------
+// The cell is re-ordered around its factorisations (same mathematics):
+//   * chol(sig_x3_f) -- needed for the smoother gain J of the cell that produced it -- and chol(P_xx + sig_x3_f) -- the pdf ratio of
+//     the NEXT cell's feedback prior -- factor two matrices that are known at the same moment, so they run as ONE pair of
+//     eliminations at the top of the next cell (q_elim2), J being stored a cell late; a last single elimination after the loop;
+//   * the prior joint is never factored: with Lt3 = chol(sig_x3_f)^T from that pair,  chol(sig_0)^T = [[Lt3, Lt3 Kt^T], [0, chol(S_u|x)^T]],
+//     S_u|x = P_uu - Kt P_xu (as the lane kernels do for d <= 5), and sig_0 itself is the product of that factor with its
+//     transpose -- no F sig_x F^T products, no d x d factorisation;
+//   * feed-forward cells (i2c.py:355-360) are the same arithmetic with Kt = 0.
 // `live`: trajectory slot b holds a real trajectory (the last wave of a batch that is not a multiple of four repeats its last
 // one in the spare slots: every lane of a wave takes part in the matrix instructions; nothing is stored for them)
 template <class M, typename R, typename S, class KC>
@@ -435,18 +484,26 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
   constexpr bool OBS_ID = st_identity<ObsStruct<M>, NZ>() && NZ == D;
   constexpr bool TERM_ID = NZT > 0 && st_identity<TermStruct<M>, NT>() && NT == NX;
   static_assert(OBS_ID || D % 4 != 0, "quad kernels: a general observation needs a spare column in the joint's last block");
+  static_assert(OBS_ID || NU == 1, "quad kernels: a general observation with one action (the factor of S_u|x is a square root)");
+  constexpr int JU = NX / 4, CU = NX % 4;  // the block (row and column) and the in-block offset where the action entries start
+  static_assert(CU + NU <= 4, "quad kernels: the action entries live in one block");
+  constexpr bool SPX = NX % 4 != 0;        // a spare column in the state blocks: the pdf-ratio right-hand side rides in it
+  constexpr int NCR = SPX ? 0 : 1;
   constexpr int O_K = D + sym(D), O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
   const int r = q.r, cc = q.c;
   const unsigned long B = c.B;
   const int T = c.T;
-  const unsigned WS = sizeof(S), bo = (unsigned)b * WS, rb = (unsigned)(B * WS);
+  const unsigned WS = sizeof(S), bo = (unsigned)b * WS, rb = (unsigned)(B * WS), bo8 = (unsigned)(b * sizeof(R));
   const Rule<R>& rule = c.rule_xu;
   int fail = 0;
   auto xrow = [&](const int i) { return 4 * i + r; };  // matrix row / column of this lane in block row i / block column j
   auto xcol = [&](const int j) { return 4 * j + cc; };
+  // lane masks as multipliers (everything they multiply is finite or belongs to a trajectory that has failed anyway)
+  const R m_ucol = (cc >= CU && cc < CU + NU) ? R(1) : R(0);                   // action columns of block column JU
+  const R m_uu = (cc >= CU && cc < CU + NU && r >= CU && r < CU + NU) ? R(1) : R(0);
 
-  // state message carried along the chain: mean in column form, covariance in FULL blocks (nx x nx, zero-padded)
-  R mx[NBX], sx[NBX * NBX];
+  // state message carried along the chain: mean in column form, covariance in UPPER blocks (nx x nx, zero-padded)
+  R mx[NBX], sx[NBX * NBX], sxy[NBX * NBD];
 #pragma unroll
   for (int j = 0; j < NBX; ++j) {
     const int col = xcol(j);
@@ -460,13 +517,27 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
       sx[i * NBX + j] = in ? sv : R(0);
     }
   }
+#pragma unroll
+  for (int k = 0; k < NBX * NBD; ++k) sxy[k] = R(0);
+  bool j_pending = false;  // (wave-uniform) the smoother gain of the previous cell still has to be formed and stored
 
   // The prior rows of a cell do not depend on the recursion: they are fetched ONE CELL AHEAD (see forward_wave_body)
-  R nx_pmu[NBD], nx_pj[NBD * NBD], nx_kt[NBX * NBD], nx_alpha, nx_zt[NBZ];
+  R nx_pmu[NBD], nx_pj[NBD * NBD], nx_kt[NBX], nx_alpha, nx_zt[NBZ];
   int nx_ff;
   const Window ffw = make_window(a.ff, (unsigned long)T);
   const Window alw = make_window(a.alpha_cell ? a.alpha_cell : a.alpha, (a.alpha_cell ? (unsigned long)T : 1ul) * B * sizeof(R));
-  const Window zw = make_window(c.z_per_cell ? a.z : a.x0, (c.z_per_cell ? (unsigned long)T * NZ : 1ul) * B * sizeof(R));  // (x0 row 0: a valid dummy)
+  // per-cell targets, or a discarded dummy (rows of sig_x0: distinct addresses, so that the loads stay independent instructions):
+  // branch-free buffer loads -- a load behind a run-time branch, or one the compiler can merge with another and then COPY, puts an
+  // s_waitcnt vmcnt(0) right behind the prefetch (measured here: 2 us of every 5 us cell)
+  static_assert(NBZ <= sym(NX), "dummy rows of the target prefetch");
+  const Window zw = make_window(c.z_per_cell ? a.z : a.sig_x0, (c.z_per_cell ? (unsigned long)T * NZ : (unsigned long)sym(NX)) * B * sizeof(R));
+  unsigned zlane[NBZ];
+#pragma unroll
+  for (int j = 0; j < NBZ; ++j) {
+    const int col = xcol(j);
+    zlane[j] = (unsigned)((((unsigned long)(c.z_per_cell ? (col < NZ ? col : 0) : j)) * B + b) * sizeof(R));
+  }
+  const unsigned zcell = c.z_per_cell ? (unsigned)((unsigned long)NZ * B * sizeof(R)) : 0u, acell = a.alpha_cell ? (unsigned)(B * sizeof(R)) : 0u;
   auto fetch_prior = [&](const int tc) {
     const int trc = c.row(tc);
     const WIO<R, S> pri = wio<R, S>(a.prior + (unsigned long)trc * C::E_POST * B, (unsigned long)C::E_POST, rb, bo);
@@ -475,24 +546,21 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
       const int col = xcol(j);
       nx_pmu[j] = pri.ld(col < D ? col : 0);
 #pragma unroll
-      for (int i = 0; i < NBD; ++i) {
+      for (int i = 0; i <= j; ++i) {  // upper blocks
         const int row = xrow(i);
         const bool in = row < D && col < D;
         nx_pj[i * NBD + j] = pri.ld(D + w_symidx(in ? row : 0, in ? col : 0));
       }
-#pragma unroll
-      for (int i = 0; i < NBX; ++i) {  // F^T = [I | K^T]: row = state index, column = joint index; the action columns hold K^T
-        const int row = xrow(i);
-        const bool in = row < NX && col >= NX && col < D;
-        nx_kt[i * NBD + j] = (4 * j + 3 >= NX) ? pri.ld(O_K + (in ? col - NX : 0) * NX + (in ? row : 0)) : R(0);
-      }
     }
-    nx_alpha = wld<R>(alw, 0u, a.alpha_cell ? (unsigned)(((unsigned long)trc * B + b) * sizeof(R)) : (unsigned)(b * sizeof(R)));
 #pragma unroll
-    for (int j = 0; j < NBZ; ++j) {
-      const int col = xcol(j);
-      nx_zt[j] = wld<R>(zw, 0u, c.z_per_cell ? (unsigned)((((unsigned long)trc * NZ + (col < NZ ? col : 0)) * B + b) * sizeof(R)) : (unsigned)(b * sizeof(R)));
+    for (int i = 0; i < NBX; ++i) {  // K^T in block column JU: row = state index, column = action
+      const int row = xrow(i);
+      const bool in = row < NX && cc >= CU && cc < CU + NU;
+      nx_kt[i] = pri.ld(O_K + (in ? cc - CU : 0) * NX + (in ? row : 0));
     }
+    nx_alpha = wld<R>(alw, (unsigned)trc * acell, bo8);
+#pragma unroll
+    for (int j = 0; j < NBZ; ++j) nx_zt[j] = wld<R>(zw, (unsigned)trc * zcell, zlane[j]);
     nx_ff = (int)wld_u8(ffw, (unsigned)trc);
   };
   fetch_prior(0);
@@ -502,15 +570,46 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
 #pragma unroll
   for (int k = 0; k < NBD; ++k) nx_pmu[k] = opaque(nx_pmu[k]);
 #pragma unroll
-  for (int k = 0; k < NBD * NBD; ++k) nx_pj[k] = opaque(nx_pj[k]);
+  for (int i = 0; i < NBD; ++i)
 #pragma unroll
-  for (int k = 0; k < NBX * NBD; ++k) nx_kt[k] = opaque(nx_kt[k]);
+    for (int j = i; j < NBD; ++j) nx_pj[i * NBD + j] = opaque(nx_pj[i * NBD + j]);
+#pragma unroll
+  for (int k = 0; k < NBX; ++k) nx_kt[k] = opaque(nx_kt[k]);
 #pragma unroll
   for (int k = 0; k < NBZ; ++k) nx_zt[k] = opaque(nx_zt[k]);
 #pragma unroll
   for (int k = 0; k < NBX; ++k) mx[k] = opaque(mx[k]);
 #pragma unroll
-  for (int k = 0; k < NBX * NBX; ++k) sx[k] = opaque(sx[k]);
+  for (int i = 0; i < NBX; ++i)
+#pragma unroll
+    for (int j = i; j < NBX; ++j) sx[i * NBX + j] = opaque(sx[i * NBX + j]);
+
+  // smoother gain J = sig_xy sig_x3^-1 (i2c.py:423-425) of cell tj from  w3 = W = chol(sig_x3)^-1  and  yj = W sig_xy^T:  J^T = W^T yj
+  auto store_gain = [&](const int tj, const R* w3, const R* yj) {
+    const WIO<R, S> oj = wio<R, S>(a.fwd + (unsigned long)tj * C::E_FWD * B, (unsigned long)C::E_FWD, rb, bo);
+    R jt[NBX * NBD];
+#pragma unroll
+    for (int k = 0; k < NBX * NBD; ++k) jt[k] = R(0);
+#pragma unroll
+    for (int i = 0; i < NBX; ++i)
+#pragma unroll
+      for (int j = 0; j < NBD; ++j)
+#pragma unroll
+        for (int k = i; k < NBX; ++k) q_mfma(q, w3[k * NBX + i], yj[k * NBD + j], jt[i * NBD + j]);  // (W is lower triangular: blocks k >= i)
+#pragma unroll
+    for (int i = 0; i < NBX; ++i)
+#pragma unroll
+      for (int j = 0; j < NBD; ++j) {
+        const bool in = xrow(i) < NX && xcol(j) < D;
+        oj.st_if(live && in, O_J + (in ? xcol(j) : 0) * NX + (in ? xrow(i) : 0), jt[i * NBD + j]);
+      }
+  };
+  auto identity_x = [&](R* w3) {
+#pragma unroll
+    for (int i = 0; i < NBX; ++i)
+#pragma unroll
+      for (int j = 0; j < NBX; ++j) w3[i * NBX + j] = (i == j && r == cc && xrow(i) < NX) ? R(1) : R(0);
+  };
 
 #if defined(I2C_QUAD_STAMPS) && !defined(I2C_HOST_SIM)
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
@@ -519,108 +618,138 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
     const WIO<R, S> out = wio<R, S>(a.fwd + (unsigned long)t * C::E_FWD * B, (unsigned long)C::E_FWD, rb, bo);
     const R alpha = nx_alpha;
     const bool ff = w_uniform(nx_ff) != 0;
-    R pmu[NBD], pj[NBD * NBD], kt[NBX * NBD], zt[NBZ];
+    R pmu[NBD], pj[NBD * NBD], kt[NBX], zt[NBZ];
 #pragma unroll
     for (int k = 0; k < NBD; ++k) pmu[k] = nx_pmu[k];
 #pragma unroll
-    for (int k = 0; k < NBD * NBD; ++k) pj[k] = nx_pj[k];
+    for (int i = 0; i < NBD; ++i)
 #pragma unroll
-    for (int k = 0; k < NBX * NBD; ++k) kt[k] = nx_kt[k];
+      for (int j = 0; j < NBD; ++j) pj[i * NBD + j] = j >= i ? nx_pj[i * NBD + j] : R(0);
+#pragma unroll
+    for (int k = 0; k < NBX; ++k) kt[k] = nx_kt[k];
 #pragma unroll
     for (int j = 0; j < NBZ; ++j) zt[j] = xcol(j) < NZ ? (c.z_per_cell ? nx_zt[j] : q_ldv(q, kc.zg, j)) : R(0);
     int cell_bad = 0;
 
-    // ---- 1. joint prior over (x, u): mean column form, covariance UPPER blocks -------------
-    R mu0[NBD], s0[NBD * NBD];
-    if (ff) {  // feed-forward: independent action prior (i2c.py:355-360)
+    // ---- 0. the pair of factorisations of the incoming state covariance -----------------------
+    //   chol(sig_x) with right-hand sides [sig_xy^T of the previous cell | I]  ->  Lt3, and J of the previous cell;
+    //   chol(P_xx + sig_x) with delta = mu_x - P_mu_x  ->  the pdf ratio rho = exp(-delta^T (P_xx + sig_x)^-1 delta / 2) (i2c.py:369-374),
+    //   y = L^-1 delta riding as the spare column nx of the sum when nx is not a multiple of 4, a right-hand side otherwise
+    R l3[NBX * NBX], dr[NBX];
+    R rho;
+    {
+      R w3[NBX * NBX], yj[NBX * NBD], sa[NBX * NBX], sm[NBX * NBX], lts[NBX * NBX], rhs[NBX];
+      identity_x(w3);
 #pragma unroll
-      for (int j = 0; j < NBD; ++j) {
-        const int col = xcol(j);
-        mu0[j] = col < NX ? (j < NBX ? mx[j < NBX ? j : 0] : R(0)) : (col < D ? pmu[j] : R(0));
+      for (int k = 0; k < NBX * NBD; ++k) yj[k] = sxy[k];
 #pragma unroll
-        for (int i = 0; i < NBD; ++i) {
-          const int row = xrow(i);
-          const bool xx = row < NX && col < NX, uu = row >= NX && row < D && col >= NX && col < D;
-          const R sxv = (i < NBX && j < NBX) ? sx[(i < NBX ? i : 0) * NBX + (j < NBX ? j : 0)] : R(0);
-          s0[i * NBD + j] = xx ? sxv : (uu ? pj[i * NBD + j] : R(0));
-        }
+      for (int i = 0; i < NBX; ++i) {
+        const R dl = xcol(i) < NX ? mx[i] - pmu[i] : R(0);
+        dr[i] = q_tr(q, dl);  // row form
       }
-    } else {  // feedback: condition the previous controller on the new state message (i2c.py:361-387)
-      // pdf ratio rho = exp(-delta^T (P_xx + sig_x)^-1 delta / 2): y = L^-1 delta is a right-hand side of the factorisation of the
-      // nx x nx sum -- riding as its spare column nx when nx is not a multiple of 4
-      R dl[NBX], dr[NBX];
 #pragma unroll
-      for (int j = 0; j < NBX; ++j) {
-        dl[j] = xcol(j) < NX ? mx[j] - pmu[j] : R(0);
-        dr[j] = q_tr(q, dl[j]);  // row form
+      for (int i = 0; i < NBX; ++i) {
+#pragma unroll
+        for (int j = i; j < NBX; ++j) {
+          const bool xx = xrow(i) < NX && xcol(j) < NX;
+          sa[i * NBX + j] = sx[i * NBX + j];
+          sm[i * NBX + j] = xx ? pj[i * NBD + j] + sx[i * NBX + j] : R(0);
+        }
+        const R dq = (cc == (SPX ? CU : 0) && xrow(i) < NX) ? dr[i] : R(0);
+        if constexpr (SPX) sm[i * NBX + NBX - 1] += dq;  // (that column of the sum is zero)
+        rhs[i] = dq;
       }
-      R rho;
-      {
-        constexpr bool SPARE = NX % 4 != 0;
-        constexpr int NCR = SPARE ? 0 : 1, QC = SPARE ? NX % 4 : 0;
-        R sm[NBX * NBX], lt[NBX * NBX], rhs[NBX];
+      bool ok3, oks;
+      q_elim2<NX, NBD, NBX, NCR>(q, sa, yj, w3, l3, &ok3, sm, rhs, lts, &oks);
+      if (j_pending) store_gain(t - 1, w3, yj);
+      // a prediction covariance that is not positive definite is the PREVIOUS cell's failure (its stage 4); the state message of
+      // cell 0 is the caller's: reported as the prior joint's
+      if (t > 0) fail = fold_cell_failure(fail, flag_stage(0, ok3, 4), t - 1);
+      else cell_bad = flag_stage(cell_bad, ok3, 1);
+      cell_bad = flag_stage(cell_bad, oks || ff, 0);
+      R ysq = R(0);
 #pragma unroll
-        for (int i = 0; i < NBX; ++i) {
-#pragma unroll
-          for (int j = 0; j < NBX; ++j) {
-            const bool xx = xrow(i) < NX && xcol(j) < NX;
-            sm[i * NBX + j] = xx ? pj[i * NBD + j] + sx[i * NBX + j] : R(0);
-          }
-          if constexpr (SPARE) sm[i * NBX + NBX - 1] = (cc == QC && xrow(i) < NX) ? dr[i] : sm[i * NBX + NBX - 1];
-          rhs[i] = (cc == QC && xrow(i) < NX) ? dr[i] : R(0);
-        }
-        cell_bad = flag_stage(cell_bad, q_elim<NX, NCR, 0>(q, sm, rhs, (R*)nullptr, lt), 0);
-        R ysq = R(0);
-#pragma unroll
-        for (int i = 0; i < NBX; ++i) {
-          const R yv = SPARE ? lt[i * NBX + NBX - 1] : rhs[i];
-          ysq += (cc == QC && xrow(i) < NX) ? yv * yv : R(0);
-        }
-        const R maha = q_bcq<QC>(q, q_colsum(q, ysq));
-        rho = r_exp(R(-0.5) * maha);
+      for (int i = 0; i < NBX; ++i) {
+        const R yv = SPX ? lts[i * NBX + NBX - 1] : rhs[i];
+        ysq += (cc == (SPX ? CU : 0) && xrow(i) < NX) ? yv * yv : R(0);
       }
-      // F^T = [I | Kt^T] (nx x d), Kt = rho K:  sig_0 = F sig_x F^T with (P_uu - Kt P_xu) added to the action block
-      R ft[NBX * NBD], m1[NBX * NBD], m1p[NBX * NBD];
+      const R maha = q_bcq<(SPX ? CU : 0)>(q, q_colsum(q, ysq));
+      rho = ff ? R(0) : r_exp(R(-0.5) * maha);  // feed-forward: independent action prior (i2c.py:355-360) = the feedback form with Kt = 0
+    }
+    // ---- 1. joint prior over (x, u) (i2c.py:361-387): mean column form, covariance UPPER blocks, factor from Lt3 ----
+    R mu0[NBD], s0[NBD * NBD], lt0[NBD * NBD];
+    {
+      // Kt^T = rho K^T in block column JU (rows = state index); G = Lt3 Kt^T
+      R ktm[NBX], g[NBX], l3t[NBX * NBX];
 #pragma unroll
-      for (int i = 0; i < NBX; ++i)
-#pragma unroll
-        for (int j = 0; j < NBD; ++j) {
-          const int row = xrow(i), col = xcol(j);
-          ft[i * NBD + j] = col < NX ? (row == col ? R(1) : R(0)) : ((col < D && row < NX) ? rho * kt[i * NBD + j] : R(0));
-          m1[i * NBD + j] = R(0);
-        }
-      q_tn<NBX, NBX, NBD>(q, sx, ft, m1);  // sig_x F^T (sig_x symmetric)
-#pragma unroll
-      for (int j = 0; j < NBD; ++j) {  // action columns: Kt delta
-        R t = R(0);
-#pragma unroll
-        for (int i = 0; i < NBX; ++i) t += ft[i * NBD + j] * dr[i];
-        const R kd = q_colsum(q, t);
-        const int col = xcol(j);
-        mu0[j] = col < NX ? (j < NBX ? mx[j < NBX ? j : 0] : R(0)) : (col < D ? pmu[j] + kd : R(0));
+      for (int i = 0; i < NBX; ++i) {
+        ktm[i] = (xrow(i) < NX ? m_ucol : R(0)) * (rho * kt[i]);
+        g[i] = R(0);
       }
 #pragma unroll
       for (int i = 0; i < NBX; ++i)
 #pragma unroll
-        for (int j = 0; j < NBD; ++j) {
-          const bool xu = xrow(i) < NX && xcol(j) >= NX && xcol(j) < D;
-          m1p[i * NBD + j] = xu ? m1[i * NBD + j] - pj[i * NBD + j] : m1[i * NBD + j];
+        for (int k = i; k < NBX; ++k) {
+          l3t[i * NBX + k] = q_tr(q, l3[i * NBX + k]);
+          q_mfma(q, l3t[i * NBX + k], ktm[k], g[i]);  // (A operand = the transpose of what is passed: Lt3[i][k] itself)
         }
+      // Lt0x = [Lt3 | G]: the state rows of chol(sig_0)^T
+      R lx[NBX * NBD];
+#pragma unroll
+      for (int i = 0; i < NBX; ++i)
+#pragma unroll
+        for (int j = 0; j < NBD; ++j) {
+          const R l3v = (j < NBX && j >= i) ? l3[i * NBX + (j < NBX ? j : 0)] : R(0);
+          lx[i * NBD + j] = j == JU ? l3v + g[i] : l3v;
+        }
+      // S_u|x = P_uu - Kt P_xu in the action entries of block (JU, JU)
+      R suu = m_uu * pj[JU * NBD + JU];
+#pragma unroll
+      for (int k = 0; k < NBX; ++k) {
+        const R pxu = (xrow(k) < NX ? m_ucol : R(0)) * pj[k * NBD + JU];
+        q_mfma(q, -ktm[k], pxu, suu);
+      }
+      // sig_0 = Lt0x^T Lt0x + S_u|x
 #pragma unroll
       for (int k = 0; k < NBD * NBD; ++k) s0[k] = R(0);
-      q_tn<NBX, NBD, NBD, false, true>(q, ft, m1p, s0);
 #pragma unroll
       for (int i = 0; i < NBD; ++i)
 #pragma unroll
-        for (int j = i; j < NBD; ++j) {
-          const int row = xrow(i), col = xcol(j);
-          const bool xrw = row < NX, urw = row >= NX && row < D, ucl = col >= NX && col < D;
-          const R m1v = i < NBX ? m1[(i < NBX ? i : 0) * NBD + j] : R(0);
-          // state rows, action columns: sig_x Kt^T itself; action block: P_uu - Kt P_xu + Kt sig_x Kt^T
-          s0[i * NBD + j] = (xrw && ucl) ? m1v : ((urw && ucl) ? s0[i * NBD + j] + pj[i * NBD + j] : s0[i * NBD + j]);
+        for (int j = i; j < NBD; ++j)
+#pragma unroll
+          for (int k = 0; k < NBX; ++k) {
+            if (k > i && i != JU) continue;  // Lt0x[k][i] = 0 below the diagonal, except in the action columns
+            q_mfma(q, lx[k * NBD + i], lx[k * NBD + j], s0[i * NBD + j]);
+          }
+      s0[JU * NBD + JU] += suu;
+      // mean: the state message, and the action prior moved by Kt delta
+#pragma unroll
+      for (int j = 0; j < NBD; ++j) {
+        R kd = R(0);
+        if (j == JU) {
+          R tt = R(0);
+#pragma unroll
+          for (int i = 0; i < NBX; ++i) tt += ktm[i] * dr[i];
+          kd = q_colsum(q, tt);
         }
+        const int col = xcol(j);
+        mu0[j] = col < NX ? (j < NBX ? mx[j < NBX ? j : 0] : R(0)) : (col < D ? pmu[j] + kd : R(0));
+      }
+      if constexpr (!OBS_ID) {
+        // chol(sig_0)^T = [[Lt3, G], [0, sqrt(S_u|x)]] (one action): the variance to every lane of the trajectory
+        const R v = q_bcq<CU>(q, q_colsum(q, suu));
+        cell_bad = flag_stage(cell_bad, v > R(0), 1);
+        const R lu = v * r_rsqrt(v);
+#pragma unroll
+        for (int i = 0; i < NBD; ++i)
+#pragma unroll
+          for (int j = i; j < NBD; ++j) {
+            const R lv = i < NBX ? lx[(i < NBX ? i : 0) * NBD + j] : R(0);
+            lt0[i * NBD + j] = (i == JU && j == JU) ? lv + m_uu * lu : lv;
+          }
+      }
     }
-    I2C_QSTAMP(0);  // joint prior
+    I2C_QSTAMP(0);  // factorisation pair + joint prior
     fetch_prior(t + 1 < T ? t + 1 : t);  // this cell's rows are consumed: the next cell's, a cell ahead
     if (a.prior_out) {
       const WIO<R, S> po = wio<R, S>(a.prior_out + (unsigned long)t * (D + sym(D)) * B, (unsigned long)(D + sym(D)), rb, bo);
@@ -643,16 +772,9 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
 #pragma unroll
       for (int k = 0; k < NBD * NBD; ++k) s0[k] = sf_[k];
     } else {
-      R lt[NBD * NBD];
-      {
-        R tmp[NBD * NBD];
-#pragma unroll
-        for (int k = 0; k < NBD * NBD; ++k) tmp[k] = s0[k];
-        cell_bad = flag_stage(cell_bad, q_elim<D, 0, 0>(q, tmp, (R*)nullptr, (R*)nullptr, lt), 1);
-      }
-      I2C_QSTAMP(1);  // chol(prior joint)
+      I2C_QSTAMP(1);
       R am[NBD * NBZ], dm[NBD * NBZ], yc[NBZ], mz[NBZ], sz[NBZ * NBZ], szx[NBZ * NBD];
-      q_points<M, D, NZ>(q, rule.sf, mu0, lt, ObserveF<M, R>{c.params}, am, dm, yc);
+      q_points<M, D, NZ>(q, rule.sf, mu0, lt0, ObserveF<M, R>{c.params}, am, dm, yc);
       I2C_QSTAMP(2);  // observation points
       q_moments<D, NZ>(q, rule.wi, am, dm, yc, mz, sz);
 #pragma unroll
@@ -662,7 +784,7 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
       // cov(z, xu) = wi sf [d_p]^T L^T
 #pragma unroll
       for (int k = 0; k < NBZ * NBD; ++k) szx[k] = R(0);
-      q_tn<NBD, NBZ, NBD, false, false, true>(q, dm, lt, szx);
+      q_tn<NBD, NBZ, NBD, false, false, true>(q, dm, lt0, szx);
       const R cw = rule.wi * rule.sf;
 #pragma unroll
       for (int k = 0; k < NBZ * NBD; ++k) szx[k] *= cw;
@@ -678,7 +800,6 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
     }
 
     // ---- 3. dynamics push-through (i2c.py:415-421) ----------------------------------------
-    R sxy[NBX * NBD];  // sig_xy^T (nx x d)
     {
       R lt[NBD * NBD];
       {
@@ -703,44 +824,36 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
 #pragma unroll
       for (int k = 0; k < NBX * NBD; ++k) sxy[k] *= cw;
     }
-    // ---- smoother gain J = sig_xy sig_x3^-1 (i2c.py:423-425): J^T = W^T (W sig_xy^T), W = chol(sig_x3)^-1 ----
-    R l3[NBX * NBX];
-    {
-      R tmp[NBX * NBX], w3[NBX * NBX], jt[NBX * NBD];
-#pragma unroll
-      for (int i = 0; i < NBX; ++i)
-#pragma unroll
-        for (int j = 0; j < NBX; ++j) {
-          tmp[i * NBX + j] = sx[i * NBX + j];
-          w3[i * NBX + j] = (i == j && r == cc && xrow(i) < NX) ? R(1) : R(0);
-        }
-      cell_bad = flag_stage(cell_bad, q_elim<NX, NBD, NBX>(q, tmp, sxy, w3, l3), 4);
-#pragma unroll
-      for (int k = 0; k < NBX * NBD; ++k) jt[k] = R(0);
-      q_tn<NBX, NBX, NBD>(q, w3, sxy, jt);
-#pragma unroll
-      for (int i = 0; i < NBX; ++i)
-#pragma unroll
-        for (int j = 0; j < NBD; ++j) {
-          const bool in = xrow(i) < NX && xcol(j) < D;
-          out.st_if(live && in, O_J + (in ? xcol(j) : 0) * NX + (in ? xrow(i) : 0), jt[i * NBD + j]);
-        }
-    }
-    // the lower blocks of sig_x3 (the next cell multiplies with the full matrix)
-#pragma unroll
-    for (int i = 0; i < NBX; ++i)
-#pragma unroll
-      for (int j = 0; j < i; ++j) sx[i * NBX + j] = q_tr(q, sx[j * NBX + i]);
+    j_pending = true;  // J = sig_xy sig_x3^-1 (i2c.py:423-425): at the top of the next cell, next to the factorisation it shares
     // ---- 4. terminal cost observation on the flagged cell, after J (i2c.py:430-443) ----
     if (NZT > 0 && t == c.terminal_cell && c.has_Qf) {  // (uniform: kernel arguments)
+      // J uses sig_x3_f BEFORE this update, the next cell the one after it: this cell's gain is formed here
+      R tmp[NBX * NBX], w3[NBX * NBX], yj[NBX * NBD], l3t[NBX * NBX];
+      identity_x(w3);
+#pragma unroll
+      for (int k = 0; k < NBX * NBX; ++k) tmp[k] = sx[k];
+#pragma unroll
+      for (int k = 0; k < NBX * NBD; ++k) yj[k] = sxy[k];
+      cell_bad = flag_stage(cell_bad, q_elim<NX, NBD, NBX>(q, tmp, yj, w3, l3t), 4);
+      store_gain(t, w3, yj);
+      j_pending = false;
       R ztT[NBT];
 #pragma unroll
       for (int j = 0; j < NBT; ++j) ztT[j] = q_ldv(q, kc.zgT, j);
       if constexpr (TERM_ID) {
-        cell_bad = flag_stage(cell_bad, q_kalman_identity<NX>(q, alpha, kc.xiT, kc.qf, c.qf_diag != 0, ztT, mx, sx), 5);
+        R sf_[NBX * NBX];
+#pragma unroll
+        for (int i = 0; i < NBX; ++i)
+#pragma unroll
+          for (int j = 0; j < NBX; ++j) sf_[i * NBX + j] = j >= i ? sx[i * NBX + j] : q_tr(q, sx[j * NBX + i]);
+        cell_bad = flag_stage(cell_bad, q_kalman_identity<NX>(q, alpha, kc.xiT, kc.qf, c.qf_diag != 0, ztT, mx, sf_), 5);
+#pragma unroll
+        for (int i = 0; i < NBX; ++i)
+#pragma unroll
+          for (int j = 0; j < NBX; ++j) sx[i * NBX + j] = j >= i ? sf_[i * NBX + j] : R(0);
       } else if constexpr (NZT > 0) {
         R am[NBX * NBT], dm[NBX * NBT], yc[NBT], mz[NBT], sz[NBT * NBT], szx[NBT * NBX];
-        q_points<M, NX, NT>(q, c.rule_x.sf, mx, l3, ObserveTermF<M, R>{c.params}, am, dm, yc);
+        q_points<M, NX, NT>(q, c.rule_x.sf, mx, l3t, ObserveTermF<M, R>{c.params}, am, dm, yc);
         q_moments<NX, NT>(q, c.rule_x.wi, am, dm, yc, mz, sz);
 #pragma unroll
         for (int i = 0; i < NBT; ++i)
@@ -748,15 +861,11 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
           for (int j = i; j < NBT; ++j) sz[i * NBT + j] += alpha * q_ldc(q, kc.xiT, i, j);
 #pragma unroll
         for (int k = 0; k < NBT * NBX; ++k) szx[k] = R(0);
-        q_tn<NBX, NBT, NBX, false, false, true>(q, dm, l3, szx);
+        q_tn<NBX, NBT, NBX, false, false, true>(q, dm, l3t, szx);
         const R cw = c.rule_x.wi * c.rule_x.sf;
 #pragma unroll
         for (int k = 0; k < NBT * NBX; ++k) szx[k] *= cw;
         cell_bad = flag_stage(cell_bad, q_kalman<NX, NT>(q, mx, sx, mz, sz, szx, ztT), 5);
-#pragma unroll
-        for (int i = 0; i < NBX; ++i)
-#pragma unroll
-          for (int j = 0; j < i; ++j) sx[i * NBX + j] = q_tr(q, sx[j * NBX + i]);
       }
     }
     fail = fold_cell_failure(fail, cell_bad, t);
@@ -766,11 +875,21 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
 #pragma unroll
       for (int i = 0; i <= j; ++i) out.st_if(live && xrow(i) <= xcol(j) && xcol(j) < NX, O_S3 + w_symidx(xrow(i), xcol(j) < NX ? xcol(j) : 0), sx[i * NBX + j]);
     }
-    I2C_QSTAMP(7);  // dynamics moments, smoother gain, terminal update, stores
+    I2C_QSTAMP(7);  // dynamics moments, terminal update, stores
+  }
+  if (j_pending) {  // the last cell's gain
+    R tmp[NBX * NBX], w3[NBX * NBX], yj[NBX * NBD], l3t[NBX * NBX];
+    identity_x(w3);
+#pragma unroll
+    for (int k = 0; k < NBX * NBX; ++k) tmp[k] = sx[k];
+#pragma unroll
+    for (int k = 0; k < NBX * NBD; ++k) yj[k] = sxy[k];
+    fail = fold_cell_failure(fail, flag_stage(0, q_elim<NX, NBD, NBX>(q, tmp, yj, w3, l3t), 4), T - 1);
+    store_gain(T - 1, w3, yj);
   }
 #if defined(I2C_QUAD_STAMPS) && !defined(I2C_HOST_SIM)
   if (b == 0 && q.l == 0)
-    printf("quad forward, clocks per cell: prior %llu | chol0 %llu | obs points %llu | obs moments %llu | kalman %llu | stores+chol1 %llu | dyn points %llu | moments+gain+stores %llu\n",
+    printf("quad forward, clocks per cell: pair + prior %llu | - %llu | obs points %llu | obs moments %llu | kalman %llu | stores+chol1 %llu | dyn points %llu | moments+stores %llu\n",
            stamp_acc[0] / T, stamp_acc[1] / T, stamp_acc[2] / T, stamp_acc[3] / T, stamp_acc[4] / T, stamp_acc[5] / T, stamp_acc[6] / T, stamp_acc[7] / T);
 #endif
   if (live && q.p() == 0 && fail != 0 && a.status[b] == 0) a.status[b] = fail;

@@ -362,7 +362,7 @@ def test_mpc_ring_every_inference_gpu(inference):
     _ring_equals_unrolled(inference, None, "cuda")
 
 
-RING_WIDE = [("cubature", "em_dcp_T60", "group"), ("cubature", "em_quad12_T20", "wave"), ("linearize", "lin_quad12_T20", "wave"),
+RING_WIDE = [("cubature", "em_dcp_T60", "quad"), ("cubature", "em_quad12_T20", "wave"), ("linearize", "lin_quad12_T20", "wave"),
              ("linearize", "lin_dcp_T80", "lane")]
 
 

@@ -238,9 +238,15 @@ def test_kernel_family_is_inspectable():
 
     assert eng("PendulumKnown", 4).forward_family == "lane"
     assert eng("PendulumKnown", 4, group_lanes=True).forward_family == "group"
-    dcp = eng("DoubleCartpoleKnown", 4096)                   # hybrid default: group forward while B * G <= 65536 ...
-    assert (dcp.forward_family, dcp.backward_family) == ("group", "lane")
-    assert eng("DoubleCartpoleKnown", 4097).forward_family == "lane"   # ... and the lane kernels beyond
+    dcp = eng("DoubleCartpoleKnown", 4096)                   # default of the d >= 7 models: the quad forward kernel up to 8192 trajectories ...
+    assert (dcp.forward_family, dcp.backward_family) == ("quad", "lane")
+    assert eng("DoubleCartpoleKnown", 8192).forward_family == "quad"
+    assert eng("DoubleCartpoleKnown", 8193).forward_family == "lane"   # ... and the lane kernels beyond
+    assert eng("CartpoleKnown", 4096).forward_family == "quad" and eng("CartpoleKnown", 4097).forward_family == "lane"
+    # what the quad form does not cover (a weight on the centre point) falls back to the round-2 hybrid: group forward while B * G <= 65536
+    assert eng("DoubleCartpoleKnown", 4096, quad=(1.2, 0.44, 0.5)).forward_family == "group"
+    assert eng("DoubleCartpoleKnown", 4097, quad=(1.2, 0.44, 0.5)).forward_family == "lane"
+    assert eng("DoubleCartpoleKnown", 64, group_lanes=True).forward_family == "group"
     assert eng("DoubleCartpoleKnown", 64, group_lanes=-1).forward_family == "lane"
     q = eng("Quadrotor12", 3)
     assert q.forward_family in ("group", "wave") and q.kernel_family("filter") in ("group", "wave")
