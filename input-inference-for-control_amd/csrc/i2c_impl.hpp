@@ -343,8 +343,8 @@ static int launch_wave_v(const Consts<M, R>& c, const A& a, void* stream) {
 #ifdef I2C_HOST_SIM
 template <class M, typename R, typename S, class A>
 static int launch_quad_forward(const Consts<M, R>& c, const A& a, void*) {
-  WConst<M, R> kc;
-  wconst_fill<M, R>(kc, &c, 0, 1);
+  QConst<M, R> kc;
+  qconst_fill<M, R>(kc, &c, 0, 1);
   for (int b0 = 0; b0 < c.B; b0 += 4) {
     std::vector<R> sh((size_t)4 * QuadLds::SIZE, R(0)), xch(128, R(0));
     HostBarrier bar(64);
@@ -362,9 +362,9 @@ static int launch_quad_forward(const Consts<M, R>& c, const A& a, void*) {
 #else
 template <class M, typename R, typename S, class A>
 __global__ __launch_bounds__(64, 2) void k_quad_forward(const Consts<M, R> c, const A a) {
-  __shared__ WConst<M, R> kc;
+  __shared__ QConst<M, R> kc;
   __shared__ R sh[4 * QuadLds::SIZE];
-  wconst_fill<M, R>(kc, (const Consts<M, R>*)__builtin_amdgcn_kernarg_segment_ptr(), (int)threadIdx.x, 64);
+  qconst_fill<M, R>(kc, (const Consts<M, R>*)__builtin_amdgcn_kernarg_segment_ptr(), (int)threadIdx.x, 64);
   __syncthreads();
   // A wave reads four consecutive trajectories (32 bytes) of every [B]-contiguous row: the four waves that share a 128-byte line
   // of each row are mapped onto workgroups of the SAME XCD (workgroups are dealt round-robin over the 8 XCDs, so blocks i and

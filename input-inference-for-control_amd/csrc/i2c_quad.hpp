@@ -33,12 +33,13 @@ namespace i2c {
 struct QuadLds {
   static constexpr int LDL = 10;               // row stride of the sigma-point directions: 8 rows (pairs) of <= 8 inputs
   static constexpr int O_L = 0;
-  static constexpr int YLD = 12;               // row stride of the evaluation outputs: 16 rows (points) of <= 12 outputs
+  static constexpr int YLD = 13;               // row stride of the evaluation outputs: 16 rows (points) of <= 12 outputs (odd: the
+                                               // sixteen lanes of a trajectory write their rows to sixteen different bank pairs)
   static constexpr int O_Y = O_L + 8 * LDL;
   static constexpr int O_MV = O_Y + 16 * YLD;  // the mean the points are built around (8)
   static constexpr int O_DG = O_MV + 8;        // 4 x 4 pivot block
   static constexpr int O_DG2 = O_DG + 16;      // ... of the second elimination of a pair (q_elim2)
-  static constexpr int SIZE = O_DG2 + 16 + 2;  // (= 26 mod 32 elements: the four regions of a wave start on different banks)
+  static constexpr int SIZE = O_DG2 + 16;      // (= 8 mod 32 elements: the four regions of a wave start 16 banks apart)
 };
 
 // Diagnostic build only (-DI2C_QUAD_STAMPS, never in the shipped library): s_memtime stamps at the phase boundaries of the forward
@@ -141,8 +142,29 @@ template <typename R> I2C_FN R q_rowsum(const Quad<R>& q, const R x) {
 #endif
 }
 
-// Batch-wide constants by (row, column), in LDS, one copy per workgroup: WConst of i2c_wave.hpp (16 x 16 row-major, zero-padded)
-template <typename R, class P> I2C_FN R q_ldc(const Quad<R>& q, const P m, const int I, const int J) { return m[(4 * I + q.r) * 16 + 4 * J + q.c]; }
+// Batch-wide constants by (row, column), in LDS, one copy per workgroup: 12 x 12 row-major, zero-padded (6 KB: with the 10 KB of
+// its four trajectory regions a workgroup stays under the 20 KB that let eight of them -- two waves per SIMD -- share a CU)
+constexpr int QLD = 12;
+template <class M, typename R> struct QConst {
+  R xi[QLD * QLD], eta[QLD * QLD], xiT[QLD * QLD], qr[QLD * QLD], qf[QLD * QLD];  // sig_xi0, sig_eta, sig_xiT0, blkdiag(Q, R), Qf
+  R zg[QLD], zgT[QLD];
+};
+template <class M, typename R, class DST> I2C_FN void qconst_fill(DST& k, const Consts<M, R>* c, const int tid, const int nthreads) {
+  constexpr int NX = M::NX, NZ = M::NZ, NT = M::NZT > 0 ? M::NZT : 1;
+  for (int e = tid; e < QLD * QLD; e += nthreads) {
+    const int i = e / QLD, j = e % QLD;
+    k.xi[e] = (i < NZ && j < NZ) ? c->sig_xi0[tri_any(i, j)] : R(0);
+    k.eta[e] = (i < NX && j < NX) ? c->sig_eta[tri_any(i, j)] : R(0);
+    k.xiT[e] = (i < NT && j < NT) ? c->sig_xiT0[tri_any(i, j)] : R(0);
+    k.qr[e] = (i < NZ && j < NZ) ? c->QR[tri_any(i, j)] : R(0);
+    k.qf[e] = (i < NT && j < NT) ? c->Qf[tri_any(i, j)] : R(0);
+  }
+  for (int e = tid; e < QLD; e += nthreads) {
+    k.zg[e] = e < NZ ? c->zg[e] : R(0);
+    k.zgT[e] = e < NT ? c->zg_term[e] : R(0);
+  }
+}
+template <typename R, class P> I2C_FN R q_ldc(const Quad<R>& q, const P m, const int I, const int J) { return m[(4 * I + q.r) * QLD + 4 * J + q.c]; }
 template <typename R, class P> I2C_FN R q_ldv(const Quad<R>& q, const P v, const int J) { return v[4 * J + q.c]; }  // column form
 
 // ---- blocked Cholesky elimination --------------------------------------------------------------------------------------------
@@ -199,9 +221,9 @@ template <int NL, typename R, class P> I2C_FN void q_pivot_algebra(const Quad<R>
     *aw_out = (m0 * y0 + m1 * y1) + (m2 * y2 + m3 * y3);
   }
 }
-// scale block row K by the inverse pivot factor (aw) and eliminate it from everything below
-template <int K, int NB, int NC1, int NC2, typename R> I2C_FN void q_elim_apply(const Quad<R>& q, const R aw, R* s, R* r1, R* r2, R* lt) {
-  // rows of L^T (the diagonal block masked to its upper triangle: what is left of it is rounding noise) ...
+// scale block row K by the inverse pivot factor (aw): rows of L^T (the diagonal block masked to its upper triangle: what is left
+// of it is rounding noise) and of every right-hand side ...
+template <int K, int NB, int NC1, int NC2, typename R> I2C_FN void q_elim_scale(const Quad<R>& q, const R aw, R* s, R* r1, R* r2, R* lt) {
 #pragma unroll
   for (int j = K; j < NB; ++j) {
     R x = R(0);
@@ -220,7 +242,9 @@ template <int K, int NB, int NC1, int NC2, typename R> I2C_FN void q_elim_apply(
     q_mfma(q, aw, r2[K * NC2 + j], x);
     r2[K * NC2 + j] = x;
   }
-  // ... and the elimination
+}
+// ... and eliminate it from everything below (the next pivot block first: it is what the next step waits for)
+template <int K, int NB, int NC1, int NC2, typename R> I2C_FN void q_elim_below(const Quad<R>& q, R* s, R* r1, R* r2, const R* lt) {
 #pragma unroll
   for (int i = K + 1; i < NB; ++i) {
     const R nl = -lt[K * NB + i];
@@ -231,6 +255,10 @@ template <int K, int NB, int NC1, int NC2, typename R> I2C_FN void q_elim_apply(
 #pragma unroll
     for (int j = 0; j < NC2; ++j) q_mfma(q, nl, r2[K * NC2 + j], r2[i * NC2 + j]);
   }
+}
+template <int K, int NB, int NC1, int NC2, typename R> I2C_FN void q_elim_apply(const Quad<R>& q, const R aw, R* s, R* r1, R* r2, R* lt) {
+  q_elim_scale<K, NB, NC1, NC2>(q, aw, s, r1, r2, lt);
+  q_elim_below<K, NB, NC1, NC2>(q, s, r1, r2, lt);
 }
 template <int K, int NB, int N, int NC1, int NC2, typename R>
 I2C_FN void q_elim_step(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* last) {
@@ -263,8 +291,11 @@ I2C_FN void q_elim2_step(const Quad<R>& q, R* sa, R* ra1, R* ra2, R* lta, R* las
   q_pivot_algebra<NL>(q, dga, &awa, &pla);
   q_pivot_algebra<NL>(q, dgb, &awb, &plb);
   if (K == NB - 1) *lasta = pla, *lastb = plb;
-  q_elim_apply<K, NB, NA1, NA2>(q, awa, sa, ra1, ra2, lta);
-  q_elim_apply<K, NB, NB1, 0>(q, awb, sb, rb1, (R*)nullptr, ltb);
+  // (interleaved: the scaled rows of one elimination are consumed after the other's independent instructions)
+  q_elim_scale<K, NB, NA1, NA2>(q, awa, sa, ra1, ra2, lta);
+  q_elim_scale<K, NB, NB1, 0>(q, awb, sb, rb1, (R*)nullptr, ltb);
+  q_elim_below<K, NB, NA1, NA2>(q, sa, ra1, ra2, lta);
+  q_elim_below<K, NB, NB1, 0>(q, sb, rb1, (R*)nullptr, ltb);
   if constexpr (K + 1 < NB) q_elim2_step<K + 1, NB, N, NA1, NA2, NB1>(q, sa, ra1, ra2, lta, lasta, sb, rb1, ltb, lastb);
 }
 template <int N, int NA1, int NA2, int NB1, typename R>
@@ -288,7 +319,7 @@ template <class M, int DIN, int NOUT, class F, typename R>
 I2C_FN void q_points(const Quad<R>& q, const R sf, const R* muc, const R* lt, const F& f, R* am, R* dm, R* yc) {
   constexpr int NBI = (DIN + 3) / 4, NBO = (NOUT + 3) / 4;
   constexpr int NA1 = M::NA > 0 ? M::NA : 1;
-  static_assert(DIN <= 8 && NOUT <= QuadLds::YLD, "quad kernels: d <= 8, <= 12 outputs");
+  static_assert(DIN <= 8 && NOUT <= 12, "quad kernels: d <= 8, <= 12 outputs");
   const auto Lr = q.sh + QuadLds::O_L, Y = q.sh + QuadLds::O_Y, mv = q.sh + QuadLds::O_MV;
   q.sync();
 #pragma unroll
@@ -421,7 +452,7 @@ template <int N, int NZ, typename R> I2C_FN bool q_kalman(const Quad<R>& q, R* m
 // The same update on an IDENTITY observation of the state itself with noise alpha * xi and target zt (i2c.py:394-403 with z = the
 // state):  with C = chol(s + alpha xi), U = C^-1 s:  s <- s - U^T U;  the mean uses the posterior-covariance form of the same gain,
 // s (s + N)^-1 = s_new N^-1  (N^-1 = W / alpha, W = the cost weight):  mu <- mu + s_new W (zt - mu) / alpha   (see w_kalman).
-// s: FULL blocks in, full blocks out. xi_m, w_m: 16 x 16 row-major constants in LDS.
+// s: FULL blocks in, full blocks out. xi_m, w_m: QLD x QLD row-major constants in LDS.
 template <int N, typename R, class P>
 I2C_FN bool q_kalman_identity(const Quad<R>& q, const R alpha, const P xi_m, const P w_m, const bool w_diag, const R* ztc, R* muc, R* s) {
   constexpr int NB = (N + 3) / 4;
@@ -439,7 +470,7 @@ I2C_FN bool q_kalman_identity(const Quad<R>& q, const R alpha, const P xi_m, con
   R wr[NB];
   if (w_diag) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j) wr[j] = q_tr(q, w_m[(4 * j + q.c) * 16 + 4 * j + q.c] * (ztc[j] - muc[j]));
+    for (int j = 0; j < NB; ++j) wr[j] = q_tr(q, w_m[(4 * j + q.c) * QLD + 4 * j + q.c] * (ztc[j] - muc[j]));
   } else {
     R rr[NB];
 #pragma unroll
