@@ -89,6 +89,9 @@ enum {
   I2C_FAMILY_QUAD = 4   /* four trajectories per wavefront: 4 x 4 blocks on v_mfma_f64_4x4x4_4b_f64, one element per lane
                            (d <= 8; forward sweep)                                                                        */
 };
+/* I2cProblem.group_lanes = I2C_LANES_QUAD asks for the quad forward kernel of a model that also has wave kernels (64 = the
+ * matrix-instruction family in general: the wave kernels where they exist, the quad kernel otherwise) */
+#define I2C_LANES_QUAD 164
 enum { I2C_SWEEP_FORWARD = 0, I2C_SWEEP_BACKWARD = 1, I2C_SWEEP_PROPAGATE = 2, I2C_SWEEP_FILTER = 3 };
 /* hybrid default of the d >= 7 lane models: their FORWARD sweep runs on the group kernels while B * G stays within this
  * many lanes (every group wave then has a SIMD of its own: 1024 SIMDs x 64 lanes) */

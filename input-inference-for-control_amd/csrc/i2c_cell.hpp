@@ -53,6 +53,7 @@ template <class M, typename R> struct Consts {
   int has_Qf, has_x_terminal, z_per_cell, use_expert, terminal_cell, inference;
   int qr_diag, qf_diag;  // cost weights are diagonal: cheap closed forms in gaussian_cost
   int post_tm;           // posterior / prior buffers are trajectory-major, [T][B][E_POST] (I2cProblem.post_layout; wave-capable models)
+  int fwd_tm;            // quad forward kernel only: write the forward messages trajectory-major, [T][B][E_FWD] (the wave kernels read them)
   // element e of trajectory b inside one cell block of the posterior / prior buffer: stride of e and offset of b
   I2C_HD inline long post_es() const { return post_tm ? 1L : (long)B; }
   I2C_HD inline long post_bo(const int b) const { return post_tm ? (long)b * E_POST : (long)b; }

@@ -339,21 +339,22 @@ static int launch_wave_v(const Consts<M, R>& c, const A& a, void* stream) {
 }
 #endif
 
-// ---- quad kernels (i2c_quad.hpp): four trajectories per wavefront, one wavefront per workgroup ------------------------------------
+// ---- quad kernels (i2c_quad.hpp): four trajectories per wavefront; one wavefront per workgroup (d <= 8), four (d = 16) ---------
+template <class M> constexpr int quad_waves_per_block() { return QG<M>::WIDE ? 4 : 1; }
 #ifdef I2C_HOST_SIM
 template <class M, typename R, typename S, class A>
 static int launch_quad_forward(const Consts<M, R>& c, const A& a, void*) {
   QConst<M, R> kc;
   qconst_fill<M, R>(kc, &c, 0, 1);
   for (int b0 = 0; b0 < c.B; b0 += 4) {
-    std::vector<R> sh((size_t)4 * QuadLds::SIZE, R(0)), xch(128, R(0));
+    std::vector<R> sh((size_t)4 * QG<M>::SIZE, R(0)), xch(128, R(0));
     HostBarrier bar(64);
     std::vector<std::thread> lanes;
     for (int l = 0; l < 64; ++l)
       lanes.emplace_back([&, l, b0] {
         const int g = (l >> 2) & 3, b = b0 + g;
         const bool live = b < c.B;
-        forward_quad_body<M, R, S>(c, kc, a, live ? b : c.B - 1, live, Quad<R>{l, l >> 4, g, l & 3, sh.data() + g * QuadLds::SIZE, &bar, xch.data()});
+        forward_quad_body<M, R, S>(c, kc, a, live ? b : c.B - 1, live, Quad<R>{l, l >> 4, g, l & 3, sh.data() + g * QG<M>::SIZE, &bar, xch.data()});
       });
     for (auto& th : lanes) th.join();
   }
@@ -361,26 +362,34 @@ static int launch_quad_forward(const Consts<M, R>& c, const A& a, void*) {
 }
 #else
 template <class M, typename R, typename S, class A>
-__global__ __launch_bounds__(64, 2) void k_quad_forward(const Consts<M, R> c, const A a) {
+__global__ __launch_bounds__(64 * quad_waves_per_block<M>(), 2) void k_quad_forward(const Consts<M, R> c, const A a) {
+  constexpr int WPB = quad_waves_per_block<M>();
   __shared__ QConst<M, R> kc;
-  __shared__ R sh[4 * QuadLds::SIZE];
-  qconst_fill<M, R>(kc, (const Consts<M, R>*)__builtin_amdgcn_kernarg_segment_ptr(), (int)threadIdx.x, 64);
+  __shared__ R sh[WPB * 4 * QG<M>::SIZE];
+  qconst_fill<M, R>(kc, (const Consts<M, R>*)__builtin_amdgcn_kernarg_segment_ptr(), (int)threadIdx.x, 64 * WPB);
   __syncthreads();
-  // A wave reads four consecutive trajectories (32 bytes) of every [B]-contiguous row: the four waves that share a 128-byte line
-  // of each row are mapped onto workgroups of the SAME XCD (workgroups are dealt round-robin over the 8 XCDs, so blocks i and
-  // i + 8 share an L2). Placement is a speed heuristic only -- any mapping computes the same result.
-  const unsigned i = blockIdx.x, x = i & 7u, rr = (i >> 3) & 3u, gg = i >> 5;
-  const int l = (int)threadIdx.x, g = (l >> 2) & 3;
-  const long b = 16L * (gg * 8u + x) + 4 * rr + g;
-  if (16L * (gg * 8u + x) + 4 * rr >= c.B) return;  // (wave-uniform: no trajectory in this wave)
+  const int l = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6), g = (l >> 2) & 3;
+  long b0;
+  if constexpr (WPB == 1) {
+    // A wave reads four consecutive trajectories (32 bytes) of every [B]-contiguous row: the four waves that share a 128-byte line
+    // of each row are mapped onto workgroups of the SAME XCD (workgroups are dealt round-robin over the 8 XCDs, so blocks i and
+    // i + 8 share an L2). Placement is a speed heuristic only -- any mapping computes the same result.
+    const unsigned i = blockIdx.x, x = i & 7u, rr = (i >> 3) & 3u, gg = i >> 5;
+    b0 = 16L * (gg * 8u + x) + 4 * rr;
+  } else {  // (trajectory-major buffers: a cell of a trajectory is contiguous, nothing is shared between waves)
+    b0 = 4L * ((long)blockIdx.x * WPB + wv);
+  }
+  if (b0 >= c.B) return;  // (wave-uniform: no trajectory in this wave)
+  const long b = b0 + g;
   const bool live = b < c.B;
-  const Quad<R> q{l, l >> 4, g, l & 3, (lds_ptr<R>)(sh + g * QuadLds::SIZE)};
+  const Quad<R> q{l, l >> 4, g, l & 3, (lds_ptr<R>)(sh + (wv * 4 + g) * QG<M>::SIZE)};
   forward_quad_body<M, R, S>(c, kc, a, (int)(live ? b : c.B - 1), live, q);
 }
 template <class M, typename R, typename S, class A>
 static int launch_quad_forward(const Consts<M, R>& c, const A& a, void* stream) {
-  const unsigned blocks = (unsigned)(((long)c.B + 127) / 128) * 32u;
-  hipLaunchKernelGGL((k_quad_forward<M, R, S, A>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, c, a);
+  constexpr int WPB = quad_waves_per_block<M>();
+  const unsigned blocks = WPB == 1 ? (unsigned)(((long)c.B + 127) / 128) * 32u : (unsigned)(((long)c.B + 4 * WPB - 1) / (4 * WPB));
+  hipLaunchKernelGGL((k_quad_forward<M, R, S, A>), dim3(blocks), dim3(64 * WPB), 0, (hipStream_t)stream, c, a);
   return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
 }
 #endif
@@ -525,7 +534,7 @@ template <class M, typename R, typename S = R> struct Impl {
 
   // 1: group kernels, 0: one lane per trajectory, < 0: error code
   static int use_group(const I2cProblem* p) {
-    if (p->group_lanes == 0 || (p->group_lanes == 64 && (M::WAVE || M::QUAD)))  // 64: the wave / quad kernels; their missing sweeps run the default
+    if (p->group_lanes == 0 || (p->group_lanes == 64 && (M::WAVE || M::QUAD)) || (p->group_lanes == I2C_LANES_QUAD && M::QUAD))  // the wave / quad kernels; their missing sweeps run the default
       return M::GROUP_ONLY ? (HAS_GROUP ? 1 : I2C_ENOTSUP) : 0;
     if (p->group_lanes == -1) return M::GROUP_ONLY ? I2C_ENOTSUP : 0;  // one lane per trajectory, no hybrid forward
     return (HAS_GROUP && p->group_lanes == G) ? 1 : I2C_ENOTSUP;
@@ -564,6 +573,17 @@ template <class M, typename R, typename S = R> struct Impl {
   static int quad_supported(const I2cProblem* p, const C& c) {
     if (p->inference != I2C_INF_CUBATURE) return I2C_ENOTSUP;
     if (!c.rule_xu.unit || !c.rule_x.unit || c.rule_xu.w0 != R(0) || c.rule_x.w0 != R(0)) return I2C_ENOTSUP;
+    if constexpr (QG<M>::WIDE) {
+      // the d = 16 form addresses trajectory-major buffers only: the posterior / prior in that layout (the engine's default for
+      // the wave-capable models) and forward messages that the wave backward sweep reads
+      if (p->post_layout != 1) return I2C_ENOTSUP;
+      if constexpr (HAS_WAVE) {
+        const int rw = wave_supported(p, c);
+        if (rw != I2C_OK) return rw;
+      } else {
+        return I2C_ENOTSUP;
+      }
+    }
     constexpr long EMAX = C::E_FWD > C::E_POST ? C::E_FWD : C::E_POST;
     if (EMAX * (long)p->B * (long)sizeof(S) >= (1L << 31)) return I2C_EINVAL;
     if (c.z_per_cell && (long)p->T * C::NZ * (long)p->B * (long)sizeof(R) >= (1L << 32)) return I2C_EINVAL;
@@ -571,12 +591,18 @@ template <class M, typename R, typename S = R> struct Impl {
     return I2C_OK;
   }
   static int family(const I2cProblem* p, const C& c, const int sweep) {
-    if constexpr (HAS_QUAD) {  // forward sweep: on request (group_lanes = 64), or the model's default for small batches
-      if (sweep == I2C_SWEEP_FORWARD && (p->group_lanes == 64 || (p->group_lanes == 0 && p->B <= M::QUAD_FORWARD_MAX_B))) {
+    if constexpr (HAS_QUAD) {  // forward sweep: on request, or the model's default inside its batch window
+      const bool asked = p->group_lanes == I2C_LANES_QUAD || (p->group_lanes == 64 && !M::WAVE);
+      if (sweep == I2C_SWEEP_FORWARD && (asked || (p->group_lanes == 0 && p->B >= M::QUAD_FORWARD_MIN_B && p->B <= M::QUAD_FORWARD_MAX_B))) {
         const int rc = quad_supported(p, c);
         if (rc == I2C_OK) return I2C_FAMILY_QUAD;
-        if (p->group_lanes == 64) return rc;
+        if (asked) return rc;
       }
+    }
+    if (p->group_lanes == I2C_LANES_QUAD) {  // the other sweeps of an explicit quad request: the model's default family
+      I2cProblem q = *p;
+      q.group_lanes = 0;
+      return family(&q, c, sweep);
     }
     if constexpr (HAS_WAVE) {  // forward and backward sweeps: on request (group_lanes = 64) or as the model's default
       if ((sweep == I2C_SWEEP_FORWARD || sweep == I2C_SWEEP_BACKWARD) &&
@@ -661,7 +687,11 @@ template <class M, typename R, typename S = R> struct Impl {
       if constexpr (HAS_WAVE && !MIXED) return launch_wave<WK_FORWARD, M, R, R>(c, a, stream);
     }
     if (fam == I2C_FAMILY_QUAD) {
-      if constexpr (HAS_QUAD) return launch_quad_forward<M, R, R>(c, a, stream);
+      if constexpr (HAS_QUAD) {  // the forward messages go where the backward family of this problem reads them
+        C cq = c;
+        cq.fwd_tm = (M::WAVE && family(p, c, I2C_SWEEP_BACKWARD) == I2C_FAMILY_WAVE) ? 1 : 0;
+        return launch_quad_forward<M, R, R>(cq, a, stream);
+      }
     }
     if (fam == I2C_FAMILY_GROUP) {
       if constexpr (HAS_GROUP) return launch_group<GK_FORWARD, M, R, G>(c, nullptr, a, stream);

@@ -138,6 +138,63 @@ I2C_FN void r_sincos(double x, double* s, double* c) {
   *s = (q & 2) ? -ss : ss;
   *c = ((q + 1) & 2) ? -cc : cc;
 }
+// The same two routines with every polynomial constant as a SCALAR operand (an s_mov pair next to its use instead of a VGPR
+// pair pinned for the whole sweep): for kernels whose registers are full and whose waves share a SIMD, where the scalar unit
+// issues beside the vector one (the d = 16 quad forward kernel: the pinned constants were spilled to scratch).
+#ifdef I2C_HOST_SIM
+I2C_FN void r_sincos_sc(double x, double* s, double* c) { r_sincos(x, s, c); }
+I2C_FN double r_exp_sc(double x) { return r_exp(x); }
+#else
+I2C_FN double p_fma_s(double p, double z, double c) {  // p * z + c, c a scalar operand
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "s"(c));
+  return r;
+}
+I2C_FN void r_sincos_sc(double x, double* s, double* c) {
+  x = m_fabs(x) < 1.0e6 ? x : __builtin_nan("");
+  const double n = m_rint(x * 6.36619772367581382433e-01);
+  double r = m_fma(-n, 1.57079632673412561417e+00, x);
+  r = m_fma(-n, 6.07710050630396597660e-11, r);
+  r = m_fma(-n, 2.02226624871116645580e-21, r);
+  const double z = r * r;
+  double ps = p_fma_s(z * 1.58969099521155010221e-10, 1.0, -2.50507602534068634195e-08);
+  ps = p_fma_s(ps, z, 2.75573137070700676789e-06);
+  ps = p_fma_s(ps, z, -1.98412698298579493134e-04);
+  ps = p_fma_s(ps, z, 8.33333333332248946124e-03);
+  const double sr = m_fma(z * r, p_fma_s(z, ps, -1.66666666666666324348e-01), r);
+  double pc = p_fma_s(z * -1.13596475577881948265e-11, 1.0, 2.08757232129817482790e-09);
+  pc = p_fma_s(pc, z, -2.75573143513906633035e-07);
+  pc = p_fma_s(pc, z, 2.48015872894767294178e-05);
+  pc = p_fma_s(pc, z, -1.38888888888741095749e-03);
+  pc = p_fma_s(pc, z, 4.16666666666666019037e-02);
+  const double cr = 1.0 - m_fma(0.5, z, -(z * z) * pc);
+  const int q = (int)n;
+  const double ss = (q & 1) ? cr : sr;
+  const double cc = (q & 1) ? sr : cr;
+  *s = (q & 2) ? -ss : ss;
+  *c = ((q + 1) & 2) ? -cc : cc;
+}
+I2C_FN double r_exp_sc(double x) {
+  const double n = m_rint(x * 1.44269504088896338700e+00);
+  double r = m_fma(-n, 6.93147180369123816490e-01, x);
+  r = m_fma(-n, 1.90821492927058770002e-10, r);
+  const double z = r * r;
+  double e = p_fma_s(z * 2.08767569878681e-09, 1.0, 2.755731922398589e-07);
+  double o = p_fma_s(z * 1.6059043836821613e-10, 1.0, 2.505210838544172e-08);
+  e = p_fma_s(e, z, 2.48015873015873e-05);
+  o = p_fma_s(o, z, 2.7557319223985893e-06);
+  e = p_fma_s(e, z, 1.388888888888889e-03);
+  o = p_fma_s(o, z, 1.984126984126984e-04);
+  e = p_fma_s(e, z, 4.1666666666666664e-02);
+  o = p_fma_s(o, z, 8.333333333333333e-03);
+  e = p_fma_s(e, z, 0.5);
+  o = p_fma_s(o, z, 1.6666666666666666e-01);
+  e = m_fma(e, z, 1.0);
+  o = m_fma(o, z, 1.0);
+  return __builtin_ldexp(m_fma(r, o, e), (int)n);
+}
+#endif
+
 // ---- polynomial constants held in VGPRs ---------------------------------------------------------------------------
 // A VALU instruction reads at most one scalar / literal operand, so a Horner step with a literal coefficient costs the
 // lone, issue-bound wave an extra instruction (s_mov pair or v_mov copy) per step. PolyTab keeps the coefficients of

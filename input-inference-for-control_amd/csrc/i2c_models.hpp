@@ -26,6 +26,7 @@ struct Pendulum {
   static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
+  static constexpr int QUAD_FORWARD_MIN_B = 0;
   I2C_HD static constexpr int ang(int) { return 0; }
   // z = [sin th, cos th, thd, u],  zT = [sin th, cos th, thd]
   I2C_HD static constexpr int obs_lin(int k) { return k < 2 ? -1 : k - 1; }
@@ -72,6 +73,7 @@ struct PendulumActReg {
   static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
+  static constexpr int QUAD_FORWARD_MIN_B = 0;
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int) { return 2; }  // z = [u]
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -99,6 +101,7 @@ struct Cartpole {
   static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 4096;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
+  static constexpr int QUAD_FORWARD_MIN_B = 0;
   I2C_HD static constexpr int ang(int) { return 1; }
   // z = [x, sin th, cos th, xd, thd, u],  zT = [x, sin th, cos th, xd, thd]
   I2C_HD static constexpr int obs_lin(int k) { return k == 0 ? 0 : (k < 3 ? -1 : k - 1); }
@@ -153,6 +156,7 @@ struct DoubleCartpole {
   static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 8192;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
+  static constexpr int QUAD_FORWARD_MIN_B = 0;
   I2C_HD static constexpr int ang(int a) { return a == 0 ? 1 : 2; }
   // z = [x, sin th1, cos th1, sin th2, cos th2, xd, th1d, th2d, u],  zT = z without u
   I2C_HD static constexpr int obs_lin(int k) { return k == 0 ? 0 : (k < 5 ? -1 : k - 2); }
@@ -233,6 +237,7 @@ struct Linear {
   static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
+  static constexpr int QUAD_FORWARD_MIN_B = 0;
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -269,6 +274,7 @@ struct LinearMinEnergy {
   static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
+  static constexpr int QUAD_FORWARD_MIN_B = 0;
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int) { return 2; }  // z = [u], zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -306,6 +312,7 @@ struct Quadrotor {
   static constexpr bool WAVE = false;  // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 8192;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
+  static constexpr int QUAD_FORWARD_MIN_B = 0;
   I2C_HD static constexpr int ang(int) { return 2; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -369,8 +376,12 @@ struct Quadrotor12 {
   static constexpr bool GROUP_ONLY = true;
   static constexpr bool GROUP_FORWARD_AUTO = false;
   static constexpr bool WAVE = true;   // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
-  static constexpr bool QUAD = false;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
-  static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
+  static constexpr bool QUAD = true;   // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp), d = 16 form
+  // the quad kernel is the DEFAULT forward sweep from 2048 trajectories up (below, every wave kernel wave has a SIMD of its own and
+  // the shorter dependent chain of one trajectory per wave wins: B = 1024: 0.34 against 0.67 ms; B = 2048: 0.59 / 0.51; 4096: 1.10 /
+  // 0.59; 8192: 2.01 / 0.91; 32768: 7.85 / 3.17 -- profiles/r4_quad12_quad_vs_wave.txt)
+  static constexpr int QUAD_FORWARD_MAX_B = 1 << 30;
+  static constexpr int QUAD_FORWARD_MIN_B = 2048;
   I2C_HD static constexpr int ang(int a) { return 3 + a; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }

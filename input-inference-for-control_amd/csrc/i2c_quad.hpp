@@ -29,17 +29,27 @@
 
 namespace i2c {
 
-// LDS region of one trajectory (elements)
-struct QuadLds {
-  static constexpr int LDL = 10;               // row stride of the sigma-point directions: 8 rows (pairs) of <= 8 inputs
-  static constexpr int O_L = 0;
-  static constexpr int YLD = 13;               // row stride of the evaluation outputs: 16 rows (points) of <= 12 outputs (odd: the
-                                               // sixteen lanes of a trajectory write their rows to sixteen different bank pairs)
-  static constexpr int O_Y = O_L + 8 * LDL;
-  static constexpr int O_MV = O_Y + 16 * YLD;  // the mean the points are built around (8)
-  static constexpr int O_DG = O_MV + 8;        // 4 x 4 pivot block
-  static constexpr int O_DG2 = O_DG + 16;      // ... of the second elimination of a pair (q_elim2)
-  static constexpr int SIZE = O_DG2 + 16;      // (= 8 mod 32 elements: the four regions of a wave start 16 banks apart)
+// LDS region of one trajectory (elements) and the geometry of a model's sigma-point evaluations.
+//   d <= 8:  eight pair rows; the sixteen lanes of a trajectory evaluate all 2 d points (and the centre) in ONE pass;
+//   d <= 16: sixteen pair rows; two passes (lane p: m + sf L[:, p], then m - sf L[:, p]); the directions share their LDS with the
+//            results of the second pass (written after the last direction has been read), so that two waves per SIMD fit a CU.
+constexpr int Q_O_DG = 0, Q_O_DG2 = 16;  // 4 x 4 pivot blocks of an elimination / of the second one of a pair (q_elim2)
+template <class M> struct QG {
+  static constexpr int D = M::NX + M::NU;
+  static constexpr bool WIDE = D > 8;
+  static constexpr int PR = WIDE ? 16 : 8;        // pair rows
+  static constexpr int LDL = WIDE ? 17 : 10;      // row stride of the sigma-point directions
+  static constexpr int YLD = 13;                  // row stride of the evaluation outputs: 2 PR rows (points) of <= 12 outputs (odd: the
+                                                  // sixteen lanes of a trajectory write their rows to sixteen different bank pairs)
+  static constexpr int NMAX = M::NZ > M::NX ? (M::NZ > M::NZT ? M::NZ : M::NZT) : (M::NX > M::NZT ? M::NX : M::NZT);
+  static constexpr int QLD = NMAX > 12 ? 16 : 12;  // row stride of the batch constants (QConst)
+  static constexpr int O_MV = 32;                 // the mean the points are built around (PR)
+  static constexpr int O_Y = O_MV + PR;           // results of the + points (d <= 8: of all points, rows 0 .. 15)
+  static constexpr int O_YM = O_Y + PR * YLD;     // results of the - points
+  static constexpr int YM_SIZE = (WIDE && PR * LDL > PR * YLD) ? PR * LDL : PR * YLD;
+  static constexpr int O_L = WIDE ? O_YM : O_YM + PR * YLD;
+  static constexpr int RAW = WIDE ? O_YM + YM_SIZE : O_L + PR * LDL;
+  static constexpr int SIZE = RAW + ((24 - RAW % 16) % 16);  // (= 8 mod 16 elements: the four regions of a wave start 16 banks apart)
 };
 
 // Diagnostic build only (-DI2C_QUAD_STAMPS, never in the shipped library): s_memtime stamps at the phase boundaries of the forward
@@ -67,6 +77,14 @@ template <typename R> struct Quad {
 #endif
   }
 };
+
+// the same lane with its block coordinates opaque to loop-invariant code motion (see forward_quad_body)
+template <typename R> I2C_FN Quad<R> q_opaque(const Quad<R>& q) {
+  Quad<R> o = q;
+  o.r = opaque_i(q.r);
+  o.c = opaque_i(q.c);
+  return o;
+}
 
 // ---- the cross-lane instructions -------------------------------------------------------------------------------------------
 // acc (block) += A B per trajectory: lane (r, c) supplies A[c][r] and B[r][c] and holds acc[r][c]
@@ -142,15 +160,15 @@ template <typename R> I2C_FN R q_rowsum(const Quad<R>& q, const R x) {
 #endif
 }
 
-// Batch-wide constants by (row, column), in LDS, one copy per workgroup: 12 x 12 row-major, zero-padded (6 KB: with the 10 KB of
-// its four trajectory regions a workgroup stays under the 20 KB that let eight of them -- two waves per SIMD -- share a CU)
-constexpr int QLD = 12;
+// Batch-wide constants by (row, column), in LDS, one copy per workgroup: QLD x QLD row-major, zero-padded (d <= 8: 6 KB; with the
+// 10 KB of its four trajectory regions a workgroup stays under the 20 KB that let eight of them -- two waves per SIMD -- share a CU)
 template <class M, typename R> struct QConst {
+  static constexpr int QLD = QG<M>::QLD;
   R xi[QLD * QLD], eta[QLD * QLD], xiT[QLD * QLD], qr[QLD * QLD], qf[QLD * QLD];  // sig_xi0, sig_eta, sig_xiT0, blkdiag(Q, R), Qf
   R zg[QLD], zgT[QLD];
 };
 template <class M, typename R, class DST> I2C_FN void qconst_fill(DST& k, const Consts<M, R>* c, const int tid, const int nthreads) {
-  constexpr int NX = M::NX, NZ = M::NZ, NT = M::NZT > 0 ? M::NZT : 1;
+  constexpr int NX = M::NX, NZ = M::NZ, NT = M::NZT > 0 ? M::NZT : 1, QLD = QG<M>::QLD;
   for (int e = tid; e < QLD * QLD; e += nthreads) {
     const int i = e / QLD, j = e % QLD;
     k.xi[e] = (i < NZ && j < NZ) ? c->sig_xi0[tri_any(i, j)] : R(0);
@@ -164,8 +182,10 @@ template <class M, typename R, class DST> I2C_FN void qconst_fill(DST& k, const 
     k.zgT[e] = e < NT ? c->zg_term[e] : R(0);
   }
 }
-template <typename R, class P> I2C_FN R q_ldc(const Quad<R>& q, const P m, const int I, const int J) { return m[(4 * I + q.r) * QLD + 4 * J + q.c]; }
-template <typename R, class P> I2C_FN R q_ldv(const Quad<R>& q, const P v, const int J) { return v[4 * J + q.c]; }  // column form
+// (kz: an index the compiler cannot see through, always 0 and refreshed per cell: the constants are READ where they are used.
+//  Loop-invariant LDS loads are otherwise hoisted out of the time loop into dozens of registers -- and, for d = 16, spilled)
+template <int QLD, typename R, class P> I2C_FN R q_ldc(const Quad<R>& q, const P m, const int I, const int J, const int kz = 0) { return m[(4 * I + q.r) * QLD + 4 * J + q.c + kz]; }
+template <typename R, class P> I2C_FN R q_ldv(const Quad<R>& q, const P v, const int J, const int kz = 0) { return v[4 * J + q.c + kz]; }  // column form
 
 // ---- blocked Cholesky elimination --------------------------------------------------------------------------------------------
 // s: SPD matrix of dimension N in NB x NB blocks, of which the UPPER blocks are read (consumed). On return lt = L^T (upper blocks;
@@ -263,7 +283,7 @@ template <int K, int NB, int NC1, int NC2, typename R> I2C_FN void q_elim_apply(
 template <int K, int NB, int N, int NC1, int NC2, typename R>
 I2C_FN void q_elim_step(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* last) {
   constexpr int NL = (N - 4 * K) >= 4 ? 4 : (N - 4 * K);
-  const auto dg = q.sh + QuadLds::O_DG;
+  const auto dg = q.sh + Q_O_DG;
   q.sync();
   dg[4 * q.r + q.c] = s[K * NB + K];
   q.sync();
@@ -282,7 +302,7 @@ template <int N, int NC1, int NC2, typename R> I2C_FN bool q_elim(const Quad<R>&
 template <int K, int NB, int N, int NA1, int NA2, int NB1, typename R>
 I2C_FN void q_elim2_step(const Quad<R>& q, R* sa, R* ra1, R* ra2, R* lta, R* lasta, R* sb, R* rb1, R* ltb, R* lastb) {
   constexpr int NL = (N - 4 * K) >= 4 ? 4 : (N - 4 * K);
-  const auto dga = q.sh + QuadLds::O_DG, dgb = q.sh + QuadLds::O_DG2;
+  const auto dga = q.sh + Q_O_DG, dgb = q.sh + Q_O_DG2;
   q.sync();
   dga[4 * q.r + q.c] = sa[K * NB + K];
   dgb[4 * q.r + q.c] = sb[K * NB + K];
@@ -307,25 +327,26 @@ I2C_FN void q_elim2(const Quad<R>& q, R* sa, R* ra1, R* ra2, R* lta, bool* oka, 
 }
 
 // ---- sigma points ------------------------------------------------------------------------------------------------------------
-// The points m +/- sf L[:, p] of a DIN-dimensional rule through f, one evaluation per lane of the trajectory (lane p < 8: +,
-// lane 8 + p: -; pairs >= DIN have a zero direction: they evaluate the centre, and row 7 is used as such). Results as pairwise
-// sums and differences about a reference value yc, in blocks [pair][output]:  am = (y+ - yc) + (y- - yc),  dm = y+ - y-.
-// yc = the centre value for DIN < 8. For DIN = 8 all sixteen lanes carry points; with no weight on the centre (the only rules
-// this family serves) the moments do not depend on the reference value, and yc = the midpoint of pair 0 stands in.
+// The points m +/- sf L[:, p] of a DIN-dimensional rule through f, one evaluation per lane of the trajectory and pass
+// (d <= 8: lane p < 8: +, lane 8 + p: -, one pass; d <= 16: lane p: + in the first pass, - in the second; geometry G = QG<model>).
+// Pairs >= DIN have a zero direction: they evaluate the centre, and the last pair row is used as such. Results as pairwise sums
+// and differences about a reference value yc, in blocks [pair][output]:  am = (y+ - yc) + (y- - yc),  dm = y+ - y-.
+// yc = the centre value when a pair row is spare. When all rows carry points (DIN = 8 or 16), with no weight on the centre (the
+// only rules this family serves) the moments do not depend on the reference value, and yc = the midpoint of pair 0 stands in.
 // No masks: a pair beyond the input dimension IS a centre evaluation (its sum and difference vanish exactly), and the output
 // columns beyond NOUT are written as zeros by every lane.
 //   muc: mean, column form [NBI]; lt: L^T, upper blocks [NBI][NBI]
-template <class M, int DIN, int NOUT, class F, typename R>
+template <class M, class G, int DIN, int NOUT, class F, typename R>
 I2C_FN void q_points(const Quad<R>& q, const R sf, const R* muc, const R* lt, const F& f, R* am, R* dm, R* yc) {
-  constexpr int NBI = (DIN + 3) / 4, NBO = (NOUT + 3) / 4;
+  constexpr int NBI = (DIN + 3) / 4, NBO = (NOUT + 3) / 4, PR = G::PR, LDL = G::LDL, YLD = G::YLD;
   constexpr int NA1 = M::NA > 0 ? M::NA : 1;
-  static_assert(DIN <= 8 && NOUT <= 12, "quad kernels: d <= 8, <= 12 outputs");
-  const auto Lr = q.sh + QuadLds::O_L, Y = q.sh + QuadLds::O_Y, mv = q.sh + QuadLds::O_MV;
+  static_assert(DIN <= PR && NOUT <= 12 && 4 * NBI <= PR, "quad kernels: <= 16 inputs, <= 12 evaluated outputs");
+  const auto Lr = q.sh + G::O_L, Y = q.sh + G::O_Y, mv = q.sh + G::O_MV;
   q.sync();
 #pragma unroll
   for (int i = 0; i < NBI; ++i)
 #pragma unroll
-    for (int j = 0; j < NBI; ++j) Lr[(4 * i + q.r) * QuadLds::LDL + 4 * j + q.c] = j >= i ? lt[i * NBI + j] : R(0);
+    for (int j = 0; j < NBI; ++j) Lr[(4 * i + q.r) * LDL + 4 * j + q.c] = j >= i ? lt[i * NBI + j] : R(0);
 #ifdef I2C_HOST_SIM
   if (q.r == 0)  // (lane-threads must not race; on the device the four rows store the same value to the same address)
 #endif
@@ -334,35 +355,43 @@ I2C_FN void q_points(const Quad<R>& q, const R sf, const R* muc, const R* lt, co
     for (int j = 0; j < NBI; ++j) mv[4 * j + q.c] = muc[j];
   }
   q.sync();
-  {
-    const int p = q.p(), pp = p & 7;
+  const int p = q.p();
+#pragma unroll
+  for (int pass = 0; pass < (G::WIDE ? 2 : 1); ++pass) {
+    const int pp = G::WIDE ? p : (p & 7);
     const bool pt = pp < DIN;  // pairs beyond the input dimension evaluate the centre (their rows may not even be written)
-    const R sg = pt ? (p < 8 ? sf : -sf) : R(0);
-    const int lrow = (pt ? pp : 0) * QuadLds::LDL;
+    const bool plus = G::WIDE ? pass == 0 : p < 8;
+    const R sg = pt ? (plus ? sf : -sf) : R(0);
+    const int lrow = (pt ? pp : 0) * LDL;
     R x[DIN], sn[NA1], cs[NA1], y[NOUT];
 #pragma unroll
     for (int i = 0; i < DIN; ++i) x[i] = mv[i] + sg * Lr[lrow + i];
 #pragma unroll
-    for (int k = 0; k < M::NA; ++k) r_sincos(x[M::ang(k)], &sn[k], &cs[k]);
+    for (int k = 0; k < M::NA; ++k) {
+      if constexpr (G::WIDE) r_sincos_sc(x[M::ang(k)], &sn[k], &cs[k]);  // (constants as scalar operands: the registers are full)
+      else r_sincos(x[M::ang(k)], &sn[k], &cs[k]);
+    }
     f(x, sn, cs, y);
+    if (G::WIDE && pass == 1) q.sync();  // the second half of the results overwrites the directions: after their last read
+    const int yrow = (G::WIDE ? pass * PR + p : p) * YLD;
 #pragma unroll
-    for (int k = 0; k < 4 * NBO; ++k) Y[p * QuadLds::YLD + k] = k < NOUT ? y[k < NOUT ? k : 0] : R(0);
+    for (int k = 0; k < 4 * NBO; ++k) Y[yrow + k] = k < NOUT ? y[k < NOUT ? k : 0] : R(0);
   }
   q.sync();
 #pragma unroll
   for (int j = 0; j < NBO; ++j) {
     const int col = 4 * j + q.c;
     R y0;
-    if constexpr (DIN < 8) {
-      y0 = Y[7 * QuadLds::YLD + col];
+    if constexpr (DIN < PR) {
+      y0 = Y[(PR - 1) * YLD + col];
     } else {
-      y0 = R(0.5) * (Y[col] + Y[8 * QuadLds::YLD + col]);
+      y0 = R(0.5) * (Y[col] + Y[PR * YLD + col]);
     }
     yc[j] = y0;
 #pragma unroll
     for (int i = 0; i < NBI; ++i) {
       const int row = 4 * i + q.r;
-      const R yp = Y[row * QuadLds::YLD + col], ym = Y[(8 + row) * QuadLds::YLD + col];
+      const R yp = Y[row * YLD + col], ym = Y[(PR + row) * YLD + col];
       am[i * NBO + j] = (yp - y0) + (ym - y0);
       dm[i * NBO + j] = yp - ym;
     }
@@ -453,15 +482,15 @@ template <int N, int NZ, typename R> I2C_FN bool q_kalman(const Quad<R>& q, R* m
 // state):  with C = chol(s + alpha xi), U = C^-1 s:  s <- s - U^T U;  the mean uses the posterior-covariance form of the same gain,
 // s (s + N)^-1 = s_new N^-1  (N^-1 = W / alpha, W = the cost weight):  mu <- mu + s_new W (zt - mu) / alpha   (see w_kalman).
 // s: FULL blocks in, full blocks out. xi_m, w_m: QLD x QLD row-major constants in LDS.
-template <int N, typename R, class P>
-I2C_FN bool q_kalman_identity(const Quad<R>& q, const R alpha, const P xi_m, const P w_m, const bool w_diag, const R* ztc, R* muc, R* s) {
+template <int N, int QLD, typename R, class P>
+I2C_FN bool q_kalman_identity(const Quad<R>& q, const R alpha, const P xi_m, const P w_m, const bool w_diag, const R* ztc, R* muc, R* s, const int kz = 0) {
   constexpr int NB = (N + 3) / 4;
   R sz[NB * NB], u[NB * NB], lt[NB * NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      sz[i * NB + j] = s[i * NB + j] + alpha * q_ldc(q, xi_m, i, j);
+      sz[i * NB + j] = s[i * NB + j] + alpha * q_ldc<QLD>(q, xi_m, i, j, kz);
       u[i * NB + j] = s[i * NB + j];
     }
   const bool ok = q_elim<N, NB, 0>(q, sz, u, (R*)nullptr, lt);
@@ -470,7 +499,7 @@ I2C_FN bool q_kalman_identity(const Quad<R>& q, const R alpha, const P xi_m, con
   R wr[NB];
   if (w_diag) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j) wr[j] = q_tr(q, w_m[(4 * j + q.c) * QLD + 4 * j + q.c] * (ztc[j] - muc[j]));
+    for (int j = 0; j < NB; ++j) wr[j] = q_tr(q, w_m[(4 * j + q.c) * QLD + 4 * j + q.c + kz] * (ztc[j] - muc[j]));
   } else {
     R rr[NB];
 #pragma unroll
@@ -479,7 +508,7 @@ I2C_FN bool q_kalman_identity(const Quad<R>& q, const R alpha, const P xi_m, con
     for (int i = 0; i < NB; ++i) {  // (W r)[i], W symmetric: sum_k W[k][i] r[k]
       wr[i] = R(0);
 #pragma unroll
-      for (int k = 0; k < NB; ++k) q_mfma(q, q_ldc(q, w_m, k, i), rr[k], wr[i]);
+      for (int k = 0; k < NB; ++k) q_mfma(q, q_ldc<QLD>(q, w_m, k, i, kz), rr[k], wr[i]);
     }
   }
   const R ia = r_rcp(alpha);
@@ -492,6 +521,36 @@ I2C_FN bool q_kalman_identity(const Quad<R>& q, const R alpha, const P xi_m, con
   }
   return ok;
 }
+
+// One cell block of a per-cell buffer for the lanes of a wave. An element index is split into a per-lane part and a part that is
+// the same for every lane (a compile-time constant after unrolling): e = lane_e + k.
+//   TM (trajectory-major [B][E], the wave-capable models): byte offset = (lane_e * sizeof(S) + b E sizeof(S)) + k * sizeof(S) -- ONE
+//   register per distinct lane part (and store predicate), k in the instruction's immediate offset: the 16 x 16 blocks of the
+//   12-state quadrotor are addressed from ~a dozen registers instead of one per (block, lane) element;
+//   [E][B] rows otherwise: byte offset = (lane_e + k) * B sizeof(S) + b sizeof(S).
+// Masked-off lanes of a store park their offset out of the window (dropped by the buffer unit, see GIO::st_if).
+template <typename R, typename S, bool TM> struct QIO {
+  Window w;
+  unsigned rb, bo;
+  // TM: the block part goes into the instruction's SCALAR offset, kept apart from the lane part by an opaque move: added to the
+  // lane part, hipcc distributes it over the predicate's select and hoists one register PER (block, predicate) out of the time
+  // loop (they were spilled to scratch for d = 16); an s_mov per access costs nothing where waves share a SIMD
+  I2C_MEM R ld(const int lane_e, const int k) const {
+    if constexpr (TM) return (R)wld<S>(w, opaque_uniform((unsigned)k * (unsigned)sizeof(S)), (unsigned)lane_e * (unsigned)sizeof(S) + bo);
+    else return (R)wld<S>(w, 0u, (unsigned)(lane_e + k) * rb + bo);
+  }
+  I2C_MEM void st_if(const bool on, const int lane_e, const int k, const R v) const {
+#ifdef I2C_HOST_SIM
+    if (on) {
+      if constexpr (TM) wst(w, (unsigned)k * (unsigned)sizeof(S), (unsigned)lane_e * (unsigned)sizeof(S) + bo, (S)v);
+      else wst(w, 0u, (unsigned)(lane_e + k) * rb + bo, (S)v);
+    }
+#else
+    if constexpr (TM) wst(w, opaque_uniform((unsigned)k * (unsigned)sizeof(S)), on ? (unsigned)lane_e * (unsigned)sizeof(S) + bo : 0x80000000u, (S)v);
+    else wst(w, 0u, on ? (unsigned)(lane_e + k) * rb + bo : 0x80000000u, (S)v);
+#endif
+  }
+};
 
 // ------------------------------------------------------------------------------------------
 // Forward sweep (i2c.py:876-880 over :350-447)
@@ -507,11 +566,14 @@ I2C_FN bool q_kalman_identity(const Quad<R>& q, const R alpha, const P xi_m, con
 // `live`: trajectory slot b holds a real trajectory (the last wave of a batch that is not a multiple of four repeats its last
 // one in the spare slots: every lane of a wave takes part in the matrix instructions; nothing is stored for them)
 template <class M, typename R, typename S, class KC>
-I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const FwdArgs<R, S>& a, const int b, const bool live, const Quad<R>& q) {
+I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const FwdArgs<R, S>& a, const int b, const bool live, const Quad<R>& qw) {
   using C = Consts<M, R>;
+  const Quad<R>& q = qw;
   constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D, NT = C::NZT1;
   constexpr int NBX = (NX + 3) / 4, NBD = (D + 3) / 4, NBZ = (NZ + 3) / 4, NBT = (NT + 3) / 4;
-  static_assert(D <= 8 && NZ <= 12 && NZT <= 12, "quad kernels: d <= 8, at most 12 observations");
+  using G = QG<M>;
+  constexpr int QLD = G::QLD;
+  static_assert(D <= 16 && NZ <= 16 && NZT <= 16, "quad kernels: d <= 16");
   constexpr bool OBS_ID = st_identity<ObsStruct<M>, NZ>() && NZ == D;
   constexpr bool TERM_ID = NZT > 0 && st_identity<TermStruct<M>, NT>() && NT == NX;
   static_assert(OBS_ID || D % 4 != 0, "quad kernels: a general observation needs a spare column in the joint's last block");
@@ -529,6 +591,24 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
   int fail = 0;
   auto xrow = [&](const int i) { return 4 * i + r; };  // matrix row / column of this lane in block row i / block column j
   auto xcol = [&](const int j) { return 4 * j + cc; };
+  // one cell block of a per-cell buffer for this lane's trajectory: [E][B] rows, or trajectory-major [B][E] (the posterior / prior
+  // buffers of the wave-capable models, Consts::post_tm; the forward messages when the wave kernels read them, Consts::fwd_tm)
+  constexpr bool TM = G::WIDE;  // (Impl::quad_supported: the d = 16 form is only chosen when both buffers are trajectory-major)
+  auto cell_io = [&](const S* cell, const int E) {
+    if constexpr (TM) return QIO<R, S, TM>{make_window(cell, (unsigned long)E * B * WS), WS, (unsigned)b * (unsigned)E * WS};
+    else return QIO<R, S, TM>{make_window(cell, (unsigned long)E * rb), rb, bo};
+  };
+  // packed-symmetric element (row, col) of block (i, j), i <= j, split into its per-lane and its per-block part:
+  //   i < j (row <= col):  col (col + 1) / 2 + row  =  [c (c + 1) / 2 + r + 4 j c]  +  [8 j^2 + 2 j + 4 i]
+  //   i = j, read as a full symmetric block (hi / lo = the larger / smaller of r, c):  [hi (hi + 1) / 2 + lo + 4 j hi]  +  [8 j^2 + 6 j]
+  const int hi = r > cc ? r : cc, lo = r > cc ? cc : r;
+  const int tri_c = cc * (cc + 1) / 2 + r, tri_d = hi * (hi + 1) / 2 + lo;
+  auto sym_lane = [&](const int i, const int j) { return i == j ? tri_d + 4 * j * hi : tri_c + 4 * j * cc; };
+  auto sym_k = [&](const int i, const int j) { return i == j ? 8 * j * j + 6 * j : 8 * j * j + 2 * j + 4 * i; };
+  // is (row of block row i, column of block column j) inside an N x N matrix? (folds to `true` for full blocks)
+  auto in_row = [&](const int i, const int N) { return 4 * i + 3 < N || 4 * i + r < N; };
+  auto in_col = [&](const int j, const int N) { return 4 * j + 3 < N || 4 * j + cc < N; };
+  auto in_n = [&](const int i, const int j, const int N) { return in_row(i, N) && in_col(j, N); };
   // lane masks as multipliers (everything they multiply is finite or belongs to a trajectory that has failed anyway)
   const R m_ucol = (cc >= CU && cc < CU + NU) ? R(1) : R(0);                   // action columns of block column JU
   const R m_uu = (cc >= CU && cc < CU + NU && r >= CU && r < CU + NU) ? R(1) : R(0);
@@ -571,29 +651,27 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
   const unsigned zcell = c.z_per_cell ? (unsigned)((unsigned long)NZ * B * sizeof(R)) : 0u, acell = a.alpha_cell ? (unsigned)(B * sizeof(R)) : 0u;
   auto fetch_prior = [&](const int tc) {
     const int trc = c.row(tc);
-    const WIO<R, S> pri = wio<R, S>(a.prior + (unsigned long)trc * C::E_POST * B, (unsigned long)C::E_POST, rb, bo);
+    const QIO<R, S, TM> pri = cell_io(a.prior + (unsigned long)trc * C::E_POST * B, C::E_POST);
 #pragma unroll
     for (int j = 0; j < NBD; ++j) {
-      const int col = xcol(j);
-      nx_pmu[j] = pri.ld(col < D ? col : 0);
+      nx_pmu[j] = pri.ld(in_col(j, D) ? cc : -4 * j, 4 * j);
 #pragma unroll
-      for (int i = 0; i <= j; ++i) {  // upper blocks
-        const int row = xrow(i);
-        const bool in = row < D && col < D;
-        nx_pj[i * NBD + j] = pri.ld(D + w_symidx(in ? row : 0, in ? col : 0));
-      }
+      for (int i = 0; i <= j; ++i)  // upper blocks (the diagonal ones as full symmetric blocks)
+        nx_pj[i * NBD + j] = pri.ld(in_n(i, j, D) ? sym_lane(i, j) : -sym_k(i, j), D + sym_k(i, j));
     }
 #pragma unroll
     for (int i = 0; i < NBX; ++i) {  // K^T in block column JU: row = state index, column = action
-      const int row = xrow(i);
-      const bool in = row < NX && cc >= CU && cc < CU + NU;
-      nx_kt[i] = pri.ld(O_K + (in ? cc - CU : 0) * NX + (in ? row : 0));
+      const bool in = in_row(i, NX) && cc >= CU && cc < CU + NU;
+      nx_kt[i] = pri.ld(in ? (cc - CU) * NX + r : -4 * i, O_K + 4 * i);
     }
     nx_alpha = wld<R>(alw, (unsigned)trc * acell, bo8);
 #pragma unroll
     for (int j = 0; j < NBZ; ++j) nx_zt[j] = wld<R>(zw, (unsigned)trc * zcell, zlane[j]);
     nx_ff = (int)wld_u8(ffw, (unsigned)trc);
   };
+  // d <= 8: a cell ahead. d = 16: at the top of the cell itself -- the 22 prefetched doubles would sit on top of a register peak that
+  // already fills the 256 registers two waves per SIMD leave each (the second wave covers the round trip)
+  constexpr bool PREFETCH = !G::WIDE;
   fetch_prior(0);
   // settled before the loop (see forward_wave_body: loads pending on the loop-entry path cost a vmcnt(0) in every cell)
   nx_alpha = opaque(nx_alpha);
@@ -617,7 +695,7 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
 
   // smoother gain J = sig_xy sig_x3^-1 (i2c.py:423-425) of cell tj from  w3 = W = chol(sig_x3)^-1  and  yj = W sig_xy^T:  J^T = W^T yj
   auto store_gain = [&](const int tj, const R* w3, const R* yj) {
-    const WIO<R, S> oj = wio<R, S>(a.fwd + (unsigned long)tj * C::E_FWD * B, (unsigned long)C::E_FWD, rb, bo);
+    const QIO<R, S, TM> oj = cell_io(a.fwd + (unsigned long)tj * C::E_FWD * B, C::E_FWD);
     R jt[NBX * NBD];
 #pragma unroll
     for (int k = 0; k < NBX * NBD; ++k) jt[k] = R(0);
@@ -630,10 +708,8 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
 #pragma unroll
     for (int i = 0; i < NBX; ++i)
 #pragma unroll
-      for (int j = 0; j < NBD; ++j) {
-        const bool in = xrow(i) < NX && xcol(j) < D;
-        oj.st_if(live && in, O_J + (in ? xcol(j) : 0) * NX + (in ? xrow(i) : 0), jt[i * NBD + j]);
-      }
+      for (int j = 0; j < NBD; ++j)  // J[col][row] = J^T[row][col]: element (4 j + c) nx + 4 i + r
+        oj.st_if(live && in_row(i, NX) && in_col(j, D), cc * NX + r, O_J + 4 * j * NX + 4 * i, jt[i * NBD + j]);
   };
   auto identity_x = [&](R* w3) {
 #pragma unroll
@@ -646,7 +722,13 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
 #endif
   for (int t = 0; t < T; ++t) {
-    const WIO<R, S> out = wio<R, S>(a.fwd + (unsigned long)t * C::E_FWD * B, (unsigned long)C::E_FWD, rb, bo);
+    const QIO<R, S, TM> out = cell_io(a.fwd + (unsigned long)t * C::E_FWD * B, C::E_FWD);
+    if (!PREFETCH && t > 0) fetch_prior(t);
+    const int kz = (int)opaque_uniform(0u);  // (see q_ldc)
+    // d = 16: the lane's block coordinates made opaque once per cell. Every 0 / 1 lane mask of the cell (one-hot selectors of the
+    // pivot algebra, identity blocks, triangle masks: ~25 fp64 values) is otherwise hoisted out of the time loop and pinned in
+    // registers the cell needs for its 16 x 16 blocks -- they were spilled to scratch; recomputing one is a compare and a select
+    const Quad<R> q = G::WIDE ? q_opaque(qw) : qw;
     const R alpha = nx_alpha;
     const bool ff = w_uniform(nx_ff) != 0;
     R pmu[NBD], pj[NBD * NBD], kt[NBX], zt[NBZ];
@@ -659,7 +741,7 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
 #pragma unroll
     for (int k = 0; k < NBX; ++k) kt[k] = nx_kt[k];
 #pragma unroll
-    for (int j = 0; j < NBZ; ++j) zt[j] = xcol(j) < NZ ? (c.z_per_cell ? nx_zt[j] : q_ldv(q, kc.zg, j)) : R(0);
+    for (int j = 0; j < NBZ; ++j) zt[j] = xcol(j) < NZ ? (c.z_per_cell ? nx_zt[j] : q_ldv(q, kc.zg, j, kz)) : R(0);
     int cell_bad = 0;
 
     // ---- 0. the pair of factorisations of the incoming state covariance -----------------------
@@ -705,7 +787,7 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
         ysq += (cc == (SPX ? CU : 0) && xrow(i) < NX) ? yv * yv : R(0);
       }
       const R maha = q_bcq<(SPX ? CU : 0)>(q, q_colsum(q, ysq));
-      rho = ff ? R(0) : r_exp(R(-0.5) * maha);  // feed-forward: independent action prior (i2c.py:355-360) = the feedback form with Kt = 0
+      rho = ff ? R(0) : (G::WIDE ? r_exp_sc(R(-0.5) * maha) : r_exp(R(-0.5) * maha));  // feed-forward: independent action prior (i2c.py:355-360) = the feedback form with Kt = 0
     }
     // ---- 1. joint prior over (x, u) (i2c.py:361-387): mean column form, covariance UPPER blocks, factor from Lt3 ----
     R mu0[NBD], s0[NBD * NBD], lt0[NBD * NBD];
@@ -781,7 +863,7 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
       }
     }
     I2C_QSTAMP(0);  // factorisation pair + joint prior
-    fetch_prior(t + 1 < T ? t + 1 : t);  // this cell's rows are consumed: the next cell's, a cell ahead
+    if (PREFETCH) fetch_prior(t + 1 < T ? t + 1 : t);  // this cell's rows are consumed: the next cell's, a cell ahead
     if (a.prior_out) {
       const WIO<R, S> po = wio<R, S>(a.prior_out + (unsigned long)t * (D + sym(D)) * B, (unsigned long)(D + sym(D)), rb, bo);
 #pragma unroll
@@ -799,19 +881,19 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
       for (int i = 0; i < NBD; ++i)
 #pragma unroll
         for (int j = 0; j < NBD; ++j) sf_[i * NBD + j] = j >= i ? s0[i * NBD + j] : q_tr(q, s0[j * NBD + i]);
-      cell_bad = flag_stage(cell_bad, q_kalman_identity<D>(q, alpha, kc.xi, kc.qr, c.qr_diag != 0, zt, mu0, sf_), 2);
+      cell_bad = flag_stage(cell_bad, q_kalman_identity<D, QLD>(q, alpha, kc.xi, kc.qr, c.qr_diag != 0, zt, mu0, sf_, kz), 2);
 #pragma unroll
       for (int k = 0; k < NBD * NBD; ++k) s0[k] = sf_[k];
     } else {
       I2C_QSTAMP(1);
       R am[NBD * NBZ], dm[NBD * NBZ], yc[NBZ], mz[NBZ], sz[NBZ * NBZ], szx[NBZ * NBD];
-      q_points<M, D, NZ>(q, rule.sf, mu0, lt0, ObserveF<M, R>{c.params}, am, dm, yc);
+      q_points<M, G, D, NZ>(q, rule.sf, mu0, lt0, ObserveF<M, R>{c.params}, am, dm, yc);
       I2C_QSTAMP(2);  // observation points
       q_moments<D, NZ>(q, rule.wi, am, dm, yc, mz, sz);
 #pragma unroll
       for (int i = 0; i < NBZ; ++i)
 #pragma unroll
-        for (int j = i; j < NBZ; ++j) sz[i * NBZ + j] += alpha * q_ldc(q, kc.xi, i, j);
+        for (int j = i; j < NBZ; ++j) sz[i * NBZ + j] += alpha * q_ldc<QLD>(q, kc.xi, i, j, kz);
       // cov(z, xu) = wi sf [d_p]^T L^T
 #pragma unroll
       for (int k = 0; k < NBZ * NBD; ++k) szx[k] = R(0);
@@ -825,9 +907,9 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
     I2C_QSTAMP(4);  // Kalman-style update
 #pragma unroll
     for (int j = 0; j < NBD; ++j) {
-      out.st_if(live && r == 0 && xcol(j) < D, xcol(j), mu0[j]);
+      out.st_if(live && r == 0 && in_col(j, D), cc, 4 * j, mu0[j]);
 #pragma unroll
-      for (int i = 0; i <= j; ++i) out.st_if(live && xrow(i) <= xcol(j) && xcol(j) < D, D + w_symidx(xrow(i), xcol(j) < D ? xcol(j) : 0), s0[i * NBD + j]);
+      for (int i = 0; i <= j; ++i) out.st_if(live && (i < j || r <= cc) && in_col(j, D), sym_lane(i, j), D + sym_k(i, j), s0[i * NBD + j]);
     }
 
     // ---- 3. dynamics push-through (i2c.py:415-421) ----------------------------------------
@@ -841,13 +923,13 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
       }
       I2C_QSTAMP(5);  // stores + chol(updated joint)
       R am[NBD * NBX], dm[NBD * NBX], yc[NBX], sy[NBX * NBX];
-      q_points<M, D, NX>(q, rule.sf, mu0, lt, DynamicsF<M, R>{c.params}, am, dm, yc);
+      q_points<M, G, D, NX>(q, rule.sf, mu0, lt, DynamicsF<M, R>{c.params}, am, dm, yc);
       I2C_QSTAMP(6);  // dynamics points
       q_moments<D, NX>(q, rule.wi, am, dm, yc, mx, sy);
 #pragma unroll
       for (int i = 0; i < NBX; ++i)
 #pragma unroll
-        for (int j = 0; j < NBX; ++j) sx[i * NBX + j] = j >= i ? sy[i * NBX + j] + q_ldc(q, kc.eta, i, j) : R(0);
+        for (int j = 0; j < NBX; ++j) sx[i * NBX + j] = j >= i ? sy[i * NBX + j] + q_ldc<QLD>(q, kc.eta, i, j, kz) : R(0);
 #pragma unroll
       for (int k = 0; k < NBX * NBD; ++k) sxy[k] = R(0);
       q_tn<NBD, NBX, NBD, false, false, true>(q, dm, lt, sxy);  // sig_xy^T = wi sf [d_p]^T L^T
@@ -870,26 +952,26 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
       j_pending = false;
       R ztT[NBT];
 #pragma unroll
-      for (int j = 0; j < NBT; ++j) ztT[j] = q_ldv(q, kc.zgT, j);
+      for (int j = 0; j < NBT; ++j) ztT[j] = q_ldv(q, kc.zgT, j, kz);
       if constexpr (TERM_ID) {
         R sf_[NBX * NBX];
 #pragma unroll
         for (int i = 0; i < NBX; ++i)
 #pragma unroll
           for (int j = 0; j < NBX; ++j) sf_[i * NBX + j] = j >= i ? sx[i * NBX + j] : q_tr(q, sx[j * NBX + i]);
-        cell_bad = flag_stage(cell_bad, q_kalman_identity<NX>(q, alpha, kc.xiT, kc.qf, c.qf_diag != 0, ztT, mx, sf_), 5);
+        cell_bad = flag_stage(cell_bad, q_kalman_identity<NX, QLD>(q, alpha, kc.xiT, kc.qf, c.qf_diag != 0, ztT, mx, sf_, kz), 5);
 #pragma unroll
         for (int i = 0; i < NBX; ++i)
 #pragma unroll
           for (int j = 0; j < NBX; ++j) sx[i * NBX + j] = j >= i ? sf_[i * NBX + j] : R(0);
       } else if constexpr (NZT > 0) {
         R am[NBX * NBT], dm[NBX * NBT], yc[NBT], mz[NBT], sz[NBT * NBT], szx[NBT * NBX];
-        q_points<M, NX, NT>(q, c.rule_x.sf, mx, l3t, ObserveTermF<M, R>{c.params}, am, dm, yc);
+        q_points<M, G, NX, NT>(q, c.rule_x.sf, mx, l3t, ObserveTermF<M, R>{c.params}, am, dm, yc);
         q_moments<NX, NT>(q, c.rule_x.wi, am, dm, yc, mz, sz);
 #pragma unroll
         for (int i = 0; i < NBT; ++i)
 #pragma unroll
-          for (int j = i; j < NBT; ++j) sz[i * NBT + j] += alpha * q_ldc(q, kc.xiT, i, j);
+          for (int j = i; j < NBT; ++j) sz[i * NBT + j] += alpha * q_ldc<QLD>(q, kc.xiT, i, j, kz);
 #pragma unroll
         for (int k = 0; k < NBT * NBX; ++k) szx[k] = R(0);
         q_tn<NBX, NBT, NBX, false, false, true>(q, dm, l3t, szx);
@@ -902,9 +984,9 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
     fail = fold_cell_failure(fail, cell_bad, t);
 #pragma unroll
     for (int j = 0; j < NBX; ++j) {
-      out.st_if(live && r == 0 && xcol(j) < NX, O_MU3 + (xcol(j) < NX ? xcol(j) : 0), mx[j]);
+      out.st_if(live && r == 0 && in_col(j, NX), cc, O_MU3 + 4 * j, mx[j]);
 #pragma unroll
-      for (int i = 0; i <= j; ++i) out.st_if(live && xrow(i) <= xcol(j) && xcol(j) < NX, O_S3 + w_symidx(xrow(i), xcol(j) < NX ? xcol(j) : 0), sx[i * NBX + j]);
+      for (int i = 0; i <= j; ++i) out.st_if(live && (i < j || r <= cc) && in_col(j, NX), sym_lane(i, j), O_S3 + sym_k(i, j), sx[i * NBX + j]);
     }
     I2C_QSTAMP(7);  // dynamics moments, terminal update, stores
   }

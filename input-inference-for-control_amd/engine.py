@@ -101,7 +101,7 @@ class BatchedI2c:
         # 64 = the wave kernels (csrc/i2c_wave.hpp: one wavefront per trajectory, blocks in the fp64 matrix-instruction layout),
         # for the models that have them (dims.wave): forward and backward sweeps; propagation and filter run the model's default
         ok = self.group_lanes in (0, dims.group_lanes) or (self.group_lanes == -1 and not dims.group_only) or \
-            (self.group_lanes == 64 and (dims.wave or dims.quad))
+            (self.group_lanes == 64 and (dims.wave or dims.quad)) or (self.group_lanes == _native.LANES_QUAD and dims.quad)
         if not ok:
             raise ValueError(f"group_lanes={self.group_lanes}: this model's group kernels use {dims.group_lanes} lanes"
                              + (" and it has no one-lane kernels" if dims.group_only else " (or -1: one lane per trajectory)")
@@ -109,10 +109,13 @@ class BatchedI2c:
                              + (" (or 64: four trajectories per wavefront, forward sweep)" if dims.quad else ""))
         # 64 on a model with the quad kernel (csrc/i2c_quad.hpp: four trajectories per wavefront on the 4 x 4 x 4 fp64 matrix
         # instruction): the FORWARD sweep runs on it, every other sweep on the model's default kernels
-        self.quad_requested = bool(self.group_lanes == 64 and dims.quad and not dims.wave)
+        # (_native.LANES_QUAD asks for it on a model that also has wave kernels, where 64 means those)
+        self.quad_requested = bool((self.group_lanes == 64 and dims.quad and not dims.wave) or self.group_lanes == _native.LANES_QUAD)
         self.uses_group_kernels = bool((self.group_lanes > 0 and not self.quad_requested) or dims.group_only)  # a multi-lane family (group or wave) serves the sweeps
         if self.mixed and inference != "cubature":
             raise ValueError("fp32 storage (storage_dtype) is available for the cubature path only")
+        if self.mixed and self.quad_requested:
+            raise ValueError("fp32 storage (storage_dtype) is not available for the quad forward kernel")
         if self.mixed and self.uses_group_kernels and not (dims.wave and self.group_lanes in (0, 64)):
             raise ValueError("fp32 storage (storage_dtype) is available for the one-lane kernels and the wave kernels only")
 
@@ -230,7 +233,7 @@ class BatchedI2c:
         mode = self.lib.i2c_backward_schedule(self.model_id, B, T, self.backward_mode)  # resolves "auto"
         if mode not in (_native.BWD_TWO_PASS, _native.BWD_FUSED, _native.BWD_CHUNKED):
             raise RuntimeError("i2c_backward_schedule() returned %d" % mode)
-        wave_ok = bool(dims.wave) and self.group_lanes in (0, 64) and not (self.linearize or self.gauss_hermite)
+        wave_ok = bool(dims.wave) and self.group_lanes in (0, 64, _native.LANES_QUAD) and not (self.linearize or self.gauss_hermite)
         lin_chunked = self.linearize and not self.uses_group_kernels and not self.mixed and mode == _native.BWD_CHUNKED
         if lin_chunked:
             pass  # Linearize on the one-lane kernels: the sequential walk or, at small batches, its chunked form
@@ -287,12 +290,16 @@ class BatchedI2c:
         self._problem = self._make_problem()
         # The forward-message buffer is private to the kernel family that writes and reads it: the wave kernels keep it
         # trajectory-major, [T][B][e_fwd] (include/i2c_hip.h); forward_messages() reads it through a view either way.
+        # (the reader decides: the wave backward sweep reads trajectory-major messages, written by the wave or the quad forward sweep)
         try:
-            self.fwd_trajectory_major = self.kernel_family("forward") == "wave"
-        except RuntimeError:  # a problem the library refuses: the sweeps report it (same code) when they are called
+            self.fwd_trajectory_major = self.kernel_family("backward") == "wave"
+            if self.kernel_family("forward") == "wave" and not self.fwd_trajectory_major:
+                raise RuntimeError("the wave forward sweep needs the wave backward sweep (forward-message layout)")
+        except RuntimeError as e:  # a problem the library refuses: the sweeps report it (same code) when they are called
+            if "layout" in str(e):
+                raise
             self.fwd_trajectory_major = False
         if self.fwd_trajectory_major:
-            assert self.kernel_family("backward") == "wave"
             self.fwd = self.fwd.reshape(T, B, dims.e_fwd)
 
     # ------------------------------------------------------------------ C-ABI plumbing

@@ -117,6 +117,18 @@ def test_hip_quad_forward_vs_reference_golden(lib, name, tol_d, tol_s):
     assert eng.forward_family == "quad" and eng.backward_family == "lane"
 
 
+@pytest.mark.parametrize("name", ["em_quad12_T20", "em_quad12_T12_propagate", "em_quad12_nondiag_T12"])
+def test_hip_quad12_quad_forward_vs_reference_golden(lib, name):
+    """The quad forward kernel on the 12-state quadrotor (next to its wave kernels: LANES_QUAD), wave backward sweep behind it."""
+    eng = parity.check_against_golden(name, lib, "cuda", 1e-6, 1e-5, group_lanes=parity.pkg._native.LANES_QUAD)
+    assert (eng.forward_family, eng.backward_family) == ("quad", "wave")
+
+
+def test_hip_quad12_quad_forward_batch_vs_oracle(lib):
+    eng, _ = parity.check_batch_against_oracle("em_quad12_T20", lib, "cuda", 203, 3, tol=1e-6, group_lanes=parity.pkg._native.LANES_QUAD)
+    assert eng.forward_family == "quad"
+
+
 @pytest.mark.parametrize("name,B", [("em_dcp_T60", 77), ("em_pendulum_T200", 1001), ("em_quadrotor_T20", 203), ("em_cartpole_T100", 130)])
 def test_hip_quad_forward_batch_vs_oracle(lib, name, B):
     """Ragged batches (not a multiple of the four trajectories of a wavefront, nor of the 16 that share a cache line) against

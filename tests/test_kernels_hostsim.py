@@ -134,6 +134,20 @@ def test_hostsim_quad_forward_batch_vs_oracle(lib, name, B):
     assert eng.forward_family == "quad"
 
 
+@pytest.mark.parametrize("name", QUAD12)
+def test_hostsim_quad12_quad_forward_vs_reference_golden(lib, name):
+    """The quad forward kernel on the 12-state quadrotor (d = 16: sixteen pair rows, two evaluation passes, four pivot blocks per
+    factorisation), asked for with LANES_QUAD next to the model's wave kernels; the wave backward sweep reads what it writes
+    (trajectory-major forward messages)."""
+    eng = parity.check_against_golden(name, lib, "cpu", 1e-7, 1e-6, group_lanes=parity.pkg._native.LANES_QUAD)
+    assert (eng.forward_family, eng.backward_family) == ("quad", "wave") and eng.fwd_trajectory_major
+
+
+def test_hostsim_quad12_quad_forward_batch_vs_oracle(lib):
+    eng, _ = parity.check_batch_against_oracle("em_quad12_T20", lib, "cpu", 5, 2, tol=1e-7, group_lanes=parity.pkg._native.LANES_QUAD)
+    assert eng.forward_family == "quad"
+
+
 def test_quad_forward_refuses_what_it_does_not_cover(lib):
     """General cubature weights (a weight on the centre point) and the other inference rules are not in the quad form: the
     library says I2C_ENOTSUP when it is asked for explicitly."""

@@ -63,6 +63,8 @@ if __name__ == "__main__":
     groups = (0, True) if "group" in sys.argv[1:] else (0,)
     if "wave" in sys.argv[1:]:
         groups = groups + (64,)
+    if "quad" in sys.argv[1:]:  # the quad forward kernel of a model that also has wave kernels (the 12-state quadrotor)
+        groups = groups + (164,)
     if "lane" in sys.argv[1:]:  # one lane per trajectory for every sweep (no group forward for the d >= 7 models)
         groups = (-1,) + groups[1:]
     for n in names:
@@ -71,6 +73,8 @@ if __name__ == "__main__":
                 for m in modes:
                     for grp in groups:
                         if grp is True and (dt != torch.float64 or m != modes[0]):
+                            continue
+                        if grp == 164 and (n != "Quadrotor12" or dt != torch.float64 or m != modes[0]):
                             continue
                         if grp == 64 and (dt != torch.float64 or m != modes[0]):
                             continue  # (64: the wave kernels of the 12-state quadrotor, the quad forward kernel of the d <= 8 models)

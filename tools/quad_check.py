@@ -15,7 +15,7 @@ bad = 0
 for name in names:
     t = time.time()
     try:
-        eng = parity.check_against_golden(name, None, "cuda", 1e-6, 1e-5, group_lanes=64)
+        eng = parity.check_against_golden(name, None, "cuda", 1e-6, 1e-5, group_lanes=164 if "quad12" in name else 64)
         print(name, "OK", eng.forward_family, eng.backward_family, f"{time.time() - t:.1f}s", flush=True)
     except Exception as e:  # noqa: BLE001
         bad += 1
