@@ -322,6 +322,8 @@ def main():
     ap.add_argument("--no-rccl", action="store_true", help="N = 1 only: do not create the single-rank RCCL group")
     ap.add_argument("--backward", default="auto", choices=["auto", "two_pass", "fused", "chunked"])
     ap.add_argument("--group-lanes", type=int, default=0, help="run the group kernels (lanes per trajectory) in the headline leg")
+    ap.add_argument("--strong-global", type=int, nargs="*", default=None,
+                    help="global batch sizes of the strong-scaling legs (default: 4096 65536)")
     ap.add_argument("--test-hostsim", action="store_true",
                     help="TESTS ONLY: gloo + the host simulation of the kernels on CPU, to exercise the launcher / N > 1 "
                          "plumbing without a GPU; its numbers mean nothing")
@@ -423,7 +425,7 @@ def main():
     strong = None
     if not args.no_extra:  # every rank takes part (collective timing)
         strong = strong_scaling_legs(pkg, T, dtype, device, rank, world, dist, barrier, max(K // 5, 2), lib=lib,
-                                     globals_=(4096, 65536) if not args.test_hostsim else (8,))
+                                     globals_=tuple(args.strong_global) if args.strong_global else ((4096, 65536) if not args.test_hostsim else (8,)))
 
     if rank != 0:
         if dist is not None:

@@ -502,11 +502,11 @@ def case_em_quadrotor(T=20, n_detail=2, n_total=8):
     save("em_quadrotor_T20", out)
 
 
-def case_mpc_quadrotor():
+def case_mpc_quadrotor(name="mpc_quadrotor_fb", H=10, steps=15, warm=10):
     """mpc_quad.py:538-650 (i2c, feedback, low noise) on the analytic quadrotor: tracking a moving target."""
     from i2c.policy.mpc import PartiallyObservedMpcPolicy
 
-    H, steps, n_iter, warm = 10, 15, 2, 10
+    n_iter = 2
     rng = np.random.default_rng(9)
     model = _reference_quadrotor()
     model.sig_zeta = np.diag([1e-6] * 8)
@@ -532,7 +532,7 @@ def case_mpc_quadrotor():
     g.calibrate_alpha()
     out["alpha_cal2"] = np.array(g.alpha)
     _mpc_loop(policy, model, steps, out, rng)
-    save("mpc_quadrotor_fb", out)
+    save(name, out)
 
 
 def _reference_quad12():
@@ -662,11 +662,11 @@ def case_em_dcp_nondiag(T=30, n_detail=2, n_total=6):
     save("em_dcp_nondiag_T30", out)
 
 
-def case_mpc_quad12(rule=None, name="mpc_quad12_fb", **meta):
+def case_mpc_quad12(rule=None, name="mpc_quad12_fb", H=8, steps=10, warm=6, **meta):
     """mpc_quad.py:538-650 (i2c, feedback, low noise) on the 12-state quadrotor: tracking a moving position target."""
     from i2c.policy.mpc import PartiallyObservedMpcPolicy
 
-    H, steps, n_iter, warm = 8, 10, 2, 6
+    n_iter = 2
     rng = np.random.default_rng(14)
     model = _reference_quad12()
     model.sig_zeta = 1e-6 * np.eye(9)
@@ -693,6 +693,17 @@ def case_mpc_quad12(rule=None, name="mpc_quad12_fb", **meta):
     out["alpha_cal2"] = np.array(g.alpha)
     _mpc_loop(policy, model, steps, out, rng)
     save(name, out)
+
+
+def case_mpc_quad12_H50():
+    """BASELINE config 4's full horizon (H = 50, mpc_iter = 2 as in mpc_quad.py:559) through the reference's own
+    PartiallyObservedMpcPolicy: four control steps after a four-iteration warm start (minutes of reference time)."""
+    case_mpc_quad12(None, "mpc_quad12_fb_H50", H=50, steps=4, warm=4)
+
+
+def case_mpc_quadrotor_H50():
+    """The planar quadrotor (the reference's actual config-4 model class, mpc_quad.py:219-383) at the full horizon."""
+    case_mpc_quadrotor(name="mpc_quadrotor_fb_H50", H=50, steps=4, warm=4)
 
 
 def case_mpc_quad12_linearize():
@@ -1122,6 +1133,8 @@ CASES = {
     "em_quad12_pf": case_em_quad12_propagate,
     "mpc_quad12": case_mpc_quad12,
     "mpc_quad12_lin": case_mpc_quad12_linearize,
+    "mpc_quad12_H50": case_mpc_quad12_H50,
+    "mpc_quad_H50": case_mpc_quadrotor_H50,
     "em_quad12_nondiag": case_em_quad12_nondiag,
     "em_dcp_nondiag": case_em_dcp_nondiag,
     "rollouts": case_rollouts,

@@ -32,6 +32,17 @@ def test_bench_self_launches_two_ranks():
     assert "TEST MODE" in out["data"]
 
 
+def test_bench_self_launches_eight_ranks_ragged():
+    """The N = 8 launcher path of the driver's scaling run (no 8-GPU lease has been available to measure it): eight gloo ranks on
+    the host simulation, a global strong-scaling batch that does not divide by 8 (4099 = 3 x 513 + 5 x 512)."""
+    out = _run(["--gpus", "8", "--test-hostsim", "--batch", "3", "--horizon", "8", "--steps", "2", "--warmup", "1", "--strong-global", "4099"])
+    assert out["n_gpus"] == 8 and out["rccl_world_size"] == 8 and out["scaling"] == "weak"
+    assert out["config"]["batch_per_gpu"] == 3 and "global batch 24" in out["config"]["workload"]
+    leg = out["strong_scaling"][0]
+    assert leg["global_batch"] == 4099 and leg["batch_per_gpu"] == 513 and leg["scaling"] == "strong" and leg["value"] > 0
+    assert out["final_allgather_ms"] is not None and out["failed_trajectories"] == 0
+
+
 def test_bench_single_process_contract():
     out = _run(["--test-hostsim", "--batch", "5", "--horizon", "10", "--steps", "2", "--warmup", "1", "--no-extra"])
     assert out["n_gpus"] == 1 and out["final_allgather_ms"] is None and out["strong_scaling"] is None

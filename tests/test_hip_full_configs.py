@@ -147,8 +147,9 @@ def test_config4_quadrotor12_sweeps_H50_vs_oracle(lanes, B):
 def test_config4_quadrotor12_mpc_H50(B):
     """... and the closed MPC loop with the cubature-KF state estimator on it: horizon 50, 8192 loops at once (or one GPU's
     share, 1024; one i2c_mpc_step per control step: filter, sweeps, first action, ring shift), lane 0 against a single loop.
-    NB a property check of the batched loop against the B = 1 loop of the SAME kernels (wave sweeps, group filter); the oracle
-    comparisons of this config are the sweeps above and the reference's own MPC replay mpc_quad12_fb (tests/test_mpc.py)."""
+    NB a property check of the batched loop against the B = 1 loop (planted duplicates bit-identical, lane 0 against a single loop).
+    The REFERENCE comparison of this loop at the full horizon and both batch sizes is
+    tests/test_mpc.py::test_mpc_replay_full_horizon_batched_gpu (fixture mpc_quad12_fb_H50, the reference's own policy class)."""
     from i2c.exp_types import CubatureQuadrature
     from i2c.i2c import I2cGraph
     from i2c.policy.mpc import PartiallyObservedMpcPolicy
@@ -182,7 +183,8 @@ def test_config4_quadrotor12_mpc_H50(B):
         uB = pB(t, y, u)
         u1 = p1(t, y[:1], u[:1])
         assert uB.shape == (B, 4) and np.all(np.isfinite(uB))
-        assert_close(uB[0], u1[:, 0], 1e-9, f"lane 0 of the batch vs the single loop, step {t}")
+        # (B >= 2048: the batch runs the quad forward kernel, the single loop the wave kernels: equal to rounding, not to the bit)
+        assert_close(uB[0], u1[:, 0], 1e-8, f"lane 0 of the batch vs the single loop, step {t}")
         assert np.array_equal(uB[0], uB[B // 2 - 96]) and np.array_equal(uB[0], uB[B - 1])
         u = np.clip(uB, 0.0, model.force_mx)
         y = model.measure(model.dynamics(np.hstack((pB.mu, u))))

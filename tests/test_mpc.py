@@ -94,6 +94,76 @@ def test_mpc_replay_quad_forward_gpu(name):
     assert pol.engine.forward_family == "quad"
 
 
+# BASELINE config 4 at its FULL horizon (H = 50, two EM iterations per control step, mpc_quad.py:559), pinned to the reference's own
+# PartiallyObservedMpcPolicy (oracle/gen_golden.py: mpc_quad12_H50, mpc_quad_H50): the single loop, and a batch of closed loops
+# whose lane 0 carries the reference's problem (the batch runs the one-call control step i2c_mpc_step; at B >= 2048 the 12-state
+# model's forward sweeps are the quad kernel's)
+@pytest.mark.parametrize("name", ["mpc_quad12_fb_H50", "mpc_quadrotor_fb_H50"])
+def test_mpc_replay_full_horizon_cpu(name):
+    _replay(name, hostsim.load(), "cpu", 1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,lanes", [("mpc_quad12_fb_H50", 0), ("mpc_quad12_fb_H50", 16), ("mpc_quadrotor_fb_H50", 0), ("mpc_quadrotor_fb_H50", -1)])
+def test_mpc_replay_full_horizon_gpu(name, lanes):
+    _replay(name, None, "cuda", 1e-6, group_lanes=lanes)
+
+
+def _replay_batched(name, lib, device, tol, B, group_lanes=0):
+    """B closed loops at once, lane 0 = the reference's problem (its measurement stream from the fixture), the other lanes
+    perturbed copies driven by their own simulated plants: lane 0's belief / control / temperature against the fixture."""
+    g = load_case(name)
+    meta = g.meta
+    model = parity.product_model(g)
+    model.sig_zeta = g["sig_zeta"]
+    rng = np.random.default_rng(3)
+    nx, nu = model.dim_x, model.dim_u
+    x0 = np.tile(np.asarray(model.x0, float).reshape(1, -1), (B, 1)) + 1e-3 * rng.normal(size=(B, nx))
+    x0[0] = np.asarray(model.x0, float).reshape(-1)
+    i2c = I2cGraph(model, meta["T"], g.get("Q"), g["R"], g.get("Qf"), meta["alpha"], meta["tol"], g["mu_u"], g["sig_u"], None, None,
+                   _rule_of(meta), lib=lib, device=device, batch=B, x0=x0, group_lanes=group_lanes)
+    i2c._propagate = True
+    pol = PartiallyObservedMpcPolicy(i2c, meta["n_iter"], g["sig_u"], np.copy(g["z_traj"]))
+    pol.set_control(feedforward=meta["feedforward"])
+    e = i2c.engine
+    i2c.calibrate_alpha()
+    assert_close(parity.np_(e.alpha)[0], g["alpha_cal1"], tol, "first alpha calibration, lane 0")
+    pol.optimize(meta["warm"])
+    i2c.calibrate_alpha()
+    assert_close(parity.np_(e.alpha)[0], g["alpha_cal2"], tol, "second alpha calibration, lane 0")
+    lo, hi = model.xu_lim[0, nx:], model.xu_lim[1, nx:]
+    x = x0.copy()
+    y = model.measure(x)
+    u = np.zeros((B, nu))
+    for t in range(meta["steps"]):
+        y[0], u[0] = g["y"][t], g["u_prev"][t]
+        ub = np.clip(pol(t, y, u), lo, hi)
+        assert ub.shape == (B, nu) and np.all(np.isfinite(ub))
+        assert_close(pol.mu[0], g["mu"][t], tol, f"{name} B={B} belief mean of lane 0, step {t}")
+        assert_close(pol.covar[0], g["covar"][t], tol * 10, f"{name} B={B} belief covariance of lane 0, step {t}")
+        assert_close(ub[0], g["ctrl"][t], tol * 10, f"{name} B={B} control of lane 0, step {t}")
+        assert_close(parity.np_(e.alpha)[0], g["alpha_steps"][t], tol, f"{name} B={B} alpha of lane 0, step {t}")
+        u = ub
+        x = model.dynamics(np.hstack((x, u)))  # the other lanes' plants (noise-free)
+        y = model.measure(x)
+    assert e.failures() == [] and e.t0 == meta["steps"] % meta["T"]
+    return pol
+
+
+def test_mpc_replay_full_horizon_batched_cpu():
+    pol = _replay_batched("mpc_quadrotor_fb_H50", hostsim.load(), "cpu", 1e-7, 5)
+    assert pol.engine.forward_family == "quad"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B,fam", [("mpc_quad12_fb_H50", 8192, "quad"), ("mpc_quad12_fb_H50", 1024, "wave"), ("mpc_quadrotor_fb_H50", 8192, "quad"),
+                                        ("mpc_quadrotor_fb_H50", 1024, "quad")])
+def test_mpc_replay_full_horizon_batched_gpu(name, B, fam):
+    """BASELINE config 4's shapes (B = 8192: the whole config on one GPU; 1024: one GPU's share of it), against the reference."""
+    pol = _replay_batched(name, None, "cuda", 1e-6, B)
+    assert pol.engine.forward_family == fam
+
+
 # mpc_quad12_fb above runs the 12-state quadrotor's default, the wave kernels; the same replay on its group kernels
 def test_mpc_replay_quad12_group_kernels_cpu():
     pol = _replay("mpc_quad12_fb", hostsim.load(), "cpu", 1e-7, group_lanes=16)

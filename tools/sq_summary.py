@@ -32,6 +32,17 @@ def main():
                 c.replace("SQ_", "").lower(): raw[c] / wc
                 for c in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA",
                           "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_MISC") if c in raw}
+        if w and wc and "SQ_INSTS_VALU_MFMA_MOPS_F64" in raw and "SQ_INSTS_VALU" in raw:
+            # what the SIMD's fp64 pipe is asked to do: 4 clocks per vector instruction of a wave64, 16 clocks per 512-flop unit
+            # of an fp64 matrix instruction (measured: tools/micro/mfma_f64.hip, mfma_f64_4x4.hip), against the wave's clocks
+            mfma, mops = raw.get("SQ_INSTS_MFMA", 0.0) / w, raw["SQ_INSTS_VALU_MFMA_MOPS_F64"] / w
+            valu = raw["SQ_INSTS_VALU"] / w - mfma
+            clocks = 4 * wc / w
+            flops_lane = (2 * raw.get("SQ_INSTS_VALU_FMA_F64", 0.0) + raw.get("SQ_INSTS_VALU_ADD_F64", 0.0) + raw.get("SQ_INSTS_VALU_MUL_F64", 0.0)) / w
+            e["issue"] = {"vector_insts_per_wave": valu, "mfma_insts_per_wave": mfma, "mfma_512flop_units_per_wave": mops,
+                          "fp64_pipe_clocks_per_wave": 4 * valu + 16 * mops, "wave_clocks": clocks,
+                          "fp64_issue_frac": (4 * valu + 16 * mops) / clocks, "waves": w, "simds_occupied": min(1.0, w / 1024.0),
+                          "fp64_vector_flops_per_lane_per_wave": flops_lane, "mfma_flops_per_wave": 512 * mops}
         out["kernels"][k] = e
     path = f"profiles/{tag}_sq_counters.json"
     json.dump(out, open(path, "w"), indent=1)
