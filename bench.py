@@ -125,7 +125,7 @@ def algorithmic_elements(d, nx, nu):
 
 def measured_traffic(B, T, dtype, kernel):
     """HBM bytes per launch from the committed PMC passes (tools/pmc_summary.py), if one matches."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_B{B}_pmc_traffic.json") for r in (3, 2, 1)) if os.path.exists(q)),
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_B{B}_pmc_traffic.json") for r in (4, 3, 2, 1)) if os.path.exists(q)),
                 os.path.join(ROOT, "profiles", f"r1_B{B}_pmc_traffic.json"))
     if not os.path.exists(path):
         return None
@@ -133,6 +133,38 @@ def measured_traffic(B, T, dtype, kernel):
     if (d["B"], d["T"], d.get("dtype", "f64")) != (B, T, dtype) or kernel not in d["kernels"]:
         return None
     return d["kernels"][kernel]["hbm_bytes_per_launch"]
+
+
+FP64_PEAK_TFLOPS = 78.6  # MI355X vector / matrix fp64: 1024 SIMDs x 16 FMA lanes x 2 flop x 2.4 GHz (the matrix rate is the same:
+#                          one v_mfma_f64_16x16x4 = 2048 flop in 64 clocks, measured, tools/micro/mfma_f64.hip)
+
+
+def issue_roofline(profile, kernel_prefix, cells_per_wave, lanes_per_trajectory, kernel_ms, cells):
+    """The instruction-issue side of a kernel that is NOT memory-bound, from the committed SQ counter passes
+    (tools/sq_counters.sh -> profiles/<profile>_sq_counters.json): how busy the SIMD's fp64 pipe is while a wave is resident
+    (4 clocks per vector instruction of a wave64, 16 clocks per 512-flop unit of an fp64 matrix instruction), how many of the chip's
+    1024 SIMDs hold a wave at all, and the executed fp64 flops against the chip's peak at the live kernel time."""
+    path = os.path.join(ROOT, "profiles", profile + "_sq_counters.json")
+    if not os.path.exists(path):
+        return None
+    ks = json.load(open(path))["kernels"]
+    k = next((v for name, v in ks.items() if name.startswith(kernel_prefix) and "issue" in v), None)
+    if k is None:
+        return None
+    i = k["issue"]
+    flops_cell = (i["fp64_vector_flops_per_lane_per_wave"] * lanes_per_trajectory + i["mfma_flops_per_wave"] / (64 // lanes_per_trajectory)) / cells_per_wave
+    return {
+        "source": "profiles/" + profile + "_sq_counters.json",
+        "vector_insts_per_cell": i["vector_insts_per_wave"] / cells_per_wave,
+        "mfma_insts_per_cell": i["mfma_insts_per_wave"] / cells_per_wave,
+        "wave_clocks_per_cell": i["wave_clocks"] / cells_per_wave,
+        "fp64_issue_frac": i["fp64_issue_frac"],
+        "simds_occupied": i["simds_occupied"],
+        "useful_flops_per_cell": flops_cell,
+        "useful_flops_note": "executed fp64 flops per trajectory-cell (2 x fma + add + mul of the lanes that own the trajectory, + matrix-instruction flops); the lane kernels compute nothing redundantly",
+        "frac_of_fp64_peak": flops_cell * cells / (kernel_ms * 1e-3) / (FP64_PEAK_TFLOPS * 1e12),
+        "peak_TFLOPs": FP64_PEAK_TFLOPS,
+    }
 
 
 def cpu_baseline(T):
@@ -224,10 +256,20 @@ def extra_config_legs(pkg, device, K=10):
     eng.learn(2)
     sync(); t0 = time.perf_counter(); eng.learn(K); sync()
     ms = (time.perf_counter() - t0) / K * 1e3
+    gb = _gbps(eng, B, T, ms)
     out["double_cartpole_T300_B4096"] = {"ms_per_step": ms, "value": B * T / ms * 1e3, "unit": "timestep-messages/s",
-                                         "algorithmic_GBps": _gbps(eng, B, T, ms), "backward": eng.backward_schedule,
+                                         "algorithmic_GBps": gb, "frac_of_hbm_peak": gb / HBM_PEAK_GBS, "backward": eng.backward_schedule,
                                          "forward_family": eng.forward_family, "backward_family": eng.backward_family,
                                          "failed_trajectories": len(eng.failures())}
+    # its forward sweep alone (the quad kernel), for the issue-side roofline: event-timed
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    sync(); evs[0].record()
+    for _ in range(5):
+        eng.forward_sweep()
+    evs[1].record(); sync()
+    fwd_ms = evs[0].elapsed_time(evs[1]) / 5
+    out["double_cartpole_T300_B4096"]["forward_sweep_ms"] = fwd_ms
+    out["double_cartpole_T300_B4096"]["issue"] = issue_roofline("r4_dcp_B4096", "k_quad_forward", T, 16, fwd_ms, B * T)
     del eng
 
     # the d >= 7 models at a batch that fills the chip (EM iteration = forward + backward + M-step, one i2c_learn call):
@@ -278,11 +320,42 @@ def extra_config_legs(pkg, device, K=10):
             act, _ = eng.mpc_step(n_iter, y, u, sig_zeta)
         sync()
         ms = (time.perf_counter() - t0) / K * 1e3
+        gb = _gbps(eng, B, T * n_iter, ms)
         out["quadrotor12_mpc_H50_B%d" % B] = {"ms_per_control_step": ms, "closed_loop_steps_per_s": B / ms * 1e3, "em_iters_per_step": n_iter,
                                               "value": B * T * n_iter / ms * 1e3, "unit": "timestep-messages/s",
-                                              "algorithmic_GBps": _gbps(eng, B, T * n_iter, ms),
+                                              "algorithmic_GBps": gb, "frac_of_hbm_peak": gb / HBM_PEAK_GBS,
                                               "forward_family": eng.forward_family, "backward_family": eng.backward_family,
                                               "failed_trajectories": len(eng.failures())}
+        del eng
+
+    # config 4 on the reference's ACTUAL model class, the planar quadrotor (mpc_quad.py:219-383: nx = 6, nu = 2, identity observation),
+    # same loop: B = 8192 and one GPU's share of it
+    m = make_env_model("PlanarQuadrotor")
+    for B in (8192, 1024):
+        T, n_iter = 50, 2
+        Q, R = np.diag([1e3, 1e3, 1e3, 1, 1, 1]) / 1e3, np.diag([1e-3, 1e-3])
+        x0 = np.asarray(m.x0, float).reshape(1, -1) + 1e-2 * rng.normal(size=(B, 6))
+        mu_u = 0.5 * m.gravity + 1e-2 * rng.normal(size=(B, T, 2))
+        eng = pkg.BatchedI2c(m, T, Q, R, Q / 1e3, 1.0, 1.0, mu_u, 1e-2 * np.eye(2), x0=x0, device=device, keep_zpost=False, keep_xm=False,
+                             z_traj=np.broadcast_to(np.concatenate((np.asarray(m.x0, float).reshape(-1), 0.5 * m.gravity * np.ones(2))), (T, 8)))
+        eng.tau = T - 1
+        eng.enable_per_cell_alpha()
+        sig_zeta = 1e-4 * np.eye(8)
+        y = torch.as_tensor(np.ascontiguousarray(m.measure(x0).T), dtype=torch.float64, device=device)
+        u = torch.as_tensor(np.ascontiguousarray(mu_u[:, 0, :].T), dtype=torch.float64, device=device)
+        for _ in range(2):
+            act, _ = eng.mpc_step(n_iter, y, u, sig_zeta)
+        sync(); t0 = time.perf_counter()
+        for _ in range(K):
+            act, _ = eng.mpc_step(n_iter, y, u, sig_zeta)
+        sync()
+        ms = (time.perf_counter() - t0) / K * 1e3
+        gb = _gbps(eng, B, T * n_iter, ms)
+        out["planar_quadrotor_mpc_H50_B%d" % B] = {"ms_per_control_step": ms, "closed_loop_steps_per_s": B / ms * 1e3, "em_iters_per_step": n_iter,
+                                                   "value": B * T * n_iter / ms * 1e3, "unit": "timestep-messages/s",
+                                                   "algorithmic_GBps": gb, "frac_of_hbm_peak": gb / HBM_PEAK_GBS,
+                                                   "forward_family": eng.forward_family, "backward_family": eng.backward_family,
+                                                   "failed_trajectories": len(eng.failures())}
         del eng
 
     # config 5: nonlinear covariance control (pendulum, action-only cost, annealed terminal prior, closed-loop propagation
@@ -302,7 +375,9 @@ def extra_config_legs(pkg, device, K=10):
         eng.learn_msgs()
     sync()
     ms = (time.perf_counter() - t0) / K * 1e3
+    gb = (_gbps(eng, B, T, ms) + eng.dims.e_prop * 8 * B * T / (ms * 1e-3) / 1e9)  # + the propagation rows written each iteration
     out["covariance_control_T100_B8192"] = {"ms_per_step": ms, "value": B * T / ms * 1e3, "unit": "timestep-messages/s",
+                                            "algorithmic_GBps": gb, "frac_of_hbm_peak": gb / HBM_PEAK_GBS,
                                             "includes": "forward, backward, closed-loop propagation, KL, M-step",
                                             "failed_trajectories": len(eng.failures())}
     return out
@@ -362,14 +437,18 @@ def main():
 
         import torch.distributed as dist
 
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        try:
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
-        except Exception as e:  # the measurement must not die with the collective library: say so in the line instead
-            rccl_error = f"{type(e).__name__}: {e}"
+        for attempt in range(3):  # (the port is picked by bind-then-close: another job may take it in between -- try again)
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            try:
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
+                rccl_error = None
+                break
+            except Exception as e:  # the measurement must not die with the collective library: say so in the line instead
+                rccl_error = f"{type(e).__name__}: {e}"
+        if rccl_error is not None:
             dist = None
 
     pkg = importlib.import_module(PKG)
@@ -479,10 +558,12 @@ def main():
                             + str(fwd_bytes),
             "algorithmic_bytes_per_cell": {k: v * wbytes for k, v in el.items()},
             "whole_iteration_GBps": el["total"] * wbytes * B * T / (elapsed / K) / 1e9,
-            "note": "instruction-issue-bound at B=4096 per GPU: 64 lone wavefronts (1024 SIMDs), each issuing ~88 % of its cycles "
-                    "(profiles/r1_k_forward_sq_counters.json); spreading a trajectory over 4 lanes (group kernels) is SLOWER for "
-                    "this model (profiles/r2_pendulum_lane_vs_group_sq_counters.json); HBM-bound from B ~ 32768 (saturated_batch); "
-                    "see DESIGN.md section 6",
+            "issue": issue_roofline("r4_pendulum_B4096", "k_forward", T, 1, fwd_ms, B * T) if (B, T) == (4096, 200) else None,
+            "note": "instruction-issue-bound at B=4096 per GPU: 64 lone wavefronts (1024 SIMDs), each issuing 88 % of its cycles "
+                    "(profiles/r4_pendulum_B4096_sq_counters.json, r3_pendulum_B4096_chunked_sq_summary.txt; `issue`: what the fp64 "
+                    "pipe of an occupied SIMD is doing); spreading a trajectory over lanes is SLOWER for this 3-dimensional model "
+                    "(group kernels: profiles/r2_pendulum_lane_vs_group_sq_counters.json; quad kernel, 4 x 4 blocks on the matrix "
+                    "instruction: profiles/r4_quad_forward_timings_v3.txt); HBM-bound from B ~ 32768 (saturated_batch); DESIGN.md 6",
         },
         "final_allgather_ms": allgather_ms,
         "strong_scaling": strong,
