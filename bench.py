@@ -139,7 +139,7 @@ FP64_PEAK_TFLOPS = 78.6  # MI355X vector / matrix fp64: 1024 SIMDs x 16 FMA lane
 #                          one v_mfma_f64_16x16x4 = 2048 flop in 64 clocks, measured, tools/micro/mfma_f64.hip)
 
 
-def issue_roofline(profile, kernel_prefix, cells_per_wave, lanes_per_trajectory, kernel_ms, cells):
+def issue_roofline(profile, kernel_prefix, cells_per_wave, lanes_per_trajectory, kernel_ms, cells, useful=None):
     """The instruction-issue side of a kernel that is NOT memory-bound, from the committed SQ counter passes
     (tools/sq_counters.sh -> profiles/<profile>_sq_counters.json): how busy the SIMD's fp64 pipe is while a wave is resident
     (4 clocks per vector instruction of a wave64, 16 clocks per 512-flop unit of an fp64 matrix instruction), how many of the chip's
@@ -153,6 +153,12 @@ def issue_roofline(profile, kernel_prefix, cells_per_wave, lanes_per_trajectory,
         return None
     i = k["issue"]
     flops_cell = (i["fp64_vector_flops_per_lane_per_wave"] * lanes_per_trajectory + i["mfma_flops_per_wave"] / (64 // lanes_per_trajectory)) / cells_per_wave
+    executed = flops_cell
+    if useful is not None:  # a multi-lane kernel repeats work on the lanes of a trajectory: the USEFUL count is the one-lane kernel's
+        up = os.path.join(ROOT, "profiles", useful[0] + "_sq_counters.json")
+        uk = next((v for name, v in (json.load(open(up))["kernels"] if os.path.exists(up) else {}).items() if name.startswith(useful[1]) and "issue" in v), None)
+        if uk is not None:
+            flops_cell = uk["issue"]["fp64_vector_flops_per_lane_per_wave"] / cells_per_wave
     return {
         "source": "profiles/" + profile + "_sq_counters.json",
         "vector_insts_per_cell": i["vector_insts_per_wave"] / cells_per_wave,
@@ -161,7 +167,10 @@ def issue_roofline(profile, kernel_prefix, cells_per_wave, lanes_per_trajectory,
         "fp64_issue_frac": i["fp64_issue_frac"],
         "simds_occupied": i["simds_occupied"],
         "useful_flops_per_cell": flops_cell,
-        "useful_flops_note": "executed fp64 flops per trajectory-cell (2 x fma + add + mul of the lanes that own the trajectory, + matrix-instruction flops); the lane kernels compute nothing redundantly",
+        "executed_flops_per_cell": executed,
+        "useful_flops_note": "fp64 flops per trajectory-cell (2 x fma + add + mul, + matrix-instruction flops). useful = what the one-lane-per-"
+                             "trajectory kernel of the same model executes (nothing redundant); executed = this kernel, all lanes of the "
+                             "trajectory (a multi-lane kernel repeats the pivot algebra on its sixteen lanes and multiplies zero padding)",
         "frac_of_fp64_peak": flops_cell * cells / (kernel_ms * 1e-3) / (FP64_PEAK_TFLOPS * 1e12),
         "peak_TFLOPs": FP64_PEAK_TFLOPS,
     }
@@ -269,7 +278,7 @@ def extra_config_legs(pkg, device, K=10):
     evs[1].record(); sync()
     fwd_ms = evs[0].elapsed_time(evs[1]) / 5
     out["double_cartpole_T300_B4096"]["forward_sweep_ms"] = fwd_ms
-    out["double_cartpole_T300_B4096"]["issue"] = issue_roofline("r4_dcp_B4096", "k_quad_forward", T, 16, fwd_ms, B * T)
+    out["double_cartpole_T300_B4096"]["issue"] = issue_roofline("r4_dcp_B4096", "k_quad_forward", T, 16, fwd_ms, B * T, useful=("r4_dcp_B4096_group_and_lane", "k_forward"))
     del eng
 
     # the d >= 7 models at a batch that fills the chip (EM iteration = forward + backward + M-step, one i2c_learn call):

@@ -546,6 +546,13 @@ template <class M, typename R, typename S = R> struct Impl {
     if (p->inference != I2C_INF_CUBATURE && !(p->inference == I2C_INF_LINEARIZE && sweep == I2C_SWEEP_PROPAGATE)) return I2C_ENOTSUP;
     constexpr long EMAX = C::E_FWD > C::E_POST ? (C::E_FWD > C::E_PROP ? C::E_FWD : C::E_PROP) : (C::E_POST > C::E_PROP ? C::E_POST : C::E_PROP);
     if (EMAX * (long)p->B * (long)sizeof(R) >= (1L << 31)) return I2C_EINVAL;
+    return window_32bit_ok(p);
+  }
+  // per-cell targets [T][NZ][B] and temperatures [T][B] are addressed through 32-bit byte offsets of one buffer window by the
+  // group, wave and quad kernels: beyond 4 GiB the offset would wrap and read the wrong cell (round-3 advice)
+  static int window_32bit_ok(const I2cProblem* p) {
+    if (p->z_per_cell && p->z && (long)p->T * C::NZ * (long)p->B * (long)sizeof(R) >= (1L << 32)) return I2C_EINVAL;
+    if (p->alpha_cell && (long)p->T * (long)p->B * (long)sizeof(R) >= (1L << 32)) return I2C_EINVAL;
     return I2C_OK;
   }
   // THE place that decides which kernel family serves a sweep (i2c_kernel_family() reports it): I2C_FAMILY_* or an error code.
@@ -566,7 +573,7 @@ template <class M, typename R, typename S = R> struct Impl {
     if (!c.rule_xu.unit || !c.rule_x.unit || c.rule_xu.w0 != R(0) || c.rule_x.w0 != R(0)) return I2C_ENOTSUP;
     constexpr long EMAX = C::E_FWD > C::E_POST ? C::E_FWD : C::E_POST;
     if (EMAX * (long)p->B * (long)sizeof(S) >= (1L << 31)) return I2C_EINVAL;
-    return I2C_OK;
+    return window_32bit_ok(p);
   }
   // what the quad form (forward sweep) covers: the cubature rule with lam = 0 (unit weights, no weight on the centre: the centring
   // of the pairwise sums relies on 2 d wi = 1, and the d = 8 models evaluate no centre point at all), windows below 2 GiB
@@ -586,9 +593,7 @@ template <class M, typename R, typename S = R> struct Impl {
     }
     constexpr long EMAX = C::E_FWD > C::E_POST ? C::E_FWD : C::E_POST;
     if (EMAX * (long)p->B * (long)sizeof(S) >= (1L << 31)) return I2C_EINVAL;
-    if (c.z_per_cell && (long)p->T * C::NZ * (long)p->B * (long)sizeof(R) >= (1L << 32)) return I2C_EINVAL;
-    if (p->alpha_cell && (long)p->T * (long)p->B * (long)sizeof(R) >= (1L << 32)) return I2C_EINVAL;
-    return I2C_OK;
+    return window_32bit_ok(p);
   }
   static int family(const I2cProblem* p, const C& c, const int sweep) {
     if constexpr (HAS_QUAD) {  // forward sweep: on request, or the model's default inside its batch window
@@ -975,6 +980,11 @@ template <class M, typename R, typename S = R> struct Impl {
   static int propagate(const I2cProblem* p, const void* post, void* prop, void* prop_stats, int use_expert,
                        int32_t* status, void* stream) {
     if constexpr (MIXED) return I2C_ENOTSUP;
+    // under Linearize() the closed-loop propagation IS CubatureQuadrature(1, 0, 0) whatever the caller left in the quad fields
+    // (i2c.py:109-115), like the state estimator's rule (filter_problem)
+    I2cProblem q = *p;
+    if (p->inference == I2C_INF_LINEARIZE) q.quad_alpha = 1.0, q.quad_beta = 0.0, q.quad_kappa = 0.0;
+    p = &q;
     const C c = make_consts<M, R>(p, 0.0, use_expert);
     PropArgs<R> a{(const R*)post, (R*)prop, (R*)prop_stats, (const R*)p->x0, (const R*)p->sig_x0,
                   (const R*)p->z, p->feedforward, status, p->expert};

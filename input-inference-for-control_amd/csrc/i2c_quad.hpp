@@ -243,7 +243,9 @@ template <int NL, typename R, class P> I2C_FN void q_pivot_algebra(const Quad<R>
 }
 // scale block row K by the inverse pivot factor (aw): rows of L^T (the diagonal block masked to its upper triangle: what is left
 // of it is rounding noise) and of every right-hand side ...
-template <int K, int NB, int NC1, int NC2, typename R> I2C_FN void q_elim_scale(const Quad<R>& q, const R aw, R* s, R* r1, R* r2, R* lt) {
+// R2LOW: the second right-hand side starts as the identity (NC2 = NB): L^-1 I is block lower triangular, its blocks right of the
+// diagonal stay zero and are skipped
+template <int K, int NB, int NC1, int NC2, bool R2LOW = false, typename R> I2C_FN void q_elim_scale(const Quad<R>& q, const R aw, R* s, R* r1, R* r2, R* lt) {
 #pragma unroll
   for (int j = K; j < NB; ++j) {
     R x = R(0);
@@ -258,13 +260,14 @@ template <int K, int NB, int NC1, int NC2, typename R> I2C_FN void q_elim_scale(
   }
 #pragma unroll
   for (int j = 0; j < NC2; ++j) {
+    if (R2LOW && j > K) continue;
     R x = R(0);
     q_mfma(q, aw, r2[K * NC2 + j], x);
     r2[K * NC2 + j] = x;
   }
 }
 // ... and eliminate it from everything below (the next pivot block first: it is what the next step waits for)
-template <int K, int NB, int NC1, int NC2, typename R> I2C_FN void q_elim_below(const Quad<R>& q, R* s, R* r1, R* r2, const R* lt) {
+template <int K, int NB, int NC1, int NC2, bool R2LOW = false, typename R> I2C_FN void q_elim_below(const Quad<R>& q, R* s, R* r1, R* r2, const R* lt) {
 #pragma unroll
   for (int i = K + 1; i < NB; ++i) {
     const R nl = -lt[K * NB + i];
@@ -273,14 +276,17 @@ template <int K, int NB, int NC1, int NC2, typename R> I2C_FN void q_elim_below(
 #pragma unroll
     for (int j = 0; j < NC1; ++j) q_mfma(q, nl, r1[K * NC1 + j], r1[i * NC1 + j]);
 #pragma unroll
-    for (int j = 0; j < NC2; ++j) q_mfma(q, nl, r2[K * NC2 + j], r2[i * NC2 + j]);
+    for (int j = 0; j < NC2; ++j) {
+      if (R2LOW && j > K) continue;
+      q_mfma(q, nl, r2[K * NC2 + j], r2[i * NC2 + j]);
+    }
   }
 }
-template <int K, int NB, int NC1, int NC2, typename R> I2C_FN void q_elim_apply(const Quad<R>& q, const R aw, R* s, R* r1, R* r2, R* lt) {
-  q_elim_scale<K, NB, NC1, NC2>(q, aw, s, r1, r2, lt);
-  q_elim_below<K, NB, NC1, NC2>(q, s, r1, r2, lt);
+template <int K, int NB, int NC1, int NC2, bool R2LOW = false, typename R> I2C_FN void q_elim_apply(const Quad<R>& q, const R aw, R* s, R* r1, R* r2, R* lt) {
+  q_elim_scale<K, NB, NC1, NC2, R2LOW>(q, aw, s, r1, r2, lt);
+  q_elim_below<K, NB, NC1, NC2, R2LOW>(q, s, r1, r2, lt);
 }
-template <int K, int NB, int N, int NC1, int NC2, typename R>
+template <int K, int NB, int N, int NC1, int NC2, bool R2LOW = false, typename R>
 I2C_FN void q_elim_step(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* last) {
   constexpr int NL = (N - 4 * K) >= 4 ? 4 : (N - 4 * K);
   const auto dg = q.sh + Q_O_DG;
@@ -290,12 +296,12 @@ I2C_FN void q_elim_step(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* last) {
   R aw, pl;
   q_pivot_algebra<NL>(q, dg, &aw, &pl);
   if (K == NB - 1) *last = pl;
-  q_elim_apply<K, NB, NC1, NC2>(q, aw, s, r1, r2, lt);
-  if constexpr (K + 1 < NB) q_elim_step<K + 1, NB, N, NC1, NC2>(q, s, r1, r2, lt, last);
+  q_elim_apply<K, NB, NC1, NC2, R2LOW>(q, aw, s, r1, r2, lt);
+  if constexpr (K + 1 < NB) q_elim_step<K + 1, NB, N, NC1, NC2, R2LOW>(q, s, r1, r2, lt, last);
 }
-template <int N, int NC1, int NC2, typename R> I2C_FN bool q_elim(const Quad<R>& q, R* s, R* r1, R* r2, R* lt) {
+template <int N, int NC1, int NC2, bool R2LOW = false, typename R> I2C_FN bool q_elim(const Quad<R>& q, R* s, R* r1, R* r2, R* lt) {
   R last = R(0);
-  q_elim_step<0, (N + 3) / 4, N, NC1, NC2>(q, s, r1, r2, lt, &last);
+  q_elim_step<0, (N + 3) / 4, N, NC1, NC2, R2LOW>(q, s, r1, r2, lt, &last);
   return last > R(0);
 }
 // two eliminations of the same dimension in lockstep: (sa; ra1, ra2) -> lta and (sb; rb1) -> ltb
@@ -312,9 +318,9 @@ I2C_FN void q_elim2_step(const Quad<R>& q, R* sa, R* ra1, R* ra2, R* lta, R* las
   q_pivot_algebra<NL>(q, dgb, &awb, &plb);
   if (K == NB - 1) *lasta = pla, *lastb = plb;
   // (interleaved: the scaled rows of one elimination are consumed after the other's independent instructions)
-  q_elim_scale<K, NB, NA1, NA2>(q, awa, sa, ra1, ra2, lta);
+  q_elim_scale<K, NB, NA1, NA2, true>(q, awa, sa, ra1, ra2, lta);  // (ra2 starts as the identity: see R2LOW)
   q_elim_scale<K, NB, NB1, 0>(q, awb, sb, rb1, (R*)nullptr, ltb);
-  q_elim_below<K, NB, NA1, NA2>(q, sa, ra1, ra2, lta);
+  q_elim_below<K, NB, NA1, NA2, true>(q, sa, ra1, ra2, lta);
   q_elim_below<K, NB, NB1, 0>(q, sb, rb1, (R*)nullptr, ltb);
   if constexpr (K + 1 < NB) q_elim2_step<K + 1, NB, N, NA1, NA2, NB1>(q, sa, ra1, ra2, lta, lasta, sb, rb1, ltb, lastb);
 }
@@ -494,7 +500,11 @@ I2C_FN bool q_kalman_identity(const Quad<R>& q, const R alpha, const P xi_m, con
       u[i * NB + j] = s[i * NB + j];
     }
   const bool ok = q_elim<N, NB, 0>(q, sz, u, (R*)nullptr, lt);
-  q_tn<NB, NB, NB, true>(q, u, u, s);
+  q_tn<NB, NB, NB, true, true>(q, u, u, s);  // the upper blocks, then their mirror images (a transpose instead of NB products each)
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < i; ++j) s[i * NB + j] = q_tr(q, s[j * NB + i]);
   // wr = W (zt - mu), row form
   R wr[NB];
   if (w_diag) {
@@ -947,7 +957,7 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
       for (int k = 0; k < NBX * NBX; ++k) tmp[k] = sx[k];
 #pragma unroll
       for (int k = 0; k < NBX * NBD; ++k) yj[k] = sxy[k];
-      cell_bad = flag_stage(cell_bad, q_elim<NX, NBD, NBX>(q, tmp, yj, w3, l3t), 4);
+      cell_bad = flag_stage(cell_bad, q_elim<NX, NBD, NBX, true>(q, tmp, yj, w3, l3t), 4);
       store_gain(t, w3, yj);
       j_pending = false;
       R ztT[NBT];
@@ -997,7 +1007,7 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
     for (int k = 0; k < NBX * NBX; ++k) tmp[k] = sx[k];
 #pragma unroll
     for (int k = 0; k < NBX * NBD; ++k) yj[k] = sxy[k];
-    fail = fold_cell_failure(fail, flag_stage(0, q_elim<NX, NBD, NBX>(q, tmp, yj, w3, l3t), 4), T - 1);
+    fail = fold_cell_failure(fail, flag_stage(0, q_elim<NX, NBD, NBX, true>(q, tmp, yj, w3, l3t), 4), T - 1);
     store_gain(T - 1, w3, yj);
   }
 #if defined(I2C_QUAD_STAMPS) && !defined(I2C_HOST_SIM)

@@ -56,7 +56,7 @@ class BatchedI2c:
                  mu_x_terminal=None, sig_x_terminal=None, quad=(1.0, 0.0, 0.0), x0=None, sig_x0=None,
                  z_traj=None, batch=None, dtype=torch.float64, device=None, lib=None, dtemp=1.0,
                  keep_zpost=True, keep_prior=False, keep_xm=True, backward_mode="auto", inference="cubature",
-                 gh_degree=None, group_lanes=0, storage_dtype=None, allow_inexact=False, keep_prior_joint=False):
+                 gh_degree=None, group_lanes=0, storage_dtype=None, allow_inexact=False, keep_prior_joint=False, post_layout=None):
         self.lib = lib if lib is not None else _native.load_library()
         if device is None:
             device = "cpu" if self.lib.is_host_sim else "cuda"
@@ -211,10 +211,13 @@ class BatchedI2c:
         # wave kernels the STORAGE is trajectory-major, [T][B][e_post] (a cell of a trajectory is contiguous: a wavefront, which
         # works on one trajectory, reads it as a few cache lines), and self.post is a permuted view of it, so every index
         # expression in this file and its callers is layout-blind; only the library (data_ptr) sees the difference.
-        layout = os.environ.get("I2C_POST_LAYOUT", "1")  # measurement knob (profiles/r3_quad12_post_layout_ab.txt)
-        if layout not in ("0", "1"):
-            raise ValueError(f"I2C_POST_LAYOUT={layout!r}: 0 ([T][e][B]) or 1 (trajectory-major, models with wave kernels)")
-        self.post_layout = int(layout) if dims.wave else 0
+        # post_layout: an explicit constructor argument (it is part of the ABI, I2cProblem.post_layout: callers handing raw pointers
+        # to the C API must know it); None = trajectory-major for the models with wave kernels, [T][e][B] for every other model
+        if post_layout is None:
+            post_layout = 1 if dims.wave else 0
+        if post_layout not in (0, 1) or (post_layout == 1 and not dims.wave):
+            raise ValueError(f"post_layout={post_layout!r}: 0 ([T][e][B]) or 1 (trajectory-major, models with wave kernels only)")
+        self.post_layout = int(post_layout)
         self.post = to(post).to(st)
         if self.post_layout == 1:
             self.post = self.post.permute(0, 2, 1).contiguous().permute(0, 2, 1)

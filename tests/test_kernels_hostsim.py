@@ -298,7 +298,7 @@ def test_hostsim_fused_em_loop_matches_stepwise(lib):
 
 def _post_layout_is_transparent(lib, device, monkeypatch):
     """The posterior / prior buffers of the wave-capable models are stored trajectory-major (I2cProblem.post_layout = 1); the
-    standard [T][e][B] layout stays available (I2C_POST_LAYOUT=0). Same arithmetic, different addressing: EM iterations on both
+    standard [T][e][B] layout stays available (post_layout=0). Same arithmetic, different addressing: EM iterations on both
     kernel families, closed-loop propagation, the MPC step with its ring shift, and policy rollouts must agree bit for bit."""
     import numpy as np
     import torch
@@ -308,9 +308,8 @@ def _post_layout_is_transparent(lib, device, monkeypatch):
     x0, mu_u = parity.batched_inputs(g, 5)
     runs = {}
     for layout in ("1", "0"):
-        monkeypatch.setenv("I2C_POST_LAYOUT", layout)
         for lanes in (0, 16):
-            e = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u, group_lanes=lanes)
+            e = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u, group_lanes=lanes, post_layout=int(layout))
             assert e.post_layout == int(layout) and e.post.shape == (g.meta["T"], e.dims.e_post, 5)
             assert e.post.stride()[1] == (1 if layout == "1" else 5)
             e.propagate()

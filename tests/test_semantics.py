@@ -260,3 +260,27 @@ def test_kernel_family_is_inspectable():
     assert gh.kernel_family("filter") == "group"
     with pytest.raises(RuntimeError, match="-2"):
         gh.kernel_family("propagate")
+
+
+def test_linearize_propagation_ignores_the_quadrature_fields():
+    """Under Linearize() the closed-loop propagation (and the plan cost) is CubatureQuadrature(1, 0, 0) whatever the caller's quad
+    fields hold (i2c.py:109-115, 841-844): the library pins the rule for that sweep, as it does for the state estimator
+    (round-3 advice: the group / lane propagation kernels took their weights from I2cProblem.quad_*)."""
+    import torch
+    from golden_util import load_case
+
+    g = load_case("lin_pendulum_T40_propagate")
+    lib = hostsim.load()
+    runs = []
+    for quad in ((1.0, 0.0, 0.0), (1.2, 0.44, 0.5)):
+        for lanes in (0, True):
+            e = parity.engine_from_case(g, lib, "cpu", quad=quad, group_lanes=lanes if lanes is not True else 0)
+            e.learn_msgs()
+            if lanes is True:  # the group kernels serve the propagation of a Linearize graph (not its sweeps)
+                e._problem.group_lanes = e.dims.group_lanes
+                assert e.kernel_family("propagate") == "group"
+            e.propagate()
+            assert e.failures() == []
+            runs.append((quad, lanes, e.prop.clone()))
+    assert torch.equal(runs[0][2], runs[2][2]), "lane kernels: the propagation depends on the quad fields"
+    assert torch.equal(runs[1][2], runs[3][2]), "group kernels: the propagation depends on the quad fields"
