@@ -96,6 +96,24 @@ template <typename R> I2C_FN void w_mfma(const Wave<R>& w, const R a, const R b,
   acc[3] = c[3];
 #endif
 }
+// One ROW BLOCK (4 x 16, a single accumulator register: lane (q, j) holds row q, column j) times a 4 x 4 matrix from the left, on
+// v_mfma_f64_4x4x4_4b_f64 (four independent 4 x 4 blocks, block n in lanes {16 k + 4 n + m}; tools/micro/mfma_f64_4x4.hip):
+//   returns A b  with  A[i][k] supplied by lane (k, .. , i) -- i.e. every lane (q, j) passes A[j & 3][q] -- and b the row block.
+// A quarter of the 64 clocks of the 16 x 16 x 4 instruction, whose tile would be 3/4 unused here (round-3 review).
+template <typename R> I2C_FN R w_mfma4(const Wave<R>& w, const R a, const R b) {
+#ifdef I2C_HOST_SIM
+  w.bar->wait();
+  w.xch[w.l] = a;
+  w.xch[64 + w.l] = b;
+  w.bar->wait();
+  const int i = w.l >> 4, n = (w.l >> 2) & 3, jj = w.l & 3;
+  R s = R(0);
+  for (int k = 0; k < 4; ++k) s = std::fma(w.xch[16 * k + 4 * n + i], w.xch[64 + 16 * k + 4 * n + jj], s);
+  return s;
+#else
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, 0.0, 0, 0, 0);
+#endif
+}
 // acc += X^T Y over the first KB row blocks of X and Y (both in the accumulator layout); NEG: acc -= X^T Y
 template <int KB, bool NEG = false, typename R> I2C_FN void w_tn(const Wave<R>& w, const R* x, const R* y, R* acc) {
 #pragma unroll
@@ -285,29 +303,22 @@ I2C_FN void w_elim_step(const Wave<R>& w, R* s, R* r1, R* r2, R* lt, const R* mq
   // falls out of the one-hot right-hand side, which is also zero outside block row KB), entry cq picked by a one-hot
   // combination. Written without selects on purpose: with selects hipcc sinks the arithmetic into per-(a, cq) divergent
   // branches, which a wavefront then executes one after the other.
-  const R e0 = (inblk && a == 0) ? R(1) : R(0), e1 = (inblk && a == 1) ? R(1) : R(0);
-  const R e2 = (inblk && a == 2) ? R(1) : R(0), e3 = (inblk && a == 3) ? R(1) : R(0);
+  // (every column block of lanes holds the entries: the small matrix instruction multiplies its four 4 x 4 blocks by the same matrix)
+  const R e0 = a == 0 ? R(1) : R(0), e1 = a == 1 ? R(1) : R(0);
+  const R e2 = a == 2 ? R(1) : R(0), e3 = a == 3 ? R(1) : R(0);
   const R y3 = e3 * i3;
   const R y2 = (e2 - l32 * y3) * i2;
   const R y1 = (e1 - l21 * y2 - l31 * y3) * i1;
   const R y0 = (e0 - l10 * y1 - l20 * y2 - l30 * y3) * i0;
   const R aw = (mq[0] * y0 + mq[1] * y1) + (mq[2] * y2 + mq[3] * y3);
   // scale block row KB: rows of L^T (masked to the upper triangle: what is left of it is rounding noise) ...
-  R x[4] = {R(0), R(0), R(0), R(0)};
-  w_mfma(w, aw, s[KB], x);
-  const R ltk = (w.j >= 4 * KB + cq) ? x[KB] : R(0);
+  // (one row block each: the small matrix instruction, w_mfma4 -- lane (q, j) passes entry (j & 3, q) of the inverse, which is aw)
+  const R xk = w_mfma4(w, aw, s[KB]);
+  const R ltk = (w.j >= 4 * KB + cq) ? xk : R(0);
   lt[KB] = ltk;
   R x1 = R(0), x2 = R(0);
-  if (NRHS >= 1) {
-    R y[4] = {R(0), R(0), R(0), R(0)};
-    w_mfma(w, aw, r1[KB], y);
-    x1 = y[KB];
-  }
-  if (NRHS >= 2) {
-    R y[4] = {R(0), R(0), R(0), R(0)};
-    w_mfma(w, aw, r2[KB], y);
-    x2 = y[KB];
-  }
+  if (NRHS >= 1) x1 = w_mfma4(w, aw, r1[KB]);
+  if (NRHS >= 2) x2 = w_mfma4(w, aw, r2[KB]);
   // ... and eliminate it from everything below
   if (KB < NB - 1) {
     const R nl = SIGNED ? -ltk * sq : -ltk;
