@@ -367,6 +367,22 @@ def extra_config_legs(pkg, device, K=10):
                                                    "failed_trajectories": len(eng.failures())}
         del eng
 
+    # the other inference rules of the reference on the headline shape (pendulum T=200, B=4096; exp_types.py:22-68): one EM iteration
+    # with Linearize() (i2c.py:244-348, 449-542) and with GaussHermiteQuadrature(3) (27 / 8 points per transform)
+    mp = make_env_model("PendulumKnown")
+    for tag, kw in (("pendulum_T200_B4096_linearize", dict(inference="linearize")), ("pendulum_T200_B4096_gauss_hermite3", dict(inference="gauss_hermite", gh_degree=3))):
+        Bp, Tp = 4096, 200
+        x0p, mu_up = synthetic_pendulum_inputs(Bp, Tp, 3)
+        eng = pkg.BatchedI2c(mp, Tp, np.diag([1.0, 100.0, 1.0]), np.diag([2.0]), np.diag([1.0, 100.0, 1.0]), 100.0, 0.0, mu_up, 2.0 * np.eye(1), x0=x0p,
+                             device=device, keep_zpost=False, keep_xm=False, **kw)
+        eng.learn(2)
+        sync(); t0 = time.perf_counter(); eng.learn(K); sync()
+        ms = (time.perf_counter() - t0) / K * 1e3
+        gb = _gbps(eng, Bp, Tp, ms)
+        out[tag] = {"ms_per_step": ms, "value": Bp * Tp / ms * 1e3, "unit": "timestep-messages/s", "algorithmic_GBps": gb,
+                    "frac_of_hbm_peak": gb / HBM_PEAK_GBS, "backward": eng.backward_schedule, "failed_trajectories": len(eng.failures())}
+        del eng
+
     # config 5: nonlinear covariance control (pendulum, action-only cost, annealed terminal prior, closed-loop propagation
     # and KL every iteration; scripts/experiments/pendulum_known_act_reg_quad.py:22-33), T=100, B=8192 = one GPU's share of 65536
     m = make_env_model("PendulumKnownActReg")

@@ -267,3 +267,122 @@ def test_group_kernels_failure_isolation_cpu(lanes):
 @pytest.mark.parametrize("lanes", [0, 16])
 def test_group_kernels_failure_isolation_gpu(lanes):
     _group_failure_isolation(None, "cuda", lanes)
+
+
+# ---- the same edge cases on the QUAD forward kernel (csrc/i2c_quad.hpp: four trajectories per wavefront): horizons of 1-3 cells
+# (the factorisation pair of the next cell never runs: the smoother gain of the only / last cell comes from the epilogue; the
+# terminal update sits on the first cell), batches that leave slots of a wave empty, per-trajectory failures -------------------
+def _short_golden(name, T):
+    import json
+
+    g = load_case(name)
+    return Case({**g, "meta": np.array(json.dumps(dict(g.meta, T=T))), "mu_u": g["mu_u"][:T]})
+
+
+def _check_quad(lib, device, case, B, lanes=64, tol=1e-8):
+    x0, mu_u = parity.batched_inputs(case, B)
+    eng = parity.engine_from_case(case, lib, device, x0=x0, mu_u=mu_u, group_lanes=lanes)
+    assert eng.forward_family == "quad"
+    o = oracle_from_case(Case({**case, "mu_u": mu_u}), x0=x0)
+    for it in range(3):
+        eng.learn_msgs()
+        o.learn_msgs()
+        f = eng.forward_messages()
+        for k in parity.FWD:
+            assert_close(parity.np_(f[k]), getattr(o, k), tol, f"quad B={B} it{it} {k}")
+        mu, sig = eng.marginal_state_action()
+        assert_close(parity.np_(mu), o.mu_xu0_m, tol, f"quad B={B} it{it} mu")
+        assert_close(parity.np_(sig), o.sig_xu0_m, tol, f"quad B={B} it{it} sig")
+        assert_close(parity.np_(eng.alpha), o.alpha, tol, f"quad B={B} it{it} alpha")
+    assert eng.failures() == []
+
+
+QUAD_SHORT = [("em_pendulum_T200", 1, 1), ("em_pendulum_T200", 2, 7), ("em_dcp_T60", 1, 2), ("em_dcp_T60", 3, 5), ("em_cartpole_T100", 2, 3),
+              ("em_quadrotor_T20", 1, 1), ("em_quadrotor_T20", 3, 6)]
+
+
+@pytest.mark.parametrize("name,T,B", QUAD_SHORT)
+def test_quad_forward_short_horizons_cpu(name, T, B):
+    _check_quad(hostsim.load(), "cpu", _short_golden(name, T), B)
+
+
+def test_quad12_quad_forward_short_horizons_cpu():
+    _check_quad(hostsim.load(), "cpu", _short_quad12(2), 3, lanes=parity.pkg._native.LANES_QUAD)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,T,B", QUAD_SHORT + [("em_dcp_T60", 4, 67), ("em_pendulum_T200", 2, 131)])
+def test_quad_forward_short_horizons_gpu(name, T, B):
+    _check_quad(None, "cuda", _short_golden(name, T), B, tol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B", [(1, 1), (2, 3), (4, 67)])
+def test_quad12_quad_forward_short_horizons_gpu(T, B):
+    _check_quad(None, "cuda", _short_quad12(T), B, lanes=parity.pkg._native.LANES_QUAD, tol=1e-7)
+
+
+def _quad_failure_isolation(lib, device, name, lanes=64):
+    """A covariance that is not positive definite in ONE trajectory of a quad wave (four trajectories share every matrix
+    instruction): its status word is the one the lane kernels report for the same problem -- also when the failure is the
+    prediction covariance of a MID-CHAIN cell, which the quad kernel only factors at the top of the next cell -- its values go
+    NaN, and the three other trajectories of the wave are bit-for-bit what they are without it."""
+    g = _short_golden(name, 6)
+    B = 6
+    x0, mu_u = parity.batched_inputs(g, B)
+    clean = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u, group_lanes=lanes)
+    bad = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u, group_lanes=lanes)
+    ref = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u, group_lanes=-1 if lanes == 64 else 16)  # lane (d = 16: group) kernels
+    for e in (bad, ref):
+        e.sig_x0[0, 2] = -1.0  # sig_x0[0][0] of trajectory 2 (packed index 0): negative variance
+    for e in (clean, bad, ref):
+        for _ in range(2):
+            e.learn_msgs()
+    assert clean.forward_family == bad.forward_family == "quad" and ref.forward_family != "quad"
+    f = bad.failures()
+    assert [b for b, _, _ in f] == [2] and f[0][2] == 0, f  # trajectory 2, first cell
+    if lanes == 64:  # the same status word as the lane kernels (reason: the prior joint is not positive definite, i2c_hip.h)
+        assert f == ref.failures(), (f, ref.failures())
+    else:  # (d = 16: the group / wave forms never factor the prior joint of an identity observation and name the next stage)
+        assert f[0][1] == 1 and [(b, t) for b, _, t in ref.failures()] == [(2, 0)], (f, ref.failures())
+    keep = [0, 1, 3, 4, 5]
+    assert torch.equal(bad.post[:, :, keep], clean.post[:, :, keep])
+    assert torch.equal(bad.alpha[keep], clean.alpha[keep])
+    assert not torch.isfinite(bad.post[:, :, 2]).all()
+    # ... and a failure in the middle of the chain: a NaN target of one cell poisons that cell's update in one trajectory
+    if lanes == 64:
+        z = np.tile(np.asarray(clean.zg, float).reshape(1, 1, -1), (B, g.meta["T"], 1))
+        z[4, 3, 0] = np.nan
+        mid = [parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u, group_lanes=gl, z_traj=z) for gl in (lanes, -1)]
+        for e in mid:
+            e.learn_msgs()
+        assert mid[0].forward_family == "quad" and [b for b, _, _ in mid[0].failures()] == [4]
+        assert mid[0].failures() == mid[1].failures(), (mid[0].failures(), mid[1].failures())
+        keep = [0, 1, 2, 3, 5]
+        assert torch.equal(mid[0].post[:, :, keep], clean_first_iteration(g, lib, device, x0, mu_u, lanes).post[:, :, keep])
+
+
+def clean_first_iteration(g, lib, device, x0, mu_u, lanes):
+    e = parity.engine_from_case(g, lib, device, x0=x0, mu_u=mu_u, group_lanes=lanes)
+    e.learn_msgs()
+    return e
+
+
+@pytest.mark.parametrize("name", ["em_dcp_T60", "em_quadrotor_T20", "em_pendulum_T200"])
+def test_quad_forward_failure_isolation_cpu(name):
+    _quad_failure_isolation(hostsim.load(), "cpu", name)
+
+
+def test_quad12_quad_forward_failure_isolation_cpu():
+    _quad_failure_isolation(hostsim.load(), "cpu", "em_quad12_T20", lanes=parity.pkg._native.LANES_QUAD)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["em_dcp_T60", "em_quadrotor_T20", "em_pendulum_T200", "em_cartpole_T100"])
+def test_quad_forward_failure_isolation_gpu(name):
+    _quad_failure_isolation(None, "cuda", name)
+
+
+@pytest.mark.gpu
+def test_quad12_quad_forward_failure_isolation_gpu():
+    _quad_failure_isolation(None, "cuda", "em_quad12_T20", lanes=parity.pkg._native.LANES_QUAD)

@@ -2,14 +2,14 @@
 // wave kernel's wavefront -- run as threads with a barrier wherever the device code has its LDS fence or a cross-lane
 // instruction, so a missing fence shows up here as a data race on the exchange region. Drives forward, backward, propagation and
 // the filter step of the 12-state quadrotor through the C ABI on a tiny problem: group kernels (16 lanes per trajectory), wave
-// kernels (cubature), wave kernels (Linearize). Built and run by tools/tsan_group.sh.
+// kernels (cubature), wave kernels (Linearize), quad forward kernel + wave backward. Built and run by tools/tsan_group.sh.
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <vector>
 #include "../include/i2c_hip.h"
 
-static int run(const int group_lanes, const int inference) {
+static int run(const int group_lanes, const int inference, const int post_layout = 0) {
   I2cDims d;
   if (i2c_query(I2C_MODEL_QUADROTOR12, &d) != I2C_OK) return 2;
   const int B = 3, T = 4, nx = d.nx, nu = d.nu, nz = d.nz, D = nx + nu;
@@ -24,6 +24,7 @@ static int run(const int group_lanes, const int inference) {
   p.terminal_cell = T - 1;
   p.inference = inference;
   p.group_lanes = group_lanes;
+  p.post_layout = post_layout;  // 1: trajectory-major posterior (what the quad forward kernel of this model addresses)
   p.quad_alpha = 1.0;
   p.dtemp = 1.0;
   auto diag = [](double* packed, int n, double v) {
@@ -49,10 +50,11 @@ static int run(const int group_lanes, const int inference) {
   std::vector<int32_t> status(B, 0);
   for (int t = 0; t < T; ++t)
     for (int b = 0; b < B; ++b) {
-      double* c = &post[(size_t)t * d.e_post * B + b];
-      for (int i = 0; i < nx; ++i) c[(size_t)i * B] = x0[i * B + b];
-      for (int i = nx; i < D; ++i) c[(size_t)i * B] = 2.45;
-      for (int i = 0; i < D; ++i) c[(size_t)(D + i * (i + 1) / 2 + i) * B] = i < nx ? 1e-5 : 1e-2;
+      const size_t es = post_layout ? 1 : (size_t)B;  // element stride
+      double* c = &post[post_layout ? ((size_t)t * B + b) * d.e_post : (size_t)t * d.e_post * B + b];
+      for (int i = 0; i < nx; ++i) c[(size_t)i * es] = x0[i * B + b];
+      for (int i = nx; i < D; ++i) c[(size_t)i * es] = 2.45;
+      for (int i = 0; i < D; ++i) c[(size_t)(D + i * (i + 1) / 2 + i) * es] = i < nx ? 1e-5 : 1e-2;
     }
   p.x0 = x0.data();
   p.sig_x0 = sx0.data();
@@ -81,5 +83,6 @@ int main() {
   int bad = run(16, I2C_INF_CUBATURE);
   bad += run(64, I2C_INF_CUBATURE);
   bad += run(64, I2C_INF_LINEARIZE);
+  bad += run(I2C_LANES_QUAD, I2C_INF_CUBATURE, 1);  // quad forward kernel (four trajectories per wavefront: 3 + one spare slot) + wave backward
   return bad;
 }
