@@ -562,14 +562,14 @@ template <class M, typename R, typename S = R> struct Impl {
   //   (measured, planar quadrotor d = 8 at B = 4096: forward 0.51 -> 0.40 ms, while its chunked lane backward stays the
   //   faster one; the buffers of the families are the same, so the backward schedules are unaffected).
   // what the wave form covers: the cubature rule with lam = 0 (every shipped config: unit weights, no weight on the centre;
-  // the centring of the pairwise sums relies on 2 d wi = 1), no terminal state prior, windows below 2 GiB (WIO::st_if)
+  // the centring of the pairwise sums relies on 2 d wi = 1), windows below 2 GiB (WIO::st_if)
   static int wave_supported(const I2cProblem* p, const C& c) {
     if (p->inference == I2C_INF_LINEARIZE) {  // Linearize(): fp64 storage; needs a terminal observation like the lane form
       if (MIXED) return I2C_ENOTSUP;
       if (M::NZT == 0) return I2C_EINVAL;
-    } else if (p->inference != I2C_INF_CUBATURE || c.has_x_terminal) {
+    } else if (p->inference != I2C_INF_CUBATURE) {
       return I2C_ENOTSUP;
-    }
+    }  // (a terminal state prior -- covariance control -- is the backward sweep's end of the chain: w_end_of_chain, round 4)
     if (!c.rule_xu.unit || !c.rule_x.unit || c.rule_xu.w0 != R(0) || c.rule_x.w0 != R(0)) return I2C_ENOTSUP;
     constexpr long EMAX = C::E_FWD > C::E_POST ? C::E_FWD : C::E_POST;
     if (EMAX * (long)p->B * (long)sizeof(S) >= (1L << 31)) return I2C_EINVAL;

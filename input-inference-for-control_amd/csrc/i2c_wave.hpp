@@ -800,6 +800,40 @@ I2C_FN void w_end_of_chain(const Consts<M, R>& c, const KC& kc, const CellArgs<R
       s3m[v] = (v < NBX && jx) ? sv : R(0);
     }
   }
+  if (!LIN && c.has_x_terminal) {
+    // covariance control (i2c.py:548-559): the smoothed terminal state is the product of the TEMPERED filtered state
+    // N(m3f, temp S3f) with the terminal prior N(mu_T, S_T) -- in Kalman form, an identity observation of the state with noise
+    // S_T and target mu_T:  with C = chol(S_T + St), [U | y] = C^-1 [St | mu_T - m3f]:  S3m = St - U^T U,  m3m = m3f + U^T y
+    // (the reference: S3m (St^-1 m3f + S_T^-1 mu_T) with three inverses: the same Gaussian). temp += dtemp per sweep.
+    const R tmp = a.temp[b];
+    w.sync();  // (every lane has read the temperature before lane 0 advances it)
+    if (w.l == 0) a.temp[b] = tmp + c.dtemp;
+    R sxT[4], st[4], sum[4], u[4], r2[4], lt[4], dr[4];
+    w_ldconst<NBX>(w, kc.sxT, sxT);
+    w_col2row<NBX>(w, 0, jx ? kc.mxT[jxc] - m3m : R(0), dr);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      st[v] = (v < NBX && jx) ? tmp * s3m[v] : R(0);
+      sum[v] = (v < NBX && jx) ? sxT[v] + st[v] : R(0);
+      u[v] = st[v];
+      r2[v] = (v < NBX && j == 0) ? dr[v] : R(0);  // the innovation as column 0 of a second right-hand side
+    }
+    if (!w_elim<NBX, 2, true>(w, sum, u, r2, lt) && w.l == 0) set_status(a.status, b, 6, T - 1);
+    R inc[4] = {R(0), R(0), R(0), R(0)};
+    w_tn<NBX, true>(w, u, u, st);
+    w_tn<NBX>(w, u, r2, inc);  // column 0: U^T y, element q + 4 v in register v of lane (q, 0)
+    {
+      const auto sl = w.vec(4);
+      w.sync();
+#pragma unroll
+      for (int v = 0; v < NBX; ++v)
+        if (j == 0) sl[w.row(v)] = inc[v];
+      w.sync();
+      m3m = jx ? m3m + sl[jxc] : R(0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) s3m[v] = (v < NBX && jx) ? st[v] : R(0);
+  }
   R xiT[4] = {R(0), R(0), R(0), R(0)};  // Linearize: the sig_xi_terminal that stays in sig_z3_m (i2c.py:460, 488, 497)
   if (LIN) {
     if (c.has_x_terminal) {

@@ -620,6 +620,26 @@ def case_em_quad12_propagate(T=12, n_detail=2, n_total=4):
     save("em_quad12_T12_propagate", out)
 
 
+def case_em_quad12_covctrl(T=12, n_detail=3, n_total=6):
+    """Covariance control (tempered terminal state prior, i2c.py:548-559) on the 12-state quadrotor, WITH a terminal cost (the
+    terminal observation statistics then come from the pinned smoothed state, :565-570), propagation + KL every iteration."""
+    model = _reference_quad12()
+    rng = np.random.default_rng(21)
+    mu_u = 0.25 * model.gravity * np.ones((T, 4)) + 1e-2 * rng.normal(size=(T, 4))
+    sig_u = 1e-2 * np.eye(4)
+    mu_xt = np.zeros(12)
+    mu_xt[:3] = [0.05, -0.03, 0.08]
+    A = rng.normal(size=(12, 12))
+    sig_xt = 1e-3 * (np.eye(12) + 0.08 * (A + A.T) / np.abs(A).max())  # coupled, positive definite
+    assert np.all(np.linalg.eigvalsh(sig_xt) > 0)
+    g = I2cGraph(model, T, QUAD12_Q, QUAD12_R, QUAD12_Q, 1.0, 0.5, mu_u, sig_u, mu_xt, sig_xt, CubatureQuadrature(1, 0, 0))
+    g._propagate = True
+    out = problem_inputs("Quadrotor12", model, T, QUAD12_Q, QUAD12_R, QUAD12_Q, 1.0, 0.5, mu_u, sig_u, mu_xt, sig_xt, (1, 0, 0),
+                         propagate=True)
+    run_em(g, n_detail, n_total, out, pre_propagate=True)
+    save("em_quad12_covctrl_T12", out)
+
+
 def _coupled(W, rng, strength=0.3):
     """A symmetric positive-definite weight with off-diagonal entries: D^1/2 (I + s (A + A^T) / (2 |A|)) D^1/2."""
     n = W.shape[0]
@@ -1136,6 +1156,7 @@ CASES = {
     "mpc_quad12_H50": case_mpc_quad12_H50,
     "mpc_quad_H50": case_mpc_quadrotor_H50,
     "em_quad12_nondiag": case_em_quad12_nondiag,
+    "em_quad12_covctrl": case_em_quad12_covctrl,
     "em_dcp_nondiag": case_em_dcp_nondiag,
     "rollouts": case_rollouts,
     "i2c_run": case_i2c_run,

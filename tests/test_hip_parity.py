@@ -69,7 +69,7 @@ def test_hip_lane_kernels_vs_reference_golden(lib, name, tol_d, tol_s):
 
 
 # the 12-state quadrotor's two multi-lane forms: wave kernels (its default, 64) and group kernels (16)
-@pytest.mark.parametrize("name", ["em_quad12_T20", "em_quad12_T12_propagate", "em_quad12_nondiag_T12"])
+@pytest.mark.parametrize("name", ["em_quad12_T20", "em_quad12_T12_propagate", "em_quad12_nondiag_T12", "em_quad12_covctrl_T12"])
 @pytest.mark.parametrize("lanes", [16, 64])
 def test_hip_quad12_both_families_vs_reference_golden(lib, name, lanes):
     eng = parity.check_against_golden(name, lib, "cuda", 1e-6, 1e-5, group_lanes=lanes)
@@ -117,7 +117,7 @@ def test_hip_quad_forward_vs_reference_golden(lib, name, tol_d, tol_s):
     assert eng.forward_family == "quad" and eng.backward_family == "lane"
 
 
-@pytest.mark.parametrize("name", ["em_quad12_T20", "em_quad12_T12_propagate", "em_quad12_nondiag_T12"])
+@pytest.mark.parametrize("name", ["em_quad12_T20", "em_quad12_T12_propagate", "em_quad12_nondiag_T12", "em_quad12_covctrl_T12"])
 def test_hip_quad12_quad_forward_vs_reference_golden(lib, name):
     """The quad forward kernel on the 12-state quadrotor (next to its wave kernels: LANES_QUAD), wave backward sweep behind it."""
     eng = parity.check_against_golden(name, lib, "cuda", 1e-6, 1e-5, group_lanes=parity.pkg._native.LANES_QUAD)

@@ -73,7 +73,7 @@ LANE_GOLDEN = [
 # The 12-state quadrotor has two multi-lane forms: its DEFAULT is the wave kernels (csrc/i2c_wave.hpp: one wavefront per
 # trajectory, 16 x 16 blocks in the fp64 matrix-instruction layout; the goldens in GOLDEN above run them), group_lanes = 16 asks
 # for the group kernels. The host simulation runs the 64 lanes as 64 threads and emulates the matrix / cross-lane instructions.
-QUAD12 = ["em_quad12_T20", "em_quad12_T12_propagate", "em_quad12_nondiag_T12"]
+QUAD12 = ["em_quad12_T20", "em_quad12_T12_propagate", "em_quad12_nondiag_T12", "em_quad12_covctrl_T12"]  # (the last: covariance control)
 
 
 @pytest.mark.parametrize("name", QUAD12)

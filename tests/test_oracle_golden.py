@@ -159,6 +159,11 @@ def test_em_quad12_propagate():
     _run_and_check("em_quad12_T12_propagate", 1e-8, 1e-7)
 
 
+def test_em_quad12_covariance_control():
+    """Tempered terminal state prior with a coupled target covariance + terminal cost on the 12-state quadrotor (i2c.py:548-570)."""
+    _run_and_check("em_quad12_covctrl_T12", 1e-8, 1e-7)
+
+
 @pytest.mark.parametrize("name", ["em_quad12_nondiag_T12", "em_dcp_nondiag_T30"])
 def test_em_non_diagonal_weights(name):
     """Non-diagonal Q, R, Qf (i2c.py:781-789): the general-weight cost and temperature statistics."""
