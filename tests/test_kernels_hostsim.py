@@ -334,8 +334,7 @@ def test_hostsim_post_layout_is_transparent(lib, monkeypatch):
 
 def _terminal_prior_with_terminal_cost(lib, device, name, T, mu_T, sig_T, family, tol):
     """Covariance control (a terminal state prior, i2c.py:548-559 / 453-472) TOGETHER with a terminal cost, against the batched
-    oracle. Under the cubature rule the wave form does not cover it and the group kernels take over (tempered product at the end
-    of the chain); under Linearize() the smoothed terminal state is pinned to the prior and sig_z3_m carries the back-calculated
+    oracle. Under the cubature rule the tempered product at the end of the chain (wave kernels: its Kalman form); under Linearize() the smoothed terminal state is pinned to the prior and sig_z3_m carries the back-calculated
     sig_xi_terminal (i2c.py:455-462, 499-501), which reaches alpha through the terminal statistic (:989-992)."""
     import json
 
@@ -375,7 +374,7 @@ def _terminal_prior_with_terminal_cost(lib, device, name, T, mu_T, sig_T, family
 
 Q12_TERM = ([0.3, -0.2, 0.5] + [0.0] * 9, np.diag([1e-2] * 3 + [1e-1] * 9))
 TERMINAL_PRIOR = [
-    ("em_quad12_T20", 8, *Q12_TERM, "group"),
+    ("em_quad12_T20", 8, *Q12_TERM, "wave"),  # (round 4: the wave backward sweep has the tempered terminal prior; group kernels until then)
     ("lin_quad12_T20", 8, *Q12_TERM, "wave"),
     ("lin_linear_T60", 30, [1.0, 0.5], [[1e-3, 2e-4], [2e-4, 50.0]], "lane"),
 ]
