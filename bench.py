@@ -607,9 +607,18 @@ def main():
             out["extra"] = extra_config_legs(pkg, device)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(T)
-    print(json.dumps(out))
+    # the JSON line is the LAST thing on stdout: tear the process group down first and flush the C runtime's buffer (RCCL prints a
+    # version banner through it, which otherwise lands after Python's output when stdout is a pipe)
     if dist is not None:
         dist.destroy_process_group()
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
