@@ -42,10 +42,6 @@ static int launch(K kernel, const long n, const int ny, const int /*block*/, voi
     for (long x = 0; x < n; ++x) kernel(x, y, args...);
   return I2C_OK;
 }
-static int clear_bytes(void* p, size_t n, void*) {
-  std::memset(p, 0, n);
-  return I2C_OK;
-}
 static int copy_bytes(void* dst, const void* src, size_t n, void*) {
   std::memcpy(dst, src, n);
   return I2C_OK;
@@ -69,9 +65,6 @@ template <class K, class... A>
 static int launch(K kernel, const long n, const int ny, const int block, void* stream, const A&... args) {
   hipLaunchKernelGGL(kernel, dim3((unsigned)((n + block - 1) / block), ny), dim3(block), 0, (hipStream_t)stream, args...);
   return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
-}
-static int clear_bytes(void* p, size_t n, void* stream) {
-  return hipMemsetAsync(p, 0, n, (hipStream_t)stream) == hipSuccess ? I2C_OK : I2C_ELAUNCH;
 }
 static int copy_bytes(void* dst, const void* src, size_t n, void* stream) {
   return hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? I2C_OK : I2C_ELAUNCH;
@@ -161,6 +154,12 @@ I2C_KERNEL(SWEEP_BLOCK) k_ckf(I2C_LANE_PARAMS const Consts<M, R> c, const ZetaAr
 template <class M, typename R> I2C_KERNEL(CELL_BLOCK) k_mpc_shift(I2C_LANE_PARAMS const Consts<M, R> c, const ShiftArgs<R> a) {
   const long b = I2C_LANE_X(CELL_BLOCK);
   if (b < c.B) mpc_shift_body<M, R>(c, a, (int)b);
+}
+// mode flags of cells 0 .. n-1 (ring rows t0 .. t0+n-1 mod T) to feedback: ONE launch (two hipMemsetAsync spans of odd length
+// are split by the runtime into up to five fill kernels, 5 us each: a twentieth of a planar-quadrotor control step)
+template <class M> I2C_KERNEL(CELL_BLOCK) k_to_feedback(I2C_LANE_PARAMS uint8_t* ff, const int t0, const int n, const int T) {
+  const long i = I2C_LANE_X(CELL_BLOCK);
+  if (i < n) ff[(t0 + (int)i) % T] = 0;
 }
 template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_rollout(I2C_LANE_PARAMS const Consts<M, R> c, const RolloutArgs<R> a) {
   const long n = I2C_LANE_X(SWEEP_BLOCK);
@@ -889,11 +888,7 @@ template <class M, typename R, typename S = R> struct Impl {
   // _update_priors (i2c.py:1210-1213): cells with index <= tau switch to feedback mode
   static int to_feedback(const I2cProblem* p, int tau, void* stream) {
     const int n = tau + 1 < p->T ? tau + 1 : p->T;  // cells 0 .. n-1 = ring rows t0 .. t0+n-1 (mod T): at most two spans
-    uint8_t* ff = const_cast<uint8_t*>(p->feedforward);
-    const int first = n < p->T - p->t0 ? n : p->T - p->t0;
-    int rc = clear_bytes(ff + p->t0, (size_t)first, stream);
-    if (rc == I2C_OK && n > first) rc = clear_bytes(ff, (size_t)(n - first), stream);
-    return rc;
+    return launch(k_to_feedback<M>, n, 1, CELL_BLOCK, stream, const_cast<uint8_t*>(p->feedforward), p->t0, n, p->T);
   }
 
   static int learn(const I2cProblem* p, void* post, void* fwd, void* xm, void* zpost, void* cell_stats,

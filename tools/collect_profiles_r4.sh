@@ -39,6 +39,9 @@ rocprofv3 --pmc WRITE_SIZE $F -d "$OUT/w_q12" -- python3 tools/bench_models.py f
 python3 tools/pmc_summary.py "r4_Quadrotor12_B8192" 8192 50 "$OUT/f_q12" "$OUT/w_q12" > "$OUT/pmc_q12.txt"
 bash tools/sq_counters.sh r4_quad12_B8192_quad_vs_wave tools/bench_models.py f64 wave Quadrotor12 8192 > "$OUT/sq_q12_8192.txt" 2>&1
 bash tools/sq_counters.sh r4_quad12_B32768_quad_vs_wave tools/bench_models.py f64 wave Quadrotor12 32768 > "$OUT/sq_q12_32768.txt" 2>&1
+# closed-loop control steps (planar quadrotor, one EM iteration per step; 12-state quadrotor, two)
+python3 tools/bench_mpc.py 1024 8192 > "$OUT/mpc_steps.txt" 2>&1
+python3 tools/bench_mpc12.py 1024 8192 >> "$OUT/mpc_steps.txt" 2>&1
 for d in kt kt_dcp kt_planar kt_cartpole kt_q12_1024 kt_q12_8192 kt_q12_32768; do
   f=$(find "$OUT/$d" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${d}_kernel_stats.csv"
   python3 tools/kstats.py "$OUT/$d" > "$OUT/${d}_kstats.txt" 2>/dev/null
