@@ -393,6 +393,55 @@ static int launch_quad_forward(const Consts<M, R>& c, const A& a, void* stream) 
 }
 #endif
 
+// the quad backward sweep (backward_quad_body): d = 16 models with identity observations
+template <class M> constexpr bool quad_backward_exists() {
+  return QG<M>::WIDE && M::NX % 4 == 0 && (M::NX + M::NU) % 4 == 0 && M::NU <= 4 && M::NZ == M::NX + M::NU && st_identity<ObsStruct<M>, M::NZ>() &&
+         (M::NZT == 0 || (M::NZT == M::NX && st_identity<TermStruct<M>, M::NZT>()));
+}
+#ifdef I2C_HOST_SIM
+template <class M, typename R, typename S, class A>
+static int launch_quad_backward(const Consts<M, R>& c, const A& a, void*) {
+  QBConst<M, R> kc;
+  qbconst_fill<M, R>(kc, &c, 0, 1);
+  for (int b0 = 0; b0 < c.B; b0 += 4) {
+    std::vector<R> sh((size_t)4 * QBG<M>::SIZE, R(0)), xch(128, R(0));
+    HostBarrier bar(64);
+    std::vector<std::thread> lanes;
+    for (int l = 0; l < 64; ++l)
+      lanes.emplace_back([&, l, b0] {
+        const int g = (l >> 2) & 3, b = b0 + g;
+        const bool live = b < c.B;
+        backward_quad_body<M, R, S>(c, kc, a, live ? b : c.B - 1, live, Quad<R>{l, l >> 4, g, l & 3, sh.data() + g * QBG<M>::SIZE, &bar, xch.data()});
+      });
+    for (auto& th : lanes) th.join();
+  }
+  return I2C_OK;
+}
+#else
+constexpr int QB_WAVES_PER_BLOCK = 4;
+template <class M, typename R, typename S, class A>
+__global__ __launch_bounds__(64 * QB_WAVES_PER_BLOCK, 2) void k_quad_backward(const Consts<M, R> c, const A a) {
+  constexpr int WPB = QB_WAVES_PER_BLOCK;
+  __shared__ QBConst<M, R> kc;
+  __shared__ R sh[WPB * 4 * QBG<M>::SIZE];
+  qbconst_fill<M, R>(kc, (const Consts<M, R>*)__builtin_amdgcn_kernarg_segment_ptr(), (int)threadIdx.x, 64 * WPB);
+  __syncthreads();
+  const int l = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6), g = (l >> 2) & 3;
+  const long b0 = 4L * ((long)blockIdx.x * WPB + wv);  // (trajectory-major buffers: nothing is shared between waves)
+  if (b0 >= c.B) return;  // (wave-uniform: no trajectory in this wave)
+  const long b = b0 + g;
+  const bool live = b < c.B;
+  const Quad<R> q{l, l >> 4, g, l & 3, (lds_ptr<R>)(sh + (wv * 4 + g) * QBG<M>::SIZE)};
+  backward_quad_body<M, R, S>(c, kc, a, (int)(live ? b : c.B - 1), live, q);
+}
+template <class M, typename R, typename S, class A>
+static int launch_quad_backward(const Consts<M, R>& c, const A& a, void* stream) {
+  constexpr int WPB = QB_WAVES_PER_BLOCK;
+  hipLaunchKernelGGL((k_quad_backward<M, R, S, A>), dim3((unsigned)(((long)c.B + 4 * WPB - 1) / (4 * WPB))), dim3(64 * WPB), 0, (hipStream_t)stream, c, a);
+  return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
+}
+#endif
+
 template <int KIND, class M, typename R, typename S, class A>
 static int launch_wave(const Consts<M, R>& c, const A& a, void* stream) {
   if constexpr (KIND == WK_FORWARD) {  // batches whose waves share a SIMD: the variant with the pivot blocks through LDS
@@ -530,6 +579,7 @@ template <class M, typename R, typename S = R> struct Impl {
   static constexpr bool LANE = !M::GROUP_ONLY;  // one-lane-per-trajectory kernels exist
   static constexpr bool HAS_WAVE = M::WAVE && sizeof(R) == 8;  // fp64 matrix instruction; the storage type S may be float
   static constexpr bool HAS_QUAD = M::QUAD && sizeof(R) == 8 && !MIXED;  // fp64 matrix instruction (i2c_quad.hpp): forward sweep
+  static constexpr bool HAS_QUAD_BACKWARD = HAS_QUAD && quad_backward_exists<M>();  // ... and, for d = 16, the backward sweep
 
   // 1: group kernels, 0: one lane per trajectory, < 0: error code
   static int use_group(const I2cProblem* p) {
@@ -597,7 +647,10 @@ template <class M, typename R, typename S = R> struct Impl {
   static int family(const I2cProblem* p, const C& c, const int sweep) {
     if constexpr (HAS_QUAD) {  // forward sweep: on request, or the model's default inside its batch window
       const bool asked = p->group_lanes == I2C_LANES_QUAD || (p->group_lanes == 64 && !M::WAVE);
-      if (sweep == I2C_SWEEP_FORWARD && (asked || (p->group_lanes == 0 && p->B >= M::QUAD_FORWARD_MIN_B && p->B <= M::QUAD_FORWARD_MAX_B))) {
+      // (the backward sweep of the d = 16 form: the fused walk, with the forward sweep -- an explicit two-pass request keeps the wave form)
+      const bool sweep_ok = sweep == I2C_SWEEP_FORWARD || (sweep == I2C_SWEEP_BACKWARD && HAS_QUAD_BACKWARD && p->backward_mode != I2C_BWD_TWO_PASS);
+      const int min_b = sweep == I2C_SWEEP_BACKWARD && M::QUAD_BACKWARD_MIN_B > M::QUAD_FORWARD_MIN_B ? M::QUAD_BACKWARD_MIN_B : M::QUAD_FORWARD_MIN_B;
+      if (sweep_ok && (asked || (p->group_lanes == 0 && p->B >= min_b && p->B <= M::QUAD_FORWARD_MAX_B))) {
         const int rc = quad_supported(p, c);
         if (rc == I2C_OK) return I2C_FAMILY_QUAD;
         if (asked) return rc;
@@ -693,7 +746,8 @@ template <class M, typename R, typename S = R> struct Impl {
     if (fam == I2C_FAMILY_QUAD) {
       if constexpr (HAS_QUAD) {  // the forward messages go where the backward family of this problem reads them
         C cq = c;
-        cq.fwd_tm = (M::WAVE && family(p, c, I2C_SWEEP_BACKWARD) == I2C_FAMILY_WAVE) ? 1 : 0;
+        const int fb = family(p, c, I2C_SWEEP_BACKWARD);
+        cq.fwd_tm = ((M::WAVE && fb == I2C_FAMILY_WAVE) || (HAS_QUAD_BACKWARD && fb == I2C_FAMILY_QUAD)) ? 1 : 0;
         return launch_quad_forward<M, R, R>(cq, a, stream);
       }
     }
@@ -791,6 +845,9 @@ template <class M, typename R, typename S = R> struct Impl {
     if (fam < 0) return fam;
     if (fam == I2C_FAMILY_WAVE) {
       if constexpr (!MIXED) return backward_wave(p, c, a, ms, fuse, stream);
+    }
+    if (fam == I2C_FAMILY_QUAD) {
+      if constexpr (HAS_QUAD_BACKWARD) return launch_quad_backward<M, R, R>(c, a, stream);
     }
     if (fam == I2C_FAMILY_GROUP) {  // one schedule: the group walks T-1..0 (the fused form); backward_mode is ignored
       if constexpr (HAS_GROUP) return launch_group<GK_BACKWARD, M, R, G>(c, nullptr, a, stream);

@@ -27,6 +27,7 @@ struct Pendulum {
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   static constexpr int QUAD_FORWARD_MIN_B = 0;
+  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (the quad backward sweep exists for d = 16 only)
   I2C_HD static constexpr int ang(int) { return 0; }
   // z = [sin th, cos th, thd, u],  zT = [sin th, cos th, thd]
   I2C_HD static constexpr int obs_lin(int k) { return k < 2 ? -1 : k - 1; }
@@ -74,6 +75,7 @@ struct PendulumActReg {
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   static constexpr int QUAD_FORWARD_MIN_B = 0;
+  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (the quad backward sweep exists for d = 16 only)
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int) { return 2; }  // z = [u]
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -102,6 +104,7 @@ struct Cartpole {
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 4096;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   static constexpr int QUAD_FORWARD_MIN_B = 0;
+  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (the quad backward sweep exists for d = 16 only)
   I2C_HD static constexpr int ang(int) { return 1; }
   // z = [x, sin th, cos th, xd, thd, u],  zT = [x, sin th, cos th, xd, thd]
   I2C_HD static constexpr int obs_lin(int k) { return k == 0 ? 0 : (k < 3 ? -1 : k - 1); }
@@ -157,6 +160,7 @@ struct DoubleCartpole {
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 8192;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   static constexpr int QUAD_FORWARD_MIN_B = 0;
+  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (the quad backward sweep exists for d = 16 only)
   I2C_HD static constexpr int ang(int a) { return a == 0 ? 1 : 2; }
   // z = [x, sin th1, cos th1, sin th2, cos th2, xd, th1d, th2d, u],  zT = z without u
   I2C_HD static constexpr int obs_lin(int k) { return k == 0 ? 0 : (k < 5 ? -1 : k - 2); }
@@ -238,6 +242,7 @@ struct Linear {
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   static constexpr int QUAD_FORWARD_MIN_B = 0;
+  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (the quad backward sweep exists for d = 16 only)
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -275,6 +280,7 @@ struct LinearMinEnergy {
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   static constexpr int QUAD_FORWARD_MIN_B = 0;
+  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (the quad backward sweep exists for d = 16 only)
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int) { return 2; }  // z = [u], zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -313,6 +319,7 @@ struct Quadrotor {
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 8192;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   static constexpr int QUAD_FORWARD_MIN_B = 0;
+  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (the quad backward sweep exists for d = 16 only)
   I2C_HD static constexpr int ang(int) { return 2; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -382,6 +389,9 @@ struct Quadrotor12 {
   // 0.59; 8192: 2.01 / 0.91; 32768: 7.85 / 3.17 -- profiles/r4_quad12_quad_vs_wave.txt)
   static constexpr int QUAD_FORWARD_MAX_B = 1 << 30;
   static constexpr int QUAD_FORWARD_MIN_B = 2048;
+  // ... and the DEFAULT backward sweep from 4096 trajectories up (the fused walk of four trajectories per wavefront against one:
+  // B = 2048: 0.245 against 0.168 ms; 4096: 0.297 / 0.310; 8192: 0.506 / 0.566; 32768: 1.90 / 2.15)
+  static constexpr int QUAD_BACKWARD_MIN_B = 4096;
   I2C_HD static constexpr int ang(int a) { return 3 + a; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }

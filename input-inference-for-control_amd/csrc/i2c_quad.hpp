@@ -1018,4 +1018,400 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
   if (live && q.p() == 0 && fail != 0 && a.status[b] == 0) a.status[b] = fail;
 }
 
+// ------------------------------------------------------------------------------------------
+// Backward sweep (i2c.py:882-886 over :544-610), d = 16 with identity observations (the 12-state quadrotor)
+// ------------------------------------------------------------------------------------------
+// The fused walk T-1 .. 0 of FOUR trajectories per wavefront: the same cell as backward_wave_body (i2c_wave.hpp) -- RTS update of
+// the joint, expected cost of the posterior observation, controller, stores -- in 4 x 4 blocks: the pivot algebra of the
+// controller's factorisation is shared by four trajectories instead of being repeated by the 64 lanes of one (it was half of the
+// wave form's vector instructions), and the products J dS J^T are sixteen-lane block products instead of 16 x 16 tiles of which
+// a quarter is used. Cubature EM only (Linearize keeps the wave form); trajectory-major forward-message and posterior buffers.
+template <class M, typename R> struct QBConst {
+  static constexpr int QLD = QG<M>::QLD;
+  R qr[QLD * QLD], qf[QLD * QLD], sxT[QLD * QLD];  // blkdiag(Q, R), Qf, sig_x_terminal
+  R zg[QLD], zgT[QLD], mxT[QLD];
+};
+template <class M, typename R, class DST> I2C_FN void qbconst_fill(DST& k, const Consts<M, R>* c, const int tid, const int nthreads) {
+  constexpr int NX = M::NX, NZ = M::NZ, NT = M::NZT > 0 ? M::NZT : 1, QLD = QG<M>::QLD;
+  for (int e = tid; e < QLD * QLD; e += nthreads) {
+    const int i = e / QLD, j = e % QLD;
+    k.qr[e] = (i < NZ && j < NZ) ? c->QR[tri_any(i, j)] : R(0);
+    k.qf[e] = (i < NT && j < NT) ? c->Qf[tri_any(i, j)] : R(0);
+    k.sxT[e] = (i < NX && j < NX) ? c->sig_x_term[tri_any(i, j)] : R(0);
+  }
+  for (int e = tid; e < QLD; e += nthreads) {
+    k.zg[e] = e < NZ ? c->zg[e] : R(0);
+    k.zgT[e] = e < NT ? c->zg_term[e] : R(0);
+    k.mxT[e] = e < NX ? c->mu_x_term[e] : R(0);
+  }
+}
+// LDS region of one trajectory: the pivot block of an elimination, then one staged cell block (the forward rows in, the posterior rows out)
+template <class M> struct QBG {
+  using C = Consts<M, double>;
+  static constexpr int O_ST = 40;
+  static constexpr int NST = C::E_FWD > C::E_POST ? C::E_FWD : C::E_POST;
+  static constexpr int RAW = O_ST + NST + (NST & 1);
+  static constexpr int SIZE = RAW + ((80 - RAW % 64) % 64);  // (= 16 mod 64 elements: the four regions of a wave start 32 banks apart)
+};
+
+// sum over the sixteen lanes of a trajectory, in every lane
+template <typename R> I2C_FN R q_sum16(const Quad<R>& q, const R x) { return q_rowsum(q, q_colsum(q, x)); }
+
+// Expected quadratic cost of N(mu, s) about a target (compute_cost_gaussian, i2c.py:1046-1065): this lane's shares of
+//   m = err^T W err + tr(s W),   v = 2 tr((s W)^2) + 4 err^T W s W err      (summed over the sixteen lanes by the caller).
+// errc: mu - target, column form [NB]; s: upper blocks [NB][NBS] (row stride NBS), the diagonal ones full; wm: the weight, QLD x QLD in LDS.
+template <int NB, int NBS, int QLD, typename R, class P>
+I2C_FN void q_cost_share(const Quad<R>& q, const bool diag, const P wm, const R* errc, const R* s, R* pm, R* pv, const int kz) {
+  R m = R(0), t2 = R(0), qd = R(0);
+  if (diag) {
+    R wdc[NB], wec[NB], wdr[NB], wer[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      wdc[j] = wm[(4 * j + q.c) * QLD + 4 * j + q.c + kz];
+      wdr[j] = wm[(4 * j + q.r) * QLD + 4 * j + q.r + kz];
+      wec[j] = wdc[j] * errc[j];
+      wer[j] = q_tr(q, wec[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      m += q.r == q.c ? wdc[j] * (errc[j] * errc[j] + s[j * NBS + j]) : R(0);
+#pragma unroll
+      for (int i = 0; i <= j; ++i) {
+        const R sv = s[i * NBS + j], f = i < j ? R(2) : R(1);
+        t2 += f * (sv * sv) * (wdr[i] * wdc[j]);
+        qd += f * (wer[i] * sv) * wec[j];
+      }
+    }
+  } else {
+    R sf[NB * NB], wb[NB * NB], g[NB * NB], er[NB], wec[NB], wer[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        sf[i * NB + j] = j >= i ? s[i * NBS + j] : q_tr(q, s[j * NBS + i]);
+        wb[i * NB + j] = q_ldc<QLD>(q, wm, i, j, kz);
+        g[i * NB + j] = R(0);
+      }
+    q_tn<NB, NB, NB>(q, sf, wb, g);  // G = s W
+#pragma unroll
+    for (int i = 0; i < NB; ++i) er[i] = q_tr(q, errc[i]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {  // W err, column and row form
+      R t = R(0);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) t += wb[i * NB + j] * er[i];
+      wec[j] = q_colsum(q, t);
+      wer[j] = q_tr(q, wec[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      m += (q.r == 0 ? errc[i] * wec[i] : R(0)) + (q.r == q.c ? g[i * NB + i] : R(0));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        t2 += g[i * NB + j] * q_tr(q, g[j * NB + i]);
+        qd += (wer[i] * sf[i * NB + j]) * wec[j];
+      }
+    }
+  }
+  *pm = m;
+  *pv = R(2) * t2 + R(4) * qd;
+}
+
+template <class M, typename R, typename S, class KC>
+I2C_HD inline void backward_quad_body(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>& a, const int b, const bool live, const Quad<R>& qw) {
+  using C = Consts<M, R>;
+  using G = QG<M>;
+  using BG = QBG<M>;
+  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D, NT = C::NZT1, QLD = G::QLD;
+  constexpr int NBX = NX / 4, NBD = D / 4, JU = NBX;
+  static_assert(G::WIDE && NX % 4 == 0 && D % 4 == 0 && NU <= 4 && NBD == NBX + 1, "quad backward sweep: d = 16, the actions in a block column of their own");
+  static_assert(NZ == D && st_identity<ObsStruct<M>, NZ>(), "quad backward sweep: identity observation of the joint");
+  static_assert(NZT == 0 || (NT == NX && st_identity<TermStruct<M>, NT>()), "quad backward sweep: identity terminal observation");
+  static_assert(sizeof(S) == 8 && C::E_FWD % 2 == 0 && C::E_POST % 2 == 0, "quad backward sweep: cell blocks move as pairs of doubles");
+  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  constexpr int O_K = D + sym(D), O_k = O_K + NU * NX, O_SK = O_k + NU;
+  constexpr int NKF = (C::E_FWD / 2 + 15) / 16, NKP = (C::E_POST / 2 + 15) / 16;  // 16-lane passes over a cell block, two doubles per lane
+  const unsigned long B = c.B;
+  const int T = c.T;
+  const unsigned WS = sizeof(S);
+  const bool lead = live && qw.p() == 0;
+  const auto st = qw.sh + BG::O_ST;  // this trajectory's staged cell block
+
+  // Cell blocks move between HBM and the block layout THROUGH LDS: the sixteen lanes of a trajectory read its forward rows as
+  // 256 consecutive bytes per instruction (a cell of a trajectory is contiguous in the trajectory-major buffers) and pick their
+  // block elements out of LDS; the posterior rows go the other way. Read / written in block layout directly, every memory
+  // instruction of the wave touched 12 - 16 cache lines (four elements of 32 bytes per trajectory), and the sweep was bound by
+  // the line rate of the vector-memory pipeline: 90 instructions x ~12 lines per cell against 14 + 7 x ~9.
+  // The forward rows of a cell are fetched a cell AHEAD into registers (nx) and written to LDS at the top of their cell.
+  // (with them the cell's target: the per-cell one or a discarded dummy -- distinct addresses at the head of the forward-message
+  //  buffer, which this sweep only reads -- through the buffer path and without a branch: a load behind a run-time branch costs an
+  //  s_waitcnt vmcnt(0) right behind it, and memory operations return in order: a load issued after the prefetch waits for all of it)
+  Dbl2 nx[NKF];
+  R nx_zt[NBD];
+  const unsigned pofs = (unsigned)qw.p() * 16u;
+  const Window zw = make_window(c.z_per_cell ? (const void*)a.z : (const void*)a.fwd, (c.z_per_cell ? (unsigned long)T * NZ : 4ul) * B * sizeof(R));
+  const unsigned zcell = c.z_per_cell ? (unsigned)((unsigned long)NZ * B * sizeof(R)) : 0u;
+  unsigned zlane[NBD];
+#pragma unroll
+  for (int j = 0; j < NBD; ++j)
+    zlane[j] = c.z_per_cell ? (unsigned)((((unsigned long)(4 * j + qw.c)) * B + b) * sizeof(R)) : (unsigned)((4 * b + j) * sizeof(R));
+  auto fetch = [&](const int tc) {
+#pragma unroll
+    for (int j = 0; j < NBD; ++j) nx_zt[j] = wld<R>(zw, (unsigned)c.row(tc) * zcell, zlane[j]);
+    const Window w = make_window(a.fwd + (unsigned long)tc * C::E_FWD * B, (unsigned long)C::E_FWD * B * WS);
+    const unsigned bo = (unsigned)b * (unsigned)C::E_FWD * WS + pofs;
+#pragma unroll
+    for (int k = 0; k < NKF; ++k) {
+#ifdef I2C_HOST_SIM
+      if (!(16 * k + 15 < C::E_FWD / 2 || 16 * k + qw.p() < C::E_FWD / 2)) {
+        nx[k] = Dbl2{0.0, 0.0};
+        continue;
+      }
+#endif
+      nx[k] = wld2(w, opaque_uniform((unsigned)k * 256u), bo);  // (the last pass reads past the block: into the next one, or zeros past the window)
+    }
+  };
+  auto commit = [&](const Quad<R>& q) {
+    q.sync();  // (the staged posterior rows of the previous cell have been read)
+#pragma unroll
+    for (int k = 0; k < NKF; ++k) {
+      const int e2 = 16 * k + q.p();
+      if (16 * k + 15 < C::E_FWD / 2 || e2 < C::E_FWD / 2) {
+        st[2 * e2] = nx[k].a;
+        st[2 * e2 + 1] = nx[k].b;
+      }
+    }
+    q.sync();
+  };
+  fetch(T - 1);
+#pragma unroll
+  for (int k = 0; k < NKF; ++k) nx[k].a = opaque(nx[k].a), nx[k].b = opaque(nx[k].b);  // settled before the loop (see forward_wave_body)
+#pragma unroll
+  for (int j = 0; j < NBD; ++j) nx_zt[j] = opaque(nx_zt[j]);
+
+  // state marginal carried along the chain: mean in column form, covariance in UPPER blocks (the diagonal ones full)
+  R m3m[NBX], s3m[NBX * NBX];
+  int fail = 0;
+  auto note = [&](const bool ok, const int reason, const int t) { fail = (fail == 0 && !ok) ? ((reason << 16) | (t + 1)) : fail; };
+  R acc_m = R(0), acc_v = R(0);
+  R ztl[NBD];  // the staged cell's target as loaded
+  for (int t = T; t >= 0; --t) {
+    // iteration T is the end of the chain (i2c.py:546-572): no cell, the terminal state and its statistics (from the rows of cell T - 1,
+    // which stay staged for iteration T - 1: nothing is written at the end of the chain)
+    const int kz = (int)opaque_uniform(0u);
+    const Quad<R> q = q_opaque(qw);
+    const int r = q.r, cc = q.c;
+    const int hi = r > cc ? r : cc, lo = r > cc ? cc : r;
+    const int tri_c = cc * (cc + 1) / 2 + r, tri_d = hi * (hi + 1) / 2 + lo;
+    auto sym_lane = [&](const int i, const int j) { return i == j ? tri_d + 4 * j * hi : tri_c + 4 * j * cc; };
+    auto sym_k = [&](const int i, const int j) { return i == j ? 8 * j * j + 6 * j : 8 * j * j + 2 * j + 4 * i; };
+    const bool up = r <= cc;
+    const bool zsel = opaque_i(c.z_per_cell) != 0;
+    if (t != T - 1) {
+      commit(q);
+#pragma unroll
+      for (int j = 0; j < NBD; ++j) ztl[j] = nx_zt[j];  // (iteration T: the target of cell T - 1, kept for iteration T - 1)
+      fetch(t == T ? (T >= 2 ? T - 2 : 0) : (t >= 1 ? t - 1 : 0));
+    }
+    R m3f[NBX], s3f[NBX * NBX];
+#pragma unroll
+    for (int j = 0; j < NBX; ++j) {
+      m3f[j] = st[cc + O_MU3 + 4 * j + kz];
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) s3f[i * NBX + j] = i <= j ? st[sym_lane(i, j) + O_S3 + sym_k(i, j) + kz] : R(0);
+    }
+    if (t == T) {
+#pragma unroll
+      for (int k = 0; k < NBX; ++k) m3m[k] = m3f[k];
+#pragma unroll
+      for (int k = 0; k < NBX * NBX; ++k) s3m[k] = s3f[k];
+      if (c.has_x_terminal) {
+        // covariance control (i2c.py:548-559): the smoothed terminal state is the product of the TEMPERED filtered state
+        // N(m3f, temp S3f) with the terminal prior N(mu_T, S_T) -- in Kalman form, an identity observation of the state with
+        // noise S_T and target mu_T (see w_end_of_chain, i2c_wave.hpp). temp += dtemp per sweep.
+        const R tmp = a.temp[b];
+        q.sync();  // (every lane has read the temperature before the leading lane advances it)
+        if (lead) a.temp[b] = tmp + c.dtemp;
+        R stt[NBX * NBX], stf[NBX * NBX], sum[NBX * NBX], mz[NBX], zt[NBX];
+#pragma unroll
+        for (int i = 0; i < NBX; ++i) {
+          mz[i] = m3m[i];
+          zt[i] = q_ldv(q, kc.mxT, i, kz);
+#pragma unroll
+          for (int j = i; j < NBX; ++j) stt[i * NBX + j] = tmp * s3m[i * NBX + j];
+        }
+#pragma unroll
+        for (int i = 0; i < NBX; ++i)
+#pragma unroll
+          for (int j = 0; j < NBX; ++j) {
+            stf[i * NBX + j] = j >= i ? stt[i * NBX + j] : q_tr(q, stt[j * NBX + i]);
+            sum[i * NBX + j] = j >= i ? stt[i * NBX + j] + q_ldc<QLD>(q, kc.sxT, i, j, kz) : R(0);
+            if (j < i) stt[i * NBX + j] = R(0);
+          }
+        note(q_kalman<NX, NX>(q, m3m, stt, mz, sum, stf, zt), 6, T - 1);
+#pragma unroll
+        for (int k = 0; k < NBX * NBX; ++k) s3m[k] = stt[k];
+      }
+      // terminal observation statistics (i2c.py:567-570, 989-992): tr(Qf (errT errT^T + sig_z3_m)), identity observation
+      R trT = R(0);
+      if (NZT > 0 && c.has_Qf) {
+        R errT[NBX], pm, pv;
+#pragma unroll
+        for (int j = 0; j < NBX; ++j) errT[j] = m3m[j] - q_ldv(q, kc.zgT, j, kz);
+        q_cost_share<NBX, NBX, QLD>(q, c.qf_diag != 0, kc.qf, errT, s3m, &pm, &pv, kz);
+        trT = q_sum16(q, pm);
+        if (live) {
+#pragma unroll
+          for (int j = 0; j < NBX; ++j) {
+            if (r == 0) a.term_stats[(long)(3 + 4 * j + cc) * B + b] = m3m[j];
+#pragma unroll
+            for (int i = 0; i <= j; ++i)
+              if (i < j || up) a.term_stats[(long)(3 + NT + sym_lane(i, j) + sym_k(i, j)) * B + b] = s3m[i * NBX + j];
+          }
+        }
+      }
+      if (lead) a.term_stats[b] = trT;
+      continue;
+    }
+    // ---- one backward cell (i2c.py:574-608) ---------------------------------------------------------------------------------
+    R mu[NBD], sg[NBD * NBD], jt[NBX * NBD], zt[NBD];
+#pragma unroll
+    for (int j = 0; j < NBD; ++j) {
+      mu[j] = st[cc + 4 * j + kz];
+#pragma unroll
+      for (int i = 0; i < NBD; ++i) sg[i * NBD + j] = i <= j ? st[sym_lane(i, j) + D + sym_k(i, j) + kz] : R(0);
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) jt[i * NBD + j] = st[cc * NX + r + O_J + 4 * j * NX + 4 * i + kz];  // J^T: row = state index, column = joint index
+      const R zgv = q_ldv(q, kc.zg, j, kz);
+      zt[j] = zsel ? ztl[j] : zgv;  // (a select on a per-lane condition: no branch)
+    }
+    if (a.xm && live) {  // (optional output: the smoothed state marginal that enters cell t)
+      S* xo = const_cast<S*>(a.xm) + ((long)t * C::E_XM) * B + b;
+#pragma unroll
+      for (int j = 0; j < NBX; ++j) {
+        if (r == 0) xo[(long)(4 * j + cc) * B] = (S)m3m[j];
+#pragma unroll
+        for (int i = 0; i <= j; ++i)
+          if (i < j || up) xo[(long)(NX + sym_lane(i, j) + sym_k(i, j)) * B] = (S)s3m[i * NBX + j];
+      }
+    }
+    // RTS update of the joint (i2c.py:580-583): mu += J (m3m - m3f), sig += J (S3m - S3f) J^T
+    {
+      R dsf[NBX * NBX], drr[NBX], p1[NBX * NBD];
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) {
+        drr[i] = q_tr(q, m3m[i] - m3f[i]);  // row form
+#pragma unroll
+        for (int j = i; j < NBX; ++j) dsf[i * NBX + j] = s3m[i * NBX + j] - s3f[i * NBX + j];
+      }
+#pragma unroll
+      for (int i = 0; i < NBX; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j) dsf[i * NBX + j] = q_tr(q, dsf[j * NBX + i]);
+#pragma unroll
+      for (int j = 0; j < NBD; ++j) {
+        R ts = R(0);
+#pragma unroll
+        for (int i = 0; i < NBX; ++i) ts += jt[i * NBD + j] * drr[i];
+        mu[j] += q_colsum(q, ts);
+      }
+#pragma unroll
+      for (int k = 0; k < NBX * NBD; ++k) p1[k] = R(0);
+      q_tn<NBX, NBX, NBD>(q, dsf, jt, p1);            // dS J^T
+      q_tn<NBX, NBD, NBD, false, true>(q, jt, p1, sg);  // J (dS J^T), upper blocks
+    }
+    // posterior observation moments = the joint itself (identity observation, i2c.py:594-596) and their expected cost
+    {
+      R err[NBD], pm, pv;
+#pragma unroll
+      for (int j = 0; j < NBD; ++j) err[j] = mu[j] - zt[j];
+      q_cost_share<NBD, NBD, QLD>(q, c.qr_diag != 0, kc.qr, err, sg, &pm, &pv, kz);
+      acc_m += pm;
+      acc_v += pv;
+      if (a.cell_stats) {
+        const R cm = q_sum16(q, pm), cv = q_sum16(q, pv);
+        if (lead) {
+          a.cell_stats[((long)t * 2 + 0) * B + b] = cm;
+          a.cell_stats[((long)t * 2 + 1) * B + b] = cv;
+        }
+      }
+    }
+    q.sync();  // (every lane has picked its forward rows out of the staged block: the posterior rows take its place)
+    // controller (i2c.py:600-608): with [W | Y] = chol(sig_xx)^-1 [I | sig_xu]:  K^T = W^T Y, sigK = sig_uu - Y^T Y
+    {
+      R sxx[NBX * NBX], y[NBX], w3[NBX * NBX], lt[NBX * NBX], kt[NBX], mr[NBX];
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) {
+        y[i] = cc < NU ? sg[i * NBD + JU] : R(0);
+        kt[i] = R(0);
+        mr[i] = q_tr(q, mu[i]);  // the state mean, row form
+#pragma unroll
+        for (int j = 0; j < NBX; ++j) {
+          sxx[i * NBX + j] = j >= i ? sg[i * NBD + j] : R(0);
+          w3[i * NBX + j] = (i == j && r == cc) ? R(1) : R(0);
+        }
+      }
+      note(q_elim<NX, 1, NBX, true>(q, sxx, y, w3, lt), 7, t);
+      R sk = (r < NU && cc < NU) ? sg[JU * NBD + JU] : R(0), tk = R(0);
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) {
+#pragma unroll
+        for (int k = i; k < NBX; ++k) q_mfma(q, w3[k * NBX + i], y[k], kt[i]);  // (W is lower triangular: blocks k >= i)
+        q_mfma(q, -y[i], y[i], sk);
+        tk += kt[i] * mr[i];
+        if (cc < NU) st[cc * NX + r + O_K + 4 * i] = kt[i];  // K[u][x], u = the column, x = 4 i + row
+      }
+      const R kx = q_colsum(q, tk);  // K mu_x, column form over the actions
+      if (r == 0 && cc < NU) st[cc + O_k] = mu[JU] - kx;
+      if (up && cc < NU) st[tri_c + O_SK] = sk;
+    }
+#pragma unroll
+    for (int j = 0; j < NBD; ++j) {
+      if (r == 0) st[cc + 4 * j] = mu[j];
+#pragma unroll
+      for (int i = 0; i <= j; ++i)
+        if (i < j || up) st[sym_lane(i, j) + D + sym_k(i, j)] = sg[i * NBD + j];
+    }
+    q.sync();
+    {  // the posterior rows of the cell, 256 consecutive bytes per trajectory and instruction
+      const Window w = make_window(a.post + (unsigned long)c.row(t) * C::E_POST * B, (unsigned long)C::E_POST * B * WS);
+      const unsigned bo = (unsigned)b * (unsigned)C::E_POST * WS + pofs;
+#pragma unroll
+      for (int k = 0; k < NKP; ++k) {
+        const int e2 = 16 * k + q.p();
+        const bool in = 16 * k + 15 < C::E_POST / 2 || e2 < C::E_POST / 2;
+        const int e2c = in ? e2 : 0;
+        const Dbl2 v{st[2 * e2c], st[2 * e2c + 1]};
+#ifdef I2C_HOST_SIM
+        if (live && in) wst2(w, (unsigned)k * 256u, bo, v);
+#else
+        wst2(w, opaque_uniform((unsigned)k * 256u), (live && in) ? bo : 0x80000000u, v);  // (out of the window: dropped by the buffer unit)
+#endif
+      }
+    }
+    if (a.zpost && live) {
+      S* zo = a.zpost + ((long)t * C::E_ZPOST) * B + b;
+#pragma unroll
+      for (int j = 0; j < NBD; ++j) {
+        if (r == 0) zo[(long)(4 * j + cc) * B] = (S)mu[j];
+#pragma unroll
+        for (int i = 0; i <= j; ++i)
+          if (i < j || up) zo[(long)(NZ + sym_lane(i, j) + sym_k(i, j)) * B] = (S)sg[i * NBD + j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NBX; ++j) {
+      m3m[j] = mu[j];
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) s3m[i * NBX + j] = i <= j ? sg[i * NBD + j] : R(0);
+    }
+  }
+  const R sm = q_sum16(qw, acc_m), sv = q_sum16(qw, acc_v);
+  if (lead) {
+    a.term_stats[B + b] = sm;
+    a.term_stats[2 * B + b] = sv;
+    if (fail != 0 && a.status[b] == 0) a.status[b] = fail;
+  }
+}
+
 }  // namespace i2c

@@ -293,9 +293,9 @@ class BatchedI2c:
         self._problem = self._make_problem()
         # The forward-message buffer is private to the kernel family that writes and reads it: the wave kernels keep it
         # trajectory-major, [T][B][e_fwd] (include/i2c_hip.h); forward_messages() reads it through a view either way.
-        # (the reader decides: the wave backward sweep reads trajectory-major messages, written by the wave or the quad forward sweep)
+        # (the reader decides: the wave and the quad backward sweeps read trajectory-major messages, written by the wave or the quad forward sweep)
         try:
-            self.fwd_trajectory_major = self.kernel_family("backward") == "wave"
+            self.fwd_trajectory_major = self.kernel_family("backward") in ("wave", "quad")  # (quad backward sweep: the d = 16 form only)
             if self.kernel_family("forward") == "wave" and not self.fwd_trajectory_major:
                 raise RuntimeError("the wave forward sweep needs the wave backward sweep (forward-message layout)")
         except RuntimeError as e:  # a problem the library refuses: the sweeps report it (same code) when they are called

@@ -119,8 +119,15 @@ def test_hip_quad_forward_vs_reference_golden(lib, name, tol_d, tol_s):
 
 @pytest.mark.parametrize("name", ["em_quad12_T20", "em_quad12_T12_propagate", "em_quad12_nondiag_T12", "em_quad12_covctrl_T12"])
 def test_hip_quad12_quad_forward_vs_reference_golden(lib, name):
-    """The quad forward kernel on the 12-state quadrotor (next to its wave kernels: LANES_QUAD), wave backward sweep behind it."""
+    """The quad kernels on the 12-state quadrotor (next to its wave kernels: LANES_QUAD), both sweeps."""
     eng = parity.check_against_golden(name, lib, "cuda", 1e-6, 1e-5, group_lanes=parity.pkg._native.LANES_QUAD)
+    assert (eng.forward_family, eng.backward_family) == ("quad", "quad")
+
+
+@pytest.mark.parametrize("name", ["em_quad12_T20", "em_quad12_covctrl_T12"])
+def test_hip_quad12_quad_forward_wave_backward_vs_reference_golden(lib, name):
+    """An explicit two-pass request keeps the wave backward sweep behind the quad forward sweep (same trajectory-major buffers)."""
+    eng = parity.check_against_golden(name, lib, "cuda", 1e-6, 1e-5, group_lanes=parity.pkg._native.LANES_QUAD, backward_mode="two_pass")
     assert (eng.forward_family, eng.backward_family) == ("quad", "wave")
 
 

@@ -136,11 +136,31 @@ def test_hostsim_quad_forward_batch_vs_oracle(lib, name, B):
 
 @pytest.mark.parametrize("name", QUAD12)
 def test_hostsim_quad12_quad_forward_vs_reference_golden(lib, name):
-    """The quad forward kernel on the 12-state quadrotor (d = 16: sixteen pair rows, two evaluation passes, four pivot blocks per
-    factorisation), asked for with LANES_QUAD next to the model's wave kernels; the wave backward sweep reads what it writes
-    (trajectory-major forward messages)."""
+    """The quad kernels on the 12-state quadrotor (d = 16: sixteen pair rows, two evaluation passes, four pivot blocks per
+    factorisation; the backward sweep as the fused walk of four trajectories per wavefront), asked for with LANES_QUAD next to
+    the model's wave kernels; forward messages trajectory-major. The last case: covariance control (tempered terminal prior)."""
     eng = parity.check_against_golden(name, lib, "cpu", 1e-7, 1e-6, group_lanes=parity.pkg._native.LANES_QUAD)
+    assert (eng.forward_family, eng.backward_family) == ("quad", "quad") and eng.fwd_trajectory_major
+
+
+@pytest.mark.parametrize("name", QUAD12)
+def test_hostsim_quad12_quad_forward_wave_backward_vs_reference_golden(lib, name):
+    """An explicit two-pass request keeps the wave backward sweep behind the quad forward sweep (same buffers)."""
+    eng = parity.check_against_golden(name, lib, "cpu", 1e-7, 1e-6, group_lanes=parity.pkg._native.LANES_QUAD, backward_mode="two_pass")
     assert (eng.forward_family, eng.backward_family) == ("quad", "wave") and eng.fwd_trajectory_major
+
+
+def test_hostsim_quad12_quad_backward_cell_statistics(lib):
+    """The per-cell cost statistics (an optional output of the fused walks: [T][2][B]) of the quad backward sweep add up to the
+    sums it reports, and agree with the wave form's."""
+    stats = {}
+    for lanes in (parity.pkg._native.LANES_QUAD, 64):
+        eng = parity.engine_from_case(load_case("em_quad12_nondiag_T12"), lib, "cpu", group_lanes=lanes)
+        eng.cell_stats = torch.zeros(eng.H, 2, eng.B, dtype=torch.float64)
+        eng.forward_backward()
+        stats[lanes] = (parity.np_(eng.cell_stats), parity.np_(eng.term_stats))
+        np.testing.assert_allclose(stats[lanes][0].sum(0)[:, 0], stats[lanes][1][1:3, 0], rtol=1e-12)
+    np.testing.assert_allclose(stats[64][0], stats[parity.pkg._native.LANES_QUAD][0], rtol=1e-9)
 
 
 def test_hostsim_quad12_quad_forward_batch_vs_oracle(lib):

@@ -155,6 +155,13 @@ def test_mpc_replay_full_horizon_batched_cpu():
     assert pol.engine.forward_family == "quad"
 
 
+def test_mpc_replay_full_horizon_quad12_quad_sweeps_cpu():
+    """Config 4's closed loop with BOTH sweeps on the quad kernels (the default from 4096 trajectories up; asked for here): ring
+    of per-cell buffers, per-cell targets and temperatures, one-call control step, a ragged batch of three loops."""
+    pol = _replay_batched("mpc_quad12_fb_H50", hostsim.load(), "cpu", 1e-7, 3, group_lanes=parity.pkg._native.LANES_QUAD)
+    assert (pol.engine.forward_family, pol.engine.backward_family) == ("quad", "quad")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,B,fam", [("mpc_quad12_fb_H50", 8192, "quad"), ("mpc_quad12_fb_H50", 1024, "wave"), ("mpc_quadrotor_fb_H50", 8192, "quad"),
                                         ("mpc_quadrotor_fb_H50", 1024, "quad")])
@@ -162,6 +169,8 @@ def test_mpc_replay_full_horizon_batched_gpu(name, B, fam):
     """BASELINE config 4's shapes (B = 8192: the whole config on one GPU; 1024: one GPU's share of it), against the reference."""
     pol = _replay_batched(name, None, "cuda", 1e-6, B)
     assert pol.engine.forward_family == fam
+    if name == "mpc_quad12_fb_H50":  # (the 12-state model's backward sweep: quad from 4096 trajectories up, wave below)
+        assert pol.engine.backward_family == ("quad" if B >= 4096 else "wave")
 
 
 # mpc_quad12_fb above runs the 12-state quadrotor's default, the wave kernels; the same replay on its group kernels
