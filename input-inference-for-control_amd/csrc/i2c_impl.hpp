@@ -380,9 +380,13 @@ __global__ __launch_bounds__(64 * quad_waves_per_block<M>(), 2) void k_quad_forw
   }
   if (b0 >= c.B) return;  // (wave-uniform: no trajectory in this wave)
   const long b = b0 + g;
+#ifdef I2C_QF_NOSTORE  // (experiment, never shipped: the sweep without its stores -- how much of it is the store path)
+  const bool live = false;
+#else
   const bool live = b < c.B;
+#endif
   const Quad<R> q{l, l >> 4, g, l & 3, (lds_ptr<R>)(sh + (wv * 4 + g) * QG<M>::SIZE)};
-  forward_quad_body<M, R, S>(c, kc, a, (int)(live ? b : c.B - 1), live, q);
+  forward_quad_body<M, R, S>(c, kc, a, (int)(b < c.B ? b : c.B - 1), live, q);
 }
 template <class M, typename R, typename S, class A>
 static int launch_quad_forward(const Consts<M, R>& c, const A& a, void* stream) {
