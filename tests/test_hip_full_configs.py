@@ -124,7 +124,7 @@ def test_config4_quadrotor_mpc_H50_B8192():
 @pytest.mark.parametrize("lanes,B", [(0, 8192), (64, 8192), (16, 8192), (0, 1024)])
 def test_config4_quadrotor12_sweeps_H50_vs_oracle(lanes, B):
     """BASELINE config 4 at nx = 12 (d = 16): the EM sweeps at horizon 50 and 8192 trajectories (the whole config on one GPU)
-    or 1024 (one GPU's share of it) on the default kernels (quad forward + wave backward at 8192, wave kernels at 1024), on the
+    or 1024 (one GPU's share of it) on the default kernels (quad forward + quad backward at 8192, wave kernels at 1024), on the
     wave kernels throughout and on the group kernels, a subset compared with the CPU
     oracle (the oracle is pinned to the reference solver on this model by em_quad12_T20 / em_quad12_T12_propagate), planted
     duplicates bit-identical, and closed-loop propagation on the whole batch."""
@@ -134,8 +134,8 @@ def test_config4_quadrotor12_sweeps_H50_vs_oracle(lanes, B):
     mu_u = np.tile(g["mu_u"][:1], (T, 1)) + 1e-2 * rng.normal(size=(T, 4))
     big = Case({**g, "meta": np.array(json.dumps(dict(g.meta, T=T))), "mu_u": mu_u})
     eng = _subset_vs_oracle(big, B, 6, 3, 1e-6, plant=(B // 2 + 1, B - 1), group_lanes=lanes)
-    # the default: quad forward sweep from 2048 trajectories up, wave kernels below and for the backward sweep
-    fam = {16: ("group", "group"), 64: ("wave", "wave"), 0: ("quad" if B >= 2048 else "wave", "wave")}[lanes]
+    # the default: quad forward sweep from 2048 trajectories up, quad backward sweep from 4096 up, wave kernels below
+    fam = {16: ("group", "group"), 64: ("wave", "wave"), 0: ("quad" if B >= 2048 else "wave", "quad" if B >= 4096 else "wave")}[lanes]
     assert (eng.forward_family, eng.backward_family) == fam and eng.post.shape == (50, 214, B)
     eng._propagate = True
     eng.propagate()
