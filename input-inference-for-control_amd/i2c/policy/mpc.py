@@ -175,6 +175,28 @@ class PartiallyObservedMpcPolicy(MpcPolicy):
         a = np.broadcast_to(np.asarray(a, dtype=float).reshape(-1, n), (self.B, n))
         return torch.as_tensor(np.array(a.T, order="C"), dtype=e.dtype, device=e.device)
 
+    # The per-step host <-> device traffic of the batched loop: the measurement and the applied action go up in ONE copy from a
+    # page-locked staging buffer, the first planned action comes down into one (a pageable numpy array costs a staging copy and a
+    # synchronisation per transfer: three of them were a sixth of a planar-quadrotor control step at B = 1024)
+    def _stage_yu(self, y, u):
+        e = self.engine
+        ny, nu = e.dims.ny, e.nu
+        if getattr(self, "_yu_host", None) is None:
+            self._yu_host = torch.empty(ny + nu, self.B, dtype=e.dtype, pin_memory=e.device.type == "cuda")
+            self._yu_np = self._yu_host.numpy()
+            self._yu_dev = torch.empty(ny + nu, self.B, dtype=e.dtype, device=e.device)
+        self._yu_np[:ny] = np.broadcast_to(np.asarray(y, dtype=float).reshape(-1, ny), (self.B, ny)).T
+        self._yu_np[ny:] = np.broadcast_to(np.asarray(u, dtype=float).reshape(-1, nu), (self.B, nu)).T
+        self._yu_dev.copy_(self._yu_host, non_blocking=True)  # (the staging buffer is reused only after this step's action has come back)
+        return self._yu_dev[:ny], self._yu_dev[ny:]
+
+    def _read_action(self):
+        e = self.engine
+        if getattr(self, "_act_host", None) is None:
+            self._act_host = torch.empty(e.nu, self.B, dtype=e.dtype, pin_memory=e.device.type == "cuda")
+        self._act_host.copy_(e._mpc_action[: e.nu])  # (contiguous rows; blocks until the step has run)
+        return np.array(self._act_host.numpy().T, dtype=float)
+
     def filter(self, y, u):
         """mpc.py:125-145. y: (dim_y, 1) or (B, dim_y); u: (dim_u, 1) or (B, dim_u)."""
         e = self.engine
@@ -206,11 +228,13 @@ class PartiallyObservedMpcPolicy(MpcPolicy):
                 sig_zeta = self.i2c.sys.sig_zeta
                 if sig_zeta is None:
                     raise ValueError("sys.sig_zeta (measurement noise) must be set before filtering")
-                mu_u, sig_u = e.mpc_step(self.n_iter, self._dev(y, e.dims.ny), self._dev(u, e.nu), sig_zeta,
-                                         z_new=self._next_target(i))
+                yd, ud = self._stage_yu(y, u)
+                mu_u, sig_u = e.mpc_step(self.n_iter, yd, ud, sig_zeta, z_new=self._next_target(i))
             else:
                 mu_u, sig_u = e.mpc_step(self.n_iter, z_new=self._next_target(i))
             self.i2c._invalidate()
+            if deterministic:
+                return self._squeeze(self._read_action(), column=True)
             return self._squeeze(self._sample_or_mean(mu_u, sig_u, deterministic), column=True)
         if i > 0:
             self.filter(y, u)
