@@ -303,6 +303,22 @@ def extra_config_legs(pkg, device, K=10):
         out[tag] = {"ms_per_step": ms, "value": Bn * Tn / ms * 1e3, "unit": "timestep-messages/s", "algorithmic_GBps": gb,
                     "frac_of_hbm_peak": gb / HBM_PEAK_GBS, "forward_family": eng.forward_family, "backward_family": eng.backward_family,
                     "backward": eng.backward_schedule, "failed_trajectories": len(eng.failures())}
+        if name == "Quadrotor12":  # its sweeps alone, event-timed, and the issue side of the forward one (the quad kernel: issue-bound)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            sync(); evs[0].record()
+            for _ in range(3):
+                eng.forward_sweep()
+            evs[1].record()
+            for _ in range(3):
+                eng.backward_sweep()
+            evs[2].record(); sync()
+            fwd_ms, bwd_ms = evs[0].elapsed_time(evs[1]) / 3, evs[1].elapsed_time(evs[2]) / 3
+            C = eng.dims
+            out[tag]["forward_sweep_ms"], out[tag]["backward_sweep_ms"] = fwd_ms, bwd_ms
+            out[tag]["backward_sweep_algorithmic_GBps"] = (C.e_fwd + C.e_post) * 8 * Bn * Tn / bwd_ms / 1e6
+            out[tag]["issue"] = issue_roofline("r4_quad12_B32768_quad_vs_wave", "k_quad_forward", Tn, 16, fwd_ms, Bn * Tn)
+            if out[tag]["issue"]:  # (d = 16 has no one-lane kernel to count the non-redundant flops with)
+                out[tag]["issue"]["useful_flops_basis"] = "executed flops of this kernel (sixteen lanes per trajectory: an upper bound of the useful count)"
         del eng, mu_u, x0
         torch.cuda.empty_cache()
 
@@ -579,7 +595,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": measured_traffic(B, T, args.dtype, "k_forward"),
             "traffic_note": "bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                            "(FETCH_SIZE x2, gfx950 correction; profiles/r3_B*_pmc_traffic.json); algorithmic = "
+                            "(FETCH_SIZE x2, gfx950 correction; profiles/r4_B4096_pmc_traffic.json); algorithmic = "
                             + str(fwd_bytes),
             "algorithmic_bytes_per_cell": {k: v * wbytes for k, v in el.items()},
             "whole_iteration_GBps": el["total"] * wbytes * B * T / (elapsed / K) / 1e9,

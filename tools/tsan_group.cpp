@@ -2,14 +2,15 @@
 // wave kernel's wavefront -- run as threads with a barrier wherever the device code has its LDS fence or a cross-lane
 // instruction, so a missing fence shows up here as a data race on the exchange region. Drives forward, backward, propagation and
 // the filter step of the 12-state quadrotor through the C ABI on a tiny problem: group kernels (16 lanes per trajectory), wave
-// kernels (cubature), wave kernels (Linearize), quad forward kernel + wave backward. Built and run by tools/tsan_group.sh.
+// kernels (cubature), wave kernels (Linearize), quad forward + quad backward kernels (plain and with the terminal state prior of
+// covariance control), quad forward + wave backward. Built and run by tools/tsan_group.sh.
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <vector>
 #include "../include/i2c_hip.h"
 
-static int run(const int group_lanes, const int inference, const int post_layout = 0) {
+static int run(const int group_lanes, const int inference, const int post_layout = 0, const bool cov_control = false, const int backward_mode = I2C_BWD_AUTO) {
   I2cDims d;
   if (i2c_query(I2C_MODEL_QUADROTOR12, &d) != I2C_OK) return 2;
   const int B = 3, T = 4, nx = d.nx, nu = d.nu, nz = d.nz, D = nx + nu;
@@ -27,6 +28,14 @@ static int run(const int group_lanes, const int inference, const int post_layout
   p.post_layout = post_layout;  // 1: trajectory-major posterior (what the quad forward kernel of this model addresses)
   p.quad_alpha = 1.0;
   p.dtemp = 1.0;
+  p.backward_mode = backward_mode;
+  if (cov_control) {
+    p.has_x_terminal = 1;
+    for (int i = 0; i < 12; ++i) {
+      p.mu_x_term[i] = 0.05 * i;
+      p.sig_x_term[i * (i + 1) / 2 + i] = 1e-3;
+    }
+  }
   auto diag = [](double* packed, int n, double v) {
     for (int i = 0; i < n; ++i) packed[i * (i + 1) / 2 + i] = v;
   };
@@ -48,6 +57,7 @@ static int run(const int group_lanes, const int inference, const int post_layout
   std::vector<double> post((size_t)T * d.e_post * B, 0.0), fwd((size_t)T * d.e_fwd * B), prop((size_t)T * d.e_prop * B), pstat(3 * B);
   std::vector<double> term((size_t)(4 + d.nzt + d.nzt * (d.nzt + 1) / 2) * B), stats(4 * B);
   std::vector<int32_t> status(B, 0);
+  std::vector<double> xm((size_t)T * (nx + nx * (nx + 1) / 2) * B), cstat((size_t)T * 2 * B);
   for (int t = 0; t < T; ++t)
     for (int b = 0; b < B; ++b) {
       const size_t es = post_layout ? 1 : (size_t)B;  // element stride
@@ -64,7 +74,8 @@ static int run(const int group_lanes, const int inference, const int post_layout
   int rc = 0;
   for (int it = 0; it < 2 && rc == 0; ++it) {
     rc = i2c_forward_sweep(&p, post.data(), fwd.data(), nullptr, status.data(), nullptr);
-    if (!rc) rc = i2c_backward_sweep(&p, fwd.data(), nullptr, post.data(), nullptr, nullptr, term.data(), status.data(), nullptr);
+    if (!rc) rc = i2c_backward_sweep(&p, fwd.data(), backward_mode == I2C_BWD_TWO_PASS ? xm.data() : nullptr, post.data(), nullptr,
+                                     backward_mode == I2C_BWD_TWO_PASS ? cstat.data() : nullptr, term.data(), status.data(), nullptr);
     if (!rc) rc = i2c_mstep(&p, term.data(), 0.5, 1, stats.data(), nullptr);
     if (!rc && inference == I2C_INF_CUBATURE) rc = i2c_propagate(&p, post.data(), prop.data(), pstat.data(), 1, status.data(), nullptr);
   }
@@ -83,6 +94,8 @@ int main() {
   int bad = run(16, I2C_INF_CUBATURE);
   bad += run(64, I2C_INF_CUBATURE);
   bad += run(64, I2C_INF_LINEARIZE);
-  bad += run(I2C_LANES_QUAD, I2C_INF_CUBATURE, 1);  // quad forward kernel (four trajectories per wavefront: 3 + one spare slot) + wave backward
+  bad += run(I2C_LANES_QUAD, I2C_INF_CUBATURE, 1);        // quad kernels, both sweeps (four trajectories per wavefront: 3 + one spare slot)
+  bad += run(I2C_LANES_QUAD, I2C_INF_CUBATURE, 1, true);  // ... with the tempered terminal state prior at the end of the backward chain
+  bad += run(I2C_LANES_QUAD, I2C_INF_CUBATURE, 1, false, I2C_BWD_TWO_PASS);  // quad forward kernel + wave backward sweep (two-pass schedule)
   return bad;
 }
