@@ -582,7 +582,7 @@ template <class M, typename R, typename S = R> struct Impl {
   static constexpr bool HAS_GROUP = G > 0 && sizeof(R) == 8 && !MIXED;
   static constexpr bool LANE = !M::GROUP_ONLY;  // one-lane-per-trajectory kernels exist
   static constexpr bool HAS_WAVE = M::WAVE && sizeof(R) == 8;  // fp64 matrix instruction; the storage type S may be float
-  static constexpr bool HAS_QUAD = M::QUAD && sizeof(R) == 8 && !MIXED;  // fp64 matrix instruction (i2c_quad.hpp): forward sweep
+  static constexpr bool HAS_QUAD = M::QUAD && sizeof(R) == 8;  // fp64 matrix instruction (i2c_quad.hpp): forward sweep; the storage type S may be float
   static constexpr bool HAS_QUAD_BACKWARD = HAS_QUAD && quad_backward_exists<M>();  // ... and, for d = 16, the backward sweep
 
   // 1: group kernels, 0: one lane per trajectory, < 0: error code
@@ -733,6 +733,9 @@ template <class M, typename R, typename S = R> struct Impl {
       if (fam == I2C_FAMILY_WAVE) {
         if constexpr (HAS_WAVE) return launch_wave<WK_FORWARD, M, R, S>(c, am, stream);
       }
+      if (fam == I2C_FAMILY_QUAD) {
+        if constexpr (HAS_QUAD) return launch_quad_forward<M, R, S>(c, am, stream);
+      }
       return forward_lane(p, c, am, stream);
     } else {
       return forward_any(p, c, prior, fwd, prior_out, status, stream);
@@ -820,6 +823,9 @@ template <class M, typename R, typename S = R> struct Impl {
       CellArgs<R, S> am{(const S*)fwd, (const S*)xm,   (const R*)p->z, (S*)post,  (S*)zpost,
                         (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   terminal_alpha(p, c)};
       if (fam == I2C_FAMILY_WAVE) return backward_wave(p, c, am, ms, fuse, stream);
+      if (fam == I2C_FAMILY_QUAD) {
+        if constexpr (HAS_QUAD_BACKWARD) return launch_quad_backward<M, R, S>(c, am, stream);
+      }
       return backward_lane(p, c, am, ms, fuse, stream);
     } else {
       return backward_any(p, c, ms, fwd, xm, post, zpost, cell_stats, term_stats, status, stream, fuse);

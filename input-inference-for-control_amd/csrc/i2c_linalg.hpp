@@ -275,16 +275,16 @@ template <typename R> I2C_FN void wst(const Window& w, unsigned row_off, unsigne
   *reinterpret_cast<R*>(w.p + row_off + lane_off) = v;
 }
 I2C_FN unsigned wld_u8(const Window& w, unsigned off) { return *reinterpret_cast<const unsigned char*>(w.p + off); }
-// two consecutive doubles in one access (16-byte aligned offsets)
-struct Dbl2 {
-  double a, b;
+// two consecutive elements in one access (offsets aligned to the pair)
+template <typename S> struct Pair2 {
+  S a, b;
 };
-I2C_FN Dbl2 wld2(const Window& w, unsigned row_off, unsigned lane_off) {
-  const double* q = reinterpret_cast<const double*>(w.p + row_off + lane_off);
-  return Dbl2{q[0], q[1]};
+template <typename S> I2C_FN Pair2<S> wld2(const Window& w, unsigned row_off, unsigned lane_off) {
+  const S* q = reinterpret_cast<const S*>(w.p + row_off + lane_off);
+  return Pair2<S>{q[0], q[1]};
 }
-I2C_FN void wst2(const Window& w, unsigned row_off, unsigned lane_off, Dbl2 v) {
-  double* q = reinterpret_cast<double*>(w.p + row_off + lane_off);
+template <typename S> I2C_FN void wst2(const Window& w, unsigned row_off, unsigned lane_off, Pair2<S> v) {
+  S* q = reinterpret_cast<S*>(w.p + row_off + lane_off);
   q[0] = v.a, q[1] = v.b;
 }
 #else
@@ -321,18 +321,29 @@ I2C_FN void wst(const Window& w, unsigned row_off, unsigned lane_off, double v) 
 I2C_FN void wst(const Window& w, unsigned row_off, unsigned lane_off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), w.r, lane_off, uniform_u32(row_off), 0);
 }
-// two consecutive doubles in one access (buffer_load / store_dwordx4; 16-byte aligned offsets)
-struct Dbl2 {
-  double a, b;
+// two consecutive elements in one access (doubles: buffer_load / store_dwordx4; floats: dwordx2; offsets aligned to the pair)
+template <typename S> struct Pair2 {
+  S a, b;
 };
-I2C_FN Dbl2 wld2(const Window& w, unsigned row_off, unsigned lane_off) {
-  typedef unsigned v4u __attribute__((ext_vector_type(4)));
-  const v4u v = __builtin_amdgcn_raw_buffer_load_b128(w.r, lane_off, uniform_u32(row_off), 0);
-  return __builtin_bit_cast(Dbl2, v);
+template <typename S> I2C_FN Pair2<S> wld2(const Window& w, unsigned row_off, unsigned lane_off) {
+  if constexpr (sizeof(S) == 8) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(w.r, lane_off, uniform_u32(row_off), 0);
+    return __builtin_bit_cast(Pair2<S>, v);
+  } else {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(w.r, lane_off, uniform_u32(row_off), 0);
+    return __builtin_bit_cast(Pair2<S>, v);
+  }
 }
-I2C_FN void wst2(const Window& w, unsigned row_off, unsigned lane_off, Dbl2 v) {
-  typedef unsigned v4u __attribute__((ext_vector_type(4)));
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), w.r, lane_off, uniform_u32(row_off), 0);
+template <typename S> I2C_FN void wst2(const Window& w, unsigned row_off, unsigned lane_off, Pair2<S> v) {
+  if constexpr (sizeof(S) == 8) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), w.r, lane_off, uniform_u32(row_off), 0);
+  } else {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), w.r, lane_off, uniform_u32(row_off), 0);
+  }
 }
 #endif
 

@@ -1127,7 +1127,7 @@ I2C_HD inline void backward_quad_body(const Consts<M, R>& c, const KC& kc, const
   static_assert(G::WIDE && NX % 4 == 0 && D % 4 == 0 && NU <= 4 && NBD == NBX + 1, "quad backward sweep: d = 16, the actions in a block column of their own");
   static_assert(NZ == D && st_identity<ObsStruct<M>, NZ>(), "quad backward sweep: identity observation of the joint");
   static_assert(NZT == 0 || (NT == NX && st_identity<TermStruct<M>, NT>()), "quad backward sweep: identity terminal observation");
-  static_assert(sizeof(S) == 8 && C::E_FWD % 2 == 0 && C::E_POST % 2 == 0, "quad backward sweep: cell blocks move as pairs of doubles");
+  static_assert(C::E_FWD % 2 == 0 && C::E_POST % 2 == 0, "quad backward sweep: cell blocks move as pairs of elements");
   constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
   constexpr int O_K = D + sym(D), O_k = O_K + NU * NX, O_SK = O_k + NU;
   constexpr int NKF = (C::E_FWD / 2 + 15) / 16, NKP = (C::E_POST / 2 + 15) / 16;  // 16-lane passes over a cell block, two doubles per lane
@@ -1146,9 +1146,9 @@ I2C_HD inline void backward_quad_body(const Consts<M, R>& c, const KC& kc, const
   // (with them the cell's target: the per-cell one or a discarded dummy -- distinct addresses at the head of the forward-message
   //  buffer, which this sweep only reads -- through the buffer path and without a branch: a load behind a run-time branch costs an
   //  s_waitcnt vmcnt(0) right behind it, and memory operations return in order: a load issued after the prefetch waits for all of it)
-  Dbl2 nx[NKF];
+  Pair2<S> nx[NKF];
   R nx_zt[NBD];
-  const unsigned pofs = (unsigned)qw.p() * 16u;
+  const unsigned pofs = (unsigned)qw.p() * 2u * WS;  // (a lane moves two elements per pass: 32 elements per trajectory and instruction)
   const Window zw = make_window(c.z_per_cell ? (const void*)a.z : (const void*)a.fwd, (c.z_per_cell ? (unsigned long)T * NZ : 4ul) * B * sizeof(R));
   const unsigned zcell = c.z_per_cell ? (unsigned)((unsigned long)NZ * B * sizeof(R)) : 0u;
   unsigned zlane[NBD];
@@ -1164,11 +1164,11 @@ I2C_HD inline void backward_quad_body(const Consts<M, R>& c, const KC& kc, const
     for (int k = 0; k < NKF; ++k) {
 #ifdef I2C_HOST_SIM
       if (!(16 * k + 15 < C::E_FWD / 2 || 16 * k + qw.p() < C::E_FWD / 2)) {
-        nx[k] = Dbl2{0.0, 0.0};
+        nx[k] = Pair2<S>{S(0), S(0)};
         continue;
       }
 #endif
-      nx[k] = wld2(w, opaque_uniform((unsigned)k * 256u), bo);  // (the last pass reads past the block: into the next one, or zeros past the window)
+      nx[k] = wld2<S>(w, opaque_uniform((unsigned)k * 32u * WS), bo);  // (the last pass reads past the block: into the next one, or zeros past the window)
     }
   };
   auto commit = [&](const Quad<R>& q) {
@@ -1177,8 +1177,8 @@ I2C_HD inline void backward_quad_body(const Consts<M, R>& c, const KC& kc, const
     for (int k = 0; k < NKF; ++k) {
       const int e2 = 16 * k + q.p();
       if (16 * k + 15 < C::E_FWD / 2 || e2 < C::E_FWD / 2) {
-        st[2 * e2] = nx[k].a;
-        st[2 * e2 + 1] = nx[k].b;
+        st[2 * e2] = (R)nx[k].a;
+        st[2 * e2 + 1] = (R)nx[k].b;
       }
     }
     q.sync();
@@ -1381,11 +1381,11 @@ I2C_HD inline void backward_quad_body(const Consts<M, R>& c, const KC& kc, const
         const int e2 = 16 * k + q.p();
         const bool in = 16 * k + 15 < C::E_POST / 2 || e2 < C::E_POST / 2;
         const int e2c = in ? e2 : 0;
-        const Dbl2 v{st[2 * e2c], st[2 * e2c + 1]};
+        const Pair2<S> v{(S)st[2 * e2c], (S)st[2 * e2c + 1]};
 #ifdef I2C_HOST_SIM
-        if (live && in) wst2(w, (unsigned)k * 256u, bo, v);
+        if (live && in) wst2<S>(w, (unsigned)k * 32u * WS, bo, v);
 #else
-        wst2(w, opaque_uniform((unsigned)k * 256u), (live && in) ? bo : 0x80000000u, v);  // (out of the window: dropped by the buffer unit)
+        wst2<S>(w, opaque_uniform((unsigned)k * 32u * WS), (live && in) ? bo : 0x80000000u, v);  // (out of the window: dropped by the buffer unit)
 #endif
       }
     }

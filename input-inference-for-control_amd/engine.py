@@ -114,10 +114,8 @@ class BatchedI2c:
         self.uses_group_kernels = bool((self.group_lanes > 0 and not self.quad_requested) or dims.group_only)  # a multi-lane family (group or wave) serves the sweeps
         if self.mixed and inference != "cubature":
             raise ValueError("fp32 storage (storage_dtype) is available for the cubature path only")
-        if self.mixed and self.quad_requested:
-            raise ValueError("fp32 storage (storage_dtype) is not available for the quad forward kernel")
-        if self.mixed and self.uses_group_kernels and not (dims.wave and self.group_lanes in (0, 64)):
-            raise ValueError("fp32 storage (storage_dtype) is available for the one-lane kernels and the wave kernels only")
+        if self.mixed and self.uses_group_kernels and not (dims.wave and self.group_lanes in (0, 64, _native.LANES_QUAD)):
+            raise ValueError("fp32 storage (storage_dtype) is available for the one-lane, the quad and the wave kernels only")
 
         mu_u = np.asarray(mu_u, dtype=np.float64)
         if mu_u.ndim == 2:

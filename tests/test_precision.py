@@ -62,7 +62,7 @@ def _sweep(name, lib, device, B, iters, **kw):
 # perturbation (measured on MI355X: worst trajectory 0.35 pendulum / 0.5 double cartpole, fp32 arithmetic 0.5 / 1.1),
 # so the worst case is reported, not bounded; the distribution is what is asserted
 # (measured: median 5e-6 / 1e-4, 99th percentile 3e-3 / 5e-3, median cost deviation 6e-7 / 9e-6).
-MIXED_BOUNDS = {"em_pendulum_T200": (1e-4, 3e-2, 1e-5), "em_dcp_T300_run20": (1e-3, 3e-2, 1e-4),
+MIXED_BOUNDS = {"em_pendulum_T200": (1e-4, 3e-2, 1e-5), "em_dcp_T300_run20": (1e-3, 3e-2, 1e-4), "em_dcp_T60": (1e-3, 3e-2, 1e-4),
                 "em_quad12_T20": (1e-4, 1e-3, 1e-5)}  # 12-state quadrotor, wave kernels: 10 KB of messages per cell, the most HBM-hungry
 
 
@@ -97,6 +97,20 @@ def test_mixed_precision_wave_kernels_cpu():
         parity.engine_from_case(load_case("em_quad12_T20"), hostsim.load(), "cpu", storage_dtype=torch.float32, group_lanes=16)
 
 
+def test_mixed_precision_quad_kernels_cpu():
+    """fp32-stored messages through the quad kernels (round 4, late): the forward sweep of the d <= 8 models (the default of the
+    double cartpole up to 8192 trajectories: without it the opt-in mode ran the slower lane forward sweep there) and both sweeps of
+    the 12-state quadrotor (cell blocks staged through LDS as pairs of floats)."""
+    rows, eng = _sweep("em_dcp_T60", hostsim.load(), "cpu", 5, 3, storage_dtype=torch.float32)
+    assert eng.forward_family == "quad" and eng.fwd.dtype == torch.float32
+    _check_mixed("em_dcp_T60", hostsim.load(), "cpu", 5, 3)
+    rows, eng = _sweep("em_quad12_T20", hostsim.load(), "cpu", 5, 3, storage_dtype=torch.float32, group_lanes=parity.pkg._native.LANES_QUAD)
+    assert (eng.forward_family, eng.backward_family) == ("quad", "quad") and eng.post.dtype == torch.float32
+    b_med, b_p99, b_cost = MIXED_BOUNDS["em_quad12_T20"]
+    for r in rows:
+        assert r["mean_median"] <= b_med and r["mean_p99"] <= b_p99 and r["cost_median"] <= b_cost, r
+
+
 def test_mixed_precision_schedules_agree_cpu():
     """fp32 storage goes through the same three backward schedules; with fp32-stored messages they agree to storage
     rounding (not bit for bit: the chunked schedule composes the recursion in fp64 across cells)."""
@@ -123,6 +137,18 @@ def test_mixed_precision_bounds_full_config_gpu(name, iters):
     for r in rows:
         print(name, "it %2d: mean deviation median %.1e p99 %.1e max %.1e | cost median %.1e max %.1e" %
               (r["it"], r["mean_median"], r["mean_p99"], r["mean"], r["cost_median"], r["cost"]))
+
+
+@pytest.mark.gpu
+def test_mixed_precision_quad_kernels_gpu():
+    """The 12-state quadrotor at a batch whose default is the quad family for both sweeps."""
+    rows, eng = _sweep("em_quad12_T20", None, "cuda", 8192, 6, storage_dtype=torch.float32)
+    assert (eng.forward_family, eng.backward_family) == ("quad", "quad") and eng.post.dtype == torch.float32
+    b_med, b_p99, b_cost = MIXED_BOUNDS["em_quad12_T20"]
+    for r in rows:
+        assert r["mean_median"] <= b_med and r["mean_p99"] <= b_p99 and r["cost_median"] <= b_cost, r
+        print("quad12 quad, fp32 storage, it %d: mean deviation median %.1e p99 %.1e max %.1e | cost median %.1e" %
+              (r["it"], r["mean_median"], r["mean_p99"], r["mean"], r["cost_median"]))
 
 
 @pytest.mark.gpu

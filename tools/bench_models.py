@@ -1,5 +1,5 @@
 """Time one EM iteration (forward / backward / M-step) for any model:
-python tools/bench_models.py [model ...] [B ...] [two_pass|fused|chunked ...] [f64] [group] [lane] [wave]
+python tools/bench_models.py [model ...] [B ...] [two_pass|fused|chunked ...] [f64] [f32s] [group] [lane] [wave] [quad]
 `group` runs the group kernels (G lanes per trajectory) as well where a model has both forms; `lane` forces one lane per
 trajectory for every sweep (the default runs the forward sweep of the d >= 7 models on the group kernels at small batches);
 `wave` runs the matrix-instruction kernels where a model has them (group_lanes = 64: one wavefront per trajectory for the 12-state
@@ -28,7 +28,7 @@ CONFIGS = {  # hyper-parameters of the reference's experiment files
 }
 
 
-def run(name, B, dtype, iters=10, mode="auto", group=0):
+def run(name, B, dtype, iters=10, mode="auto", group=0, storage=None):
     cfg = CONFIGS[name]
     model = make_env_model(name)
     T, nu = cfg["T"], model.dim_u
@@ -38,6 +38,7 @@ def run(name, B, dtype, iters=10, mode="auto", group=0):
     mu_u = base + cfg["mu_u"] * rng.normal(size=(B, T, nu))
     eng = pkg.BatchedI2c(model, T, cfg["Q"], cfg["R"], cfg["Q"], cfg["alpha"], cfg["tol"], mu_u, cfg["sig_u"] * np.eye(nu), x0=x0,
                          dtype=dtype, keep_zpost=False, keep_xm=False, backward_mode=mode, group_lanes=group, allow_inexact=True,
+                         **({"storage_dtype": storage} if storage is not None else {}),
                          lib=pkg.load_library(os.environ["I2C_BENCH_LIB"]) if os.environ.get("I2C_BENCH_LIB") else None)
     for _ in range(3):
         eng.learn_msgs()
@@ -48,10 +49,10 @@ def run(name, B, dtype, iters=10, mode="auto", group=0):
     torch.cuda.synchronize()
     ms = [np.mean([ev[i][j].elapsed_time(ev[i][j + 1]) for i in range(iters)]) for j in range(3)]
     d = eng.dims
-    w = 8 if dtype == torch.float64 else 4
+    w = 4 if (storage == torch.float32 or dtype != torch.float64) else 8
     el = (d.e_post - nu - nu * (nu + 1) // 2) + 2 * d.e_fwd + d.e_post
     tot = sum(ms)
-    print(f"{name:22s} B={B:6d} T={T:3d} {str(dtype)[6:]:8s} fwd {ms[0]:8.3f} bwd {ms[1]:8.3f} mstep {ms[2]:6.3f} ms | "
+    print(f"{name:22s} B={B:6d} T={T:3d} {('f64/f32s' if storage == torch.float32 else str(dtype)[6:]):8s} fwd {ms[0]:8.3f} bwd {ms[1]:8.3f} mstep {ms[2]:6.3f} ms | "
           f"[{eng.backward_schedule:8s} {eng.forward_family:5s}/{eng.backward_family:5s}] {B * T / tot * 1e3:10.3e} msg/s | {el * w * B * T / tot / 1e6:8.1f} GB/s | fails {len(eng.failures())}")
 
 
@@ -83,3 +84,5 @@ if __name__ == "__main__":
                         if grp == -1 and n == "Quadrotor12":
                             grp = 0
                         run(n, B, dt, mode=m, group=grp)
+                        if "f32s" in sys.argv[1:] and dt == torch.float64 and grp in (0, 64, 164):  # fp64 arithmetic on fp32-stored messages
+                            run(n, B, dt, mode=m, group=grp, storage=torch.float32)
