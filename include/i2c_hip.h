@@ -58,8 +58,8 @@ enum {
 /* I2cProblem.dtype. I2C_F64: the reference's arithmetic, parity-grade. I2C_F64_F32S: fp64 ARITHMETIC on fp32-STORED per-cell
  * buffers (prior/post, fwd, xm, zpost, prior_out are float; everything per trajectory -- x0, sig_x0, z, alpha, alpha_cell, temp,
  * term_stats, cell_stats, stats, the chunk workspace -- stays double): half the HBM bytes of the sweeps; deviation from fp64
- * bounded (tests/test_precision.py). Only the cubature EM path of the one-lane kernels (forward, backward, M-step,
- * i2c_learn); other entry points return I2C_ENOTSUP. I2C_F32: fp32 arithmetic and storage -- NOT parity-grade (the sigma-point
+ * bounded (tests/test_precision.py). Only the cubature EM path (forward, backward, M-step, i2c_learn) of the one-lane, the quad
+ * and the wave kernels; other entry points return I2C_ENOTSUP. I2C_F32: fp32 arithmetic and storage -- NOT parity-grade (the sigma-point
  * curvature terms are below fp32 resolution; O(1) deviation after a few EM iterations): for tolerance sweeps only. */
 enum { I2C_F64 = 0, I2C_F32 = 1, I2C_F64_F32S = 2 };
 
@@ -87,18 +87,18 @@ enum {
   I2C_FAMILY_GROUP = 2, /* G = I2cDims.group_lanes lanes per trajectory, blocks row-distributed, exchanged through LDS  */
   I2C_FAMILY_WAVE = 3,  /* one wavefront per trajectory: 16 x 16 blocks in the MFMA accumulator layout (d = 16)          */
   I2C_FAMILY_QUAD = 4   /* four trajectories per wavefront: 4 x 4 blocks on v_mfma_f64_4x4x4_4b_f64, one element per lane
-                           (d <= 8; forward sweep)                                                                        */
+                           (forward sweep: every model; backward sweep: d = 16)                                            */
 };
-/* I2cProblem.group_lanes = I2C_LANES_QUAD asks for the quad forward kernel of a model that also has wave kernels (64 = the
- * matrix-instruction family in general: the wave kernels where they exist, the quad kernel otherwise) */
+/* I2cProblem.group_lanes = I2C_LANES_QUAD asks for the quad kernels of a model that also has wave kernels (64 = the
+ * wave kernels there): the 12-state quadrotor -- forward and backward sweep, at any batch size */
 #define I2C_LANES_QUAD 164
 enum { I2C_SWEEP_FORWARD = 0, I2C_SWEEP_BACKWARD = 1, I2C_SWEEP_PROPAGATE = 2, I2C_SWEEP_FILTER = 3 };
-/* hybrid default of the d >= 7 lane models: their FORWARD sweep runs on the group kernels while B * G stays within this
- * many lanes (every group wave then has a SIMD of its own: 1024 SIMDs x 64 lanes) */
+/* hybrid default of the d >= 7 lane models WHERE THE QUAD FORWARD KERNEL DOES NOT APPLY (cubature weights with lam != 0): their
+ * FORWARD sweep runs on the group kernels while B * G stays within this many lanes (every group wave then has a SIMD of its own:
+ * 1024 SIMDs x 64 lanes). i2c_kernel_family() reports the family of a sweep. */
 #define I2C_GROUP_FORWARD_MAX_LANES 65536
-/* The models that have wave kernels (I2cDims.wave) run their forward and backward sweeps on them by default at EVERY batch size
- * (measured on MI355X, 12-state quadrotor T = 50, forward + backward ms, wave / group: B = 1024: 0.48 / 1.21; 2048: 0.85 / 1.35;
- * 4096: 1.67 / 1.66; 8192: 3.29 / 3.29; 32768: 13.3 / 16.0): one family for all batches keeps results independent of B. */
+/* The family -- hence the last bits of a result -- of the d >= 5 models depends on the batch size: a caller who needs results
+ * that do not depend on how a batch is sharded pins it (group_lanes = -1, 64 or I2C_LANES_QUAD); INTEGRATION.md section 1b. */
 
 enum {
   I2C_OK = 0,
@@ -159,11 +159,16 @@ typedef struct I2cProblem {
   int32_t expert_controller; /* Linearize forward pass only: scale the feedback gain by the pdf ratio (use_expert_controller,
                               i2c.py:143,259-265); the cubature forward pass always scales it (i2c.py:366-375)      */
   int32_t gh_degree;       /* I2C_INF_GAUSS_HERMITE: 1 <= degree <= I2C_MAX_GH_DEGREE                               */
-  int32_t group_lanes;     /* 0: the model's default kernels (one lane per trajectory; the group kernels for a group_only
-                              model -- or its wave kernels, I2cDims.wave, wherever they apply; for the d >= 7 lane models
-                              the FORWARD sweep runs on the group kernels while B * G <= 65536); 64: the wave kernels (one wavefront
-                              per trajectory: forward and backward sweeps, fp64 or I2C_F64_F32S, cubature rule with lam = 0, no
-                              terminal state prior; propagation and filter run the model's default);
+  int32_t group_lanes;     /* which kernel family serves a sweep -- resolved in ONE place, reported by i2c_kernel_family():
+                              0: the model's default per sweep and batch size (one lane per trajectory; the quad forward kernel
+                              of the d >= 5 models inside their batch windows; for the d = 16 model the wave kernels below 2048
+                              trajectories, the quad forward sweep from 2048 and the quad backward sweep from 4096 up; the
+                              group kernels for what those forms do not cover);
+                              64: the matrix-instruction family: the wave kernels where they exist (I2cDims.wave: one wavefront per
+                              trajectory, forward and backward sweeps), the quad forward kernel otherwise (I2cDims.quad);
+                              I2C_LANES_QUAD: the quad kernels of a model that also has wave kernels, at any batch size;
+                              (all of these: fp64 or I2C_F64_F32S, cubature rule with lam = 0; propagation and filter run the
+                              model's default)
                               I2cDims.group_lanes: run forward / backward / propagate / filter with that many lanes of
                               a wavefront per trajectory (fp64, cubature rule;
                               the backward sweep then has one schedule, the fused walk); -1: one lane per trajectory for

@@ -574,7 +574,7 @@ template <class M> static size_t workspace_elems(int B, int T) {
 //   I2cProblem.group_lanes   0: the model's default (Impl::family); G = M::GROUP: ask for the group kernels; 64: the wave kernels;
 //                 -1: one lane per trajectory; anything else: I2C_ENOTSUP
 //   S             storage type of the per-cell buffers: R, or float with R = double (I2C_F64_F32S: the cubature EM path of the
-//                 one-lane and the wave kernels -- forward, backward, M-step, i2c_learn; everything else is I2C_ENOTSUP)
+//                 one-lane, the quad and the wave kernels -- forward, backward, M-step, i2c_learn; everything else is I2C_ENOTSUP)
 template <class M, typename R, typename S = R> struct Impl {
   using C = Consts<M, R>;
   static constexpr bool MIXED = sizeof(S) != sizeof(R);
@@ -673,7 +673,7 @@ template <class M, typename R, typename S = R> struct Impl {
         if (p->group_lanes == 64 || MIXED) return rc;
       }
     }
-    if constexpr (MIXED) {  // fp64 arithmetic on fp32-stored messages: the cubature EM path of the one-lane kernels only
+    if constexpr (MIXED) {  // fp64 arithmetic on fp32-stored messages: the cubature EM path (one-lane, quad and wave kernels)
       if (p->inference != I2C_INF_CUBATURE || use_group(p) != 0) return I2C_ENOTSUP;
       if (sweep != I2C_SWEEP_FORWARD && sweep != I2C_SWEEP_BACKWARD) return I2C_ENOTSUP;
       return LANE ? I2C_FAMILY_LANE : I2C_ENOTSUP;
@@ -725,7 +725,7 @@ template <class M, typename R, typename S = R> struct Impl {
   static int forward(const I2cProblem* p, const void* prior, void* fwd, void* prior_out, int32_t* status,
                      void* stream) {
     const C c = make_consts<M, R>(p, 0.0, p->inference == I2C_INF_LINEARIZE ? p->expert_controller : 0);
-    if constexpr (MIXED) {  // fp64 arithmetic on fp32-stored messages: the cubature path of the one-lane kernels only
+    if constexpr (MIXED) {  // fp64 arithmetic on fp32-stored messages: the cubature path (one-lane, quad and wave kernels)
       const int fam = family(p, c, I2C_SWEEP_FORWARD);
       if (fam < 0) return fam;
       FwdArgs<R, S> am{(const S*)prior, (S*)fwd, (S*)prior_out, (const R*)p->x0, (const R*)p->sig_x0,
