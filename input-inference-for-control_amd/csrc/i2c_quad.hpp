@@ -1,5 +1,6 @@
-// FOUR trajectories per wavefront on the small fp64 matrix instruction of gfx950: the forward cubature cell for the models with
-// d = nx + nu <= 8 (pendulum ... double cartpole, planar quadrotor), whatever their observation function.
+// FOUR trajectories per wavefront on the small fp64 matrix instruction of gfx950: the forward cubature cell of every model --
+// d = nx + nu <= 8 (pendulum ... double cartpole, planar quadrotor), whatever their observation function, and d = 16 (the 12-state
+// quadrotor) -- and the backward cell of the d = 16 model (backward_quad_body, at the end of this file).
 //
 //   v_mfma_f64_4x4x4_4b_f64 multiplies four independent 4 x 4 blocks at once. Block g lives in lanes {16 k + 4 g + m}: lane
 //   l = 16 r + 4 g + c holds element (r, c) of block g -- as result / accumulator and as B operand; as A operand the same lane
