@@ -23,8 +23,8 @@ def _spd(rng, n, lo, hi, coupled):
     return 0.5 * (m + m.T)
 
 
-def random_case(rng):
-    name = BASES[rng.integers(len(BASES))]
+def random_case(rng, bases=BASES):
+    name = bases[rng.integers(len(bases))]
     g = load_case(name)
     meta = dict(g.meta)
     T, B = int(rng.integers(2, 12)), int(rng.integers(1, 5))
@@ -51,11 +51,22 @@ def random_case(rng):
     return name, Case(d), B, int(rng.integers(1 << 30)), float(10 ** rng.uniform(-3, -1))
 
 
-def run_random_case(lib, device, seed, tol):
+# kernel families a model can be asked for (cubature rule): 0 = its default, -1 = one lane per trajectory, True = the group kernels,
+# 64 = the matrix-instruction family (wave kernels where they exist, the quad forward kernel otherwise), LANES_QUAD = the quad
+# kernels of the model that also has wave kernels (forward and backward sweep)
+FAMILIES = {"em_pendulum_T200": (0, 64, True), "em_linear_T60": (0, 64), "em_cartpole_T100": (0, -1, 64, True), "em_dcp_T60": (0, -1, 64, True),
+            "em_quadrotor_T20": (0, -1, 64, True), "em_quad12_T20": (0, 16, 64, parity.pkg._native.LANES_QUAD)}
+
+
+def run_random_case(lib, device, seed, tol, random_family=False):
     rng = np.random.default_rng(seed)
-    name, case, B, seed_b, x0_scale = random_case(rng)
+    name, case, B, seed_b, x0_scale = random_case(rng, sorted(FAMILIES) if random_family else BASES)
     x0, mu_u = parity.batched_inputs(case, B, seed=seed_b, x0_scale=x0_scale)
-    eng = parity.engine_from_case(case, lib, device, x0=x0, mu_u=mu_u)
+    kw = {}
+    if random_family and name in FAMILIES:
+        fam = FAMILIES[name]
+        kw["group_lanes"] = fam[np.random.default_rng(seed + 7919).integers(len(fam))]
+    eng = parity.engine_from_case(case, lib, device, x0=x0, mu_u=mu_u, **kw)
     o = oracle_from_case(Case({**case, "mu_u": mu_u}), x0=x0)
     if case.meta.get("propagate"):
         eng.propagate()
@@ -82,3 +93,15 @@ def test_hostsim_random_problems_vs_oracle(seed):
 @pytest.mark.parametrize("seed", range(100, 130))
 def test_hip_random_problems_vs_oracle(seed):
     run_random_case(parity.pkg.load_library(), "cuda", seed, 1e-5)
+
+
+# the same random problems with a random kernel family asked for (round 4: four families per model, two of them new)
+@pytest.mark.parametrize("seed", range(200, 240))
+def test_hostsim_random_problems_random_family_vs_oracle(seed):
+    run_random_case(hostsim.load(), "cpu", seed, 1e-6, random_family=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(200, 240))
+def test_hip_random_problems_random_family_vs_oracle(seed):
+    run_random_case(parity.pkg.load_library(), "cuda", seed, 1e-5, random_family=True)
