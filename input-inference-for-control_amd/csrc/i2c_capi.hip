@@ -56,7 +56,7 @@ const char* i2c_build_info(void) {
 #ifdef I2C_HOST_SIM
   return "i2c host-simulation build (CPU, tests only)";
 #else
-  return "i2c hip build: gfx950 (MI355X), wave64; lane kernels (one trajectory per lane) + group kernels (4/8/16 lanes per trajectory, LDS exchange) + wave kernels (one wavefront per trajectory, v_mfma_f64_16x16x4_f64)";
+  return "i2c hip build: gfx950 (MI355X), wave64; lane kernels (one trajectory per lane) + group kernels (4/8/16 lanes per trajectory, LDS exchange) + wave kernels (one wavefront per trajectory, v_mfma_f64_16x16x4_f64) + quad kernels (four trajectories per wavefront, v_mfma_f64_4x4x4_4b_f64)";
 #endif
 }
 
