@@ -136,6 +136,14 @@ def test_hip_quad12_quad_forward_batch_vs_oracle(lib):
     assert eng.forward_family == "quad"
 
 
+@pytest.mark.parametrize("name", ["em_quad12_covctrl_T12", "em_quad12_nondiag_T12"])
+def test_hip_quad12_quad_sweeps_batch_vs_oracle(lib, name):
+    """Covariance control (tempered terminal state prior at the end of the backward chain) and non-diagonal cost weights on a ragged
+    batch, both sweeps on the quad kernels."""
+    eng, _ = parity.check_batch_against_oracle(name, lib, "cuda", 203, 3, tol=1e-6, group_lanes=parity.pkg._native.LANES_QUAD)
+    assert (eng.forward_family, eng.backward_family) == ("quad", "quad")
+
+
 @pytest.mark.parametrize("name,B", [("em_dcp_T60", 77), ("em_pendulum_T200", 1001), ("em_quadrotor_T20", 203), ("em_cartpole_T100", 130)])
 def test_hip_quad_forward_batch_vs_oracle(lib, name, B):
     """Ragged batches (not a multiple of the four trajectories of a wavefront, nor of the 16 that share a cache line) against

@@ -163,6 +163,14 @@ def test_hostsim_quad12_quad_backward_cell_statistics(lib):
     np.testing.assert_allclose(stats[64][0], stats[parity.pkg._native.LANES_QUAD][0], rtol=1e-9)
 
 
+@pytest.mark.parametrize("name", ["em_quad12_covctrl_T12", "em_quad12_nondiag_T12"])
+def test_hostsim_quad12_quad_sweeps_batch_vs_oracle(lib, name):
+    """Covariance control and non-diagonal cost weights on a ragged batch (five trajectories: a full wavefront slot set and one
+    with three spare slots), both sweeps on the quad kernels."""
+    eng, _ = parity.check_batch_against_oracle(name, lib, "cpu", 5, 2, tol=1e-7, group_lanes=parity.pkg._native.LANES_QUAD)
+    assert (eng.forward_family, eng.backward_family) == ("quad", "quad")
+
+
 def test_hostsim_quad12_quad_forward_batch_vs_oracle(lib):
     eng, _ = parity.check_batch_against_oracle("em_quad12_T20", lib, "cpu", 5, 2, tol=1e-7, group_lanes=parity.pkg._native.LANES_QUAD)
     assert eng.forward_family == "quad"
