@@ -143,6 +143,30 @@ def test_config4_quadrotor12_sweeps_H50_vs_oracle(lanes, B):
     assert torch.equal(eng.prop[:, :, 0], eng.prop[:, :, B - 1])
 
 
+def test_config4_quadrotor12_families_agree_after_60_iterations():
+    """The three families of the d = 16 model -- quad (both sweeps), wave, group -- on 4096 problems of config 4's shape, 60 free-running
+    EM iterations each: a self-comparison (the oracle comparison is the test above), here for what it adds: no family drifts or
+    fails over a long run (measured: 1e-13)."""
+    m = parity.make_env_model("Quadrotor12")
+    B, T = 4096, 50
+    rng = np.random.default_rng(0)
+    x0 = 1e-2 * rng.normal(size=(B, 12))
+    mu_u = 0.25 * m.gravity + 1e-2 * rng.normal(size=(B, T, 4))
+    Q, R = np.diag([10.0] * 3 + [1.0] * 3 + [0.1] * 6), 1e-2 * np.eye(4)
+    out = {}
+    for fam, lanes in (("quad", parity.pkg._native.LANES_QUAD), ("wave", 64), ("group", 16)):
+        e = parity.pkg.BatchedI2c(m, T, Q, R, Q, 1.0, 0.5, mu_u, 1e-2 * np.eye(4), x0=x0, group_lanes=lanes, keep_zpost=False, keep_xm=False)
+        for _ in range(60):
+            e.learn_msgs()
+        assert e.failures() == [] and e.forward_family == e.backward_family == fam
+        out[fam] = (e.marginal_state_action(), e.local_linear_policy()[0], e.alpha)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())  # noqa: E731
+    for fam in ("quad", "wave"):
+        (mu, sig), K, al = out[fam]
+        (mr, sr), Kr, ar = out["group"]
+        assert rel(mu, mr) < 1e-9 and rel(sig, sr) < 1e-9 and rel(K, Kr) < 1e-8 and rel(al, ar) < 1e-10, fam
+
+
 @pytest.mark.parametrize("B", [8192, 1024])
 def test_config4_quadrotor12_mpc_H50(B):
     """... and the closed MPC loop with the cubature-KF state estimator on it: horizon 50, 8192 loops at once (or one GPU's
