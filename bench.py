@@ -280,6 +280,20 @@ def extra_config_legs(pkg, device, K=10):
     out["double_cartpole_T300_B4096"]["forward_sweep_ms"] = fwd_ms
     out["double_cartpole_T300_B4096"]["issue"] = issue_roofline("r4_dcp_B4096", "k_quad_forward", T, 16, fwd_ms, B * T, useful=("r4_dcp_B4096_group_and_lane", "k_forward"))
     del eng
+    # config 2's "fp32 vs fp64 tolerance sweep", the speed side: the same problem with fp32-STORED messages (fp64 arithmetic; the
+    # deviation from the fp64 run is bounded and asserted in tests/test_precision.py: median 1e-4, 99th percentile 3e-2 of the batch)
+    eng = pkg.BatchedI2c(m, T, Q, R, Q, 0.05, 0.99, 1e-2 * np.random.default_rng(7).normal(size=(B, T, 1)), np.eye(1), x0=x0, device=device,
+                         keep_zpost=False, keep_xm=False, storage_dtype=torch.float32)
+    eng.learn(2)
+    sync(); t0 = time.perf_counter(); eng.learn(K); sync()
+    ms = (time.perf_counter() - t0) / K * 1e3
+    gb = _gbps(eng, B, T, ms, wbytes=4)
+    out["double_cartpole_T300_B4096_fp32_storage"] = {"ms_per_step": ms, "value": B * T / ms * 1e3, "unit": "timestep-messages/s",
+                                                      "algorithmic_GBps": gb, "frac_of_hbm_peak": gb / HBM_PEAK_GBS,
+                                                      "dtype": "f64 arithmetic, f32 storage (I2C_F64_F32S)", "backward": eng.backward_schedule,
+                                                      "forward_family": eng.forward_family, "backward_family": eng.backward_family,
+                                                      "failed_trajectories": len(eng.failures())}
+    del eng
 
     # the d >= 7 models at a batch that fills the chip (EM iteration = forward + backward + M-step, one i2c_learn call):
     # double cartpole T=300 and the 12-state quadrotor T=50 at B = 32768
