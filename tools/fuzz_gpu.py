@@ -1,0 +1,22 @@
+"""More seeds of tests/test_fuzz_vs_oracle.py on the GPU than the test-suite runs: random problems (model, inference rule, horizon, batch,
+cost weights, temperature, feedback horizon, propagation, expert controller), every other one with a random kernel family asked for,
+against the CPU oracle.   python tools/fuzz_gpu.py [first_seed] [n_seeds]   (2026-10-03: seeds 1000..1399, 0 failures)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "input-inference-for-control_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import parity
+import test_fuzz_vs_oracle as f
+bad = 0
+lib = parity.pkg.load_library()
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+for seed in range(first, first + (int(sys.argv[2]) if len(sys.argv) > 2 else 400)):
+    try:
+        f.run_random_case(lib, "cuda", seed, 1e-5, random_family=(seed % 2 == 0))
+    except AssertionError as e:
+        bad += 1
+        print("FAIL", seed, str(e)[:300], flush=True)
+    except Exception as e:
+        bad += 1
+        print("ERROR", seed, repr(e)[:300], flush=True)
+print("done, failures:", bad)
