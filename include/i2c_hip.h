@@ -20,7 +20,8 @@
  *    Per-trajectory numerical failures (a covariance that is not positive definite -- the
  *    reference raises LinAlgError from quadrature.py:17-24 or scipy) never abort the batch:
  *    they are recorded in status[b] = (reason << 16) | (t + 1) for the FIRST failing step.
- *  - The library keeps no global mutable state; calls on different streams are independent.
+ *  - The library keeps no global mutable state apart from the append-only table of out-of-tree models (i2c_register_model,
+ *    mutex-guarded); calls on different streams are independent (tests/test_streams.py runs two engines on two streams).
  *    Nothing is allocated or freed by the library: every buffer is owned by the caller.
  */
 #ifndef I2C_HIP_H
@@ -33,7 +34,7 @@
 extern "C" {
 #endif
 
-#define I2C_ABI_VERSION 6
+#define I2C_ABI_VERSION 7
 
 #define I2C_MAX_NX 12
 #define I2C_MAX_NU 4
@@ -54,6 +55,12 @@ enum {
   I2C_MODEL_QUADROTOR12 = 7,      /* build-defined 12-state / 4-rotor quadrotor (BASELINE config 4: nx = 12); wave + group kernels */
   I2C_NUM_MODELS = 8
 };
+/* Out-of-tree models: ids I2C_MODEL_PLUGIN_BASE .. handed out by i2c_register_model / i2c_load_model (below). The reference takes
+ * ANY object with dim_*, forward, observe, observe_terminal_x as a model (i2c/model.py:19-44, 154-156; env_def.py:34-82); here a
+ * model is a functor struct in a header, compiled into a library of its own without touching this tree. */
+#define I2C_MODEL_PLUGIN_BASE 64
+#define I2C_MAX_PLUGIN_MODELS 32
+typedef struct I2cModelOps I2cModelOps; /* opaque: the per-(model, dtype) table of entry points a model library exports */
 
 /* I2cProblem.dtype. I2C_F64: the reference's arithmetic, parity-grade. I2C_F64_F32S: fp64 ARITHMETIC on fp32-STORED per-cell
  * buffers (prior/post, fwd, xm, zpost, prior_out are float; everything per trajectory -- x0, sig_x0, z, alpha, alpha_cell, temp,
@@ -241,6 +248,23 @@ typedef struct I2cProblem {
 
 /* Query compile-time dimensions of a model. Replaces reading sys.dim_* (env_def.py:34-82). */
 int i2c_query(int model_id, I2cDims* out);
+
+/*
+ * Bring a model that is not one of the I2C_NUM_MODELS compiled in: replaces "write a *Def mixin + a dynamics function and hand
+ * the object to I2cGraph" (i2c/env_def.py:34-82, 233-298; i2c/env_autograd.py:5-19; i2c/model.py:19-44).
+ * A model library (lib/libi2c_model_<name>.so, built from ONE header by `python build.py --model <header>`: the same kernels
+ * instantiated for the header's functor struct) exports
+ *     int i2c_model_abi_version(void);  const char* i2c_model_name(void);  const I2cModelOps* i2c_model_ops(int dtype);
+ * i2c_load_model dlopens it, checks the ABI version and registers its tables; i2c_register_model does the registration alone for
+ * a caller that linked or loaded the model library itself. Both return the model_id to put into I2cProblem.model_id (>=
+ * I2C_MODEL_PLUGIN_BASE; the same library registered twice gets the same id) or a negative I2C_E* code: I2C_EINVAL for an ABI
+ * mismatch, a missing symbol, or dimensions beyond the I2C_MAX_* capacities of I2cProblem; I2C_ENOTSUP when the table is full.
+ * ops_f32 / ops_f64s may be NULL (that precision was not built). dims_out (optional) receives the model's dimensions.
+ * Thread-safe; ids stay valid for the life of the process.
+ */
+int i2c_register_model(int abi_version, const I2cModelOps* ops_f64, const I2cModelOps* ops_f32, const I2cModelOps* ops_f64s,
+                       I2cDims* dims_out);
+int i2c_load_model(const char* path, I2cDims* dims_out);
 
 /* Bytes of I2cProblem.work the chunked backward sweep needs for (model_id, dtype, B, T). */
 size_t i2c_workspace_bytes(int model_id, int dtype, int B, int T);

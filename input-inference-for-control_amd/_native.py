@@ -9,7 +9,7 @@ without a GPU; nothing in the package ever looks for it.)
 import ctypes as C
 import os
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_NX, MAX_NU, MAX_NZ, MAX_PARAMS = 12, 4, 16, 16
 MAX_GH_DEGREE = 8
 
@@ -25,6 +25,8 @@ FAMILY_LANE, FAMILY_GROUP, FAMILY_WAVE, FAMILY_QUAD = 1, 2, 3, 4  # i2c_kernel_f
 FAMILY_NAMES = {FAMILY_LANE: "lane", FAMILY_GROUP: "group", FAMILY_WAVE: "wave", FAMILY_QUAD: "quad"}
 SWEEP_FORWARD, SWEEP_BACKWARD, SWEEP_PROPAGATE, SWEEP_FILTER = 0, 1, 2, 3
 LANES_QUAD = 164  # I2cProblem.group_lanes: the quad forward kernel of a model that also has wave kernels (I2C_LANES_QUAD)
+
+PLUGIN_BASE = 64  # I2C_MODEL_PLUGIN_BASE: ids of out-of-tree models start here
 
 MODEL_IDS = {
     "PendulumKnown": 0,
@@ -120,6 +122,8 @@ _SIGNATURES = {
     "i2c_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "i2c_backward_schedule": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "i2c_query": (C.c_int, [C.c_int, C.POINTER(I2cDims)]),
+    "i2c_register_model": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(I2cDims)]),
+    "i2c_load_model": (C.c_int, [C.c_char_p, C.POINTER(I2cDims)]),
     "i2c_kernel_family": (C.c_int, [C.POINTER(I2cProblem), C.c_int]),
     "i2c_forward_sweep": (C.c_int, [C.POINTER(I2cProblem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "i2c_backward_sweep": (
@@ -173,6 +177,17 @@ class NativeLibrary:
                               f"{C.sizeof(I2cProblem)} bytes (include/i2c_hip.h and _native.py disagree)")
         self.build_info = self.i2c_build_info().decode()
         self.is_host_sim = "host-simulation" in self.build_info
+
+    def load_model(self, path):
+        """Register an out-of-tree model library (built by build.py's build_model) with this library: -> (model_id, I2cDims)."""
+        if not os.path.exists(path):
+            raise ImportError(f"model library not found at {path}; build it with `python build.py --model <header>`")
+        d = I2cDims()
+        mid = self.i2c_load_model(os.fsencode(path), C.byref(d))
+        if mid < 0:
+            raise ImportError(f"i2c_load_model({path}) failed with {mid}: not a model library of ABI version {ABI_VERSION}, or its "
+                              "dimensions exceed the capacities of I2cProblem (include/i2c_hip.h)")
+        return mid, d
 
     def query(self, model_id):
         d = I2cDims()

@@ -1,11 +1,35 @@
 // C ABI (include/i2c_hip.h): argument checks and dispatch over (model_id, dtype) to the per-pair translation units
 // (i2c_model_tu.hip -> i2c_impl.hpp). No kernel code is compiled here.
+#include <dlfcn.h>
+
+#include <mutex>
+
 #include "i2c_entry.hpp"
 
 namespace {
 
+// Out-of-tree models (i2c_register_model / i2c_load_model): an append-only table of per-dtype ops tables. The only mutable
+// state of the library: entries are written once under the mutex and never change or move afterwards, so readers of a
+// published id need no lock.
+struct PluginEntry {
+  const i2c::ModelOps* ops[3];  // I2C_F64, I2C_F32, I2C_F64_F32S (nullptr: that precision was not built)
+  void* handle;                 // dlopen handle of i2c_load_model (kept for the life of the process), or nullptr
+};
+PluginEntry g_plugins[I2C_MAX_PLUGIN_MODELS];
+int g_n_plugins = 0;
+std::mutex g_plugin_mutex;
+
 const i2c::ModelOps* find_ops(int model_id, int dtype) {
   if (dtype != I2C_F64 && dtype != I2C_F32 && dtype != I2C_F64_F32S) return nullptr;
+  if (model_id >= I2C_MODEL_PLUGIN_BASE) {
+    const int k = model_id - I2C_MODEL_PLUGIN_BASE;
+    int n;
+    {
+      std::lock_guard<std::mutex> lock(g_plugin_mutex);
+      n = g_n_plugins;
+    }
+    return k < n ? g_plugins[k].ops[dtype] : nullptr;
+  }
   switch (model_id) {
 #define I2C_CASE(ID, MODEL, name) \
   case ID: return dtype == I2C_F64 ? i2c::ops_##name##_f64() : (dtype == I2C_F32 ? i2c::ops_##name##_f32() : i2c::ops_##name##_f64s());
@@ -75,6 +99,45 @@ size_t i2c_workspace_bytes(int model_id, int dtype, int B, int T) {
   if (B < 1 || T < 1) return 0;
   const i2c::ModelOps* ops = find_ops(model_id, I2C_F64);
   return ops ? (dtype == I2C_F32 ? 4 : 8) * ops->workspace_elems(B, T) : 0;  // the workspace is arithmetic-typed (fp64 in I2C_F64_F32S)
+}
+
+int i2c_register_model(int abi_version, const I2cModelOps* ops_f64, const I2cModelOps* ops_f32, const I2cModelOps* ops_f64s,
+                       I2cDims* dims_out) {
+  if (abi_version != I2C_ABI_VERSION || !ops_f64) return I2C_EINVAL;
+  const i2c::ModelOps* t[3] = {reinterpret_cast<const i2c::ModelOps*>(ops_f64), reinterpret_cast<const i2c::ModelOps*>(ops_f32),
+                               reinterpret_cast<const i2c::ModelOps*>(ops_f64s)};
+  I2cDims d;
+  t[0]->dims(&d);
+  if (d.nx < 1 || d.nx > I2C_MAX_NX || d.nu < 1 || d.nu > I2C_MAX_NU || d.nz < 1 || d.nz > I2C_MAX_NZ || d.nzt < 0 || d.nzt > I2C_MAX_NZ ||
+      d.n_params < 0 || d.n_params > I2C_MAX_PARAMS || d.ny < 0 || d.ny > I2C_MAX_NZ)
+    return I2C_EINVAL;  // the host constants of I2cProblem have fixed capacities
+  std::lock_guard<std::mutex> lock(g_plugin_mutex);
+  for (int k = 0; k < g_n_plugins; ++k)  // registering the same tables again returns the id they already have
+    if (g_plugins[k].ops[0] == t[0]) {
+      if (dims_out) *dims_out = d;
+      return I2C_MODEL_PLUGIN_BASE + k;
+    }
+  if (g_n_plugins >= I2C_MAX_PLUGIN_MODELS) return I2C_ENOTSUP;
+  g_plugins[g_n_plugins] = PluginEntry{{t[0], t[1], t[2]}, nullptr};
+  if (dims_out) *dims_out = d;
+  return I2C_MODEL_PLUGIN_BASE + g_n_plugins++;
+}
+
+int i2c_load_model(const char* path, I2cDims* dims_out) {
+  if (!path) return I2C_EINVAL;
+  void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) return I2C_EINVAL;
+  typedef int (*abi_fn)(void);
+  typedef const I2cModelOps* (*ops_fn)(int);
+  abi_fn abi = (abi_fn)dlsym(h, "i2c_model_abi_version");
+  ops_fn ops = (ops_fn)dlsym(h, "i2c_model_ops");
+  if (!abi || !ops) {
+    dlclose(h);
+    return I2C_EINVAL;
+  }
+  const int id = i2c_register_model(abi(), ops(I2C_F64), ops(I2C_F32), ops(I2C_F64_F32S), dims_out);
+  if (id < 0) dlclose(h);  // (a library registered twice keeps its first handle: dlopen reference-counts)
+  return id;
 }
 
 int i2c_query(int model_id, I2cDims* out) {

@@ -8,6 +8,7 @@
 
 namespace i2c {
 
+// (the C header names this table I2cModelOps, opaque: a model library hands it to i2c_register_model)
 struct ModelOps {
   int (*forward)(const I2cProblem*, const void* prior, void* fwd, void* prior_out, int32_t* status, void* stream);
   int (*backward)(const I2cProblem*, const void* fwd, void* xm, void* post, void* zpost, void* cell_stats,

@@ -360,8 +360,11 @@ static int launch_quad_forward(const Consts<M, R>& c, const A& a, void*) {
   return I2C_OK;
 }
 #else
+#ifndef I2C_QF_ATTR  // (experiment knob: extra attributes of the quad forward kernel, e.g. __attribute__((amdgpu_waves_per_eu(1, 1))))
+#define I2C_QF_ATTR
+#endif
 template <class M, typename R, typename S, class A>
-__global__ __launch_bounds__(64 * quad_waves_per_block<M>(), 2) void k_quad_forward(const Consts<M, R> c, const A a) {
+__global__ __launch_bounds__(64 * quad_waves_per_block<M>(), 2) I2C_QF_ATTR void k_quad_forward(const Consts<M, R> c, const A a) {
   constexpr int WPB = quad_waves_per_block<M>();
   __shared__ QConst<M, R> kc;
   __shared__ R sh[WPB * 4 * QG<M>::SIZE];

@@ -44,6 +44,12 @@ template <typename T> I2C_FN Dual<T> r_rcp(const Dual<T>& x) {
   return Dual<T>(r, -x.d * r * r);
 }
 
+template <typename T> I2C_FN Dual<T> r_exp(const Dual<T>& x) {
+  const T e = r_exp(x.v);
+  return Dual<T>(e, e * x.d);
+}
+// (the operations a model functor may apply to its arguments: + - * /, r_clip, r_rcp, r_exp, and the sines / cosines it is handed)
+
 enum { FN_DYNAMICS = 0, FN_OBSERVE = 1, FN_OBSERVE_TERMINAL = 2 };
 template <class M, int FN, typename T> I2C_FN void call_model(const T* p, const T* x, const T* sn, const T* cs, T* y) {
   if (FN == FN_DYNAMICS) M::dynamics(p, x, sn, cs, y);

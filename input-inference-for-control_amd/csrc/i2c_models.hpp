@@ -15,6 +15,34 @@
 
 namespace i2c {
 
+// Kernel-family knobs every model functor carries, with the values of a model that only asks for the one-lane-per-trajectory
+// kernels. An OUT-OF-TREE model (`python build.py --model my_model.hpp`) derives from this and states
+// its dimensions, its structure hints and its three functions; it may opt into the multi-lane families by overriding a knob:
+//   GROUP = 4 / 8 / 16   group kernels (G lanes per trajectory; G >= the largest of d, nz, and a power of two)
+//   QUAD = true          quad forward kernel: d <= 8 with an identity observation, or d % 4 != 0 with one action (i2c_quad.hpp)
+struct ModelDefaults {
+  static constexpr int ID = -1;   // in-tree models: their I2C_MODEL_* value; plugins get an id from i2c_register_model
+  static constexpr int NP = 0, NA = 0;
+  static constexpr int GROUP = 0;
+  static constexpr bool GROUP_ONLY = false;
+  static constexpr bool GROUP_FORWARD_AUTO = false;
+  static constexpr bool WAVE = false;
+  static constexpr bool QUAD = false;
+  static constexpr int QUAD_FORWARD_MAX_B = 0;
+  static constexpr int QUAD_FORWARD_MIN_B = 0;
+  static constexpr int QUAD_BACKWARD_MIN_B = 0;
+  I2C_HD static constexpr int ang(int) { return 0; }
+  // structure hints of the observation functions (ObsStruct, i2c_cell.hpp): output k is a pass-through of input obs_lin(k), or
+  // (-1) a general function that depends on no input with an index above obs_dep(k). The defaults say "nothing is known"
+  // (every output depends on every input): always correct; sharper hints only save work.
+  I2C_HD static constexpr int obs_lin(int) { return -1; }
+  I2C_HD static constexpr int obs_dep(int) { return 1 << 20; }
+  I2C_HD static constexpr int term_lin(int) { return -1; }
+  I2C_HD static constexpr int term_dep(int) { return 1 << 20; }
+  I2C_HD static constexpr int meas_lin(int) { return -1; }
+  I2C_HD static constexpr int meas_dep(int) { return 1 << 20; }
+};
+
 // PendulumKnown: i2c/env_def.py:233-309, step i2c/env_autograd.py:5-19
 struct Pendulum {
   static constexpr int ID = 0, NX = 2, NU = 1, NZ = 4, NZT = 3, NP = 0, NA = 1;

@@ -197,28 +197,49 @@ template <typename R, class P> I2C_FN R q_ldv(const Quad<R>& q, const P v, const
 // forms ITS entry of the inverse factor, (c) matrix instructions scale block row K and eliminate it from everything below.
 // q_elim2 runs two independent eliminations in lockstep: one LDS round trip per pair of pivot blocks, and two independent
 // instruction streams for the scheduler to interleave (a lone wave per SIMD has nothing else to hide its latencies behind).
-template <int NL, typename R, class P> I2C_FN void q_pivot_algebra(const Quad<R>& q, const P dg, R* aw_out, R* pl_out) {
+// The lower triangle of the pivot block from its LDS slot into registers: d = {d00, d10, d11, d20, d21, d22, d30, d31, d32, d33} (the NL
+// live rows). Fetched as ONE batch and settled by ONE wait (q_pivot_settle): left to itself hipcc sinks the reads of the later
+// rows into the factorisation to save registers, and a lone wave then pays a full LDS latency three times per pivot block.
+template <int NL, typename R, class P> I2C_FN void q_pivot_fetch(const P dg, R* d) {
+  static_assert(NL >= 1 && NL <= 4, "pivot block");
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) d[tri(i, j)] = dg[4 * i + j];
+}
+template <int NL, typename R> I2C_FN void q_pivot_settle(R* d) {
+#ifndef I2C_HOST_SIM
+  if constexpr (NL == 1) asm volatile("" : "+v"(d[0]));
+  if constexpr (NL == 2) asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]));
+  if constexpr (NL == 3) asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]));
+  if constexpr (NL == 4)
+    asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]), "+v"(d[9]));
+#else
+  (void)d;
+#endif
+}
+template <int NL, typename R> I2C_FN void q_pivot_algebra(const Quad<R>& q, const R* d, R* aw_out, R* pl_out) {
   static_assert(NL >= 1 && NL <= 4, "pivot block");
   // 4 x 4 Cholesky of the pivot block (l), column by column; rows >= NL are identity rows
-  const R d00 = dg[0];
+  const R d00 = d[0];
   const R i0 = r_rsqrt(d00);
   R pl = d00, i1 = R(1), i2 = R(1), i3 = R(1);
   R l10 = R(0), l20 = R(0), l21 = R(0), l30 = R(0), l31 = R(0), l32 = R(0);
   if constexpr (NL > 1) {
-    const R d10 = dg[4], d11 = dg[5];
+    const R d10 = d[1], d11 = d[2];
     l10 = d10 * i0;
     pl = d11 - l10 * l10;
     i1 = r_rsqrt(pl);
   }
   if constexpr (NL > 2) {
-    const R d20 = dg[8], d21 = dg[9], d22 = dg[10];
+    const R d20 = d[3], d21 = d[4], d22 = d[5];
     l20 = d20 * i0;
     l21 = (d21 - l20 * l10) * i1;
     pl = d22 - l20 * l20 - l21 * l21;
     i2 = r_rsqrt(pl);
   }
   if constexpr (NL > 3) {
-    const R d30 = dg[12], d31 = dg[13], d32 = dg[14], d33 = dg[15];
+    const R d30 = d[6], d31 = d[7], d32 = d[8], d33 = d[9];
     l30 = d30 * i0;
     l31 = (d31 - l30 * l10) * i1;
     l32 = (d32 - l30 * l20 - l31 * l21) * i2;
@@ -242,17 +263,23 @@ template <int NL, typename R, class P> I2C_FN void q_pivot_algebra(const Quad<R>
     *aw_out = (m0 * y0 + m1 * y1) + (m2 * y2 + m3 * y3);
   }
 }
-// scale block row K by the inverse pivot factor (aw): rows of L^T (the diagonal block masked to its upper triangle: what is left
-// of it is rounding noise) and of every right-hand side ...
-// R2LOW: the second right-hand side starts as the identity (NC2 = NB): L^-1 I is block lower triangular, its blocks right of the
-// diagonal stay zero and are skipped
-template <int K, int NB, int NC1, int NC2, bool R2LOW = false, typename R> I2C_FN void q_elim_scale(const Quad<R>& q, const R aw, R* s, R* r1, R* r2, R* lt) {
+// One pivot step, ordered for a lone wave (nothing else hides its latencies): the rows of L^T first, then the NEXT pivot block --
+// updated, sent through LDS and fetched -- and only then the rest of the step (the right-hand sides, the trailing blocks), which
+// runs while the fetch is in flight (look-ahead).
+//   scale block row K by the inverse pivot factor (aw): rows of L^T (the diagonal block masked to its upper triangle: what is left
+//   of it is rounding noise) ...
+template <int K, int NB, typename R> I2C_FN void q_elim_scale_lt(const Quad<R>& q, const R aw, const R* s, R* lt) {
 #pragma unroll
   for (int j = K; j < NB; ++j) {
     R x = R(0);
     q_mfma(q, aw, s[K * NB + j], x);
     lt[K * NB + j] = (j > K || q.c >= q.r) ? x : R(0);
   }
+}
+// ... and of every right-hand side.
+// R2LOW: the second right-hand side starts as the identity (NC2 = NB): L^-1 I is block lower triangular, its blocks right of the
+// diagonal stay zero and are skipped
+template <int K, int NC1, int NC2, bool R2LOW = false, typename R> I2C_FN void q_elim_scale_rhs(const Quad<R>& q, const R aw, R* r1, R* r2) {
 #pragma unroll
   for (int j = 0; j < NC1; ++j) {
     R x = R(0);
@@ -267,13 +294,20 @@ template <int K, int NB, int NC1, int NC2, bool R2LOW = false, typename R> I2C_F
     r2[K * NC2 + j] = x;
   }
 }
-// ... and eliminate it from everything below (the next pivot block first: it is what the next step waits for)
+// the next pivot block: s[K+1][K+1] -= lt[K][K+1]^T lt[K][K+1]
+template <int K, int NB, typename R> I2C_FN void q_elim_next_pivot(const Quad<R>& q, R* s, const R* lt) {
+  q_mfma(q, -lt[K * NB + K + 1], lt[K * NB + K + 1], s[(K + 1) * NB + K + 1]);
+}
+// eliminate block row K from everything below, except the next pivot block (q_elim_next_pivot)
 template <int K, int NB, int NC1, int NC2, bool R2LOW = false, typename R> I2C_FN void q_elim_below(const Quad<R>& q, R* s, R* r1, R* r2, const R* lt) {
 #pragma unroll
   for (int i = K + 1; i < NB; ++i) {
     const R nl = -lt[K * NB + i];
 #pragma unroll
-    for (int j = i; j < NB; ++j) q_mfma(q, nl, lt[K * NB + j], s[i * NB + j]);
+    for (int j = i; j < NB; ++j) {
+      if (i == K + 1 && j == K + 1) continue;
+      q_mfma(q, nl, lt[K * NB + j], s[i * NB + j]);
+    }
 #pragma unroll
     for (int j = 0; j < NC1; ++j) q_mfma(q, nl, r1[K * NC1 + j], r1[i * NC1 + j]);
 #pragma unroll
@@ -283,52 +317,105 @@ template <int K, int NB, int NC1, int NC2, bool R2LOW = false, typename R> I2C_F
     }
   }
 }
-template <int K, int NB, int NC1, int NC2, bool R2LOW = false, typename R> I2C_FN void q_elim_apply(const Quad<R>& q, const R aw, R* s, R* r1, R* r2, R* lt) {
-  q_elim_scale<K, NB, NC1, NC2, R2LOW>(q, aw, s, r1, r2, lt);
-  q_elim_below<K, NB, NC1, NC2, R2LOW>(q, s, r1, r2, lt);
+// nothing is scheduled across this point (device only): keeps the look-ahead order hipcc would otherwise undo
+I2C_FN void q_sched_fence() {
+#ifndef I2C_HOST_SIM
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 }
-template <int K, int NB, int N, int NC1, int NC2, bool R2LOW = false, typename R>
-I2C_FN void q_elim_step(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* last) {
-  constexpr int NL = (N - 4 * K) >= 4 ? 4 : (N - 4 * K);
-  const auto dg = q.sh + Q_O_DG;
+template <int N, int K> constexpr int q_live_rows() { return (N - 4 * K) >= 4 ? 4 : (N - 4 * K); }
+// the pivot block K of s through the LDS slot at `off` to the sixteen lanes of its trajectory (issued, not yet settled)
+template <int NL, int NB, int K, typename R> I2C_FN void q_pivot_send(const Quad<R>& q, const R* s, const int off, R* d) {
+  const auto dg = q.sh + off;
   q.sync();
   dg[4 * q.r + q.c] = s[K * NB + K];
   q.sync();
+  q_pivot_fetch<NL>(dg, d);
+}
+// d: pivot block K, fetched by the caller (the previous step, or q_elim)
+template <int K, int NB, int N, int NC1, int NC2, bool R2LOW = false, typename R>
+I2C_FN void q_elim_step(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* last, R* d) {
+  constexpr int NL = q_live_rows<N, K>();
   R aw, pl;
-  q_pivot_algebra<NL>(q, dg, &aw, &pl);
+  q_pivot_settle<NL>(d);
+  q_pivot_algebra<NL>(q, d, &aw, &pl);
   if (K == NB - 1) *last = pl;
-  q_elim_apply<K, NB, NC1, NC2, R2LOW>(q, aw, s, r1, r2, lt);
-  if constexpr (K + 1 < NB) q_elim_step<K + 1, NB, N, NC1, NC2, R2LOW>(q, s, r1, r2, lt, last);
+  q_elim_scale_lt<K, NB>(q, aw, s, lt);
+  if constexpr (K + 1 < NB) {
+    R dn[10];
+    q_sched_fence();
+    q_elim_next_pivot<K, NB>(q, s, lt);
+    q_pivot_send<q_live_rows<N, K + 1>(), NB, K + 1>(q, s, Q_O_DG, dn);
+    q_sched_fence();
+    q_elim_scale_rhs<K, NC1, NC2, R2LOW>(q, aw, r1, r2);
+    q_elim_below<K, NB, NC1, NC2, R2LOW>(q, s, r1, r2, lt);
+    q_sched_fence();
+    q_elim_step<K + 1, NB, N, NC1, NC2, R2LOW>(q, s, r1, r2, lt, last, dn);
+  } else {
+    q_elim_scale_rhs<K, NC1, NC2, R2LOW>(q, aw, r1, r2);
+  }
 }
 template <int N, int NC1, int NC2, bool R2LOW = false, typename R> I2C_FN bool q_elim(const Quad<R>& q, R* s, R* r1, R* r2, R* lt) {
-  R last = R(0);
-  q_elim_step<0, (N + 3) / 4, N, NC1, NC2, R2LOW>(q, s, r1, r2, lt, &last);
+  constexpr int NB = (N + 3) / 4;
+  R last = R(0), d[10];
+  q_pivot_send<q_live_rows<N, 0>(), NB, 0>(q, s, Q_O_DG, d);
+  q_elim_step<0, NB, N, NC1, NC2, R2LOW>(q, s, r1, r2, lt, &last, d);
   return last > R(0);
 }
 // two eliminations of the same dimension in lockstep: (sa; ra1, ra2) -> lta and (sb; rb1) -> ltb
 template <int K, int NB, int N, int NA1, int NA2, int NB1, typename R>
-I2C_FN void q_elim2_step(const Quad<R>& q, R* sa, R* ra1, R* ra2, R* lta, R* lasta, R* sb, R* rb1, R* ltb, R* lastb) {
-  constexpr int NL = (N - 4 * K) >= 4 ? 4 : (N - 4 * K);
-  const auto dga = q.sh + Q_O_DG, dgb = q.sh + Q_O_DG2;
-  q.sync();
-  dga[4 * q.r + q.c] = sa[K * NB + K];
-  dgb[4 * q.r + q.c] = sb[K * NB + K];
-  q.sync();
+I2C_FN void q_elim2_step(const Quad<R>& q, R* sa, R* ra1, R* ra2, R* lta, R* lasta, R* sb, R* rb1, R* ltb, R* lastb, R* da, R* db) {
+  constexpr int NL = q_live_rows<N, K>();
   R awa, pla, awb, plb;
-  q_pivot_algebra<NL>(q, dga, &awa, &pla);
-  q_pivot_algebra<NL>(q, dgb, &awb, &plb);
+  q_pivot_settle<NL>(da);
+  q_pivot_settle<NL>(db);
+  q_pivot_algebra<NL>(q, da, &awa, &pla);
+  q_pivot_algebra<NL>(q, db, &awb, &plb);
   if (K == NB - 1) *lasta = pla, *lastb = plb;
-  // (interleaved: the scaled rows of one elimination are consumed after the other's independent instructions)
-  q_elim_scale<K, NB, NA1, NA2, true>(q, awa, sa, ra1, ra2, lta);  // (ra2 starts as the identity: see R2LOW)
-  q_elim_scale<K, NB, NB1, 0>(q, awb, sb, rb1, (R*)nullptr, ltb);
-  q_elim_below<K, NB, NA1, NA2, true>(q, sa, ra1, ra2, lta);
-  q_elim_below<K, NB, NB1, 0>(q, sb, rb1, (R*)nullptr, ltb);
-  if constexpr (K + 1 < NB) q_elim2_step<K + 1, NB, N, NA1, NA2, NB1>(q, sa, ra1, ra2, lta, lasta, sb, rb1, ltb, lastb);
+  q_elim_scale_lt<K, NB>(q, awa, sa, lta);
+  q_elim_scale_lt<K, NB>(q, awb, sb, ltb);
+  if constexpr (K + 1 < NB) {
+    constexpr int NLN = q_live_rows<N, K + 1>();
+    R dna[10], dnb[10];
+    q_sched_fence();
+    q_elim_next_pivot<K, NB>(q, sa, lta);
+    q_elim_next_pivot<K, NB>(q, sb, ltb);
+    {  // both next pivot blocks in one LDS round trip
+      const auto dga = q.sh + Q_O_DG, dgb = q.sh + Q_O_DG2;
+      q.sync();
+      dga[4 * q.r + q.c] = sa[(K + 1) * NB + K + 1];
+      dgb[4 * q.r + q.c] = sb[(K + 1) * NB + K + 1];
+      q.sync();
+      q_pivot_fetch<NLN>(dga, dna);
+      q_pivot_fetch<NLN>(dgb, dnb);
+    }
+    q_sched_fence();
+    // (interleaved: the scaled rows of one elimination are consumed after the other's independent instructions)
+    q_elim_scale_rhs<K, NA1, NA2, true>(q, awa, ra1, ra2);  // (ra2 starts as the identity: see R2LOW)
+    q_elim_scale_rhs<K, NB1, 0>(q, awb, rb1, (R*)nullptr);
+    q_elim_below<K, NB, NA1, NA2, true>(q, sa, ra1, ra2, lta);
+    q_elim_below<K, NB, NB1, 0>(q, sb, rb1, (R*)nullptr, ltb);
+    q_sched_fence();
+    q_elim2_step<K + 1, NB, N, NA1, NA2, NB1>(q, sa, ra1, ra2, lta, lasta, sb, rb1, ltb, lastb, dna, dnb);
+  } else {
+    q_elim_scale_rhs<K, NA1, NA2, true>(q, awa, ra1, ra2);
+    q_elim_scale_rhs<K, NB1, 0>(q, awb, rb1, (R*)nullptr);
+  }
 }
 template <int N, int NA1, int NA2, int NB1, typename R>
 I2C_FN void q_elim2(const Quad<R>& q, R* sa, R* ra1, R* ra2, R* lta, bool* oka, R* sb, R* rb1, R* ltb, bool* okb) {
-  R lasta = R(0), lastb = R(0);
-  q_elim2_step<0, (N + 3) / 4, N, NA1, NA2, NB1>(q, sa, ra1, ra2, lta, &lasta, sb, rb1, ltb, &lastb);
+  constexpr int NB = (N + 3) / 4, NL0 = q_live_rows<N, 0>();
+  R lasta = R(0), lastb = R(0), da[10], db[10];
+  {
+    const auto dga = q.sh + Q_O_DG, dgb = q.sh + Q_O_DG2;
+    q.sync();
+    dga[4 * q.r + q.c] = sa[0];
+    dgb[4 * q.r + q.c] = sb[0];
+    q.sync();
+    q_pivot_fetch<NL0>(dga, da);
+    q_pivot_fetch<NL0>(dgb, db);
+  }
+  q_elim2_step<0, NB, N, NA1, NA2, NB1>(q, sa, ra1, ra2, lta, &lasta, sb, rb1, ltb, &lastb, da, db);
   *oka = lasta > R(0);
   *okb = lastb > R(0);
 }

@@ -84,7 +84,7 @@ class BatchedI2c:
         self.store_dtype = dtype if storage_dtype is None else storage_dtype
         self.mixed = self.store_dtype != self.dtype
         self.sys = model
-        self.model_id = int(model.model_id)
+        self.model_id = int(model.resolve_model_id(self.lib)) if hasattr(model, "resolve_model_id") else int(model.model_id)
         dims = self.lib.query(self.model_id)
         self.dims = dims
         nx, nu, nz, nzt = dims.nx, dims.nu, dims.nz, dims.nzt

@@ -121,10 +121,11 @@ class I2cGraph:
                  device=None, dtype=torch.float64, lib=None, group_lanes=0):
         if not isinstance(inference, (CubatureQuadrature, GaussHermiteQuadrature, Linearize)):
             raise ValueError("Unknown inference method")
-        if not hasattr(sys, "model_id") or sys.model_id is None:
+        if not hasattr(sys, "model_id") or (sys.model_id is None and getattr(sys, "hip_header", None) is None):
             raise TypeError(
                 "the MI355X build evaluates models as compiled device functors: `sys` must come from "
-                "i2c.model.make_env_model (arbitrary Python callables cannot run inside the kernels)"
+                "i2c.model.make_env_model, or be a KnownModel that names the header of its functor (hip_header; "
+                "INTEGRATION.md section 3) -- arbitrary Python callables cannot run inside the kernels"
             )
         self.sys = sys
         self.H = int(horizon)

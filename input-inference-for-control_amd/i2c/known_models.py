@@ -9,6 +9,8 @@ The NumPy methods (``dynamics``, ``observe``, ``observe_terminal``, ``forward`` 
 the host-side callers of the same protocol (simulators, the MPC state estimator, scripts that
 poke ``sys.forward`` directly): they are NOT used by I2cGraph, whose sweeps run on the GPU.
 """
+import os
+
 import numpy as np
 
 
@@ -55,8 +57,40 @@ class KnownModel:
         return self.zg
 
     # ---- device side ------------------------------------------------------------------
+    # An OUT-OF-TREE model names the header with its device functor instead of a compiled-in
+    # model_id: hip_header = path of the header, hip_struct = the functor's name in namespace i2c (default: the file name in
+    # CamelCase), hip_name = the library's name (default: the file name). resolve_model_id() builds lib/libi2c_model_<name>.so
+    # when it is missing or older than its sources, loads it into the solver library and returns the id it was given.
+    hip_header = None
+    hip_struct = None
+    hip_name = None
+
     def device_params(self):
         return []
+
+    def resolve_model_id(self, lib):
+        """The I2cProblem.model_id of this model in `lib` (a _native.NativeLibrary): compiled in, or registered on first use."""
+        if self.model_id is not None:
+            return int(self.model_id)
+        if self.hip_header is None:
+            raise TypeError(f"{type(self).__name__}: a model needs a compiled-in model_id or a hip_header with its device functor "
+                            "(arbitrary Python callables cannot run inside the kernels; INTEGRATION.md section 3)")
+        ids = lib.__dict__.setdefault("_plugin_ids", {})
+        key = (os.path.abspath(self.hip_header), self.hip_struct, self.hip_name)
+        if key not in ids:
+            ids[key] = lib.load_model(self._build_plugin(lib))[0]
+        return ids[key]
+
+    def _build_plugin(self, lib):
+        import importlib.util
+
+        pkg_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("i2c_amd_build", os.path.join(pkg_dir, "build.py"))
+        build = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(build)
+        # (the host simulation of tests/ gets the g++ build of the same header, next to its own library)
+        return build.build_model(self.hip_header, struct=self.hip_struct, name=self.hip_name, host_sim=lib.is_host_sim,
+                                 out_dir=os.path.dirname(lib.path) if lib.is_host_sim else None, verbose=False)
 
     # ---- host-side protocol -----------------------------------------------------------
     def dynamics(self, xu):
@@ -488,6 +522,10 @@ def make_env_model(env_def, model_def=None):
     """Same call as the reference's i2c.model.make_env_model (model.py:19-44); known models only."""
     if model_def is not None:
         raise ValueError("learned models are not part of the MI355X build (none exists in the reference either)")
+    if isinstance(env_def, KnownModel):  # an out-of-tree model object (hip_header): taken as it is
+        return env_def
+    if isinstance(env_def, type) and issubclass(env_def, KnownModel):
+        return env_def()
     try:
         return ENVIRONMENTS[env_def]()
     except KeyError:
