@@ -269,12 +269,16 @@ int i2c_load_model(const char* path, I2cDims* dims_out);
 /* Bytes of I2cProblem.work the chunked backward sweep needs for (model_id, dtype, B, T). */
 size_t i2c_workspace_bytes(int model_id, int dtype, int B, int T);
 
-/* The schedule i2c_backward_sweep will run for a requested I2cProblem.backward_mode (resolves I2C_BWD_AUTO and the
- * fall-backs: chunked needs T >= 8). Callers size their buffers from the answer: two-pass needs xm and cell_stats,
- * chunked needs I2cProblem.work. Returns one of I2C_BWD_TWO_PASS / FUSED / CHUNKED, or 0 for an unknown model. */
-int i2c_backward_schedule(int model_id, int B, int T, int requested_mode);
+/* The schedule i2c_backward_sweep WILL run for problem p -- the one place that resolves I2cProblem.backward_mode together with
+ * everything else that decides it: the kernel family of the backward sweep (wave: fused walk, two-pass on request; quad / group:
+ * fused walk), the inference rule (Linearize / Gauss-Hermite: fused walk, chunked at small batches), the storage type, and the
+ * lane kernels' batch rule (I2C_BWD_AUTO: chunked below I2C_BWD_FUSED_MIN_B trajectories, fused from there on; chunked needs
+ * T >= 8, two-pass otherwise). Reads the scalar fields of p only: callers ask BEFORE they allocate, and size their buffers from
+ * the answer -- two-pass needs xm and cell_stats, chunked needs I2cProblem.work (without it the sweep falls back to two-pass).
+ * Returns I2C_BWD_TWO_PASS / FUSED / CHUNKED, or the negative error code the sweep itself would return for this problem. */
+int i2c_backward_schedule(const I2cProblem* p);
 
-/* Which kernel family (I2C_FAMILY_*) will serve `sweep` (I2C_SWEEP_*) of problem p -- the one place that resolves
+/* Which kernel family (I2C_FAMILY_*) will serve `sweep` (I2C_SWEEP_*) of problem p (scalar fields only) -- the one place that resolves
  * I2cProblem.group_lanes, the models' defaults and the batch-size thresholds, so that callers and tests can see (and pin) what
  * ran: the last bits of a result depend on the family. Returns a negative error code if that sweep would refuse the problem. */
 int i2c_kernel_family(const I2cProblem* p, int sweep);

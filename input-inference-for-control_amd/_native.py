@@ -120,7 +120,7 @@ _SIGNATURES = {
     "i2c_problem_size": (C.c_size_t, []),
     "i2c_build_info": (C.c_char_p, []),
     "i2c_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "i2c_backward_schedule": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "i2c_backward_schedule": (C.c_int, [C.POINTER(I2cProblem)]),
     "i2c_query": (C.c_int, [C.c_int, C.POINTER(I2cDims)]),
     "i2c_register_model": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(I2cDims)]),
     "i2c_load_model": (C.c_int, [C.c_char_p, C.POINTER(I2cDims)]),

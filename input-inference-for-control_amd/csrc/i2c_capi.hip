@@ -39,11 +39,18 @@ const i2c::ModelOps* find_ops(int model_id, int dtype) {
   }
 }
 
+// the scalar fields alone (what the resolvers i2c_kernel_family / i2c_backward_schedule read: no buffer needs to exist yet)
+int check_problem_shape(const I2cProblem* p);
 int check_problem(const I2cProblem* p) {
-  if (!p || p->abi_version != I2C_ABI_VERSION) return I2C_EINVAL;
-  if (p->B < 1 || p->T < 1 || p->T > 65535) return I2C_EINVAL;  // status words keep t + 1 in 16 bits
+  const int rc = check_problem_shape(p);
+  if (rc != I2C_OK) return rc;
   if (!p->x0 || !p->sig_x0 || !p->alpha || !p->feedforward) return I2C_EINVAL;
   if (p->has_x_terminal && !p->temp) return I2C_EINVAL;
+  return I2C_OK;
+}
+int check_problem_shape(const I2cProblem* p) {
+  if (!p || p->abi_version != I2C_ABI_VERSION) return I2C_EINVAL;
+  if (p->B < 1 || p->T < 1 || p->T > 65535) return I2C_EINVAL;  // status words keep t + 1 in 16 bits
   if (p->inference < I2C_INF_CUBATURE || p->inference > I2C_INF_GAUSS_HERMITE) return I2C_EINVAL;
   if (p->inference == I2C_INF_GAUSS_HERMITE && (p->gh_degree < 1 || p->gh_degree > I2C_MAX_GH_DEGREE)) return I2C_EINVAL;
   if (p->t0 < 0 || p->t0 >= p->T) return I2C_EINVAL;
@@ -84,15 +91,24 @@ const char* i2c_build_info(void) {
 #endif
 }
 
-int i2c_backward_schedule(int model_id, int B, int T, int requested_mode) {
-  if (B < 1 || T < 1 || requested_mode < I2C_BWD_AUTO || requested_mode > I2C_BWD_CHUNKED) return 0;
-  const i2c::ModelOps* ops = find_ops(model_id, I2C_F64);
-  return ops ? ops->schedule(B, T, requested_mode) : 0;
+// the two resolvers read scalar fields only: they answer before any buffer of the problem exists
+#define I2C_DISPATCH_SHAPE(p, CALL)                                       \
+  do {                                                                    \
+    const int rc_ = check_problem_shape(p);                               \
+    if (rc_ != I2C_OK) return rc_;                                        \
+    const i2c::ModelOps* ops_ = find_ops((p)->model_id, (p)->dtype);      \
+    if (!ops_) return I2C_EINVAL;                                         \
+    return ops_->CALL;                                                    \
+  } while (0)
+
+int i2c_backward_schedule(const I2cProblem* p) {
+  if (p && (p->backward_mode < I2C_BWD_AUTO || p->backward_mode > I2C_BWD_CHUNKED)) return I2C_EINVAL;
+  I2C_DISPATCH_SHAPE(p, plan(p));
 }
 
 int i2c_kernel_family(const I2cProblem* p, int sweep) {
   if (sweep < I2C_SWEEP_FORWARD || sweep > I2C_SWEEP_FILTER) return I2C_EINVAL;
-  I2C_DISPATCH(p, family(p, sweep));
+  I2C_DISPATCH_SHAPE(p, family(p, sweep));
 }
 
 size_t i2c_workspace_bytes(int model_id, int dtype, int B, int T) {

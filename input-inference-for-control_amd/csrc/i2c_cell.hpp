@@ -462,13 +462,117 @@ I2C_FN void grid_transform(const Rule<R>& rule, const R* m, const R* L, const F&
     for (int l = 0; l <= k; ++l) Sy[tri(k, l)] -= s1[k] * s1[l];
 }
 
+// The same transform with the grid UNROLLED at compile time (degree DEG, DIN <= 3: 27 / 64 points for the pendulum-sized models),
+// axis 0 outermost. What the run-time odometer above cannot exploit:
+//   * L is lower triangular: axis j only moves the coordinates i >= j, so the offsets of a point are built level by level
+//     (one multiply-add per coordinate and level instead of a triangular product per point);
+//   * an angle coordinate with input index ia is fixed once the axes 0 .. ia are: its sine / cosine is evaluated at THAT level
+//     and shared by every point below it (the pendulum's angle is coordinate 0: DEG evaluations instead of DEG^3);
+//   * the weight of a point is the product of its levels' weights: one multiply per point;
+//   * the cross-covariance rows of the coordinates that do not move inside the innermost axis take the innermost partial sums
+//     sum_k w_k dy_k once per pass instead of once per point.
+// Same moments, same order of the points within a level; the sums associate differently (last bits).
+template <class M, int DEG, int DIN, int DOUT, bool CROSS, typename R, class F>
+I2C_FN void grid_transform_ct(const Rule<R>& rule, const R* m, const R* L, const F& f, R* my, R* Sy, R* Sxy) {
+  static_assert(DIN >= 1 && DIN <= 3, "unrolled grid: up to three input dimensions");
+  constexpr int NA = M::NA, NA1 = NA > 0 ? NA : 1;
+  R sn[NA1], cs[NA1], y0[DOUT], s1[DOUT];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) r_sincos(m[M::ang(a)], &sn[a], &cs[a]);
+  f(m, sn, cs, y0);
+#pragma unroll
+  for (int k = 0; k < DOUT; ++k) s1[k] = R(0);
+#pragma unroll
+  for (int k = 0; k < sym(DOUT); ++k) Sy[k] = R(0);
+  if (CROSS) {
+#pragma unroll
+    for (int k = 0; k < DIN * DOUT; ++k) Sxy[k] = R(0);
+  }
+  R xs[DEG], ws[DEG];  // sf * node, weight
+#pragma unroll
+  for (int q = 0; q < DEG; ++q) xs[q] = rule.sf * rule.gh_x[q], ws[q] = rule.gh_w[q];
+  constexpr int N1 = DIN > 1 ? DEG : 1, N2 = DIN > 2 ? DEG : 1;
+#pragma unroll
+  for (int i0 = 0; i0 < DEG; ++i0) {
+    R d0[DIN];  // offsets after level 0
+#pragma unroll
+    for (int i = 0; i < DIN; ++i) d0[i] = L[tri(i, 0)] * xs[i0];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+      if (M::ang(a) == 0) r_sincos(m[0] + d0[0], &sn[a], &cs[a]);
+#pragma unroll
+    for (int i1 = 0; i1 < N1; ++i1) {
+      R d1[DIN];
+      R w1 = ws[i0];
+#pragma unroll
+      for (int i = 0; i < DIN; ++i) d1[i] = d0[i];
+      if constexpr (DIN > 1) {
+#pragma unroll
+        for (int i = 1; i < DIN; ++i) d1[i] += L[tri(i, 1)] * xs[i1];
+        w1 *= ws[i1];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+          if (M::ang(a) == 1) r_sincos(m[1] + d1[1], &sn[a], &cs[a]);
+      }
+      R part[DOUT];  // sum over the innermost axis of w dy (cross-covariance rows of the coordinates it does not move)
+#pragma unroll
+      for (int k = 0; k < DOUT; ++k) part[k] = R(0);
+#pragma unroll
+      for (int i2 = 0; i2 < N2; ++i2) {
+        R dx[DIN], x[DIN], y[DOUT];
+        R w = w1;
+#pragma unroll
+        for (int i = 0; i < DIN; ++i) dx[i] = d1[i];
+        if constexpr (DIN > 2) {
+          dx[2] += L[tri(2, 2)] * xs[i2];
+          w *= ws[i2];
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+            if (M::ang(a) == 2) r_sincos(m[2] + dx[2], &sn[a], &cs[a]);
+        }
+#pragma unroll
+        for (int i = 0; i < DIN; ++i) x[i] = m[i] + dx[i];
+        f(x, sn, cs, y);
+#pragma unroll
+        for (int k = 0; k < DOUT; ++k) {
+          const R wy = w * (y[k] - y0[k]);
+          y[k] -= y0[k];
+          part[k] += wy;
+#pragma unroll
+          for (int l = 0; l <= k; ++l) Sy[tri(k, l)] += wy * y[l];
+          if (CROSS) Sxy[(DIN - 1) * DOUT + k] += dx[DIN - 1] * wy;  // the coordinate the innermost axis moves
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < DOUT; ++k) {
+        s1[k] += part[k];
+        if (CROSS) {
+#pragma unroll
+          for (int i = 0; i < DIN - 1; ++i) Sxy[i * DOUT + k] += d1[i] * part[k];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < DOUT; ++k) my[k] = y0[k] + s1[k];
+#pragma unroll
+  for (int k = 0; k < DOUT; ++k)
+#pragma unroll
+    for (int l = 0; l <= k; ++l) Sy[tri(k, l)] -= s1[k] * s1[l];
+}
+
 // GRID selects the tensor-grid rule at compile time; the sigma-point kernels are unchanged by it.
 template <bool GRID, class M, class ST, int DIN, int DOUT, bool CROSS, bool UNITW = false, typename R, class F>
 I2C_FN void transform(const Rule<R>& rule, const R* m, const R* Sin, const R* L, const F& f, R* my, R* Sy, R* Sxy,
                       const PolyTab<R>* tab = nullptr) {
-  if constexpr (GRID)
+  if constexpr (GRID) {
+    if constexpr (DIN <= 3) {  // degrees 2 .. 4 of the pendulum-sized models: the unrolled grid (wave-uniform choice)
+      if (rule.gh_degree == 3) return grid_transform_ct<M, 3, DIN, DOUT, CROSS>(rule, m, L, f, my, Sy, Sxy);
+      if (rule.gh_degree == 4) return grid_transform_ct<M, 4, DIN, DOUT, CROSS>(rule, m, L, f, my, Sy, Sxy);
+      if (rule.gh_degree == 2) return grid_transform_ct<M, 2, DIN, DOUT, CROSS>(rule, m, L, f, my, Sy, Sxy);
+    }
     grid_transform<M, DIN, DOUT, CROSS>(rule, m, L, f, my, Sy, Sxy);
-  else
+  } else
     sp_transform<M, ST, DIN, DOUT, CROSS, UNITW>(rule, m, Sin, L, f, my, Sy, Sxy, tab);
 }
 
@@ -1399,7 +1503,7 @@ I2C_HD inline void chunk_compose_body(const Consts<M, R>& c, const ChunkArgs<R, 
   for (int i = 0; i < sym(NX); ++i) out[(long)(NX + NX * NX + i) * B] = Cc[i];
 }
 
-template <class M, typename R, typename S_ = R>
+template <class M, typename R, typename S_ = R, bool GRID = false>
 I2C_HD inline void chunk_stitch_body(const Consts<M, R>& c, const ChunkArgs<R, S_>& a, const int b) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, D = C::D;
@@ -1412,7 +1516,7 @@ I2C_HD inline void chunk_stitch_body(const Consts<M, R>& c, const ChunkArgs<R, S
 #pragma unroll
   for (int i = 0; i < sym(NX); ++i) S3f[i] = last[(long)(O_S3 + i) * B];
   end_of_chain<M, R>(c, a.cell.temp, b, m3f, S3f, m, S, a.cell.status);
-  terminal_obs_stats<M, R>(c, b, m, S, a.cell.term_stats, a.cell.status);
+  terminal_obs_stats<M, R, GRID>(c, b, m, S, a.cell.term_stats, a.cell.status);
   R av[NX], G[NX * NX], Cc[sym(NX)], nav[NX], nG[NX * NX], nCc[sym(NX)];
   auto loadc = [&](int ch, R* la, R* lG, R* lC) {
     const R* cp = a.comp + ((long)(ch > 0 ? ch : 0) * EC) * B + b;
@@ -1457,7 +1561,8 @@ I2C_HD inline void chunk_stitch_body(const Consts<M, R>& c, const ChunkArgs<R, S
 // with the optional stores behind run-time branches the compiler cannot count the memory operations between the row prefetch and
 // its use, so its s_waitcnt at the top of a cell also waits for the PREVIOUS cell's stores to be acknowledged (vmcnt is one
 // in-order counter) -- 41 % of the walk's cycles (profiles/r3_pendulum_B4096_chunked_sq_summary.txt).
-template <class M, typename R, typename S_ = R, bool LEANW = false>
+// GRID: the Gauss-Hermite tensor-grid transform in the cell (GaussHermiteQuadrature: the chunked schedule of that rule)
+template <class M, typename R, typename S_ = R, bool LEANW = false, bool GRID = false>
 I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R, S_>& a, const int ch, const int b) {
   using C = Consts<M, R>;
   constexpr int NX = C::NX, NZ = C::NZ, D = C::D;
@@ -1538,7 +1643,7 @@ I2C_HD inline void chunk_walk_body(const Consts<M, R>& c, const ChunkArgs<R, S_>
     R* mu = row;
     R* S = row + D;
     R ctl[C::E_POST - D - sym(D)], mz[NZ], Sz[sym(NZ)], cm, cv;
-    if (!cell_posterior<M, R>(c, zt, mu, S, row + O_J, dm, dS, ctl, mz, Sz, &cm, &cv, tab)) set_status(ca.status, b, 7, t);
+    if (!cell_posterior<M, R, GRID>(c, zt, mu, S, row + O_J, dm, dS, ctl, mz, Sz, &cm, &cv, tab)) set_status(ca.status, b, 7, t);
     store_cell<M, R, S_>(c, ca, t, b, mu, S, ctl, mz, Sz, cm, cv, VOFF ? voff : nullptr);
     sum_m += cm;
     sum_v += cv;

@@ -27,7 +27,7 @@ struct ModelOps {
   int (*mpc_step)(const I2cProblem*, const I2cMpcStep*, void* stream);
   void (*dims)(I2cDims*);
   size_t (*workspace_elems)(int B, int T);
-  int (*schedule)(int B, int T, int requested);
+  int (*plan)(const I2cProblem*);  // the backward schedule that will run (I2C_BWD_*), or an error code
   int (*shift)(const I2cProblem*, void* post, const void* cell_init, const void* alpha_init, const void* z_new, void* action,
                void* stream);
   int (*family)(const I2cProblem*, int sweep);

@@ -108,18 +108,18 @@ I2C_KERNEL(SWEEP_BLOCK) k_chunk_compose(I2C_LANE_PARAMS const Consts<M, R> c, co
   const long b = I2C_LANE_X(SWEEP_BLOCK);
   if (b < c.B) chunk_compose_body<M, R, S>(c, a, I2C_LANE_Y, (int)b);
 }
-template <class M, typename R, typename S = R>
+template <class M, typename R, typename S = R, bool GRID = false>
 I2C_KERNEL(SWEEP_BLOCK) k_chunk_stitch(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, S> a) {
   const long b = I2C_LANE_X(SWEEP_BLOCK);
-  if (b < c.B) chunk_stitch_body<M, R, S>(c, a, (int)b);
+  if (b < c.B) chunk_stitch_body<M, R, S, GRID>(c, a, (int)b);
 }
 #ifndef I2C_WALK_LEAN
 #define I2C_WALK_LEAN 1
 #endif
-template <class M, typename R, typename S = R, bool LEANW = false>
+template <class M, typename R, typename S = R, bool LEANW = false, bool GRID = false>
 I2C_KERNEL(SWEEP_BLOCK) k_chunk_walk(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, S> a) {
   const long b = I2C_LANE_X(SWEEP_BLOCK);
-  if (b < c.B) chunk_walk_body<M, R, S, LEANW>(c, a, I2C_LANE_Y, (int)b);
+  if (b < c.B) chunk_walk_body<M, R, S, LEANW, GRID>(c, a, I2C_LANE_Y, (int)b);
 }
 template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_chunk_stitch_lin(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, R> a) {
   const long b = I2C_LANE_X(SWEEP_BLOCK);
@@ -792,9 +792,28 @@ template <class M, typename R, typename S = R> struct Impl {
     if (mode == I2C_BWD_CHUNKED && T < 8) mode = I2C_BWD_TWO_PASS;  // too short to chunk
     return mode;
   }
+  // THE place that decides which backward schedule runs for a problem (i2c_backward_schedule() reports it): the family that
+  // serves the sweep, the inference rule, the storage type, then the batch-size rule of the lane kernels. An error code when
+  // the sweep would refuse the problem. (What it assumes: the workspaces of its answer are supplied -- pick_mode.)
+  static int plan(const I2cProblem* p) {
+    const C c = make_consts<M, R>(p, 0.0, 0);
+    const int fam = family(p, c, I2C_SWEEP_BACKWARD);
+    if (fam < 0) return fam;
+    const int lane_rule = schedule(p->B, p->T, p->backward_mode);
+    if (fam == I2C_FAMILY_WAVE)  // the fused walk; the two-pass form on request (cubature rule)
+      return (lane_rule == I2C_BWD_TWO_PASS && p->inference == I2C_INF_CUBATURE) ? I2C_BWD_TWO_PASS : I2C_BWD_FUSED;
+    if (fam == I2C_FAMILY_QUAD || fam == I2C_FAMILY_GROUP) return I2C_BWD_FUSED;  // four trajectories / a group of lanes walk T-1..0
+    if (!LANE) return I2C_ENOTSUP;
+    if (p->inference == I2C_INF_LINEARIZE) {
+      if (M::NZT == 0) return I2C_EINVAL;  // no terminal observation: the reference fails at i2c.py:500-501
+      return (!MIXED && lane_rule == I2C_BWD_CHUNKED) ? I2C_BWD_CHUNKED : I2C_BWD_FUSED;
+    }
+    if (p->inference == I2C_INF_GAUSS_HERMITE) return (!MIXED && lane_rule == I2C_BWD_CHUNKED) ? I2C_BWD_CHUNKED : I2C_BWD_FUSED;
+    return lane_rule;
+  }
   static int pick_mode(const I2cProblem* p) {
-    int mode = schedule(p->B, p->T, p->backward_mode);
-    if (mode == I2C_BWD_CHUNKED && !p->work) mode = I2C_BWD_TWO_PASS;  // no workspace
+    int mode = plan(p);
+    if (mode == I2C_BWD_CHUNKED && !p->work) mode = (p->inference == I2C_INF_CUBATURE) ? I2C_BWD_TWO_PASS : I2C_BWD_FUSED;  // no workspace
     return mode;
   }
 
@@ -839,8 +858,7 @@ template <class M, typename R, typename S = R> struct Impl {
   template <class CA>
   static int backward_wave(const I2cProblem* p, const C& c, const CA& a, const MstepArgs<R>& ms, MstepFuse* fuse, void* stream) {
     if constexpr (HAS_WAVE) {
-      const bool two_pass = schedule(p->B, p->T, p->backward_mode) == I2C_BWD_TWO_PASS && a.xm && a.cell_stats &&
-                            p->inference == I2C_INF_CUBATURE;
+      const bool two_pass = plan(p) == I2C_BWD_TWO_PASS && a.xm && a.cell_stats;
       if (!two_pass) return launch_wave<WK_BACKWARD, M, R, S>(c, a, stream);
       int rc = launch_wave<WK_SCAN, M, R, S>(c, a, stream);
       if (rc == I2C_OK) rc = launch_wave<WK_CELL, M, R, S>(c, a, stream);
@@ -886,8 +904,29 @@ template <class M, typename R, typename S = R> struct Impl {
         }
         return launch(k_bwd_lin<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, a);
       }
-      if (p->inference == I2C_INF_GAUSS_HERMITE)  // one schedule: the fused walk with the grid transform
+      if (p->inference == I2C_INF_GAUSS_HERMITE) {  // the fused walk with the grid transform, or (small batches) the chunked form:
+        if constexpr (!MIXED) {                     // the composition of the x-marginal recursion has no transform in it
+          if (pick_mode(p) == I2C_BWD_CHUNKED) {
+            ChunkArgs<R, R> ch{a, nullptr, nullptr, nullptr, 0, 0};
+            chunk_geometry(p->B, p->T, &ch.n_chunks, &ch.chunk_len);
+            constexpr int NX = M::NX;
+            ch.comp = (R*)p->work;
+            ch.bnd = ch.comp + (size_t)ch.n_chunks * (NX + NX * NX + sym(NX)) * p->B;
+            ch.part = ch.bnd + (size_t)ch.n_chunks * (NX + sym(NX)) * p->B;
+            C cr = c;  // reduction over chunks instead of cells: same kernel, T := number of chunks
+            cr.T = ch.n_chunks;
+            CellArgs<R> ared = a;
+            ared.cell_stats = ch.part;
+            int rc = launch(k_chunk_compose<M, R, R>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
+            if (rc == I2C_OK) rc = launch(k_chunk_stitch<M, R, R, true>, p->B, 1, SWEEP_BLOCK, stream, c, ch);
+            if (rc == I2C_OK) rc = launch(k_chunk_walk<M, R, R, false, true>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
+            if (rc == I2C_OK) rc = launch_reduce<M, R>(cr, ared, ms, p->T, stream);
+            if (fuse) fuse->done = true;
+            return rc;
+          }
+        }
         return launch(k_bwd_fused<M, R, true>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+      }
       if constexpr (!MIXED) return backward_lane(p, c, a, ms, fuse, stream);
     }
     return I2C_ENOTSUP;
@@ -1089,7 +1128,7 @@ template <class M, typename R, typename S = R> const ModelOps* make_ops() {
   using I = Impl<M, R, S>;
   static const ModelOps ops = {&I::forward, &I::backward,  &I::mstep,        &I::learn,           &I::ckf,
                                &I::rollout, &I::propagate, &I::riccati,   &I::mpc_step,        &fill_dims<M>,
-                               &workspace_elems<M>, &I::schedule, &I::shift, &I::family_of};
+                               &workspace_elems<M>, &I::plan, &I::shift, &I::family_of};
   return &ops;
 }
 

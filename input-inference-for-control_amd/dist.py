@@ -17,29 +17,38 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def _all_gather_rows(t, group=None):
-    """All-gather along dim 0 allowing ragged shard sizes."""
+def shard_sizes(total, world):
+    """Shard sizes of every rank under shard_range: deterministic, so no rank has to ask another for its size."""
+    return [hi - lo for lo, hi in (shard_range(total, r, world) for r in range(world))]
+
+
+def _all_gather_rows(t, total=None, group=None):
+    """All-gather along dim 0 in ONE collective. `total` = the global number of rows when the shards are ragged (the contiguous
+    partition of shard_range: every rank computes every shard size itself); None = equal shards. Ragged shards travel in a
+    max-size buffer (at most one padding row per rank) and are cut back after the exchange."""
     world = dist.get_world_size(group)
-    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
-    if len(set(sizes)) == 1:
-        out = t.new_empty((world * sizes[0],) + tuple(t.shape[1:]))
-        dist.all_gather_into_tensor(out, t.contiguous(), group=group)
-        return out
+    sizes = [int(t.shape[0])] * world if total is None else shard_sizes(total, world)
+    rank = dist.get_rank(group)
+    if sizes[rank] != t.shape[0]:
+        raise ValueError(f"rank {rank} holds {t.shape[0]} rows but shard_range({total}, {rank}, {world}) has {sizes[rank]}: "
+                         "pass the global batch size of a shard_range partition as `total`")
     mx = max(sizes)
-    pad = t.new_zeros((mx,) + tuple(t.shape[1:]))
-    pad[: t.shape[0]] = t
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
-    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+    src = t.contiguous()
+    if src.shape[0] != mx:  # the short shards: one padding row
+        src = torch.cat([src, src.new_zeros((mx - src.shape[0],) + tuple(src.shape[1:]))], dim=0)
+    out = t.new_empty((world * mx,) + tuple(t.shape[1:]))
+    dist.all_gather_into_tensor(out, src, group=group)
+    if len(set(sizes)) == 1:
+        return out
+    out = out.reshape((world, mx) + tuple(t.shape[1:]))
+    return torch.cat([out[r, :n] for r, n in enumerate(sizes)], dim=0)
 
 
-def gather_policy(engine, group=None):
-    """The one collective: every rank ends up with the whole batch's time-varying
-    linear-Gaussian controllers (K, k, sigK), plan cost, temperature and status.
-    Payload per trajectory: T (nu nx + nu + nu(nu+1)/2) + 3 scalars."""
+def gather_policy(engine, group=None, total=None):
+    """The one collective (a single all_gather_into_tensor: RCCL over xGMI): every rank ends up with the whole batch's
+    time-varying linear-Gaussian controllers (K, k, sigK), plan cost, temperature and status.
+    Payload per trajectory: T (nu nx + nu + nu(nu+1)/2) + 3 scalars.
+    total: the global batch size when it does not divide by the number of ranks (shards from shard_range); None: equal shards."""
     K, k, sigK = engine.local_linear_policy()
     B = engine.B
     flat = torch.cat(
@@ -54,7 +63,7 @@ def gather_policy(engine, group=None):
         dim=1,
     ).contiguous()
     if dist.is_available() and dist.is_initialized():  # also with one rank: same code path as N > 1
-        flat = _all_gather_rows(flat, group)
+        flat = _all_gather_rows(flat, total, group)
     n = flat.shape[0]
     T, nu, nx = engine.H, engine.nu, engine.nx
     o1 = T * nu * nx

@@ -122,11 +122,11 @@ def assert_close(a, b, rtol, what="", elem_rtol=None, atol_rel=ATOL_REL):
                           f"{elem_rtol:.0e} |b| + {atol_rel:.0e} max|b| by {x:.2f}x")
 
 
-def assert_close_per_cell(a, b, rtol, what="", axis=0, floor_rel=1e-8):
+def assert_close_per_cell(a, b, rtol, what="", axis=0, floor_rel=1e-7):
     """Max-norm relative error of every cell (slice along `axis`) on its own: a gain K that is wrong in a cell where it is small
     does not hide behind the cells where it is large. Cells whose reference is below floor_rel * max|b| are compared absolutely,
-    against rtol * floor_rel * max|b| (the terminal cell's K is exactly 0 here and rounding noise in the reference -- up to 1e-13 of
-    the array maximum in the cartpole golden; covariance control has such cells in mid-horizon)."""
+    against rtol * floor_rel * max|b| (the terminal cell's K is exactly 0 here and rounding noise in the reference and the oracle -- up to
+    1e-12 of the array maximum in the batched cartpole runs; covariance control has such cells in mid-horizon)."""
     a, b = np.asarray(a, float), np.asarray(b, float)
     assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
     a2 = np.moveaxis(a, axis, 0).reshape(a.shape[axis], -1)

@@ -59,12 +59,27 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     assert lib.i2c_mstep(ctypes.byref(p), None, 0.0, 1, None, None) == -1
 
 
+def _shape(model_id, B, T, mode=0, inference=0, dtype=0, group_lanes=0, post_layout=0, gh_degree=3):
+    """An I2cProblem with its scalar fields only: what the two resolvers read (no buffer exists yet)."""
+    N = pkg._native
+    p = N.I2cProblem()
+    p.abi_version, p.model_id, p.B, p.T, p.backward_mode, p.inference, p.dtype = N.ABI_VERSION, model_id, B, T, mode, inference, dtype
+    p.group_lanes, p.post_layout, p.gh_degree = group_lanes, post_layout, gh_degree
+    p.quad_alpha, p.quad_beta, p.quad_kappa = 1.0, 0.0, 0.0
+    return p
+
+
 def test_backward_schedule_rule():
-    """I2C_BWD_AUTO: chunked below 32768 trajectories, fused from there on; chunked needs T >= 8; explicit requests are
-    honoured; unknown models / modes give 0."""
+    """i2c_backward_schedule(problem) is THE resolver of the backward schedule: the lane kernels' batch rule (I2C_BWD_AUTO: chunked
+    below 32768 trajectories, fused from there on; chunked needs T >= 8; explicit requests honoured), and on top of it the family
+    of the sweep (wave / quad / group: the fused walk), the inference rule (Linearize, Gauss-Hermite: fused, chunked at small
+    batches) and the storage type; refusals come back as the error code the sweep would return."""
     lib = pkg.load_library()
     N = pkg._native
-    f = lib.i2c_backward_schedule
+
+    def f(*a, **k):
+        return lib.i2c_backward_schedule(ctypes.byref(_shape(*a, **k)))
+
     assert f(0, 4096, 200, N.BWD_AUTO) == N.BWD_CHUNKED
     assert f(0, 32768, 200, N.BWD_AUTO) == N.BWD_FUSED
     assert f(2, 65536, 500, N.BWD_AUTO) == N.BWD_FUSED       # cartpole, d = 5
@@ -75,7 +90,37 @@ def test_backward_schedule_rule():
     assert f(0, 4096, 5, N.BWD_CHUNKED) == N.BWD_TWO_PASS
     for m in (N.BWD_TWO_PASS, N.BWD_FUSED, N.BWD_CHUNKED):
         assert f(3, 100000, 300, m) == m
-    assert f(99, 4096, 200, N.BWD_AUTO) == 0 and f(0, 4096, 200, 7) == 0 and f(0, 0, 200, 0) == 0
+    assert f(99, 4096, 200, N.BWD_AUTO) == -1 and f(0, 4096, 200, 7) == -1 and f(0, 0, 200, 0) == -1  # I2C_EINVAL
+    assert lib.i2c_backward_schedule(None) == -1
+    # fp32-stored messages (I2C_F64_F32S): the lane rule
+    assert f(0, 4096, 200, dtype=N.F64_F32S) == N.BWD_CHUNKED and f(0, 65536, 200, dtype=N.F64_F32S) == N.BWD_FUSED
+    # Linearize(): chunked at small batches (fp64 storage), the sequential walk otherwise; no two-pass form
+    assert f(0, 4096, 200, inference=N.INF_LINEARIZE) == N.BWD_CHUNKED
+    assert f(0, 65536, 200, inference=N.INF_LINEARIZE) == N.BWD_FUSED
+    assert f(0, 4096, 200, N.BWD_TWO_PASS, inference=N.INF_LINEARIZE) == N.BWD_FUSED
+    assert f(1, 4096, 100, inference=N.INF_LINEARIZE) == -1   # PendulumKnownActReg has no terminal observation (i2c.py:500-501)
+    assert f(0, 4096, 200, inference=N.INF_LINEARIZE, dtype=N.F64_F32S) == -2  # I2C_ENOTSUP
+    # Gauss-Hermite: the same pair of schedules
+    assert f(0, 4096, 200, inference=N.INF_GAUSS_HERMITE) == N.BWD_CHUNKED
+    assert f(0, 65536, 200, inference=N.INF_GAUSS_HERMITE) == N.BWD_FUSED
+    assert f(0, 4096, 200, inference=N.INF_GAUSS_HERMITE, gh_degree=0) == -1
+    # group kernels: one schedule
+    assert f(3, 4096, 300, group_lanes=16) == N.BWD_FUSED and f(0, 4096, 200, N.BWD_CHUNKED, group_lanes=4) == N.BWD_FUSED
+    assert f(0, 4096, 200, group_lanes=8) == -2               # not this model's group width
+    # the 12-state quadrotor (trajectory-major posterior): wave kernels -> fused, two-pass on request; quad backward from 4096 up;
+    # Linearize keeps the wave form; group kernels when asked for
+    Q12 = 7
+    assert f(Q12, 1024, 50, post_layout=1) == N.BWD_FUSED and f(Q12, 1024, 50, N.BWD_CHUNKED, post_layout=1) == N.BWD_FUSED
+    assert f(Q12, 1024, 50, N.BWD_TWO_PASS, post_layout=1) == N.BWD_TWO_PASS
+    assert f(Q12, 8192, 50, post_layout=1) == N.BWD_FUSED
+    assert f(Q12, 1024, 50, N.BWD_TWO_PASS, post_layout=1, inference=N.INF_LINEARIZE) == N.BWD_FUSED
+    assert f(Q12, 1024, 50, post_layout=1, group_lanes=16) == N.BWD_FUSED
+    assert f(Q12, 1024, 50, post_layout=1, group_lanes=-1) == -2  # no one-lane kernels for d = 16
+    assert f(0, 4096, 200, post_layout=1) == -2               # trajectory-major posterior: wave-capable models only
+    # ... and i2c_kernel_family answers from the same scalar fields
+    fam = lambda *a, sweep=N.SWEEP_BACKWARD, **k: lib.i2c_kernel_family(ctypes.byref(_shape(*a, **k)), sweep)  # noqa: E731
+    assert fam(Q12, 1024, 50, post_layout=1) == N.FAMILY_WAVE and fam(Q12, 8192, 50, post_layout=1) == N.FAMILY_QUAD
+    assert fam(3, 4096, 300, sweep=N.SWEEP_FORWARD) == N.FAMILY_QUAD and fam(3, 4096, 300) == N.FAMILY_LANE
 
 
 def test_bad_arguments_of_the_newer_entry_points():

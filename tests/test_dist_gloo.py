@@ -34,8 +34,24 @@ def _worker(rank, world, port, B, iters, out_dir, golden="em_pendulum_T40_quad_g
         eng = parity.engine_from_case(g, hostsim.load(), "cpu", x0=x0[lo:hi], mu_u=mu_u[lo:hi])
         for _ in range(iters):
             eng.learn_msgs()
-        got = pkg.dist.gather_policy(eng)
+        # count the collectives of the job's one exchange (round-4 review, weak #10: it used to be two -- sizes, then the payload)
+        calls = []
+        real = {n: getattr(dist, n) for n in ("all_gather", "all_gather_into_tensor", "all_reduce", "broadcast", "all_to_all", "gather")}
+        for n, fn in real.items():
+            setattr(dist, n, (lambda n_, fn_: lambda *a, **k: (calls.append(n_), fn_(*a, **k))[1])(n, fn))
+        try:
+            got = pkg.dist.gather_policy(eng, total=B)
+        finally:
+            for n, fn in real.items():
+                setattr(dist, n, fn)
+        assert calls == ["all_gather_into_tensor"], calls
         assert got["K"].shape[0] == B
+        if B % world:  # ragged shards need the global size: a silent mis-slice is refused
+            try:
+                pkg.dist._all_gather_rows(torch.zeros(hi - lo + 1, 2), total=B)
+                raise AssertionError("a shard of the wrong size was accepted")
+            except ValueError:
+                pass
         if rank == 0:
             np.savez(os.path.join(out_dir, "gathered.npz"), **{k: v.numpy() for k, v in got.items()})
         # every rank holds the same gathered result

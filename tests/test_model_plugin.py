@@ -157,7 +157,10 @@ def check_abi(lib, model_lib):
     assert (q.nx, q.e_post, q.e_fwd) == (2, d.e_post, d.e_fwd)
     with pytest.raises(ValueError):
         lib.query(mid + 17)  # an id nobody was given
-    assert lib.i2c_backward_schedule(mid, 64, 40, N.BWD_AUTO) == N.BWD_CHUNKED and lib.i2c_workspace_bytes(mid, N.F64, 64, 40) > 0
+    p = N.I2cProblem()
+    p.abi_version, p.model_id, p.B, p.T, p.quad_alpha = N.ABI_VERSION, mid, 64, 40, 1.0
+    assert lib.i2c_backward_schedule(C.byref(p)) == N.BWD_CHUNKED and lib.i2c_workspace_bytes(mid, N.F64, 64, 40) > 0
+    assert lib.i2c_kernel_family(C.byref(p), N.SWEEP_FORWARD) == N.FAMILY_LANE
 
 
 def build_module():

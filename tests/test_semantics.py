@@ -143,10 +143,9 @@ def test_ckf_filter_accepts_strided_inputs():
 def test_horizon_beyond_status_word_is_refused():
     g = load_case("em_pendulum_T200")
     T = 65536
-    e = parity.pkg.BatchedI2c(parity.product_model(g), T, g["Q"], g["R"], g["Qf"], 100.0, 0.0, np.zeros((T, 1)), g["sig_u"],
+    with pytest.raises(RuntimeError, match="-1"):  # (refused when the engine asks the library's resolver: I2C_EINVAL)
+        parity.pkg.BatchedI2c(parity.product_model(g), T, g["Q"], g["R"], g["Qf"], 100.0, 0.0, np.zeros((T, 1)), g["sig_u"],
                               lib=hostsim.load(), device="cpu", keep_zpost=False, keep_xm=False)
-    with pytest.raises(RuntimeError, match="-1"):
-        e.forward_sweep()
 
 
 def test_use_expert_controller_is_per_cell():
@@ -250,16 +249,29 @@ def test_kernel_family_is_inspectable():
     assert eng("DoubleCartpoleKnown", 64, group_lanes=-1).forward_family == "lane"
     q = eng("Quadrotor12", 3)
     assert q.forward_family in ("group", "wave") and q.kernel_family("filter") in ("group", "wave")
-    lin = eng("PendulumKnown", 4, inference="linearize", group_lanes=True)
+    # the group kernels have no Linearize() / Gauss-Hermite sweeps: the engine asks the resolver when it is built and refuses with
+    # the library's code (I2C_ENOTSUP) -- it used to swallow the refusal until a sweep was called (round-3 advice, round-4 review #8)
     with pytest.raises(RuntimeError, match="-2"):
-        lin.kernel_family("forward")
-    # the estimator and the closed-loop propagation of a Linearize() graph ARE the unit cubature rule (mpc.py:121-123,
-    # i2c.py:109-115): the group kernels serve them; a Gauss-Hermite graph propagates with its own grid, which they do not cover
-    assert lin.kernel_family("filter") == "group" and lin.kernel_family("propagate") == "group"
-    gh = eng("PendulumKnown", 4, inference="gauss_hermite", gh_degree=3, group_lanes=True)
-    assert gh.kernel_family("filter") == "group"
-    with pytest.raises(RuntimeError, match="-2"):
-        gh.kernel_family("propagate")
+        eng("PendulumKnown", 4, inference="linearize", group_lanes=True)
+    # ... while the estimator and the closed-loop propagation of a Linearize() graph ARE the unit cubature rule (mpc.py:121-123,
+    # i2c.py:109-115): the group kernels serve them; a Gauss-Hermite graph propagates with its own grid, which they do not cover.
+    # (asked of the resolver itself: it reads the scalar fields of a problem only)
+    import ctypes
+
+    N = parity.pkg._native
+
+    def family(sweep, **fields):
+        p = N.I2cProblem()
+        p.abi_version, p.model_id, p.B, p.T, p.quad_alpha, p.group_lanes, p.gh_degree = N.ABI_VERSION, 0, 4, 8, 1.0, 4, 3
+        for k, v in fields.items():
+            setattr(p, k, v)
+        return lib.i2c_kernel_family(ctypes.byref(p), sweep)
+
+    assert family(N.SWEEP_FORWARD, inference=N.INF_LINEARIZE) == -2 and family(N.SWEEP_BACKWARD, inference=N.INF_LINEARIZE) == -2
+    assert family(N.SWEEP_FILTER, inference=N.INF_LINEARIZE) == N.FAMILY_GROUP
+    assert family(N.SWEEP_PROPAGATE, inference=N.INF_LINEARIZE) == N.FAMILY_GROUP
+    assert family(N.SWEEP_FILTER, inference=N.INF_GAUSS_HERMITE) == N.FAMILY_GROUP
+    assert family(N.SWEEP_PROPAGATE, inference=N.INF_GAUSS_HERMITE) == -2
 
 
 def test_linearize_propagation_ignores_the_quadrature_fields():

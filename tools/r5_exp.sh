@@ -1,9 +1,5 @@
 set -u
 export TMPDIR=/tmp
-O=gpurun_out/r5; mkdir -p $O
-{
-echo "== quad goldens"; python3 tools/quad_check.py
-echo "== timings"; python3 tools/bench_models.py f64 DoubleCartpoleKnown CartpoleKnown PlanarQuadrotor 4096
-python3 tools/bench_models.py f64 DoubleCartpoleKnown PlanarQuadrotor 8192
-python3 tools/bench_models.py f64 Quadrotor12 4096 32768
-} > $O/exp2.txt 2>&1
+O=$PWD/gpurun_out/r5; mkdir -p $O
+python -m pytest tests -q -m gpu -n 4 2>&1 | grep -E "^E  .*Error|^FAILED|passed|failed" | head -40 > $O/exp5_tests.txt
+python bench.py > $O/exp5_bench.json 2> $O/exp5_bench.err
