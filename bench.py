@@ -125,7 +125,7 @@ def algorithmic_elements(d, nx, nu):
 
 def measured_traffic(B, T, dtype, kernel):
     """HBM bytes per launch from the committed PMC passes (tools/pmc_summary.py), if one matches."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_B{B}_pmc_traffic.json") for r in (4, 3, 2, 1)) if os.path.exists(q)),
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_B{B}_pmc_traffic.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(q)),
                 os.path.join(ROOT, "profiles", f"r1_B{B}_pmc_traffic.json"))
     if not os.path.exists(path):
         return None
@@ -144,6 +144,12 @@ def issue_roofline(profile, kernel_prefix, cells_per_wave, lanes_per_trajectory,
     (tools/sq_counters.sh -> profiles/<profile>_sq_counters.json): how busy the SIMD's fp64 pipe is while a wave is resident
     (4 clocks per vector instruction of a wave64, 16 clocks per 512-flop unit of an fp64 matrix instruction), how many of the chip's
     1024 SIMDs hold a wave at all, and the executed fp64 flops against the chip's peak at the live kernel time."""
+    def latest(name):  # "rN_<name>": the newest round that committed this profile
+        return next((f"r{r}_{name}" for r in (5, 4, 3, 2) if os.path.exists(os.path.join(ROOT, "profiles", f"r{r}_{name}_sq_counters.json"))), "r4_" + name)
+
+    profile = latest(profile)
+    if useful is not None:
+        useful = (latest(useful[0]), useful[1])
     path = os.path.join(ROOT, "profiles", profile + "_sq_counters.json")
     if not os.path.exists(path):
         return None
@@ -292,7 +298,7 @@ def extra_config_legs(pkg, device, K=10):
     evs[1].record(); sync()
     fwd_ms = evs[0].elapsed_time(evs[1]) / 5
     out["double_cartpole_T300_B4096"]["forward_sweep_ms"] = fwd_ms
-    out["double_cartpole_T300_B4096"]["issue"] = issue_roofline("r4_dcp_B4096", "k_quad_forward", T, 16, fwd_ms, B * T, useful=("r4_dcp_B4096_group_and_lane", "k_forward"))
+    out["double_cartpole_T300_B4096"]["issue"] = issue_roofline("dcp_B4096", "k_quad_forward", T, 16, fwd_ms, B * T, useful=("dcp_B4096_group_and_lane", "k_forward"))
     del eng
     # config 3's "fp32 vs fp64 tolerance sweep", the speed side: the same problem with fp32-STORED messages (fp64 arithmetic; the
     # deviation from the fp64 run is bounded and asserted in tests/test_precision.py: median 1e-4, 99th percentile 3e-2 of the batch)
@@ -344,7 +350,7 @@ def extra_config_legs(pkg, device, K=10):
             C = eng.dims
             out[tag]["forward_sweep_ms"], out[tag]["backward_sweep_ms"] = fwd_ms, bwd_ms
             out[tag]["backward_sweep_algorithmic_GBps"] = (C.e_fwd + C.e_post) * 8 * Bn * Tn / bwd_ms / 1e6
-            out[tag]["issue"] = issue_roofline("r4_quad12_B32768_quad_vs_wave", "k_quad_forward", Tn, 16, fwd_ms, Bn * Tn)
+            out[tag]["issue"] = issue_roofline("quad12_B32768_quad_vs_wave", "k_quad_forward", Tn, 16, fwd_ms, Bn * Tn)
             if out[tag]["issue"]:  # (d = 16 has no one-lane kernel to count the non-redundant flops with)
                 out[tag]["issue"]["useful_flops_basis"] = "executed flops of this kernel (sixteen lanes per trajectory: an upper bound of the useful count)"
         del eng, mu_u, x0
@@ -637,11 +643,11 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": measured_traffic(B, T, args.dtype, "k_forward"),
             "traffic_note": "bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                            "(FETCH_SIZE x2, gfx950 correction; profiles/r4_B4096_pmc_traffic.json); algorithmic = "
+                            "(FETCH_SIZE x2, gfx950 correction; profiles/r5_B4096_pmc_traffic.json, r4_ before it); algorithmic = "
                             + str(fwd_bytes),
             "algorithmic_bytes_per_cell": {k: v * wbytes for k, v in el.items()},
             "whole_iteration_GBps": el["total"] * wbytes * B * T / (elapsed / K) / 1e9,
-            "issue": issue_roofline("r4_pendulum_B4096", "k_forward", T, 1, fwd_ms, B * T) if (B, T) == (4096, 200) else None,
+            "issue": issue_roofline("pendulum_B4096", "k_forward", T, 1, fwd_ms, B * T) if (B, T) == (4096, 200) else None,
             "note": "instruction-issue-bound at B=4096 per GPU: 64 lone wavefronts (1024 SIMDs), each issuing 88 % of its cycles "
                     "(profiles/r4_pendulum_B4096_sq_counters.json, r3_pendulum_B4096_chunked_sq_summary.txt; `issue`: what the fp64 "
                     "pipe of an occupied SIMD is doing); spreading a trajectory over lanes is SLOWER for this 3-dimensional model "

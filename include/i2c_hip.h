@@ -81,12 +81,14 @@ enum {
 
 /* how i2c_backward_sweep is scheduled (results are identical up to summation order of the cost) */
 enum {
-  I2C_BWD_AUTO = 0,     /* resolved by i2c_backward_schedule(): chunked below I2C_BWD_FUSED_MIN_B trajectories, fused from there on */
+  I2C_BWD_AUTO = 0,     /* resolved by i2c_backward_schedule(): chunked below the model's crossover batch, fused from there on */
   I2C_BWD_TWO_PASS = 1, /* sequential nx x nx scan + one lane per (t, b) + reduction                  */
   I2C_BWD_FUSED = 2,    /* one lane per trajectory does the whole cell: lowest HBM traffic            */
   I2C_BWD_CHUNKED = 3   /* the affine x-recursion composed per chunk of cells: sequential depth ~2T/NC; needs `work` */
 };
-#define I2C_BWD_FUSED_MIN_B 32768
+#define I2C_BWD_FUSED_MIN_B 12288 /* library-wide default, re-derived in round 5 from time and HBM traffic at B = 8192 .. 32768 (pendulum,
+                                     cartpole, planar quadrotor all cross between 8192 and 16384; it was 32768); a model may carry its own
+                                     (double cartpole: 20480) -- profiles/r5_backward_crossover.txt; i2c_backward_schedule() answers */
 
 /* kernel families (i2c_kernel_family): how the lanes of a wavefront are mapped onto trajectories */
 enum {

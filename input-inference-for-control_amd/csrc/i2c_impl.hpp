@@ -567,6 +567,14 @@ template <class M> static size_t workspace_elems(int B, int T) {
   return (size_t)nc * (size_t)B * (size_t)((NX + NX * NX + sym(NX)) + (NX + sym(NX)) + 3);  // (3: the Linearize form's partial sums)
 }
 
+// batch size from which I2C_BWD_AUTO runs the fused walk: the model's own measured crossover, or the library-wide default
+template <class M, class = void> struct bwd_fused_min_b {
+  static constexpr int value = I2C_BWD_FUSED_MIN_B;
+};
+template <class M> struct bwd_fused_min_b<M, std::void_t<decltype(M::BWD_FUSED_MIN_B)>> {
+  static constexpr int value = M::BWD_FUSED_MIN_B;
+};
+
 // ---- per-(model, dtype) entry points ------------------------------------------------------
 // Which kernels serve a call:
 //   M::GROUP      lanes per trajectory of the model's group kernels (0: none compiled); fp64 only
@@ -773,9 +781,13 @@ template <class M, typename R, typename S = R> struct Impl {
     return I2C_ENOTSUP;
   }
 
-  // Measured on MI355X (tools/bench_models.py): below ~32k trajectories the sequential depth decides -> chunked.
-  // Above, HBM traffic decides -> fused (264 instead of ~490 B/cell for the pendulum; double cartpole B = 32768: fused 2.45,
-  // chunked 3.31 ms; B = 16384: 2.25 against 1.76). Models that only have group kernels run the fused walk.
+  // Small batches: the sequential depth decides -> chunked. Large ones: HBM traffic decides -> fused (the chunked form moves
+  // compose + stitch + walk = 1.44x the walk's bytes, PMC: pendulum 381 against 264.5 B per cell, double cartpole 1 914 against
+  // 1 177). The crossover is PER MODEL (M::BWD_FUSED_MIN_B, i2c_models.hpp), re-derived in round 5 from time AND traffic at
+  // B = 8192 .. 32768, beyond the 256 MB Infinity Cache (profiles/r5_backward_crossover.txt): pendulum 8192: chunked 0.111 /
+  // fused 0.175 ms, 16384: 0.237 / 0.193 (cartpole 0.72 / 0.99, 1.38 / 1.01; planar quadrotor 0.21 / 0.27, 0.38 / 0.30); double
+  // cartpole 16384: 1.67 / 1.86, 24576: 3.44 / 2.20. Models that only have group
+  // kernels run the fused walk.
   static int schedule(int B, int T, int requested) {
     if (M::WAVE && M::GROUP_ONLY) {
       // wave kernels: the fused walk, or on request the two-pass schedule (scan + one wave per (t, b) cell). Measured on MI355X
@@ -788,7 +800,7 @@ template <class M, typename R, typename S = R> struct Impl {
     if (M::GROUP_ONLY) return I2C_BWD_FUSED;
     int mode = requested;
     if (mode == I2C_BWD_AUTO)
-      mode = B < I2C_BWD_FUSED_MIN_B ? I2C_BWD_CHUNKED : I2C_BWD_FUSED;
+      mode = B < bwd_fused_min_b<M>::value ? I2C_BWD_CHUNKED : I2C_BWD_FUSED;
     if (mode == I2C_BWD_CHUNKED && T < 8) mode = I2C_BWD_TWO_PASS;  // too short to chunk
     return mode;
   }

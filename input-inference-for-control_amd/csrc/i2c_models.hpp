@@ -31,6 +31,8 @@ struct ModelDefaults {
   static constexpr int QUAD_FORWARD_MAX_B = 0;
   static constexpr int QUAD_FORWARD_MIN_B = 0;
   static constexpr int QUAD_BACKWARD_MIN_B = 0;
+  // (optional) static constexpr int BWD_FUSED_MIN_B: batch size from which I2C_BWD_AUTO runs the fused backward walk instead of the
+  // chunked schedule; models without it take I2C_BWD_FUSED_MIN_B (include/i2c_hip.h)
   I2C_HD static constexpr int ang(int) { return 0; }
   // structure hints of the observation functions (ObsStruct, i2c_cell.hpp): output k is a pass-through of input obs_lin(k), or
   // (-1) a general function that depends on no input with an index above obs_dep(k). The defaults say "nothing is known"
@@ -189,6 +191,7 @@ struct DoubleCartpole {
   static constexpr int QUAD_FORWARD_MAX_B = 8192;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   static constexpr int QUAD_FORWARD_MIN_B = 0;
   static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (the quad backward sweep exists for d = 16 only)
+  static constexpr int BWD_FUSED_MIN_B = 20480;  // I2C_BWD_AUTO runs the fused backward walk from here up: its rows are the widest (104 doubles), the chunked form keeps its lead longer (measured: 16384: chunked 1.67 / fused 1.86 ms; 24576: 3.44 / 2.20)
   I2C_HD static constexpr int ang(int a) { return a == 0 ? 1 : 2; }
   // z = [x, sin th1, cos th1, sin th2, cos th2, xd, th1d, th2d, u],  zT = z without u
   I2C_HD static constexpr int obs_lin(int k) { return k == 0 ? 0 : (k < 5 ? -1 : k - 2); }

@@ -420,6 +420,17 @@ I2C_FN void q_elim2(const Quad<R>& q, R* sa, R* ra1, R* ra2, R* lta, bool* oka, 
   *okb = lastb > R(0);
 }
 
+// observe() without its last outputs (LASTLIN, forward_quad_body): the first NOUT of them
+template <class M, typename R, int NOUT> struct ObserveHeadF {
+  const R* p;
+  I2C_HD inline void operator()(const R* x, const R* sn, const R* cs, R* y) const {
+    R yy[M::NZ];
+    M::observe(p, x, sn, cs, yy);
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) y[k] = yy[k];
+  }
+};
+
 // ---- sigma points ------------------------------------------------------------------------------------------------------------
 // The points m +/- sf L[:, p] of a DIN-dimensional rule through f, one evaluation per lane of the trajectory and pass
 // (d <= 8: lane p < 8: +, lane 8 + p: -, one pass; d <= 16: lane p: + in the first pass, - in the second; geometry G = QG<model>).
@@ -674,6 +685,13 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
   static_assert(D <= 16 && NZ <= 16 && NZT <= 16, "quad kernels: d <= 16");
   constexpr bool OBS_ID = st_identity<ObsStruct<M>, NZ>() && NZ == D;
   constexpr bool TERM_ID = NZT > 0 && st_identity<TermStruct<M>, NT>() && NT == NX;
+  // the last observation output as a scalar pre-elimination (see stage 2): a pass-through of a coordinate of the joint's last block
+  // that would otherwise be a block row of its own
+#ifndef I2C_QUAD_LASTLIN
+#define I2C_QUAD_LASTLIN 1
+#endif
+  constexpr int JZL = M::obs_lin(NZ - 1);
+  constexpr bool LASTLIN = I2C_QUAD_LASTLIN && !OBS_ID && NZ % 4 == 1 && NZ > 4 && JZL >= 0 && JZL / 4 == (D + 3) / 4 - 1;
   static_assert(OBS_ID || D % 4 != 0, "quad kernels: a general observation needs a spare column in the joint's last block");
   static_assert(OBS_ID || NU == 1, "quad kernels: a general observation with one action (the factor of S_u|x is a square root)");
   constexpr int JU = NX / 4, CU = NX % 4;  // the block (row and column) and the in-block offset where the action entries start
@@ -982,6 +1000,65 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
       cell_bad = flag_stage(cell_bad, q_kalman_identity<D, QLD>(q, alpha, kc.xi, kc.qr, c.qr_diag != 0, zt, mu0, sf_, kz), 2);
 #pragma unroll
       for (int k = 0; k < NBD * NBD; ++k) s0[k] = sf_[k];
+    } else if constexpr (LASTLIN) {
+      // The last observation output is a PASS-THROUGH of joint coordinate JZL (the double cartpole observes its action as z[8]) and
+      // would be a block row of its own (NZ = 4 n + 1). Its moments are exact -- mean mu0[JZL], variance sig_0[JZL][JZL], covariances
+      // rows of sig_0 and a column of cov(z, xu) -- so it is conditioned on FIRST, as a scalar (any order of a Gaussian conditioning
+      // gives the same posterior: the block elimination below with this pivot taken first): rank-one corrections of sig_0, of
+      // the remaining observation covariance and cross-covariance, elementwise. The points evaluate NZ - 1 outputs, the
+      // factorisation has one pivot phase less, and every block matrix of the update loses a block row / column.
+      I2C_QSTAMP(1);
+      constexpr int NZ8 = NZ - 1, NB8 = NZ8 / 4, BJ = JZL / 4, CZ = JZL % 4;
+      R am[NBD * NB8], dm[NBD * NB8], yc[NB8], mz[NB8], sz[NB8 * NB8], szx[NB8 * NBD];
+      q_points<M, G, D, NZ8>(q, rule.sf, mu0, lt0, ObserveHeadF<M, R, NZ8>{c.params}, am, dm, yc);
+      I2C_QSTAMP(2);  // observation points
+      q_moments<D, NZ8>(q, rule.wi, am, dm, yc, mz, sz);
+#pragma unroll
+      for (int i = 0; i < NB8; ++i)
+#pragma unroll
+        for (int j = i; j < NB8; ++j) sz[i * NB8 + j] += alpha * q_ldc<QLD>(q, kc.xi, i, j, kz);
+#pragma unroll
+      for (int k = 0; k < NB8 * NBD; ++k) szx[k] = R(0);
+      q_tn<NBD, NB8, NBD, false, false, true>(q, dm, lt0, szx);  // cov(z, xu) = wi sf [d_p]^T L^T
+      const R cw = rule.wi * rule.sf;
+#pragma unroll
+      for (int k = 0; k < NB8 * NBD; ++k) szx[k] *= cw;
+      I2C_QSTAMP(3);  // observation moments
+      // h = sig_0[:, JZL] = cov(xu, z_last), b = cov(z_head, z_last) (+ the noise column), both in row and in column form
+      R hrow[NBD], hcol[NBD], brow[NB8], bcol[NB8];
+#pragma unroll
+      for (int i = 0; i < NBD; ++i) {
+        hrow[i] = q_bcq<CZ>(q, s0[i * NBD + BJ]);
+        hcol[i] = q_tr(q, hrow[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < NB8; ++i) {
+        brow[i] = q_bcq<CZ>(q, szx[i * NBD + BJ]) + alpha * kc.xi[(4 * i + r) * QLD + NZ8 + kz];
+        bcol[i] = q_tr(q, brow[i]);
+      }
+      // c = var(z_last) + its noise, to every lane of the trajectory; nu = target - mean
+      const R cvar = q_colsum(q, r == CZ ? hrow[BJ] : R(0)) + alpha * kc.xi[NZ8 * QLD + NZ8 + kz];
+      cell_bad = flag_stage(cell_bad, cvar > R(0), 2);
+      const R ic = r_rcp(cvar);
+      const R nu = (q_bcq<0>(q, zt[NB8]) - q_bcq<CZ>(q, mu0[BJ])) * ic;  // (target of output NZ - 1: column 0 of its block)
+      R zth[NB8];
+#pragma unroll
+      for (int i = 0; i < NB8; ++i) {
+        const R bi = brow[i] * ic;
+#pragma unroll
+        for (int j = i; j < NB8; ++j) sz[i * NB8 + j] -= bi * bcol[j];
+#pragma unroll
+        for (int j = 0; j < NBD; ++j) szx[i * NBD + j] -= bi * hcol[j];
+        zth[i] = zt[i] - bcol[i] * nu;  // the head's innovation given the last output: (zt - mz) - b nu
+      }
+#pragma unroll
+      for (int i = 0; i < NBD; ++i) {
+        const R hi_ = hrow[i] * ic;
+#pragma unroll
+        for (int j = i; j < NBD; ++j) s0[i * NBD + j] -= hi_ * hcol[j];
+        mu0[i] += hcol[i] * nu;
+      }
+      cell_bad = flag_stage(cell_bad, q_kalman<D, NZ8>(q, mu0, s0, mz, sz, szx, zth), 2);
     } else {
       I2C_QSTAMP(1);
       R am[NBD * NBZ], dm[NBD * NBZ], yc[NBZ], mz[NBZ], sz[NBZ * NBZ], szx[NBZ * NBD];

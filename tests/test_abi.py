@@ -71,7 +71,7 @@ def _shape(model_id, B, T, mode=0, inference=0, dtype=0, group_lanes=0, post_lay
 
 def test_backward_schedule_rule():
     """i2c_backward_schedule(problem) is THE resolver of the backward schedule: the lane kernels' batch rule (I2C_BWD_AUTO: chunked
-    below 32768 trajectories, fused from there on; chunked needs T >= 8; explicit requests honoured), and on top of it the family
+    below the model's crossover batch (12288; double cartpole 20480), fused from there on; chunked needs T >= 8; explicit requests honoured), and on top of it the family
     of the sweep (wave / quad / group: the fused walk), the inference rule (Linearize, Gauss-Hermite: fused, chunked at small
     batches) and the storage type; refusals come back as the error code the sweep would return."""
     lib = pkg.load_library()
@@ -81,11 +81,15 @@ def test_backward_schedule_rule():
         return lib.i2c_backward_schedule(ctypes.byref(_shape(*a, **k)))
 
     assert f(0, 4096, 200, N.BWD_AUTO) == N.BWD_CHUNKED
-    assert f(0, 32768, 200, N.BWD_AUTO) == N.BWD_FUSED
+    assert f(0, 32768, 200, N.BWD_AUTO) == N.BWD_FUSED and f(0, 8192, 200, N.BWD_AUTO) == N.BWD_CHUNKED
     assert f(2, 65536, 500, N.BWD_AUTO) == N.BWD_FUSED       # cartpole, d = 5
     assert f(3, 32768, 300, N.BWD_AUTO) == N.BWD_FUSED       # double cartpole, d = 7 (its fused walk no longer spills)
     assert f(6, 32768, 50, N.BWD_AUTO) == N.BWD_FUSED        # quadrotor, d = 8: fits since the rows are single-buffered
     assert f(3, 4096, 300, N.BWD_AUTO) == N.BWD_CHUNKED
+    # the crossover is per model, re-derived from time and HBM traffic in round 5 (profiles/r5_backward_crossover.txt)
+    assert f(0, 12287, 200) == N.BWD_CHUNKED and f(0, 12288, 200) == N.BWD_FUSED      # pendulum-sized models
+    assert f(3, 20479, 300) == N.BWD_CHUNKED and f(3, 20480, 300) == N.BWD_FUSED      # double cartpole
+    assert f(2, 12287, 500) == N.BWD_CHUNKED and f(2, 12288, 500) == N.BWD_FUSED      # cartpole: the library-wide default
     assert f(0, 4096, 5, N.BWD_AUTO) == N.BWD_TWO_PASS
     assert f(0, 4096, 5, N.BWD_CHUNKED) == N.BWD_TWO_PASS
     for m in (N.BWD_TWO_PASS, N.BWD_FUSED, N.BWD_CHUNKED):
