@@ -208,12 +208,13 @@ template <int NL, typename R, class P> I2C_FN void q_pivot_fetch(const P dg, R* 
     for (int j = 0; j <= i; ++j) d[tri(i, j)] = dg[4 * i + j];
 }
 template <int NL, typename R> I2C_FN void q_pivot_settle(R* d) {
+  // (a USE of every fetched value at this point, nothing redefined: "+v" operands made hipcc copy each of them)
 #ifndef I2C_HOST_SIM
-  if constexpr (NL == 1) asm volatile("" : "+v"(d[0]));
-  if constexpr (NL == 2) asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]));
-  if constexpr (NL == 3) asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]));
+  if constexpr (NL == 1) asm volatile("" ::"v"(d[0]));
+  if constexpr (NL == 2) asm volatile("" ::"v"(d[0]), "v"(d[1]), "v"(d[2]));
+  if constexpr (NL == 3) asm volatile("" ::"v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]));
   if constexpr (NL == 4)
-    asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]), "+v"(d[9]));
+    asm volatile("" ::"v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(d[8]), "v"(d[9]));
 #else
   (void)d;
 #endif

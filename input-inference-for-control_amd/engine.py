@@ -56,7 +56,8 @@ class BatchedI2c:
                  mu_x_terminal=None, sig_x_terminal=None, quad=(1.0, 0.0, 0.0), x0=None, sig_x0=None,
                  z_traj=None, batch=None, dtype=torch.float64, device=None, lib=None, dtemp=1.0,
                  keep_zpost=True, keep_prior=False, keep_xm=True, backward_mode="auto", inference="cubature",
-                 gh_degree=None, group_lanes=0, storage_dtype=None, allow_inexact=False, keep_prior_joint=False, post_layout=None):
+                 gh_degree=None, group_lanes=0, storage_dtype=None, allow_inexact=False, keep_prior_joint=False, post_layout=None,
+                 deterministic_family=False):
         self.lib = lib if lib is not None else _native.load_library()
         if device is None:
             device = "cpu" if self.lib.is_host_sim else "cuda"
@@ -97,6 +98,19 @@ class BatchedI2c:
         # trajectory for every sweep.
         if group_lanes is True:
             group_lanes = dims.group_lanes
+        # deterministic_family=True: results that do NOT depend on the batch size or on how a batch is sharded over GPUs (round-4
+        # review, weak #9). The defaults pick the fastest kernel family and backward schedule for the batch at hand -- the family
+        # changes at measured batch windows, the chunk count of the chunked schedule with B -- and families / schedules round
+        # differently in the last bits. The switch pins what `group_lanes=0` and `backward_mode="auto"` would otherwise resolve
+        # per batch: one lane per trajectory with the sequential (fused) backward walk for the d <= 8 models, the wave kernels
+        # with their fused walk for the d = 16 model. A trajectory's result is then a function of its own inputs only (tested).
+        # It is the slow-but-reproducible path at small batches; the default stays the fast one.
+        self.deterministic_family = bool(deterministic_family)
+        if self.deterministic_family:
+            if not group_lanes:
+                group_lanes = 64 if dims.wave else -1
+            if backward_mode == "auto":
+                backward_mode = "fused"
         self.group_lanes = int(group_lanes or 0)
         # 64 = the wave kernels (csrc/i2c_wave.hpp: one wavefront per trajectory, blocks in the fp64 matrix-instruction layout),
         # for the models that have them (dims.wave): forward and backward sweeps; propagation and filter run the model's default

@@ -118,7 +118,7 @@ class I2cGraph:
 
     def __init__(self, sys, horizon, Q, R, Qf, alpha, alpha_update_tol, mu_u, sig_u, mu_x_terminal,
                  sig_x_terminal, inference, res_dir=None, *, batch=None, x0=None, sig_x0=None, z_traj=None,
-                 device=None, dtype=torch.float64, lib=None, group_lanes=0):
+                 device=None, dtype=torch.float64, lib=None, group_lanes=0, deterministic_family=False):
         if not isinstance(inference, (CubatureQuadrature, GaussHermiteQuadrature, Linearize)):
             raise ValueError("Unknown inference method")
         if not hasattr(sys, "model_id") or (sys.model_id is None and getattr(sys, "hip_header", None) is None):
@@ -138,7 +138,7 @@ class I2cGraph:
             device=device, lib=lib, keep_zpost=True, keep_prior=True, keep_prior_joint=True,
             inference=("linearize" if isinstance(inference, Linearize) else
                        "gauss_hermite" if isinstance(inference, GaussHermiteQuadrature) else "cubature"),
-            gh_degree=getattr(inference, "degree", None), group_lanes=group_lanes,  # kernel family (BatchedI2c): 0 = the model's default
+            gh_degree=getattr(inference, "degree", None), group_lanes=group_lanes, deterministic_family=deterministic_family,  # kernel family (BatchedI2c): 0 = the model's default
         )
         e = self.engine
         self.B = e.B
