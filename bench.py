@@ -258,11 +258,18 @@ def extra_config_legs(pkg, device, K=10):
     from i2c.known_models import make_env_model
 
     out = {}
+
     sync = lambda: torch.cuda.synchronize(device)  # noqa: E731
     rng = np.random.default_rng(7)
 
     # BASELINE.json configs[1]: pendulum_known_quad cubature i2c, nx=2 nu=1 T=200, batch B=1024 on one MI355X (the headline's
     # problem at a quarter of its batch: 16 lone wavefronts; the sweep is a fixed-length chain of T dependent cells)
+    # (a sweep of 16 lone wavefronts is a chain of dependent instructions: its time is 1 / clock. The leg is short and light, so it
+    # is preceded by 0.1 s of the same work on a throwaway engine -- measured without it: 0.39 ms right after the 131072-trajectory
+    # legs, 0.59 ms after a 1 s pause, 0.33 ms in a loop of its own (tools/sweep_batch.py))
+    warm = make_engine(pkg, 1024, 200, torch.float64, device, rank=2)
+    warm.learn(300)
+    del warm
     eng = make_engine(pkg, 1024, 200, torch.float64, device, rank=1)
     eng.learn(5)
     Kp = max(10 * K, 100)
