@@ -449,6 +449,54 @@ static int launch_quad_backward(const Consts<M, R>& c, const A& a, void* stream)
 }
 #endif
 
+// the quad filter step (ckf_quad_body): d = 16 models
+#ifdef I2C_HOST_SIM
+template <class M, typename R>
+static int launch_quad_ckf(const Consts<M, R>& c, const ZetaArg<M, R>& zeta, const CkfArgs<R>& a, void*) {
+  QKConst<M, R> kc;
+  qkconst_fill<M, R>(kc, &c, zeta.v, 0, 1);
+  for (int b0 = 0; b0 < c.B; b0 += 4) {
+    std::vector<R> sh((size_t)4 * QG<M>::SIZE, R(0)), xch(128, R(0));
+    HostBarrier bar(64);
+    std::vector<std::thread> lanes;
+    for (int l = 0; l < 64; ++l)
+      lanes.emplace_back([&, l, b0] {
+        const int g = (l >> 2) & 3, b = b0 + g;
+        const bool live = b < c.B;
+        ckf_quad_body<M, R>(c, kc, a, live ? b : c.B - 1, live, Quad<R>{l, l >> 4, g, l & 3, sh.data() + g * QG<M>::SIZE, &bar, xch.data()});
+      });
+    for (auto& th : lanes) th.join();
+  }
+  return I2C_OK;
+}
+#else
+template <class M, typename R>
+__global__ __launch_bounds__(64 * quad_waves_per_block<M>(), 2) void k_quad_ckf(const Consts<M, R> c, const ZetaArg<M, R> zeta, const CkfArgs<R> a) {
+  constexpr int WPB = quad_waves_per_block<M>();
+  __shared__ QKConst<M, R> kc;
+  __shared__ R sh[WPB * 4 * QG<M>::SIZE];
+  {  // (`c` is the first kernel parameter, `zeta` follows it at its natural alignment: see k_group)
+    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr size_t zoff = (sizeof(Consts<M, R>) + alignof(ZetaArg<M, R>) - 1) / alignof(ZetaArg<M, R>) * alignof(ZetaArg<M, R>);
+    qkconst_fill<M, R>(kc, (const Consts<M, R>*)ka, ((const ZetaArg<M, R>*)(ka + zoff))->v, (int)threadIdx.x, 64 * WPB);
+  }
+  __syncthreads();
+  const int l = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6), g = (l >> 2) & 3;
+  const long b0 = 4L * ((long)blockIdx.x * WPB + wv);
+  if (b0 >= c.B) return;  // (wave-uniform: no trajectory in this wave)
+  const long b = b0 + g;
+  const bool live = b < c.B;
+  const Quad<R> q{l, l >> 4, g, l & 3, (lds_ptr<R>)(sh + (wv * 4 + g) * QG<M>::SIZE)};
+  ckf_quad_body<M, R>(c, kc, a, (int)(live ? b : c.B - 1), live, q);
+}
+template <class M, typename R>
+static int launch_quad_ckf(const Consts<M, R>& c, const ZetaArg<M, R>& zeta, const CkfArgs<R>& a, void* stream) {
+  constexpr int WPB = quad_waves_per_block<M>();
+  hipLaunchKernelGGL((k_quad_ckf<M, R>), dim3((unsigned)(((long)c.B + 4 * WPB - 1) / (4 * WPB))), dim3(64 * WPB), 0, (hipStream_t)stream, c, zeta, a);
+  return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
+}
+#endif
+
 template <int KIND, class M, typename R, typename S, class A>
 static int launch_wave(const Consts<M, R>& c, const A& a, void* stream) {
   if constexpr (KIND == WK_FORWARD) {  // batches whose waves share a SIMD: the variant with the pivot blocks through LDS
@@ -659,7 +707,11 @@ template <class M, typename R, typename S = R> struct Impl {
     if (EMAX * (long)p->B * (long)sizeof(S) >= (1L << 31)) return I2C_EINVAL;
     return window_32bit_ok(p);
   }
+  static constexpr bool HAS_QUAD_CKF = HAS_QUAD && !MIXED && quad_ckf_exists<M>();  // the filter step of the d = 16 form
   static int family(const I2cProblem* p, const C& c, const int sweep) {
+    if constexpr (HAS_QUAD_CKF) {  // the state estimator of a matrix-instruction graph (default, 64 or I2C_LANES_QUAD): the quad filter step
+      if (sweep == I2C_SWEEP_FILTER && (p->group_lanes == 0 || p->group_lanes == 64 || p->group_lanes == I2C_LANES_QUAD)) return I2C_FAMILY_QUAD;
+    }
     if constexpr (HAS_QUAD) {  // forward sweep: on request, or the model's default inside its batch window
       const bool asked = p->group_lanes == I2C_LANES_QUAD || (p->group_lanes == 64 && !M::WAVE);
       // (the backward sweep of the d = 16 form: the fused walk, with the forward sweep -- an explicit two-pass request keeps the wave form)
@@ -1044,6 +1096,9 @@ template <class M, typename R, typename S = R> struct Impl {
     CkfArgs<R> a{(const R*)y, (const R*)u, (R*)mu, (R*)cov, status};
     const int fam = family(p, c, I2C_SWEEP_FILTER);
     if (fam < 0) return fam;
+    if (fam == I2C_FAMILY_QUAD) {
+      if constexpr (HAS_QUAD_CKF) return launch_quad_ckf<M, R>(c, z, a, stream);
+    }
     if (fam == I2C_FAMILY_GROUP) {
       if constexpr (HAS_GROUP) return launch_group<GK_CKF, M, R, G>(c, &z, a, stream);
     }

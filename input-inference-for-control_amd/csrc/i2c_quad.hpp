@@ -1580,4 +1580,98 @@ I2C_HD inline void backward_quad_body(const Consts<M, R>& c, const KC& kc, const
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Cubature Kalman filter step of the MPC state estimator (PartiallyObservedMpcPolicy.filter, i2c/policy/mpc.py:125-145), d = 16
+// ------------------------------------------------------------------------------------------
+// FOUR beliefs per wavefront, the same blocks and phases as the forward cell: chol of the belief, 2 nx (+ centre) state-only sigma
+// points through the dynamics with the applied action appended (mpc.py:129-137), chol of the prediction, the points through
+// sys.measure, Kalman update on the measurement (mpc.py:139-145). With it a control step of the 12-state quadrotor (filter +
+// sweeps, i2c_mpc_step) runs on matrix-instruction kernels end to end; the estimator's rule is CubatureQuadrature(1, 0, 0)
+// whatever the graph infers with (mpc.py:121-123: Impl::filter_problem), so the unit-weight forms of q_moments always apply.
+template <class M, typename R> struct QKConst {
+  static constexpr int QLD = QG<M>::QLD;
+  R eta[QLD * QLD], zeta[QLD * QLD];  // sig_eta (nx x nx), sig_zeta (ny x ny), zero-padded
+};
+template <class M, typename R, class DST> I2C_FN void qkconst_fill(DST& k, const Consts<M, R>* c, const R* zeta, const int tid, const int nthreads) {
+  constexpr int NX = M::NX, NY = M::NY, QLD = QG<M>::QLD;
+  for (int e = tid; e < QLD * QLD; e += nthreads) {
+    const int i = e / QLD, j = e % QLD;
+    k.eta[e] = (i < NX && j < NX) ? c->sig_eta[tri_any(i, j)] : R(0);
+    k.zeta[e] = (i < NY && j < NY) ? zeta[tri_any(i, j)] : R(0);
+  }
+}
+template <class M> constexpr bool quad_ckf_exists() { return QG<M>::WIDE && M::NX % 4 == 0 && M::NX <= 12 && M::NY <= 12; }
+
+template <class M, typename R, class KC>
+I2C_HD inline void ckf_quad_body(const Consts<M, R>& c, const KC& kc, const CkfArgs<R>& a, const int b, const bool live, const Quad<R>& q) {
+  using C = Consts<M, R>;
+  using G = QG<M>;
+  constexpr int NX = C::NX, NU = C::NU, NY = M::NY, NBX = NX / 4, NBY = (NY + 3) / 4, QLD = G::QLD;
+  static_assert(quad_ckf_exists<M>(), "quad filter: the d = 16 geometry, nx a multiple of four");
+  const int r = q.r, cc = q.c;
+  const long B = c.B;
+  const Rule<R>& rule = c.rule_x;
+  auto xrow = [&](const int i) { return 4 * i + r; };
+  auto xcol = [&](const int j) { return 4 * j + cc; };
+  R mu[NBX], S[NBX * NBX], u[NU], yt[NBY];
+#pragma unroll
+  for (int j = 0; j < NBX; ++j) {
+    mu[j] = a.mu[(long)xcol(j) * B + b];
+#pragma unroll
+    for (int i = 0; i < NBX; ++i) S[i * NBX + j] = j >= i ? a.cov[(long)w_symidx(xrow(i), xcol(j)) * B + b] : R(0);  // upper blocks, the diagonal ones full
+  }
+#pragma unroll
+  for (int i = 0; i < NU; ++i) u[i] = a.u[(long)i * B + b];
+#pragma unroll
+  for (int j = 0; j < NBY; ++j) {
+    const int col = xcol(j);
+    const R v = a.y[(long)(col < NY ? col : 0) * B + b];
+    yt[j] = col < NY ? v : R(0);
+  }
+  const int kz = (int)opaque_uniform(0u);
+  bool ok;
+  // prediction: chol(S), the points through the dynamics, moments + process noise
+  R mf[NBX], Sf[NBX * NBX];
+  {
+    R tmp[NBX * NBX], lt[NBX * NBX], am[NBX * NBX], dm[NBX * NBX], yc[NBX];
+#pragma unroll
+    for (int k = 0; k < NBX * NBX; ++k) tmp[k] = S[k];
+    ok = q_elim<NX, 0, 0>(q, tmp, (R*)nullptr, (R*)nullptr, lt);
+    q_points<M, G, NX, NX>(q, rule.sf, mu, lt, DynamicsFixedUF<M, R>{c.params, u}, am, dm, yc);
+    q_moments<NX, NX>(q, rule.wi, am, dm, yc, mf, Sf);
+#pragma unroll
+    for (int i = 0; i < NBX; ++i)
+#pragma unroll
+      for (int j = 0; j < NBX; ++j) Sf[i * NBX + j] = j >= i ? Sf[i * NBX + j] + q_ldc<QLD>(q, kc.eta, i, j, kz) : R(0);
+  }
+  // innovation: chol(Sf), the points through sys.measure, K = sig_xy sig_y^-1 (as a Cholesky elimination), update
+  {
+    R tmp[NBX * NBX], lt[NBX * NBX], am[NBX * NBY], dm[NBX * NBY], yc[NBY], my[NBY], Sy[NBY * NBY], Syx[NBY * NBX];
+#pragma unroll
+    for (int k = 0; k < NBX * NBX; ++k) tmp[k] = Sf[k];
+    ok = q_elim<NX, 0, 0>(q, tmp, (R*)nullptr, (R*)nullptr, lt) && ok;
+    q_points<M, G, NX, NY>(q, rule.sf, mf, lt, MeasureF<M, R>{c.params}, am, dm, yc);
+    q_moments<NX, NY>(q, rule.wi, am, dm, yc, my, Sy);
+#pragma unroll
+    for (int i = 0; i < NBY; ++i)
+#pragma unroll
+      for (int j = i; j < NBY; ++j) Sy[i * NBY + j] += q_ldc<QLD>(q, kc.zeta, i, j, kz);
+#pragma unroll
+    for (int k = 0; k < NBY * NBX; ++k) Syx[k] = R(0);
+    q_tn<NBX, NBY, NBX, false, false, true>(q, dm, lt, Syx);  // cov(y, x) = wi sf [d_p]^T L^T
+    const R cw = rule.wi * rule.sf;
+#pragma unroll
+    for (int k = 0; k < NBY * NBX; ++k) Syx[k] *= cw;
+    ok = q_kalman<NX, NY>(q, mf, Sf, my, Sy, Syx, yt) && ok;
+  }
+#pragma unroll
+  for (int j = 0; j < NBX; ++j) {
+    if (live && r == 0) a.mu[(long)xcol(j) * B + b] = mf[j];
+#pragma unroll
+    for (int i = 0; i <= j; ++i)
+      if (live && xrow(i) <= xcol(j)) a.cov[(long)w_symidx(xrow(i), xcol(j)) * B + b] = Sf[i * NBX + j];
+  }
+  if (live && q.p() == 0 && !ok && a.status[b] == 0) a.status[b] = (9 << 16) | 1;  // I2C_FAIL_FILTER, as set_status(.., 9, 0)
+}
+
 }  // namespace i2c

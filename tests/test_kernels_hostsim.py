@@ -96,7 +96,9 @@ def test_hostsim_wave_kernels_are_the_quad12_default(lib):
 
     eng = parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu")
     assert (eng.forward_family, eng.backward_family, eng.backward_schedule) == ("wave", "wave", "fused")
-    assert eng.kernel_family("propagate") == "group" and eng.kernel_family("filter") == "group"  # sweeps the wave form lacks
+    assert eng.kernel_family("propagate") == "group"  # the sweep the matrix-instruction families lack
+    assert eng.kernel_family("filter") == "quad"      # round 5: the state estimator's step on the quad kernels (ckf_quad_body)
+    assert parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu", group_lanes=16).kernel_family("filter") == "group"
     general = parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu", quad=(1.2, 0.44, 0.5))
     assert general.forward_family == "group"  # weights with lam != 0: not covered by the wave form, the group kernels take over
     with pytest.raises(RuntimeError, match="-2"):

@@ -202,7 +202,7 @@ def _ckf_oracle(model, rule_w, mu, cov, u, y, sig_zeta):
     return mu_f + np.einsum("bij,bj->bi", K, y - mu_y), sig_f - K @ sig_y @ np.swapaxes(K, -1, -2)
 
 
-def _ckf_batch(lib, device, model_name, B=37, rule=None):
+def _ckf_batch(lib, device, model_name, B=37, rule=None, group_lanes=0, family=None):
     """The filter kernel on a ragged batch of random beliefs against the oracle restatement. `rule`: the graph's inference --
     the filter's own rule is CubatureQuadrature(1, 0, 0) whatever the graph infers with (mpc.py:121-123)."""
     from oracle.models_numpy import make_model
@@ -218,7 +218,9 @@ def _ckf_batch(lib, device, model_name, B=37, rule=None):
     u = rng.normal(size=(B, nu)) + (om.u_max / 4 if hasattr(om, "u_max") else 0.0)
     sig_zeta = np.diag(10.0 ** rng.uniform(-5, -2, size=ny))
     y = om.measure(mu) + 0.01 * rng.normal(size=(B, ny))
-    _, i2c, pol = _policy(g, lib, device, batch=B, rule=rule)
+    _, i2c, pol = _policy(g, lib, device, batch=B, rule=rule, group_lanes=group_lanes)
+    if family is not None:
+        assert i2c.engine.kernel_family("filter") == family
     i2c.sys.sig_zeta = sig_zeta
     i2c.engine.set_initial_state(mu, cov)
     pol.filter(y, u)
@@ -230,13 +232,23 @@ def _ckf_batch(lib, device, model_name, B=37, rule=None):
 
 @pytest.mark.parametrize("model_name", ["PendulumKnown", "PlanarQuadrotor", "Quadrotor12"])
 def test_ckf_batch_cpu(model_name):
-    _ckf_batch(hostsim.load(), "cpu", model_name)
+    _ckf_batch(hostsim.load(), "cpu", model_name, family="quad" if model_name == "Quadrotor12" else "lane")  # (round 5: the quad filter step for d = 16)
+
+
+def test_ckf_batch_quad12_group_kernels_cpu():
+    """The filter of the 12-state quadrotor on its group kernels (the fallback, asked for): the same oracle."""
+    _ckf_batch(hostsim.load(), "cpu", "Quadrotor12", B=6, group_lanes=16, family="group")
+
+
+@pytest.mark.gpu
+def test_ckf_batch_quad12_group_kernels_gpu():
+    _ckf_batch(None, "cuda", "Quadrotor12", group_lanes=16, family="group")
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("model_name", ["PendulumKnown", "PlanarQuadrotor", "Quadrotor12"])
 def test_ckf_batch_gpu(model_name):
-    _ckf_batch(None, "cuda", model_name)
+    _ckf_batch(None, "cuda", model_name, family="quad" if model_name == "Quadrotor12" else "lane")
 
 
 def _graph_rules():

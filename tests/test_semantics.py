@@ -248,7 +248,7 @@ def test_kernel_family_is_inspectable():
     assert eng("DoubleCartpoleKnown", 64, group_lanes=True).forward_family == "group"
     assert eng("DoubleCartpoleKnown", 64, group_lanes=-1).forward_family == "lane"
     q = eng("Quadrotor12", 3)
-    assert q.forward_family in ("group", "wave") and q.kernel_family("filter") in ("group", "wave")
+    assert q.forward_family in ("group", "wave") and q.kernel_family("filter") == "quad"  # (round 5: the quad filter step)
     # the group kernels have no Linearize() / Gauss-Hermite sweeps: the engine asks the resolver when it is built and refuses with
     # the library's code (I2C_ENOTSUP) -- it used to swallow the refusal until a sweep was called (round-3 advice, round-4 review #8)
     with pytest.raises(RuntimeError, match="-2"):
