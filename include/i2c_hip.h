@@ -407,6 +407,20 @@ int i2c_learn(const I2cProblem* p, void* post, void* fwd, void* xm, void* zpost,
               int32_t* status, void* stream);
 
 /*
+ * i2c_learn WITH closed-loop propagation: n_iters x I2cGraph.learn_msgs of a graph whose `_propagate` is on (covariance control,
+ * scripts/nonlinear_covariance_control.py:107-113; i2c.py:1238-1251): forward sweep, backward sweep, propagate, M-step per
+ * iteration, enqueued back to back. With `overlap` != 0 the propagation of iteration k shares ONE launch with the forward sweep of
+ * iteration k + 1 from the second iteration on (both only read the posterior, each is a chain of T dependent cells on a fraction
+ * of the chip; lane kernels of the d <= 5 models, cubature rule) -- the results are those of the one-by-one calls.
+ *   prop       [T][e_prop][B]     out: the last iteration's propagation (as i2c_propagate)
+ *   prop_hist  [n_iters][3][B]    out: the prop_stats of every iteration
+ *   stats_hist [n_iters][4][B]    out: as i2c_learn
+ */
+int i2c_learn_propagate(const I2cProblem* p, void* post, void* fwd, void* xm, void* zpost, void* cell_stats, void* term_stats,
+                        void* prop, void* prop_hist, double alpha_update_tol, int tau, int n_iters, void* stats_hist,
+                        int use_expert_controller, int overlap, int32_t* status, void* stream);
+
+/*
  * Closed-loop propagation of the controller distribution: replaces I2cGraph.propagate
  * (i2c.py:1247-1251) calling I2cCell._propagate_forward_quadrature (i2c.py:150-199), plus the
  * per-cell propagated cost statistics (i2c.py:685-688, 1055-1063).

@@ -135,6 +135,10 @@ _SIGNATURES = {
         C.c_int,
         [C.POINTER(I2cProblem)] + [C.c_void_p] * 6 + [C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "i2c_learn_propagate": (
+        C.c_int,
+        [C.POINTER(I2cProblem)] + [C.c_void_p] * 8 + [C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    ),
     "i2c_riccati_sweep": (C.c_int, [C.POINTER(I2cProblem)] + [C.c_void_p] * 7),
     "i2c_mpc_step": (C.c_int, [C.POINTER(I2cProblem), C.POINTER(I2cMpcStep), C.c_void_p]),
     "i2c_shift_horizon": (C.c_int, [C.POINTER(I2cProblem)] + [C.c_void_p] * 6),

@@ -194,6 +194,14 @@ int i2c_learn(const I2cProblem* p, void* post, void* fwd, void* xm, void* zpost,
                         status, stream));
 }
 
+int i2c_learn_propagate(const I2cProblem* p, void* post, void* fwd, void* xm, void* zpost, void* cell_stats, void* term_stats, void* prop,
+                        void* prop_hist, double alpha_update_tol, int tau, int n_iters, void* stats_hist, int use_expert_controller,
+                        int overlap, int32_t* status, void* stream) {
+  if (!post || !fwd || !term_stats || !prop || !prop_hist || !stats_hist || !status || n_iters < 0) return I2C_EINVAL;
+  I2C_DISPATCH(p, learn_propagate(p, post, fwd, xm, zpost, cell_stats, term_stats, prop, prop_hist, alpha_update_tol, tau, n_iters,
+                                  stats_hist, use_expert_controller, overlap, status, stream));
+}
+
 int i2c_rollout(const I2cProblem* p, const void* post, int n_rollouts, int policy, const void* eps_x0,
                 const void* eps_x, const void* eps_u, void* xu, void* z, void* x_final, void* z_term, void* stream) {
   if (!post || n_rollouts < 1 || policy < 0 || policy > 2) return I2C_EINVAL;

@@ -31,6 +31,9 @@ struct ModelOps {
   int (*shift)(const I2cProblem*, void* post, const void* cell_init, const void* alpha_init, const void* z_new, void* action,
                void* stream);
   int (*family)(const I2cProblem*, int sweep);
+  int (*learn_propagate)(const I2cProblem*, void* post, void* fwd, void* xm, void* zpost, void* cell_stats, void* term_stats, void* prop,
+                         void* prop_hist, double tol, int tau, int n_iters, void* stats_hist, int use_expert, int overlap, int32_t* status,
+                         void* stream);
 };
 
 // defined by the translation units generated from i2c_model_tu.hip

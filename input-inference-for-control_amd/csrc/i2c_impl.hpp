@@ -143,6 +143,18 @@ I2C_KERNEL(SWEEP_BLOCK) k_propagate(I2C_LANE_PARAMS const Consts<M, R> c, const 
   const long b = I2C_LANE_X(SWEEP_BLOCK);
   if (b < c.B) propagate_body<M, R, GRID>(c, a, (int)b);
 }
+// The forward sweep of one EM iteration and the closed-loop propagation of the PREVIOUS one in ONE launch (grid row 0 / row 1).
+// Both walk T dependent cells with one lane per trajectory, both only read the posterior buffer; at the batch sizes of covariance
+// control (B = 8192: 128 wavefronts each) run one after the other they are two chains, in one dispatch the workgroup distributor
+// deals the 256 workgroups onto 256 different CUs and they are one. (Two STREAMS do not do this: measured, the two kernels' waves
+// land on the same SIMDs and the propagation takes 165 instead of 95 us -- profiles/r5_covctrl_overlap.txt.)
+template <class M, typename R, bool LEAN>
+I2C_KERNEL(SWEEP_BLOCK) k_forward_propagate(I2C_LANE_PARAMS const Consts<M, R> c, const FwdArgs<R, R> af, const PropArgs<R> ap) {
+  const long b = I2C_LANE_X(SWEEP_BLOCK);
+  if (b >= c.B) return;
+  if (I2C_LANE_Y == 0) forward_sweep_body<M, R, LEAN, false, R>(c, af, (int)b);
+  else propagate_body<M, R, false>(c, ap, (int)b);
+}
 template <class M, typename R> struct ZetaArg {
   R v[sym(M::NY)];
 };
@@ -1085,6 +1097,70 @@ template <class M, typename R, typename S = R> struct Impl {
     return I2C_OK;
   }
 
+  // n_iters EM iterations WITH closed-loop propagation (covariance control: learn_msgs with _propagate, i2c.py:1238-1251) enqueued by
+  // one call: forward, backward, propagate, M-step per iteration. From the second iteration on the propagation of iteration k
+  // shares a launch with the forward sweep of iteration k + 1 (k_forward_propagate) where both run on the lane kernels; the
+  // first one runs in order -- its M-step is followed by the mode-flag switch the propagation reads. Same kernels' bodies, same
+  // inputs as the one-by-one calls: identical results (a trajectory that fails in BOTH overlapped sweeps records either code).
+  static int learn_propagate(const I2cProblem* p, void* post, void* fwd, void* xm, void* zpost, void* cell_stats, void* term_stats,
+                             void* prop, void* prop_hist, double tol, int tau, int n_iters, void* stats_hist, int use_expert,
+                             int overlap, int32_t* status, void* stream) {
+    if constexpr (MIXED) return I2C_ENOTSUP;
+    auto prop_row = [&](int it) { return (void*)((R*)prop_hist + (size_t)it * 3 * p->B); };
+    bool fusable = false;
+    if constexpr (LANE && C::D <= 5) {
+      const C c0 = make_consts<M, R>(p, 0.0, use_expert);
+      fusable = overlap && p->inference == I2C_INF_CUBATURE && family(p, c0, I2C_SWEEP_FORWARD) == I2C_FAMILY_LANE &&
+                family(p, c0, I2C_SWEEP_PROPAGATE) == I2C_FAMILY_LANE && c0.rule_xu.unit && c0.rule_x.unit && !c0.z_per_cell &&
+                !p->alpha_cell && c0.t0 == 0;
+    }
+    int pending = -1;  // iteration whose propagation has not run yet
+    for (int it = 0; it < n_iters; ++it) {
+      int rc = I2C_OK;
+      bool fused = false;
+      if constexpr (LANE && C::D <= 5) {
+        if (fusable && pending >= 0) {
+          const C c = make_consts<M, R>(p, 0.0, use_expert);
+          FwdArgs<R> af{(const R*)post, (R*)fwd, nullptr, (const R*)p->x0, (const R*)p->sig_x0, (const R*)p->z, (const R*)p->alpha,
+                        (const R*)p->alpha_cell, p->feedforward, status, p->expert};
+          PropArgs<R> ap{(const R*)post, (R*)prop, (R*)prop_row(pending), (const R*)p->x0, (const R*)p->sig_x0,
+                         (const R*)p->z, p->feedforward, status, p->expert};
+          rc = launch(k_forward_propagate<M, R, true>, p->B, 2, SWEEP_BLOCK, stream, c, af, ap);
+          fused = true;
+          pending = -1;
+        }
+      }
+      if (!fused) {
+        if (pending >= 0) {
+          rc = propagate(p, post, prop, prop_row(pending), use_expert, status, stream);
+          pending = -1;
+          if (rc != I2C_OK) return rc;
+        }
+        rc = forward(p, post, fwd, nullptr, status, stream);
+      }
+      if (rc != I2C_OK) return rc;
+      MstepFuse fuse{tol, 1, (R*)stats_hist + (size_t)it * 4 * p->B, false};
+      rc = backward_impl(p, fwd, xm, post, zpost, cell_stats, term_stats, status, stream, &fuse);
+      if (rc != I2C_OK) return rc;
+      if (it == 0) {  // in order: the mode flags change right after this M-step
+        rc = propagate(p, post, prop, prop_row(0), use_expert, status, stream);
+        if (rc != I2C_OK) return rc;
+      } else {
+        pending = it;
+      }
+      if (!fuse.done) {
+        rc = mstep(p, term_stats, tol, 1, (R*)stats_hist + (size_t)it * 4 * p->B, stream);
+        if (rc != I2C_OK) return rc;
+      }
+      if (tau > 0 && it == 0) {
+        rc = to_feedback(p, tau, stream);
+        if (rc != I2C_OK) return rc;
+      }
+    }
+    if (pending >= 0) return propagate(p, post, prop, prop_row(pending), use_expert, status, stream);
+    return I2C_OK;
+  }
+
   static int ckf(const I2cProblem* p, const double* sig_zeta, const void* y, const void* u, void* mu, void* cov,
                  int32_t* status, void* stream) {
     if constexpr (MIXED) return I2C_ENOTSUP;
@@ -1195,7 +1271,7 @@ template <class M, typename R, typename S = R> const ModelOps* make_ops() {
   using I = Impl<M, R, S>;
   static const ModelOps ops = {&I::forward, &I::backward,  &I::mstep,        &I::learn,           &I::ckf,
                                &I::rollout, &I::propagate, &I::riccati,   &I::mpc_step,        &fill_dims<M>,
-                               &workspace_elems<M>, &I::plan, &I::shift, &I::family_of};
+                               &workspace_elems<M>, &I::plan, &I::shift, &I::family_of, &I::learn_propagate};
   return &ops;
 }
 

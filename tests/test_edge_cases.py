@@ -423,3 +423,33 @@ def test_deterministic_family_makes_results_independent_of_the_batch():
             assert torch.equal(part.post, whole.post[..., sl]) and torch.equal(part.alpha, whole.alpha[sl]), (name, sl)
         # an explicit request still wins over the switch
         assert solve(slice(0, 2), backward_mode="two_pass").backward_schedule == "two_pass"
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_learn_with_propagation_equals_stepwise(overlap):
+    """learn(n) of a graph with closed-loop propagation is ONE library call (i2c_learn_propagate; from the second iteration on the
+    propagation of iteration k shares a launch with the forward sweep of iteration k + 1): every buffer and every history entry
+    equal n x learn_msgs(), whose calls go one by one (covariance control: golden em_covctrl_T100's problem, batched)."""
+    import hostsim
+    import parity
+    from golden_util import load_case
+
+    g = load_case("em_covctrl_T100")
+    x0, mu_u = parity.batched_inputs(g, 5)
+    engines = []
+    for fused in (True, False):
+        e = parity.engine_from_case(g, hostsim.load(), "cpu", x0=x0, mu_u=mu_u, overlap_propagation=overlap)
+        e.propagate()
+        if fused:
+            e.learn(4)
+        else:
+            for _ in range(4):
+                e.learn_msgs()
+        engines.append(e)
+    a, b = engines
+    assert a.em_iter == b.em_iter == 4 and a.failures() == b.failures() == []
+    for k in ("post", "prop", "prop_stats", "alpha", "temp", "feedforward", "stats_out"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    for k in ("alphas", "alphas_desired", "alphas_pf", "costs_m", "costs_m_var", "costs_pf", "costs_pf_var", "kl_terms"):
+        la, lb = getattr(a, k), getattr(b, k)
+        assert len(la) == len(lb) and all(torch.equal(x, y) for x, y in zip(la, lb)), k

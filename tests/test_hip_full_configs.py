@@ -246,3 +246,37 @@ def test_deterministic_family_across_batch_windows_gpu():
     assert (fast_whole.forward_family, fast_shard.forward_family) == ("lane", "quad")  # the defaults: a different family per batch size
     d = (fast_shard.post - fast_whole.post[..., lo:hi]).abs().max().item()
     assert 0.0 < d < 1e-6 * whole.post.abs().max().item()  # ... which agree, but not to the last bit
+
+
+@pytest.mark.gpu
+def test_overlapped_propagation_is_bit_identical_gpu():
+    """learn(n) with closed-loop propagation (covariance control, BASELINE config 5) runs the propagation of iteration k on a second
+    stream next to the forward sweep of iteration k + 1: the same numbers as n x learn_msgs(), every history entry included."""
+    import importlib
+
+    from i2c.known_models import make_env_model
+
+    pkg = importlib.import_module("input-inference-for-control_amd")
+    B, T = 2048, 60
+    rng = np.random.default_rng(4)
+    x0 = np.array([np.pi, 0.0]) + 1e-2 * rng.normal(size=(B, 2))
+
+    def make(**kw):
+        e = pkg.BatchedI2c(make_env_model("PendulumKnownActReg"), T, None, np.diag([1.0]), None, 300.0, 1.0, np.zeros((B, T, 1)), 0.5 * np.eye(1),
+                           np.array([0.0, 0.0]), np.diag([1e-3, 1e-3]), x0=x0, device="cuda", keep_zpost=False, **kw)
+        e.use_expert_controller = False
+        e._propagate = True
+        e.propagate()
+        return e
+
+    a, b = make(), make(overlap_propagation=False)
+    a.learn(7)
+    for _ in range(7):
+        b.learn_msgs()
+    torch.cuda.synchronize()
+    assert a.failures() == b.failures() and a.em_iter == b.em_iter == 7, (a.failures()[:3], b.failures()[:3], a.em_iter, b.em_iter)
+    for k in ("post", "prop", "prop_stats", "alpha", "temp", "feedforward"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    for k in ("alphas", "alphas_desired", "alphas_pf", "costs_m", "costs_m_var", "costs_pf", "costs_pf_var", "kl_terms"):
+        la, lb = getattr(a, k), getattr(b, k)
+        assert len(la) == len(lb) and all(torch.equal(x, y) for x, y in zip(la, lb)), k
