@@ -13,8 +13,7 @@ namespace {
 // published id need no lock.
 struct PluginEntry {
   const i2c::ModelOps* ops[3];  // I2C_F64, I2C_F32, I2C_F64_F32S (nullptr: that precision was not built)
-  void* handle;                 // dlopen handle of i2c_load_model (kept for the life of the process), or nullptr
-};
+};  // (a library opened by i2c_load_model stays loaded for the life of the process: its handle is never closed once registered)
 PluginEntry g_plugins[I2C_MAX_PLUGIN_MODELS];
 int g_n_plugins = 0;
 std::mutex g_plugin_mutex;
@@ -134,7 +133,7 @@ int i2c_register_model(int abi_version, const I2cModelOps* ops_f64, const I2cMod
       return I2C_MODEL_PLUGIN_BASE + k;
     }
   if (g_n_plugins >= I2C_MAX_PLUGIN_MODELS) return I2C_ENOTSUP;
-  g_plugins[g_n_plugins] = PluginEntry{{t[0], t[1], t[2]}, nullptr};
+  g_plugins[g_n_plugins] = PluginEntry{{t[0], t[1], t[2]}};
   if (dims_out) *dims_out = d;
   return I2C_MODEL_PLUGIN_BASE + g_n_plugins++;
 }

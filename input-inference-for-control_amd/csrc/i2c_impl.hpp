@@ -353,8 +353,8 @@ static int launch_wave_v(const Consts<M, R>& c, const A& a, void* stream) {
 // ---- quad kernels (i2c_quad.hpp): four trajectories per wavefront; one wavefront per workgroup (d <= 8), four (d = 16) ---------
 template <class M> constexpr int quad_waves_per_block() { return QG<M>::WIDE ? 4 : 1; }
 #ifdef I2C_HOST_SIM
-template <class M, typename R, typename S, class A>
-static int launch_quad_forward(const Consts<M, R>& c, const A& a, void*) {
+template <class M, typename R, typename S, bool GENERAL, class A>
+static int launch_quad_forward_g(const Consts<M, R>& c, const A& a, void*) {
   QConst<M, R> kc;
   qconst_fill<M, R>(kc, &c, 0, 1);
   for (int b0 = 0; b0 < c.B; b0 += 4) {
@@ -365,7 +365,7 @@ static int launch_quad_forward(const Consts<M, R>& c, const A& a, void*) {
       lanes.emplace_back([&, l, b0] {
         const int g = (l >> 2) & 3, b = b0 + g;
         const bool live = b < c.B;
-        forward_quad_body<M, R, S>(c, kc, a, live ? b : c.B - 1, live, Quad<R>{l, l >> 4, g, l & 3, sh.data() + g * QG<M>::SIZE, &bar, xch.data()});
+        forward_quad_body<M, R, S, GENERAL>(c, kc, a, live ? b : c.B - 1, live, Quad<R>{l, l >> 4, g, l & 3, sh.data() + g * QG<M>::SIZE, &bar, xch.data()});
       });
     for (auto& th : lanes) th.join();
   }
@@ -375,7 +375,7 @@ static int launch_quad_forward(const Consts<M, R>& c, const A& a, void*) {
 #ifndef I2C_QF_ATTR  // (experiment knob: extra attributes of the quad forward kernel, e.g. __attribute__((amdgpu_waves_per_eu(1, 1))))
 #define I2C_QF_ATTR
 #endif
-template <class M, typename R, typename S, class A>
+template <class M, typename R, typename S, class A, bool GENERAL = false>
 __global__ __launch_bounds__(64 * quad_waves_per_block<M>(), 2) I2C_QF_ATTR void k_quad_forward(const Consts<M, R> c, const A a) {
   constexpr int WPB = quad_waves_per_block<M>();
   __shared__ QConst<M, R> kc;
@@ -401,16 +401,25 @@ __global__ __launch_bounds__(64 * quad_waves_per_block<M>(), 2) I2C_QF_ATTR void
   const bool live = b < c.B;
 #endif
   const Quad<R> q{l, l >> 4, g, l & 3, (lds_ptr<R>)(sh + (wv * 4 + g) * QG<M>::SIZE)};
-  forward_quad_body<M, R, S>(c, kc, a, (int)(b < c.B ? b : c.B - 1), live, q);
+  forward_quad_body<M, R, S, GENERAL>(c, kc, a, (int)(b < c.B ? b : c.B - 1), live, q);
 }
-template <class M, typename R, typename S, class A>
-static int launch_quad_forward(const Consts<M, R>& c, const A& a, void* stream) {
+template <class M, typename R, typename S, bool GENERAL, class A>
+static int launch_quad_forward_g(const Consts<M, R>& c, const A& a, void* stream) {
   constexpr int WPB = quad_waves_per_block<M>();
   const unsigned blocks = WPB == 1 ? (unsigned)(((long)c.B + 127) / 128) * 32u : (unsigned)(((long)c.B + 4 * WPB - 1) / (4 * WPB));
-  hipLaunchKernelGGL((k_quad_forward<M, R, S, A>), dim3(blocks), dim3(64 * WPB), 0, (hipStream_t)stream, c, a);
+  hipLaunchKernelGGL((k_quad_forward<M, R, S, A, GENERAL>), dim3(blocks), dim3(64 * WPB), 0, (hipStream_t)stream, c, a);
   return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
 }
 #endif
+// unit weights (lam = 0, every shipped config), or the GENERAL variant where the model has it (Impl::quad_supported has checked)
+template <class M, typename R, typename S, class A>
+static int launch_quad_forward(const Consts<M, R>& c, const A& a, void* stream) {
+  const bool unit = c.rule_xu.unit && c.rule_x.unit && c.rule_xu.w0 == R(0) && c.rule_x.w0 == R(0);
+  if constexpr (quad_general_exists<M>()) {
+    if (!unit) return launch_quad_forward_g<M, R, S, true>(c, a, stream);
+  }
+  return unit ? launch_quad_forward_g<M, R, S, false>(c, a, stream) : I2C_ENOTSUP;
+}
 
 // the quad backward sweep (backward_quad_body): d = 16 models with identity observations
 template <class M> constexpr bool quad_backward_exists() {
@@ -700,10 +709,13 @@ template <class M, typename R, typename S = R> struct Impl {
     return window_32bit_ok(p);
   }
   // what the quad form (forward sweep) covers: the cubature rule with lam = 0 (unit weights, no weight on the centre: the centring
-  // of the pairwise sums relies on 2 d wi = 1, and the d = 8 models evaluate no centre point at all), windows below 2 GiB
+  // of the pairwise sums relies on 2 d wi = 1, and the d = 8 models evaluate no centre point at all) for every model; any
+  // CubatureQuadrature(alpha, beta, kappa) for the models with sigma-point observations and a spare pair row (quad_general_exists:
+  // pendulum, cartpole, double cartpole -- the GENERAL variant, round 5); windows below 2 GiB
   static int quad_supported(const I2cProblem* p, const C& c) {
     if (p->inference != I2C_INF_CUBATURE) return I2C_ENOTSUP;
-    if (!c.rule_xu.unit || !c.rule_x.unit || c.rule_xu.w0 != R(0) || c.rule_x.w0 != R(0)) return I2C_ENOTSUP;
+    // cubature weights with lam != 0 (round 5): the GENERAL variant, for the models that have it (quad_general_exists)
+    if (!quad_general_exists<M>() && (!c.rule_xu.unit || !c.rule_x.unit || c.rule_xu.w0 != R(0) || c.rule_x.w0 != R(0))) return I2C_ENOTSUP;
     if constexpr (QG<M>::WIDE) {
       // the d = 16 form addresses trajectory-major buffers only: the posterior / prior in that layout (the engine's default for
       // the wave-capable models) and forward messages that the wave backward sweep reads

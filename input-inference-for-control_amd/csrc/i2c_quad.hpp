@@ -505,22 +505,34 @@ I2C_FN void q_points(const Quad<R>& q, const R sf, const R* muc, const R* lt, co
 }
 // Moments from the pairwise sums / differences (quadrature.py:34-44 in the form of sp_transform): mean (column form), the
 // centred sums (am is overwritten), and sy [NBO][NBO] upper blocks = wi/2 (am^T am + dm^T dm) (+ nothing: the caller adds noise)
-template <int DIN, int NOUT, typename R>
-I2C_FN void q_moments(const Quad<R>& q, const R wi, R* am, const R* dm, const R* yc, R* myc, R* sy) {
+// GENERAL (round 5): any CubatureQuadrature(alpha, beta, kappa) -- a weight on the centre point and weights that need not sum to
+// one (W = sum of weights_sig = 2 - alpha^2 + beta; the reference's mean AND covariance use weights_sig, quadrature.py:36,49). With
+// y0 the centre value, A = sum_p a_p:   my = W y0 + wi A,
+//   sig_y = wi/2 sum_p (a_p a_p^T + d_p d_p^T) - wi^2 A A^T + (W - W^2) y0 y0^T + wi (1 - W) (y0 A^T + A y0^T)
+// (the last two terms vanish for W = 1; 2 d wi = 1 -- lam = 0 -- is what lets the unit form centre the a_p instead of the
+// explicit wi^2 A A^T). Needs the centre EVALUATED: a spare pair row (DIN < the geometry's pair rows).
+template <int DIN, int NOUT, bool GENERAL = false, typename R>
+I2C_FN void q_moments(const Quad<R>& q, const Rule<R>& rule, R* am, const R* dm, const R* yc, R* myc, R* sy) {
   constexpr int NBI = (DIN + 3) / 4, NBO = (NOUT + 3) / 4;
-  const R hw = R(0.5) * wi;
+  const R wi = rule.wi, hw = R(0.5) * wi;
   const R rm = (4 * (NBI - 1) + q.r < DIN) ? R(1) : R(0);  // live pairs of the last pair block
+  R acol[NBO];
 #pragma unroll
   for (int j = 0; j < NBO; ++j) {
     R t = am[j];
 #pragma unroll
     for (int i = 1; i < NBI; ++i) t += am[i * NBO + j];
     const R asum = q_colsum(q, t);
-    myc[j] = yc[j] + wi * asum;
-    // sig_y = wi/2 sum_p (a_p a_p^T + d_p d_p^T) - wi^2 A A^T: with 2 d wi = 1 the last term centres the a_p
-    const R amean = (R(2) * wi) * asum;
+    acol[j] = asum;
+    if constexpr (GENERAL) {
+      myc[j] = rule.W * yc[j] + wi * asum;
+    } else {
+      myc[j] = yc[j] + wi * asum;
+      // sig_y = wi/2 sum_p (a_p a_p^T + d_p d_p^T) - wi^2 A A^T: with 2 d wi = 1 the last term centres the a_p
+      const R amean = (R(2) * wi) * asum;
 #pragma unroll
-    for (int i = 0; i < NBI; ++i) am[i * NBO + j] = (i < NBI - 1 || DIN % 4 == 0) ? am[i * NBO + j] - amean : am[i * NBO + j] - amean * rm;
+      for (int i = 0; i < NBI; ++i) am[i * NBO + j] = (i < NBI - 1 || DIN % 4 == 0) ? am[i * NBO + j] - amean : am[i * NBO + j] - amean * rm;
+    }
   }
 #pragma unroll
   for (int k = 0; k < NBO * NBO; ++k) sy[k] = R(0);
@@ -528,6 +540,20 @@ I2C_FN void q_moments(const Quad<R>& q, const R wi, R* am, const R* dm, const R*
   q_tn<NBI, NBO, NBO, false, true>(q, dm, dm, sy);
 #pragma unroll
   for (int k = 0; k < NBO * NBO; ++k) sy[k] *= hw;
+  if constexpr (GENERAL) {
+    const R W = rule.W, c_yy = W - W * W, c_ya = wi * (R(1) - W), c_aa = -(wi * wi);
+    R arow[NBO], y0row[NBO];
+#pragma unroll
+    for (int i = 0; i < NBO; ++i) {
+      arow[i] = q_tr(q, acol[i]);
+      y0row[i] = q_tr(q, yc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NBO; ++i)
+#pragma unroll
+      for (int j = i; j < NBO; ++j)
+        sy[i * NBO + j] += (c_aa * arow[i] + c_ya * y0row[i]) * acol[j] + (c_yy * y0row[i] + c_ya * arow[i]) * yc[j];
+  }
 }
 
 // ---- Kalman-style updates ------------------------------------------------------------------------------------------------------
@@ -675,7 +701,15 @@ template <typename R, typename S, bool TM> struct QIO {
 //   * feed-forward cells (i2c.py:355-360) are the same arithmetic with Kt = 0.
 // `live`: trajectory slot b holds a real trajectory (the last wave of a batch that is not a multiple of four repeats its last
 // one in the spare slots: every lane of a wave takes part in the matrix instructions; nothing is stored for them)
-template <class M, typename R, typename S, class KC>
+// GENERAL: cubature weights with lam != 0 / weights that do not sum to one (q_moments). For the models that evaluate every
+// observation through their sigma points and have a spare pair row for the centre (quad_general_exists): the identity-observation
+// forms take their moments from the input covariance, which is the W = 1 case only.
+template <class M> constexpr bool quad_general_exists() {
+  constexpr int D = M::NX + M::NU, NT = M::NZT > 0 ? M::NZT : 1;
+  return !QG<M>::WIDE && D < QG<M>::PR && !(st_identity<ObsStruct<M>, M::NZ>() && M::NZ == D) &&
+         !(M::NZT > 0 && st_identity<TermStruct<M>, NT>() && NT == M::NX);
+}
+template <class M, typename R, typename S, bool GENERAL = false, class KC>
 I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const FwdArgs<R, S>& a, const int b, const bool live, const Quad<R>& qw) {
   using C = Consts<M, R>;
   const Quad<R>& q = qw;
@@ -692,7 +726,9 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
 #define I2C_QUAD_LASTLIN 1
 #endif
   constexpr int JZL = M::obs_lin(NZ - 1);
-  constexpr bool LASTLIN = I2C_QUAD_LASTLIN && !OBS_ID && NZ % 4 == 1 && NZ > 4 && JZL >= 0 && JZL / 4 == (D + 3) / 4 - 1;
+  // (unit weights only: with W != 1 the moments of a pass-through output carry (W - W^2) m^2 terms, q_moments)
+  constexpr bool LASTLIN = I2C_QUAD_LASTLIN && !GENERAL && !OBS_ID && NZ % 4 == 1 && NZ > 4 && JZL >= 0 && JZL / 4 == (D + 3) / 4 - 1;
+  static_assert(!GENERAL || quad_general_exists<M>(), "general cubature weights: sigma-point observations and a spare pair row for the centre");
   static_assert(OBS_ID || D % 4 != 0, "quad kernels: a general observation needs a spare column in the joint's last block");
   static_assert(OBS_ID || NU == 1, "quad kernels: a general observation with one action (the factor of S_u|x is a square root)");
   constexpr int JU = NX / 4, CU = NX % 4;  // the block (row and column) and the in-block offset where the action entries start
@@ -1013,7 +1049,7 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
       R am[NBD * NB8], dm[NBD * NB8], yc[NB8], mz[NB8], sz[NB8 * NB8], szx[NB8 * NBD];
       q_points<M, G, D, NZ8>(q, rule.sf, mu0, lt0, ObserveHeadF<M, R, NZ8>{c.params}, am, dm, yc);
       I2C_QSTAMP(2);  // observation points
-      q_moments<D, NZ8>(q, rule.wi, am, dm, yc, mz, sz);
+      q_moments<D, NZ8>(q, rule, am, dm, yc, mz, sz);
 #pragma unroll
       for (int i = 0; i < NB8; ++i)
 #pragma unroll
@@ -1065,7 +1101,7 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
       R am[NBD * NBZ], dm[NBD * NBZ], yc[NBZ], mz[NBZ], sz[NBZ * NBZ], szx[NBZ * NBD];
       q_points<M, G, D, NZ>(q, rule.sf, mu0, lt0, ObserveF<M, R>{c.params}, am, dm, yc);
       I2C_QSTAMP(2);  // observation points
-      q_moments<D, NZ>(q, rule.wi, am, dm, yc, mz, sz);
+      q_moments<D, NZ, GENERAL>(q, rule, am, dm, yc, mz, sz);
 #pragma unroll
       for (int i = 0; i < NBZ; ++i)
 #pragma unroll
@@ -1101,7 +1137,7 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
       R am[NBD * NBX], dm[NBD * NBX], yc[NBX], sy[NBX * NBX];
       q_points<M, G, D, NX>(q, rule.sf, mu0, lt, DynamicsF<M, R>{c.params}, am, dm, yc);
       I2C_QSTAMP(6);  // dynamics points
-      q_moments<D, NX>(q, rule.wi, am, dm, yc, mx, sy);
+      q_moments<D, NX, GENERAL>(q, rule, am, dm, yc, mx, sy);
 #pragma unroll
       for (int i = 0; i < NBX; ++i)
 #pragma unroll
@@ -1143,7 +1179,7 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
       } else if constexpr (NZT > 0) {
         R am[NBX * NBT], dm[NBX * NBT], yc[NBT], mz[NBT], sz[NBT * NBT], szx[NBT * NBX];
         q_points<M, G, NX, NT>(q, c.rule_x.sf, mx, l3t, ObserveTermF<M, R>{c.params}, am, dm, yc);
-        q_moments<NX, NT>(q, c.rule_x.wi, am, dm, yc, mz, sz);
+        q_moments<NX, NT, GENERAL>(q, c.rule_x, am, dm, yc, mz, sz);
 #pragma unroll
         for (int i = 0; i < NBT; ++i)
 #pragma unroll
@@ -1638,7 +1674,7 @@ I2C_HD inline void ckf_quad_body(const Consts<M, R>& c, const KC& kc, const CkfA
     for (int k = 0; k < NBX * NBX; ++k) tmp[k] = S[k];
     ok = q_elim<NX, 0, 0>(q, tmp, (R*)nullptr, (R*)nullptr, lt);
     q_points<M, G, NX, NX>(q, rule.sf, mu, lt, DynamicsFixedUF<M, R>{c.params, u}, am, dm, yc);
-    q_moments<NX, NX>(q, rule.wi, am, dm, yc, mf, Sf);
+    q_moments<NX, NX>(q, rule, am, dm, yc, mf, Sf);
 #pragma unroll
     for (int i = 0; i < NBX; ++i)
 #pragma unroll
@@ -1651,7 +1687,7 @@ I2C_HD inline void ckf_quad_body(const Consts<M, R>& c, const KC& kc, const CkfA
     for (int k = 0; k < NBX * NBX; ++k) tmp[k] = Sf[k];
     ok = q_elim<NX, 0, 0>(q, tmp, (R*)nullptr, (R*)nullptr, lt) && ok;
     q_points<M, G, NX, NY>(q, rule.sf, mf, lt, MeasureF<M, R>{c.params}, am, dm, yc);
-    q_moments<NX, NY>(q, rule.wi, am, dm, yc, my, Sy);
+    q_moments<NX, NY>(q, rule, am, dm, yc, my, Sy);
 #pragma unroll
     for (int i = 0; i < NBY; ++i)
 #pragma unroll

@@ -158,6 +158,10 @@ def check_batch_against_oracle(name, lib, device, B, n_iters, tol=1e-8, dtype=to
     x0, mu_u = batched_inputs(g, B)
     eng = engine_from_case(g, lib, device, dtype=dtype, x0=x0, mu_u=mu_u, **kw)
     g2 = dict(g)
+    if "quad" in kw:  # the cubature weights asked of the engine: the oracle integrates with the same rule
+        import json
+
+        g2["meta"] = np.array(json.dumps({**g.meta, "quad": list(kw["quad"])}))
     o = oracle_from_case(type(g)({**g2, "mu_u": mu_u}), x0=x0)
     if g.meta.get("propagate"):
         eng.propagate()

@@ -108,13 +108,24 @@ def test_hip_wave_fused_learn_matches_stepwise(lib):
 QUAD_GOLDEN = [("em_pendulum_T200", 1e-8, 1e-7), ("em_pendulum_T200_run200", 1e-6, 1e-5), ("em_dcp_T60", 1e-6, 1e-5),
                ("em_dcp_T300_run20", 1e-6, 1e-5), ("em_dcp_T300_run50", 1e-6, 1e-5), ("em_dcp_nondiag_T30", 1e-6, 1e-5),
                ("em_cartpole_T100", 1e-6, 1e-5), ("em_linear_T60", 1e-8, 1e-7), ("em_quadrotor_T20", 1e-6, 1e-5),
-               ("em_pendulum_T30_tau7", 1e-8, 1e-7), ("em_covctrl_T100", 1e-7, 1e-6), ("em_covctrl_qf_T40", 1e-7, 1e-6)]
+               ("em_pendulum_T30_tau7", 1e-8, 1e-7), ("em_covctrl_T100", 1e-7, 1e-6), ("em_covctrl_qf_T40", 1e-7, 1e-6),
+               ("em_pendulum_T40_quad_general", 1e-8, 1e-7)]  # (round 5: cubature weights with lam != 0 and W != 1, the GENERAL variant)
 
 
 @pytest.mark.parametrize("name,tol_d,tol_s", QUAD_GOLDEN)
 def test_hip_quad_forward_vs_reference_golden(lib, name, tol_d, tol_s):
     eng = parity.check_against_golden(name, lib, "cuda", tol_d, tol_s, group_lanes=64)
     assert eng.forward_family == "quad" and eng.backward_family == "lane"
+
+
+@pytest.mark.parametrize("name,B", [("em_dcp_T60", 131), ("em_cartpole_T100", 67)])
+def test_hip_quad_forward_general_weights_batch_vs_oracle(lib, name, B):
+    """General cubature weights on the d = 5 / 7 models: the quad kernel's GENERAL variant (the default inside the quad window since
+    round 5; it was the group fallback) against the batched oracle integrating with the same rule, ragged batches."""
+    eng, _ = parity.check_batch_against_oracle(name, lib, "cuda", B, 2, tol=1e-6, quad=(1.2, 0.44, 0.5))
+    assert eng.forward_family == "quad"
+    eng, _ = parity.check_batch_against_oracle(name, lib, "cuda", B, 2, tol=1e-6, quad=(1.0, 0.0, 0.5), group_lanes=64)
+    assert eng.forward_family == "quad"
 
 
 @pytest.mark.parametrize("name", ["em_quad12_T20", "em_quad12_T12_propagate", "em_quad12_nondiag_T12", "em_quad12_covctrl_T12"])

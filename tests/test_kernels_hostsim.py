@@ -119,6 +119,8 @@ QUAD_GOLDEN = [
     ("em_pendulum_T30_tau7", 1e-9, 1e-8, None),  # feed-forward and feedback cells in one sweep
     ("em_covctrl_T100", 1e-8, 1e-7, 8),        # nz = 1 (only the action is observed), no terminal observation; covariance control behind it
     ("em_covctrl_qf_T40", 1e-8, 1e-7, None),
+    ("em_pendulum_T40_quad_general", 1e-9, 1e-8, None),  # CubatureQuadrature(1.2, 0.44, 0.5): a weight on the centre, weights that do not
+                                                        # sum to one -- the GENERAL variant of the quad kernel (round 5)
 ]
 
 
@@ -126,6 +128,16 @@ QUAD_GOLDEN = [
 def test_hostsim_quad_forward_vs_reference_golden(lib, name, tol_d, tol_s, n_iters):
     eng = parity.check_against_golden(name, lib, "cpu", tol_d, tol_s, n_iters=n_iters, group_lanes=64)
     assert eng.forward_family == "quad" and eng.backward_family == "lane"
+
+
+@pytest.mark.parametrize("name,B", [("em_dcp_T60", 5), ("em_cartpole_T100", 3), ("em_pendulum_T200", 6)])
+def test_hostsim_quad_forward_general_weights_batch_vs_oracle(lib, name, B):
+    """The GENERAL variant (cubature weights with lam != 0, W != 1) on the d = 5 / 7 models against the batched oracle with the same
+    rule -- and the default family of such a problem inside the quad window is the quad kernel now (it was the group fallback)."""
+    eng, _ = parity.check_batch_against_oracle(name, lib, "cpu", B, 2, tol=1e-7, quad=(1.2, 0.44, 0.5))
+    assert eng.forward_family == ("quad" if name != "em_pendulum_T200" else "lane")
+    eng, _ = parity.check_batch_against_oracle(name, lib, "cpu", B, 2, tol=1e-7, quad=(1.0, 0.0, 0.5), group_lanes=64)  # (W = 1, but a weight on the centre: lam = 0.5)
+    assert eng.forward_family == "quad"
 
 
 @pytest.mark.parametrize("name,B", [("em_dcp_T60", 6), ("em_pendulum_T200", 9), ("em_quadrotor_T20", 5), ("em_cartpole_T100", 3)])
@@ -179,10 +191,14 @@ def test_hostsim_quad12_quad_forward_batch_vs_oracle(lib):
 
 
 def test_quad_forward_refuses_what_it_does_not_cover(lib):
-    """General cubature weights (a weight on the centre point) and the other inference rules are not in the quad form: the
-    library says I2C_ENOTSUP when it is asked for explicitly."""
-    with pytest.raises(RuntimeError, match="-2"):
-        parity.engine_from_case(load_case("em_pendulum_T40_quad_general"), lib, "cpu", group_lanes=64).forward_sweep()
+    """General cubature weights (a weight on the centre point) are in the quad form only where every observation goes through the
+    sigma points and the geometry has a spare pair row for the centre (pendulum, cartpole, double cartpole: round 5); the
+    identity-observation models, d = 8 / 16 and the other inference rules are refused with I2C_ENOTSUP when asked for explicitly."""
+    for name in ("em_linear_T60", "em_quadrotor_T20"):
+        with pytest.raises(RuntimeError, match="-2"):
+            parity.engine_from_case(load_case(name), lib, "cpu", quad=(1.2, 0.44, 0.5), group_lanes=64)
+    with pytest.raises(RuntimeError, match="-2"):  # Linearize() on the quad kernels
+        parity.engine_from_case(load_case("lin_pendulum_T100"), lib, "cpu", group_lanes=64)
     with pytest.raises(ValueError):  # d = 16 has the wave kernels under 64; models without either refuse it
         parity.engine_from_case(load_case("em_pendulum_T200"), lib, "cpu", group_lanes=32)
 
