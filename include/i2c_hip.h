@@ -96,7 +96,7 @@ enum {
   I2C_FAMILY_GROUP = 2, /* G = I2cDims.group_lanes lanes per trajectory, blocks row-distributed, exchanged through LDS  */
   I2C_FAMILY_WAVE = 3,  /* one wavefront per trajectory: 16 x 16 blocks in the MFMA accumulator layout (d = 16)          */
   I2C_FAMILY_QUAD = 4   /* four trajectories per wavefront: 4 x 4 blocks on v_mfma_f64_4x4x4_4b_f64, one element per lane
-                           (forward sweep: every model; backward sweep and filter step: d = 16)                            */
+                           (forward sweep: every model; backward sweep, propagation and filter step: d = 16)               */
 };
 /* I2cProblem.group_lanes = I2C_LANES_QUAD asks for the quad kernels of a model that also has wave kernels (64 = the
  * wave kernels there): the 12-state quadrotor -- forward and backward sweep, at any batch size */
@@ -176,8 +176,9 @@ typedef struct I2cProblem {
                               64: the matrix-instruction family: the wave kernels where they exist (I2cDims.wave: one wavefront per
                               trajectory, forward and backward sweeps), the quad forward kernel otherwise (I2cDims.quad);
                               I2C_LANES_QUAD: the quad kernels of a model that also has wave kernels, at any batch size;
-                              (all of these: fp64 or I2C_F64_F32S, cubature rule with lam = 0; the propagation runs the model's default --
-                              group kernels for d = 16 --, the filter step of the d = 16 model the quad kernels, ckf_quad_body)
+                              (all of these: fp64 or I2C_F64_F32S, cubature rule with lam = 0 -- any weights for the quad forward kernel of
+                              the pendulum / cartpole / double cartpole; the closed-loop propagation and the filter step of the d = 16
+                              model run on the quad kernels too: propagate_quad_body, ckf_quad_body)
                               I2cDims.group_lanes: run forward / backward / propagate / filter with that many lanes of
                               a wavefront per trajectory (fp64, cubature rule;
                               the backward sweep then has one schedule, the fused walk); -1: one lane per trajectory for

@@ -470,6 +470,50 @@ static int launch_quad_backward(const Consts<M, R>& c, const A& a, void* stream)
 }
 #endif
 
+// the quad propagation (propagate_quad_body): d = 16 models with identity observations
+#ifdef I2C_HOST_SIM
+template <class M, typename R>
+static int launch_quad_propagate(const Consts<M, R>& c, const PropArgs<R>& a, void*) {
+  QPConst<M, R> kc;
+  qpconst_fill<M, R>(kc, &c, 0, 1);
+  for (int b0 = 0; b0 < c.B; b0 += 4) {
+    std::vector<R> sh((size_t)4 * QG<M>::SIZE, R(0)), xch(128, R(0));
+    HostBarrier bar(64);
+    std::vector<std::thread> lanes;
+    for (int l = 0; l < 64; ++l)
+      lanes.emplace_back([&, l, b0] {
+        const int g = (l >> 2) & 3, b = b0 + g;
+        const bool live = b < c.B;
+        propagate_quad_body<M, R>(c, kc, a, live ? b : c.B - 1, live, Quad<R>{l, l >> 4, g, l & 3, sh.data() + g * QG<M>::SIZE, &bar, xch.data()});
+      });
+    for (auto& th : lanes) th.join();
+  }
+  return I2C_OK;
+}
+#else
+template <class M, typename R>
+__global__ __launch_bounds__(64 * quad_waves_per_block<M>(), 2) void k_quad_propagate(const Consts<M, R> c, const PropArgs<R> a) {
+  constexpr int WPB = quad_waves_per_block<M>();
+  __shared__ QPConst<M, R> kc;
+  __shared__ R sh[WPB * 4 * QG<M>::SIZE];
+  qpconst_fill<M, R>(kc, (const Consts<M, R>*)__builtin_amdgcn_kernarg_segment_ptr(), (int)threadIdx.x, 64 * WPB);
+  __syncthreads();
+  const int l = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6), g = (l >> 2) & 3;
+  const long b0 = 4L * ((long)blockIdx.x * WPB + wv);
+  if (b0 >= c.B) return;  // (wave-uniform: no trajectory in this wave)
+  const long b = b0 + g;
+  const bool live = b < c.B;
+  const Quad<R> q{l, l >> 4, g, l & 3, (lds_ptr<R>)(sh + (wv * 4 + g) * QG<M>::SIZE)};
+  propagate_quad_body<M, R>(c, kc, a, (int)(live ? b : c.B - 1), live, q);
+}
+template <class M, typename R>
+static int launch_quad_propagate(const Consts<M, R>& c, const PropArgs<R>& a, void* stream) {
+  constexpr int WPB = quad_waves_per_block<M>();
+  hipLaunchKernelGGL((k_quad_propagate<M, R>), dim3((unsigned)(((long)c.B + 4 * WPB - 1) / (4 * WPB))), dim3(64 * WPB), 0, (hipStream_t)stream, c, a);
+  return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
+}
+#endif
+
 // the quad filter step (ckf_quad_body): d = 16 models
 #ifdef I2C_HOST_SIM
 template <class M, typename R>
@@ -732,7 +776,15 @@ template <class M, typename R, typename S = R> struct Impl {
     return window_32bit_ok(p);
   }
   static constexpr bool HAS_QUAD_CKF = HAS_QUAD && !MIXED && quad_ckf_exists<M>();  // the filter step of the d = 16 form
+  static constexpr bool HAS_QUAD_PROP = HAS_QUAD && !MIXED && quad_propagate_exists<M>();  // the closed-loop propagation of the d = 16 form
   static int family(const I2cProblem* p, const C& c, const int sweep) {
+    if constexpr (HAS_QUAD_PROP) {  // the closed-loop propagation of a matrix-instruction graph: the quad form where it applies
+      // (unit cubature rule -- a Linearize() graph propagates with it, i2c.py:109-115 --, trajectory-major posterior)
+      if (sweep == I2C_SWEEP_PROPAGATE && (p->group_lanes == 0 || p->group_lanes == 64 || p->group_lanes == I2C_LANES_QUAD) &&
+          (p->inference == I2C_INF_CUBATURE || p->inference == I2C_INF_LINEARIZE) && p->post_layout == 1 && c.rule_xu.unit &&
+          c.rule_xu.w0 == R(0) && window_32bit_ok(p) == I2C_OK)
+        return I2C_FAMILY_QUAD;
+    }
     if constexpr (HAS_QUAD_CKF) {  // the state estimator of a matrix-instruction graph (default, 64 or I2C_LANES_QUAD): the quad filter step
       if (sweep == I2C_SWEEP_FILTER && (p->group_lanes == 0 || p->group_lanes == 64 || p->group_lanes == I2C_LANES_QUAD)) return I2C_FAMILY_QUAD;
     }
@@ -789,7 +841,8 @@ template <class M, typename R, typename S = R> struct Impl {
     return q;
   }
   static int family_of(const I2cProblem* p, int sweep) {
-    const I2cProblem q = sweep == I2C_SWEEP_FILTER ? filter_problem(p) : *p;
+    I2cProblem q = sweep == I2C_SWEEP_FILTER ? filter_problem(p) : *p;
+    if (sweep == I2C_SWEEP_PROPAGATE && p->inference == I2C_INF_LINEARIZE) q.quad_alpha = 1.0, q.quad_beta = 0.0, q.quad_kappa = 0.0;  // (as propagate())
     const C c = make_consts<M, R>(&q, 0.0, 0);
     return family(&q, c, sweep);
   }
@@ -1249,6 +1302,9 @@ template <class M, typename R, typename S = R> struct Impl {
                   (const R*)p->z, p->feedforward, status, p->expert};
     const int fam = family(p, c, I2C_SWEEP_PROPAGATE);
     if (fam < 0) return fam;
+    if (fam == I2C_FAMILY_QUAD) {
+      if constexpr (HAS_QUAD_PROP) return launch_quad_propagate<M, R>(c, a, stream);
+    }
     if (fam == I2C_FAMILY_GROUP) {
       if constexpr (HAS_GROUP) return launch_group<GK_PROPAGATE, M, R, G>(c, nullptr, a, stream);
     }

@@ -1710,4 +1710,236 @@ I2C_HD inline void ckf_quad_body(const Consts<M, R>& c, const KC& kc, const CkfA
   if (live && q.p() == 0 && !ok && a.status[b] == 0) a.status[b] = (9 << 16) | 1;  // I2C_FAIL_FILTER, as set_status(.., 9, 0)
 }
 
+// ------------------------------------------------------------------------------------------
+// Closed-loop propagation (i2c.py:150-199, 1247-1251), d = 16 with identity observations (the 12-state quadrotor)
+// ------------------------------------------------------------------------------------------
+// FOUR trajectories per wavefront, the blocks and phases of the forward cell: the (optional) pdf-ratio scaling of the feedback gain
+// (i2c.py:160-167: one elimination with the state offset as right-hand side; a failed one leaves K unscaled like the reference,
+// which logs the exception), the joint N(xu) from the state marginal and the controller -- sig_0 = [[S, S K^T], [K S, sig_u]] with
+// sig_u = the posterior's action block (feed-forward cells) or K S K^T + sig_uu_m - K sig_xx_m K^T (feedback cells,
+// i2c.py:169-171) --, the expected cost of the propagated observation (= the joint: identity observation), the 2 d sigma
+// points through the dynamics, and at the end of the horizon the KL divergence to the terminal state prior (covariance control,
+// i2c.py:1012-1019). With it covariance control / calibrate_alpha of the 12-state model no longer drop to the group kernels,
+// whose waves serialise beyond 1024 (4096 trajectories). Posterior buffer trajectory-major, propagation buffer [T][E][B].
+template <class M, typename R> struct QPConst {
+  static constexpr int QLD = QG<M>::QLD;
+  R qr[QLD * QLD], eta[QLD * QLD], sxT[QLD * QLD];  // blkdiag(Q, R), sig_eta, sig_x_terminal
+  R zg[QLD], mxT[QLD];
+};
+template <class M, typename R, class DST> I2C_FN void qpconst_fill(DST& k, const Consts<M, R>* c, const int tid, const int nthreads) {
+  constexpr int NX = M::NX, NZ = M::NZ, QLD = QG<M>::QLD;
+  for (int e = tid; e < QLD * QLD; e += nthreads) {
+    const int i = e / QLD, j = e % QLD;
+    k.qr[e] = (i < NZ && j < NZ) ? c->QR[tri_any(i, j)] : R(0);
+    k.eta[e] = (i < NX && j < NX) ? c->sig_eta[tri_any(i, j)] : R(0);
+    k.sxT[e] = (i < NX && j < NX) ? c->sig_x_term[tri_any(i, j)] : R(0);
+  }
+  for (int e = tid; e < QLD; e += nthreads) {
+    k.zg[e] = e < NZ ? c->zg[e] : R(0);
+    k.mxT[e] = e < NX ? c->mu_x_term[e] : R(0);
+  }
+}
+template <class M> constexpr bool quad_propagate_exists() {
+  return QG<M>::WIDE && M::NX % 4 == 0 && (M::NX + M::NU) % 4 == 0 && M::NU <= 4 && M::NZ == M::NX + M::NU && st_identity<ObsStruct<M>, M::NZ>();
+}
+
+template <class M, typename R, class KC>
+I2C_HD inline void propagate_quad_body(const Consts<M, R>& c, const KC& kc, const PropArgs<R>& a, const int b, const bool live, const Quad<R>& qw) {
+  using C = Consts<M, R>;
+  using G = QG<M>;
+  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, D = C::D, NBX = NX / 4, NBD = D / 4, JU = NX / 4, QLD = G::QLD;
+  static_assert(quad_propagate_exists<M>(), "quad propagation: d = 16 geometry, identity observation of the joint");
+  constexpr int O_K = D + sym(D), O_X3 = D + sym(D), O_SX3 = O_X3 + NX;
+  const unsigned long B = c.B;
+  const int T = c.T;
+  const unsigned WS = sizeof(R), bo = (unsigned)b * WS, rb = (unsigned)(B * WS);
+  const Rule<R>& rule = c.rule_xu;
+  int fail = 0;
+  auto note = [&](const bool ok, const int t) { fail = (fail == 0 && !ok) ? ((8 << 16) | (t + 1)) : fail; };  // I2C_FAIL_PROPAGATE
+
+  // state marginal carried along the chain: mean in column form, covariance in UPPER blocks (the diagonal ones full)
+  R mx[NBX], sx[NBX * NBX];
+#pragma unroll
+  for (int j = 0; j < NBX; ++j) {
+    mx[j] = a.x0[(long)(4 * j + qw.c) * B + b];
+#pragma unroll
+    for (int i = 0; i < NBX; ++i) sx[i * NBX + j] = j >= i ? a.sig_x0[(long)w_symidx(4 * i + qw.r, 4 * j + qw.c) * B + b] : R(0);
+  }
+  const Window ffw = make_window(a.ff, (unsigned long)T), exw = make_window(a.expert ? a.expert : a.ff, (unsigned long)T);
+  R acc_m = R(0), acc_v = R(0);
+
+  for (int t = 0; t < T; ++t) {
+    const int kz = (int)opaque_uniform(0u);
+    const Quad<R> q = q_opaque(qw);
+    const int r = q.r, cc = q.c;
+    const int hi = r > cc ? r : cc, lo = r > cc ? cc : r;
+    const int tri_c = cc * (cc + 1) / 2 + r, tri_d = hi * (hi + 1) / 2 + lo;
+    auto sym_lane = [&](const int i, const int j) { return i == j ? tri_d + 4 * j * hi : tri_c + 4 * j * cc; };
+    auto sym_k = [&](const int i, const int j) { return i == j ? 8 * j * j + 6 * j : 8 * j * j + 2 * j + 4 * i; };
+    const int trc = c.row(t);
+    // the posterior rows of this cell (trajectory-major: a cell of a trajectory is contiguous)
+    const QIO<R, R, true> pri{make_window(a.post + (unsigned long)trc * C::E_POST * B, (unsigned long)C::E_POST * B * WS), WS, (unsigned)b * (unsigned)C::E_POST * WS};
+    R pmu[NBD], pj[NBD * NBD], kt[NBX], zt[NBD];
+#pragma unroll
+    for (int j = 0; j < NBD; ++j) {
+      pmu[j] = pri.ld(cc, 4 * j);
+#pragma unroll
+      for (int i = 0; i < NBD; ++i) pj[i * NBD + j] = i <= j ? pri.ld(sym_lane(i, j), D + sym_k(i, j)) : R(0);  // upper blocks, the diagonal ones full
+      const R ztv = (c.z_per_cell ? a.z : a.x0)[c.z_per_cell ? ((long)trc * NZ + 4 * j + cc) * B + b : b];  // (or a discarded dummy)
+      zt[j] = c.z_per_cell ? ztv : q_ldv(q, kc.zg, j, kz);
+    }
+#pragma unroll
+    for (int i = 0; i < NBX; ++i) kt[i] = cc < NU ? pri.ld(cc * NX + r, O_K + 4 * i) : R(0);  // K^T, block (i, JU): row = state, column = action
+    const bool ff = w_uniform((int)wld_u8(ffw, (unsigned)trc)) != 0;
+    const bool ex = a.expert ? w_uniform((int)wld_u8(exw, (unsigned)trc)) != 0 : c.use_expert != 0;
+
+    // state offset to the posterior's state mean, row form; pdf-ratio scaling of the gain (expert controller, feedback cells)
+    R dr[NBX];
+#pragma unroll
+    for (int i = 0; i < NBX; ++i) dr[i] = q_tr(q, mx[i] - pmu[i]);
+    R rho = R(1);
+    if (!ff && ex) {
+      R sm[NBX * NBX], rhs[NBX], lts[NBX * NBX];
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) {
+#pragma unroll
+        for (int j = 0; j < NBX; ++j) sm[i * NBX + j] = j >= i ? pj[i * NBD + j] + sx[i * NBX + j] : R(0);
+        rhs[i] = cc == 0 ? dr[i] : R(0);
+      }
+      const bool ok = q_elim<NX, 1, 0>(q, sm, rhs, (R*)nullptr, lts);
+      R ysq = R(0);
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) ysq += cc == 0 ? rhs[i] * rhs[i] : R(0);
+      const R maha = q_bcq<0>(q, q_colsum(q, ysq));
+      rho = ok ? r_exp_sc(R(-0.5) * maha) : R(1);  // the reference logs the exception and keeps K unscaled (i2c.py:166-167)
+    }
+    // joint N(xu): sig_0 = [[S, S K^T], [K S, sig_u]], mu_0 = [mx; mu_u + K (mx - x_ref)]
+    R mu0[NBD], s0[NBD * NBD];
+    {
+      R ktm[NBX], sxf[NBX * NBX], g[NBX], kxk = R(0);
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) {
+        ktm[i] = rho * kt[i];
+        g[i] = R(0);
+#pragma unroll
+        for (int j = 0; j < NBX; ++j) sxf[i * NBX + j] = j >= i ? sx[i * NBX + j] : q_tr(q, sx[j * NBX + i]);
+      }
+#pragma unroll
+      for (int i = 0; i < NBX; ++i)
+#pragma unroll
+        for (int k = 0; k < NBX; ++k) q_mfma(q, sxf[k * NBX + i], ktm[k], g[i]);  // (S K^T)[i] = sum_k S[i][k] K^T[k]
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) q_mfma(q, ktm[i], g[i], kxk);                 // K S K^T
+      R suu = pj[JU * NBD + JU];
+      if (!ff) {  // sig_u = K S K^T + sig_uu_m - K sig_xx_m K^T (i2c.py:169-171)
+        R pxf[NBX * NBX], h[NBX], kpk = R(0);
+#pragma unroll
+        for (int i = 0; i < NBX; ++i) {
+          h[i] = R(0);
+#pragma unroll
+          for (int j = 0; j < NBX; ++j) pxf[i * NBX + j] = j >= i ? pj[i * NBD + j] : q_tr(q, pj[j * NBD + i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NBX; ++i)
+#pragma unroll
+          for (int k = 0; k < NBX; ++k) q_mfma(q, pxf[k * NBX + i], ktm[k], h[i]);
+#pragma unroll
+        for (int i = 0; i < NBX; ++i) q_mfma(q, ktm[i], h[i], kpk);
+        suu -= kpk;
+      }
+#pragma unroll
+      for (int i = 0; i < NBD; ++i)
+#pragma unroll
+        for (int j = 0; j < NBD; ++j) {
+          R v = R(0);
+          if (i < NBX && j < NBX) v = j >= i ? sx[(i < NBX ? i : 0) * NBX + (j < NBX ? j : 0)] : R(0);
+          else if (i < NBX && j == JU) v = g[i < NBX ? i : 0];
+          else if (i == JU && j == JU) v = ff ? suu : kxk + suu;  // (feed-forward cells: the action marginal ITSELF, while the joint still carries K S: i2c.py:155-157, 173-179)
+          s0[i * NBD + j] = v;
+        }
+      R tt = R(0);
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) tt += ktm[i] * dr[i];
+      const R kd = ff ? R(0) : q_colsum(q, tt);  // feed-forward cells: the action marginal itself (i2c.py:155-157)
+#pragma unroll
+      for (int j = 0; j < NBD; ++j) mu0[j] = j < NBX ? mx[j < NBX ? j : 0] : pmu[j] + kd;
+    }
+    const QIO<R, R, false> out{make_window(a.prop + (unsigned long)t * C::E_PROP * B, (unsigned long)C::E_PROP * rb), rb, bo};
+#pragma unroll
+    for (int j = 0; j < NBD; ++j) {
+      out.st_if(live && r == 0, cc, 4 * j, mu0[j]);
+#pragma unroll
+      for (int i = 0; i <= j; ++i) out.st_if(live && (i < j || r <= cc), sym_lane(i, j), D + sym_k(i, j), s0[i * NBD + j]);
+    }
+    // expected cost of the propagated observation (= the joint: identity observation; compute_cost_gaussian, i2c.py:1034-1043)
+    {
+      R err[NBD], pm, pv;
+#pragma unroll
+      for (int j = 0; j < NBD; ++j) err[j] = mu0[j] - zt[j];
+      q_cost_share<NBD, NBD, QLD>(q, c.qr_diag != 0, kc.qr, err, s0, &pm, &pv, kz);
+      acc_m += pm;
+      acc_v += pv;
+    }
+    // dynamics push-through
+    {
+      R tmp[NBD * NBD], lt[NBD * NBD], am[NBD * NBX], dm[NBD * NBX], yc[NBX], sy[NBX * NBX];
+#pragma unroll
+      for (int k = 0; k < NBD * NBD; ++k) tmp[k] = s0[k];
+      note(q_elim<D, 0, 0>(q, tmp, (R*)nullptr, (R*)nullptr, lt), t);
+      q_points<M, G, D, NX>(q, rule.sf, mu0, lt, DynamicsF<M, R>{c.params}, am, dm, yc);
+      q_moments<D, NX>(q, rule, am, dm, yc, mx, sy);
+#pragma unroll
+      for (int i = 0; i < NBX; ++i)
+#pragma unroll
+        for (int j = 0; j < NBX; ++j) sx[i * NBX + j] = j >= i ? sy[i * NBX + j] + q_ldc<QLD>(q, kc.eta, i, j, kz) : R(0);
+    }
+#pragma unroll
+    for (int j = 0; j < NBX; ++j) {
+      out.st_if(live && r == 0, cc, O_X3 + 4 * j, mx[j]);
+#pragma unroll
+      for (int i = 0; i <= j; ++i) out.st_if(live && (i < j || r <= cc), sym_lane(i, j), O_SX3 + sym_k(i, j), sx[i * NBX + j]);
+    }
+  }
+  // KL(N(mx, sx) || terminal state prior) (covariance control): with L1 = chol(sx), L2 = chol(sig_T):
+  //   2 KL = 2 sum log(L2_ii / L1_ii) + ||L2^-1 L1||_F^2 + |L2^-1 (mu_T - mx)|^2 - nx
+  R kl = R(0);
+  if (c.has_x_terminal) {
+    const Quad<R>& q = qw;
+    const int kz = (int)opaque_uniform(0u);
+    R t1[NBX * NBX], lt1[NBX * NBX], sT[NBX * NBX], rl[NBX * NBX], dq[NBX], lt2[NBX * NBX];
+#pragma unroll
+    for (int k = 0; k < NBX * NBX; ++k) t1[k] = sx[k];
+    const bool ok1 = q_elim<NX, 0, 0>(q, t1, (R*)nullptr, (R*)nullptr, lt1);
+#pragma unroll
+    for (int i = 0; i < NBX; ++i) {
+#pragma unroll
+      for (int j = 0; j < NBX; ++j) {
+        sT[i * NBX + j] = j >= i ? q_ldc<QLD>(q, kc.sxT, i, j, kz) : R(0);
+        rl[i * NBX + j] = j <= i ? q_tr(q, lt1[j * NBX + i]) : R(0);  // L1 = (L1^T)^T, block lower triangular
+      }
+      const R dqr = q_tr(q, q_ldv(q, kc.mxT, i, kz) - mx[i]);  // (every lane takes part in the matrix instruction)
+      dq[i] = q.c == 0 ? dqr : R(0);
+    }
+    const bool ok2 = q_elim<NX, NBX, 1>(q, sT, rl, dq, lt2);
+    R part = R(0);
+#pragma unroll
+    for (int i = 0; i < NBX; ++i) {
+      part += dq[i] * dq[i];
+#pragma unroll
+      for (int j = 0; j < NBX; ++j) part += rl[i * NBX + j] * rl[i * NBX + j];
+      const R l1 = lt1[i * NBX + i], l2 = lt2[i * NBX + i];
+      part += q.r == q.c ? R(2) * (r_log(q.r == q.c ? l2 : R(1)) - r_log(q.r == q.c ? l1 : R(1))) : R(0);
+    }
+    kl = R(0.5) * (q_sum16(q, part) - R(NX));
+    note(ok1 && ok2, T - 1);
+  }
+  const R sum_m = q_sum16(qw, acc_m), sum_v = q_sum16(qw, acc_v);
+  if (live && qw.p() == 0) {
+    a.prop_stats[b] = sum_m;
+    a.prop_stats[B + b] = sum_v;
+    a.prop_stats[2 * B + b] = kl;
+    if (fail != 0 && a.status[b] == 0) a.status[b] = fail;
+  }
+}
+
 }  // namespace i2c

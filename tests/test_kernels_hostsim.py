@@ -96,9 +96,10 @@ def test_hostsim_wave_kernels_are_the_quad12_default(lib):
 
     eng = parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu")
     assert (eng.forward_family, eng.backward_family, eng.backward_schedule) == ("wave", "wave", "fused")
-    assert eng.kernel_family("propagate") == "group"  # the sweep the matrix-instruction families lack
-    assert eng.kernel_family("filter") == "quad"      # round 5: the state estimator's step on the quad kernels (ckf_quad_body)
-    assert parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu", group_lanes=16).kernel_family("filter") == "group"
+    # round 5: the closed-loop propagation and the state estimator's step on the quad kernels (propagate_quad_body, ckf_quad_body)
+    assert eng.kernel_family("propagate") == "quad" and eng.kernel_family("filter") == "quad"
+    grp = parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu", group_lanes=16)
+    assert grp.kernel_family("filter") == "group" and grp.kernel_family("propagate") == "group"
     general = parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu", quad=(1.2, 0.44, 0.5))
     assert general.forward_family == "group"  # weights with lam != 0: not covered by the wave form, the group kernels take over
     with pytest.raises(RuntimeError, match="-2"):
@@ -370,8 +371,13 @@ def _post_layout_is_transparent(lib, device, monkeypatch):
             assert e.failures() == []
             runs[(layout, lanes)] = (e.post.clone(), e.prop.clone(), torch.stack(act), roll["xu"].clone(), e.alpha.clone())
     for lanes in (0, 16):
-        for a, b in zip(runs[("1", lanes)], runs[("0", lanes)]):
-            assert torch.equal(a, b)
+        for k, (a, b) in enumerate(zip(runs[("1", lanes)], runs[("0", lanes)])):
+            if k == 1 and lanes == 0:
+                # the automatic pick propagates d=16 with the quad kernel on the trajectory-major layout and with the group
+                # kernel on the standard one: the same recursion in a different summation order
+                assert torch.allclose(a, b, rtol=1e-9, atol=1e-12)
+            else:
+                assert torch.equal(a, b)
 
 
 def test_hostsim_post_layout_is_transparent(lib, monkeypatch):
