@@ -422,6 +422,70 @@ template <int NB, bool PL = false, typename R, class P> I2C_FN bool w_kalman(con
   return ok;
 }
 
+// The same update in square-root form, for a prior that arrives as its Cholesky factor (round 5): with s = L L^T and
+// N^-1 = W / alpha,  s_new = L (I + L^T N^-1 L)^-1 L^T.  Factor M = I + L^T N^-1 L from its LAST row and column upwards,
+// M = U U^T with U upper triangular: then  s_new = (L U^-T)(L U^-T)^T  and L U^-T is lower triangular with a positive diagonal --
+// it IS chol(s_new), the factor the cubature rule of the dynamics needs (quadrature.py:17-24), with no second factorisation of a
+// 16 x 16 matrix and no difference of two covariances. The reversed elimination is the ordinary one on the index-reversed matrix:
+// with J the exchange matrix, J M J = I + X^T N^-1 X (X = L J, read column-reversed from the LDS copy of L^T) = L' L'^T, and
+// Y = L'^-1 (J L^T) -- the right-hand side of that elimination, L^T read row-reversed -- is  J chol(s_new)^T: the rows of
+// chol(s_new)^T in reverse order. A set of sigma-point directions has no order, and s_new = Y^T Y.
+// l: in L^T (accumulator layout), out Y;  s: out s_new;  mu, zt, W as in w_kalman. M >= I: the elimination fails only on
+// non-finite input.
+template <bool PL = false, typename R, class P> I2C_FN bool w_kalman_sqrt(const Wave<R>& w, const R alpha, const P w_m, const bool w_diag, const R zt,
+                                                                   R* mu, R* l, R* s) {
+  const auto Lt = w.mat();
+  const R ra = r_rcp(alpha);
+  w.sync();
+#pragma unroll
+  for (int v = 0; v < 4; ++v) Lt[w.row(v) * WLD + w.j] = l[v];
+  w.sync();
+  R x[4], y[4], m[4], lt[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    x[v] = Lt[(15 - w.j) * WLD + w.row(v)];  // (L J)[row][j]
+    l[v] = Lt[(15 - w.row(v)) * WLD + w.j];  // (J L^T)[row][j]
+  }
+  if (w_diag) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) y[v] = (w_m[w.row(v) * 17] * ra) * x[v];
+  } else {
+    R wm[4];
+    w_ldconst<4>(w, w_m, wm);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) y[v] = R(0);
+    w_tn<4>(w, wm, x, y);  // W symmetric
+#pragma unroll
+    for (int v = 0; v < 4; ++v) y[v] *= ra;
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) m[v] = w.row(v) == w.j ? R(1) : R(0);
+  w_tn<4>(w, x, y, m);
+  const bool ok = w_elim<4, 1, PL>(w, m, l, (R*)nullptr, lt);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) s[v] = R(0);
+  w_tn<4>(w, l, l, s);
+  const R r = zt - *mu;
+  R wr[4];
+  if (w_diag) {
+    const R wd = w_m[w.j * 16 + w.j];
+    w_col2row<4>(w, 0, wd * r, wr);
+  } else {
+    R rr[4], wm[4];
+    w_col2row<4>(w, 0, r, rr);
+    w_ldconst<4>(w, w_m, wm);
+    R t = R(0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) t += wm[v] * rr[v];
+    w_col2row<4>(w, 1, w_rowsum(w, t), wr);
+  }
+  R t = R(0);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) t += s[v] * wr[v];
+  *mu += w_rowsum(w, t) * ra;
+  return ok;
+}
+
 // ------------------------------------------------------------------------------------------
 // Forward sweep (i2c.py:876-880 over :350-447)
 // ------------------------------------------------------------------------------------------
@@ -489,6 +553,33 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
 #pragma unroll
   for (int v = 0; v < 4; ++v) sx[v] = opaque(sx[v]);
 
+  // Sigma-point cells carry the FACTOR of the state message next to it (round 5): lx = chol(sig_x)^T and, in its action columns,
+  // lk = chol(sig_x)^T K^T for the controller of the coming cell (whose rows are fetched a cell ahead). The joint prior of a cell
+  // is then known by its factor,  chol(sig_0)^T = [lx | rho lk; 0 | chol(P_uu - rho K P_xu)^T]  -- one 4 x 4 pivot --, and the cost
+  // observation updates that factor directly (w_kalman_sqrt): 11 pivot blocks per cell instead of 14, nothing re-factored. Both
+  // come out of the elimination of sig_x3 that the smoother gain needs anyway: lk rides in the free action columns of its
+  // identity right-hand side.
+  R lx[4] = {R(0), R(0), R(0), R(0)}, lk[4] = {R(0), R(0), R(0), R(0)};
+  bool lx_ok = true;
+  auto state_gain_rhs = [&](R* r) {  // [I | sig_x K^T] with the rows of the coming cell
+    R fn[4], mk[4] = {R(0), R(0), R(0), R(0)};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) fn[v] = v < NBX ? (jx ? (w.row(v) == j ? R(1) : R(0)) : nx_kt[v]) : R(0);
+    w_tn<NBX>(w, sx, fn, mk);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) r[v] = v < NBX ? (jx ? fn[v] : mk[v]) : R(0);
+  };
+  auto refactor_state = [&]() {  // the chain's entry and the cell after a terminal update: the factor on its own
+    R tmp[4], r[4], l3[4];
+    state_gain_rhs(r);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) tmp[v] = sx[v];
+    lx_ok = w_elim<NBX, 1, PL>(w, tmp, r, (R*)nullptr, l3);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) lx[v] = l3[v], lk[v] = r[v];
+  };
+  if constexpr (!LIN) refactor_state();
+
   for (int t = 0; t < T; ++t) {
     const WIO<R, S> out = w_fwd_cell<R, S>(a.fwd, C::E_FWD, B, t, b);
     const R alpha = nx_alpha, zt = c.z_per_cell ? nx_zt : kc.zg[j], pmu = nx_pmu;
@@ -504,10 +595,14 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
 
     // ---- 1. joint prior over (x, u) ---------------------------------------------------
     R mu0, s0[4];
+    R l0[4];  // sigma-point cells: chol(sig_0)^T, then the sigma-point directions of the updated joint
     if (ff) {  // feed-forward: independent action prior (i2c.py:355-360)
       mu0 = jx ? mx : pmu;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) s0[v] = (v < NBX) ? (jx ? sx[v] : R(0)) : (jx ? R(0) : pj[v]);
+      for (int v = 0; v < 4; ++v) {
+        if constexpr (LIN) s0[v] = (v < NBX) ? (jx ? sx[v] : R(0)) : (jx ? R(0) : pj[v]);
+        else l0[v] = (v < NBX) ? (jx ? lx[v] : R(0)) : (jx ? R(0) : pj[v]);  // (action block: factored below)
+      }
     } else {  // feedback: condition the previous controller on the new state message (i2c.py:361-387)
       // pdf ratio rho = exp(-delta^T (P_xx + sig_x)^-1 delta / 2): delta rides as column NX of the nx x nx matrix ITSELF (its tile
       // has 16 columns): the scaling and the rank-4 updates of the elimination treat that column like any other, so
@@ -528,38 +623,66 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
         rho = r_exp(R(-0.5) * maha);
       }
       // F^T = [I | Kt^T] (nx x 16), Kt = rho K:  sig_0 = F sig_x F^T with (P_uu - Kt P_xu) added to the action block
-      R ft[4], m1[4] = {R(0), R(0), R(0), R(0)};
+      R ft[4];
 #pragma unroll
       for (int v = 0; v < 4; ++v) ft[v] = v < NBX ? (jx ? (w.row(v) == j ? R(1) : R(0)) : rho * kt[v]) : R(0);
-      w_tn<NBX>(w, sx, ft, m1);  // sig_x F^T
       R kd = R(0);
 #pragma unroll
       for (int v = 0; v < NBX; ++v) kd += ft[v] * dr[v];
       kd = w_rowsum(w, kd);  // action lanes: Kt delta
       mu0 = jx ? mx : pmu + kd;
-      R m1p[4];
+      if constexpr (LIN) {
+        R m1[4] = {R(0), R(0), R(0), R(0)}, m1p[4];
+        w_tn<NBX>(w, sx, ft, m1);  // sig_x F^T
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          m1p[v] = (v < NBX && !jx) ? m1[v] - pj[v] : m1[v];
+          s0[v] = R(0);
+        }
+        w_tn<NBX>(w, ft, m1p, s0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          if (v < NBX) s0[v] = jx ? s0[v] : m1[v];  // state-action block: sig_x Kt^T itself
+          else s0[v] = jx ? s0[v] : s0[v] + pj[v];  // action block: P_uu - Kt P_xu + Kt sig_x Kt^T
+        }
+      } else {
+        // the Schur complement of the state block, P_uu - Kt P_xu (the action block of sig_0 without Kt sig_x Kt^T)
+        R pm[4], su[4] = {R(0), R(0), R(0), R(0)};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) pm[v] = (v < NBX && !jx) ? pj[v] : R(0);
+        w_tn<NBX>(w, ft, pm, su);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) l0[v] = (v < NBX) ? (jx ? lx[v] : rho * lk[v]) : (jx ? R(0) : pj[v] - su[v]);
+      }
+    }
+    if constexpr (!LIN) {  // chol of the action block: the trailing pivot(s) of the joint's factorisation, on their own
+      R sb[4], lu[4] = {R(0), R(0), R(0), R(0)}, mq[4], last = R(0);
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        m1p[v] = (v < NBX && !jx) ? m1[v] - pj[v] : m1[v];
-        s0[v] = R(0);
+        sb[v] = v < NBX ? R(0) : l0[v];
+        mq[v] = w.q == v ? R(1) : R(0);
       }
-      w_tn<NBX>(w, ft, m1p, s0);
+      w_elim_step<NBX, 4, 0, PL>(w, sb, (R*)nullptr, (R*)nullptr, lu, mq, &last);
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        if (v < NBX) s0[v] = jx ? s0[v] : m1[v];  // state-action block: sig_x Kt^T itself
-        else s0[v] = jx ? s0[v] : s0[v] + pj[v];  // action block: P_uu - Kt P_xu + Kt sig_x Kt^T
-      }
+      for (int v = NBX; v < 4; ++v) l0[v] = lu[v];
+      cell_bad = flag_stage(cell_bad, lx_ok && last > R(0), 1);
     }
     fetch_prior(t + 1 < T ? t + 1 : t);  // this cell's rows are consumed: the next cell's, a cell ahead
     if (a.prior_out) {
       const WIO<R, S> po = wio<R, S>(a.prior_out + (unsigned long)t * (D + sym(D)) * B, D + sym(D), rb, bo);
       po.st_if(q == 0, j, mu0);
+      if constexpr (!LIN) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) s0[v] = R(0);
+        w_tn<4>(w, l0, l0, s0);
+      }
 #pragma unroll
       for (int v = 0; v < 4; ++v) po.st_if(w.row(v) >= j, D + w_symidx(w.row(v), j), s0[v]);
     }
 
     // ---- 2. cost "observation" z = (x, u): measurement update (i2c.py:390-407) ----------
-    cell_bad = flag_stage(cell_bad, w_kalman<4, PL>(w, alpha, kc.xi, kc.qr, c.qr_diag != 0, zt, &mu0, s0), 2);
+    if constexpr (LIN) cell_bad = flag_stage(cell_bad, w_kalman<4, PL>(w, alpha, kc.xi, kc.qr, c.qr_diag != 0, zt, &mu0, s0), 2);
+    else cell_bad = flag_stage(cell_bad, w_kalman_sqrt<PL>(w, alpha, kc.qr, c.qr_diag != 0, zt, &mu0, l0, s0), 2);
     out.st_if(q == 0, j, mu0);
 #pragma unroll
     for (int v = 0; v < 4; ++v) out.st_if(w.row(v) >= j, D + w_symidx(w.row(v), j), s0[v]);
@@ -567,13 +690,7 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
     // ---- 3. dynamics push-through (i2c.py:415-421; Linearize: :321-341) ----------------------
     R sxy[4] = {R(0), R(0), R(0), R(0)};  // sig_xy^T (nx x 16)
     if constexpr (!LIN) {
-      R lt[4];
-      {
-        R tmp[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) tmp[v] = s0[v];
-        cell_bad = flag_stage(cell_bad, w_elim<4, 0, PL>(w, tmp, (R*)nullptr, (R*)nullptr, lt), 3);
-      }
+      const R* lt = l0;  // rows of chol(sig_xu1_f)^T (in reverse order): the factor came out of the update itself
       const auto Lt = w.mat();
       const auto mv = w.vec(2);
       w.sync();
@@ -694,19 +811,32 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
     // ---- smoother gain J = sig_xy sig_x3^-1 (i2c.py:423-425): J^T = W^T (W sig_xy^T), W = chol(sig_x3)^-1 ----
     {
       R tmp[4], w3[4], l3[4], jt[4] = {R(0), R(0), R(0), R(0)};
+      if constexpr (LIN) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        tmp[v] = sx[v];
-        w3[v] = (v < NBX && w.row(v) == j) ? R(1) : R(0);
+        for (int v = 0; v < 4; ++v) w3[v] = (v < NBX && w.row(v) == j) ? R(1) : R(0);
+      } else {
+        state_gain_rhs(w3);  // identity | sig_x3 K^T of the next cell (its rows are in flight since the top of this one)
       }
-      cell_bad = flag_stage(cell_bad, w_elim<NBX, 2, PL>(w, tmp, sxy, w3, l3), 4);
-      w_tn<NBX>(w, w3, sxy, jt);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) tmp[v] = sx[v];
+      const bool ok3 = w_elim<NBX, 2, PL>(w, tmp, sxy, w3, l3);
+      cell_bad = flag_stage(cell_bad, ok3, 4);
+      if constexpr (!LIN) {
+        lx_ok = ok3;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) lx[v] = l3[v], lk[v] = w3[v];
+      }
+      w_tn<NBX>(w, w3, sxy, jt);  // (rows >= nx of the product, from the action columns of w3, are not part of J)
 #pragma unroll
       for (int v = 0; v < NBX; ++v) out.st(O_J + j * NX + w.row(v), jt[v]);
     }
     // ---- 4. terminal cost observation on the flagged cell, after J (i2c.py:430-443) ----
-    if (!LIN && NZT > 0 && t == c.terminal_cell && c.has_Qf)  // (uniform: kernel arguments)
+    if (!LIN && NZT > 0 && t == c.terminal_cell && c.has_Qf) {  // (uniform: kernel arguments)
       cell_bad = flag_stage(cell_bad, w_kalman<NBX, PL>(w, alpha, kc.xiT, kc.qf, c.qf_diag != 0, kc.zgT[j], &mx, sx), 5);
+      if constexpr (!LIN) {
+        if (t + 1 < T) refactor_state();  // the state message changed after its factorisation
+      }
+    }
     fail = fold_cell_failure(fail, cell_bad, t);
     out.st_if(q == 0 && jx, O_MU3 + jxc, mx);
 #pragma unroll

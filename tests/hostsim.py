@@ -17,6 +17,20 @@ OUT = os.path.join(OUT_DIR, "libi2c_hostsim.so")
 
 
 def build(force=False):
+    """Rebuilds when a source is newer than the library. pytest-xdist workers arrive here together: an exclusive file lock makes
+    one of them build and the others wait and find the library up to date."""
+    import fcntl
+
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with open(os.path.join(OUT_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force):
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "i2c_hip.h")]
     newest = max(os.path.getmtime(s) for s in srcs)
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
