@@ -278,11 +278,14 @@ template <int K, int NB, typename R> I2C_FN void q_elim_scale_lt(const Quad<R>& 
   }
 }
 // ... and of every right-hand side.
+// R1ANTI: the first right-hand side (NC1 = NB) has zero blocks left of its anti-diagonal -- block (i, j) with j < NB - 1 - i --, as
+// the row-reversed transpose of a triangular factor has (q_kalman_sqrt); the elimination keeps that pattern and skips those blocks.
 // R2LOW: the second right-hand side starts as the identity (NC2 = NB): L^-1 I is block lower triangular, its blocks right of the
 // diagonal stay zero and are skipped
-template <int K, int NC1, int NC2, bool R2LOW = false, typename R> I2C_FN void q_elim_scale_rhs(const Quad<R>& q, const R aw, R* r1, R* r2) {
+template <int K, int NC1, int NC2, bool R2LOW = false, bool R1ANTI = false, typename R> I2C_FN void q_elim_scale_rhs(const Quad<R>& q, const R aw, R* r1, R* r2) {
 #pragma unroll
   for (int j = 0; j < NC1; ++j) {
+    if (R1ANTI && j < NC1 - 1 - K) continue;
     R x = R(0);
     q_mfma(q, aw, r1[K * NC1 + j], x);
     r1[K * NC1 + j] = x;
@@ -300,7 +303,7 @@ template <int K, int NB, typename R> I2C_FN void q_elim_next_pivot(const Quad<R>
   q_mfma(q, -lt[K * NB + K + 1], lt[K * NB + K + 1], s[(K + 1) * NB + K + 1]);
 }
 // eliminate block row K from everything below, except the next pivot block (q_elim_next_pivot)
-template <int K, int NB, int NC1, int NC2, bool R2LOW = false, typename R> I2C_FN void q_elim_below(const Quad<R>& q, R* s, R* r1, R* r2, const R* lt) {
+template <int K, int NB, int NC1, int NC2, bool R2LOW = false, bool R1ANTI = false, typename R> I2C_FN void q_elim_below(const Quad<R>& q, R* s, R* r1, R* r2, const R* lt) {
 #pragma unroll
   for (int i = K + 1; i < NB; ++i) {
     const R nl = -lt[K * NB + i];
@@ -310,7 +313,10 @@ template <int K, int NB, int NC1, int NC2, bool R2LOW = false, typename R> I2C_F
       q_mfma(q, nl, lt[K * NB + j], s[i * NB + j]);
     }
 #pragma unroll
-    for (int j = 0; j < NC1; ++j) q_mfma(q, nl, r1[K * NC1 + j], r1[i * NC1 + j]);
+    for (int j = 0; j < NC1; ++j) {
+      if (R1ANTI && j < NC1 - 1 - K) continue;
+      q_mfma(q, nl, r1[K * NC1 + j], r1[i * NC1 + j]);
+    }
 #pragma unroll
     for (int j = 0; j < NC2; ++j) {
       if (R2LOW && j > K) continue;
@@ -334,7 +340,7 @@ template <int NL, int NB, int K, typename R> I2C_FN void q_pivot_send(const Quad
   q_pivot_fetch<NL>(dg, d);
 }
 // d: pivot block K, fetched by the caller (the previous step, or q_elim)
-template <int K, int NB, int N, int NC1, int NC2, bool R2LOW = false, typename R>
+template <int K, int NB, int N, int NC1, int NC2, bool R2LOW = false, bool R1ANTI = false, typename R>
 I2C_FN void q_elim_step(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* last, R* d) {
   constexpr int NL = q_live_rows<N, K>();
   R aw, pl;
@@ -348,19 +354,20 @@ I2C_FN void q_elim_step(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* last, R*
     q_elim_next_pivot<K, NB>(q, s, lt);
     q_pivot_send<q_live_rows<N, K + 1>(), NB, K + 1>(q, s, Q_O_DG, dn);
     q_sched_fence();
-    q_elim_scale_rhs<K, NC1, NC2, R2LOW>(q, aw, r1, r2);
-    q_elim_below<K, NB, NC1, NC2, R2LOW>(q, s, r1, r2, lt);
+    q_elim_scale_rhs<K, NC1, NC2, R2LOW, R1ANTI>(q, aw, r1, r2);
+    q_elim_below<K, NB, NC1, NC2, R2LOW, R1ANTI>(q, s, r1, r2, lt);
     q_sched_fence();
-    q_elim_step<K + 1, NB, N, NC1, NC2, R2LOW>(q, s, r1, r2, lt, last, dn);
+    q_elim_step<K + 1, NB, N, NC1, NC2, R2LOW, R1ANTI>(q, s, r1, r2, lt, last, dn);
   } else {
-    q_elim_scale_rhs<K, NC1, NC2, R2LOW>(q, aw, r1, r2);
+    q_elim_scale_rhs<K, NC1, NC2, R2LOW, R1ANTI>(q, aw, r1, r2);
   }
 }
-template <int N, int NC1, int NC2, bool R2LOW = false, typename R> I2C_FN bool q_elim(const Quad<R>& q, R* s, R* r1, R* r2, R* lt) {
+template <int N, int NC1, int NC2, bool R2LOW = false, bool R1ANTI = false, typename R> I2C_FN bool q_elim(const Quad<R>& q, R* s, R* r1, R* r2, R* lt) {
   constexpr int NB = (N + 3) / 4;
+  static_assert(!R1ANTI || NC1 == NB, "R1ANTI: a square right-hand side");
   R last = R(0), d[10];
   q_pivot_send<q_live_rows<N, 0>(), NB, 0>(q, s, Q_O_DG, d);
-  q_elim_step<0, NB, N, NC1, NC2, R2LOW>(q, s, r1, r2, lt, &last, d);
+  q_elim_step<0, NB, N, NC1, NC2, R2LOW, R1ANTI>(q, s, r1, r2, lt, &last, d);
   return last > R(0);
 }
 // two eliminations of the same dimension in lockstep: (sa; ra1, ra2) -> lta and (sb; rb1) -> ltb
@@ -658,6 +665,106 @@ I2C_FN bool q_kalman_identity(const Quad<R>& q, const R alpha, const P xi_m, con
   return ok;
 }
 
+// The identity-observation update in square-root form (round 5; the mathematics in w_kalman_sqrt, i2c_wave.hpp): the prior arrives
+// as l0 = chol(s)^T (upper blocks), and with N^-1 = W / alpha
+//   s_new = L (I + L^T N^-1 L)^-1 L^T,   chol(s_new) = L U^-T   for   I + L^T N^-1 L = U U^T  (U upper triangular),
+// computed as the ordinary elimination of the index-reversed matrix M' = I + X^T N^-1 X, X = L J (J the exchange matrix), with the
+// right-hand side J L^T: its result Y = J chol(s_new)^T holds the rows of the new factor in reverse order. Index reversal in blocks:
+// block (I, P) of X is block (NB-1-P, I) of L^T transposed with its columns reversed, block (P, I) of J L^T the same block with its
+// rows reversed -- one matrix instruction each, with the 4 x 4 exchange matrix as the other operand. Out: z = the block rows of Y
+// in natural order (upper blocks; rows inside a block reversed: a set of sigma-point directions has no order), s = Y^T Y (upper
+// blocks), the mean as in q_kalman_identity. Saves the factorisation of s + N AND that of s_new: N / 4 + 1 pivot blocks (with the
+// caller's action block) instead of 2 N / 4. N a multiple of 4 (the reversal must not move padding to the front).
+template <int N, int QLD, typename R, class P>
+I2C_FN bool q_kalman_sqrt(const Quad<R>& q, const R alpha, const P w_m, const bool w_diag, const R* ztc, R* muc, const R* l0, R* z, R* s, const int kz = 0) {
+  static_assert(N % 4 == 0, "q_kalman_sqrt: whole blocks");
+  constexpr int NB = N / 4;
+  const R j4 = (q.r + q.c == 3) ? R(1) : R(0);
+  const R ia = r_rcp(alpha);
+  R x[NB * NB], rr[NB * NB], yw[NB * NB], m[NB * NB], ltm[NB * NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+      x[i * NB + p] = R(0);
+      rr[p * NB + i] = R(0);
+      if (p < NB - 1 - i) continue;  // block (NB-1-p, i) of L^T is below the diagonal
+      q_mfma(q, l0[(NB - 1 - p) * NB + i], j4, x[i * NB + p]);   // (L J)(i, p) = block^T J4
+      q_mfma(q, j4, l0[(NB - 1 - p) * NB + i], rr[p * NB + i]);  // (J L^T)(p, i) = J4 block
+    }
+  if (w_diag) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const R wi = w_m[(4 * i + q.r) * QLD + 4 * i + q.r + kz] * ia;
+#pragma unroll
+      for (int p = 0; p < NB; ++p) yw[i * NB + p] = wi * x[i * NB + p];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int p = 0; p < NB; ++p) {
+        R t = R(0);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          if (p < NB - 1 - k) continue;
+          q_mfma(q, q_ldc<QLD>(q, w_m, k, i, kz), x[k * NB + p], t);  // W symmetric: block (i, k) = block (k, i)^T
+        }
+        yw[i * NB + p] = t * ia;
+      }
+  }
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      m[a * NB + b] = (a == b && q.r == q.c) ? R(1) : R(0);
+      if (b < a) continue;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        if (a < NB - 1 - i) continue;
+        q_mfma(q, x[i * NB + a], yw[i * NB + b], m[a * NB + b]);
+      }
+    }
+  const bool ok = q_elim<N, NB, 0, false, true>(q, m, rr, (R*)nullptr, ltm);
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      s[a * NB + b] = R(0);
+      z[a * NB + b] = b >= a ? rr[(NB - 1 - a) * NB + b] : R(0);
+      if (b < a) continue;
+#pragma unroll
+      for (int p = 0; p < NB; ++p) {
+        if (a < NB - 1 - p) continue;
+        q_mfma(q, rr[p * NB + a], rr[p * NB + b], s[a * NB + b]);
+      }
+    }
+  // wr = W (zt - mu), row form
+  R wr[NB];
+  if (w_diag) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) wr[j] = q_tr(q, w_m[(4 * j + q.c) * QLD + 4 * j + q.c + kz] * (ztc[j] - muc[j]));
+  } else {
+    R rv[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rv[j] = q_tr(q, ztc[j] - muc[j]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      wr[i] = R(0);
+#pragma unroll
+      for (int k = 0; k < NB; ++k) q_mfma(q, q_ldc<QLD>(q, w_m, k, i, kz), rv[k], wr[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {  // (s wr)[i] = sum_k s[i][k] wr[k]: the A operand is the transpose of what is passed
+    R t = R(0);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) q_mfma(q, k <= i ? s[k * NB + i] : q_tr(q, s[i * NB + k]), wr[k], t);
+    muc[i] += q_tr(q, t) * ia;
+  }
+  return ok;
+}
+
 // One cell block of a per-cell buffer for the lanes of a wave. An element index is split into a per-lane part and a part that is
 // the same for every lane (a compile-time constant after unrolling): e = lane_e + k.
 //   TM (trajectory-major [B][E], the wave-capable models): byte offset = (lane_e * sizeof(S) + b E sizeof(S)) + k * sizeof(S) -- ONE
@@ -709,6 +816,9 @@ template <class M> constexpr bool quad_general_exists() {
   return !QG<M>::WIDE && D < QG<M>::PR && !(st_identity<ObsStruct<M>, M::NZ>() && M::NZ == D) &&
          !(M::NZT > 0 && st_identity<TermStruct<M>, NT>() && NT == M::NX);
 }
+#ifndef I2C_QUAD_SQRT_ID
+#define I2C_QUAD_SQRT_ID 1  // (A/B knob: 0 = the covariance form of the identity-observation update, q_kalman_identity)
+#endif
 template <class M, typename R, typename S, bool GENERAL = false, class KC>
 I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const FwdArgs<R, S>& a, const int b, const bool live, const Quad<R>& qw) {
   using C = Consts<M, R>;
@@ -720,6 +830,8 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
   static_assert(D <= 16 && NZ <= 16 && NZT <= 16, "quad kernels: d <= 16");
   constexpr bool OBS_ID = st_identity<ObsStruct<M>, NZ>() && NZ == D;
   constexpr bool TERM_ID = NZT > 0 && st_identity<TermStruct<M>, NT>() && NT == NX;
+  // identity observation of a joint made of whole blocks, the actions in a block of their own: the update works on the factor
+  constexpr bool SQRT_ID = I2C_QUAD_SQRT_ID && OBS_ID && D % 4 == 0 && NX % 4 == 0;
   // the last observation output as a scalar pre-elimination (see stage 2): a pass-through of a coordinate of the joint's last block
   // that would otherwise be a block row of its own
 #ifndef I2C_QUAD_LASTLIN
@@ -975,19 +1087,21 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
         const R pxu = (xrow(k) < NX ? m_ucol : R(0)) * pj[k * NBD + JU];
         q_mfma(q, -ktm[k], pxu, suu);
       }
-      // sig_0 = Lt0x^T Lt0x + S_u|x
+      // sig_0 = Lt0x^T Lt0x + S_u|x  (SQRT_ID: the update works on the factor; only a caller who asked for the prior joint gets it)
 #pragma unroll
       for (int k = 0; k < NBD * NBD; ++k) s0[k] = R(0);
+      if (!SQRT_ID || a.prior_out) {
 #pragma unroll
-      for (int i = 0; i < NBD; ++i)
+        for (int i = 0; i < NBD; ++i)
 #pragma unroll
-        for (int j = i; j < NBD; ++j)
+          for (int j = i; j < NBD; ++j)
 #pragma unroll
-          for (int k = 0; k < NBX; ++k) {
-            if (k > i && i != JU) continue;  // Lt0x[k][i] = 0 below the diagonal, except in the action columns
-            q_mfma(q, lx[k * NBD + i], lx[k * NBD + j], s0[i * NBD + j]);
-          }
-      s0[JU * NBD + JU] += suu;
+            for (int k = 0; k < NBX; ++k) {
+              if (k > i && i != JU) continue;  // Lt0x[k][i] = 0 below the diagonal, except in the action columns
+              q_mfma(q, lx[k * NBD + i], lx[k * NBD + j], s0[i * NBD + j]);
+            }
+        s0[JU * NBD + JU] += suu;
+      }
       // mean: the state message, and the action prior moved by Kt delta
 #pragma unroll
       for (int j = 0; j < NBD; ++j) {
@@ -1014,6 +1128,15 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
             lt0[i * NBD + j] = (i == JU && j == JU) ? lv + m_uu * lu : lv;
           }
       }
+      if constexpr (SQRT_ID) {
+        // chol(sig_0)^T = [[Lt3, G], [0, chol(S_u|x)^T]]: the action block is a pivot block of its own
+        R su1[1] = {suu}, lu1[1] = {R(0)};
+        cell_bad = flag_stage(cell_bad, q_elim<NU, 0, 0>(q, su1, (R*)nullptr, (R*)nullptr, lu1), 1);
+#pragma unroll
+        for (int i = 0; i < NBD; ++i)
+#pragma unroll
+          for (int j = 0; j < NBD; ++j) lt0[i * NBD + j] = j < i ? R(0) : (i < NBX ? lx[(i < NBX ? i : 0) * NBD + j] : lu1[0]);
+      }
     }
     I2C_QSTAMP(0);  // factorisation pair + joint prior
     if (PREFETCH) fetch_prior(t + 1 < T ? t + 1 : t);  // this cell's rows are consumed: the next cell's, a cell ahead
@@ -1028,7 +1151,12 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
     }
 
     // ---- 2. cost "observation": measurement update on z (i2c.py:390-407) ----------------
-    if constexpr (OBS_ID) {
+    if constexpr (SQRT_ID) {
+      R zf[NBD * NBD];
+      cell_bad = flag_stage(cell_bad, q_kalman_sqrt<D, QLD>(q, alpha, kc.qr, c.qr_diag != 0, zt, mu0, lt0, zf, s0, kz), 2);
+#pragma unroll
+      for (int k = 0; k < NBD * NBD; ++k) lt0[k] = zf[k];
+    } else if constexpr (OBS_ID) {
       R sf_[NBD * NBD];  // full blocks for the identity form
 #pragma unroll
       for (int i = 0; i < NBD; ++i)
@@ -1127,7 +1255,10 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
     // ---- 3. dynamics push-through (i2c.py:415-421) ----------------------------------------
     {
       R lt[NBD * NBD];
-      {
+      if constexpr (SQRT_ID) {  // the factor of the updated joint came out of the update
+#pragma unroll
+        for (int k = 0; k < NBD * NBD; ++k) lt[k] = lt0[k];
+      } else {
         R tmp[NBD * NBD];
 #pragma unroll
         for (int k = 0; k < NBD * NBD; ++k) tmp[k] = s0[k];

@@ -27,6 +27,14 @@
 
 namespace i2c {
 
+// Diagnostic build only (-DI2C_WAVE_STAMPS, never in the shipped library): s_memtime stamps at the phase boundaries of the forward
+// cell, printed by trajectory 0 (tools/build_variant_tu.py).
+#if defined(I2C_WAVE_STAMPS) && !defined(I2C_HOST_SIM)
+#define I2C_WSTAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += now_ - stamp_last; stamp_last = now_; } while (0)
+#else
+#define I2C_WSTAMP(i) do { } while (0)
+#endif
+
 constexpr int WLD = 17;  // row stride (elements) of a 16 x 16 block in LDS: column reads of 16 lanes hit 16 different bank pairs
 
 // LDS region of one wave (elements)
@@ -580,6 +588,9 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
   };
   if constexpr (!LIN) refactor_state();
 
+#if defined(I2C_WAVE_STAMPS) && !defined(I2C_HOST_SIM)
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#endif
   for (int t = 0; t < T; ++t) {
     const WIO<R, S> out = w_fwd_cell<R, S>(a.fwd, C::E_FWD, B, t, b);
     const R alpha = nx_alpha, zt = c.z_per_cell ? nx_zt : kc.zg[j], pmu = nx_pmu;
@@ -655,6 +666,7 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
         for (int v = 0; v < 4; ++v) l0[v] = (v < NBX) ? (jx ? lx[v] : rho * lk[v]) : (jx ? R(0) : pj[v] - su[v]);
       }
     }
+    I2C_WSTAMP(0);  // pdf ratio + prior mean / factor rows
     if constexpr (!LIN) {  // chol of the action block: the trailing pivot(s) of the joint's factorisation, on their own
       R sb[4], lu[4] = {R(0), R(0), R(0), R(0)}, mq[4], last = R(0);
 #pragma unroll
@@ -667,6 +679,7 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
       for (int v = NBX; v < 4; ++v) l0[v] = lu[v];
       cell_bad = flag_stage(cell_bad, lx_ok && last > R(0), 1);
     }
+    I2C_WSTAMP(1);  // action-block pivot
     fetch_prior(t + 1 < T ? t + 1 : t);  // this cell's rows are consumed: the next cell's, a cell ahead
     if (a.prior_out) {
       const WIO<R, S> po = wio<R, S>(a.prior_out + (unsigned long)t * (D + sym(D)) * B, D + sym(D), rb, bo);
@@ -683,6 +696,7 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
     // ---- 2. cost "observation" z = (x, u): measurement update (i2c.py:390-407) ----------
     if constexpr (LIN) cell_bad = flag_stage(cell_bad, w_kalman<4, PL>(w, alpha, kc.xi, kc.qr, c.qr_diag != 0, zt, &mu0, s0), 2);
     else cell_bad = flag_stage(cell_bad, w_kalman_sqrt<PL>(w, alpha, kc.qr, c.qr_diag != 0, zt, &mu0, l0, s0), 2);
+    I2C_WSTAMP(2);  // cost observation update
     out.st_if(q == 0, j, mu0);
 #pragma unroll
     for (int v = 0; v < 4; ++v) out.st_if(w.row(v) >= j, D + w_symidx(w.row(v), j), s0[v]);
@@ -718,6 +732,7 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
         }
       }
       w.sync();
+      I2C_WSTAMP(3);  // stores + dynamics at the sigma points
       // a_p = (y+ - y0) + (y- - y0), d_p = y+ - y-, in the accumulator layout (row = point pair, column = output)
       R am[4], dm[4], y0;
       {
@@ -808,6 +823,7 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
         sxy[v] = v < NBX ? sxy[v] : R(0);
       }
     }
+    I2C_WSTAMP(4);  // dynamics moments
     // ---- smoother gain J = sig_xy sig_x3^-1 (i2c.py:423-425): J^T = W^T (W sig_xy^T), W = chol(sig_x3)^-1 ----
     {
       R tmp[4], w3[4], l3[4], jt[4] = {R(0), R(0), R(0), R(0)};
@@ -841,7 +857,13 @@ I2C_HD inline void forward_wave_body(const Consts<M, R>& c, const KC& kc, const 
     out.st_if(q == 0 && jx, O_MU3 + jxc, mx);
 #pragma unroll
     for (int v = 0; v < NBX; ++v) out.st_if(jx && w.row(v) >= j, O_S3 + w_symidx(w.row(v), jxc), sx[v]);
+    I2C_WSTAMP(5);  // smoother gain + factor of the state message, terminal update, stores
   }
+#if defined(I2C_WAVE_STAMPS) && !defined(I2C_HOST_SIM)
+  if (b == 0 && w.l == 0)
+    printf("wave forward, clocks per cell: pdf ratio + prior %llu | action pivot %llu | cost update %llu | stores + dynamics points %llu | moments %llu | gain + state factor %llu\n",
+           stamp_acc[0] / T, stamp_acc[1] / T, stamp_acc[2] / T, stamp_acc[3] / T, stamp_acc[4] / T, stamp_acc[5] / T);
+#endif
   if (w.l == 0 && fail != 0 && a.status[b] == 0) a.status[b] = fail;
 }
 
