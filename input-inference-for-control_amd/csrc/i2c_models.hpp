@@ -415,14 +415,15 @@ struct Quadrotor12 {
   static constexpr bool GROUP_FORWARD_AUTO = false;
   static constexpr bool WAVE = true;   // one-wavefront-per-trajectory kernels (i2c_wave.hpp): d = 16 models only
   static constexpr bool QUAD = true;   // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp), d = 16 form
-  // the quad kernel is the DEFAULT forward sweep from 2048 trajectories up (below, every wave kernel wave has a SIMD of its own and
-  // the shorter dependent chain of one trajectory per wave wins: B = 1024: 0.34 against 0.67 ms; B = 2048: 0.59 / 0.51; 4096: 1.10 /
-  // 0.59; 8192: 2.01 / 0.91; 32768: 7.85 / 3.17 -- profiles/r4_quad12_quad_vs_wave.txt)
+  // the quad kernel is the DEFAULT forward sweep as soon as wave-kernel waves would share a SIMD, i.e. above 1024 trajectories
+  // (up to there every wave has a SIMD of its own and the shorter dependent chain of one trajectory per wave wins; round 5, with
+  // the square-root update in both forms: B = 1024: wave 0.303 against quad 0.408 ms; 1152: 0.453 / 0.412; 1536: 0.469 / 0.419;
+  // 2048: 0.502 / 0.427; 4096: 0.948 / 0.515 -- profiles/r5_quad12_wave_quad_crossover.txt)
   static constexpr int QUAD_FORWARD_MAX_B = 1 << 30;
-  static constexpr int QUAD_FORWARD_MIN_B = 2048;
-  // ... and the DEFAULT backward sweep from 4096 trajectories up (the fused walk of four trajectories per wavefront against one:
-  // B = 2048: 0.245 against 0.168 ms; 4096: 0.297 / 0.310; 8192: 0.506 / 0.566; 32768: 1.90 / 2.15)
-  static constexpr int QUAD_BACKWARD_MIN_B = 4096;
+  static constexpr int QUAD_FORWARD_MIN_B = 1025;
+  // ... and the DEFAULT backward sweep above 2048 trajectories (the fused walk of four trajectories per wavefront against one:
+  // B = 1536: 0.173 against 0.156 ms; 2048: 0.175 / 0.161; 3072: 0.189 / 0.256; 4096: 0.214 / 0.315)
+  static constexpr int QUAD_BACKWARD_MIN_B = 2049;
   I2C_HD static constexpr int ang(int a) { return 3 + a; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }

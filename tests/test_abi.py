@@ -111,7 +111,7 @@ def test_backward_schedule_rule():
     # group kernels: one schedule
     assert f(3, 4096, 300, group_lanes=16) == N.BWD_FUSED and f(0, 4096, 200, N.BWD_CHUNKED, group_lanes=4) == N.BWD_FUSED
     assert f(0, 4096, 200, group_lanes=8) == -2               # not this model's group width
-    # the 12-state quadrotor (trajectory-major posterior): wave kernels -> fused, two-pass on request; quad backward from 4096 up;
+    # the 12-state quadrotor (trajectory-major posterior): wave kernels -> fused, two-pass on request; quad forward above 1024, quad backward above 2048 trajectories;
     # Linearize keeps the wave form; group kernels when asked for
     Q12 = 7
     assert f(Q12, 1024, 50, post_layout=1) == N.BWD_FUSED and f(Q12, 1024, 50, N.BWD_CHUNKED, post_layout=1) == N.BWD_FUSED

@@ -169,8 +169,8 @@ def test_mpc_replay_full_horizon_batched_gpu(name, B, fam):
     """BASELINE config 4's shapes (B = 8192: the whole config on one GPU; 1024: one GPU's share of it), against the reference."""
     pol = _replay_batched(name, None, "cuda", 1e-6, B)
     assert pol.engine.forward_family == fam
-    if name == "mpc_quad12_fb_H50":  # (the 12-state model's backward sweep: quad from 4096 trajectories up, wave below)
-        assert pol.engine.backward_family == ("quad" if B >= 4096 else "wave")
+    if name == "mpc_quad12_fb_H50":  # (the 12-state model's backward sweep: quad above 2048 trajectories, wave up to there)
+        assert pol.engine.backward_family == ("quad" if B > 2048 else "wave")
 
 
 # mpc_quad12_fb above runs the 12-state quadrotor's default, the wave kernels; the same replay on its group kernels
