@@ -170,8 +170,8 @@ typedef struct I2cProblem {
   int32_t gh_degree;       /* I2C_INF_GAUSS_HERMITE: 1 <= degree <= I2C_MAX_GH_DEGREE                               */
   int32_t group_lanes;     /* which kernel family serves a sweep -- resolved in ONE place, reported by i2c_kernel_family():
                               0: the model's default per sweep and batch size (one lane per trajectory; the quad forward kernel
-                              of the d >= 5 models inside their batch windows; for the d = 16 model the wave kernels below 2048
-                              trajectories, the quad forward sweep from 2048 and the quad backward sweep from 4096 up; the
+                              of the d >= 5 models inside their batch windows; for the d = 16 model the wave kernels up to 1024
+                              trajectories, the quad forward sweep above 1024 and the quad backward sweep above 2048; the
                               group kernels for what those forms do not cover);
                               64: the matrix-instruction family: the wave kernels where they exist (I2cDims.wave: one wavefront per
                               trajectory, forward and backward sweeps), the quad forward kernel otherwise (I2cDims.quad);

@@ -830,8 +830,8 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
   static_assert(D <= 16 && NZ <= 16 && NZT <= 16, "quad kernels: d <= 16");
   constexpr bool OBS_ID = st_identity<ObsStruct<M>, NZ>() && NZ == D;
   constexpr bool TERM_ID = NZT > 0 && st_identity<TermStruct<M>, NT>() && NT == NX;
-  // identity observation of a joint made of whole blocks, the actions in a block of their own: the update works on the factor
-  constexpr bool SQRT_ID = I2C_QUAD_SQRT_ID && OBS_ID && D % 4 == 0 && NX % 4 == 0;
+  // identity observation of a joint made of whole blocks (12-state and planar quadrotor): the update works on the factor
+  constexpr bool SQRT_ID = I2C_QUAD_SQRT_ID && OBS_ID && D % 4 == 0;
   // the last observation output as a scalar pre-elimination (see stage 2): a pass-through of a coordinate of the joint's last block
   // that would otherwise be a block row of its own
 #ifndef I2C_QUAD_LASTLIN
@@ -1129,13 +1129,17 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
           }
       }
       if constexpr (SQRT_ID) {
-        // chol(sig_0)^T = [[Lt3, G], [0, chol(S_u|x)^T]]: the action block is a pivot block of its own
-        R su1[1] = {suu}, lu1[1] = {R(0)};
-        cell_bad = flag_stage(cell_bad, q_elim<NU, 0, 0>(q, su1, (R*)nullptr, (R*)nullptr, lu1), 1);
+        // chol(sig_0)^T = [[Lt3, G], [0, chol(S_u|x)^T]]: the action entries of block (JU, JU) are a pivot block of their own (the
+        // state rows that share the block with them -- planar quadrotor: two -- ride along as identity rows)
+        R su1[1] = {suu + ((r == cc && (cc < CU || cc >= CU + NU)) ? R(1) : R(0))}, lu1[1] = {R(0)};
+        cell_bad = flag_stage(cell_bad, q_elim<4, 0, 0>(q, su1, (R*)nullptr, (R*)nullptr, lu1), 1);
 #pragma unroll
         for (int i = 0; i < NBD; ++i)
 #pragma unroll
-          for (int j = 0; j < NBD; ++j) lt0[i * NBD + j] = j < i ? R(0) : (i < NBX ? lx[(i < NBX ? i : 0) * NBD + j] : lu1[0]);
+          for (int j = 0; j < NBD; ++j) {
+            const R lv = (i < NBX && j >= i) ? lx[(i < NBX ? i : 0) * NBD + j] : R(0);
+            lt0[i * NBD + j] = (i == JU && j == JU) ? lv + m_uu * lu1[0] : lv;
+          }
       }
     }
     I2C_QSTAMP(0);  // factorisation pair + joint prior

@@ -79,8 +79,8 @@ if __name__ == "__main__":
                             continue
                         if grp == 64 and (dt != torch.float64 or m != modes[0]):
                             continue  # (64: the wave kernels of the 12-state quadrotor, the quad forward kernel of the d <= 8 models)
-                        if grp == 0 and n == "Quadrotor12" and 64 in groups and B < 2048:
-                            continue  # below 2048 trajectories the default IS the wave family
+                        if grp == 0 and n == "Quadrotor12" and 64 in groups and B <= 1024:
+                            continue  # up to 1024 trajectories the default IS the wave family
                         if grp == -1 and n == "Quadrotor12":
                             grp = 0
                         run(n, B, dt, mode=m, group=grp)
