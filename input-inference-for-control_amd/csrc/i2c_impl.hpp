@@ -23,7 +23,16 @@ namespace i2c {
 
 // One wavefront per workgroup for the sequential sweeps: at B = 4096 that is 64 workgroups on
 // 64 different CUs, each wave with a CU's issue ports, L1 and scalar cache to itself.
-constexpr int SWEEP_BLOCK = 64;
+constexpr int SWEEP_BLOCK = 64;   // a wavefront: workgroup of the group kernels and of k_reduce
+// Workgroup of the one-lane-per-trajectory kernels: ONE wavefront. (Round 5 measured four -- the hardware deals the waves of one
+// workgroup onto the four SIMDs of its CU, while single-wave workgroups may double up on a SIMD, see quad_waves_per_block below --
+// and kept one: these kernels move a 512-byte segment of a different row with every memory instruction, and four waves behind ONE
+// CU's memory pipeline cost more than a doubled SIMD: pendulum B = 16384 backward 0.19 -> 0.28 ms, planar quadrotor B = 1024
+// backward 0.071 -> 0.100, covariance-control iteration 0.18 -> 0.28; no shape got faster. -DI2C_LANE_BLOCK=256 rebuilds that.)
+#ifndef I2C_LANE_BLOCK
+#define I2C_LANE_BLOCK 64
+#endif
+constexpr int LANE_BLOCK = I2C_LANE_BLOCK;
 constexpr int CELL_BLOCK = 256;
 
 // ---- the ONE place that knows how a per-lane body runs ---------------------------------------------------------------
@@ -56,8 +65,8 @@ static int copy_bytes(void* dst, const void* src, size_t n, void*) {
 static int sweep_lanes() {
   static int v = [] {
     const char* e = getenv("I2C_SWEEP_LANES");
-    const int n = e ? atoi(e) : SWEEP_BLOCK;
-    return (n >= 1 && n <= SWEEP_BLOCK) ? n : SWEEP_BLOCK;
+    const int n = e ? atoi(e) : LANE_BLOCK;
+    return (n >= 1 && n <= LANE_BLOCK) ? n : LANE_BLOCK;
   }();
   return v;
 }
@@ -72,25 +81,25 @@ static int copy_bytes(void* dst, const void* src, size_t n, void* stream) {
 #endif
 
 template <class M, typename R, bool LEAN, bool GRID = false, typename S = R>
-I2C_KERNEL(SWEEP_BLOCK) k_forward(I2C_LANE_PARAMS const Consts<M, R> c, const FwdArgs<R, S> a, const int block) {
+I2C_KERNEL(LANE_BLOCK) k_forward(I2C_LANE_PARAMS const Consts<M, R> c, const FwdArgs<R, S> a, const int block) {
   const long b = I2C_LANE_X(block);  // `block` = active lanes per wave (I2C_SWEEP_LANES experiment), normally 64
   if (b < c.B) forward_sweep_body<M, R, LEAN, GRID, S>(c, a, (int)b);
 }
-template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_forward_lin(I2C_LANE_PARAMS const Consts<M, R> c, const FwdArgs<R> a) {
-  const long b = I2C_LANE_X(SWEEP_BLOCK);
+template <class M, typename R> I2C_KERNEL(LANE_BLOCK) k_forward_lin(I2C_LANE_PARAMS const Consts<M, R> c, const FwdArgs<R> a) {
+  const long b = I2C_LANE_X(LANE_BLOCK);
   if (b < c.B) forward_lin_body<M, R>(c, a, (int)b);
 }
-template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_bwd_lin(I2C_LANE_PARAMS const Consts<M, R> c, const CellArgs<R> a) {
-  const long b = I2C_LANE_X(SWEEP_BLOCK);
+template <class M, typename R> I2C_KERNEL(LANE_BLOCK) k_bwd_lin(I2C_LANE_PARAMS const Consts<M, R> c, const CellArgs<R> a) {
+  const long b = I2C_LANE_X(LANE_BLOCK);
   if (b < c.B) backward_lin_body<M, R>(c, a, (int)b);
 }
-template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_riccati(I2C_LANE_PARAMS const Consts<M, R> c, const RiccatiArgs<R> a) {
-  const long b = I2C_LANE_X(SWEEP_BLOCK);
+template <class M, typename R> I2C_KERNEL(LANE_BLOCK) k_riccati(I2C_LANE_PARAMS const Consts<M, R> c, const RiccatiArgs<R> a) {
+  const long b = I2C_LANE_X(LANE_BLOCK);
   if (b < c.B) riccati_body<M, R>(c, a, (int)b);
 }
 template <class M, typename R, typename S = R>
-I2C_KERNEL(SWEEP_BLOCK) k_scan(I2C_LANE_PARAMS const Consts<M, R> c, const ScanArgs<R, S> a) {
-  const long b = I2C_LANE_X(SWEEP_BLOCK);
+I2C_KERNEL(LANE_BLOCK) k_scan(I2C_LANE_PARAMS const Consts<M, R> c, const ScanArgs<R, S> a) {
+  const long b = I2C_LANE_X(LANE_BLOCK);
   if (b < c.B) backward_scan_body<M, R, S>(c, a, (int)b);
 }
 template <class M, typename R, typename S = R>
@@ -99,48 +108,48 @@ I2C_KERNEL(CELL_BLOCK) k_cell(I2C_LANE_PARAMS const Consts<M, R> c, const CellAr
   if (b < c.B) backward_cell_body<M, R, S>(c, a, I2C_LANE_Y, (int)b);
 }
 template <class M, typename R, bool GRID = false, typename S = R, bool LEANW = false>
-I2C_KERNEL(SWEEP_BLOCK) k_bwd_fused(I2C_LANE_PARAMS const Consts<M, R> c, const CellArgs<R, S> a) {
-  const long b = I2C_LANE_X(SWEEP_BLOCK);
+I2C_KERNEL(LANE_BLOCK) k_bwd_fused(I2C_LANE_PARAMS const Consts<M, R> c, const CellArgs<R, S> a) {
+  const long b = I2C_LANE_X(LANE_BLOCK);
   if (b < c.B) backward_fused_body<M, R, GRID, S, LEANW>(c, a, (int)b);
 }
 template <class M, typename R, typename S = R>
-I2C_KERNEL(SWEEP_BLOCK) k_chunk_compose(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, S> a) {
-  const long b = I2C_LANE_X(SWEEP_BLOCK);
+I2C_KERNEL(LANE_BLOCK) k_chunk_compose(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, S> a) {
+  const long b = I2C_LANE_X(LANE_BLOCK);
   if (b < c.B) chunk_compose_body<M, R, S>(c, a, I2C_LANE_Y, (int)b);
 }
 template <class M, typename R, typename S = R, bool GRID = false>
-I2C_KERNEL(SWEEP_BLOCK) k_chunk_stitch(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, S> a) {
-  const long b = I2C_LANE_X(SWEEP_BLOCK);
+I2C_KERNEL(LANE_BLOCK) k_chunk_stitch(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, S> a) {
+  const long b = I2C_LANE_X(LANE_BLOCK);
   if (b < c.B) chunk_stitch_body<M, R, S, GRID>(c, a, (int)b);
 }
 #ifndef I2C_WALK_LEAN
 #define I2C_WALK_LEAN 1
 #endif
 template <class M, typename R, typename S = R, bool LEANW = false, bool GRID = false>
-I2C_KERNEL(SWEEP_BLOCK) k_chunk_walk(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, S> a) {
-  const long b = I2C_LANE_X(SWEEP_BLOCK);
+I2C_KERNEL(LANE_BLOCK) k_chunk_walk(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, S> a) {
+  const long b = I2C_LANE_X(LANE_BLOCK);
   if (b < c.B) chunk_walk_body<M, R, S, LEANW, GRID>(c, a, I2C_LANE_Y, (int)b);
 }
-template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_chunk_stitch_lin(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, R> a) {
-  const long b = I2C_LANE_X(SWEEP_BLOCK);
+template <class M, typename R> I2C_KERNEL(LANE_BLOCK) k_chunk_stitch_lin(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, R> a) {
+  const long b = I2C_LANE_X(LANE_BLOCK);
   if (b < c.B) chunk_stitch_lin_body<M, R>(c, a, (int)b);
 }
-template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_chunk_walk_lin(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, R> a) {
-  const long b = I2C_LANE_X(SWEEP_BLOCK);
+template <class M, typename R> I2C_KERNEL(LANE_BLOCK) k_chunk_walk_lin(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, R> a) {
+  const long b = I2C_LANE_X(LANE_BLOCK);
   if (b < c.B) chunk_walk_lin_body<M, R>(c, a, I2C_LANE_Y, (int)b);
 }
 template <class M, typename R>
-I2C_KERNEL(SWEEP_BLOCK) k_chunk_reduce_lin(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, R> a, const MstepArgs<R> ms) {
-  const long b = I2C_LANE_X(SWEEP_BLOCK);
+I2C_KERNEL(LANE_BLOCK) k_chunk_reduce_lin(I2C_LANE_PARAMS const Consts<M, R> c, const ChunkArgs<R, R> a, const MstepArgs<R> ms) {
+  const long b = I2C_LANE_X(LANE_BLOCK);
   if (b < c.B) chunk_reduce_lin_body<M, R>(c, a, ms, (int)b);
 }
-template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_mstep(I2C_LANE_PARAMS const Consts<M, R> c, const MstepArgs<R> a) {
-  const long b = I2C_LANE_X(SWEEP_BLOCK);
+template <class M, typename R> I2C_KERNEL(LANE_BLOCK) k_mstep(I2C_LANE_PARAMS const Consts<M, R> c, const MstepArgs<R> a) {
+  const long b = I2C_LANE_X(LANE_BLOCK);
   if (b < c.B) mstep_body<M, R>(c, a, (int)b);
 }
 template <class M, typename R, bool GRID = false>
-I2C_KERNEL(SWEEP_BLOCK) k_propagate(I2C_LANE_PARAMS const Consts<M, R> c, const PropArgs<R> a) {
-  const long b = I2C_LANE_X(SWEEP_BLOCK);
+I2C_KERNEL(LANE_BLOCK) k_propagate(I2C_LANE_PARAMS const Consts<M, R> c, const PropArgs<R> a) {
+  const long b = I2C_LANE_X(LANE_BLOCK);
   if (b < c.B) propagate_body<M, R, GRID>(c, a, (int)b);
 }
 // The forward sweep of one EM iteration and the closed-loop propagation of the PREVIOUS one in ONE launch (grid row 0 / row 1).
@@ -149,8 +158,8 @@ I2C_KERNEL(SWEEP_BLOCK) k_propagate(I2C_LANE_PARAMS const Consts<M, R> c, const 
 // deals the 256 workgroups onto 256 different CUs and they are one. (Two STREAMS do not do this: measured, the two kernels' waves
 // land on the same SIMDs and the propagation takes 165 instead of 95 us -- profiles/r5_covctrl_overlap.txt.)
 template <class M, typename R, bool LEAN>
-I2C_KERNEL(SWEEP_BLOCK) k_forward_propagate(I2C_LANE_PARAMS const Consts<M, R> c, const FwdArgs<R, R> af, const PropArgs<R> ap) {
-  const long b = I2C_LANE_X(SWEEP_BLOCK);
+I2C_KERNEL(LANE_BLOCK) k_forward_propagate(I2C_LANE_PARAMS const Consts<M, R> c, const FwdArgs<R, R> af, const PropArgs<R> ap) {
+  const long b = I2C_LANE_X(LANE_BLOCK);
   if (b >= c.B) return;
   if (I2C_LANE_Y == 0) forward_sweep_body<M, R, LEAN, false, R>(c, af, (int)b);
   else propagate_body<M, R, false>(c, ap, (int)b);
@@ -159,8 +168,8 @@ template <class M, typename R> struct ZetaArg {
   R v[sym(M::NY)];
 };
 template <class M, typename R>
-I2C_KERNEL(SWEEP_BLOCK) k_ckf(I2C_LANE_PARAMS const Consts<M, R> c, const ZetaArg<M, R> z, const CkfArgs<R> a) {
-  const long b = I2C_LANE_X(SWEEP_BLOCK);
+I2C_KERNEL(LANE_BLOCK) k_ckf(I2C_LANE_PARAMS const Consts<M, R> c, const ZetaArg<M, R> z, const CkfArgs<R> a) {
+  const long b = I2C_LANE_X(LANE_BLOCK);
   if (b < c.B) ckf_filter_body<M, R>(c, z.v, a, (int)b);
 }
 template <class M, typename R> I2C_KERNEL(CELL_BLOCK) k_mpc_shift(I2C_LANE_PARAMS const Consts<M, R> c, const ShiftArgs<R> a) {
@@ -173,8 +182,8 @@ template <class M> I2C_KERNEL(CELL_BLOCK) k_to_feedback(I2C_LANE_PARAMS uint8_t*
   const long i = I2C_LANE_X(CELL_BLOCK);
   if (i < n) ff[(t0 + (int)i) % T] = 0;
 }
-template <class M, typename R> I2C_KERNEL(SWEEP_BLOCK) k_rollout(I2C_LANE_PARAMS const Consts<M, R> c, const RolloutArgs<R> a) {
-  const long n = I2C_LANE_X(SWEEP_BLOCK);
+template <class M, typename R> I2C_KERNEL(LANE_BLOCK) k_rollout(I2C_LANE_PARAMS const Consts<M, R> c, const RolloutArgs<R> a) {
+  const long n = I2C_LANE_X(LANE_BLOCK);
   if (n < (long)a.n_rollouts * c.B) rollout_body<M, R>(c, a, (int)n);
 }
 
@@ -350,8 +359,18 @@ static int launch_wave_v(const Consts<M, R>& c, const A& a, void* stream) {
 }
 #endif
 
-// ---- quad kernels (i2c_quad.hpp): four trajectories per wavefront; one wavefront per workgroup (d <= 8), four (d = 16) ---------
-template <class M> constexpr int quad_waves_per_block() { return QG<M>::WIDE ? 4 : 1; }
+// ---- quad kernels (i2c_quad.hpp): four trajectories per wavefront, four wavefronts per workgroup ------------------------------
+// Workgroup of the quad kernels: FOUR wavefronts for every model (round 5; d <= 8 had one). With single-wave workgroups the
+// dispatcher dealt 1024 waves as four per CU, but inside a CU a wave could land on a SIMD that already had one while another
+// stayed empty (s_getreg HW_ID of every wave, profiles/r5_wave_placement.txt: 28 - 35 of 1024 SIMDs doubled) -- depending on the
+// batch size and on what ran before, the SAME forward sweep took 1.27 or 1.87 ms (double cartpole B = 4096 / 4032; cartpole
+// 1.39 / 2.02): the two-waves-per-SIMD issue rate for the whole launch, which is as slow as its slowest wave. The waves of ONE
+// workgroup go to the four SIMDs of its CU: 1.26 ms at every batch size <= 4096. They also cover one whole 128-byte line of every
+// [B]-contiguous row between them (four trajectories = 32 bytes per wave).
+#ifndef I2C_QUAD_WPB
+#define I2C_QUAD_WPB 4
+#endif
+template <class M> constexpr int quad_waves_per_block() { return QG<M>::WIDE ? 4 : I2C_QUAD_WPB; }
 #ifdef I2C_HOST_SIM
 template <class M, typename R, typename S, bool GENERAL, class A>
 static int launch_quad_forward_g(const Consts<M, R>& c, const A& a, void*) {
@@ -390,9 +409,14 @@ __global__ __launch_bounds__(64 * quad_waves_per_block<M>(), 2) I2C_QF_ATTR void
     // i + 8 share an L2). Placement is a speed heuristic only -- any mapping computes the same result.
     const unsigned i = blockIdx.x, x = i & 7u, rr = (i >> 3) & 3u, gg = i >> 5;
     b0 = 16L * (gg * 8u + x) + 4 * rr;
-  } else {  // (trajectory-major buffers: a cell of a trajectory is contiguous, nothing is shared between waves)
+  } else {  // (the waves of a workgroup take consecutive groups of four trajectories: one 128-byte line of a [B]-contiguous row)
     b0 = 4L * ((long)blockIdx.x * WPB + wv);
   }
+#ifdef I2C_QUAD_PLACEMENT  // (diagnostic build, never shipped: where the dispatcher put this wave -- tools/placement_summary.py)
+  if (l == 0)
+    printf("placement %u %d %u %u\n", blockIdx.x, b0 < c.B ? 1 : 0, (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4),
+           (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20));
+#endif
   if (b0 >= c.B) return;  // (wave-uniform: no trajectory in this wave)
   const long b = b0 + g;
 #ifdef I2C_QF_NOSTORE  // (experiment, never shipped: the sweep without its stores -- how much of it is the store path)
@@ -851,7 +875,7 @@ template <class M, typename R, typename S = R> struct Impl {
   static int forward_lane(const I2cProblem* p, const C& c, const FwdArgs<R, S>& a, void* stream) {
     if constexpr (LANE) {
 #ifdef I2C_HOST_SIM
-      const int lanes = SWEEP_BLOCK;
+      const int lanes = LANE_BLOCK;
 #else
       const int lanes = sweep_lanes();
 #endif
@@ -902,9 +926,9 @@ template <class M, typename R, typename S = R> struct Impl {
       if constexpr (HAS_GROUP) return launch_group<GK_FORWARD, M, R, G>(c, nullptr, a, stream);
     }
     if constexpr (LANE) {
-      if (p->inference == I2C_INF_LINEARIZE) return launch(k_forward_lin<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+      if (p->inference == I2C_INF_LINEARIZE) return launch(k_forward_lin<M, R>, p->B, 1, LANE_BLOCK, stream, c, a);
       if (p->inference == I2C_INF_GAUSS_HERMITE)
-        return launch(k_forward<M, R, false, true>, p->B, 1, SWEEP_BLOCK, stream, c, a, SWEEP_BLOCK);
+        return launch(k_forward<M, R, false, true>, p->B, 1, LANE_BLOCK, stream, c, a, LANE_BLOCK);
       if constexpr (!MIXED) return forward_lane(p, c, a, stream);
     }
     return I2C_ENOTSUP;
@@ -1035,15 +1059,15 @@ template <class M, typename R, typename S = R> struct Impl {
             ch.comp = (R*)p->work;
             ch.bnd = ch.comp + (size_t)ch.n_chunks * (NX + NX * NX + sym(NX)) * p->B;
             ch.part = ch.bnd + (size_t)ch.n_chunks * (NX + sym(NX)) * p->B;
-            int rc = launch(k_chunk_compose<M, R, R>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
-            if (rc == I2C_OK) rc = launch(k_chunk_stitch_lin<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, ch);
-            if (rc == I2C_OK) rc = launch(k_chunk_walk_lin<M, R>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
-            if (rc == I2C_OK) rc = launch(k_chunk_reduce_lin<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, ch, ms);
+            int rc = launch(k_chunk_compose<M, R, R>, p->B, ch.n_chunks, LANE_BLOCK, stream, c, ch);
+            if (rc == I2C_OK) rc = launch(k_chunk_stitch_lin<M, R>, p->B, 1, LANE_BLOCK, stream, c, ch);
+            if (rc == I2C_OK) rc = launch(k_chunk_walk_lin<M, R>, p->B, ch.n_chunks, LANE_BLOCK, stream, c, ch);
+            if (rc == I2C_OK) rc = launch(k_chunk_reduce_lin<M, R>, p->B, 1, LANE_BLOCK, stream, c, ch, ms);
             if (fuse) fuse->done = true;
             return rc;
           }
         }
-        return launch(k_bwd_lin<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+        return launch(k_bwd_lin<M, R>, p->B, 1, LANE_BLOCK, stream, c, a);
       }
       if (p->inference == I2C_INF_GAUSS_HERMITE) {  // the fused walk with the grid transform, or (small batches) the chunked form:
         if constexpr (!MIXED) {                     // the composition of the x-marginal recursion has no transform in it
@@ -1058,15 +1082,15 @@ template <class M, typename R, typename S = R> struct Impl {
             cr.T = ch.n_chunks;
             CellArgs<R> ared = a;
             ared.cell_stats = ch.part;
-            int rc = launch(k_chunk_compose<M, R, R>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
-            if (rc == I2C_OK) rc = launch(k_chunk_stitch<M, R, R, true>, p->B, 1, SWEEP_BLOCK, stream, c, ch);
-            if (rc == I2C_OK) rc = launch(k_chunk_walk<M, R, R, false, true>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
+            int rc = launch(k_chunk_compose<M, R, R>, p->B, ch.n_chunks, LANE_BLOCK, stream, c, ch);
+            if (rc == I2C_OK) rc = launch(k_chunk_stitch<M, R, R, true>, p->B, 1, LANE_BLOCK, stream, c, ch);
+            if (rc == I2C_OK) rc = launch(k_chunk_walk<M, R, R, false, true>, p->B, ch.n_chunks, LANE_BLOCK, stream, c, ch);
             if (rc == I2C_OK) rc = launch_reduce<M, R>(cr, ared, ms, p->T, stream);
             if (fuse) fuse->done = true;
             return rc;
           }
         }
-        return launch(k_bwd_fused<M, R, true>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+        return launch(k_bwd_fused<M, R, true>, p->B, 1, LANE_BLOCK, stream, c, a);
       }
       if constexpr (!MIXED) return backward_lane(p, c, a, ms, fuse, stream);
     }
@@ -1079,8 +1103,8 @@ template <class M, typename R, typename S = R> struct Impl {
       const int mode = pick_mode(p);
       if (mode == I2C_BWD_FUSED) {
         const bool lean = I2C_WALK_LEAN && !a.xm && !a.zpost && !a.cell_stats && !c.z_per_cell;  // see chunk_walk_body
-        return lean ? launch(k_bwd_fused<M, R, false, S, true>, p->B, 1, SWEEP_BLOCK, stream, c, a)
-                    : launch(k_bwd_fused<M, R, false, S>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+        return lean ? launch(k_bwd_fused<M, R, false, S, true>, p->B, 1, LANE_BLOCK, stream, c, a)
+                    : launch(k_bwd_fused<M, R, false, S>, p->B, 1, LANE_BLOCK, stream, c, a);
       }
       if (mode == I2C_BWD_CHUNKED) {
         ChunkArgs<R, S> ch{a, nullptr, nullptr, nullptr, 0, 0};
@@ -1093,12 +1117,12 @@ template <class M, typename R, typename S = R> struct Impl {
         cr.T = ch.n_chunks;
         CellArgs<R, S> ared = a;
         ared.cell_stats = ch.part;
-        int rc = launch(k_chunk_compose<M, R, S>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
-        if (rc == I2C_OK) rc = launch(k_chunk_stitch<M, R, S>, p->B, 1, SWEEP_BLOCK, stream, c, ch);
+        int rc = launch(k_chunk_compose<M, R, S>, p->B, ch.n_chunks, LANE_BLOCK, stream, c, ch);
+        if (rc == I2C_OK) rc = launch(k_chunk_stitch<M, R, S>, p->B, 1, LANE_BLOCK, stream, c, ch);
         if (rc == I2C_OK) {
           const bool lean = I2C_WALK_LEAN && !a.xm && !a.zpost && !a.cell_stats && !c.z_per_cell;  // see chunk_walk_body
-          rc = lean ? launch(k_chunk_walk<M, R, S, true>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch)
-                    : launch(k_chunk_walk<M, R, S>, p->B, ch.n_chunks, SWEEP_BLOCK, stream, c, ch);
+          rc = lean ? launch(k_chunk_walk<M, R, S, true>, p->B, ch.n_chunks, LANE_BLOCK, stream, c, ch)
+                    : launch(k_chunk_walk<M, R, S>, p->B, ch.n_chunks, LANE_BLOCK, stream, c, ch);
         }
         if (rc == I2C_OK) rc = launch_reduce<M, R>(cr, ared, ms, p->T, stream);
         if (fuse) fuse->done = true;
@@ -1106,7 +1130,7 @@ template <class M, typename R, typename S = R> struct Impl {
       }
       if (!a.xm || !a.cell_stats) return I2C_EINVAL;  // two-pass needs both as workspace
       ScanArgs<R, S> sc{a.fwd, const_cast<S*>(a.xm), (R*)p->temp, a.status};
-      int rc = launch(k_scan<M, R, S>, p->B, 1, SWEEP_BLOCK, stream, c, sc);
+      int rc = launch(k_scan<M, R, S>, p->B, 1, LANE_BLOCK, stream, c, sc);
       if (rc == I2C_OK) rc = launch(k_cell<M, R, S>, p->B, p->T, CELL_BLOCK, stream, c, a);
       if (rc == I2C_OK) rc = launch_reduce<M, R>(c, a, ms, p->T, stream);
       if (fuse) fuse->done = true;
@@ -1123,7 +1147,7 @@ template <class M, typename R, typename S = R> struct Impl {
       const C c = make_consts<M, R>(p, 0.0, 0);
       RiccatiArgs<R> a{(const R*)prior_out, (const R*)fwd, (const R*)xm, (const R*)p->z, (const R*)p->alpha,
                        (R*)post,            (R*)ric,       status};
-      return launch(k_riccati<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+      return launch(k_riccati<M, R>, p->B, 1, LANE_BLOCK, stream, c, a);
     }
     return I2C_ENOTSUP;
   }
@@ -1132,7 +1156,7 @@ template <class M, typename R, typename S = R> struct Impl {
                    void* stream) {
     const C c = make_consts<M, R>(p, tol, 0);
     MstepArgs<R> a{(const R*)term_stats, (R*)p->alpha, (R*)stats_out, update};
-    return launch(k_mstep<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+    return launch(k_mstep<M, R>, p->B, 1, LANE_BLOCK, stream, c, a);
   }
 
   // _update_priors (i2c.py:1210-1213): cells with index <= tau switch to feedback mode
@@ -1190,7 +1214,7 @@ template <class M, typename R, typename S = R> struct Impl {
                         (const R*)p->alpha_cell, p->feedforward, status, p->expert};
           PropArgs<R> ap{(const R*)post, (R*)prop, (R*)prop_row(pending), (const R*)p->x0, (const R*)p->sig_x0,
                          (const R*)p->z, p->feedforward, status, p->expert};
-          rc = launch(k_forward_propagate<M, R, true>, p->B, 2, SWEEP_BLOCK, stream, c, af, ap);
+          rc = launch(k_forward_propagate<M, R, true>, p->B, 2, LANE_BLOCK, stream, c, af, ap);
           fused = true;
           pending = -1;
         }
@@ -1243,7 +1267,7 @@ template <class M, typename R, typename S = R> struct Impl {
     if (fam == I2C_FAMILY_GROUP) {
       if constexpr (HAS_GROUP) return launch_group<GK_CKF, M, R, G>(c, &z, a, stream);
     }
-    if constexpr (LANE) return launch(k_ckf<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, z, a);
+    if constexpr (LANE) return launch(k_ckf<M, R>, p->B, 1, LANE_BLOCK, stream, c, z, a);
     return I2C_ENOTSUP;
   }
 
@@ -1286,7 +1310,7 @@ template <class M, typename R, typename S = R> struct Impl {
     const C c = make_consts<M, R>(p, 0.0, 0);
     RolloutArgs<R> a{(const R*)post, (const R*)p->x0, (const R*)p->sig_x0, (const R*)eps_x0, (const R*)eps_x,
                      (const R*)eps_u, (R*)xu, (R*)z, (R*)x_final, (R*)z_term, n_rollouts, policy};
-    return launch(k_rollout<M, R>, (long)n_rollouts * p->B, 1, SWEEP_BLOCK, stream, c, a);
+    return launch(k_rollout<M, R>, (long)n_rollouts * p->B, 1, LANE_BLOCK, stream, c, a);
   }
 
   static int propagate(const I2cProblem* p, const void* post, void* prop, void* prop_stats, int use_expert,
@@ -1309,8 +1333,8 @@ template <class M, typename R, typename S = R> struct Impl {
       if constexpr (HAS_GROUP) return launch_group<GK_PROPAGATE, M, R, G>(c, nullptr, a, stream);
     }
     if constexpr (LANE) {
-      if (p->inference == I2C_INF_GAUSS_HERMITE) return launch(k_propagate<M, R, true>, p->B, 1, SWEEP_BLOCK, stream, c, a);
-      return launch(k_propagate<M, R>, p->B, 1, SWEEP_BLOCK, stream, c, a);
+      if (p->inference == I2C_INF_GAUSS_HERMITE) return launch(k_propagate<M, R, true>, p->B, 1, LANE_BLOCK, stream, c, a);
+      return launch(k_propagate<M, R>, p->B, 1, LANE_BLOCK, stream, c, a);
     }
     return I2C_ENOTSUP;
   }

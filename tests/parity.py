@@ -155,6 +155,11 @@ def batched_inputs(case, B, seed=1234, x0_scale=1e-2):
 def check_batch_against_oracle(name, lib, device, B, n_iters, tol=1e-8, dtype=torch.float64, tol_policy=None, **kw):
     """Batched engine vs the batched CPU oracle on identical inputs, all trajectories, every cell."""
     g = load_case(name)
+    meta_override = kw.pop("meta_override", None)
+    if meta_override:  # the same case with other hyper-parameters (e.g. the temperature), for the engine AND the oracle
+        import json
+
+        g = type(g)({**dict(g), "meta": np.array(json.dumps({**g.meta, **meta_override}))})
     x0, mu_u = batched_inputs(g, B)
     eng = engine_from_case(g, lib, device, dtype=dtype, x0=x0, mu_u=mu_u, **kw)
     g2 = dict(g)

@@ -147,6 +147,18 @@ def test_hip_quad12_quad_forward_batch_vs_oracle(lib):
     assert eng.forward_family == "quad"
 
 
+@pytest.mark.parametrize("name,lanes,family", [("em_quad12_T20", 64, "wave"), ("em_quad12_T20", 164, "quad"), ("em_quadrotor_T20", 64, "quad")])
+@pytest.mark.parametrize("scale", [1e-3, 1e3])
+def test_hip_square_root_update_at_extreme_temperatures(lib, name, lanes, family, scale):
+    """The square-root form of the identity-observation update (w_kalman_sqrt / q_kalman_sqrt) with the cost noise N = alpha * xi
+    10^3 times smaller / larger than the case's, against the oracle's covariance form (see the host-simulation twin)."""
+    from golden_util import load_case
+
+    alpha = load_case(name).meta["alpha"] * scale
+    eng, _ = parity.check_batch_against_oracle(name, lib, "cuda", 37, 2, tol=1e-6, group_lanes=lanes, meta_override={"alpha": alpha})
+    assert eng.forward_family == family
+
+
 @pytest.mark.parametrize("name", ["em_quad12_covctrl_T12", "em_quad12_nondiag_T12"])
 def test_hip_quad12_quad_sweeps_batch_vs_oracle(lib, name):
     """Covariance control (tempered terminal state prior at the end of the backward chain) and non-diagonal cost weights on a ragged

@@ -191,6 +191,23 @@ def test_hostsim_quad12_quad_forward_batch_vs_oracle(lib):
     assert eng.forward_family == "quad"
 
 
+@pytest.mark.parametrize("name,lanes,family", [("em_quad12_T20", 64, "wave"), ("em_quad12_T20", 164, "quad"), ("em_quadrotor_T20", 64, "quad")])
+@pytest.mark.parametrize("scale", [1e-3, 1e3])
+def test_hostsim_square_root_update_at_extreme_temperatures(lib, name, lanes, family, scale):
+    """The identity-observation models update the FACTOR of the joint prior (w_kalman_sqrt / q_kalman_sqrt: chol(I + L^T N^-1 L) from
+    the last row upwards) instead of factoring sig_0 + N and the updated joint. N = alpha * xi: a temperature 10^3 times smaller
+    makes N^-1 dominate that matrix, one 10^3 times larger leaves it next to the identity -- both against the oracle, which solves
+    the reference's covariance form (i2c.py:394-403). (At 10^-4 the last cell's gain, ~1e-7 of the largest, differs from the oracle's by
+    8e-4 of itself on EVERY kernel family, the classical group form included: the comparison's floor, not this update.)"""
+    import json
+
+    from golden_util import load_case
+
+    alpha = load_case(name).meta["alpha"] * scale
+    eng, _ = parity.check_batch_against_oracle(name, lib, "cpu", 5, 2, tol=1e-6, group_lanes=lanes, meta_override={"alpha": alpha})
+    assert eng.forward_family == family
+
+
 def test_quad_forward_refuses_what_it_does_not_cover(lib):
     """General cubature weights (a weight on the centre point) are in the quad form only where every observation goes through the
     sigma points and the geometry has a spare pair row for the centre (pendulum, cartpole, double cartpole: round 5); the
