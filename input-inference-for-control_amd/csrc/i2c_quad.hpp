@@ -1901,7 +1901,44 @@ I2C_HD inline void propagate_quad_body(const Consts<M, R>& c, const KC& kc, cons
     for (int i = 0; i < NBX; ++i) sx[i * NBX + j] = j >= i ? a.sig_x0[(long)w_symidx(4 * i + qw.r, 4 * j + qw.c) * B + b] : R(0);
   }
   const Window ffw = make_window(a.ff, (unsigned long)T), exw = make_window(a.expert ? a.expert : a.ff, (unsigned long)T);
+  const Window zw = make_window(c.z_per_cell ? a.z : a.x0, (c.z_per_cell ? (unsigned long)T * NZ : 1ul) * B * sizeof(R));  // (x0 row 0: a valid dummy)
   R acc_m = R(0), acc_v = R(0);
+
+  // The posterior rows of a cell do not depend on the recursion: they are fetched ONE CELL AHEAD (issued once the current cell's have
+  // been consumed; see forward_wave_body), through the buffer path and without branches. (trajectory-major: a cell of a trajectory
+  // is contiguous)
+  R nx_pmu[NBD], nx_pj[NBD * NBD], nx_kt[NBX], nx_zt[NBD];
+  int nx_ff, nx_ex;
+  auto fetch_rows = [&](const int tc) {
+    const int r = qw.r, cc = qw.c;
+    const int hi = r > cc ? r : cc, lo = r > cc ? cc : r;
+    const int tri_c = cc * (cc + 1) / 2 + r, tri_d = hi * (hi + 1) / 2 + lo;
+    auto sym_lane = [&](const int i, const int j) { return i == j ? tri_d + 4 * j * hi : tri_c + 4 * j * cc; };
+    auto sym_k = [&](const int i, const int j) { return i == j ? 8 * j * j + 6 * j : 8 * j * j + 2 * j + 4 * i; };
+    const int trc = c.row(tc);
+    const QIO<R, R, true> pri{make_window(a.post + (unsigned long)trc * C::E_POST * B, (unsigned long)C::E_POST * B * WS), WS, (unsigned)b * (unsigned)C::E_POST * WS};
+#pragma unroll
+    for (int j = 0; j < NBD; ++j) {
+      nx_pmu[j] = pri.ld(cc, 4 * j);
+#pragma unroll
+      for (int i = 0; i < NBD; ++i) nx_pj[i * NBD + j] = i <= j ? pri.ld(sym_lane(i, j), D + sym_k(i, j)) : R(0);  // upper blocks, the diagonal ones full
+      // (the per-cell target or a discarded dummy; the choice is made where the value is used)
+      nx_zt[j] = wld<R>(zw, 0u, c.z_per_cell ? (unsigned)((((unsigned long)trc * NZ + 4 * j + cc) * B + b) * sizeof(R)) : (unsigned)(b * sizeof(R)));
+    }
+#pragma unroll
+    for (int i = 0; i < NBX; ++i) nx_kt[i] = pri.ld(cc < NU ? cc * NX + r : 0, O_K + 4 * i);  // K^T, block (i, JU): row = state, column = action (masked where used)
+    nx_ff = (int)wld_u8(ffw, (unsigned)trc);
+    nx_ex = (int)wld_u8(exw, (unsigned)trc);
+  };
+  fetch_rows(0);
+  // settled before the loop (loads pending on the loop-entry path cost a vmcnt(0) in every cell: forward_wave_body)
+#pragma unroll
+  for (int k = 0; k < NBD; ++k) nx_pmu[k] = opaque(nx_pmu[k]), nx_zt[k] = opaque(nx_zt[k]);
+#pragma unroll
+  for (int k = 0; k < NBD * NBD; ++k) nx_pj[k] = opaque(nx_pj[k]);
+#pragma unroll
+  for (int k = 0; k < NBX; ++k) nx_kt[k] = opaque(nx_kt[k]);
+  nx_ff = (int)opaque((unsigned)nx_ff), nx_ex = (int)opaque((unsigned)nx_ex);
 
   for (int t = 0; t < T; ++t) {
     const int kz = (int)opaque_uniform(0u);
@@ -1911,22 +1948,18 @@ I2C_HD inline void propagate_quad_body(const Consts<M, R>& c, const KC& kc, cons
     const int tri_c = cc * (cc + 1) / 2 + r, tri_d = hi * (hi + 1) / 2 + lo;
     auto sym_lane = [&](const int i, const int j) { return i == j ? tri_d + 4 * j * hi : tri_c + 4 * j * cc; };
     auto sym_k = [&](const int i, const int j) { return i == j ? 8 * j * j + 6 * j : 8 * j * j + 2 * j + 4 * i; };
-    const int trc = c.row(t);
-    // the posterior rows of this cell (trajectory-major: a cell of a trajectory is contiguous)
-    const QIO<R, R, true> pri{make_window(a.post + (unsigned long)trc * C::E_POST * B, (unsigned long)C::E_POST * B * WS), WS, (unsigned)b * (unsigned)C::E_POST * WS};
     R pmu[NBD], pj[NBD * NBD], kt[NBX], zt[NBD];
 #pragma unroll
     for (int j = 0; j < NBD; ++j) {
-      pmu[j] = pri.ld(cc, 4 * j);
+      pmu[j] = nx_pmu[j];
 #pragma unroll
-      for (int i = 0; i < NBD; ++i) pj[i * NBD + j] = i <= j ? pri.ld(sym_lane(i, j), D + sym_k(i, j)) : R(0);  // upper blocks, the diagonal ones full
-      const R ztv = (c.z_per_cell ? a.z : a.x0)[c.z_per_cell ? ((long)trc * NZ + 4 * j + cc) * B + b : b];  // (or a discarded dummy)
-      zt[j] = c.z_per_cell ? ztv : q_ldv(q, kc.zg, j, kz);
+      for (int i = 0; i < NBD; ++i) pj[i * NBD + j] = i <= j ? nx_pj[i * NBD + j] : R(0);
+      zt[j] = c.z_per_cell ? nx_zt[j] : q_ldv(q, kc.zg, j, kz);
     }
 #pragma unroll
-    for (int i = 0; i < NBX; ++i) kt[i] = cc < NU ? pri.ld(cc * NX + r, O_K + 4 * i) : R(0);  // K^T, block (i, JU): row = state, column = action
-    const bool ff = w_uniform((int)wld_u8(ffw, (unsigned)trc)) != 0;
-    const bool ex = a.expert ? w_uniform((int)wld_u8(exw, (unsigned)trc)) != 0 : c.use_expert != 0;
+    for (int i = 0; i < NBX; ++i) kt[i] = cc < NU ? nx_kt[i] : R(0);
+    const bool ff = w_uniform(nx_ff) != 0;
+    const bool ex = a.expert ? w_uniform(nx_ex) != 0 : c.use_expert != 0;
 
     // state offset to the posterior's state mean, row form; pdf-ratio scaling of the gain (expert controller, feedback cells)
     R dr[NBX];
@@ -1999,6 +2032,7 @@ I2C_HD inline void propagate_quad_body(const Consts<M, R>& c, const KC& kc, cons
 #pragma unroll
       for (int j = 0; j < NBD; ++j) mu0[j] = j < NBX ? mx[j < NBX ? j : 0] : pmu[j] + kd;
     }
+    fetch_rows(t + 1 < T ? t + 1 : t);  // this cell's rows are consumed: the next cell's, a cell ahead
     const QIO<R, R, false> out{make_window(a.prop + (unsigned long)t * C::E_PROP * B, (unsigned long)C::E_PROP * rb), rb, bo};
 #pragma unroll
     for (int j = 0; j < NBD; ++j) {
