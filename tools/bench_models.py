@@ -36,10 +36,14 @@ def run(name, B, dtype, iters=10, mode="auto", group=0, storage=None):
     x0 = np.asarray(model.x0, float).reshape(1, -1) + 1e-3 * rng.normal(size=(B, model.dim_x))
     base = {"PlanarQuadrotor": 0.5, "Quadrotor12": 0.25}.get(name, 0.0) * getattr(model, "gravity", 0.0)
     mu_u = base + cfg["mu_u"] * rng.normal(size=(B, T, nu))
-    eng = pkg.BatchedI2c(model, T, cfg["Q"], cfg["R"], cfg["Q"], cfg["alpha"], cfg["tol"], mu_u, cfg["sig_u"] * np.eye(nu), x0=x0,
-                         dtype=dtype, keep_zpost=False, keep_xm=False, backward_mode=mode, group_lanes=group, allow_inexact=True,
-                         **({"storage_dtype": storage} if storage is not None else {}),
-                         lib=pkg.load_library(os.environ["I2C_BENCH_LIB"]) if os.environ.get("I2C_BENCH_LIB") else None)
+    try:
+        eng = pkg.BatchedI2c(model, T, cfg["Q"], cfg["R"], cfg["Q"], cfg["alpha"], cfg["tol"], mu_u, cfg["sig_u"] * np.eye(nu), x0=x0,
+                             dtype=dtype, keep_zpost=False, keep_xm=False, backward_mode=mode, group_lanes=group, allow_inexact=True,
+                             **({"storage_dtype": storage} if storage is not None else {}),
+                             lib=pkg.load_library(os.environ["I2C_BENCH_LIB"]) if os.environ.get("I2C_BENCH_LIB") else None)
+    except RuntimeError as e:  # a combination the library refuses (e.g. fp32 arithmetic on the d = 16 model)
+        print(f"{name:22s} B={B:6d} T={T:3d} {str(dtype)[6:]:8s} refused: {str(e)[:90]}")
+        return
     for _ in range(3):
         eng.learn_msgs()
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(iters)]
