@@ -497,6 +497,23 @@ class BatchedI2c:
             self._broadcast_alpha()
         return out[0], out[1]
 
+    def record_costs(self):
+        """I2cGraph.calc_cost (i2c.py:1045-1066) alone: the expected cost of the current posterior (and of the propagation) appended
+        to the cost lists, from the statistics the last backward sweep / propagation left on the device. The temperature is not
+        touched (the M-step kernel runs with update_alpha = 0)."""
+        rc = self.lib.i2c_mstep(C.byref(self._problem), self._ptr(self.term_stats), self.alpha_update_tol, 0,
+                                self._ptr(self.stats_out), self._stream())
+        self._check(rc, "i2c_mstep")
+        out = self.stats_out.clone()
+        self.costs_m.append(out[2])
+        self.costs_m_var.append(out[3])
+        if self._propagate:
+            ps = self.prop_stats.clone()
+            self.costs_pf.append(ps[0])
+            self.costs_pf_var.append(ps[1])
+        else:
+            self.costs_pf.append(torch.full_like(out[2], -1.0))  # i2c.py:1065
+
     def maximize(self, update_alpha=True):
         """I2cGraph._maximize (i2c.py:1004-1019): cost, prior update, temperature M-step."""
         rc = self.lib.i2c_mstep(C.byref(self._problem), self._ptr(self.term_stats), self.alpha_update_tol,

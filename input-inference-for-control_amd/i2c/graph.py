@@ -24,6 +24,7 @@ from . import core
 
 BatchedI2c = core.BatchedI2c
 from .exp_types import CubatureQuadrature, GaussHermiteQuadrature, Linearize
+from .graph_metrics import GraphMetrics
 
 PLOT_TIKZ = False
 CHECK_COVAR = False
@@ -103,6 +104,27 @@ class I2cCell:
     def temp(self):
         return self._g._maybe_scalar(_np(self._g.engine.temp))
 
+    # -- the cell's own statistics (i2c.py:680-688, 721-730) -----------------------------------
+    def _outer_plus(self, mu, sig):
+        g = self._g
+        z = np.asarray(self.z, float).reshape(-1, g.sys.dim_z)
+        d = z - np.asarray(mu, float).reshape(-1, g.sys.dim_z)
+        e = d[:, :, None] * d[:, None, :] + np.asarray(sig, float).reshape(-1, g.sys.dim_z, g.sys.dim_z)
+        return e[0] if g.B == 1 else e
+
+    def expected_observation_covar(self):
+        return self._outer_plus(self.mu_z0_m, self.sig_z0_m)
+
+    def expected_propagated_observation_covar(self):
+        return self._outer_plus(self.mu_z0_pf, self.sig_z0_pf)
+
+    def get_obs_covar(self):
+        return self._outer_plus(self.mu_z0_m, self.sig_z0_m)
+
+    @staticmethod
+    def are_nan(*args):
+        return any(np.any(np.isnan(a)) for a in args)
+
     # -- read-only message / posterior state ------------------------------------------------
     def __getattr__(self, name):
         g = object.__getattribute__(self, "_g")
@@ -113,8 +135,10 @@ class I2cCell:
         return self._pick(arr, column)
 
 
-class I2cGraph:
-    """Manages Gaussian i2c for a whole trajectory (or a batch of them) on the GPU."""
+class I2cGraph(GraphMetrics):
+    """Manages Gaussian i2c for a whole trajectory (or a batch of them) on the GPU. (GraphMetrics, graph_metrics.py: the host-side
+    bookkeeping surface of the reference's class -- temperature helpers, observation covariances, cost helpers, entropy and
+    likelihood metrics.)"""
 
     def __init__(self, sys, horizon, Q, R, Qf, alpha, alpha_update_tol, mu_u, sig_u, mu_x_terminal,
                  sig_x_terminal, inference, res_dir=None, *, batch=None, x0=None, sig_x0=None, z_traj=None,
@@ -155,6 +179,9 @@ class I2cGraph:
         self.cells = [I2cCell(self, t) for t in range(self.H)]
         self.alpha_risk = []
         self.alpha_sigma = 0
+        # the entropy lists _maximize appends to every iteration (i2c.py:1021-1027) cost a device -> host copy of the posterior
+        # per EM iteration: kept for single-trajectory graphs (the reference's use, its plots), opt-in for batches
+        self.record_metrics = self.B == 1
         self.policy_valid = False
         # the engine starts from the constructor's x0 / sig_x0; re-upload only when a caller later CHANGES
         # sys.x0 / sys.sig_x0 (the MPC protocol, mpc.py:149-150)
@@ -230,6 +257,8 @@ class I2cGraph:
         X = lambda: c("xm", xm)  # noqa: E731
         R_ = lambda: c("pri", pri)  # noqa: E731
         G = lambda: c("prop", prop)  # noqa: E731
+        # observation moments of the propagated joint: pushed through sys.observe on the host (GraphMetrics._observed_moments)
+        ZP = lambda: c("zpf", lambda: self._observed_moments(G()["mu_xu0_pf"], G()["sig_xu0_pf"]))  # noqa: E731
         return {
             "mu_xu0_m": lambda: (P()[0], True), "sig_xu0_m": lambda: (P()[1], False),
             "mu_xu1_m": lambda: (P()[0], True), "sig_xu1_m": lambda: (P()[1], False),
@@ -249,6 +278,7 @@ class I2cGraph:
             "mu_u0_pf": lambda: (G()["mu_xu0_pf"][..., nx:], True),
             "sig_u0_pf": lambda: (G()["sig_xu0_pf"][..., nx:, nx:], False),
             "mu_x3_pf": lambda: (G()["mu_x3_pf"], True), "sig_x3_pf": lambda: (G()["sig_x3_pf"], False),
+            "mu_z0_pf": lambda: (ZP()[0], True), "sig_z0_pf": lambda: (ZP()[1], False),
             # Riccati-form backward messages (after _backward_ricatti_msgs, i2c.py:612-678)
             "nu_x0_b": lambda: (self._riccati_np()[0], True), "lambda_x0_b": lambda: (self._riccati_np()[1], False),
             "nu_x3_b": lambda: (self._riccati_np()[2], True), "lambda_x3_b": lambda: (self._riccati_np()[3], False),
@@ -406,6 +436,9 @@ class I2cGraph:
         self.engine.maximize(update_alpha=True)
         if self.B == 1 and np.isnan(_np(self.engine.alphas_desired[-1])).any():
             raise ValueError("Alpha is NaN")
+        self._invalidate()
+        if self.record_metrics:
+            self._append_iteration_metrics()  # entropies of the posterior policy, the state prior, the propagation (i2c.py:1021-1027)
 
     def compute_update_alpha(self, update_alpha):
         """i2c.py:921-963: alpha_hat, the clamp, and (with update_alpha) the new temperature in every cell -- nothing else:
@@ -419,6 +452,8 @@ class I2cGraph:
         self._check()
         if self.B == 1 and np.isnan(_np(self.engine.alphas_desired[-1])).any():
             raise ValueError("Alpha is NaN")
+        if self.record_metrics:
+            self._append_iteration_metrics()
 
     def update_models(self):
         pass
@@ -500,8 +535,7 @@ class I2cGraph:
 
     def get_z_covar(self):
         mz, sz = (_np(x) for x in self.engine.observed_marginal())
-        zt = np.stack([np.asarray(self._cell_target(t)).reshape(self.B, -1) for t in range(self.H)], axis=1)
-        err = zt - mz
+        err = self._targets() - mz
         return self._squeeze((err[..., :, None] * err[..., None, :] + sz).sum(axis=1))
 
     def converged(self):
@@ -602,4 +636,4 @@ class I2cGraph:
         return None
 
     plot_traj = plot_metrics = plot_alphas = plot_cost = plot_controller = plot_observed_traj = _no_plot
-    plot_propagate = plot_uncertainty = plot_cost_all = plot_system_dynamics = _no_plot
+    plot_propagate = plot_uncertainty = plot_cost_all = plot_system_dynamics = plot_ricatti = plot_terminal_observed_traj = _no_plot

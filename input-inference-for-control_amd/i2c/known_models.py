@@ -151,6 +151,76 @@ class KnownModel:
     def save(self, path):
         print("Known model, no saving")
 
+    # ---- host-side linearisations (reference: env_def.py observe_linearize / observe_terminal_linearize / dydxu of each model,
+    # BaseModelKnown.forward_linearize model.py:158-164). The solver's Linearize() cells differentiate the DEVICE functors with dual
+    # numbers; these are for callers that poke the model directly. Jacobians by central differences of the NumPy functions
+    # (relative step 1e-6: ~1e-9 accurate), so every model -- out-of-tree ones included -- has them without writing derivatives.
+    @staticmethod
+    def _jacobian(f, x):
+        x = np.asarray(x, float).reshape(1, -1)
+        y0 = np.reshape(f(x), -1)
+        jac = np.zeros((y0.size, x.shape[1]))
+        for i in range(x.shape[1]):
+            h = 1e-6 * max(1.0, abs(x[0, i]))
+            e = np.zeros_like(x)
+            e[0, i] = h
+            jac[:, i] = (np.reshape(f(x + e), -1) - np.reshape(f(x - e), -1)) / (2.0 * h)
+        return jac
+
+    def dydxu(self, xu):
+        """d dynamics / d [x; u] at one point, (dim_x, dim_xu)."""
+        return self._jacobian(self.dynamics, xu)
+
+    def forward_linearize(self, xu):
+        """(x', A, B, a, sig_eta) with x' = A x + B u + a to first order about xu (1, dim_xu)."""
+        xu = np.asarray(xu, float)
+        assert xu.shape == (1, self.dim_xu)
+        xn = np.reshape(self.dynamics(xu), (-1, 1))
+        ab = self.dydxu(xu)
+        return xn, ab[:, :self.dim_x], ab[:, self.dim_x:], xn - ab @ xu.T, self.sig_eta
+
+    def observe_linearize(self, xu):
+        """(z, C, c, D) with z = C x + D u + c to first order about xu (1, dim_xu)."""
+        xu = np.asarray(xu, float).reshape(1, self.dim_xu)
+        z = np.reshape(self.observe(xu), (-1, 1))
+        cd = self._jacobian(self.observe, xu)
+        return z, cd[:, :self.dim_x], z - cd @ xu.T, cd[:, self.dim_x:]
+
+    def observe_terminal_linearize(self, x):
+        """(z, C, c) with z = C x + c to first order about x (dim_x, 1) or (1, dim_x)."""
+        x = np.asarray(x, float).reshape(1, self.dim_x)
+        z = np.reshape(self.observe_terminal(x), (-1, 1))
+        cj = self._jacobian(self.observe_terminal, x)
+        return z, cj, z - cj @ x.T
+
+    def predict_1d(self, x, u):
+        return self.dynamics(np.hstack((np.reshape(x, -1), np.reshape(u, -1))).reshape(1, self.dim_xu))
+
+    # ---- state / action limits (reference BaseDef, env_def.py:96-137) ------------------------------------------------------
+    def remove_state_bounds(self):
+        pass
+
+    def xu_in_bounds(self, xu):
+        lim = np.asarray(self.xu_lim, float)
+        assert lim.shape == (2, self.dim_xu)
+        return bool(np.all(lim[0, :, None] < xu) and np.all(lim[1, :, None] > xu))
+
+    def x_in_bounds(self, xu):
+        lim = np.asarray(self.xu_lim, float)
+        assert lim.shape == (2, self.dim_xu)
+        x = xu[:, :self.dim_x]
+        return bool(np.all(lim[0, :self.dim_x, None] < x) and np.all(lim[1, :self.dim_x, None] > x))
+
+    def filter_state_constraint_violations(self, xu, dx):
+        """Cut an episode (rows of xu and dx) at the first state outside 99.9 % of its limits."""
+        lim = np.asarray(self.xu_lim, float)
+        x = xu[:, :self.dim_x]
+        inside = np.clip(x, 0.999 * lim[0, :self.dim_x], 0.999 * lim[1, :self.dim_x])
+        bad = np.flatnonzero(np.any(inside != x, axis=1))
+        if bad.size == 0:
+            return xu, dx
+        return xu[:bad[0]], dx[:bad[0]]
+
 
 _INF = np.inf
 

@@ -19,6 +19,10 @@ class MpcPolicy:
     """Fully observed MPC (reference mpc.py:16-111). NB the reference's own __call__ is broken
     (it passes unknown kwargs to compute_update_alpha); this one runs."""
 
+    def plot_history(self, res_path, name=""):
+        """Figures are presentation, not part of the solver (I2cGraph._no_plot): the planned trajectories stay in xu_history."""
+        return None
+
     def __init__(self, i2c, n_iter, sig_u, z_traj=None):
         self.i2c = i2c
         self.engine = e = i2c.engine

@@ -38,6 +38,25 @@ def finite_horizon_lqr(H, A, a, B, Q, R, x0, xg, ug, dim_x, dim_u):
     return xs, us, K, k, cost, Ps, ps
 
 
+def finite_horizon_lqr_tv(H, A, a, B, Q, R, Qf, q, r, qf, x0, dim_x, dim_u):
+    """Time-varying affine LQR with linear cost terms: feedback gains K (H, nu, nx) and offsets k (H, nu) of u_t = K_t x_t + k_t for
+    x' = A_t x + B_t u + a_t and the stage cost x^T Q_t x - 2 q_t^T x + u^T R_t u - 2 r_t^T u (terminal: Qf, qf); the reference's
+    signature and sign conventions (utils.py:30-56). A, B, Q, R, a, q, r are stacked over the horizon, vectors as columns."""
+    K, k = np.zeros((H, dim_u, dim_x)), np.zeros((H, dim_u))
+    P, p = np.asarray(Qf, float), -np.asarray(qf, float).reshape(dim_x, 1)
+    for i in reversed(range(H)):
+        Ai, Bi = np.asarray(A[i], float), np.asarray(B[i], float)
+        ai, qi, ri = (np.asarray(v[i], float).reshape(-1, 1) for v in (a, q, r))
+        Minv = np.linalg.inv(np.asarray(R[i], float) + Bi.T @ P @ Bi)
+        drift = P @ ai + p
+        rhs = Bi.T @ drift - ri
+        K[i] = -Minv @ Bi.T @ P @ Ai
+        k[i] = (-Minv @ rhs).reshape(-1)
+        p = Ai.T @ (drift - P @ Bi @ Minv @ rhs) - qi
+        P = np.asarray(Q[i], float) + Ai.T @ P @ Ai - Ai.T @ P @ Bi @ Minv @ Bi.T @ P @ Ai
+    return K, k
+
+
 class _Evaluator:
     def __init__(self, W, Wf, sg, sg_term, dim_x):
         self.W, self.Wf = np.asarray(W, float), np.asarray(Wf, float)
