@@ -136,6 +136,13 @@ def test_host_side_model_helpers():
     zt, Ct, ct = m.observe_terminal_linearize(xu[:, :2].T)
     np.testing.assert_allclose(Ct @ xu[:, :2].T + ct, zt, atol=1e-12)
     assert m.dydxu(xu).shape == (2, 3) and m.predict_1d(xu[0, :2], xu[0, 2:]).shape == (1, 2)
+    # the module-level functions of the reference's env_autograd under their names (env_autograd.py:5-22)
+    import i2c.env_autograd as dyn
+
+    np.testing.assert_allclose(dyn.pendulum_dynamics(xu), m.dynamics(xu))
+    jac = dyn.pendulum_dydxu(xu)[0, :, 0, :]
+    np.testing.assert_allclose(jac[1, 0], 0.05 * (-3.0 * 9.80665 / 2.0) * np.cos(0.7 + np.pi), rtol=1e-7)  # d thd' / d th
+    np.testing.assert_allclose(jac, np.hstack((A, B)), atol=1e-12)
     lim = np.asarray(m.xu_lim, float)
     assert lim.shape == (2, 3)
     traj = np.array([[0.1, 0.0, 0.0], [0.2, 2.0 * abs(lim[1, 1]) if np.isfinite(lim[1, 1]) else 1e30, 0.0], [0.3, 0.0, 0.0]])
