@@ -148,6 +148,7 @@ class BatchedI2c:
         sig_x0 = np.asarray(model.sig_x0 if sig_x0 is None else sig_x0, dtype=np.float64)
         sig_x0 = np.broadcast_to(sig_x0, (B, nx, nx))
         sig_u = np.atleast_2d(np.asarray(sig_u, dtype=np.float64))
+        self.mu_u0_base, self.sig_u0_base = np.array(mu_u), np.array(sig_u)  # the initial action prior (I2cCell.mu_u0_base, i2c.py:128-129)
 
         # cost model (i2c.py:778-793)
         R = np.atleast_2d(np.asarray(R, dtype=np.float64))
@@ -408,6 +409,8 @@ class BatchedI2c:
     def forward_sweep(self):
         """I2cGraph._forward_msgs (i2c.py:876-880)."""
         self._problem.expert_controller = int(bool(self.use_expert_controller))
+        if self.prior_out is not None:  # (the graph facade: the temperature THIS sweep ran at, for the cells' sig_z0_f = S_z + alpha xi)
+            self.alpha_fwd = self.alpha.clone()
         rc = self.lib.i2c_forward_sweep(C.byref(self._problem), self._ptr(self.prior), self._ptr(self.fwd),
                                         self._ptr(self.prior_out), self._ptr(self.status), self._stream())
         self._check(rc, "i2c_forward_sweep")

@@ -125,6 +125,25 @@ class I2cCell:
     def are_nan(*args):
         return any(np.any(np.isnan(a)) for a in args)
 
+    # -- constants of the problem the reference copies into every cell (i2c.py:54-98) --------------------
+    lam_xi = property(lambda self: np.linalg.inv(np.asarray(self._g.sig_xi, float)))
+    sig_xi_terminal = property(lambda self: self._g.sig_xi_terminal)
+    z_term = property(lambda self: self._g.z_term)
+    mu_x_terminal = property(lambda self: self._g.mu_x_terminal)
+    sig_x_terminal = property(lambda self: self._g.sig_x_terminal)
+    obs_inf = prop_obs_inf = property(lambda self: self._g.obs_inf)
+
+    @property
+    def mu_z3_m(self):
+        """Terminal observation moments of the smoothed state: the last cell's (i2c.py:565-570), None elsewhere."""
+        m = self._g.engine.terminal_observed_marginal()[0] if self.terminal_cell else None
+        return None if m is None else (_np(m)[0].reshape(-1, 1) if self._g.B == 1 else _np(m))
+
+    @property
+    def sig_z3_m(self):
+        s = self._g.engine.terminal_observed_marginal()[1] if self.terminal_cell else None
+        return None if s is None else (_np(s)[0] if self._g.B == 1 else _np(s))
+
     # -- read-only message / posterior state ------------------------------------------------
     def __getattr__(self, name):
         g = object.__getattribute__(self, "_g")
@@ -279,10 +298,42 @@ class I2cGraph(GraphMetrics):
             "sig_u0_pf": lambda: (G()["sig_xu0_pf"][..., nx:, nx:], False),
             "mu_x3_pf": lambda: (G()["mu_x3_pf"], True), "sig_x3_pf": lambda: (G()["sig_x3_pf"], False),
             "mu_z0_pf": lambda: (ZP()[0], True), "sig_z0_pf": lambda: (ZP()[1], False),
+            # derived views the reference keeps as cell attributes: the state message entering the cell (x0 for cell 0, the previous
+            # cell's prediction after it), slices of the updated joint, the observation moments of the PRIOR joint (pushed through
+            # sys.observe on the host), the smoother's lag covariance J_x sig_x3_m (i2c.py:578), constants of the problem
+            "mu_x0_f": lambda: (self._entering_state()[0], True), "sig_x0_f": lambda: (self._entering_state()[1], False),
+            "mu_x1_f": lambda: (F()["mu_xu1_f"][..., :nx], True), "sig_x1_f": lambda: (F()["sig_xu1_f"][..., :nx, :nx], False),
+            "mu_u1_f": lambda: (F()["mu_xu1_f"][..., nx:], True), "sig_u1_f": lambda: (F()["sig_xu1_f"][..., nx:, nx:], False),
+            "mu_z0_f": lambda: (c("zf", self._prior_observation)[0], True), "sig_z0_f": lambda: (c("zf", self._prior_observation)[1], False),
+            "sig_x_lag_m": lambda: (np.einsum("btij,btjk->btik", F()["J_dyn"][..., :nx, :], X()[1]), False),
+            "sig_eta": lambda: (self._const_cells(self.sys.sig_eta), False), "sig_eta_pf": lambda: (self._const_cells(self.sys.sig_eta), False),
+            "mu_u0_base": lambda: (np.array(e.mu_u0_base), True), "sig_u0_base": lambda: (self._const_cells(e.sig_u0_base), False),
             # Riccati-form backward messages (after _backward_ricatti_msgs, i2c.py:612-678)
             "nu_x0_b": lambda: (self._riccati_np()[0], True), "lambda_x0_b": lambda: (self._riccati_np()[1], False),
             "nu_x3_b": lambda: (self._riccati_np()[2], True), "lambda_x3_b": lambda: (self._riccati_np()[3], False),
         }
+
+    def _const_cells(self, a):
+        a = np.asarray(a, float)
+        return np.broadcast_to(a, (self.B, self.H) + a.shape)
+
+    def _prior_observation(self):
+        """(mu_z0_f, sig_z0_f): the prior joint of the last forward sweep through sys.observe, plus the cost noise alpha xi at the
+        temperature that sweep ran at -- the innovation covariance, as the reference stores it (i2c.py:390-393, 402)."""
+        mz, sz = self._observed_moments(*(_np(x) for x in self.engine.prior_state_action()))
+        a = _np(getattr(self.engine, "alpha_fwd", self.engine.alpha)).reshape(self.B, 1, 1, 1)
+        return mz, sz + a * np.asarray(self.sig_xi0, float)
+
+    def _entering_state(self):
+        """(mu_x0_f, sig_x0_f) of every cell as (B, T, nx), (B, T, nx, nx): the belief over the initial state for cell 0, the
+        previous cell's prediction afterwards (i2c.py:876-880)."""
+        def make():
+            f = {k: _np(v) for k, v in self.engine.forward_messages().items()}
+            m0 = _np(self.engine.x0).T.reshape(self.B, 1, -1)
+            s0 = _np(self.engine._sym_rows(self.engine.sig_x0.unsqueeze(0), 0, self.engine.nx))[:, :1]
+            return np.concatenate((m0, f["mu_x3_f"][:, :-1]), axis=1), np.concatenate((s0, f["sig_x3_f"][:, :-1]), axis=1)
+
+        return self._cached("x0f", make)
 
     def _riccati_np(self):
         """(nu_x0_b, lambda_x0_b, nu_x3_b, lambda_x3_b) as (B, T, ...) arrays. The message entering cell t at x3 is the

@@ -158,3 +158,30 @@ def test_host_side_model_helpers():
                                    rep((R @ ug).reshape(1, 1)), (Q @ xg).reshape(2, 1), np.zeros(2), nx, nu)
     np.testing.assert_allclose(K2, K, atol=1e-10)
     np.testing.assert_allclose(k2, k, atol=1e-10)
+
+
+def test_derived_cell_attributes_vs_reference_golden():
+    """Cell attributes the facade derives on the host (the kernels do not store them): the observation moments of the PRIOR joint
+    (mu_z0_f / sig_z0_f, i2c.py:391-393) against the reference's first forward sweep (golden em_pendulum_T200, it1), the state
+    message entering each cell, the smoother's lag covariance, the constants every reference cell carries."""
+    g = load_case("em_pendulum_T200")
+    m = g.meta
+    gr = I2cGraph(make_env_model(m["model"], None), m["T"], g["Q"], g["R"], g["Qf"], m["alpha"], m["tol"], g["mu_u"], g["sig_u"], None, None,
+                  CubatureQuadrature(*m["quad"]), lib=hostsim.load(), device="cpu")
+    gr.learn_msgs()
+    _close(np.stack([c.mu_z0_f.reshape(-1) for c in gr.cells]), g["it1/mu_z0_f"], 1e-9, "mu_z0_f")
+    _close(np.stack([c.sig_z0_f for c in gr.cells]), g["it1/sig_z0_f"], 1e-9, "sig_z0_f")
+    c0, c7 = gr.cells[0], gr.cells[7]
+    np.testing.assert_allclose(c0.mu_x0_f.reshape(-1), g["x0"])
+    np.testing.assert_allclose(c0.sig_x0_f, g["sig_x0"])
+    np.testing.assert_allclose(c7.mu_x0_f, gr.cells[6].mu_x3_f)
+    np.testing.assert_allclose(c7.sig_x0_f, gr.cells[6].sig_x3_f)
+    np.testing.assert_allclose(c7.sig_x_lag_m, c7.Jx_dyn @ c7.sig_x3_m)
+    np.testing.assert_allclose(c7.mu_x1_f, c7.mu_xu1_f[:2])
+    np.testing.assert_allclose(c7.sig_u1_f, c7.sig_xu1_f[2:, 2:])
+    np.testing.assert_allclose(c7.lam_xi @ c7.sig_xi, np.eye(4), atol=1e-12)
+    np.testing.assert_allclose(c7.mu_u0_base.reshape(-1), g["mu_u"][7])
+    np.testing.assert_allclose(c7.sig_u0_base, g["sig_u"])
+    np.testing.assert_allclose(c7.sig_eta, g["sig_eta"])
+    assert c7.mu_z3_m is None and gr.cells[-1].mu_z3_m.shape == (3, 1) and gr.cells[-1].sig_z3_m.shape == (3, 3)
+    _close(gr.cells[-1].mu_z3_m.reshape(-1), g["it1/mu_z3_m"], 1e-8, "mu_z3_m")
