@@ -150,6 +150,10 @@ _SIMULATORS = {
 }
 
 
+# the reference's base-class names (env.py:34, 168, 198): one simulator class serves every known model here
+BaseSim = BaseKnownSim = BaseLinear = KnownSim
+
+
 def make_env(exp):
     """Simulator for an experiment module (same call as the reference's make_env, env.py:17-32)."""
     return _SIMULATORS[exp.ENVIRONMENT](exp.N_DURATION)

@@ -13,3 +13,5 @@ from .known_models import (  # noqa: F401
 )
 
 BaseModelKnown = KnownModel
+BaseModel = KnownModel  # (model.py:19-78: the common base; the learned-model classes are outside this build)
+LinearBase = LinearExact
