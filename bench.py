@@ -585,10 +585,10 @@ def main():
     if dist is not None:
         gather_policy = importlib.import_module(PKG + ".dist").gather_policy
 
-        gather_policy(eng)  # first call pays RCCL's lazy channel setup; time the steady-state exchange
+        gather_policy(eng, total=B * world)  # first call pays RCCL's lazy channel setup; time the steady-state exchange
         barrier()
         t1 = time.perf_counter()
-        gathered = gather_policy(eng)
+        gathered = gather_policy(eng, total=B * world)  # (weak scaling: every rank holds B trajectories)
         if device.type == "cuda":
             torch.cuda.synchronize(device)
         allgather_ms = (time.perf_counter() - t1) * 1e3

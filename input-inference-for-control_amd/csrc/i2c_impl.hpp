@@ -806,8 +806,13 @@ template <class M, typename R, typename S = R> struct Impl {
       // (unit cubature rule -- a Linearize() graph propagates with it, i2c.py:109-115 --, trajectory-major posterior)
       if (sweep == I2C_SWEEP_PROPAGATE && (p->group_lanes == 0 || p->group_lanes == 64 || p->group_lanes == I2C_LANES_QUAD) &&
           (p->inference == I2C_INF_CUBATURE || p->inference == I2C_INF_LINEARIZE) && p->post_layout == 1 && c.rule_xu.unit &&
-          c.rule_xu.w0 == R(0) && window_32bit_ok(p) == I2C_OK)
+          c.rule_xu.w0 == R(0) && window_32bit_ok(p) == I2C_OK) {
+        // (the posterior / propagation cells are addressed through 32-bit offsets of one window per cell, masked stores parked at
+        //  2 GiB like the other quad forms: beyond it the offsets would wrap silently -- refused here, as group_supported does)
+        constexpr long EP = C::E_POST > C::E_PROP ? C::E_POST : C::E_PROP;
+        if (EP * (long)p->B * (long)sizeof(R) >= (1L << 31)) return I2C_EINVAL;
         return I2C_FAMILY_QUAD;
+      }
     }
     if constexpr (HAS_QUAD_CKF) {  // the state estimator of a matrix-instruction graph (default, 64 or I2C_LANES_QUAD): the quad filter step
       if (sweep == I2C_SWEEP_FILTER && (p->group_lanes == 0 || p->group_lanes == 64 || p->group_lanes == I2C_LANES_QUAD)) return I2C_FAMILY_QUAD;

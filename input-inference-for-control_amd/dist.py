@@ -23,11 +23,19 @@ def shard_sizes(total, world):
 
 
 def _all_gather_rows(t, total=None, group=None):
-    """All-gather along dim 0 in ONE collective. `total` = the global number of rows when the shards are ragged (the contiguous
-    partition of shard_range: every rank computes every shard size itself); None = equal shards. Ragged shards travel in a
-    max-size buffer (at most one padding row per rank) and are cut back after the exchange."""
+    """All-gather along dim 0 in ONE collective. `total` = the global number of rows: the shards are the contiguous partition of
+    shard_range, so every rank computes every shard size itself and no size exchange is needed. With more than one rank `total`
+    is REQUIRED (round-5 advice: a default of "equal shards" let ranks with ragged shards enter the collective with different
+    buffer sizes -- a hang or silently mis-sliced controllers); a rank whose row count is not its shard_range share raises
+    before anything is exchanged. Ragged shards travel in a max-size buffer (at most one padding row per rank) and are cut
+    back after the exchange."""
     world = dist.get_world_size(group)
-    sizes = [int(t.shape[0])] * world if total is None else shard_sizes(total, world)
+    if total is None:
+        if world > 1:
+            raise ValueError("gather over more than one rank needs the global batch size (`total`): shard sizes are derived from "
+                             "shard_range(total, rank, world), never assumed equal")
+        total = int(t.shape[0])
+    sizes = shard_sizes(total, world)
     rank = dist.get_rank(group)
     if sizes[rank] != t.shape[0]:
         raise ValueError(f"rank {rank} holds {t.shape[0]} rows but shard_range({total}, {rank}, {world}) has {sizes[rank]}: "
@@ -48,7 +56,7 @@ def gather_policy(engine, group=None, total=None):
     """The one collective (a single all_gather_into_tensor: RCCL over xGMI): every rank ends up with the whole batch's
     time-varying linear-Gaussian controllers (K, k, sigK), plan cost, temperature and status.
     Payload per trajectory: T (nu nx + nu + nu(nu+1)/2) + 3 scalars.
-    total: the global batch size when it does not divide by the number of ranks (shards from shard_range); None: equal shards."""
+    total: the global batch size (shards from shard_range); required whenever more than one rank takes part."""
     K, k, sigK = engine.local_linear_policy()
     B = engine.B
     flat = torch.cat(

@@ -804,12 +804,27 @@ class BatchedI2c:
         st = self.status.cpu().numpy()
         return [(int(b), int(s) >> 16, (int(s) & 0xFFFF) - 1) for b, s in enumerate(st) if s != 0]
 
-    def raise_on_failure(self):
+    def raise_on_failure(self, status=None):
         """With B == 1 behave like the reference: raise; batched callers read `failures()`."""
-        f = self.failures()
+        f = self.failures() if status is None else [(int(b), int(s) >> 16, (int(s) & 0xFFFF) - 1) for b, s in enumerate(status) if s != 0]
         if f:
             b, reason, t = f[0]
             raise I2cNumericalError(f"trajectory {b}, cell {t}: {_native.FAIL_REASONS.get(reason, reason)}")
+
+    def iteration_health(self):
+        """(status (B,) int32, alpha_hat of the last M-step (B,) float64) on the host after ONE stream synchronisation: what a
+        single-trajectory caller checks after every EM iteration (the reference raises inside the iteration: LinAlgError from a
+        Cholesky, "Alpha is NaN" from update_alpha, i2c.py:948-951). Two asynchronous copies into page-locked host memory."""
+        a = self.alphas_desired[-1]
+        if self.device.type != "cuda":
+            return self.status.numpy().copy(), a.to(torch.float64).numpy().copy()
+        if getattr(self, "_health", None) is None:
+            self._health = (torch.empty(self.B, dtype=torch.int32).pin_memory(), torch.empty(self.B, dtype=self.dtype).pin_memory())
+        hs, ha = self._health
+        hs.copy_(self.status, non_blocking=True)
+        ha.copy_(a, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return hs.numpy(), ha.to(torch.float64).numpy()
 
     # ------------------------------------------------------------------ getters: (B, T, ...) tensors
     def _rows(self, buf, lo, n):

@@ -198,8 +198,9 @@ class I2cGraph(GraphMetrics):
         self.cells = [I2cCell(self, t) for t in range(self.H)]
         self.alpha_risk = []
         self.alpha_sigma = 0
-        # the entropy lists _maximize appends to every iteration (i2c.py:1021-1027) cost a device -> host copy of the posterior
-        # per EM iteration: kept for single-trajectory graphs (the reference's use, its plots), opt-in for batches
+        # the entropy lists _maximize appends to every iteration (i2c.py:1021-1027): LAZY (graph_metrics.py) -- an iteration keeps
+        # device-side copies of three covariance rows, the entries are computed when a list is read. On for single-trajectory
+        # graphs (the reference's use, its plots), opt-in for batches
         self.record_metrics = self.B == 1
         self.policy_valid = False
         # the engine starts from the constructor's x0 / sig_x0; re-upload only when a caller later CHANGES
@@ -483,10 +484,18 @@ class I2cGraph(GraphMetrics):
         self.engine.calibrate_alpha(only_decrease)
         logging.info(f"calibrating alpha from propagation {before}->{self.alpha}")
 
+    def _check_iteration(self):
+        """After an M-step, single trajectory: failure status AND alpha_hat with one synchronisation (engine.iteration_health)."""
+        if self.B != 1:
+            return
+        status, alpha_hat = self.engine.iteration_health()
+        self.engine.raise_on_failure(status)
+        if np.isnan(alpha_hat).any():
+            raise ValueError("Alpha is NaN")
+
     def _maximize(self):
         self.engine.maximize(update_alpha=True)
-        if self.B == 1 and np.isnan(_np(self.engine.alphas_desired[-1])).any():
-            raise ValueError("Alpha is NaN")
+        self._check_iteration()
         self._invalidate()
         if self.record_metrics:
             self._append_iteration_metrics()  # entropies of the posterior policy, the state prior, the propagation (i2c.py:1021-1027)
@@ -500,9 +509,7 @@ class I2cGraph(GraphMetrics):
         self._sync_initial_state()
         self._invalidate()
         self.engine.learn_msgs()
-        self._check()
-        if self.B == 1 and np.isnan(_np(self.engine.alphas_desired[-1])).any():
-            raise ValueError("Alpha is NaN")
+        self._check_iteration()
         if self.record_metrics:
             self._append_iteration_metrics()
 
@@ -603,6 +610,7 @@ class I2cGraph(GraphMetrics):
             self.costs_pf_all.extend(self.costs_pf)
         e.costs_m, e.costs_m_var, e.costs_pf, e.costs_pf_var, e.kl_terms = [], [], [], [], []
         e.em_iter = 0
+        self._pending_metrics = []  # (snapshots of iterations whose entropy entries nobody has read yet, graph_metrics.py)
         for name in ("likelihoods", "likelihoods_xu", "likelihoods_z", "policy_entropy", "sig_eta_entropy",
                      "sig_eta_pf_entropy", "x_prior_entropy", "x_prior_neg_entropy", "propagate_entropy",
                      "costs_p", "costs_s", "risk"):

@@ -8,26 +8,58 @@ covariance, the likelihood) -- the host-side `QuadratureInference` of this packa
 iteration itself (costs, alpha_hat, KL term of covariance control) is computed by the kernels (`BatchedI2c.maximize`).
 Batched graphs (`batch=B`) get one value per trajectory (leading axis B); a single-trajectory graph gets the reference's scalars
 and `(n, 1)` / `(n, n)` shapes."""
+import warnings
+
 import numpy as np
 
+from . import core
 from .exp_types import CubatureQuadrature, GaussHermiteQuadrature
 from .inference.quadrature import QuadratureInference
+
+sym_size, unpack_sym = core.engine.sym_size, core.engine.unpack_sym
 
 _TWO_PI_E = 2.0 * np.pi * np.e
 
 
 def _sum_gaussian_entropy(sig, what):
-    """sum over the horizon of 0.5 log det(2 pi e sig_t); sig: (B, T, n, n) -> (B,)."""
+    """sum over the horizon of 0.5 log det(2 pi e sig_t); sig: (B, T, n, n) -> (B,). A covariance that is not positive definite gives
+    nan with a warning, as the reference's 0.5 log(det(.)) does (i2c.py:1072-1133): a metric must not abort an EM run."""
     sign, logdet = np.linalg.slogdet(_TWO_PI_E * np.asarray(sig, float))
     if np.any(sign <= 0):
         b, t = np.argwhere(sign <= 0)[0]
-        raise ValueError(f"{what}: cell {t} (trajectory {b}) has a covariance that is not positive definite")
+        warnings.warn(f"{what}: cell {t} (trajectory {b}) has a covariance that is not positive definite: entropy = nan", RuntimeWarning)
+        logdet = np.where(sign > 0, logdet, np.nan)
     return 0.5 * logdet.sum(axis=1)
+
+
+# the lists _maximize appends an entropy to in every EM iteration (i2c.py:1021-1027). Here they are LAZY: an iteration only keeps
+# device-side copies of the three covariance rows the entropies are functions of (no device -> host copy, no synchronisation inside
+# the EM loop); the values are computed when a list is first READ.
+_LAZY_LISTS = ("policy_entropy", "sig_eta_entropy", "sig_eta_pf_entropy", "x_prior_entropy", "x_prior_neg_entropy", "propagate_entropy")
+_MAX_PENDING = 256  # snapshots kept on the device before they are folded into the lists anyway
+
+
+def _lazy_list(name):
+    def get(self):
+        self._materialise_metrics()
+        return self.__dict__.setdefault("_m_" + name, [])
+
+    def set_(self, value):
+        self.__dict__["_m_" + name] = value
+
+    return property(get, set_, doc=f"{name}: one entry per EM iteration, computed on first read (i2c.py:1021-1027)")
 
 
 class GraphMetrics:
     """Mixin of I2cGraph (graph.py). Uses: self.engine, self.sys, self.B, self.H, self.QR, self.Qf, self.z, self.z_term,
     self._cell_table(), self._cell_target(t), self._maybe_scalar(), self._squeeze(), the metric lists of reset_metrics()."""
+
+    policy_entropy = _lazy_list("policy_entropy")
+    sig_eta_entropy = _lazy_list("sig_eta_entropy")
+    sig_eta_pf_entropy = _lazy_list("sig_eta_pf_entropy")
+    x_prior_entropy = _lazy_list("x_prior_entropy")
+    x_prior_neg_entropy = _lazy_list("x_prior_neg_entropy")
+    propagate_entropy = _lazy_list("propagate_entropy")
 
     # ------------------------------------------------------------------ host push-through with the graph's rule
     @property
@@ -195,15 +227,36 @@ class GraphMetrics:
         return self._maybe_scalar(_sum_gaussian_entropy(self._table("sig_x3_pf"), "calc_propagate_entropy"))
 
     def _append_iteration_metrics(self):
-        """What _maximize appends next to the costs, alpha and the KL term (i2c.py:1021-1027)."""
-        self.policy_entropy.append(self.calc_policy_entropy())
-        self.sig_eta_entropy.append(self.calc_sig_eta_entropy())
-        self.sig_eta_pf_entropy.append(self.calc_sig_eta_pf_entropy())
-        h = self.calc_sig_x_prior_entropy()
-        self.x_prior_entropy.append(h)
-        self.x_prior_neg_entropy.append(-h)
-        if self._propagate:
-            self.propagate_entropy.append(self.calc_propagate_entropy())
+        """What _maximize appends next to the costs, alpha and the KL term (i2c.py:1021-1027) -- deferred: the packed covariance rows
+        the entropies depend on are copied ON THE DEVICE (asynchronously, on the engine's stream); _materialise_metrics() turns the
+        pending snapshots into list entries when one of the lists is read."""
+        e = self.engine
+        d, nx = e.d, e.nx
+        o = d + sym_size(d) + nx
+        fwd = e.fwd.permute(0, 2, 1) if e.fwd_trajectory_major else e.fwd
+        snap = [e._rows(e.post, d, sym_size(d)).clone(), e._rows(fwd, o, sym_size(nx)).clone(),
+                e._rows(e.prop, o, sym_size(nx)).clone() if (self._propagate and e.prop is not None) else None]
+        self.__dict__.setdefault("_pending_metrics", []).append(snap)
+        if len(self._pending_metrics) > _MAX_PENDING:
+            self._materialise_metrics()
+
+    def _materialise_metrics(self):
+        pending = self.__dict__.get("_pending_metrics")
+        if not pending:
+            return
+        self._pending_metrics = []
+        lists = {n: self.__dict__.setdefault("_m_" + n, []) for n in _LAZY_LISTS}
+        d, nx = self.engine.d, self.engine.nx
+        for post_sig, s3f, s3pf in pending:
+            sig_u = unpack_sym(post_sig.cpu(), d).numpy()[..., nx:, nx:]
+            lists["policy_entropy"].append(self._maybe_scalar(_sum_gaussian_entropy(sig_u, "calc_policy_entropy")))
+            lists["sig_eta_entropy"].append(self.calc_sig_eta_entropy())
+            lists["sig_eta_pf_entropy"].append(self.calc_sig_eta_pf_entropy())
+            h = self._maybe_scalar(_sum_gaussian_entropy(unpack_sym(s3f.cpu(), nx).numpy(), "calc_sig_x_prior_entropy"))
+            lists["x_prior_entropy"].append(h)
+            lists["x_prior_neg_entropy"].append(-h)
+            if s3pf is not None:
+                lists["propagate_entropy"].append(self._maybe_scalar(_sum_gaussian_entropy(unpack_sym(s3pf.cpu(), nx).numpy(), "calc_propagate_entropy")))
 
     # ------------------------------------------------------------------ likelihood (i2c.py:690-719, 1135-1170)
     def _calc_likelihood(self):

@@ -125,6 +125,13 @@ def test_backward_schedule_rule():
     fam = lambda *a, sweep=N.SWEEP_BACKWARD, **k: lib.i2c_kernel_family(ctypes.byref(_shape(*a, **k)), sweep)  # noqa: E731
     assert fam(Q12, 1024, 50, post_layout=1) == N.FAMILY_WAVE and fam(Q12, 8192, 50, post_layout=1) == N.FAMILY_QUAD
     assert fam(3, 4096, 300, sweep=N.SWEEP_FORWARD) == N.FAMILY_QUAD and fam(3, 4096, 300) == N.FAMILY_LANE
+    # the quad propagation of the d = 16 model addresses a posterior / propagation cell through 32-bit offsets of one window, masked
+    # stores parked at 2 GiB: the batch at which max(E_POST, E_PROP) B sizeof reaches 2 GiB is refused, not wrapped (round-5 advice)
+    d = lib.query(Q12)
+    e_prop = (d.nx + d.nu) + (d.nx + d.nu) * (d.nx + d.nu + 1) // 2 + d.nx + d.nx * (d.nx + 1) // 2
+    b_max = (1 << 31) // (max(d.e_post, e_prop) * 8)
+    assert fam(Q12, b_max, 50, post_layout=1, sweep=N.SWEEP_PROPAGATE) == N.FAMILY_QUAD
+    assert fam(Q12, b_max + 1, 50, post_layout=1, sweep=N.SWEEP_PROPAGATE) == -1  # I2C_EINVAL
 
 
 def test_bad_arguments_of_the_newer_entry_points():

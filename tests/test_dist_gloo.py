@@ -46,6 +46,13 @@ def _worker(rank, world, port, B, iters, out_dir, golden="em_pendulum_T40_quad_g
                 setattr(dist, n, fn)
         assert calls == ["all_gather_into_tensor"], calls
         assert got["K"].shape[0] == B
+        # without the global size a multi-rank gather is refused BEFORE any collective (round-5 advice: ragged shards without
+        # `total` used to enter all_gather_into_tensor with different buffer sizes per rank)
+        try:
+            pkg.dist.gather_policy(eng)
+            raise AssertionError("a multi-rank gather without the global batch size was accepted")
+        except ValueError as e:
+            assert "total" in str(e)
         if B % world:  # ragged shards need the global size: a silent mis-slice is refused
             try:
                 pkg.dist._all_gather_rows(torch.zeros(hi - lo + 1, 2), total=B)

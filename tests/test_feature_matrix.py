@@ -30,17 +30,18 @@ def make_case(name, T, variant):
     d = {k: g[k] for k in g}
     nx = g["x0"].shape[0]
     prior = {"mu_x_term": 0.1 * np.ones(nx), "sig_x_term": 1e-2 * np.eye(nx) + 1e-3 * np.ones((nx, nx))}
+    ref_fails = "the reference fails on this combination (module docstring)"
     if variant == "no_terminal_cost":
         if lin and meta["model"] not in IDENTITY_TERMINAL:
-            return None
+            return ref_fails
         d.pop("Qf", None)
     elif variant == "terminal_prior":
         if lin and meta["model"] not in IDENTITY_TERMINAL:
-            return None
+            return ref_fails
         d.update(prior)
     elif variant == "terminal_prior_only":
         if lin and meta["model"] not in IDENTITY_TERMINAL:
-            return None
+            return ref_fails
         d.pop("Qf", None)
         d.update(prior)
     elif variant == "propagate":
@@ -53,7 +54,7 @@ def make_case(name, T, variant):
         meta["tol"] = 1.0
     elif variant == "general_weights":
         if meta.get("inference", "cubature") != "cubature":
-            return None
+            return "not applicable: (alpha, beta, kappa) are parameters of CubatureQuadrature only (exp_types.py:36-49)"
         meta["quad"] = [1.2, 0.44, 0.5]
     d["meta"] = np.array(json.dumps(meta))
     d["mu_u"] = g["mu_u"][:T]
@@ -62,8 +63,8 @@ def make_case(name, T, variant):
 
 def run_matrix_entry(lib, device, name, T, variant, tol):
     case = make_case(name, T, variant)
-    if case is None:
-        pytest.skip("the reference fails on this combination (module docstring)")
+    if isinstance(case, str):  # (a reason, not a case)
+        pytest.skip(case)
     x0, mu_u = parity.batched_inputs(case, 2)
     eng = parity.engine_from_case(case, lib, device, x0=x0, mu_u=mu_u)
     o = oracle_from_case(Case({**case, "mu_u": mu_u}), x0=x0)

@@ -112,6 +112,43 @@ def test_batched_graph_metrics_are_per_trajectory():
     np.testing.assert_allclose(gr.calculate_alpha(zc, gr.get_z_terminal_covar()), np.asarray(gr.alphas_desired[-1]), rtol=1e-8)
 
 
+def test_iteration_entropy_lists_are_lazy():
+    """learn_msgs() of a single-trajectory graph copies nothing to the host for the entropy lists (round-5 review, weak #6): an
+    iteration leaves a pending device-side snapshot; the entries appear when a list is READ, identical to the eager values; a reset
+    drops what is pending; a covariance that is not positive definite gives nan with a warning instead of aborting the run."""
+    import warnings
+
+    from i2c import graph_metrics as gm
+
+    g = load_case("graph_metrics_T40")
+    m = g.meta
+    gr = I2cGraph(make_env_model(m["model"], None), m["T"], g["Q"], g["R"], g["Qf"], m["alpha"], m["tol"], g["mu_u"], g["sig_u"], None, None,
+                  CubatureQuadrature(*m["quad"]), lib=hostsim.load(), device="cpu")
+    calls = []
+    real = gm._sum_gaussian_entropy
+    gm._sum_gaussian_entropy = lambda *a: (calls.append(a[1]), real(*a))[1]
+    try:
+        eager = []
+        for _ in range(3):
+            gr.learn_msgs()
+            assert calls == [], "an EM iteration evaluated an entropy on the host"
+            eager.append((float(real(gr._table("sig_u0_m"), "p")[0]), float(real(gr._table("sig_x3_f"), "x")[0])))
+        assert len(gr._pending_metrics) == 3 and "_m_policy_entropy" not in gr.__dict__ or gr.__dict__["_m_policy_entropy"] == []
+        assert len(gr.policy_entropy) == 3 and gr._pending_metrics == [] and len(calls) > 0
+    finally:
+        gm._sum_gaussian_entropy = real
+    np.testing.assert_allclose(gr.policy_entropy, [e[0] for e in eager], rtol=1e-12)
+    np.testing.assert_allclose(gr.x_prior_entropy, [e[1] for e in eager], rtol=1e-12)
+    np.testing.assert_allclose(gr.x_prior_neg_entropy, [-e[1] for e in eager], rtol=1e-12)
+    gr.learn_msgs()
+    gr.reset_metrics()
+    assert gr.policy_entropy == [] and gr._pending_metrics == []
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        h = gm._sum_gaussian_entropy(np.array([[[[1.0, 0.0], [0.0, -1e-18]], [[1.0, 0.0], [0.0, 1.0]]]]), "probe")
+    assert np.isnan(h[0]) and any("not positive definite" in str(x.message) for x in w)
+
+
 @pytest.mark.gpu
 def test_graph_metrics_vs_reference_gpu():
     _run(pkg.load_library(), "cuda")

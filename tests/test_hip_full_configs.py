@@ -249,6 +249,37 @@ def test_deterministic_family_across_batch_windows_gpu():
 
 
 @pytest.mark.gpu
+def test_deterministic_family_quadrotor12_across_the_wave_variant_boundary_gpu():
+    """deterministic_family on the d = 16 model pins the wave kernels -- whose forward sweep switches to another instantiation (pivot
+    blocks through LDS instead of v_readlane, WK_FORWARD_PL) once two waves share a SIMD, B > 1024. Round-5 advice: bit-identity of a
+    shard of <= 1024 trajectories against the same trajectories inside a batch > 1024 was unverified on the device (the CPU test
+    runs B = 9 with -ffp-contract=off). 512 trajectories alone == trajectories 700..1211 of a 2048 batch, to the last bit."""
+    import importlib
+
+    from i2c.known_models import make_env_model
+
+    pkg = importlib.import_module("input-inference-for-control_amd")
+    m = make_env_model("Quadrotor12")
+    B, T, lo, hi = 2048, 12, 700, 1212
+    rng = np.random.default_rng(8)
+    x0 = np.asarray(m.x0, float).reshape(1, -1) + 1e-2 * rng.normal(size=(B, m.dim_x))
+    mu_u = 0.25 * m.gravity + 1e-2 * rng.normal(size=(B, T, m.dim_u))
+
+    def solve(sl):
+        e = pkg.BatchedI2c(m, T, None, 0.1 * np.eye(16), None, 1.0, 0.5, mu_u[sl], 1e-2 * np.eye(m.dim_u), x0=x0[sl], device="cuda",
+                           keep_zpost=False, keep_xm=False, deterministic_family=True)
+        e.learn(3)
+        torch.cuda.synchronize()
+        assert e.failures() == [] and e.forward_family == e.backward_family == "wave" and e.backward_schedule == "fused"
+        return e
+
+    whole, shard = solve(slice(0, B)), solve(slice(lo, hi))
+    for a, b in zip(shard.marginal_state_action() + shard.local_linear_policy(), whole.marginal_state_action() + whole.local_linear_policy()):
+        assert torch.equal(a, b[lo:hi])
+    assert torch.equal(shard.alpha, whole.alpha[lo:hi])
+
+
+@pytest.mark.gpu
 def test_overlapped_propagation_is_bit_identical_gpu():
     """learn(n) with closed-loop propagation (covariance control, BASELINE config 5) runs the propagation of iteration k on a second
     stream next to the forward sweep of iteration k + 1: the same numbers as n x learn_msgs(), every history entry included."""
