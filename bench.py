@@ -464,6 +464,80 @@ def extra_config_legs(pkg, device, K=10):
     return out
 
 
+def reference_shape_legs(pkg, device, lib=None, scale=1.0):
+    """The shapes the REFERENCE itself runs -- one trajectory (B = 1) -- driven the way its scripts drive them: through the drop-in
+    facade, `I2cGraph.learn_msgs()` in a Python loop (scripts/i2c_run.py:89-94) and `PartiallyObservedMpcPolicy.__call__`
+    (i2c/policy/mpc.py:156-182), each beside the reference's own CPU figure of BASELINE.md section 2 (one core of the survey
+    container; a stated baseline, not measured on this box). `kernel_ms` = the same iterations enqueued by ONE library call on a
+    plain engine (BatchedI2c.learn: no Python between the sweeps); `host_ms` = what the facade's per-iteration Python, ctypes calls,
+    failure check (one synchronisation per iteration: the reference raises inside the iteration) and bookkeeping add to it."""
+    from i2c.exp_types import CubatureQuadrature
+    from i2c.i2c import I2cGraph
+    from i2c.known_models import make_env_model
+    from i2c.policy.mpc import PartiallyObservedMpcPolicy
+
+    device = torch.device(device)
+    sync = (lambda: torch.cuda.synchronize(device)) if device.type == "cuda" else (lambda: None)  # noqa: E731
+    out = {}
+
+    def em_leg(tag, model, T, Q, R, Qf, alpha, tol, sig_u, mu_u, ref_its, n=60):
+        n = max(int(n * scale), 2)
+        g = I2cGraph(make_env_model(model), T, Q, R, Qf, alpha, tol, mu_u, sig_u, None, None, CubatureQuadrature(1, 0, 0), device=device, lib=lib)
+        for _ in range(max(int(100 * scale), 5)):  # (warm: a lone wave's sweep is a chain of dependent instructions, its time is 1 / clock)
+            g.learn_msgs()
+        g.reset_metrics()
+        sync(); t0 = time.perf_counter()
+        for _ in range(n):
+            g.learn_msgs()
+        sync()
+        facade_ms = (time.perf_counter() - t0) / n * 1e3
+        n_lists = len(g.costs_m)  # (the lists the runner prints: read once, after the loop, as scripts/i2c_run.py:108-114 does)
+        eng = pkg.BatchedI2c(make_env_model(model), T, Q, R, Qf, alpha, tol, mu_u[None], sig_u, device=device, keep_zpost=False, keep_xm=False, lib=lib)
+        eng.learn(5)
+        sync(); t0 = time.perf_counter(); eng.learn(n); sync()
+        kernel_ms = (time.perf_counter() - t0) / n * 1e3
+        out[tag] = {"facade_ms_per_em_iter": facade_ms, "em_iters_per_s": 1e3 / facade_ms, "kernel_ms": kernel_ms, "host_ms": facade_ms - kernel_ms,
+                    "facade_over_engine_learn": facade_ms / kernel_ms, "reference_em_iters_per_s_1core": ref_its,
+                    "vs_reference_1core": (1e3 / facade_ms) / ref_its, "iterations": n, "history_entries": n_lists,
+                    "forward_family": g.engine.forward_family, "backward": g.engine.backward_schedule, "failed_trajectories": len(g.engine.failures())}
+
+    rs = np.random.RandomState(0)
+    Qp = np.diag([1.0, 100.0, 1.0])
+    em_leg("pendulum_T100_B1", "PendulumKnown", 100, Qp, np.diag([2.0]), Qp, 100.0, 0.0, 2.0 * np.eye(1), 1e-2 * rs.randn(100, 1), 13.6)
+    em_leg("pendulum_T200_B1", "PendulumKnown", 200, Qp, np.diag([2.0]), Qp, 100.0, 0.0, 2.0 * np.eye(1), 1e-2 * rs.randn(200, 1), 6.35)
+    Qd = 1e-3 * np.diag([1.0, 1.0, 100.0, 1.0, 100.0, 10.0, 1.0, 1.0])
+    em_leg("double_cartpole_T300_B1", "DoubleCartpoleKnown", 300, Qd, 1e-3 * np.diag([0.1]), Qd, 0.05, 0.99, np.eye(1), 1e-2 * rs.randn(300, 1), 3.75, n=30)
+
+    # MPC control step, H = 10, n_iter = 2, one closed loop, feed-forward and feedback (BASELINE.md: 6 / 12 ms on the stand-in model)
+    for tag, ff, ref_ms in (("mpc_pendulum_H10_B1_feedforward", True, 6.0), ("mpc_pendulum_H10_B1_feedback", False, 12.0)):
+        model = make_env_model("PendulumKnown")
+        model.sig_zeta = 1e-4 * np.eye(model.dim_y if hasattr(model, "dim_y") else 3)
+        H = 10
+        i2c = I2cGraph(model, H, Qp, np.diag([2.0]), Qp, 10.0, 1.0, np.zeros((H, 1)), 2.0 * np.eye(1), None, None, CubatureQuadrature(1, 0, 0), device=device, lib=lib)
+        i2c._propagate = True
+        steps = max(int(60 * scale), 14)
+        z_traj = np.tile(np.asarray(model.zg, float).reshape(1, -1), (steps + H + 10, 1))
+        pol = PartiallyObservedMpcPolicy(i2c, 2, 2.0 * np.eye(1), z_traj)
+        pol.set_control(feedforward=ff)
+        i2c.calibrate_alpha()
+        pol.optimize(8, model.x0, model.sig_x0)
+        i2c.calibrate_alpha()
+        x = np.asarray(model.x0, float).reshape(1, -1)
+        u = np.zeros((1, 1))
+        ts = []
+        for t in range(steps):
+            y = model.measure(x).reshape(-1, 1)
+            sync(); t0 = time.perf_counter()
+            u = np.clip(pol(t, y, u.reshape(-1, 1)), -2.0, 2.0)
+            sync()
+            ts.append(time.perf_counter() - t0)
+            x = model.dynamics(np.concatenate((x, u.reshape(1, -1)), axis=1)).reshape(1, -1)
+        ms = float(np.median(ts[10:])) * 1e3
+        out[tag] = {"ms_per_control_step": ms, "reference_ms_per_control_step_1core": ref_ms, "vs_reference_1core": ref_ms / ms, "steps": steps - 10,
+                    "em_iters_per_step": 2, "horizon": H, "history_recorded": bool(pol.record_history), "failed_trajectories": len(i2c.engine.failures())}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -675,6 +749,7 @@ def main():
             out["saturated_batch_fp32_storage"] = mixed
         if not args.no_extra and world == 1:
             out["extra"] = extra_config_legs(pkg, device)
+            out["extra"]["reference_shapes"] = reference_shape_legs(pkg, device)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(T)
     # the JSON line is the LAST thing on stdout: tear the process group down first and flush the C runtime's buffer (RCCL prints a

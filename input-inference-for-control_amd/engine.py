@@ -62,6 +62,7 @@ class BatchedI2c:
         if device is None:
             device = "cpu" if self.lib.is_host_sim else "cuda"
         self.device = torch.device(device)
+        self._dev_index = None
         if self.lib.is_host_sim != (self.device.type == "cpu"):
             raise RuntimeError(
                 f"library '{self.lib.build_info}' cannot run on device {self.device}: the HIP build needs a "
@@ -392,7 +393,15 @@ class BatchedI2c:
         self._problem = self._make_problem()
 
     def _stream(self):
+        """The caller's current HIP stream on the engine's device (what torch.cuda.current_stream(device).cuda_stream returns, read
+        through the raw accessor: three sweeps per EM iteration ask for it, and the Stream-object path costs ~9 us each -- a tenth of
+        a single-trajectory iteration's host time)."""
         if self.device.type == "cuda":
+            if self._dev_index is None:
+                self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+            if raw is not None:
+                return C.c_void_p(raw(self._dev_index))
             return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         return None
 

@@ -36,7 +36,7 @@ def _sum_gaussian_entropy(sig, what):
 # device-side copies of the three covariance rows the entropies are functions of (no device -> host copy, no synchronisation inside
 # the EM loop); the values are computed when a list is first READ.
 _LAZY_LISTS = ("policy_entropy", "sig_eta_entropy", "sig_eta_pf_entropy", "x_prior_entropy", "x_prior_neg_entropy", "propagate_entropy")
-_MAX_PENDING = 256  # snapshots kept on the device before they are folded into the lists anyway
+_MAX_PENDING_BYTES = 256 << 20  # device memory the pending snapshots may hold before they are folded into the lists anyway
 
 
 def _lazy_list(name):
@@ -233,11 +233,15 @@ class GraphMetrics:
         e = self.engine
         d, nx = e.d, e.nx
         o = d + sym_size(d) + nx
+        # raw [T][rows][B] slices in the buffers' own row order (a sum over the horizon does not care where the ring starts)
         fwd = e.fwd.permute(0, 2, 1) if e.fwd_trajectory_major else e.fwd
-        snap = [e._rows(e.post, d, sym_size(d)).clone(), e._rows(fwd, o, sym_size(nx)).clone(),
-                e._rows(e.prop, o, sym_size(nx)).clone() if (self._propagate and e.prop is not None) else None]
-        self.__dict__.setdefault("_pending_metrics", []).append(snap)
-        if len(self._pending_metrics) > _MAX_PENDING:
+        snap = [e.post[:, d: d + sym_size(d)].clone(),  # (e.post is logically [T][e][B] whatever its storage layout)
+                fwd[:, o: o + sym_size(nx)].clone(),
+                e.prop[:, o: o + sym_size(nx)].clone() if (self._propagate and e.prop is not None) else None]
+        pend = self.__dict__.setdefault("_pending_metrics", [])
+        pend.append(snap)
+        nbytes = sum(x.numel() * x.element_size() for x in snap if x is not None)
+        if len(pend) * nbytes > _MAX_PENDING_BYTES:
             self._materialise_metrics()
 
     def _materialise_metrics(self):
@@ -247,16 +251,17 @@ class GraphMetrics:
         self._pending_metrics = []
         lists = {n: self.__dict__.setdefault("_m_" + n, []) for n in _LAZY_LISTS}
         d, nx = self.engine.d, self.engine.nx
+        rows = lambda x, n: unpack_sym(x.permute(2, 0, 1).cpu(), n).numpy()  # noqa: E731  [T][sym][B] -> (B, T, n, n)
         for post_sig, s3f, s3pf in pending:
-            sig_u = unpack_sym(post_sig.cpu(), d).numpy()[..., nx:, nx:]
+            sig_u = rows(post_sig, d)[..., nx:, nx:]
             lists["policy_entropy"].append(self._maybe_scalar(_sum_gaussian_entropy(sig_u, "calc_policy_entropy")))
             lists["sig_eta_entropy"].append(self.calc_sig_eta_entropy())
             lists["sig_eta_pf_entropy"].append(self.calc_sig_eta_pf_entropy())
-            h = self._maybe_scalar(_sum_gaussian_entropy(unpack_sym(s3f.cpu(), nx).numpy(), "calc_sig_x_prior_entropy"))
+            h = self._maybe_scalar(_sum_gaussian_entropy(rows(s3f, nx), "calc_sig_x_prior_entropy"))
             lists["x_prior_entropy"].append(h)
             lists["x_prior_neg_entropy"].append(-h)
             if s3pf is not None:
-                lists["propagate_entropy"].append(self._maybe_scalar(_sum_gaussian_entropy(unpack_sym(s3pf.cpu(), nx).numpy(), "calc_propagate_entropy")))
+                lists["propagate_entropy"].append(self._maybe_scalar(_sum_gaussian_entropy(rows(s3pf, nx), "calc_propagate_entropy")))
 
     # ------------------------------------------------------------------ likelihood (i2c.py:690-719, 1135-1170)
     def _calc_likelihood(self):
