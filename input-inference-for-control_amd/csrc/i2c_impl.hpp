@@ -445,25 +445,36 @@ static int launch_quad_forward(const Consts<M, R>& c, const A& a, void* stream) 
   return unit ? launch_quad_forward_g<M, R, S, false>(c, a, stream) : I2C_ENOTSUP;
 }
 
-// the quad backward sweep (backward_quad_body): d = 16 models with identity observations
+// the quad backward sweep: d = 16 models with identity observations (backward_quad_body, trajectory-major buffers), and -- round 6 --
+// every model of the d <= 8 geometry (backward_quad8_body: sigma-point observations, actions that share a block with states)
 template <class M> constexpr bool quad_backward_exists() {
-  return QG<M>::WIDE && M::NX % 4 == 0 && (M::NX + M::NU) % 4 == 0 && M::NU <= 4 && M::NZ == M::NX + M::NU && st_identity<ObsStruct<M>, M::NZ>() &&
-         (M::NZT == 0 || (M::NZT == M::NX && st_identity<TermStruct<M>, M::NZT>()));
+  if constexpr (!QG<M>::WIDE) return quad_backward8_exists<M>();
+  else
+    return M::NX % 4 == 0 && (M::NX + M::NU) % 4 == 0 && M::NU <= 4 && M::NZ == M::NX + M::NU && st_identity<ObsStruct<M>, M::NZ>() &&
+           (M::NZT == 0 || (M::NZT == M::NX && st_identity<TermStruct<M>, M::NZT>()));
+}
+// LDS region of one trajectory: the staged cell block of the d = 16 form, the sigma-point geometry of the d <= 8 one
+template <class M> constexpr int quad_backward_lds() { return QG<M>::WIDE ? QBG<M>::SIZE : QG<M>::SIZE; }
+template <class M, typename R, typename S, bool GENERAL, bool LEANQ, class KC, class A>
+I2C_FN void quad_backward_dispatch(const Consts<M, R>& c, const KC& kc, const A& a, const int b, const bool live, const Quad<R>& q) {
+  if constexpr (QG<M>::WIDE) backward_quad_body<M, R, S>(c, kc, a, b, live, q);
+  else backward_quad8_body<M, R, S, GENERAL, LEANQ>(c, kc, a, b, live, q);
 }
 #ifdef I2C_HOST_SIM
-template <class M, typename R, typename S, class A>
-static int launch_quad_backward(const Consts<M, R>& c, const A& a, void*) {
+template <class M, typename R, typename S, bool GENERAL, bool LEANQ, class A>
+static int launch_quad_backward_g(const Consts<M, R>& c, const A& a, void*) {
   QBConst<M, R> kc;
   qbconst_fill<M, R>(kc, &c, 0, 1);
+  constexpr int LSZ = quad_backward_lds<M>();
   for (int b0 = 0; b0 < c.B; b0 += 4) {
-    std::vector<R> sh((size_t)4 * QBG<M>::SIZE, R(0)), xch(128, R(0));
+    std::vector<R> sh((size_t)4 * LSZ, R(0)), xch(128, R(0));
     HostBarrier bar(64);
     std::vector<std::thread> lanes;
     for (int l = 0; l < 64; ++l)
       lanes.emplace_back([&, l, b0] {
         const int g = (l >> 2) & 3, b = b0 + g;
         const bool live = b < c.B;
-        backward_quad_body<M, R, S>(c, kc, a, live ? b : c.B - 1, live, Quad<R>{l, l >> 4, g, l & 3, sh.data() + g * QBG<M>::SIZE, &bar, xch.data()});
+        quad_backward_dispatch<M, R, S, GENERAL, LEANQ>(c, kc, a, live ? b : c.B - 1, live, Quad<R>{l, l >> 4, g, l & 3, sh.data() + g * LSZ, &bar, xch.data()});
       });
     for (auto& th : lanes) th.join();
   }
@@ -471,28 +482,46 @@ static int launch_quad_backward(const Consts<M, R>& c, const A& a, void*) {
 }
 #else
 constexpr int QB_WAVES_PER_BLOCK = 4;
-template <class M, typename R, typename S, class A>
+template <class M, typename R, typename S, class A, bool GENERAL = false, bool LEANQ = false>
 __global__ __launch_bounds__(64 * QB_WAVES_PER_BLOCK, 2) void k_quad_backward(const Consts<M, R> c, const A a) {
-  constexpr int WPB = QB_WAVES_PER_BLOCK;
+  constexpr int WPB = QB_WAVES_PER_BLOCK, LSZ = quad_backward_lds<M>();
   __shared__ QBConst<M, R> kc;
-  __shared__ R sh[WPB * 4 * QBG<M>::SIZE];
+  __shared__ R sh[WPB * 4 * LSZ];
   qbconst_fill<M, R>(kc, (const Consts<M, R>*)__builtin_amdgcn_kernarg_segment_ptr(), (int)threadIdx.x, 64 * WPB);
   __syncthreads();
   const int l = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6), g = (l >> 2) & 3;
-  const long b0 = 4L * ((long)blockIdx.x * WPB + wv);  // (trajectory-major buffers: nothing is shared between waves)
+  // d = 16: trajectory-major buffers, nothing is shared between waves. d <= 8: the four waves of a workgroup take consecutive
+  // groups of four trajectories -- together one 128-byte line of every [B]-contiguous row (as k_quad_forward)
+  const long b0 = 4L * ((long)blockIdx.x * WPB + wv);
   if (b0 >= c.B) return;  // (wave-uniform: no trajectory in this wave)
   const long b = b0 + g;
   const bool live = b < c.B;
-  const Quad<R> q{l, l >> 4, g, l & 3, (lds_ptr<R>)(sh + (wv * 4 + g) * QBG<M>::SIZE)};
-  backward_quad_body<M, R, S>(c, kc, a, (int)(live ? b : c.B - 1), live, q);
+  const Quad<R> q{l, l >> 4, g, l & 3, (lds_ptr<R>)(sh + (wv * 4 + g) * LSZ)};
+  quad_backward_dispatch<M, R, S, GENERAL, LEANQ>(c, kc, a, (int)(live ? b : c.B - 1), live, q);
 }
-template <class M, typename R, typename S, class A>
-static int launch_quad_backward(const Consts<M, R>& c, const A& a, void* stream) {
+template <class M, typename R, typename S, bool GENERAL, bool LEANQ, class A>
+static int launch_quad_backward_g(const Consts<M, R>& c, const A& a, void* stream) {
   constexpr int WPB = QB_WAVES_PER_BLOCK;
-  hipLaunchKernelGGL((k_quad_backward<M, R, S, A>), dim3((unsigned)(((long)c.B + 4 * WPB - 1) / (4 * WPB))), dim3(64 * WPB), 0, (hipStream_t)stream, c, a);
+  hipLaunchKernelGGL((k_quad_backward<M, R, S, A, GENERAL, LEANQ>), dim3((unsigned)(((long)c.B + 4 * WPB - 1) / (4 * WPB))), dim3(64 * WPB), 0, (hipStream_t)stream, c, a);
   return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
 }
 #endif
+// unit weights (lam = 0, every shipped config), or the GENERAL variant where the model has it (Impl::quad_supported has checked);
+// d <= 8: the lean variant when no optional output is asked for
+template <class M, typename R, typename S, class A>
+static int launch_quad_backward(const Consts<M, R>& c, const A& a, void* stream) {
+  const bool unit = c.rule_xu.unit && c.rule_x.unit && c.rule_xu.w0 == R(0) && c.rule_x.w0 == R(0);
+  if constexpr (QG<M>::WIDE) {
+    return unit ? launch_quad_backward_g<M, R, S, false, false>(c, a, stream) : I2C_ENOTSUP;
+  } else {
+    const bool lean = !a.xm && !a.zpost && !a.cell_stats;
+    if constexpr (quad_general_exists<M>()) {
+      if (!unit) return lean ? launch_quad_backward_g<M, R, S, true, true>(c, a, stream) : launch_quad_backward_g<M, R, S, true, false>(c, a, stream);
+    }
+    if (!unit) return I2C_ENOTSUP;
+    return lean ? launch_quad_backward_g<M, R, S, false, true>(c, a, stream) : launch_quad_backward_g<M, R, S, false, false>(c, a, stream);
+  }
+}
 
 // the quad propagation (propagate_quad_body): d = 16 models with identity observations
 #ifdef I2C_HOST_SIM
@@ -712,6 +741,15 @@ template <class M> struct bwd_fused_min_b<M, std::void_t<decltype(M::BWD_FUSED_M
   static constexpr int value = M::BWD_FUSED_MIN_B;
 };
 
+// batch window in which the d <= 8 quad backward sweep is the model's DEFAULT (measured per model, i2c_models.hpp:
+// QUAD_BACKWARD8_MIN_B / _MAX_B); models without the pair: on request only
+template <class M, class = void> struct quad_backward_window {
+  static constexpr int min_b = 0, max_b = -1;
+};
+template <class M> struct quad_backward_window<M, std::void_t<decltype(M::QUAD_BACKWARD8_MAX_B)>> {
+  static constexpr int min_b = M::QUAD_BACKWARD8_MIN_B, max_b = M::QUAD_BACKWARD8_MAX_B;
+};
+
 // ---- per-(model, dtype) entry points ------------------------------------------------------
 // Which kernels serve a call:
 //   M::GROUP      lanes per trajectory of the model's group kernels (0: none compiled); fp64 only
@@ -819,10 +857,22 @@ template <class M, typename R, typename S = R> struct Impl {
     }
     if constexpr (HAS_QUAD) {  // forward sweep: on request, or the model's default inside its batch window
       const bool asked = p->group_lanes == I2C_LANES_QUAD || (p->group_lanes == 64 && !M::WAVE);
-      // (the backward sweep of the d = 16 form: the fused walk, with the forward sweep -- an explicit two-pass request keeps the wave form)
-      const bool sweep_ok = sweep == I2C_SWEEP_FORWARD || (sweep == I2C_SWEEP_BACKWARD && HAS_QUAD_BACKWARD && p->backward_mode != I2C_BWD_TWO_PASS);
-      const int min_b = sweep == I2C_SWEEP_BACKWARD && M::QUAD_BACKWARD_MIN_B > M::QUAD_FORWARD_MIN_B ? M::QUAD_BACKWARD_MIN_B : M::QUAD_FORWARD_MIN_B;
-      if (sweep_ok && (asked || (p->group_lanes == 0 && p->B >= min_b && p->B <= M::QUAD_FORWARD_MAX_B))) {
+      bool sweep_ok = sweep == I2C_SWEEP_FORWARD;
+      int min_b = M::QUAD_FORWARD_MIN_B, max_b = M::QUAD_FORWARD_MAX_B;
+      if (sweep == I2C_SWEEP_BACKWARD && HAS_QUAD_BACKWARD) {
+        if constexpr (QG<M>::WIDE) {
+          // (the backward sweep of the d = 16 form: the fused walk, with the forward sweep -- an explicit two-pass request keeps the wave form)
+          sweep_ok = p->backward_mode != I2C_BWD_TWO_PASS;
+          min_b = M::QUAD_BACKWARD_MIN_B > M::QUAD_FORWARD_MIN_B ? M::QUAD_BACKWARD_MIN_B : M::QUAD_FORWARD_MIN_B;
+        } else {
+          // d <= 8 (round 6): the fused walk of four trajectories per wavefront, ONE pass over the forward messages. On request
+          // (with the schedule left open or asked to be the fused walk: chunked / two-pass are lane schedules), or as the model's
+          // default inside its own measured window (quad_backward_window; I2C_BWD_AUTO only)
+          sweep_ok = asked ? (p->backward_mode == I2C_BWD_AUTO || p->backward_mode == I2C_BWD_FUSED) : p->backward_mode == I2C_BWD_AUTO;
+          min_b = quad_backward_window<M>::min_b, max_b = quad_backward_window<M>::max_b;
+        }
+      }
+      if (sweep_ok && (asked || (p->group_lanes == 0 && p->B >= min_b && p->B <= max_b))) {
         const int rc = quad_supported(p, c);
         if (rc == I2C_OK) return I2C_FAMILY_QUAD;
         if (asked) return rc;

@@ -340,13 +340,16 @@ template <int NL, int NB, int K, typename R> I2C_FN void q_pivot_send(const Quad
   q_pivot_fetch<NL>(dg, d);
 }
 // d: pivot block K, fetched by the caller (the previous step, or q_elim)
+// awk (optional): receives the inverse pivot factors, awk[K] = (l_K^-1)^T as a resident block -- i.e. the INVERSE of the diagonal
+// block (K, K) of L^T (rows >= the live rows: identity) -- for a blocked back substitution with L^T afterwards (backward_quad8_body)
 template <int K, int NB, int N, int NC1, int NC2, bool R2LOW = false, bool R1ANTI = false, typename R>
-I2C_FN void q_elim_step(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* last, R* d) {
+I2C_FN void q_elim_step(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* last, R* d, R* awk = nullptr) {
   constexpr int NL = q_live_rows<N, K>();
   R aw, pl;
   q_pivot_settle<NL>(d);
   q_pivot_algebra<NL>(q, d, &aw, &pl);
   if (K == NB - 1) *last = pl;
+  if (awk) awk[K] = aw;
   q_elim_scale_lt<K, NB>(q, aw, s, lt);
   if constexpr (K + 1 < NB) {
     R dn[10];
@@ -357,17 +360,17 @@ I2C_FN void q_elim_step(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* last, R*
     q_elim_scale_rhs<K, NC1, NC2, R2LOW, R1ANTI>(q, aw, r1, r2);
     q_elim_below<K, NB, NC1, NC2, R2LOW, R1ANTI>(q, s, r1, r2, lt);
     q_sched_fence();
-    q_elim_step<K + 1, NB, N, NC1, NC2, R2LOW, R1ANTI>(q, s, r1, r2, lt, last, dn);
+    q_elim_step<K + 1, NB, N, NC1, NC2, R2LOW, R1ANTI>(q, s, r1, r2, lt, last, dn, awk);
   } else {
     q_elim_scale_rhs<K, NC1, NC2, R2LOW, R1ANTI>(q, aw, r1, r2);
   }
 }
-template <int N, int NC1, int NC2, bool R2LOW = false, bool R1ANTI = false, typename R> I2C_FN bool q_elim(const Quad<R>& q, R* s, R* r1, R* r2, R* lt) {
+template <int N, int NC1, int NC2, bool R2LOW = false, bool R1ANTI = false, typename R> I2C_FN bool q_elim(const Quad<R>& q, R* s, R* r1, R* r2, R* lt, R* awk = nullptr) {
   constexpr int NB = (N + 3) / 4;
   static_assert(!R1ANTI || NC1 == NB, "R1ANTI: a square right-hand side");
   R last = R(0), d[10];
   q_pivot_send<q_live_rows<N, 0>(), NB, 0>(q, s, Q_O_DG, d);
-  q_elim_step<0, NB, N, NC1, NC2, R2LOW, R1ANTI>(q, s, r1, r2, lt, &last, d);
+  q_elim_step<0, NB, N, NC1, NC2, R2LOW, R1ANTI>(q, s, r1, r2, lt, &last, d, awk);
   return last > R(0);
 }
 // two eliminations of the same dimension in lockstep: (sa; ra1, ra2) -> lta and (sb; rb1) -> ltb
@@ -1744,6 +1747,416 @@ I2C_HD inline void backward_quad_body(const Consts<M, R>& c, const KC& kc, const
     }
   }
   const R sm = q_sum16(qw, acc_m), sv = q_sum16(qw, acc_v);
+  if (lead) {
+    a.term_stats[B + b] = sm;
+    a.term_stats[2 * B + b] = sv;
+    if (fail != 0 && a.status[b] == 0) a.status[b] = fail;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward sweep (i2c.py:882-886 over :544-610), d <= 8: every model of the forward kernel's d <= 8 geometry (round 6)
+// ------------------------------------------------------------------------------------------
+// The fused walk T-1 .. 0 of FOUR trajectories per wavefront on the common [T][E][B] buffers: ONE pass over the forward messages
+// (E_FWD elements read, E_POST written per cell: the algorithmic bytes) where the chunked lane schedule makes three (compose +
+// stitch + walk: 1.5 - 1.7x the bytes, profiles/r5_*_pmc_traffic.json). What this form has that the d = 16 one lacks:
+//   * the posterior observation through SIGMA POINTS (i2c.py:594-596 for a general sys.observe: q_points / q_moments on the smoothed
+//     joint, the forward kernel's building blocks), and the terminal observation the same way at the end of the chain (:567-570);
+//   * actions that share a block with states: the controller is read off ONE factorisation of the smoothed joint -- lt = chol(sig)^T
+//     serves the sigma points AND the controller:  K L_xx = L_ux  as a blocked back substitution with the upper blocks of lt and
+//     the inverses of its 4 x 4 diagonal blocks (a by-product of the pivot algebra, q_elim's awk),  sigK = L_uu L_uu^T  (the lane
+//     kernels read the same controller off the same factor: cell_posterior, i2c_cell.hpp).
+// The forward rows of a cell are fetched a cell AHEAD (registers); cubature rule with lam = 0, or any (alpha, beta, kappa) for the
+// models that have the GENERAL moments (quad_general_exists); fp64 or fp32-stored messages.
+template <class M> constexpr bool quad_backward8_exists() {
+  constexpr int D = M::NX + M::NU;
+  return !QG<M>::WIDE && D <= 8 && (M::NX % 4) + M::NU <= 4 && M::NZ <= 12 && M::NZT <= 12;
+}
+// Cell blocks of the [E][B] buffers for the lanes of a quad wave, with the address of an element split three ways: the block part
+// k (a compile-time constant after unrolling) x the row stride goes into the instruction's SCALAR offset; the lane part -- lane_e rows
+// + the trajectory's offset, or, for a lane that holds padding, an offset parked out of the buffer window -- is ONE loop-invariant
+// register per lane pattern, shared by every access of that pattern. A parked load returns 0 (the buffer unit's range check) and a
+// parked store is dropped: zero padding and store predicates cost no instruction inside the time loop. (The forward kernel computes
+// (lane_e + k) * rb + bo and a select per access: 370 of the 535 vector instructions of this sweep's first version were such.)
+template <typename R, typename S> struct QIO8 {
+  unsigned rb, bo;
+  static constexpr unsigned PARK = 0x80000000u;
+  I2C_MEM unsigned lane(const bool on, const int lane_e) const { return on ? (unsigned)lane_e * rb + bo : PARK; }
+  I2C_MEM R ld(const Window& w, const unsigned off, const int k) const {
+#ifdef I2C_HOST_SIM
+    if (off == PARK) return R(0);
+#endif
+    return (R)wld<S>(w, (unsigned)k * rb, off);
+  }
+  I2C_MEM void st(const Window& w, const unsigned off, const int k, const R v) const {
+#ifdef I2C_HOST_SIM
+    if (off == PARK) return;
+#endif
+    wst(w, (unsigned)k * rb, off, (S)v);
+  }
+};
+// LEANQ: no optional outputs (smoothed state per cell, observation moments, per-cell cost statistics): what i2c_learn / i2c_mpc_step
+// run. Compiled out, not branched over: a store behind a run-time branch costs the lone wave an s_waitcnt vmcnt(0) per cell.
+template <class M, typename R, typename S, bool GENERAL = false, bool LEANQ = false, class KC>
+I2C_HD inline void backward_quad8_body(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>& a_in, const int b, const bool live, const Quad<R>& q) {
+  CellArgs<R, S> a = a_in;
+  if (LEANQ) a.xm = nullptr, a.zpost = nullptr, a.cell_stats = nullptr;
+  using C = Consts<M, R>;
+  using G = QG<M>;
+  constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D, NT = C::NZT1, QLD = G::QLD;
+  constexpr int NBX = (NX + 3) / 4, NBD = (D + 3) / 4, NBZ = (NZ + 3) / 4, NBT = (NT + 3) / 4;
+  static_assert(quad_backward8_exists<M>(), "quad backward sweep (d <= 8): the actions live in one block");
+  static_assert(!GENERAL || quad_general_exists<M>(), "general cubature weights: sigma-point observations and a spare pair row for the centre");
+  constexpr bool OBS_ID = st_identity<ObsStruct<M>, NZ>() && NZ == D;
+  constexpr bool TERM_ID = NZT > 0 && st_identity<TermStruct<M>, NT>() && NT == NX;
+  constexpr int JU = NX / 4, CU = NX % 4;  // the block (row and column) and the in-block offset where the action entries start
+  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX);
+  constexpr int O_K = D + sym(D), O_k = O_K + NU * NX, O_SK = O_k + NU;
+  const int r = q.r, cc = q.c;
+  const unsigned long B = c.B;
+  const int T = c.T;
+  const unsigned WS = sizeof(S), bo = (unsigned)b * WS, rb = (unsigned)(B * WS);
+  const bool lead = live && q.p() == 0;
+  const Rule<R>& rule = c.rule_xu;
+  auto xrow = [&](const int i) { return 4 * i + r; };
+  auto xcol = [&](const int j) { return 4 * j + cc; };
+  // packed-symmetric element (row, col) of block (i, j), i <= j, split into its per-lane and its per-block part (forward_quad_body)
+  const int hi = r > cc ? r : cc, lo = r > cc ? cc : r;
+  const int tri_c = cc * (cc + 1) / 2 + r, tri_d = hi * (hi + 1) / 2 + lo;
+  auto sym_lane = [&](const int i, const int j) { return i == j ? tri_d + 4 * j * hi : tri_c + 4 * j * cc; };
+  auto sym_k = [&](const int i, const int j) { return i == j ? 8 * j * j + 6 * j : 8 * j * j + 2 * j + 4 * i; };
+  auto in_row = [&](const int i, const int N) { return 4 * i + 3 < N || 4 * i + r < N; };
+  auto in_col = [&](const int j, const int N) { return 4 * j + 3 < N || 4 * j + cc < N; };
+  auto in_n = [&](const int i, const int j, const int N) { return in_row(i, N) && in_col(j, N); };
+  const bool up = r <= cc;
+  const bool u_row = r >= CU && r < CU + NU, u_col = cc >= CU && cc < CU + NU;  // action rows / columns of block JU
+  // the lane parts of every access of a cell (loop-invariant; a lane that holds padding is parked: loads give 0, stores are dropped)
+  const QIO8<R, S> io{rb, bo};
+  unsigned l_mu[NBD], l_sg[NBD * NBD], l_m3[NBX], l_s3[NBX * NBX], l_jt[NBX * NBD];                        // loads (forward rows)
+  unsigned s_mu[NBD], s_sg[NBD * NBD], s_kt[NBX], s_k, s_sk;                                              // stores (posterior rows)
+#pragma unroll
+  for (int j = 0; j < NBD; ++j) {
+    l_mu[j] = io.lane(in_col(j, D), cc);
+    s_mu[j] = io.lane(live && r == 0 && in_col(j, D), cc);
+#pragma unroll
+    for (int i = 0; i < NBD; ++i) {
+      l_sg[i * NBD + j] = io.lane(i <= j && in_n(i, j, D), sym_lane(i, j));  // upper blocks (the diagonal ones as full symmetric blocks)
+      s_sg[i * NBD + j] = io.lane(live && i <= j && (i < j || up) && in_col(j, D), sym_lane(i, j));
+    }
+#pragma unroll
+    for (int i = 0; i < NBX; ++i) l_jt[i * NBD + j] = io.lane(in_row(i, NX) && in_col(j, D), cc * NX + r);  // J^T: row = state, column = joint index
+  }
+#pragma unroll
+  for (int j = 0; j < NBX; ++j) {
+    l_m3[j] = io.lane(in_col(j, NX), cc);
+#pragma unroll
+    for (int i = 0; i < NBX; ++i) l_s3[i * NBX + j] = io.lane(i <= j && in_n(i, j, NX), sym_lane(i, j));
+    s_kt[j] = io.lane(live && in_row(j, NX) && (j != JU || r < CU) && u_col, (cc - CU) * NX + r);  // K[u][x], u = the column, x = 4 j + row
+  }
+  s_k = io.lane(live && r == 0 && u_col, cc - CU);
+  s_sk = io.lane(live && u_row && u_col && r >= cc, (r - CU) * (r - CU + 1) / 2 + (cc - CU));
+
+  // ---- the forward rows of a cell, a cell ahead ---------------------------------------------------------------------------
+  R nx_mu[NBD], nx_sg[NBD * NBD], nx_m3[NBX], nx_s3[NBX * NBX], nx_jt[NBX * NBD], nx_zt[NBZ];
+  // per-cell targets, or a discarded dummy (the head of the forward-message buffer, which this sweep only reads: distinct addresses,
+  // so that the loads stay independent instructions -- see forward_quad_body): branch-free buffer loads
+  const Window zw = make_window(c.z_per_cell ? (const void*)a.z : (const void*)a.fwd,
+                                c.z_per_cell ? (unsigned long)T * NZ * B * sizeof(R) : (unsigned long)C::E_FWD * B * WS);
+  const unsigned zcell = c.z_per_cell ? (unsigned)((unsigned long)NZ * B * sizeof(R)) : 0u;
+  unsigned zlane[NBZ];
+#pragma unroll
+  for (int j = 0; j < NBZ; ++j) {
+    const int col = xcol(j);
+    zlane[j] = c.z_per_cell ? (unsigned)((((unsigned long)(col < NZ ? col : 0)) * B + b) * sizeof(R)) : (unsigned)(((unsigned long)j * B + b) * WS);
+  }
+  auto fetch = [&](const int tc) {
+    const Window f = make_window(a.fwd + (unsigned long)tc * C::E_FWD * B, (unsigned long)C::E_FWD * rb);
+#pragma unroll
+    for (int j = 0; j < NBD; ++j) {
+      nx_mu[j] = io.ld(f, l_mu[j], 4 * j);
+#pragma unroll
+      for (int i = 0; i <= j; ++i) nx_sg[i * NBD + j] = io.ld(f, l_sg[i * NBD + j], D + sym_k(i, j));
+    }
+#pragma unroll
+    for (int j = 0; j < NBX; ++j) {
+      nx_m3[j] = io.ld(f, l_m3[j], O_MU3 + 4 * j);
+#pragma unroll
+      for (int i = 0; i <= j; ++i) nx_s3[i * NBX + j] = io.ld(f, l_s3[i * NBX + j], O_S3 + sym_k(i, j));
+    }
+#pragma unroll
+    for (int i = 0; i < NBX; ++i)
+#pragma unroll
+      for (int j = 0; j < NBD; ++j) nx_jt[i * NBD + j] = io.ld(f, l_jt[i * NBD + j], O_J + 4 * j * NX + 4 * i);  // stored as J[joint][state]
+#pragma unroll
+    for (int j = 0; j < NBZ; ++j) nx_zt[j] = wld<R>(zw, (unsigned)c.row(tc) * zcell, zlane[j]);
+  };
+  fetch(T - 1);
+  // settled before the loop (see forward_wave_body: loads pending on the loop-entry path cost a vmcnt(0) in every cell)
+#pragma unroll
+  for (int k = 0; k < NBD; ++k) nx_mu[k] = opaque(nx_mu[k]);
+#pragma unroll
+  for (int i = 0; i < NBD; ++i)
+#pragma unroll
+    for (int j = i; j < NBD; ++j) nx_sg[i * NBD + j] = opaque(nx_sg[i * NBD + j]);
+#pragma unroll
+  for (int k = 0; k < NBX; ++k) nx_m3[k] = opaque(nx_m3[k]);
+#pragma unroll
+  for (int i = 0; i < NBX; ++i)
+#pragma unroll
+    for (int j = i; j < NBX; ++j) nx_s3[i * NBX + j] = opaque(nx_s3[i * NBX + j]);
+#pragma unroll
+  for (int k = 0; k < NBX * NBD; ++k) nx_jt[k] = opaque(nx_jt[k]);
+#pragma unroll
+  for (int k = 0; k < NBZ; ++k) nx_zt[k] = opaque(nx_zt[k]);
+
+  int fail = 0;
+  auto note = [&](const bool ok, const int reason, const int t) { fail = (fail == 0 && !ok) ? ((reason << 16) | (t + 1)) : fail; };
+  // state marginal carried along the chain: mean in column form, covariance in UPPER blocks (the diagonal ones full), zero-padded
+  R m3m[NBX], s3m[NBX * NBX];
+  // ---- end of the chain (i2c.py:546-572): the smoothed terminal state and its statistics, from the rows of cell T - 1 ----------
+  {
+    const int kz = (int)opaque_uniform(0u);
+#pragma unroll
+    for (int j = 0; j < NBX; ++j) {
+      m3m[j] = nx_m3[j];  // (padding lanes loaded zeros)
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) s3m[i * NBX + j] = i <= j ? nx_s3[i * NBX + j] : R(0);
+    }
+    if (c.has_x_terminal) {
+      // covariance control (i2c.py:548-559): the smoothed terminal state is the product of the TEMPERED filtered state
+      // N(m3f, temp S3f) with the terminal prior N(mu_T, S_T) -- in Kalman form, an identity observation of the state with noise
+      // S_T and target mu_T (see backward_quad_body / w_end_of_chain). temp += dtemp per sweep.
+      const R tmp = a.temp[b];
+      q.sync();  // (every lane has read the temperature before the leading lane advances it)
+      if (lead) a.temp[b] = tmp + c.dtemp;
+      R stt[NBX * NBX], stf[NBX * NBX], sum[NBX * NBX], mz[NBX], zt[NBX];
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) {
+        mz[i] = m3m[i];
+        zt[i] = q_ldv(q, kc.mxT, i, kz);
+#pragma unroll
+        for (int j = i; j < NBX; ++j) stt[i * NBX + j] = tmp * s3m[i * NBX + j];
+      }
+#pragma unroll
+      for (int i = 0; i < NBX; ++i)
+#pragma unroll
+        for (int j = 0; j < NBX; ++j) {
+          stf[i * NBX + j] = j >= i ? stt[i * NBX + j] : q_tr(q, stt[j * NBX + i]);
+          sum[i * NBX + j] = j >= i ? stt[i * NBX + j] + q_ldc<QLD>(q, kc.sxT, i, j, kz) : R(0);
+          if (j < i) stt[i * NBX + j] = R(0);
+        }
+      note(q_kalman<NX, NX>(q, m3m, stt, mz, sum, stf, zt), 6, T - 1);
+#pragma unroll
+      for (int k = 0; k < NBX * NBX; ++k) s3m[k] = stt[k];
+    }
+    // terminal observation statistics (i2c.py:567-570, 989-992): tr(Qf (errT errT^T + sig_z3_m))
+    R trT = R(0);
+    if (NZT > 0 && c.has_Qf) {
+      if constexpr (TERM_ID) {
+        R errT[NBX], pm, pv;
+#pragma unroll
+        for (int j = 0; j < NBX; ++j) errT[j] = m3m[j] - q_ldv(q, kc.zgT, j, kz);
+        q_cost_share<NBX, NBX, QLD>(q, c.qf_diag != 0, kc.qf, errT, s3m, &pm, &pv, kz);
+        trT = q_sum16(q, pm);
+        if (live) {
+#pragma unroll
+          for (int j = 0; j < NBX; ++j) {
+            if (r == 0 && in_col(j, NX)) a.term_stats[(long)(3 + 4 * j + cc) * B + b] = m3m[j];
+#pragma unroll
+            for (int i = 0; i <= j; ++i)
+              if ((i < j || up) && in_col(j, NX)) a.term_stats[(long)(3 + NT + sym_lane(i, j) + sym_k(i, j)) * B + b] = s3m[i * NBX + j];
+          }
+        }
+      } else if constexpr (NZT > 0) {
+        // a general terminal observation: the sigma points of the smoothed terminal state through sys.observe_terminal_x
+        R tmp[NBX * NBX], l3t[NBX * NBX], am[NBX * NBT], dm[NBX * NBT], yc[NBT], mzt[NBT], szt[NBT * NBT], errT[NBT], pm, pv;
+#pragma unroll
+        for (int k = 0; k < NBX * NBX; ++k) tmp[k] = s3m[k];
+        note(q_elim<NX, 0, 0>(q, tmp, (R*)nullptr, (R*)nullptr, l3t), 6, T - 1);
+        q_points<M, G, NX, NT>(q, c.rule_x.sf, m3m, l3t, ObserveTermF<M, R>{c.params}, am, dm, yc);
+        q_moments<NX, NT, GENERAL>(q, c.rule_x, am, dm, yc, mzt, szt);
+#pragma unroll
+        for (int j = 0; j < NBT; ++j) errT[j] = mzt[j] - q_ldv(q, kc.zgT, j, kz);
+        q_cost_share<NBT, NBT, QLD>(q, c.qf_diag != 0, kc.qf, errT, szt, &pm, &pv, kz);
+        trT = q_sum16(q, pm);
+        if (live) {
+#pragma unroll
+          for (int j = 0; j < NBT; ++j) {
+            if (r == 0 && in_col(j, NT)) a.term_stats[(long)(3 + 4 * j + cc) * B + b] = mzt[j];
+#pragma unroll
+            for (int i = 0; i <= j; ++i)
+              if ((i < j || up) && in_col(j, NT)) a.term_stats[(long)(3 + NT + sym_lane(i, j) + sym_k(i, j)) * B + b] = szt[i * NBT + j];
+          }
+        }
+      }
+    }
+    if (lead) a.term_stats[b] = trT;
+  }
+
+  R acc_m = R(0), acc_v = R(0);
+  for (int t = T - 1; t >= 0; --t) {
+    const int kz = (int)opaque_uniform(0u);  // (see q_ldc)
+    const Window out = make_window(a.post + (unsigned long)c.row(t) * C::E_POST * B, (unsigned long)C::E_POST * rb);
+    // this cell's rows (zero-padded), then the fetch of the next one
+    R mu[NBD], sg[NBD * NBD], jt[NBX * NBD], m3f[NBX], s3f[NBX * NBX], zt[NBZ];
+#pragma unroll
+    for (int j = 0; j < NBD; ++j) {
+      mu[j] = nx_mu[j];  // (padding lanes loaded zeros)
+#pragma unroll
+      for (int i = 0; i < NBD; ++i) sg[i * NBD + j] = i <= j ? nx_sg[i * NBD + j] : R(0);
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) jt[i * NBD + j] = nx_jt[i * NBD + j];
+    }
+#pragma unroll
+    for (int j = 0; j < NBX; ++j) {
+      m3f[j] = nx_m3[j];
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) s3f[i * NBX + j] = i <= j ? nx_s3[i * NBX + j] : R(0);
+    }
+#pragma unroll
+    for (int j = 0; j < NBZ; ++j) zt[j] = xcol(j) < NZ ? (c.z_per_cell ? nx_zt[j] : q_ldv(q, kc.zg, j, kz)) : R(0);
+    fetch(t >= 1 ? t - 1 : 0);
+    if (a.xm && live) {  // (optional output: the smoothed state marginal that enters cell t)
+      S* xo = const_cast<S*>(a.xm) + ((long)t * C::E_XM) * B + b;
+#pragma unroll
+      for (int j = 0; j < NBX; ++j) {
+        if (r == 0 && in_col(j, NX)) xo[(long)(4 * j + cc) * B] = (S)m3m[j];
+#pragma unroll
+        for (int i = 0; i <= j; ++i)
+          if ((i < j || up) && in_col(j, NX)) xo[(long)(NX + sym_lane(i, j) + sym_k(i, j)) * B] = (S)s3m[i * NBX + j];
+      }
+    }
+    // ---- RTS update of the joint (i2c.py:580-583): mu += J (m3m - m3f), sig += J (S3m - S3f) J^T --------------------------------
+    {
+      R dsf[NBX * NBX], drr[NBX], p1[NBX * NBD];
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) {
+        drr[i] = q_tr(q, m3m[i] - m3f[i]);  // row form
+#pragma unroll
+        for (int j = i; j < NBX; ++j) dsf[i * NBX + j] = s3m[i * NBX + j] - s3f[i * NBX + j];
+      }
+#pragma unroll
+      for (int i = 0; i < NBX; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j) dsf[i * NBX + j] = q_tr(q, dsf[j * NBX + i]);
+#pragma unroll
+      for (int j = 0; j < NBD; ++j) {
+        R ts = R(0);
+#pragma unroll
+        for (int i = 0; i < NBX; ++i) ts += jt[i * NBD + j] * drr[i];
+        mu[j] += q_colsum(q, ts);
+      }
+#pragma unroll
+      for (int k = 0; k < NBX * NBD; ++k) p1[k] = R(0);
+      q_tn<NBX, NBX, NBD>(q, dsf, jt, p1);              // dS J^T
+      q_tn<NBX, NBD, NBD, false, true>(q, jt, p1, sg);  // J (dS J^T), upper blocks
+      // the diagonal blocks, exactly symmetric again: both triangles of J dS J^T are computed, each with its own rounding, and the
+      // antisymmetric part A of the carried state covariance obeys A <- Jx A Jx^T along the chain -- it GROWS where the smoother gain
+      // has a direction > 1 (double cartpole, first iteration: 1e-10 of the joint after 60 cells, 6e-5 of K)
+#pragma unroll
+      for (int i = 0; i < NBD; ++i) {
+        const R st = q_tr(q, sg[i * NBD + i]);
+        sg[i * NBD + i] = up ? sg[i * NBD + i] : st;
+      }
+    }
+    // ---- ONE factorisation of the smoothed joint: lt = chol(sig)^T (sigma points, controller) and the inverses of its diagonal blocks
+    R lt[NBD * NBD], aw[NBD];
+    {
+      R tmp[NBD * NBD];
+#pragma unroll
+      for (int k = 0; k < NBD * NBD; ++k) tmp[k] = sg[k];
+      note(q_elim<D, 0, 0>(q, tmp, (R*)nullptr, (R*)nullptr, lt, aw), 7, t);
+    }
+    // ---- posterior observation moments (i2c.py:594-596) and their expected cost (calc_cost, i2c.py:1046-1065) --------------------
+    {
+      R pm, pv;
+      if constexpr (OBS_ID) {
+        R err[NBD];
+#pragma unroll
+        for (int j = 0; j < NBD; ++j) err[j] = mu[j] - zt[j];
+        q_cost_share<NBD, NBD, QLD>(q, c.qr_diag != 0, kc.qr, err, sg, &pm, &pv, kz);
+        if (a.zpost && live) {
+          S* zo = a.zpost + ((long)t * C::E_ZPOST) * B + b;
+#pragma unroll
+          for (int j = 0; j < NBD; ++j) {
+            if (r == 0 && in_col(j, D)) zo[(long)(4 * j + cc) * B] = (S)mu[j];
+#pragma unroll
+            for (int i = 0; i <= j; ++i)
+              if ((i < j || up) && in_col(j, D)) zo[(long)(NZ + sym_lane(i, j) + sym_k(i, j)) * B] = (S)sg[i * NBD + j];
+          }
+        }
+      } else {
+        R am[NBD * NBZ], dm[NBD * NBZ], yc[NBZ], mz[NBZ], sz[NBZ * NBZ], err[NBZ];
+        q_points<M, G, D, NZ>(q, rule.sf, mu, lt, ObserveF<M, R>{c.params}, am, dm, yc);
+        q_moments<D, NZ, GENERAL>(q, rule, am, dm, yc, mz, sz);
+#pragma unroll
+        for (int j = 0; j < NBZ; ++j) err[j] = mz[j] - zt[j];
+        q_cost_share<NBZ, NBZ, QLD>(q, c.qr_diag != 0, kc.qr, err, sz, &pm, &pv, kz);
+        if (a.zpost && live) {
+          S* zo = a.zpost + ((long)t * C::E_ZPOST) * B + b;
+#pragma unroll
+          for (int j = 0; j < NBZ; ++j) {
+            if (r == 0 && in_col(j, NZ)) zo[(long)(4 * j + cc) * B] = (S)mz[j];
+#pragma unroll
+            for (int i = 0; i <= j; ++i)
+              if ((i < j || up) && in_col(j, NZ)) zo[(long)(NZ + sym_lane(i, j) + sym_k(i, j)) * B] = (S)sz[i * NBZ + j];
+          }
+        }
+      }
+      acc_m += pm;
+      acc_v += pv;
+      if (a.cell_stats) {
+        const R cm = q_sum16(q, pm), cv = q_sum16(q, pv);
+        if (lead) {
+          a.cell_stats[((long)t * 2 + 0) * B + b] = cm;
+          a.cell_stats[((long)t * 2 + 1) * B + b] = cv;
+        }
+      }
+    }
+    // ---- controller (i2c.py:600-608) off the factor, as the lane kernels read it (cell_posterior):  K L_xx = L_ux, i.e. the blocked
+    // BACK SUBSTITUTION  L_xx^T K^T = L_ux^T  with the upper blocks of lt -- rows = state index, the action columns of block column JU --
+    // and the inverses of its diagonal blocks; sigK = L_uu L_uu^T; k = mu_u - K mu_x.
+    // (K = -L_uu W_ux from an identity right-hand side of the elimination is the same matrix, but an explicit inverse loses a factor
+    //  cond(L_xx) of accuracy: 6e-5 on the first iteration of the double cartpole, whose state covariance is ~1e-6 of the action's)
+    {
+      R kt[NBX], tk = R(0);
+#pragma unroll
+      for (int i = NBX - 1; i >= 0; --i) {
+        const bool xr = in_row(i, NX) && (i != JU || r < CU);  // state rows of block row i
+        R rhs = (xr && u_col) ? lt[i * NBD + JU] : R(0);
+#pragma unroll
+        for (int j = i + 1; j < NBX; ++j) {
+          const bool xcj = in_col(j, NX) && (j != JU || cc < CU);  // state columns of block column j
+          q_mfma(q, -q_tr(q, (xr && xcj) ? lt[i * NBD + j] : R(0)), kt[j], rhs);  // rhs -= L^T(i, j) K^T_j  (A operand = the transpose of what is passed)
+        }
+        const bool xci = in_col(i, NX) && (i != JU || cc < CU);
+        kt[i] = R(0);
+        q_mfma(q, q_tr(q, (xr && xci) ? aw[i] : R(0)), rhs, kt[i]);  // K^T_i = (L^T(i, i))^-1 rhs
+        tk += kt[i] * q_tr(q, mu[i]);                                 // (row form of the state mean: lane (r, c) holds mu_x[4 i + r])
+        io.st(out, s_kt[i], O_K + 4 * i, kt[i]);
+      }
+      const R kx = q_colsum(q, tk);  // K mu_x, column form over the action columns
+      io.st(out, s_k, O_k, mu[JU] - kx);
+      const R luu = (u_row && u_col) ? lt[JU * NBD + JU] : R(0);  // L_uu^T: the action entries of the factor's block (JU, JU)
+      R sk = R(0);
+      q_mfma(q, luu, luu, sk);  // L_uu L_uu^T
+      io.st(out, s_sk, O_SK, sk);
+    }
+#pragma unroll
+    for (int j = 0; j < NBD; ++j) {
+      io.st(out, s_mu[j], 4 * j, mu[j]);
+#pragma unroll
+      for (int i = 0; i <= j; ++i) io.st(out, s_sg[i * NBD + j], D + sym_k(i, j), sg[i * NBD + j]);
+    }
+    // the state marginal that enters cell t - 1: the x entries of the smoothed joint
+#pragma unroll
+    for (int j = 0; j < NBX; ++j) {
+      m3m[j] = in_col(j, NX) ? mu[j] : R(0);
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) s3m[i * NBX + j] = (i <= j && in_n(i, j, NX)) ? sg[i * NBD + j] : R(0);
+    }
+  }
+  const R sm = q_sum16(q, acc_m), sv = q_sum16(q, acc_v);
   if (lead) {
     a.term_stats[B + b] = sm;
     a.term_stats[2 * B + b] = sv;

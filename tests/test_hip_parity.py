@@ -114,8 +114,55 @@ QUAD_GOLDEN = [("em_pendulum_T200", 1e-8, 1e-7), ("em_pendulum_T200_run200", 1e-
 
 @pytest.mark.parametrize("name,tol_d,tol_s", QUAD_GOLDEN)
 def test_hip_quad_forward_vs_reference_golden(lib, name, tol_d, tol_s):
+    """(a lane schedule asked for by name keeps the lane backward sweep behind the quad forward sweep)"""
+    eng = parity.check_against_golden(name, lib, "cuda", tol_d, tol_s, group_lanes=64, backward_mode="chunked")
+    assert eng.forward_family == "quad" and eng.backward_family == "lane" and eng.backward_schedule == "chunked"
+
+
+# The QUAD backward sweep of the d <= 8 models (round 6, backward_quad8_body: the fused walk of four trajectories per wavefront --
+# posterior observation through sigma points, controller by a blocked back substitution with the joint's factor, covariance
+# control's tempered terminal prior and the terminal observation at the end of the chain): every QUAD_GOLDEN case, every per-cell
+# quantity and the EM summaries, through the C ABI on the device.
+@pytest.mark.parametrize("name,tol_d,tol_s", QUAD_GOLDEN)
+def test_hip_quad_backward_vs_reference_golden(lib, name, tol_d, tol_s):
     eng = parity.check_against_golden(name, lib, "cuda", tol_d, tol_s, group_lanes=64)
-    assert eng.forward_family == "quad" and eng.backward_family == "lane"
+    assert (eng.forward_family, eng.backward_family, eng.backward_schedule) == ("quad", "quad", "fused") and eng.work is None
+
+
+@pytest.mark.parametrize("name,B", [("em_dcp_T60", 131), ("em_dcp_nondiag_T30", 66), ("em_cartpole_T100", 67), ("em_quadrotor_T20", 1027),
+                                    ("em_pendulum_T200", 259), ("em_covctrl_T100", 130), ("em_covctrl_qf_T40", 5), ("em_linear_T60", 1)])
+def test_hip_quad_backward_batch_vs_oracle(lib, name, B):
+    """Ragged batches (the last wave repeats its last trajectory in the spare slots and stores nothing for them) against the batched
+    oracle on identical inputs: every trajectory, every cell."""
+    eng, _ = parity.check_batch_against_oracle(name, lib, "cuda", B, 3, tol=1e-6, group_lanes=64)
+    assert (eng.forward_family, eng.backward_family) == ("quad", "quad")
+
+
+def test_hip_quad_backward_optional_outputs_and_statistics(lib):
+    """The optional outputs of the fused quad walk (per-cell cost statistics, the smoothed state entering every cell, observation
+    moments, terminal moments) against the lane walk's on the same problem; fp32-stored messages run and stay close."""
+    import torch
+
+    from golden_util import assert_close, load_case
+
+    g = load_case("em_dcp_nondiag_T30")
+    x0, mu_u = parity.batched_inputs(g, 37)
+    out = {}
+    for key, kw in (("quad", dict(group_lanes=64)), ("lane", dict(group_lanes=-1, backward_mode="fused"))):
+        eng = parity.engine_from_case(g, lib, "cuda", x0=x0, mu_u=mu_u, keep_xm=True, keep_zpost=True, **kw)
+        eng.cell_stats = torch.zeros(eng.H, 2, eng.B, dtype=torch.float64, device="cuda")
+        eng.forward_backward()
+        assert eng.backward_family == key and eng.failures() == []
+        out[key] = [parity.np_(x) for x in (eng.cell_stats, eng.term_stats, *eng.smoothed_next_state(), *eng.observed_marginal(), *eng.terminal_observed_marginal())]
+        np.testing.assert_allclose(out[key][0].sum(0), out[key][1][1:3], rtol=1e-12)
+    for a, b in zip(out["quad"], out["lane"]):
+        assert_close(a, b, 1e-7, "quad backward walk vs lane backward walk")
+    mixed = parity.engine_from_case(g, lib, "cuda", x0=x0, mu_u=mu_u, group_lanes=64, storage_dtype=torch.float32)
+    ref = parity.engine_from_case(g, lib, "cuda", x0=x0, mu_u=mu_u, group_lanes=64)
+    for e in (mixed, ref):
+        e.learn_msgs()
+    assert mixed.backward_family == "quad" and mixed.failures() == []
+    assert_close(parity.np_(mixed.marginal_state_action()[0]), parity.np_(ref.marginal_state_action()[0]), 1e-4, "fp32-stored messages, quad backward")
 
 
 @pytest.mark.parametrize("name,B", [("em_dcp_T60", 131), ("em_cartpole_T100", 67)])
@@ -125,7 +172,7 @@ def test_hip_quad_forward_general_weights_batch_vs_oracle(lib, name, B):
     eng, _ = parity.check_batch_against_oracle(name, lib, "cuda", B, 2, tol=1e-6, quad=(1.2, 0.44, 0.5))
     assert eng.forward_family == "quad"
     eng, _ = parity.check_batch_against_oracle(name, lib, "cuda", B, 2, tol=1e-6, quad=(1.0, 0.0, 0.5), group_lanes=64)
-    assert eng.forward_family == "quad"
+    assert eng.forward_family == "quad" and eng.backward_family == "quad"  # (round 6: the GENERAL moments in the backward walk too)
 
 
 @pytest.mark.parametrize("name", ["em_quad12_T20", "em_quad12_T12_propagate", "em_quad12_nondiag_T12", "em_quad12_covctrl_T12"])
@@ -375,3 +422,23 @@ def test_hip_linearize_chunked_backward_equals_sequential(lib, name):
     from test_kernels_hostsim import _linearize_chunked_equals_sequential
 
     _linearize_chunked_equals_sequential(lib, "cuda", name, 1e-8)
+
+
+def test_hip_quad_backward_failure_is_per_trajectory(lib):
+    """A smoothed joint that is not positive definite in ONE cell of ONE trajectory (its filtered variance poisoned between the
+    sweeps) is reported as that trajectory's failure -- reason 7 (the backward cell), that cell -- and leaves the other three
+    trajectories of its wavefront, and the rest of the batch, untouched."""
+    g = load_case("em_dcp_T60")
+    x0, mu_u = parity.batched_inputs(g, 6)
+    eng = parity.engine_from_case(g, lib, "cuda", x0=x0, mu_u=mu_u, group_lanes=64)
+    clean = parity.engine_from_case(g, lib, "cuda", x0=x0, mu_u=mu_u, group_lanes=64)
+    for e in (eng, clean):
+        e.forward_sweep()
+    eng.fwd[17, eng.d, 2] = -1.0  # sig_xu1_f[0][0] of cell 17, trajectory 2
+    for e in (eng, clean):
+        e.backward_sweep()
+    assert eng.backward_family == "quad" and eng.failures() == [(2, 7, 17)] and clean.failures() == []
+    ok = [0, 1, 3, 4, 5]
+    for a, b in zip(eng.marginal_state_action() + eng.local_linear_policy(), clean.marginal_state_action() + clean.local_linear_policy()):
+        assert torch.equal(a[ok], b[ok])
+    assert not torch.isfinite(eng.local_linear_policy()[0][2, 17]).all()  # the failed cell's controller is NaN, not silently wrong

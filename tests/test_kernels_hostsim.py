@@ -8,7 +8,7 @@ import pytest
 
 import hostsim
 import parity
-from golden_util import load_case
+from golden_util import assert_close, load_case
 
 
 @pytest.fixture(scope="module")
@@ -127,8 +127,56 @@ QUAD_GOLDEN = [
 
 @pytest.mark.parametrize("name,tol_d,tol_s,n_iters", QUAD_GOLDEN)
 def test_hostsim_quad_forward_vs_reference_golden(lib, name, tol_d, tol_s, n_iters):
+    """(a lane schedule asked for by name keeps the lane backward sweep behind the quad forward sweep: the default pair of the
+    d >= 5 models at the BASELINE batch sizes)"""
+    eng = parity.check_against_golden(name, lib, "cpu", tol_d, tol_s, n_iters=n_iters, group_lanes=64, backward_mode="chunked")
+    assert eng.forward_family == "quad" and eng.backward_family == "lane" and eng.backward_schedule == "chunked"
+
+
+# The QUAD backward sweep of the d <= 8 models (round 6, backward_quad8_body): the fused walk of four trajectories per wavefront --
+# posterior observation through sigma points, controller by a blocked back substitution with the joint's factor, the tempered
+# terminal prior of covariance control and the terminal observation at the end of the chain -- on the same goldens, every per-cell
+# quantity (posterior, controller, observation moments, smoothed state, terminal moments) and the EM summaries.
+@pytest.mark.parametrize("name,tol_d,tol_s,n_iters", QUAD_GOLDEN)
+def test_hostsim_quad_backward_vs_reference_golden(lib, name, tol_d, tol_s, n_iters):
     eng = parity.check_against_golden(name, lib, "cpu", tol_d, tol_s, n_iters=n_iters, group_lanes=64)
-    assert eng.forward_family == "quad" and eng.backward_family == "lane"
+    assert (eng.forward_family, eng.backward_family, eng.backward_schedule) == ("quad", "quad", "fused")
+    assert eng.work is None  # (one pass: no chunk workspace)
+
+
+def test_hostsim_quad_backward_resolver(lib):
+    """Which backward sweep a quad request gets (i2c_kernel_family / i2c_backward_schedule, the one resolver): the quad walk with the
+    schedule left open or asked to be the fused walk; the lane schedules when one of them is asked for by name; nothing changes for a
+    problem that does not ask (no default window is compiled in for a model until it is measured on the device)."""
+    g = load_case("em_dcp_T60")
+    fam = lambda **kw: (lambda e: (e.forward_family, e.backward_family, e.backward_schedule))(parity.engine_from_case(g, lib, "cpu", **kw))  # noqa: E731
+    Q = parity.pkg._native.LANES_QUAD
+    assert fam(group_lanes=64) == fam(group_lanes=Q) == fam(group_lanes=Q, backward_mode="fused") == ("quad", "quad", "fused")
+    assert fam(group_lanes=64, backward_mode="chunked") == ("quad", "lane", "chunked")
+    assert fam(group_lanes=64, backward_mode="two_pass") == ("quad", "lane", "two_pass")
+    assert fam(group_lanes=-1) == ("lane", "lane", "chunked")
+    assert fam(deterministic_family=True) == ("lane", "lane", "fused")
+    assert fam(group_lanes=Q, storage_dtype=torch.float32) == ("quad", "quad", "fused")  # fp32-stored messages
+
+
+def test_hostsim_quad_backward_optional_outputs_and_statistics(lib):
+    """The optional outputs of the fused quad walk -- per-cell cost statistics [T][2][B], the smoothed state entering every cell,
+    the observation moments -- against the lane walk's on the same forward messages; a ragged batch (5 = one full wave + one
+    with three spare slots)."""
+    g = load_case("em_dcp_nondiag_T30")
+    x0, mu_u = parity.batched_inputs(g, 5)
+    out = {}
+    for key, kw in (("quad", dict(group_lanes=64)), ("lane", dict(group_lanes=64, backward_mode="fused"))):
+        eng = parity.engine_from_case(g, lib, "cpu", x0=x0, mu_u=mu_u, keep_xm=True, keep_zpost=True, **kw)
+        if key == "lane":  # (a quad request with the fused walk asked for IS the quad walk: pin the lane one through the lane family)
+            eng = parity.engine_from_case(g, lib, "cpu", x0=x0, mu_u=mu_u, keep_xm=True, keep_zpost=True, group_lanes=-1, backward_mode="fused")
+        eng.cell_stats = torch.zeros(eng.H, 2, eng.B, dtype=torch.float64)
+        eng.forward_backward()
+        assert eng.backward_family == key and eng.failures() == []
+        out[key] = [parity.np_(x) for x in (eng.cell_stats, eng.term_stats, *eng.smoothed_next_state(), *eng.observed_marginal(), *eng.terminal_observed_marginal())]
+        np.testing.assert_allclose(out[key][0].sum(0), out[key][1][1:3], rtol=1e-12)
+    for a, b in zip(out["quad"], out["lane"]):
+        assert_close(a, b, 1e-7, "quad backward walk vs lane backward walk")
 
 
 @pytest.mark.parametrize("name,B", [("em_dcp_T60", 5), ("em_cartpole_T100", 3), ("em_pendulum_T200", 6)])
@@ -138,7 +186,7 @@ def test_hostsim_quad_forward_general_weights_batch_vs_oracle(lib, name, B):
     eng, _ = parity.check_batch_against_oracle(name, lib, "cpu", B, 2, tol=1e-7, quad=(1.2, 0.44, 0.5))
     assert eng.forward_family == ("quad" if name != "em_pendulum_T200" else "lane")
     eng, _ = parity.check_batch_against_oracle(name, lib, "cpu", B, 2, tol=1e-7, quad=(1.0, 0.0, 0.5), group_lanes=64)  # (W = 1, but a weight on the centre: lam = 0.5)
-    assert eng.forward_family == "quad"
+    assert eng.forward_family == "quad" and eng.backward_family == "quad"  # (round 6: the GENERAL moments in the backward walk too)
 
 
 @pytest.mark.parametrize("name,B", [("em_dcp_T60", 6), ("em_pendulum_T200", 9), ("em_quadrotor_T20", 5), ("em_cartpole_T100", 3)])
@@ -146,7 +194,7 @@ def test_hostsim_quad_forward_batch_vs_oracle(lib, name, B):
     """Ragged batches (not a multiple of the four trajectories of a wavefront: the spare slots repeat the last trajectory and
     store nothing) against the batched oracle."""
     eng, _ = parity.check_batch_against_oracle(name, lib, "cpu", B, 2, tol=1e-7, group_lanes=64)
-    assert eng.forward_family == "quad"
+    assert eng.forward_family == "quad" and eng.backward_family == "quad"
 
 
 @pytest.mark.parametrize("name", QUAD12)
@@ -482,3 +530,23 @@ def _linearize_chunked_equals_sequential(lib, device, name, rtol):
 @pytest.mark.parametrize("name", ["lin_pendulum_T100", "lin_cartpole_T100", "lin_dcp_T80", "lin_covctrl_qf_T30"])
 def test_hostsim_linearize_chunked_backward_equals_sequential(lib, name):
     _linearize_chunked_equals_sequential(lib, "cpu", name, 1e-9)
+
+
+def test_hostsim_quad_backward_failure_is_per_trajectory(lib):
+    """A smoothed joint that is not positive definite in ONE cell of ONE trajectory (its filtered variance poisoned between the
+    sweeps) is reported as that trajectory's failure -- reason 7 (the backward cell), that cell -- and leaves the other three
+    trajectories of its wavefront, and the rest of the batch, untouched."""
+    g = load_case("em_dcp_T60")
+    x0, mu_u = parity.batched_inputs(g, 6)
+    eng = parity.engine_from_case(g, lib, "cpu", x0=x0, mu_u=mu_u, group_lanes=64)
+    clean = parity.engine_from_case(g, lib, "cpu", x0=x0, mu_u=mu_u, group_lanes=64)
+    for e in (eng, clean):
+        e.forward_sweep()
+    eng.fwd[17, eng.d, 2] = -1.0  # sig_xu1_f[0][0] of cell 17, trajectory 2
+    for e in (eng, clean):
+        e.backward_sweep()
+    assert eng.backward_family == "quad" and eng.failures() == [(2, 7, 17)] and clean.failures() == []
+    ok = [0, 1, 3, 4, 5]
+    for a, b in zip(eng.marginal_state_action() + eng.local_linear_policy(), clean.marginal_state_action() + clean.local_linear_policy()):
+        assert torch.equal(a[ok], b[ok])
+    assert not torch.isfinite(eng.local_linear_policy()[0][2, 17]).all()  # the failed cell's controller is NaN, not silently wrong
