@@ -125,7 +125,7 @@ def algorithmic_elements(d, nx, nu):
 
 def measured_traffic(B, T, dtype, kernel):
     """HBM bytes per launch from the committed PMC passes (tools/pmc_summary.py), if one matches."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_B{B}_pmc_traffic.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(q)),
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_B{B}_pmc_traffic.json") for r in (6, 5, 4, 3, 2, 1)) if os.path.exists(q)),
                 os.path.join(ROOT, "profiles", f"r1_B{B}_pmc_traffic.json"))
     if not os.path.exists(path):
         return None
@@ -145,7 +145,7 @@ def issue_roofline(profile, kernel_prefix, cells_per_wave, lanes_per_trajectory,
     (4 clocks per vector instruction of a wave64, 16 clocks per 512-flop unit of an fp64 matrix instruction), how many of the chip's
     1024 SIMDs hold a wave at all, and the executed fp64 flops against the chip's peak at the live kernel time."""
     def latest(name):  # "rN_<name>": the newest round that committed this profile
-        return next((f"r{r}_{name}" for r in (5, 4, 3, 2) if os.path.exists(os.path.join(ROOT, "profiles", f"r{r}_{name}_sq_counters.json"))), "r4_" + name)
+        return next((f"r{r}_{name}" for r in (6, 5, 4, 3, 2) if os.path.exists(os.path.join(ROOT, "profiles", f"r{r}_{name}_sq_counters.json"))), "r4_" + name)
 
     profile = latest(profile)
     if useful is not None:
@@ -242,7 +242,8 @@ def strong_scaling_legs(pkg, T, dtype, device, rank, world, dist, barrier, K, li
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = float(tmax.item())
         legs.append({"global_batch": Bg, "batch_per_gpu": hi - lo, "ms_per_step": el / K * 1e3,
-                     "value": Bg * T * K / el, "unit": "timestep-messages/s", "scaling": "strong"})
+                     "value": Bg * T * K / el, "unit": "timestep-messages/s", "scaling": "strong",
+                     "forward_family": eng.forward_family, "backward_family": eng.backward_family, "backward": eng.backward_schedule})
         del eng
     return legs
 
@@ -387,11 +388,19 @@ def extra_config_legs(pkg, device, K=10):
         sync()
         ms = (time.perf_counter() - t0) / K * 1e3
         gb = _gbps(eng, B, T * n_iter, ms)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        sync(); evs[0].record()
+        for _ in range(5):
+            eng.forward_sweep()
+        evs[1].record(); sync()
+        fwd_ms12 = evs[0].elapsed_time(evs[1]) / 5
         out["quadrotor12_mpc_H50_B%d" % B] = {"ms_per_control_step": ms, "closed_loop_steps_per_s": B / ms * 1e3, "em_iters_per_step": n_iter,
                                               "value": B * T * n_iter / ms * 1e3, "unit": "timestep-messages/s",
                                               "algorithmic_GBps": gb, "frac_of_hbm_peak": gb / HBM_PEAK_GBS,
                                               "forward_family": eng.forward_family, "backward_family": eng.backward_family,
-                                              "failed_trajectories": len(eng.failures())}
+                                              "failed_trajectories": len(eng.failures()), "forward_sweep_ms": fwd_ms12}
+        if B == 1024:  # (one wave per SIMD: the wave kernels; the issue side of their forward sweep from the committed SQ pass of this step)
+            out["quadrotor12_mpc_H50_B1024"]["issue"] = issue_roofline("quad12_mpc_B1024", "k_wave<0", T, 64, fwd_ms12, B * T)
         del eng
 
     # config 4 on the reference's ACTUAL model class, the planar quadrotor (mpc_quad.py:219-383: nx = 6, nu = 2, identity observation),
@@ -417,11 +426,19 @@ def extra_config_legs(pkg, device, K=10):
         sync()
         ms = (time.perf_counter() - t0) / K * 1e3
         gb = _gbps(eng, B, T * n_iter, ms)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        sync(); evs[0].record()
+        for _ in range(5):
+            eng.forward_sweep()
+        evs[1].record(); sync()
+        fwd_msp = evs[0].elapsed_time(evs[1]) / 5
         out["planar_quadrotor_mpc_H50_B%d" % B] = {"ms_per_control_step": ms, "closed_loop_steps_per_s": B / ms * 1e3, "em_iters_per_step": n_iter,
                                                    "value": B * T * n_iter / ms * 1e3, "unit": "timestep-messages/s",
                                                    "algorithmic_GBps": gb, "frac_of_hbm_peak": gb / HBM_PEAK_GBS,
                                                    "forward_family": eng.forward_family, "backward_family": eng.backward_family,
-                                                   "failed_trajectories": len(eng.failures())}
+                                                   "failed_trajectories": len(eng.failures()), "forward_sweep_ms": fwd_msp}
+        if B == 1024:
+            out["planar_quadrotor_mpc_H50_B1024"]["issue"] = issue_roofline("planar_mpc_B1024", "k_quad_forward", T, 16, fwd_msp, B * T)
         del eng
 
     # the other inference rules of the reference on the headline shape (pendulum T=200, B=4096; exp_types.py:22-68): one EM iteration
@@ -668,6 +685,11 @@ def main():
         allgather_ms = (time.perf_counter() - t1) * 1e3
         assert gathered["K"].shape[0] == B * world
 
+    mine = {"rank": rank, "batch": B, "forward_family": eng.forward_family, "backward_family": eng.backward_family, "backward": eng.backward_schedule}
+    families = [mine]
+    if dist is not None and world > 1:
+        families = [None] * world
+        dist.all_gather_object(families, mine)
     strong = None
     if not args.no_extra:  # every rank takes part (collective timing)
         strong = strong_scaling_legs(pkg, T, dtype, device, rank, world, dist, barrier, max(K // 5, 2), lib=lib,
@@ -723,7 +745,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": measured_traffic(B, T, args.dtype, "k_forward"),
             "traffic_note": "bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                            "(FETCH_SIZE x2, gfx950 correction; profiles/r5_B4096_pmc_traffic.json, r4_ before it); algorithmic = "
+                            "(FETCH_SIZE x2, gfx950 correction; the newest profiles/rN_B4096_pmc_traffic.json); algorithmic = "
                             + str(fwd_bytes),
             "algorithmic_bytes_per_cell": {k: v * wbytes for k, v in el.items()},
             "whole_iteration_GBps": el["total"] * wbytes * B * T / (elapsed / K) / 1e9,
@@ -736,6 +758,8 @@ def main():
         },
         "final_allgather_ms": allgather_ms,
         "strong_scaling": strong,
+        # what every rank ran (the default family and the backward schedule depend on the shard size: DESIGN.md section 8)
+        "families_per_rank": families,
     }
     if device.type == "cuda":
         if not args.no_saturated and world == 1:

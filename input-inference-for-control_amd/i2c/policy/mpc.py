@@ -15,6 +15,27 @@ def _np(t):
     return np.array(t.detach().to(torch.float64).cpu().numpy(), copy=True)  # never alias a device/host buffer
 
 
+class _LazyList(list):
+    """A history list whose entries may be zero-argument callables -- device-side snapshots taken inside the control loop -- that are
+    replaced by their host value when first READ: the single closed loop (the reference's shape) keeps the reference's histories
+    (mus, covars, xu_history, z_history: mpc.py:165-170, plots) without a device -> host copy per entry and step."""
+
+    def _at(self, k):
+        v = list.__getitem__(self, k)
+        if callable(v):
+            v = v()
+            list.__setitem__(self, k, v)
+        return v
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._at(k) for k in range(*i.indices(len(self)))]
+        return self._at(i if i >= 0 else len(self) + i)
+
+    def __iter__(self):
+        return (self._at(k) for k in range(len(self)))
+
+
 class MpcPolicy:
     """Fully observed MPC (reference mpc.py:16-111). NB the reference's own __call__ is broken
     (it passes unknown kwargs to compute_update_alpha); this one runs."""
@@ -43,7 +64,7 @@ class MpcPolicy:
         self._init_t0 = e.t0  # the snapshot is in physical row order: it is only valid with the ring where it was taken
         self._init_z = None if e.z is None else e.z.clone()
         self.record_history = self.B == 1
-        self.xu_history, self.z_history = [], []
+        self.xu_history, self.z_history = _LazyList(), _LazyList()
 
     def set_control(self, feedforward):
         """mpc.py:35-41: feed-forward keeps every cell's action prior independent of the state."""
@@ -65,7 +86,8 @@ class MpcPolicy:
         e.terminal_cell = self._init_terminal
         e.t0 = self._init_t0  # rows were cloned in physical order, at this offset of the ring
         e._problem.terminal_cell, e._problem.t0 = int(e.terminal_cell), int(e.t0)
-        self.xu_history, self.z_history = [], []
+        self.xu_history, self.z_history = _LazyList(), _LazyList()
+        self._belief_host = None
 
     def _squeeze(self, a, column=False):
         if self.B == 1:
@@ -107,9 +129,16 @@ class MpcPolicy:
         return mu_u
 
     def _record(self):
+        """xu_history / z_history of this step's plan (mpc.py:165-170): device-side copies now, host arrays when read (_LazyList)."""
         if self.record_history:
-            self.xu_history.append(self.i2c.get_marginal_state_action())
-            self.z_history.append(self.i2c.get_marginal_observed_trajectory()[0])
+            e = self.engine
+            mu = e._rows(e.post, 0, e.d).clone()  # (B, T, d) in cell order (a copy: the ring row of cell 0 is about to be reused)
+            self.xu_history.append(lambda mu=mu: (lambda m: m[0][:, :, None] if self.B == 1 else m)(_np(mu)))
+            if e.zpost is not None:
+                mz = e._rows(e.zpost, 0, e.nz).clone()
+                self.z_history.append(lambda mz=mz: (lambda m: m[0] if self.B == 1 else m)(_np(mz)))
+            else:
+                self.z_history.append(None)
 
     def optimize(self, n_iter, x):
         x = np.asarray(x, dtype=float)
@@ -163,15 +192,20 @@ class PartiallyObservedMpcPolicy(MpcPolicy):
         e = self.engine
         # the belief lives in the solver's x0 / sig_x0 tensors: filter() updates them in place and the
         # next forward sweep starts from them, with no host round trip
-        self.mus, self.covars = [], []
+        self.mus, self.covars = _LazyList(), _LazyList()
+        self._belief_host = None  # (mu, covar) as host arrays while they are known to equal the device belief
 
     # -- belief as reference-shaped arrays ----------------------------------------------------
     @property
     def mu(self):
+        if self._belief_host is not None:
+            return np.array(self._belief_host[0], copy=True)
         return self._squeeze(_np(self.engine.x0.T), column=True)
 
     @property
     def covar(self):
+        if self._belief_host is not None:
+            return np.array(self._belief_host[1], copy=True)
         return self._squeeze(_np(unpack(self.engine)))
 
     def _dev(self, a, n):
@@ -207,6 +241,7 @@ class PartiallyObservedMpcPolicy(MpcPolicy):
         sig_zeta = self.i2c.sys.sig_zeta
         if sig_zeta is None:
             raise ValueError("sys.sig_zeta (measurement noise) must be set before filtering")
+        self._belief_host = None
         e.ckf_filter(self._dev(y, e.dims.ny), self._dev(u, e.nu), sig_zeta)
         if self.B == 1:
             e.raise_on_failure()
@@ -218,6 +253,7 @@ class PartiallyObservedMpcPolicy(MpcPolicy):
         if mu is not None:
             mu = np.asarray(mu, dtype=float)
             assert mu.reshape(-1, self.dim_x).shape[0] in (1, self.B), f"{mu.shape}, {(self.dim_x, 1)}"
+            self._belief_host = None
             e.set_initial_state(mu.reshape(-1, self.dim_x), covar)
         if self.B == 1:  # keep the facade's view of sys.x0 / sig_x0 consistent (mpc.py:149-150)
             self.i2c.sys.x0, self.i2c.sys.sig_x0 = self.mu, self.covar
@@ -240,14 +276,54 @@ class PartiallyObservedMpcPolicy(MpcPolicy):
             if deterministic:
                 return self._squeeze(self._read_action(), column=True)
             return self._squeeze(self._sample_or_mean(mu_u, sig_u, deterministic), column=True)
+        return self._single_loop_step(i, y, u, deterministic)
+
+    def _single_loop_step(self, i, y, u, deterministic):
+        """One closed loop (B = 1, the reference's shape; mpc.py:156-182): filter, plan, record, first action, shift -- the same
+        library calls as the separate methods, enqueued without a host round trip in between and settled by ONE synchronisation:
+        the failure status (the reference raises inside the step), the first action and the filtered belief come back together
+        through page-locked buffers; the histories keep device-side snapshots until they are read (_LazyList). (Round 6: the
+        step used to make a dozen blocking device -> host copies -- 0.86 ms per step on MI355X, most of it waiting.)"""
+        e = self.engine
+        d, nx, nu = e.d, e.nx, e.nu
         if i > 0:
-            self.filter(y, u)
-        if self.record_history:
-            self.mus.append(self.mu)
-            self.covars.append(self.covar)
-        self.optimize(self.n_iter)
+            sig_zeta = self.i2c.sys.sig_zeta
+            if sig_zeta is None:
+                raise ValueError("sys.sig_zeta (measurement noise) must be set before filtering")
+            yd, ud = self._stage_yu(y, u)
+            e.ckf_filter(yd, ud, sig_zeta)
+        cuda = e.device.type == "cuda"
+        if getattr(self, "_step_host", None) is None:
+            pin = dict(pin_memory=True) if cuda else {}
+            self._step_host = (torch.empty(nx, self.B, dtype=e.dtype, **pin), torch.empty(nx * (nx + 1) // 2, self.B, dtype=e.dtype, **pin),
+                               torch.empty(d + d * (d + 1) // 2, self.B, dtype=e.dtype, **pin), torch.empty(self.B, dtype=torch.int32, **pin))
+        h_mu, h_cov, h_cell0, h_status = self._step_host
+        h_mu.copy_(e.x0, non_blocking=True)      # the belief the plan starts from (planning does not change it)
+        h_cov.copy_(e.sig_x0, non_blocking=True)
+        for _ in range(self.n_iter):
+            e.forward_backward()
+            e.update_priors()
         self._record()
-        ctrl = self._first_action(deterministic)
-        self.engine.shift_horizon(self._next_target(i))
+        h_cell0.copy_(e.post[e.t0, : d + d * (d + 1) // 2, :], non_blocking=True)  # cells[0]: mu_xu0_m, sig_xu0_m (row t0 of the ring)
+        h_status.copy_(e.status, non_blocking=True)
+        if cuda:
+            torch.cuda.current_stream(e.device).synchronize()
+        e.raise_on_failure(h_status.numpy())
+        from .. import core
+
+        mu_b = self._squeeze(np.array(h_mu.numpy().T, dtype=float), column=True)
+        cov_b = self._squeeze(core.engine.unpack_sym(h_cov.T.clone(), nx).numpy().astype(float))
+        self._belief_host = (mu_b, cov_b)
+        self.mus.append(np.array(mu_b, copy=True))
+        self.covars.append(np.array(cov_b, copy=True))
+        # keep the facade's view of sys.x0 / sig_x0 consistent (mpc.py:149-150)
+        self.i2c.sys.x0, self.i2c.sys.sig_x0 = self.mu, self.covar
+        self.i2c._x0_seen = (np.asarray(self.i2c.sys.x0, float).reshape(-1).tobytes(), np.asarray(self.i2c.sys.sig_x0, float).tobytes())
+        cell0 = np.array(h_cell0.numpy().T, dtype=float)  # (B, d + sym d)
+        ctrl = cell0[:, nx:d]
+        if not deterministic:
+            sig = core.engine.unpack_sym(torch.as_tensor(cell0[:, d:]), d).numpy()[:, nx:, nx:]
+            ctrl = np.stack([np.random.multivariate_normal(m, s_) for m, s_ in zip(ctrl, sig)])
+        e.shift_horizon(self._next_target(i))
         self.i2c._invalidate()
         return self._squeeze(ctrl, column=True)

@@ -146,3 +146,18 @@ def test_bad_arguments_of_the_newer_entry_points():
     assert lib.i2c_problem_size() == ctypes.sizeof(N.I2cProblem)
     p.inference = 7
     assert lib.i2c_forward_sweep(ctypes.byref(p), None, None, None, None, None) == -1
+
+
+def test_design_family_table_is_current():
+    """DESIGN.md section 8 ("what runs by default": model x batch window -> forward family / backward family + schedule / propagation
+    / filter) is GENERATED from i2c_kernel_family / i2c_backward_schedule by tools/family_table.py; the committed block must be what
+    the library answers today (round-5 review, item 6: a table that cannot drift)."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("family_table", os.path.join(root, "tools", "family_table.py"))
+    ft = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ft)
+    doc = open(os.path.join(root, "DESIGN.md")).read()
+    committed = doc[doc.index(ft.BEGIN): doc.index(ft.END) + len(ft.END)]
+    assert committed == ft.block(pkg.load_library()), "DESIGN.md section 8 is stale: python tools/family_table.py --write"

@@ -29,6 +29,10 @@ def test_bench_self_launches_two_ranks():
     assert out["config"]["batch_per_gpu"] == 6 and "global batch 12" in out["config"]["workload"]
     assert out["value"] > 0 and out["final_allgather_ms"] is not None
     assert out["strong_scaling"][0]["global_batch"] == 8 and out["strong_scaling"][0]["batch_per_gpu"] == 4
+    # every rank reports what it ran (the default family / schedule depend on the shard size: a SCALE record must show them)
+    fam = out["families_per_rank"]
+    assert [f["rank"] for f in fam] == [0, 1] and all(f["batch"] == 6 and f["forward_family"] == "lane" and f["backward"] for f in fam)
+    assert out["strong_scaling"][0]["forward_family"] == "lane"
     assert "TEST MODE" in out["data"]
 
 
@@ -41,6 +45,7 @@ def test_bench_self_launches_eight_ranks_ragged():
     leg = out["strong_scaling"][0]
     assert leg["global_batch"] == 4099 and leg["batch_per_gpu"] == 513 and leg["scaling"] == "strong" and leg["value"] > 0
     assert out["final_allgather_ms"] is not None and out["failed_trajectories"] == 0
+    assert len(out["families_per_rank"]) == 8 and {f["rank"] for f in out["families_per_rank"]} == set(range(8))
 
 
 def test_bench_single_process_contract():
