@@ -290,11 +290,12 @@ def extra_config_legs(pkg, device, K=10):
     x0 = np.asarray(m.x0, float).reshape(1, -1) + 1e-3 * rng.normal(size=(B, m.dim_x))
     eng = pkg.BatchedI2c(m, T, Q, R, Q, 0.05, 0.99, 1e-2 * rng.normal(size=(B, T, 1)), np.eye(1), x0=x0, device=device,
                          keep_zpost=False, keep_xm=False)
-    eng.learn(2)
-    sync(); t0 = time.perf_counter(); eng.learn(K); sync()
-    ms = (time.perf_counter() - t0) / K * 1e3
+    eng.learn(5)
+    Kd = max(2 * K, 20)  # (20 iterations = 34 ms: the 10-iteration figure read 4 % high right after the light B = 1024 leg -- clocks)
+    sync(); t0 = time.perf_counter(); eng.learn(Kd); sync()
+    ms = (time.perf_counter() - t0) / Kd * 1e3
     gb = _gbps(eng, B, T, ms)
-    out["double_cartpole_T300_B4096"] = {"ms_per_step": ms, "value": B * T / ms * 1e3, "unit": "timestep-messages/s",
+    out["double_cartpole_T300_B4096"] = {"ms_per_step": ms, "steps": Kd, "value": B * T / ms * 1e3, "unit": "timestep-messages/s",
                                          "algorithmic_GBps": gb, "frac_of_hbm_peak": gb / HBM_PEAK_GBS, "backward": eng.backward_schedule,
                                          "forward_family": eng.forward_family, "backward_family": eng.backward_family,
                                          "failed_trajectories": len(eng.failures())}
