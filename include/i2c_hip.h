@@ -174,7 +174,10 @@ typedef struct I2cProblem {
                               trajectories, the quad forward sweep above 1024 and the quad backward sweep above 2048; the
                               group kernels for what those forms do not cover);
                               64: the matrix-instruction family: the wave kernels where they exist (I2cDims.wave: one wavefront per
-                              trajectory, forward and backward sweeps), the quad forward kernel otherwise (I2cDims.quad);
+                              trajectory, forward and backward sweeps), the quad kernels otherwise (I2cDims.quad: four trajectories per
+                              wavefront) -- the forward sweep and, since round 6, the backward sweep of every d <= 8 model (the fused walk,
+                              one pass over the forward messages, no chunk workspace: with backward_mode I2C_BWD_AUTO or I2C_BWD_FUSED;
+                              I2C_BWD_CHUNKED / I2C_BWD_TWO_PASS name lane schedules and keep the lane backward sweep);
                               I2C_LANES_QUAD: the quad kernels of a model that also has wave kernels, at any batch size;
                               (all of these: fp64 or I2C_F64_F32S, cubature rule with lam = 0 -- any weights for the quad forward kernel of
                               the pendulum / cartpole / double cartpole; the closed-loop propagation and the filter step of the d = 16

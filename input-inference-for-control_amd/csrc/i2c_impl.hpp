@@ -718,9 +718,10 @@ static void chunk_geometry(int B, int T, int* n_chunks, int* chunk_len) {
     const char* e = getenv("I2C_CHUNKS");
     return e ? atoi(e) : 0;
   }();
-  int nc = forced > 0 ? forced : (65536 + B - 1) / B;
+  int nc = (65536 + B - 1) / B;
   if (nc > 32) nc = 32;
   if (nc > T / 4) nc = T / 4;
+  if (forced > 0) nc = forced < T ? forced : T;  // (the knob overrides the caps: tools/r6_chunk_sweep.sh)
   if (nc < 1) nc = 1;
   const int len = (T + nc - 1) / nc;
   *chunk_len = len;

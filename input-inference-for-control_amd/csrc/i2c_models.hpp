@@ -19,7 +19,10 @@ namespace i2c {
 // kernels. An OUT-OF-TREE model (`python build.py --model my_model.hpp`) derives from this and states
 // its dimensions, its structure hints and its three functions; it may opt into the multi-lane families by overriding a knob:
 //   GROUP = 4 / 8 / 16   group kernels (G lanes per trajectory; G >= the largest of d, nz, and a power of two)
-//   QUAD = true          quad forward kernel: d <= 8 with an identity observation, or d % 4 != 0 with one action (i2c_quad.hpp)
+//   QUAD = true          quad kernels: d <= 8 with an identity observation, or d % 4 != 0 with one action (i2c_quad.hpp): the forward sweep
+//                        inside [QUAD_FORWARD_MIN_B, QUAD_FORWARD_MAX_B] by default, and both sweeps on request (group_lanes = 64)
+//   (optional) QUAD_BACKWARD8_MIN_B / _MAX_B: a default batch window for the d <= 8 quad backward walk (none is measured faster
+//                        than the chunked lane schedule on MI355X, so no in-tree model sets it)
 struct ModelDefaults {
   static constexpr int ID = -1;   // in-tree models: their I2C_MODEL_* value; plugins get an id from i2c_register_model
   static constexpr int NP = 0, NA = 0;
@@ -57,7 +60,7 @@ struct Pendulum {
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   static constexpr int QUAD_FORWARD_MIN_B = 0;
-  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (the quad backward sweep exists for d = 16 only)
+  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (d = 16 only; the d <= 8 quad backward walk has no default window: on request)
   I2C_HD static constexpr int ang(int) { return 0; }
   // z = [sin th, cos th, thd, u],  zT = [sin th, cos th, thd]
   I2C_HD static constexpr int obs_lin(int k) { return k < 2 ? -1 : k - 1; }
@@ -105,7 +108,7 @@ struct PendulumActReg {
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   static constexpr int QUAD_FORWARD_MIN_B = 0;
-  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (the quad backward sweep exists for d = 16 only)
+  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (d = 16 only; the d <= 8 quad backward walk has no default window: on request)
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int) { return 2; }  // z = [u]
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -134,7 +137,7 @@ struct Cartpole {
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 4096;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   static constexpr int QUAD_FORWARD_MIN_B = 0;
-  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (the quad backward sweep exists for d = 16 only)
+  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (d = 16 only; the d <= 8 quad backward walk has no default window: on request)
   I2C_HD static constexpr int ang(int) { return 1; }
   // z = [x, sin th, cos th, xd, thd, u],  zT = [x, sin th, cos th, xd, thd]
   I2C_HD static constexpr int obs_lin(int k) { return k == 0 ? 0 : (k < 3 ? -1 : k - 1); }
@@ -190,7 +193,7 @@ struct DoubleCartpole {
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 8192;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   static constexpr int QUAD_FORWARD_MIN_B = 0;
-  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (the quad backward sweep exists for d = 16 only)
+  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (d = 16 only; the d <= 8 quad backward walk has no default window: on request)
   static constexpr int BWD_FUSED_MIN_B = 20480;  // I2C_BWD_AUTO runs the fused backward walk from here up: its rows are the widest (104 doubles), the chunked form keeps its lead longer (measured: 16384: chunked 1.67 / fused 1.86 ms; 24576: 3.44 / 2.20)
   I2C_HD static constexpr int ang(int a) { return a == 0 ? 1 : 2; }
   // z = [x, sin th1, cos th1, sin th2, cos th2, xd, th1d, th2d, u],  zT = z without u
@@ -273,7 +276,7 @@ struct Linear {
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   static constexpr int QUAD_FORWARD_MIN_B = 0;
-  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (the quad backward sweep exists for d = 16 only)
+  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (d = 16 only; the d <= 8 quad backward walk has no default window: on request)
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -311,7 +314,7 @@ struct LinearMinEnergy {
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 0;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   static constexpr int QUAD_FORWARD_MIN_B = 0;
-  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (the quad backward sweep exists for d = 16 only)
+  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (d = 16 only; the d <= 8 quad backward walk has no default window: on request)
   I2C_HD static constexpr int ang(int) { return 0; }
   I2C_HD static constexpr int obs_lin(int) { return 2; }  // z = [u], zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }
@@ -350,7 +353,7 @@ struct Quadrotor {
   static constexpr bool QUAD = true;  // four-trajectories-per-wavefront forward kernel (i2c_quad.hpp): d <= 8 models
   static constexpr int QUAD_FORWARD_MAX_B = 8192;  // the quad kernel is the DEFAULT forward sweep up to this batch size (measured crossover, profiles/README.md); 0: only on request
   static constexpr int QUAD_FORWARD_MIN_B = 0;
-  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (the quad backward sweep exists for d = 16 only)
+  static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (d = 16 only; the d <= 8 quad backward walk has no default window: on request)
   I2C_HD static constexpr int ang(int) { return 2; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x
   I2C_HD static constexpr int obs_dep(int) { return 0; }

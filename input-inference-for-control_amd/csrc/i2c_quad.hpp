@@ -173,7 +173,7 @@ template <class M, typename R, class DST> I2C_FN void qconst_fill(DST& k, const 
   for (int e = tid; e < QLD * QLD; e += nthreads) {
     const int i = e / QLD, j = e % QLD;
     k.xi[e] = (i < NZ && j < NZ) ? c->sig_xi0[tri_any(i, j)] : R(0);
-    k.eta[e] = (i < NX && j < NX) ? c->sig_eta[tri_any(i, j)] : R(0);
+    k.eta[e] = (i < NX && j < NX) ? c->sig_eta_w[tri_any(i, j)] : R(0);  // W sig_eta = sum_p w_p sig_eta (quadrature.py:57; W = 1 unless 1 - alpha^2 + beta != 0)
     k.xiT[e] = (i < NT && j < NT) ? c->sig_xiT0[tri_any(i, j)] : R(0);
     k.qr[e] = (i < NZ && j < NZ) ? c->QR[tri_any(i, j)] : R(0);
     k.qf[e] = (i < NT && j < NT) ? c->Qf[tri_any(i, j)] : R(0);
@@ -1659,6 +1659,13 @@ I2C_HD inline void backward_quad_body(const Consts<M, R>& c, const KC& kc, const
       for (int k = 0; k < NBX * NBD; ++k) p1[k] = R(0);
       q_tn<NBX, NBX, NBD>(q, dsf, jt, p1);            // dS J^T
       q_tn<NBX, NBD, NBD, false, true>(q, jt, p1, sg);  // J (dS J^T), upper blocks
+      // the diagonal blocks exactly symmetric again (round 6, see backward_quad8_body: both triangles of J dS J^T are computed, each
+      // with its own rounding, and the antisymmetric part of the carried covariance obeys A <- Jx A Jx^T along the chain)
+#pragma unroll
+      for (int i = 0; i < NBD; ++i) {
+        const R st_ = q_tr(q, sg[i * NBD + i]);
+        sg[i * NBD + i] = up ? sg[i * NBD + i] : st_;
+      }
     }
     // posterior observation moments = the joint itself (identity observation, i2c.py:594-596) and their expected cost
     {

@@ -442,3 +442,23 @@ def test_hip_quad_backward_failure_is_per_trajectory(lib):
     for a, b in zip(eng.marginal_state_action() + eng.local_linear_policy(), clean.marginal_state_action() + clean.local_linear_policy()):
         assert torch.equal(a[ok], b[ok])
     assert not torch.isfinite(eng.local_linear_policy()[0][2, 17]).all()  # the failed cell's controller is NaN, not silently wrong
+
+
+def test_hip_quad_sweeps_minimum_energy_model_vs_oracle(lib):
+    """LinearKnownMinimumEnergy (only the action is observed, identity terminal observation, covariance control with a tempered
+    terminal prior; env_def.py:173-230) ships with a Linearize golden only: the same problem under the cubature rule, both sweeps on
+    the quad kernels, against the batched oracle."""
+    eng, _ = parity.check_batch_against_oracle("lin_covctrl_T50", lib, "cuda", 6, 3, tol=1e-7 if "cuda" == "cpu" else 1e-6, group_lanes=64,
+                                               meta_override={"inference": "cubature", "quad": [1.0, 0.0, 0.0]})
+    assert (eng.forward_family, eng.backward_family) == ("quad", "quad")
+
+
+@pytest.mark.parametrize("name,B", [("em_pendulum_T200", 259), ("em_cartpole_T100", 67), ("em_dcp_T60", 131)])
+def test_hip_quad_sweeps_weights_that_do_not_sum_to_one(lib, name, B):
+    """CubatureQuadrature(1.05, 0, 0.3): W = sum of weights_sig = 2 - alpha^2 + beta = 0.8975 -- the reference weighs the mean, the
+    covariance AND the process noise (sum_p w_p sig_eta = W sig_eta, quadrature.py:57) with it. Round 6 found the quad forward kernel's
+    GENERAL variant adding the UNWEIGHTED sig_eta (every earlier general-weights case -- (1.2, 0.44, 0.5), (1, 0, 0.5) -- happens to have
+    W = 1): up to 0.35 relative on the double cartpole. Both quad sweeps against the batched oracle with the same rule. (W > 1 is not a
+    usable regime: the reference's own covariances lose positive definiteness.)"""
+    eng, _ = parity.check_batch_against_oracle(name, lib, "cuda", B, 2, tol=1e-6, quad=(1.05, 0.0, 0.3), group_lanes=64)
+    assert (eng.forward_family, eng.backward_family) == ("quad", "quad")

@@ -55,6 +55,12 @@ def _replay(name, lib, device, tol, group_lanes=0):
         assert_close(u[:, 0], g["ctrl"][t], tol * 10, f"{name} control, step {t}")
         assert_close(i2c.alpha, g["alpha_steps"][t], tol, f"{name} alpha, step {t}")
     assert_close(pol.xu_history[-1][:, :, 0], g["xu_plan_last"], tol * 10, f"{name} last plan")
+    # the histories of the single closed loop (round 6: device-side snapshots, host arrays when read): one entry per step, the
+    # filtered beliefs the steps reported, every plan with the reference's shape
+    assert len(pol.mus) == len(pol.covars) == len(pol.xu_history) == len(pol.z_history) == meta["steps"]
+    assert_close(np.stack([m[:, 0] for m in pol.mus]), g["mu"], tol, f"{name} mus history")
+    assert_close(np.stack(list(pol.covars)), g["covar"], tol * 10, f"{name} covars history")
+    assert all(h.shape == (meta["T"], model.dim_xu, 1) for h in pol.xu_history[:3]) and pol.z_history[0].shape == (meta["T"], model.dim_z)
     # the horizon shift: after the loop the last cell is a fresh feed-forward cell
     assert i2c.cells[-1].state_action_independence
     return pol
