@@ -452,9 +452,13 @@ template <class M, typename R, int NOUT> struct ObserveHeadF {
 // No masks: a pair beyond the input dimension IS a centre evaluation (its sum and difference vanish exactly), and the output
 // columns beyond NOUT are written as zeros by every lane.
 //   muc: mean, column form [NBI]; lt: L^T, upper blocks [NBI][NBI]
-template <class M, class G, int DIN, int NOUT, class F, typename R>
+// CENTRE (general cubature weights, round 6): the reference value must BE the centre value f(m). Where every pair row carries a
+// point (DIN = the geometry's pair rows: the planar quadrotor, d = 8) every lane evaluates the centre once more, for itself -- the
+// whole output vector lands in its registers and it keeps the entries of its block column: no exchange.
+template <class M, class G, int DIN, int NOUT, bool CENTRE = false, class F, typename R>
 I2C_FN void q_points(const Quad<R>& q, const R sf, const R* muc, const R* lt, const F& f, R* am, R* dm, R* yc) {
   constexpr int NBI = (DIN + 3) / 4, NBO = (NOUT + 3) / 4, PR = G::PR, LDL = G::LDL, YLD = G::YLD;
+  static_assert(!CENTRE || !G::WIDE, "q_points: the extra centre evaluation exists for the d <= 8 geometry");
   constexpr int NA1 = M::NA > 0 ? M::NA : 1;
   static_assert(DIN <= PR && NOUT <= 12 && 4 * NBI <= PR, "quad kernels: <= 16 inputs, <= 12 evaluated outputs");
   const auto Lr = q.sh + G::O_L, Y = q.sh + G::O_Y, mv = q.sh + G::O_MV;
@@ -493,6 +497,22 @@ I2C_FN void q_points(const Quad<R>& q, const R sf, const R* muc, const R* lt, co
 #pragma unroll
     for (int k = 0; k < 4 * NBO; ++k) Y[yrow + k] = k < NOUT ? y[k < NOUT ? k : 0] : R(0);
   }
+  if constexpr (CENTRE && DIN >= PR) {
+    R x[DIN], sn[NA1], cs[NA1], y[NOUT];
+#pragma unroll
+    for (int i = 0; i < DIN; ++i) x[i] = mv[i];
+#pragma unroll
+    for (int k = 0; k < M::NA; ++k) r_sincos(x[M::ang(k)], &sn[k], &cs[k]);
+    f(x, sn, cs, y);
+#pragma unroll
+    for (int j = 0; j < NBO; ++j) {
+      R v = R(0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (4 * j + k < NOUT) v = q.c == k ? y[4 * j + k] : v;
+      yc[j] = v;
+    }
+  }
   q.sync();
 #pragma unroll
   for (int j = 0; j < NBO; ++j) {
@@ -500,6 +520,8 @@ I2C_FN void q_points(const Quad<R>& q, const R sf, const R* muc, const R* lt, co
     R y0;
     if constexpr (DIN < PR) {
       y0 = Y[(PR - 1) * YLD + col];
+    } else if constexpr (CENTRE) {
+      y0 = yc[j];  // (evaluated below the points, before this loop)
     } else {
       y0 = R(0.5) * (Y[col] + Y[PR * YLD + col]);
     }
@@ -668,6 +690,29 @@ I2C_FN bool q_kalman_identity(const Quad<R>& q, const R alpha, const P xi_m, con
   return ok;
 }
 
+// The identity-observation update under GENERAL cubature weights (round 6): z = the N-vector itself, so the rule's moments are exact
+// (quadrature.py:34-44 with y_p = x_p and 2 wi sf^2 = 1):  mz = W m,  sig_z = S + (W - W^2) m m^T,  cov(z, x) = S  -- the W = 1 forms
+// above are the special case. Through the general update (q_kalman). s: upper blocks (the diagonal ones full), in and out.
+template <int N, int QLD, typename R, class P>
+I2C_FN bool q_kalman_identity_general(const Quad<R>& q, const R W, const R alpha, const P xi_m, const R* ztc, R* muc, R* s, const int kz = 0) {
+  constexpr int NB = (N + 3) / 4;
+  const R cww = W - W * W;
+  R mz[NB], mr[NB], sz[NB * NB], szx[NB * NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    mz[i] = W * muc[i];
+    mr[i] = q_tr(q, muc[i]);  // row form
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      szx[i * NB + j] = j >= i ? s[i * NB + j] : q_tr(q, s[j * NB + i]);
+      sz[i * NB + j] = j >= i ? s[i * NB + j] + cww * (mr[i] * muc[j]) + alpha * q_ldc<QLD>(q, xi_m, i, j, kz) : R(0);
+    }
+  return q_kalman<N, N>(q, muc, s, mz, sz, szx, ztc);
+}
+
 // The identity-observation update in square-root form (round 5; the mathematics in w_kalman_sqrt, i2c_wave.hpp): the prior arrives
 // as l0 = chol(s)^T (upper blocks), and with N^-1 = W / alpha
 //   s_new = L (I + L^T N^-1 L)^-1 L^T,   chol(s_new) = L U^-T   for   I + L^T N^-1 L = U U^T  (U upper triangular),
@@ -811,14 +856,12 @@ template <typename R, typename S, bool TM> struct QIO {
 //   * feed-forward cells (i2c.py:355-360) are the same arithmetic with Kt = 0.
 // `live`: trajectory slot b holds a real trajectory (the last wave of a batch that is not a multiple of four repeats its last
 // one in the spare slots: every lane of a wave takes part in the matrix instructions; nothing is stored for them)
-// GENERAL: cubature weights with lam != 0 / weights that do not sum to one (q_moments). For the models that evaluate every
-// observation through their sigma points and have a spare pair row for the centre (quad_general_exists): the identity-observation
-// forms take their moments from the input covariance, which is the W = 1 case only.
-template <class M> constexpr bool quad_general_exists() {
-  constexpr int D = M::NX + M::NU, NT = M::NZT > 0 ? M::NZT : 1;
-  return !QG<M>::WIDE && D < QG<M>::PR && !(st_identity<ObsStruct<M>, M::NZ>() && M::NZ == D) &&
-         !(M::NZT > 0 && st_identity<TermStruct<M>, NT>() && NT == M::NX);
-}
+// GENERAL: cubature weights with lam != 0 / weights that do not sum to one (q_moments), for every model of the d <= 8 geometry
+// (quad_general_exists; round 5: the models whose observations all go through sigma points; round 6: the identity-observation
+// models too -- their moments are exact, mean W m, covariance S + (W - W^2) m m^T, cross-covariance S, and go through the general
+// Kalman-style update instead of the factor form, which is the W = 1 case; a model whose 2 d points fill the sixteen lanes of a
+// trajectory evaluates the centre in an extra pass, q_points<CENTRE>).
+template <class M> constexpr bool quad_general_exists() { return !QG<M>::WIDE; }
 #ifndef I2C_QUAD_SQRT_ID
 #define I2C_QUAD_SQRT_ID 1  // (A/B knob: 0 = the covariance form of the identity-observation update, q_kalman_identity)
 #endif
@@ -834,7 +877,8 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
   constexpr bool OBS_ID = st_identity<ObsStruct<M>, NZ>() && NZ == D;
   constexpr bool TERM_ID = NZT > 0 && st_identity<TermStruct<M>, NT>() && NT == NX;
   // identity observation of a joint made of whole blocks (12-state and planar quadrotor): the update works on the factor
-  constexpr bool SQRT_ID = I2C_QUAD_SQRT_ID && OBS_ID && D % 4 == 0;
+  constexpr bool SQRT_ID = I2C_QUAD_SQRT_ID && OBS_ID && D % 4 == 0 && !GENERAL;  // (the factor form is the W = 1 case)
+  constexpr bool CENTRE = GENERAL && D >= QG<M>::PR;  // no spare pair row for the centre point: an extra evaluation (q_points)
   // the last observation output as a scalar pre-elimination (see stage 2): a pass-through of a coordinate of the joint's last block
   // that would otherwise be a block row of its own
 #ifndef I2C_QUAD_LASTLIN
@@ -843,7 +887,7 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
   constexpr int JZL = M::obs_lin(NZ - 1);
   // (unit weights only: with W != 1 the moments of a pass-through output carry (W - W^2) m^2 terms, q_moments)
   constexpr bool LASTLIN = I2C_QUAD_LASTLIN && !GENERAL && !OBS_ID && NZ % 4 == 1 && NZ > 4 && JZL >= 0 && JZL / 4 == (D + 3) / 4 - 1;
-  static_assert(!GENERAL || quad_general_exists<M>(), "general cubature weights: sigma-point observations and a spare pair row for the centre");
+  static_assert(!GENERAL || quad_general_exists<M>(), "general cubature weights: the d <= 8 geometry");
   static_assert(OBS_ID || D % 4 != 0, "quad kernels: a general observation needs a spare column in the joint's last block");
   static_assert(OBS_ID || NU == 1, "quad kernels: a general observation with one action (the factor of S_u|x is a square root)");
   constexpr int JU = NX / 4, CU = NX % 4;  // the block (row and column) and the in-block offset where the action entries start
@@ -1163,6 +1207,8 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
       cell_bad = flag_stage(cell_bad, q_kalman_sqrt<D, QLD>(q, alpha, kc.qr, c.qr_diag != 0, zt, mu0, lt0, zf, s0, kz), 2);
 #pragma unroll
       for (int k = 0; k < NBD * NBD; ++k) lt0[k] = zf[k];
+    } else if constexpr (OBS_ID && GENERAL) {
+      cell_bad = flag_stage(cell_bad, q_kalman_identity_general<D, QLD>(q, rule.W, alpha, kc.xi, zt, mu0, s0, kz), 2);
     } else if constexpr (OBS_ID) {
       R sf_[NBD * NBD];  // full blocks for the identity form
 #pragma unroll
@@ -1273,7 +1319,7 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
       }
       I2C_QSTAMP(5);  // stores + chol(updated joint)
       R am[NBD * NBX], dm[NBD * NBX], yc[NBX], sy[NBX * NBX];
-      q_points<M, G, D, NX>(q, rule.sf, mu0, lt, DynamicsF<M, R>{c.params}, am, dm, yc);
+      q_points<M, G, D, NX, CENTRE>(q, rule.sf, mu0, lt, DynamicsF<M, R>{c.params}, am, dm, yc);
       I2C_QSTAMP(6);  // dynamics points
       q_moments<D, NX, GENERAL>(q, rule, am, dm, yc, mx, sy);
 #pragma unroll
@@ -1303,7 +1349,9 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
       R ztT[NBT];
 #pragma unroll
       for (int j = 0; j < NBT; ++j) ztT[j] = q_ldv(q, kc.zgT, j, kz);
-      if constexpr (TERM_ID) {
+      if constexpr (TERM_ID && GENERAL) {
+        cell_bad = flag_stage(cell_bad, q_kalman_identity_general<NX, QLD>(q, c.rule_x.W, alpha, kc.xiT, ztT, mx, sx, kz), 5);
+      } else if constexpr (TERM_ID) {
         R sf_[NBX * NBX];
 #pragma unroll
         for (int i = 0; i < NBX; ++i)
@@ -1813,7 +1861,7 @@ I2C_HD inline void backward_quad8_body(const Consts<M, R>& c, const KC& kc, cons
   constexpr int NX = C::NX, NU = C::NU, NZ = C::NZ, NZT = C::NZT, D = C::D, NT = C::NZT1, QLD = G::QLD;
   constexpr int NBX = (NX + 3) / 4, NBD = (D + 3) / 4, NBZ = (NZ + 3) / 4, NBT = (NT + 3) / 4;
   static_assert(quad_backward8_exists<M>(), "quad backward sweep (d <= 8): the actions live in one block");
-  static_assert(!GENERAL || quad_general_exists<M>(), "general cubature weights: sigma-point observations and a spare pair row for the centre");
+  static_assert(!GENERAL || quad_general_exists<M>(), "general cubature weights: the d <= 8 geometry");
   constexpr bool OBS_ID = st_identity<ObsStruct<M>, NZ>() && NZ == D;
   constexpr bool TERM_ID = NZT > 0 && st_identity<TermStruct<M>, NT>() && NT == NX;
   constexpr int JU = NX / 4, CU = NX % 4;  // the block (row and column) and the in-block offset where the action entries start
@@ -1960,18 +2008,27 @@ I2C_HD inline void backward_quad8_body(const Consts<M, R>& c, const KC& kc, cons
     R trT = R(0);
     if (NZT > 0 && c.has_Qf) {
       if constexpr (TERM_ID) {
-        R errT[NBX], pm, pv;
+        // identity terminal observation: the rule's exact moments  mzT = W m,  sig_zT = S + (W - W^2) m m^T  (W = 1: the state itself)
+        R mzt[NBX], szt[NBX * NBX], errT[NBX], pm, pv;
+        const R Wx = GENERAL ? c.rule_x.W : R(1), cww = Wx - Wx * Wx;
 #pragma unroll
-        for (int j = 0; j < NBX; ++j) errT[j] = m3m[j] - q_ldv(q, kc.zgT, j, kz);
-        q_cost_share<NBX, NBX, QLD>(q, c.qf_diag != 0, kc.qf, errT, s3m, &pm, &pv, kz);
+        for (int i = 0; i < NBX; ++i) {
+          mzt[i] = GENERAL ? Wx * m3m[i] : m3m[i];
+          const R mr = GENERAL ? q_tr(q, m3m[i]) : R(0);
+#pragma unroll
+          for (int j = 0; j < NBX; ++j) szt[i * NBX + j] = (GENERAL && j >= i) ? s3m[i * NBX + j] + cww * (mr * m3m[j]) : s3m[i * NBX + j];
+        }
+#pragma unroll
+        for (int j = 0; j < NBX; ++j) errT[j] = mzt[j] - q_ldv(q, kc.zgT, j, kz);
+        q_cost_share<NBX, NBX, QLD>(q, c.qf_diag != 0, kc.qf, errT, szt, &pm, &pv, kz);
         trT = q_sum16(q, pm);
         if (live) {
 #pragma unroll
           for (int j = 0; j < NBX; ++j) {
-            if (r == 0 && in_col(j, NX)) a.term_stats[(long)(3 + 4 * j + cc) * B + b] = m3m[j];
+            if (r == 0 && in_col(j, NX)) a.term_stats[(long)(3 + 4 * j + cc) * B + b] = mzt[j];
 #pragma unroll
             for (int i = 0; i <= j; ++i)
-              if ((i < j || up) && in_col(j, NX)) a.term_stats[(long)(3 + NT + sym_lane(i, j) + sym_k(i, j)) * B + b] = s3m[i * NBX + j];
+              if ((i < j || up) && in_col(j, NX)) a.term_stats[(long)(3 + NT + sym_lane(i, j) + sym_k(i, j)) * B + b] = szt[i * NBX + j];
           }
         }
       } else if constexpr (NZT > 0) {
@@ -2078,18 +2135,27 @@ I2C_HD inline void backward_quad8_body(const Consts<M, R>& c, const KC& kc, cons
     {
       R pm, pv;
       if constexpr (OBS_ID) {
-        R err[NBD];
+        // identity observation: the rule's exact moments  mz = W mu,  sig_z = sig + (W - W^2) mu mu^T  (W = 1: the joint itself)
+        R mz[NBD], sz[NBD * NBD], err[NBD];
+        const R Wd = GENERAL ? rule.W : R(1), cww = Wd - Wd * Wd;
 #pragma unroll
-        for (int j = 0; j < NBD; ++j) err[j] = mu[j] - zt[j];
-        q_cost_share<NBD, NBD, QLD>(q, c.qr_diag != 0, kc.qr, err, sg, &pm, &pv, kz);
+        for (int i = 0; i < NBD; ++i) {
+          mz[i] = GENERAL ? Wd * mu[i] : mu[i];
+          const R mr = GENERAL ? q_tr(q, mu[i]) : R(0);
+#pragma unroll
+          for (int j = 0; j < NBD; ++j) sz[i * NBD + j] = (GENERAL && j >= i) ? sg[i * NBD + j] + cww * (mr * mu[j]) : sg[i * NBD + j];
+        }
+#pragma unroll
+        for (int j = 0; j < NBD; ++j) err[j] = mz[j] - zt[j];
+        q_cost_share<NBD, NBD, QLD>(q, c.qr_diag != 0, kc.qr, err, sz, &pm, &pv, kz);
         if (a.zpost && live) {
           S* zo = a.zpost + ((long)t * C::E_ZPOST) * B + b;
 #pragma unroll
           for (int j = 0; j < NBD; ++j) {
-            if (r == 0 && in_col(j, D)) zo[(long)(4 * j + cc) * B] = (S)mu[j];
+            if (r == 0 && in_col(j, D)) zo[(long)(4 * j + cc) * B] = (S)mz[j];
 #pragma unroll
             for (int i = 0; i <= j; ++i)
-              if ((i < j || up) && in_col(j, D)) zo[(long)(NZ + sym_lane(i, j) + sym_k(i, j)) * B] = (S)sg[i * NBD + j];
+              if ((i < j || up) && in_col(j, D)) zo[(long)(NZ + sym_lane(i, j) + sym_k(i, j)) * B] = (S)sz[i * NBD + j];
           }
         }
       } else {

@@ -257,12 +257,11 @@ def test_hostsim_square_root_update_at_extreme_temperatures(lib, name, lanes, fa
 
 
 def test_quad_forward_refuses_what_it_does_not_cover(lib):
-    """General cubature weights (a weight on the centre point) are in the quad form only where every observation goes through the
-    sigma points and the geometry has a spare pair row for the centre (pendulum, cartpole, double cartpole: round 5); the
-    identity-observation models, d = 8 / 16 and the other inference rules are refused with I2C_ENOTSUP when asked for explicitly."""
-    for name in ("em_linear_T60", "em_quadrotor_T20"):
-        with pytest.raises(RuntimeError, match="-2"):
-            parity.engine_from_case(load_case(name), lib, "cpu", quad=(1.2, 0.44, 0.5), group_lanes=64)
+    """General cubature weights (a weight on the centre point, weights that need not sum to one) are in the quad form for every
+    model of the d <= 8 geometry (round 5: where every observation goes through the sigma points; round 6: the identity-observation
+    models too); d = 16 and the other inference rules are refused with I2C_ENOTSUP when asked for explicitly."""
+    with pytest.raises(RuntimeError, match="-2"):
+        parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu", quad=(1.2, 0.44, 0.5), group_lanes=parity.pkg._native.LANES_QUAD)
     with pytest.raises(RuntimeError, match="-2"):  # Linearize() on the quad kernels
         parity.engine_from_case(load_case("lin_pendulum_T100"), lib, "cpu", group_lanes=64)
     with pytest.raises(ValueError):  # d = 16 has the wave kernels under 64; models without either refuse it
@@ -570,3 +569,17 @@ def test_hostsim_quad_sweeps_weights_that_do_not_sum_to_one(lib, name, B):
     usable regime: the reference's own covariances lose positive definiteness.)"""
     eng, _ = parity.check_batch_against_oracle(name, lib, "cpu", B, 2, tol=1e-7, quad=(1.05, 0.0, 0.3), group_lanes=64)
     assert (eng.forward_family, eng.backward_family) == ("quad", "quad")
+
+
+@pytest.mark.parametrize("name,quad", [("em_quadrotor_T20", (1.2, 0.44, 0.5)), ("em_linear_T60", (1.2, 0.44, 0.5)), ("em_linear_T60", (1.05, 0.0, 0.3)),
+                                       ("lin_covctrl_T50", (1.2, 0.44, 0.5))])
+def test_hostsim_quad_sweeps_general_weights_identity_observation_models(lib, name, quad):
+    """Round 6 (review item 8, the d <= 8 part): CubatureQuadrature(alpha, beta, kappa) with lam != 0 / W != 1 on the models whose
+    observation is the joint itself (planar quadrotor: d = 8, no spare pair row -- the centre is an extra evaluation pass; linear models;
+    the minimum-energy model's identity TERMINAL observation): exact moments W m, S + (W - W^2) m m^T through the general update in the
+    forward sweep, the same moments in the backward walk's cost -- both quad sweeps against the batched oracle."""
+    kw = dict(meta_override={"inference": "cubature"}) if name.startswith("lin_") else {}
+    eng, _ = parity.check_batch_against_oracle(name, lib, "cpu", 5, 2, tol=1e-6, quad=quad, group_lanes=64, **kw)
+    assert (eng.forward_family, eng.backward_family) == ("quad", "quad")
+    if name == "em_quadrotor_T20":  # ... and it is the DEFAULT forward sweep of such a problem inside the quad window (it was the group fallback)
+        assert parity.engine_from_case(load_case(name), lib, "cpu", quad=quad).forward_family == "quad"

@@ -242,11 +242,12 @@ def test_kernel_family_is_inspectable():
     assert eng("DoubleCartpoleKnown", 8192).forward_family == "quad"
     assert eng("DoubleCartpoleKnown", 8193).forward_family == "lane"   # ... and the lane kernels beyond
     assert eng("CartpoleKnown", 4096).forward_family == "quad" and eng("CartpoleKnown", 4097).forward_family == "lane"
-    # cubature weights with a weight on the centre point: the GENERAL variant of the quad kernel (round 5) inside the same window;
-    # what it does not cover (identity observations, d = 8) falls back to the round-2 hybrid: group forward while B * G <= 65536
+    # cubature weights with a weight on the centre point: the GENERAL variant of the quad kernel inside the same window -- round 5 for
+    # the sigma-point-observation models, round 6 for the identity-observation ones (the planar quadrotor used to fall back to the
+    # round-2 hybrid, the group forward sweep)
     assert eng("DoubleCartpoleKnown", 4096, quad=(1.2, 0.44, 0.5)).forward_family == "quad"
     assert eng("DoubleCartpoleKnown", 8193, quad=(1.2, 0.44, 0.5)).forward_family == "lane"
-    assert eng("PlanarQuadrotor", 4096, quad=(1.2, 0.44, 0.5)).forward_family == "group"
+    assert eng("PlanarQuadrotor", 4096, quad=(1.2, 0.44, 0.5)).forward_family == "quad"
     assert eng("PlanarQuadrotor", 8193, quad=(1.2, 0.44, 0.5)).forward_family == "lane"
     assert eng("DoubleCartpoleKnown", 64, group_lanes=True).forward_family == "group"
     assert eng("DoubleCartpoleKnown", 64, group_lanes=-1).forward_family == "lane"
