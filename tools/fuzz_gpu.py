@@ -1,6 +1,6 @@
 """More seeds of tests/test_fuzz_vs_oracle.py on the GPU than the test-suite runs: random problems (model, inference rule, horizon, batch,
 cost weights, temperature, feedback horizon, propagation, expert controller), every other one with a random kernel family asked for,
-against the CPU oracle.   python tools/fuzz_gpu.py [first_seed] [n_seeds]   (2026-10-03: seeds 1000..1399, 0 failures; round 5, after the quad-kernel, Gauss-Hermite and
+against the CPU oracle.   python tools/fuzz_gpu.py [first_seed] [n_seeds] [weights]   (`weights`: a random cubature rule on top, round 6)   (2026-10-03: seeds 1000..1399, 0 failures; round 5, after the quad-kernel, Gauss-Hermite and
 resolver work: seeds 2000..2299, 0 failures; after the square-root update of the identity-observation models and the four-wave
 workgroups of the quad forward kernel: seeds 60..699 and 3000..4499, 0 failures; round 6, with the d <= 8 quad backward walk behind every
 `group_lanes = 64` request: seeds 6000..7499, 0 failures)"""
@@ -12,10 +12,11 @@ import parity
 import test_fuzz_vs_oracle as f
 bad = 0
 lib = parity.pkg.load_library()
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-for seed in range(first, first + (int(sys.argv[2]) if len(sys.argv) > 2 else 400)):
+nums = [int(a) for a in sys.argv[1:] if a.isdigit()]
+first = nums[0] if nums else 1000
+for seed in range(first, first + (nums[1] if len(nums) > 1 else 400)):
     try:
-        f.run_random_case(lib, "cuda", seed, 1e-5, random_family=(seed % 2 == 0))
+        f.run_random_case(lib, "cuda", seed, 1e-5, random_family=(seed % 2 == 0), random_weights="weights" in sys.argv[1:])
     except AssertionError as e:
         bad += 1
         print("FAIL", seed, str(e)[:300], flush=True)
