@@ -102,9 +102,10 @@ enum {
  * wave kernels there): the 12-state quadrotor -- forward and backward sweep, at any batch size */
 #define I2C_LANES_QUAD 164
 enum { I2C_SWEEP_FORWARD = 0, I2C_SWEEP_BACKWARD = 1, I2C_SWEEP_PROPAGATE = 2, I2C_SWEEP_FILTER = 3 };
-/* hybrid default of the d >= 7 lane models WHERE THE QUAD FORWARD KERNEL DOES NOT APPLY (cubature weights with lam != 0): their
- * FORWARD sweep runs on the group kernels while B * G stays within this many lanes (every group wave then has a SIMD of its own:
- * 1024 SIMDs x 64 lanes). i2c_kernel_family() reports the family of a sweep. */
+/* hybrid default of a d >= 7 lane model WHOSE QUAD FORWARD KERNEL DOES NOT APPLY (none of the in-tree models since round 6: the quad
+ * kernels take any cubature weights; an out-of-tree model with GROUP_FORWARD_AUTO and no quad form): its FORWARD sweep runs on the
+ * group kernels while B * G stays within this many lanes (every group wave then has a SIMD of its own: 1024 SIMDs x 64 lanes).
+ * i2c_kernel_family() reports the family of a sweep. */
 #define I2C_GROUP_FORWARD_MAX_LANES 65536
 /* The family -- hence the last bits of a result -- of the d >= 5 models depends on the batch size: a caller who needs results
  * that do not depend on how a batch is sharded pins it (group_lanes = -1, 64 or I2C_LANES_QUAD); INTEGRATION.md section 1b. */
@@ -179,9 +180,10 @@ typedef struct I2cProblem {
                               one pass over the forward messages, no chunk workspace: with backward_mode I2C_BWD_AUTO or I2C_BWD_FUSED;
                               I2C_BWD_CHUNKED / I2C_BWD_TWO_PASS name lane schedules and keep the lane backward sweep);
                               I2C_LANES_QUAD: the quad kernels of a model that also has wave kernels, at any batch size;
-                              (all of these: fp64 or I2C_F64_F32S, cubature rule with lam = 0 -- any weights for the quad forward kernel of
-                              the pendulum / cartpole / double cartpole; the closed-loop propagation and the filter step of the d = 16
-                              model run on the quad kernels too: propagate_quad_body, ckf_quad_body)
+                              (all of these: fp64 or I2C_F64_F32S; the wave kernels: cubature rule with lam = 0; the quad kernels: any
+                              CubatureQuadrature(alpha, beta, kappa) -- with general weights the d = 16 model runs on them at every
+                              batch size; the closed-loop propagation and the filter step of the d = 16 model run on the quad
+                              kernels too: propagate_quad_body, ckf_quad_body)
                               I2cDims.group_lanes: run forward / backward / propagate / filter with that many lanes of
                               a wavefront per trajectory (fp64, cubature rule;
                               the backward sweep then has one schedule, the fused walk); -1: one lane per trajectory for

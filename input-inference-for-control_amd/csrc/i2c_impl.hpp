@@ -457,7 +457,7 @@ template <class M> constexpr bool quad_backward_exists() {
 template <class M> constexpr int quad_backward_lds() { return QG<M>::WIDE ? QBG<M>::SIZE : QG<M>::SIZE; }
 template <class M, typename R, typename S, bool GENERAL, bool LEANQ, class KC, class A>
 I2C_FN void quad_backward_dispatch(const Consts<M, R>& c, const KC& kc, const A& a, const int b, const bool live, const Quad<R>& q) {
-  if constexpr (QG<M>::WIDE) backward_quad_body<M, R, S>(c, kc, a, b, live, q);
+  if constexpr (QG<M>::WIDE) backward_quad_body<M, R, S, GENERAL>(c, kc, a, b, live, q);
   else backward_quad8_body<M, R, S, GENERAL, LEANQ>(c, kc, a, b, live, q);
 }
 #ifdef I2C_HOST_SIM
@@ -512,6 +512,9 @@ template <class M, typename R, typename S, class A>
 static int launch_quad_backward(const Consts<M, R>& c, const A& a, void* stream) {
   const bool unit = c.rule_xu.unit && c.rule_x.unit && c.rule_xu.w0 == R(0) && c.rule_x.w0 == R(0);
   if constexpr (QG<M>::WIDE) {
+    if constexpr (quad_general_exists<M>()) {
+      if (!unit) return launch_quad_backward_g<M, R, S, true, false>(c, a, stream);
+    }
     return unit ? launch_quad_backward_g<M, R, S, false, false>(c, a, stream) : I2C_ENOTSUP;
   } else {
     const bool lean = !a.xm && !a.zpost && !a.cell_stats;
@@ -525,8 +528,8 @@ static int launch_quad_backward(const Consts<M, R>& c, const A& a, void* stream)
 
 // the quad propagation (propagate_quad_body): d = 16 models with identity observations
 #ifdef I2C_HOST_SIM
-template <class M, typename R>
-static int launch_quad_propagate(const Consts<M, R>& c, const PropArgs<R>& a, void*) {
+template <class M, typename R, bool GENERAL>
+static int launch_quad_propagate_g(const Consts<M, R>& c, const PropArgs<R>& a, void*) {
   QPConst<M, R> kc;
   qpconst_fill<M, R>(kc, &c, 0, 1);
   for (int b0 = 0; b0 < c.B; b0 += 4) {
@@ -537,14 +540,14 @@ static int launch_quad_propagate(const Consts<M, R>& c, const PropArgs<R>& a, vo
       lanes.emplace_back([&, l, b0] {
         const int g = (l >> 2) & 3, b = b0 + g;
         const bool live = b < c.B;
-        propagate_quad_body<M, R>(c, kc, a, live ? b : c.B - 1, live, Quad<R>{l, l >> 4, g, l & 3, sh.data() + g * QG<M>::SIZE, &bar, xch.data()});
+        propagate_quad_body<M, R, GENERAL>(c, kc, a, live ? b : c.B - 1, live, Quad<R>{l, l >> 4, g, l & 3, sh.data() + g * QG<M>::SIZE, &bar, xch.data()});
       });
     for (auto& th : lanes) th.join();
   }
   return I2C_OK;
 }
 #else
-template <class M, typename R>
+template <class M, typename R, bool GENERAL = false>
 __global__ __launch_bounds__(64 * quad_waves_per_block<M>(), 2) void k_quad_propagate(const Consts<M, R> c, const PropArgs<R> a) {
   constexpr int WPB = quad_waves_per_block<M>();
   __shared__ QPConst<M, R> kc;
@@ -557,15 +560,24 @@ __global__ __launch_bounds__(64 * quad_waves_per_block<M>(), 2) void k_quad_prop
   const long b = b0 + g;
   const bool live = b < c.B;
   const Quad<R> q{l, l >> 4, g, l & 3, (lds_ptr<R>)(sh + (wv * 4 + g) * QG<M>::SIZE)};
-  propagate_quad_body<M, R>(c, kc, a, (int)(live ? b : c.B - 1), live, q);
+  propagate_quad_body<M, R, GENERAL>(c, kc, a, (int)(live ? b : c.B - 1), live, q);
 }
-template <class M, typename R>
-static int launch_quad_propagate(const Consts<M, R>& c, const PropArgs<R>& a, void* stream) {
+template <class M, typename R, bool GENERAL>
+static int launch_quad_propagate_g(const Consts<M, R>& c, const PropArgs<R>& a, void* stream) {
   constexpr int WPB = quad_waves_per_block<M>();
-  hipLaunchKernelGGL((k_quad_propagate<M, R>), dim3((unsigned)(((long)c.B + 4 * WPB - 1) / (4 * WPB))), dim3(64 * WPB), 0, (hipStream_t)stream, c, a);
+  hipLaunchKernelGGL((k_quad_propagate<M, R, GENERAL>), dim3((unsigned)(((long)c.B + 4 * WPB - 1) / (4 * WPB))), dim3(64 * WPB), 0, (hipStream_t)stream, c, a);
   return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
 }
 #endif
+// unit weights, or (round 6) the GENERAL variant: any CubatureQuadrature(alpha, beta, kappa)
+template <class M, typename R>
+static int launch_quad_propagate(const Consts<M, R>& c, const PropArgs<R>& a, void* stream) {
+  const bool unit = c.rule_xu.unit && c.rule_xu.w0 == R(0);
+  if constexpr (quad_general_exists<M>()) {
+    if (!unit) return launch_quad_propagate_g<M, R, true>(c, a, stream);
+  }
+  return unit ? launch_quad_propagate_g<M, R, false>(c, a, stream) : I2C_ENOTSUP;
+}
 
 // the quad filter step (ckf_quad_body): d = 16 models
 #ifdef I2C_HOST_SIM
@@ -827,12 +839,8 @@ template <class M, typename R, typename S = R> struct Impl {
       // the d = 16 form addresses trajectory-major buffers only: the posterior / prior in that layout (the engine's default for
       // the wave-capable models) and forward messages that the wave backward sweep reads
       if (p->post_layout != 1) return I2C_ENOTSUP;
-      if constexpr (HAS_WAVE) {
-        const int rw = wave_supported(p, c);
-        if (rw != I2C_OK) return rw;
-      } else {
-        return I2C_ENOTSUP;
-      }
+      if constexpr (!HAS_WAVE) return I2C_ENOTSUP;
+      // (what wave_supported checks beyond the rule -- the window sizes -- follows below; general weights are this family's alone)
     }
     constexpr long EMAX = C::E_FWD > C::E_POST ? C::E_FWD : C::E_POST;
     if (EMAX * (long)p->B * (long)sizeof(S) >= (1L << 31)) return I2C_EINVAL;
@@ -844,8 +852,8 @@ template <class M, typename R, typename S = R> struct Impl {
     if constexpr (HAS_QUAD_PROP) {  // the closed-loop propagation of a matrix-instruction graph: the quad form where it applies
       // (unit cubature rule -- a Linearize() graph propagates with it, i2c.py:109-115 --, trajectory-major posterior)
       if (sweep == I2C_SWEEP_PROPAGATE && (p->group_lanes == 0 || p->group_lanes == 64 || p->group_lanes == I2C_LANES_QUAD) &&
-          (p->inference == I2C_INF_CUBATURE || p->inference == I2C_INF_LINEARIZE) && p->post_layout == 1 && c.rule_xu.unit &&
-          c.rule_xu.w0 == R(0) && window_32bit_ok(p) == I2C_OK) {
+          (p->inference == I2C_INF_CUBATURE || p->inference == I2C_INF_LINEARIZE) && p->post_layout == 1 &&
+          ((c.rule_xu.unit && c.rule_xu.w0 == R(0)) || quad_general_exists<M>()) && window_32bit_ok(p) == I2C_OK) {
         // (the posterior / propagation cells are addressed through 32-bit offsets of one window per cell, masked stores parked at
         //  2 GiB like the other quad forms: beyond it the offsets would wrap silently -- refused here, as group_supported does)
         constexpr long EP = C::E_POST > C::E_PROP ? C::E_POST : C::E_PROP;
@@ -873,7 +881,9 @@ template <class M, typename R, typename S = R> struct Impl {
           min_b = quad_backward_window<M>::min_b, max_b = quad_backward_window<M>::max_b;
         }
       }
-      if (sweep_ok && (asked || (p->group_lanes == 0 && p->B >= min_b && p->B <= max_b))) {
+      // (d = 16 with general cubature weights: the wave kernels only have the unit rule -- the quad kernels at every batch size)
+      const bool general_wide = QG<M>::WIDE && quad_general_exists<M>() && (!c.rule_xu.unit || !c.rule_x.unit || c.rule_xu.w0 != R(0) || c.rule_x.w0 != R(0));
+      if (sweep_ok && (asked || (p->group_lanes == 0 && ((p->B >= min_b && p->B <= max_b) || general_wide)))) {
         const int rc = quad_supported(p, c);
         if (rc == I2C_OK) return I2C_FAMILY_QUAD;
         if (asked) return rc;

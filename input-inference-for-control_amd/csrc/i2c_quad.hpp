@@ -453,12 +453,11 @@ template <class M, typename R, int NOUT> struct ObserveHeadF {
 // columns beyond NOUT are written as zeros by every lane.
 //   muc: mean, column form [NBI]; lt: L^T, upper blocks [NBI][NBI]
 // CENTRE (general cubature weights, round 6): the reference value must BE the centre value f(m). Where every pair row carries a
-// point (DIN = the geometry's pair rows: the planar quadrotor, d = 8) every lane evaluates the centre once more, for itself -- the
-// whole output vector lands in its registers and it keeps the entries of its block column: no exchange.
+// point (DIN = the geometry's pair rows: the planar quadrotor, d = 8; the 12-state quadrotor, d = 16) every lane evaluates the centre
+// once more, for itself -- the whole output vector lands in its registers and it keeps the entries of its block column: no exchange.
 template <class M, class G, int DIN, int NOUT, bool CENTRE = false, class F, typename R>
 I2C_FN void q_points(const Quad<R>& q, const R sf, const R* muc, const R* lt, const F& f, R* am, R* dm, R* yc) {
   constexpr int NBI = (DIN + 3) / 4, NBO = (NOUT + 3) / 4, PR = G::PR, LDL = G::LDL, YLD = G::YLD;
-  static_assert(!CENTRE || !G::WIDE, "q_points: the extra centre evaluation exists for the d <= 8 geometry");
   constexpr int NA1 = M::NA > 0 ? M::NA : 1;
   static_assert(DIN <= PR && NOUT <= 12 && 4 * NBI <= PR, "quad kernels: <= 16 inputs, <= 12 evaluated outputs");
   const auto Lr = q.sh + G::O_L, Y = q.sh + G::O_Y, mv = q.sh + G::O_MV;
@@ -502,7 +501,10 @@ I2C_FN void q_points(const Quad<R>& q, const R sf, const R* muc, const R* lt, co
 #pragma unroll
     for (int i = 0; i < DIN; ++i) x[i] = mv[i];
 #pragma unroll
-    for (int k = 0; k < M::NA; ++k) r_sincos(x[M::ang(k)], &sn[k], &cs[k]);
+    for (int k = 0; k < M::NA; ++k) {
+      if constexpr (G::WIDE) r_sincos_sc(x[M::ang(k)], &sn[k], &cs[k]);
+      else r_sincos(x[M::ang(k)], &sn[k], &cs[k]);
+    }
     f(x, sn, cs, y);
 #pragma unroll
     for (int j = 0; j < NBO; ++j) {
@@ -861,7 +863,10 @@ template <typename R, typename S, bool TM> struct QIO {
 // models too -- their moments are exact, mean W m, covariance S + (W - W^2) m m^T, cross-covariance S, and go through the general
 // Kalman-style update instead of the factor form, which is the W = 1 case; a model whose 2 d points fill the sixteen lanes of a
 // trajectory evaluates the centre in an extra pass, q_points<CENTRE>).
-template <class M> constexpr bool quad_general_exists() { return !QG<M>::WIDE; }
+template <class M> constexpr bool quad_general_exists() {
+  constexpr int NT = M::NZT > 0 ? M::NZT : 1;
+  return !QG<M>::WIDE || (st_identity<ObsStruct<M>, M::NZ>() && M::NZ == M::NX + M::NU && (M::NZT == 0 || (st_identity<TermStruct<M>, NT>() && NT == M::NX)));
+}
 #ifndef I2C_QUAD_SQRT_ID
 #define I2C_QUAD_SQRT_ID 1  // (A/B knob: 0 = the covariance form of the identity-observation update, q_kalman_identity)
 #endif
@@ -887,7 +892,7 @@ I2C_HD inline void forward_quad_body(const Consts<M, R>& c, const KC& kc, const 
   constexpr int JZL = M::obs_lin(NZ - 1);
   // (unit weights only: with W != 1 the moments of a pass-through output carry (W - W^2) m^2 terms, q_moments)
   constexpr bool LASTLIN = I2C_QUAD_LASTLIN && !GENERAL && !OBS_ID && NZ % 4 == 1 && NZ > 4 && JZL >= 0 && JZL / 4 == (D + 3) / 4 - 1;
-  static_assert(!GENERAL || quad_general_exists<M>(), "general cubature weights: the d <= 8 geometry");
+  static_assert(!GENERAL || quad_general_exists<M>(), "general cubature weights: the d <= 8 geometry, or d = 16 with identity observations");
   static_assert(OBS_ID || D % 4 != 0, "quad kernels: a general observation needs a spare column in the joint's last block");
   static_assert(OBS_ID || NU == 1, "quad kernels: a general observation with one action (the factor of S_u|x is a square root)");
   constexpr int JU = NX / 4, CU = NX % 4;  // the block (row and column) and the in-block offset where the action entries start
@@ -1505,7 +1510,9 @@ I2C_FN void q_cost_share(const Quad<R>& q, const bool diag, const P wm, const R*
   *pv = R(2) * t2 + R(4) * qd;
 }
 
-template <class M, typename R, typename S, class KC>
+// GENERAL (round 6): any CubatureQuadrature(alpha, beta, kappa): the identity observation's exact moments  mz = W mu,
+// sig_z = sig + (W - W^2) mu mu^T  in the expected cost (and the terminal observation's likewise); W = 1 is the joint itself.
+template <class M, typename R, typename S, bool GENERAL = false, class KC>
 I2C_HD inline void backward_quad_body(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>& a, const int b, const bool live, const Quad<R>& qw) {
   using C = Consts<M, R>;
   using G = QG<M>;
@@ -1643,18 +1650,26 @@ I2C_HD inline void backward_quad_body(const Consts<M, R>& c, const KC& kc, const
       // terminal observation statistics (i2c.py:567-570, 989-992): tr(Qf (errT errT^T + sig_z3_m)), identity observation
       R trT = R(0);
       if (NZT > 0 && c.has_Qf) {
-        R errT[NBX], pm, pv;
+        R mzt[NBX], szt[NBX * NBX], errT[NBX], pm, pv;
+        const R Wx = GENERAL ? c.rule_x.W : R(1), cwx = Wx - Wx * Wx;
 #pragma unroll
-        for (int j = 0; j < NBX; ++j) errT[j] = m3m[j] - q_ldv(q, kc.zgT, j, kz);
-        q_cost_share<NBX, NBX, QLD>(q, c.qf_diag != 0, kc.qf, errT, s3m, &pm, &pv, kz);
+        for (int i = 0; i < NBX; ++i) {
+          mzt[i] = GENERAL ? Wx * m3m[i] : m3m[i];
+          const R mrx = GENERAL ? q_tr(q, m3m[i]) : R(0);
+#pragma unroll
+          for (int j = 0; j < NBX; ++j) szt[i * NBX + j] = (GENERAL && j >= i) ? s3m[i * NBX + j] + cwx * (mrx * m3m[j]) : s3m[i * NBX + j];
+        }
+#pragma unroll
+        for (int j = 0; j < NBX; ++j) errT[j] = mzt[j] - q_ldv(q, kc.zgT, j, kz);
+        q_cost_share<NBX, NBX, QLD>(q, c.qf_diag != 0, kc.qf, errT, szt, &pm, &pv, kz);
         trT = q_sum16(q, pm);
         if (live) {
 #pragma unroll
           for (int j = 0; j < NBX; ++j) {
-            if (r == 0) a.term_stats[(long)(3 + 4 * j + cc) * B + b] = m3m[j];
+            if (r == 0) a.term_stats[(long)(3 + 4 * j + cc) * B + b] = mzt[j];
 #pragma unroll
             for (int i = 0; i <= j; ++i)
-              if (i < j || up) a.term_stats[(long)(3 + NT + sym_lane(i, j) + sym_k(i, j)) * B + b] = s3m[i * NBX + j];
+              if (i < j || up) a.term_stats[(long)(3 + NT + sym_lane(i, j) + sym_k(i, j)) * B + b] = szt[i * NBX + j];
           }
         }
       }
@@ -1716,11 +1731,26 @@ I2C_HD inline void backward_quad_body(const Consts<M, R>& c, const KC& kc, const
       }
     }
     // posterior observation moments = the joint itself (identity observation, i2c.py:594-596) and their expected cost
+    R mzg[NBD], szg[NBD * NBD];  // (GENERAL: the observation moments; otherwise unused)
     {
       R err[NBD], pm, pv;
+      if constexpr (GENERAL) {
+        const R Wd = c.rule_xu.W, cwd = Wd - Wd * Wd;
 #pragma unroll
-      for (int j = 0; j < NBD; ++j) err[j] = mu[j] - zt[j];
-      q_cost_share<NBD, NBD, QLD>(q, c.qr_diag != 0, kc.qr, err, sg, &pm, &pv, kz);
+        for (int i = 0; i < NBD; ++i) {
+          mzg[i] = Wd * mu[i];
+          const R mrd = q_tr(q, mu[i]);
+#pragma unroll
+          for (int j = 0; j < NBD; ++j) szg[i * NBD + j] = j >= i ? sg[i * NBD + j] + cwd * (mrd * mu[j]) : sg[i * NBD + j];
+        }
+#pragma unroll
+        for (int j = 0; j < NBD; ++j) err[j] = mzg[j] - zt[j];
+        q_cost_share<NBD, NBD, QLD>(q, c.qr_diag != 0, kc.qr, err, szg, &pm, &pv, kz);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NBD; ++j) err[j] = mu[j] - zt[j];
+        q_cost_share<NBD, NBD, QLD>(q, c.qr_diag != 0, kc.qr, err, sg, &pm, &pv, kz);
+      }
       acc_m += pm;
       acc_v += pv;
       if (a.cell_stats) {
@@ -1788,10 +1818,10 @@ I2C_HD inline void backward_quad_body(const Consts<M, R>& c, const KC& kc, const
       S* zo = a.zpost + ((long)t * C::E_ZPOST) * B + b;
 #pragma unroll
       for (int j = 0; j < NBD; ++j) {
-        if (r == 0) zo[(long)(4 * j + cc) * B] = (S)mu[j];
+        if (r == 0) zo[(long)(4 * j + cc) * B] = (S)(GENERAL ? mzg[j] : mu[j]);
 #pragma unroll
         for (int i = 0; i <= j; ++i)
-          if (i < j || up) zo[(long)(NZ + sym_lane(i, j) + sym_k(i, j)) * B] = (S)sg[i * NBD + j];
+          if (i < j || up) zo[(long)(NZ + sym_lane(i, j) + sym_k(i, j)) * B] = (S)(GENERAL ? szg[i * NBD + j] : sg[i * NBD + j]);
       }
     }
 #pragma unroll
@@ -2352,7 +2382,7 @@ template <class M, typename R, class DST> I2C_FN void qpconst_fill(DST& k, const
   for (int e = tid; e < QLD * QLD; e += nthreads) {
     const int i = e / QLD, j = e % QLD;
     k.qr[e] = (i < NZ && j < NZ) ? c->QR[tri_any(i, j)] : R(0);
-    k.eta[e] = (i < NX && j < NX) ? c->sig_eta[tri_any(i, j)] : R(0);
+    k.eta[e] = (i < NX && j < NX) ? c->sig_eta_w[tri_any(i, j)] : R(0);  // W sig_eta (quadrature.py:57; W = 1 for the unit rule)
     k.sxT[e] = (i < NX && j < NX) ? c->sig_x_term[tri_any(i, j)] : R(0);
   }
   for (int e = tid; e < QLD; e += nthreads) {
@@ -2364,7 +2394,7 @@ template <class M> constexpr bool quad_propagate_exists() {
   return QG<M>::WIDE && M::NX % 4 == 0 && (M::NX + M::NU) % 4 == 0 && M::NU <= 4 && M::NZ == M::NX + M::NU && st_identity<ObsStruct<M>, M::NZ>();
 }
 
-template <class M, typename R, class KC>
+template <class M, typename R, bool GENERAL = false, class KC>
 I2C_HD inline void propagate_quad_body(const Consts<M, R>& c, const KC& kc, const PropArgs<R>& a, const int b, const bool live, const Quad<R>& qw) {
   using C = Consts<M, R>;
   using G = QG<M>;
@@ -2529,9 +2559,24 @@ I2C_HD inline void propagate_quad_body(const Consts<M, R>& c, const KC& kc, cons
     // expected cost of the propagated observation (= the joint: identity observation; compute_cost_gaussian, i2c.py:1034-1043)
     {
       R err[NBD], pm, pv;
+      if constexpr (GENERAL) {  // the identity observation's exact moments under general weights: W mu, sig + (W - W^2) mu mu^T
+        R mzg[NBD], szg[NBD * NBD];
+        const R Wd = rule.W, cwd = Wd - Wd * Wd;
 #pragma unroll
-      for (int j = 0; j < NBD; ++j) err[j] = mu0[j] - zt[j];
-      q_cost_share<NBD, NBD, QLD>(q, c.qr_diag != 0, kc.qr, err, s0, &pm, &pv, kz);
+        for (int i = 0; i < NBD; ++i) {
+          mzg[i] = Wd * mu0[i];
+          const R mrd = q_tr(q, mu0[i]);
+#pragma unroll
+          for (int j = 0; j < NBD; ++j) szg[i * NBD + j] = j >= i ? s0[i * NBD + j] + cwd * (mrd * mu0[j]) : s0[i * NBD + j];
+        }
+#pragma unroll
+        for (int j = 0; j < NBD; ++j) err[j] = mzg[j] - zt[j];
+        q_cost_share<NBD, NBD, QLD>(q, c.qr_diag != 0, kc.qr, err, szg, &pm, &pv, kz);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NBD; ++j) err[j] = mu0[j] - zt[j];
+        q_cost_share<NBD, NBD, QLD>(q, c.qr_diag != 0, kc.qr, err, s0, &pm, &pv, kz);
+      }
       acc_m += pm;
       acc_v += pv;
     }
@@ -2541,8 +2586,8 @@ I2C_HD inline void propagate_quad_body(const Consts<M, R>& c, const KC& kc, cons
 #pragma unroll
       for (int k = 0; k < NBD * NBD; ++k) tmp[k] = s0[k];
       note(q_elim<D, 0, 0>(q, tmp, (R*)nullptr, (R*)nullptr, lt), t);
-      q_points<M, G, D, NX>(q, rule.sf, mu0, lt, DynamicsF<M, R>{c.params}, am, dm, yc);
-      q_moments<D, NX>(q, rule, am, dm, yc, mx, sy);
+      q_points<M, G, D, NX, GENERAL>(q, rule.sf, mu0, lt, DynamicsF<M, R>{c.params}, am, dm, yc);  // (d = 16: no spare pair row, the centre is an extra pass)
+      q_moments<D, NX, GENERAL>(q, rule, am, dm, yc, mx, sy);
 #pragma unroll
       for (int i = 0; i < NBX; ++i)
 #pragma unroll

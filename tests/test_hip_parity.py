@@ -473,3 +473,20 @@ def test_hip_quad_sweeps_general_weights_identity_observation_models(lib, name, 
     kw = dict(meta_override={"inference": "cubature"}) if name.startswith("lin_") else {}
     eng, _ = parity.check_batch_against_oracle(name, lib, "cuda", B, 2, tol=1e-6, quad=quad, group_lanes=64, **kw)
     assert (eng.forward_family, eng.backward_family) == ("quad", "quad")
+
+
+@pytest.mark.parametrize("name", ["em_quad12_T20", "em_quad12_T12_propagate", "em_quad12_covctrl_T12", "em_quad12_nondiag_T12"])
+@pytest.mark.parametrize("quad", [(1.2, 0.44, 0.5), (1.05, 0.0, 0.3)])
+def test_hip_quad12_general_weights_run_on_the_quad_kernels(lib, name, quad):
+    """Round 6 (review item 8, the d = 16 part): any CubatureQuadrature(alpha, beta, kappa) on the 12-state quadrotor is the quad
+    kernels' at EVERY batch size -- forward sweep (general identity update, the centre point as a third evaluation pass), backward
+    walk and closed-loop propagation (the identity observation's exact moments W m, S + (W - W^2) m m^T in the expected cost) --
+    where it used to fall back to the group kernels, whose waves serialise beyond 1024. Against the batched oracle with the same
+    rule, propagated quantities included."""
+    eng, o = parity.check_batch_against_oracle(name, lib, "cuda", 203, 2, tol=1e-6, quad=quad)
+    assert (eng.forward_family, eng.backward_family, eng.kernel_family("propagate")) == ("quad", "quad", "quad")
+    if eng._propagate:
+        p = eng.propagated()
+        for key in ("mu_xu0_pf", "sig_xu0_pf", "mu_x3_pf", "sig_x3_pf"):
+            parity.close(parity.np_(p[key]), getattr(o, key), 1e-6, f"{name} {key}")
+        parity.close(parity.np_(eng.costs_pf[-1]), o.costs_pf[-1], 1e-6, f"{name} propagated cost")

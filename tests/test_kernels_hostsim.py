@@ -101,7 +101,8 @@ def test_hostsim_wave_kernels_are_the_quad12_default(lib):
     grp = parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu", group_lanes=16)
     assert grp.kernel_family("filter") == "group" and grp.kernel_family("propagate") == "group"
     general = parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu", quad=(1.2, 0.44, 0.5))
-    assert general.forward_family == "group"  # weights with lam != 0: not covered by the wave form, the group kernels take over
+    # weights with lam != 0 are not covered by the wave form: the quad kernels take over at every batch size (round 6; it was the group kernels)
+    assert (general.forward_family, general.backward_family, general.kernel_family("propagate")) == ("quad", "quad", "quad")
     with pytest.raises(RuntimeError, match="-2"):
         parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu", quad=(1.2, 0.44, 0.5), group_lanes=64).forward_sweep()
 
@@ -259,9 +260,9 @@ def test_hostsim_square_root_update_at_extreme_temperatures(lib, name, lanes, fa
 def test_quad_forward_refuses_what_it_does_not_cover(lib):
     """General cubature weights (a weight on the centre point, weights that need not sum to one) are in the quad form for every
     model of the d <= 8 geometry (round 5: where every observation goes through the sigma points; round 6: the identity-observation
-    models too); d = 16 and the other inference rules are refused with I2C_ENOTSUP when asked for explicitly."""
-    with pytest.raises(RuntimeError, match="-2"):
-        parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu", quad=(1.2, 0.44, 0.5), group_lanes=parity.pkg._native.LANES_QUAD)
+    models too) and for d = 16 (round 6); the wave kernels and the other inference rules are refused with I2C_ENOTSUP when asked for."""
+    with pytest.raises(RuntimeError, match="-2"):  # the wave kernels (64 on the d = 16 model) only have the unit rule
+        parity.engine_from_case(load_case("em_quad12_T20"), lib, "cpu", quad=(1.2, 0.44, 0.5), group_lanes=64)
     with pytest.raises(RuntimeError, match="-2"):  # Linearize() on the quad kernels
         parity.engine_from_case(load_case("lin_pendulum_T100"), lib, "cpu", group_lanes=64)
     with pytest.raises(ValueError):  # d = 16 has the wave kernels under 64; models without either refuse it
@@ -583,3 +584,20 @@ def test_hostsim_quad_sweeps_general_weights_identity_observation_models(lib, na
     assert (eng.forward_family, eng.backward_family) == ("quad", "quad")
     if name == "em_quadrotor_T20":  # ... and it is the DEFAULT forward sweep of such a problem inside the quad window (it was the group fallback)
         assert parity.engine_from_case(load_case(name), lib, "cpu", quad=quad).forward_family == "quad"
+
+
+@pytest.mark.parametrize("name", ["em_quad12_T20", "em_quad12_T12_propagate", "em_quad12_covctrl_T12", "em_quad12_nondiag_T12"])
+@pytest.mark.parametrize("quad", [(1.2, 0.44, 0.5), (1.05, 0.0, 0.3)])
+def test_hostsim_quad12_general_weights_run_on_the_quad_kernels(lib, name, quad):
+    """Round 6 (review item 8, the d = 16 part): any CubatureQuadrature(alpha, beta, kappa) on the 12-state quadrotor is the quad
+    kernels' at EVERY batch size -- forward sweep (general identity update, the centre point as a third evaluation pass), backward
+    walk and closed-loop propagation (the identity observation's exact moments W m, S + (W - W^2) m m^T in the expected cost) --
+    where it used to fall back to the group kernels, whose waves serialise beyond 1024. Against the batched oracle with the same
+    rule, propagated quantities included."""
+    eng, o = parity.check_batch_against_oracle(name, lib, "cpu", 5, 2, tol=1e-6, quad=quad)
+    assert (eng.forward_family, eng.backward_family, eng.kernel_family("propagate")) == ("quad", "quad", "quad")
+    if eng._propagate:
+        p = eng.propagated()
+        for key in ("mu_xu0_pf", "sig_xu0_pf", "mu_x3_pf", "sig_x3_pf"):
+            parity.close(parity.np_(p[key]), getattr(o, key), 1e-6, f"{name} {key}")
+        parity.close(parity.np_(eng.costs_pf[-1]), o.costs_pf[-1], 1e-6, f"{name} propagated cost")
