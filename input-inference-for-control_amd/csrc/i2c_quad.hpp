@@ -1722,13 +1722,6 @@ I2C_HD inline void backward_quad_body(const Consts<M, R>& c, const KC& kc, const
       for (int k = 0; k < NBX * NBD; ++k) p1[k] = R(0);
       q_tn<NBX, NBX, NBD>(q, dsf, jt, p1);            // dS J^T
       q_tn<NBX, NBD, NBD, false, true>(q, jt, p1, sg);  // J (dS J^T), upper blocks
-      // the diagonal blocks exactly symmetric again (round 6, see backward_quad8_body: both triangles of J dS J^T are computed, each
-      // with its own rounding, and the antisymmetric part of the carried covariance obeys A <- Jx A Jx^T along the chain)
-#pragma unroll
-      for (int i = 0; i < NBD; ++i) {
-        const R st_ = q_tr(q, sg[i * NBD + i]);
-        sg[i * NBD + i] = up ? sg[i * NBD + i] : st_;
-      }
     }
     // posterior observation moments = the joint itself (identity observation, i2c.py:594-596) and their expected cost
     R mzg[NBD], szg[NBD * NBD];  // (GENERAL: the observation moments; otherwise unused)
@@ -1824,11 +1817,22 @@ I2C_HD inline void backward_quad_body(const Consts<M, R>& c, const KC& kc, const
           if (i < j || up) zo[(long)(NZ + sym_lane(i, j) + sym_k(i, j)) * B] = (S)(GENERAL ? szg[i * NBD + j] : sg[i * NBD + j]);
       }
     }
+#ifndef I2C_QB16_SYM
+#define I2C_QB16_SYM 1
+#endif
 #pragma unroll
     for (int j = 0; j < NBX; ++j) {
       m3m[j] = mu[j];
 #pragma unroll
       for (int i = 0; i < NBX; ++i) s3m[i * NBX + j] = i <= j ? sg[i * NBD + j] : R(0);
+      // the CARRIED diagonal blocks exactly symmetric again (round 6, see backward_quad8_body: both triangles of J dS J^T are computed,
+      // each with its own rounding, and the antisymmetric part of the carried covariance obeys A <- Jx A Jx^T along the chain). Here,
+      // at the end of the cell, and not where the blocks are formed: there the four transposes pushed the kernel over its register
+      // budget (2 -> 38 spilled registers, 1.67 -> 1.97 ms at B = 32768)
+      if constexpr (I2C_QB16_SYM != 0) {
+        const R st_ = q_tr(q, s3m[j * NBX + j]);
+        s3m[j * NBX + j] = up ? s3m[j * NBX + j] : st_;
+      }
     }
   }
   const R sm = q_sum16(qw, acc_m), sv = q_sum16(qw, acc_v);
