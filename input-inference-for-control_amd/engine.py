@@ -111,6 +111,8 @@ class BatchedI2c:
         if self.deterministic_family:
             if not group_lanes:
                 group_lanes = 64 if dims.wave else -1
+                if dims.wave and inference == "cubature" and tuple(float(v) for v in quad) != (1.0, 0.0, 0.0):
+                    group_lanes = _native.LANES_QUAD  # (the wave kernels only have the unit rule: general weights are the quad kernels', round 6)
             if backward_mode == "auto":
                 backward_mode = "fused"
         self.group_lanes = int(group_lanes or 0)

@@ -423,6 +423,11 @@ def test_deterministic_family_makes_results_independent_of_the_batch():
             assert torch.equal(part.post, whole.post[..., sl]) and torch.equal(part.alpha, whole.alpha[sl]), (name, sl)
         # an explicit request still wins over the switch
         assert solve(slice(0, 2), backward_mode="two_pass").backward_schedule == "two_pass"
+        if name == "Quadrotor12":  # general cubature weights on d = 16: the switch pins the quad kernels (the wave kernels refuse them)
+            gen = solve(slice(0, B), quad=(1.2, 0.44, 0.5))
+            assert (gen.forward_family, gen.backward_family) == ("quad", "quad")
+            part = solve(slice(3, 8), quad=(1.2, 0.44, 0.5))
+            assert torch.equal(part.post, gen.post[..., 3:8]) and torch.equal(part.alpha, gen.alpha[3:8])
 
 
 @pytest.mark.parametrize("overlap", [True, False])
