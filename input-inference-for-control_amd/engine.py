@@ -543,7 +543,9 @@ class BatchedI2c:
             self.costs_pf_var.append(ps[1])
             self.alphas_pf.append(ps[0] / float(self.nz * self.H))  # = _alpha_from_propagation()
         else:
-            self.costs_pf.append(torch.full_like(out[2], -1.0))  # i2c.py:1065
+            if getattr(self, "_minus_one", None) is None:
+                self._minus_one = torch.full_like(out[2], -1.0)  # (one constant row shared by every entry: no fill kernel per iteration)
+            self.costs_pf.append(self._minus_one)  # i2c.py:1065
         self.update_priors()
         self.alphas_desired.append(out[0])
         self.alphas.append(out[1])
