@@ -686,11 +686,16 @@ def main():
         allgather_ms = (time.perf_counter() - t1) * 1e3
         assert gathered["K"].shape[0] == B * world
 
-    mine = {"rank": rank, "batch": B, "forward_family": eng.forward_family, "backward_family": eng.backward_family, "backward": eng.backward_schedule}
-    families = [mine]
+    # (as a tensor of small integers through the same collective primitive as the job's all-gather: no pickling, no object collectives)
+    FAM, SCH = ["lane", "group", "wave", "quad"], ["two_pass", "fused", "chunked"]
+    mine = torch.tensor([rank, B, FAM.index(eng.forward_family), FAM.index(eng.backward_family), SCH.index(eng.backward_schedule)],
+                        dtype=torch.int64, device=device)
+    rows = mine.reshape(1, -1)
     if dist is not None and world > 1:
-        families = [None] * world
-        dist.all_gather_object(families, mine)
+        rows = torch.empty(world, mine.numel(), dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(rows, mine.reshape(1, -1).contiguous())
+    families = [{"rank": int(r[0]), "batch": int(r[1]), "forward_family": FAM[int(r[2])], "backward_family": FAM[int(r[3])], "backward": SCH[int(r[4])]}
+                for r in rows.cpu().tolist()]
     strong = None
     if not args.no_extra:  # every rank takes part (collective timing)
         strong = strong_scaling_legs(pkg, T, dtype, device, rank, world, dist, barrier, max(K // 5, 2), lib=lib,
