@@ -3,7 +3,8 @@ cost weights, temperature, feedback horizon, propagation, expert controller), ev
 against the CPU oracle.   python tools/fuzz_gpu.py [first_seed] [n_seeds] [weights]   (`weights`: a random cubature rule on top, round 6)   (2026-10-03: seeds 1000..1399, 0 failures; round 5, after the quad-kernel, Gauss-Hermite and
 resolver work: seeds 2000..2299, 0 failures; after the square-root update of the identity-observation models and the four-wave
 workgroups of the quad forward kernel: seeds 60..699 and 3000..4499, 0 failures; round 6, with the d <= 8 quad backward walk behind every
-`group_lanes = 64` request: seeds 6000..7499, 0 failures)"""
+`group_lanes = 64` request: seeds 6000..7499, 0 failures; final kernels of round 6: seeds 20000..21499 and, with random cubature
+weights, 30000..31499, 0 failures)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "input-inference-for-control_amd"), os.path.join(ROOT, "tests")):
