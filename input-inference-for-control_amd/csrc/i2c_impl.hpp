@@ -526,6 +526,76 @@ static int launch_quad_backward(const Consts<M, R>& c, const A& a, void* stream)
   }
 }
 
+// the quad WALKER of the chunked schedule (d <= 8; backward_quad8_body<CHUNK>): grid = groups of four trajectories x chunks
+template <class M, typename R, typename S> static QChunk<R> quad_chunk_of(const Consts<M, R>& c, const ChunkArgs<R, S>& a, const int ch) {
+  const int t_lo = ch * a.chunk_len, t_hi = (t_lo + a.chunk_len < c.T) ? t_lo + a.chunk_len : c.T;
+  return QChunk<R>{a.bnd, a.part, ch, t_lo, t_hi};
+}
+#ifdef I2C_HOST_SIM
+template <class M, typename R, typename S, bool GENERAL, bool LEANQ>
+static int launch_quad_chunk_walk_g(const Consts<M, R>& c, const ChunkArgs<R, S>& a, void*) {
+  if constexpr (!QG<M>::WIDE) {
+    QBConst<M, R> kc;
+    qbconst_fill<M, R>(kc, &c, 0, 1);
+    constexpr int LSZ = quad_backward_lds<M>();
+    for (int b0 = 0; b0 < c.B; b0 += 4) {  // (the simulated wavefront of a group walks its chunks one after the other: 64 threads per group)
+      std::vector<R> sh((size_t)4 * LSZ, R(0)), xch(128, R(0));
+      HostBarrier bar(64);
+      std::vector<std::thread> lanes;
+      for (int l = 0; l < 64; ++l)
+        lanes.emplace_back([&, l, b0] {
+          const int g = (l >> 2) & 3, b = b0 + g;
+          const bool live = b < c.B;
+          for (int ch = 0; ch < a.n_chunks; ++ch)
+            backward_quad8_body<M, R, S, GENERAL, LEANQ, true>(c, kc, a.cell, live ? b : c.B - 1, live,
+                                                               Quad<R>{l, l >> 4, g, l & 3, sh.data() + g * LSZ, &bar, xch.data()},
+                                                               quad_chunk_of<M, R, S>(c, a, ch));
+        });
+      for (auto& th : lanes) th.join();
+    }
+    return I2C_OK;
+  }
+  return I2C_ENOTSUP;
+}
+#else
+template <class M, typename R, typename S, bool GENERAL = false, bool LEANQ = false>
+__global__ __launch_bounds__(64 * QB_WAVES_PER_BLOCK, 2) void k_quad_chunk_walk(const Consts<M, R> c, const ChunkArgs<R, S> a) {
+  constexpr int WPB = QB_WAVES_PER_BLOCK, LSZ = quad_backward_lds<M>();
+  __shared__ QBConst<M, R> kc;
+  __shared__ R sh[WPB * 4 * LSZ];
+  qbconst_fill<M, R>(kc, (const Consts<M, R>*)__builtin_amdgcn_kernarg_segment_ptr(), (int)threadIdx.x, 64 * WPB);
+  __syncthreads();
+  const int l = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6), g = (l >> 2) & 3;
+  const long b0 = 4L * ((long)blockIdx.x * WPB + wv);
+  if (b0 >= c.B) return;  // (wave-uniform: no trajectory in this wave)
+  const long b = b0 + g;
+  const bool live = b < c.B;
+  const Quad<R> q{l, l >> 4, g, l & 3, (lds_ptr<R>)(sh + (wv * 4 + g) * LSZ)};
+  const int ch = (int)blockIdx.y, t_lo = ch * a.chunk_len, t_hi = (t_lo + a.chunk_len < c.T) ? t_lo + a.chunk_len : c.T;
+  backward_quad8_body<M, R, S, GENERAL, LEANQ, true>(c, kc, a.cell, (int)(live ? b : c.B - 1), live, q, QChunk<R>{a.bnd, a.part, ch, t_lo, t_hi});
+}
+template <class M, typename R, typename S, bool GENERAL, bool LEANQ>
+static int launch_quad_chunk_walk_g(const Consts<M, R>& c, const ChunkArgs<R, S>& a, void* stream) {
+  if constexpr (!QG<M>::WIDE) {
+    constexpr int WPB = QB_WAVES_PER_BLOCK;
+    hipLaunchKernelGGL((k_quad_chunk_walk<M, R, S, GENERAL, LEANQ>), dim3((unsigned)(((long)c.B + 4 * WPB - 1) / (4 * WPB)), (unsigned)a.n_chunks), dim3(64 * WPB), 0,
+                       (hipStream_t)stream, c, a);
+    return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
+  }
+  return I2C_ENOTSUP;
+}
+#endif
+template <class M, typename R, typename S>
+static int launch_quad_chunk_walk(const Consts<M, R>& c, const ChunkArgs<R, S>& a, void* stream) {
+  const bool unit = c.rule_xu.unit && c.rule_x.unit && c.rule_xu.w0 == R(0) && c.rule_x.w0 == R(0);
+  const bool lean = !a.cell.xm && !a.cell.zpost && !a.cell.cell_stats;
+  if constexpr (quad_general_exists<M>()) {
+    if (!unit) return lean ? launch_quad_chunk_walk_g<M, R, S, true, true>(c, a, stream) : launch_quad_chunk_walk_g<M, R, S, true, false>(c, a, stream);
+  }
+  if (!unit) return I2C_ENOTSUP;
+  return lean ? launch_quad_chunk_walk_g<M, R, S, false, true>(c, a, stream) : launch_quad_chunk_walk_g<M, R, S, false, false>(c, a, stream);
+}
+
 // the quad propagation (propagate_quad_body): d = 16 models with identity observations
 #ifdef I2C_HOST_SIM
 template <class M, typename R, bool GENERAL>
@@ -763,6 +833,15 @@ template <class M> struct quad_backward_window<M, std::void_t<decltype(M::QUAD_B
   static constexpr int min_b = M::QUAD_BACKWARD8_MIN_B, max_b = M::QUAD_BACKWARD8_MAX_B;
 };
 
+// batch window in which the chunked schedule's WALK pass runs on the quad walker by default (backward_quad8_body<CHUNK>; measured per
+// model, i2c_models.hpp: QUAD_CHUNK_WALK_MIN_B / _MAX_B); models without the pair: on request only (group_lanes = 64 + "chunked")
+template <class M, class = void> struct quad_chunk_walk_window {
+  static constexpr int min_b = 0, max_b = -1;
+};
+template <class M> struct quad_chunk_walk_window<M, std::void_t<decltype(M::QUAD_CHUNK_WALK_MAX_B)>> {
+  static constexpr int min_b = M::QUAD_CHUNK_WALK_MIN_B, max_b = M::QUAD_CHUNK_WALK_MAX_B;
+};
+
 // ---- per-(model, dtype) entry points ------------------------------------------------------
 // Which kernels serve a call:
 //   M::GROUP      lanes per trajectory of the model's group kernels (0: none compiled); fp64 only
@@ -846,6 +925,14 @@ template <class M, typename R, typename S = R> struct Impl {
     if (EMAX * (long)p->B * (long)sizeof(S) >= (1L << 31)) return I2C_EINVAL;
     return window_32bit_ok(p);
   }
+  // d <= 8: is the quad walker the DEFAULT walk pass of this problem? (no request, the chunked schedule is the batch's default and
+  // long enough to chunk, the batch inside the model's measured window)
+  static bool quad_chunk_default(const I2cProblem* p) {
+    if constexpr (HAS_QUAD_BACKWARD && !QG<M>::WIDE && LANE)
+      return (p->group_lanes == 0 || p->group_lanes == I2C_LANES_QUAD) && p->backward_mode == I2C_BWD_AUTO && p->inference == I2C_INF_CUBATURE &&
+             p->B >= quad_chunk_walk_window<M>::min_b && p->B <= quad_chunk_walk_window<M>::max_b && schedule(p->B, p->T, I2C_BWD_AUTO) == I2C_BWD_CHUNKED;
+    return false;
+  }
   static constexpr bool HAS_QUAD_CKF = HAS_QUAD && !MIXED && quad_ckf_exists<M>();  // the filter step of the d = 16 form
   static constexpr bool HAS_QUAD_PROP = HAS_QUAD && !MIXED && quad_propagate_exists<M>();  // the closed-loop propagation of the d = 16 form
   static int family(const I2cProblem* p, const C& c, const int sweep) {
@@ -865,7 +952,7 @@ template <class M, typename R, typename S = R> struct Impl {
       if (sweep == I2C_SWEEP_FILTER && (p->group_lanes == 0 || p->group_lanes == 64 || p->group_lanes == I2C_LANES_QUAD)) return I2C_FAMILY_QUAD;
     }
     if constexpr (HAS_QUAD) {  // forward sweep: on request, or the model's default inside its batch window
-      const bool asked = p->group_lanes == I2C_LANES_QUAD || (p->group_lanes == 64 && !M::WAVE);
+      bool asked = p->group_lanes == I2C_LANES_QUAD || (p->group_lanes == 64 && !M::WAVE);
       bool sweep_ok = sweep == I2C_SWEEP_FORWARD;
       int min_b = M::QUAD_FORWARD_MIN_B, max_b = M::QUAD_FORWARD_MAX_B;
       if (sweep == I2C_SWEEP_BACKWARD && HAS_QUAD_BACKWARD) {
@@ -874,11 +961,16 @@ template <class M, typename R, typename S = R> struct Impl {
           sweep_ok = p->backward_mode != I2C_BWD_TWO_PASS;
           min_b = M::QUAD_BACKWARD_MIN_B > M::QUAD_FORWARD_MIN_B ? M::QUAD_BACKWARD_MIN_B : M::QUAD_FORWARD_MIN_B;
         } else {
-          // d <= 8 (round 6): the fused walk of four trajectories per wavefront, ONE pass over the forward messages. On request
-          // (with the schedule left open or asked to be the fused walk: chunked / two-pass are lane schedules), or as the model's
-          // default inside its own measured window (quad_backward_window; I2C_BWD_AUTO only)
-          sweep_ok = asked ? (p->backward_mode == I2C_BWD_AUTO || p->backward_mode == I2C_BWD_FUSED) : p->backward_mode == I2C_BWD_AUTO;
+          // d <= 8 (round 6), two forms of backward_quad8_body. (i) The fused walk of four trajectories per wavefront, ONE pass over the
+          // forward messages: on request (group_lanes = 64 with the schedule left open or "fused"), or inside quad_backward_window
+          // (no in-tree model has one). (ii) The WALKER of the chunked schedule (compose / stitch / reduce stay lane kernels): on
+          // request (group_lanes = 64 with "chunked"), or the default inside the model's quad_chunk_walk_window where the chunked
+          // schedule is the batch's default (quad_chunk_default). An explicit "two_pass" is the lane kernels'.
+          // I2C_LANES_QUAD asks for the quad FORWARD sweep only: its backward sweep resolves as the default does (below).
+          asked = p->group_lanes == 64;
+          sweep_ok = asked ? p->backward_mode != I2C_BWD_TWO_PASS : p->backward_mode == I2C_BWD_AUTO;
           min_b = quad_backward_window<M>::min_b, max_b = quad_backward_window<M>::max_b;
+          if (!asked && quad_chunk_default(p)) min_b = quad_chunk_walk_window<M>::min_b, max_b = quad_chunk_walk_window<M>::max_b;
         }
       }
       // (d = 16 with general cubature weights: the wave kernels only have the unit rule -- the quad kernels at every batch size)
@@ -1033,6 +1125,11 @@ template <class M, typename R, typename S = R> struct Impl {
     const int lane_rule = schedule(p->B, p->T, p->backward_mode);
     if (fam == I2C_FAMILY_WAVE)  // the fused walk; the two-pass form on request (cubature rule)
       return (lane_rule == I2C_BWD_TWO_PASS && p->inference == I2C_INF_CUBATURE) ? I2C_BWD_TWO_PASS : I2C_BWD_FUSED;
+    if constexpr (HAS_QUAD_BACKWARD && !QG<M>::WIDE && LANE) {
+      // d <= 8 quad: the fused walk, or the chunked schedule with the quad walker (compose / stitch / reduce are the lane kernels) --
+      // when asked for by name, or as the model's default inside its quad_chunk_walk_window
+      if (fam == I2C_FAMILY_QUAD && p->T >= 8 && (p->backward_mode == I2C_BWD_CHUNKED || quad_chunk_default(p))) return I2C_BWD_CHUNKED;
+    }
     if (fam == I2C_FAMILY_QUAD || fam == I2C_FAMILY_GROUP) return I2C_BWD_FUSED;  // four trajectories / a group of lanes walk T-1..0
     if (!LANE) return I2C_ENOTSUP;
     if (p->inference == I2C_INF_LINEARIZE) {
@@ -1044,7 +1141,10 @@ template <class M, typename R, typename S = R> struct Impl {
   }
   static int pick_mode(const I2cProblem* p) {
     int mode = plan(p);
-    if (mode == I2C_BWD_CHUNKED && !p->work) mode = (p->inference == I2C_INF_CUBATURE) ? I2C_BWD_TWO_PASS : I2C_BWD_FUSED;  // no workspace
+    if (mode == I2C_BWD_CHUNKED && !p->work) {  // no workspace
+      const C c = make_consts<M, R>(p, 0.0, 0);
+      mode = (p->inference == I2C_INF_CUBATURE && family(p, c, I2C_SWEEP_BACKWARD) != I2C_FAMILY_QUAD) ? I2C_BWD_TWO_PASS : I2C_BWD_FUSED;
+    }
     return mode;
   }
 
@@ -1077,7 +1177,12 @@ template <class M, typename R, typename S = R> struct Impl {
                         (R*)cell_stats, (R*)term_stats, (R*)p->temp,    status,   terminal_alpha(p, c)};
       if (fam == I2C_FAMILY_WAVE) return backward_wave(p, c, am, ms, fuse, stream);
       if (fam == I2C_FAMILY_QUAD) {
-        if constexpr (HAS_QUAD_BACKWARD) return launch_quad_backward<M, R, S>(c, am, stream);
+        if constexpr (HAS_QUAD_BACKWARD) {
+          if constexpr (!QG<M>::WIDE && LANE) {
+            if (pick_mode(p) == I2C_BWD_CHUNKED) return backward_chunked(p, c, am, ms, fuse, stream, true);
+          }
+          return launch_quad_backward<M, R, S>(c, am, stream);
+        }
       }
       return backward_lane(p, c, am, ms, fuse, stream);
     } else {
@@ -1109,7 +1214,12 @@ template <class M, typename R, typename S = R> struct Impl {
       if constexpr (!MIXED) return backward_wave(p, c, a, ms, fuse, stream);
     }
     if (fam == I2C_FAMILY_QUAD) {
-      if constexpr (HAS_QUAD_BACKWARD) return launch_quad_backward<M, R, R>(c, a, stream);
+      if constexpr (HAS_QUAD_BACKWARD) {
+        if constexpr (!QG<M>::WIDE && LANE && !MIXED) {
+          if (pick_mode(p) == I2C_BWD_CHUNKED) return backward_chunked(p, c, a, ms, fuse, stream, true);
+        }
+        return launch_quad_backward<M, R, R>(c, a, stream);
+      }
     }
     if (fam == I2C_FAMILY_GROUP) {  // one schedule: the group walks T-1..0 (the fused form); backward_mode is ignored
       if constexpr (HAS_GROUP) return launch_group<GK_BACKWARD, M, R, G>(c, nullptr, a, stream);
@@ -1162,6 +1272,39 @@ template <class M, typename R, typename S = R> struct Impl {
     }
     return I2C_ENOTSUP;
   }
+  // the chunked schedule of the sigma-point backward sweep: compose (one lane per trajectory and chunk) + stitch + walk + reduce; the
+  // walk pass on the lane walker, or -- quad_walk, d <= 8 -- on the quad walker (four trajectories per wavefront and chunk)
+  static int backward_chunked(const I2cProblem* p, const C& c, const CellArgs<R, S>& a, const MstepArgs<R>& ms, MstepFuse* fuse, void* stream,
+                              const bool quad_walk) {
+    if constexpr (LANE) {
+      ChunkArgs<R, S> ch{a, nullptr, nullptr, nullptr, 0, 0};
+      chunk_geometry(p->B, p->T, &ch.n_chunks, &ch.chunk_len);
+      constexpr int NX = M::NX;
+      ch.comp = (R*)p->work;
+      ch.bnd = ch.comp + (size_t)ch.n_chunks * (NX + NX * NX + sym(NX)) * p->B;
+      ch.part = ch.bnd + (size_t)ch.n_chunks * (NX + sym(NX)) * p->B;
+      C cr = c;  // reduction over chunks instead of cells: same kernel, T := number of chunks
+      cr.T = ch.n_chunks;
+      CellArgs<R, S> ared = a;
+      ared.cell_stats = ch.part;
+      int rc = launch(k_chunk_compose<M, R, S>, p->B, ch.n_chunks, LANE_BLOCK, stream, c, ch);
+      if (rc == I2C_OK) rc = launch(k_chunk_stitch<M, R, S>, p->B, 1, LANE_BLOCK, stream, c, ch);
+      if (rc == I2C_OK) {
+        if (quad_walk) {
+          if constexpr (HAS_QUAD_BACKWARD && !QG<M>::WIDE) rc = launch_quad_chunk_walk<M, R, S>(c, ch, stream);
+          else rc = I2C_ENOTSUP;
+        } else {
+          const bool lean = I2C_WALK_LEAN && !a.xm && !a.zpost && !a.cell_stats && !c.z_per_cell;  // see chunk_walk_body
+          rc = lean ? launch(k_chunk_walk<M, R, S, true>, p->B, ch.n_chunks, LANE_BLOCK, stream, c, ch)
+                    : launch(k_chunk_walk<M, R, S>, p->B, ch.n_chunks, LANE_BLOCK, stream, c, ch);
+        }
+      }
+      if (rc == I2C_OK) rc = launch_reduce<M, R>(cr, ared, ms, p->T, stream);
+      if (fuse) fuse->done = true;
+      return rc;
+    }
+    return I2C_ENOTSUP;
+  }
   // the three schedules of the sigma-point backward sweep of the one-lane kernels, for either storage type
   static int backward_lane(const I2cProblem* p, const C& c, const CellArgs<R, S>& a, const MstepArgs<R>& ms, MstepFuse* fuse,
                            void* stream) {
@@ -1172,28 +1315,7 @@ template <class M, typename R, typename S = R> struct Impl {
         return lean ? launch(k_bwd_fused<M, R, false, S, true>, p->B, 1, LANE_BLOCK, stream, c, a)
                     : launch(k_bwd_fused<M, R, false, S>, p->B, 1, LANE_BLOCK, stream, c, a);
       }
-      if (mode == I2C_BWD_CHUNKED) {
-        ChunkArgs<R, S> ch{a, nullptr, nullptr, nullptr, 0, 0};
-        chunk_geometry(p->B, p->T, &ch.n_chunks, &ch.chunk_len);
-        constexpr int NX = M::NX;
-        ch.comp = (R*)p->work;
-        ch.bnd = ch.comp + (size_t)ch.n_chunks * (NX + NX * NX + sym(NX)) * p->B;
-        ch.part = ch.bnd + (size_t)ch.n_chunks * (NX + sym(NX)) * p->B;
-        C cr = c;  // reduction over chunks instead of cells: same kernel, T := number of chunks
-        cr.T = ch.n_chunks;
-        CellArgs<R, S> ared = a;
-        ared.cell_stats = ch.part;
-        int rc = launch(k_chunk_compose<M, R, S>, p->B, ch.n_chunks, LANE_BLOCK, stream, c, ch);
-        if (rc == I2C_OK) rc = launch(k_chunk_stitch<M, R, S>, p->B, 1, LANE_BLOCK, stream, c, ch);
-        if (rc == I2C_OK) {
-          const bool lean = I2C_WALK_LEAN && !a.xm && !a.zpost && !a.cell_stats && !c.z_per_cell;  // see chunk_walk_body
-          rc = lean ? launch(k_chunk_walk<M, R, S, true>, p->B, ch.n_chunks, LANE_BLOCK, stream, c, ch)
-                    : launch(k_chunk_walk<M, R, S>, p->B, ch.n_chunks, LANE_BLOCK, stream, c, ch);
-        }
-        if (rc == I2C_OK) rc = launch_reduce<M, R>(cr, ared, ms, p->T, stream);
-        if (fuse) fuse->done = true;
-        return rc;
-      }
+      if (mode == I2C_BWD_CHUNKED) return backward_chunked(p, c, a, ms, fuse, stream, false);
       if (!a.xm || !a.cell_stats) return I2C_EINVAL;  // two-pass needs both as workspace
       ScanArgs<R, S> sc{a.fwd, const_cast<S*>(a.xm), (R*)p->temp, a.status};
       int rc = launch(k_scan<M, R, S>, p->B, 1, LANE_BLOCK, stream, c, sc);

@@ -1886,8 +1886,19 @@ template <typename R, typename S> struct QIO8 {
 };
 // LEANQ: no optional outputs (smoothed state per cell, observation moments, per-cell cost statistics): what i2c_learn / i2c_mpc_step
 // run. Compiled out, not branched over: a store behind a run-time branch costs the lone wave an s_waitcnt vmcnt(0) per cell.
-template <class M, typename R, typename S, bool GENERAL = false, bool LEANQ = false, class KC>
-I2C_HD inline void backward_quad8_body(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>& a_in, const int b, const bool live, const Quad<R>& q) {
+// CHUNK: the walker of the CHUNKED schedule (compose + stitch + walk + reduce, i2c_cell.hpp): cells t_hi - 1 .. t_lo of ONE chunk,
+// entered with the smoothed state the stitch pass left in bnd[ch] (the end of the chain and the terminal statistics are the stitch
+// pass's), cost sums into part[ch] for the reduction. Small batches are bound by the DEPTH of the chain: the lane walker needs
+// ~ 24 k clocks for a d = 8 cell of 64 trajectories, this one 4.2 k for a cell of four -- with chunks supplying the parallelism
+// over t, the walk of a batch that leaves most SIMDs idle is as long as its chunk, not as its lane cell.
+template <typename R> struct QChunk {
+  const R* bnd;  // [NC][NX + sym(NX)][B]  smoothed state entering each chunk (chunk_stitch_body)
+  R* part;       // [NC][2][B]             per-chunk cost sums
+  int ch, t_lo, t_hi;
+};
+template <class M, typename R, typename S, bool GENERAL = false, bool LEANQ = false, bool CHUNK = false, class KC>
+I2C_HD inline void backward_quad8_body(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>& a_in, const int b, const bool live, const Quad<R>& q,
+                                       const QChunk<R> qc = QChunk<R>{nullptr, nullptr, 0, 0, 0}) {
   CellArgs<R, S> a = a_in;
   if (LEANQ) a.xm = nullptr, a.zpost = nullptr, a.cell_stats = nullptr;
   using C = Consts<M, R>;
@@ -1979,7 +1990,8 @@ I2C_HD inline void backward_quad8_body(const Consts<M, R>& c, const KC& kc, cons
 #pragma unroll
     for (int j = 0; j < NBZ; ++j) nx_zt[j] = wld<R>(zw, (unsigned)c.row(tc) * zcell, zlane[j]);
   };
-  fetch(T - 1);
+  const int t_hi = CHUNK ? qc.t_hi : T, t_lo = CHUNK ? qc.t_lo : 0;
+  fetch(t_hi - 1);
   // settled before the loop (see forward_wave_body: loads pending on the loop-entry path cost a vmcnt(0) in every cell)
 #pragma unroll
   for (int k = 0; k < NBD; ++k) nx_mu[k] = opaque(nx_mu[k]);
@@ -2002,8 +2014,23 @@ I2C_HD inline void backward_quad8_body(const Consts<M, R>& c, const KC& kc, cons
   auto note = [&](const bool ok, const int reason, const int t) { fail = (fail == 0 && !ok) ? ((reason << 16) | (t + 1)) : fail; };
   // state marginal carried along the chain: mean in column form, covariance in UPPER blocks (the diagonal ones full), zero-padded
   R m3m[NBX], s3m[NBX * NBX];
+  if constexpr (CHUNK) {
+    // ---- the smoothed state that enters the chunk's last cell: what the stitch pass composed (R-typed, packed lower) -------------
+    const R* bi = qc.bnd + ((long)qc.ch * C::E_XM) * (long)B + b;
+#pragma unroll
+    for (int j = 0; j < NBX; ++j) {
+      const bool cj = in_col(j, NX);
+      const R v = bi[(long)(cj ? 4 * j + cc : 0) * (long)B];
+      m3m[j] = cj ? v : R(0);
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) {
+        const bool on = i <= j && in_n(i, j, NX);
+        const R w = bi[(long)(NX + (on ? sym_lane(i, j) + sym_k(i, j) : 0)) * (long)B];
+        s3m[i * NBX + j] = on ? w : R(0);
+      }
+    }
+  } else {
   // ---- end of the chain (i2c.py:546-572): the smoothed terminal state and its statistics, from the rows of cell T - 1 ----------
-  {
     const int kz = (int)opaque_uniform(0u);
 #pragma unroll
     for (int j = 0; j < NBX; ++j) {
@@ -2092,7 +2119,7 @@ I2C_HD inline void backward_quad8_body(const Consts<M, R>& c, const KC& kc, cons
   }
 
   R acc_m = R(0), acc_v = R(0);
-  for (int t = T - 1; t >= 0; --t) {
+  for (int t = t_hi - 1; t >= t_lo; --t) {
     const int kz = (int)opaque_uniform(0u);  // (see q_ldc)
     const Window out = make_window(a.post + (unsigned long)c.row(t) * C::E_POST * B, (unsigned long)C::E_POST * rb);
     // this cell's rows (zero-padded), then the fetch of the next one
@@ -2113,7 +2140,7 @@ I2C_HD inline void backward_quad8_body(const Consts<M, R>& c, const KC& kc, cons
     }
 #pragma unroll
     for (int j = 0; j < NBZ; ++j) zt[j] = xcol(j) < NZ ? (c.z_per_cell ? nx_zt[j] : q_ldv(q, kc.zg, j, kz)) : R(0);
-    fetch(t >= 1 ? t - 1 : 0);
+    fetch(t > t_lo ? t - 1 : t_lo);
     if (a.xm && live) {  // (optional output: the smoothed state marginal that enters cell t)
       S* xo = const_cast<S*>(a.xm) + ((long)t * C::E_XM) * B + b;
 #pragma unroll
@@ -2265,8 +2292,13 @@ I2C_HD inline void backward_quad8_body(const Consts<M, R>& c, const KC& kc, cons
   }
   const R sm = q_sum16(q, acc_m), sv = q_sum16(q, acc_v);
   if (lead) {
-    a.term_stats[B + b] = sm;
-    a.term_stats[2 * B + b] = sv;
+    if constexpr (CHUNK) {
+      qc.part[((long)qc.ch * 2 + 0) * (long)B + b] = sm;
+      qc.part[((long)qc.ch * 2 + 1) * (long)B + b] = sv;
+    } else {
+      a.term_stats[B + b] = sm;
+      a.term_stats[2 * B + b] = sv;
+    }
     if (fail != 0 && a.status[b] == 0) a.status[b] = fail;
   }
 }

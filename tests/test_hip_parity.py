@@ -114,9 +114,29 @@ QUAD_GOLDEN = [("em_pendulum_T200", 1e-8, 1e-7), ("em_pendulum_T200_run200", 1e-
 
 @pytest.mark.parametrize("name,tol_d,tol_s", QUAD_GOLDEN)
 def test_hip_quad_forward_vs_reference_golden(lib, name, tol_d, tol_s):
-    """(a lane schedule asked for by name keeps the lane backward sweep behind the quad forward sweep)"""
-    eng = parity.check_against_golden(name, lib, "cuda", tol_d, tol_s, group_lanes=64, backward_mode="chunked")
+    """(LANES_QUAD asks for the quad FORWARD sweep only; a lane schedule asked for by name keeps the lane backward sweep behind it)"""
+    eng = parity.check_against_golden(name, lib, "cuda", tol_d, tol_s, group_lanes=parity.pkg._native.LANES_QUAD, backward_mode="chunked")
     assert eng.forward_family == "quad" and eng.backward_family == "lane" and eng.backward_schedule == "chunked"
+
+
+# The quad WALKER of the chunked schedule (backward_quad8_body<CHUNK>; group_lanes = 64 with "chunked", and the DEFAULT of the d >= 5
+# models up to a few hundred trajectories): every QUAD_GOLDEN case through the C ABI on the device.
+@pytest.mark.parametrize("name,tol_d,tol_s", QUAD_GOLDEN)
+def test_hip_quad_chunk_walk_vs_reference_golden(lib, name, tol_d, tol_s):
+    eng = parity.check_against_golden(name, lib, "cuda", tol_d, tol_s, group_lanes=64, backward_mode="chunked")
+    assert (eng.forward_family, eng.backward_family, eng.backward_schedule) == ("quad", "quad", "chunked") and eng.work is not None
+
+
+@pytest.mark.parametrize("name,B,want", [("em_dcp_T60", 131, "quad"), ("em_dcp_T60", 259, "lane"), ("em_cartpole_T100", 61, "quad"), ("em_quadrotor_T20", 255, "quad"),
+                                         ("em_quadrotor_T20", 1027, "lane"), ("em_dcp_nondiag_T30", 3, "quad")])
+def test_hip_quad_chunk_walk_is_the_small_batch_default(lib, name, B, want):
+    """Nothing asked for: inside the model's measured window the chunked schedule walks on the quad walker, beyond it on the lane
+    walker -- ragged batches against the batched oracle either way. Asked for on a batch beyond the window: same answers."""
+    eng, _ = parity.check_batch_against_oracle(name, lib, "cuda", B, 3, tol=1e-6)
+    assert (eng.forward_family, eng.backward_family, eng.backward_schedule) == ("quad", want, "chunked")
+    if want == "lane":
+        eng, _ = parity.check_batch_against_oracle(name, lib, "cuda", B, 3, tol=1e-6, group_lanes=64, backward_mode="chunked")
+        assert (eng.backward_family, eng.backward_schedule) == ("quad", "chunked")
 
 
 # The QUAD backward sweep of the d <= 8 models (round 6, backward_quad8_body: the fused walk of four trajectories per wavefront --

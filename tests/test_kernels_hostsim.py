@@ -128,10 +128,20 @@ QUAD_GOLDEN = [
 
 @pytest.mark.parametrize("name,tol_d,tol_s,n_iters", QUAD_GOLDEN)
 def test_hostsim_quad_forward_vs_reference_golden(lib, name, tol_d, tol_s, n_iters):
-    """(a lane schedule asked for by name keeps the lane backward sweep behind the quad forward sweep: the default pair of the
-    d >= 5 models at the BASELINE batch sizes)"""
-    eng = parity.check_against_golden(name, lib, "cpu", tol_d, tol_s, n_iters=n_iters, group_lanes=64, backward_mode="chunked")
+    """(LANES_QUAD asks for the quad FORWARD sweep only; with a lane schedule asked for by name the lane backward sweep runs behind
+    it: the default pair of the d >= 5 models at the BASELINE batch sizes)"""
+    eng = parity.check_against_golden(name, lib, "cpu", tol_d, tol_s, n_iters=n_iters, group_lanes=parity.pkg._native.LANES_QUAD, backward_mode="chunked")
     assert eng.forward_family == "quad" and eng.backward_family == "lane" and eng.backward_schedule == "chunked"
+
+
+# The quad WALKER of the chunked schedule (backward_quad8_body<CHUNK>): compose + stitch on the lane kernels, then four trajectories
+# per wavefront and chunk walk their cells from the stitched boundary state; cost sums per chunk into the common reduction.
+# group_lanes = 64 with "chunked" asks for it; the default of the d >= 5 models up to a few hundred trajectories.
+@pytest.mark.parametrize("name,tol_d,tol_s,n_iters", QUAD_GOLDEN)
+def test_hostsim_quad_chunk_walk_vs_reference_golden(lib, name, tol_d, tol_s, n_iters):
+    eng = parity.check_against_golden(name, lib, "cpu", tol_d, tol_s, n_iters=n_iters, group_lanes=64, backward_mode="chunked")
+    assert (eng.forward_family, eng.backward_family, eng.backward_schedule) == ("quad", "quad", "chunked")
+    assert eng.work is not None
 
 
 # The QUAD backward sweep of the d <= 8 models (round 6, backward_quad8_body): the fused walk of four trajectories per wavefront --
@@ -146,18 +156,34 @@ def test_hostsim_quad_backward_vs_reference_golden(lib, name, tol_d, tol_s, n_it
 
 
 def test_hostsim_quad_backward_resolver(lib):
-    """Which backward sweep a quad request gets (i2c_kernel_family / i2c_backward_schedule, the one resolver): the quad walk with the
-    schedule left open or asked to be the fused walk; the lane schedules when one of them is asked for by name; nothing changes for a
-    problem that does not ask (no default window is compiled in for a model until it is measured on the device)."""
+    """Which backward sweep a problem gets (i2c_kernel_family / i2c_backward_schedule, the one resolver). group_lanes = 64: the quad
+    fused walk with the schedule left open or "fused", the quad walker inside the chunked schedule with "chunked", the lane kernels
+    with "two_pass". LANES_QUAD asks for the forward sweep only: the backward sweep resolves as the default does -- the quad walker
+    inside the model's measured window (a few hundred trajectories: the double cartpole's is 1 ... 256), the lane kernels beyond it
+    and whenever a lane schedule is asked for by name."""
     g = load_case("em_dcp_T60")
     fam = lambda **kw: (lambda e: (e.forward_family, e.backward_family, e.backward_schedule))(parity.engine_from_case(g, lib, "cpu", **kw))  # noqa: E731
     Q = parity.pkg._native.LANES_QUAD
-    assert fam(group_lanes=64) == fam(group_lanes=Q) == fam(group_lanes=Q, backward_mode="fused") == ("quad", "quad", "fused")
-    assert fam(group_lanes=64, backward_mode="chunked") == ("quad", "lane", "chunked")
+    assert fam(group_lanes=64) == fam(group_lanes=64, backward_mode="fused") == ("quad", "quad", "fused")
+    assert fam(group_lanes=64, backward_mode="chunked") == ("quad", "quad", "chunked")
     assert fam(group_lanes=64, backward_mode="two_pass") == ("quad", "lane", "two_pass")
+    assert fam() == fam(group_lanes=Q) == ("quad", "quad", "chunked")  # (B = 1: inside the default window)
+    assert fam(group_lanes=Q, backward_mode="chunked") == fam(backward_mode="chunked") == ("quad", "lane", "chunked")
+    assert fam(group_lanes=Q, backward_mode="fused") == ("quad", "lane", "fused")
     assert fam(group_lanes=-1) == ("lane", "lane", "chunked")
     assert fam(deterministic_family=True) == ("lane", "lane", "fused")
-    assert fam(group_lanes=Q, storage_dtype=torch.float32) == ("quad", "quad", "fused")  # fp32-stored messages
+    assert fam(storage_dtype=torch.float32) == ("quad", "quad", "chunked")  # fp32-stored messages
+    N = parity.pkg._native  # the window's edge, asked of the resolver alone (no buffers)
+    p = N.I2cProblem()
+    p.abi_version, p.model_id, p.T, p.backward_mode, p.inference, p.dtype = N.ABI_VERSION, N.MODEL_IDS["DoubleCartpoleKnown"], 300, N.BWD_AUTO, N.INF_CUBATURE, 0
+    p.group_lanes, p.post_layout, p.gh_degree, p.quad_alpha, p.quad_beta, p.quad_kappa = 0, 0, 3, 1.0, 0.0, 0.0
+    import ctypes
+    for B, want in ((1, "quad"), (256, "quad"), (257, "lane"), (4096, "lane")):
+        p.B = B
+        assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_BACKWARD)] == want
+        assert lib.i2c_backward_schedule(ctypes.byref(p)) == N.BWD_CHUNKED
+    p.B, p.T = 1, 6  # too short to chunk: the lane kernels' two-pass schedule, as before
+    assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_BACKWARD)] == "lane" and lib.i2c_backward_schedule(ctypes.byref(p)) == N.BWD_TWO_PASS
 
 
 def test_hostsim_quad_backward_optional_outputs_and_statistics(lib):

@@ -3,6 +3,9 @@
 For every (model, B): forward / backward sweep (HIP events, 20 repetitions) and one EM iteration (i2c_learn, wall clock) with
   default     what the resolver picks (quad forward inside the model's window + the lane backward schedule)
   quad        group_lanes = 64: quad forward + quad backward (the fused walk of four trajectories per wavefront)
+  quad-chunk  group_lanes = 64 + backward_mode = "chunked": the chunked schedule with the quad WALKER (four trajectories per wavefront
+              and chunk; compose / stitch / reduce stay lane kernels)
+  lane-chunk  one lane per trajectory everywhere, chunked schedule
   lane-fused  the lane kernels' fused walk behind the default forward sweep (same bytes as the quad walk, one trajectory per lane)
 `mpc`: the planar-quadrotor control step of bench.py (H = 50, two EM iterations per step) at B = 1024 / 8192, default vs quad."""
 import importlib
@@ -34,7 +37,8 @@ def engine(name, B, **kw):
 
 def sweeps(name, B, reps=20):
     rows = []
-    for tag, kw in (("default", {}), ("quad", dict(group_lanes=64)), ("lane-fused", dict(backward_mode="fused"))):
+    for tag, kw in (("default", {}), ("lane-chunk", dict(group_lanes=-1, backward_mode="chunked")), ("quad", dict(group_lanes=64)),
+                    ("quad-chunk", dict(group_lanes=64, backward_mode="chunked")), ("lane-fused", dict(backward_mode="fused"))):
         eng = engine(name, B, **kw)
         eng.learn(3)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -65,7 +69,7 @@ def sweeps(name, B, reps=20):
 def mpc(B, K=20):
     m = make_env_model("PlanarQuadrotor")
     rng = np.random.default_rng(7)
-    for tag, kw in (("default", {}), ("quad", dict(group_lanes=64))):
+    for tag, kw in (("default", {}), ("quad", dict(group_lanes=64)), ("quad-chunk", dict(group_lanes=64, backward_mode="chunked"))):
         T, n_iter = 50, 2
         Q, R = np.diag([1e3, 1e3, 1e3, 1, 1, 1]) / 1e3, np.diag([1e-3, 1e-3])
         x0 = np.asarray(m.x0, float).reshape(1, -1) + 1e-2 * rng.normal(size=(B, 6))
