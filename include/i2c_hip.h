@@ -96,10 +96,12 @@ enum {
   I2C_FAMILY_GROUP = 2, /* G = I2cDims.group_lanes lanes per trajectory, blocks row-distributed, exchanged through LDS  */
   I2C_FAMILY_WAVE = 3,  /* one wavefront per trajectory: 16 x 16 blocks in the MFMA accumulator layout (d = 16)          */
   I2C_FAMILY_QUAD = 4   /* four trajectories per wavefront: 4 x 4 blocks on v_mfma_f64_4x4x4_4b_f64, one element per lane
-                           (forward sweep: every model; backward sweep, propagation and filter step: d = 16)               */
+                           (forward and backward sweep: every model; propagation and filter step: d = 16)                  */
 };
 /* I2cProblem.group_lanes = I2C_LANES_QUAD asks for the quad kernels of a model that also has wave kernels (64 = the
- * wave kernels there): the 12-state quadrotor -- forward and backward sweep, at any batch size */
+ * wave kernels there): the 12-state quadrotor -- forward and backward sweep, at any batch size. On a d <= 8 model it asks for the
+ * quad FORWARD sweep only: the backward sweep resolves as group_lanes = 0 does (so I2C_LANES_QUAD with I2C_BWD_CHUNKED is the
+ * quad forward sweep + the lane kernels' chunked schedule at any batch size). */
 #define I2C_LANES_QUAD 164
 enum { I2C_SWEEP_FORWARD = 0, I2C_SWEEP_BACKWARD = 1, I2C_SWEEP_PROPAGATE = 2, I2C_SWEEP_FILTER = 3 };
 /* hybrid default of a d >= 7 lane model WHOSE QUAD FORWARD KERNEL DOES NOT APPLY (none of the in-tree models since round 6: the quad
@@ -176,10 +178,14 @@ typedef struct I2cProblem {
                               group kernels for what those forms do not cover);
                               64: the matrix-instruction family: the wave kernels where they exist (I2cDims.wave: one wavefront per
                               trajectory, forward and backward sweeps), the quad kernels otherwise (I2cDims.quad: four trajectories per
-                              wavefront) -- the forward sweep and, since round 6, the backward sweep of every d <= 8 model (the fused walk,
-                              one pass over the forward messages, no chunk workspace: with backward_mode I2C_BWD_AUTO or I2C_BWD_FUSED;
-                              I2C_BWD_CHUNKED / I2C_BWD_TWO_PASS name lane schedules and keep the lane backward sweep);
-                              I2C_LANES_QUAD: the quad kernels of a model that also has wave kernels, at any batch size;
+                              wavefront) -- the forward sweep and, since round 6, the backward sweep of every d <= 8 model: the fused walk
+                              (one pass over the forward messages, no chunk workspace) with backward_mode I2C_BWD_AUTO or
+                              I2C_BWD_FUSED, the chunked schedule with the quad WALKER (compose / stitch / reduce stay lane kernels;
+                              I2cProblem.work as for the lane schedule) with I2C_BWD_CHUNKED -- also the DEFAULT of the d >= 5 models up
+                              to a few hundred trajectories (cartpole 64, double cartpole / planar quadrotor 256: i2c_kernel_family
+                              answers I2C_FAMILY_QUAD, i2c_backward_schedule I2C_BWD_CHUNKED); I2C_BWD_TWO_PASS keeps the lane kernels;
+                              I2C_LANES_QUAD: the quad kernels of a model that also has wave kernels, at any batch size; on a d <= 8
+                              model the quad forward sweep only (see the define);
                               (all of these: fp64 or I2C_F64_F32S; the wave kernels: cubature rule with lam = 0; the quad kernels: any
                               CubatureQuadrature(alpha, beta, kappa) -- with general weights the d = 16 model runs on them at every
                               batch size; the closed-loop propagation and the filter step of the d = 16 model run on the quad

@@ -1,11 +1,12 @@
 """Round 6: the d <= 8 quad backward sweep (backward_quad8_body) against the lane schedules, sweep by sweep.
     python tools/bench_quad_backward8.py [model ...] [B ...] [mpc]
 For every (model, B): forward / backward sweep (HIP events, 20 repetitions) and one EM iteration (i2c_learn, wall clock) with
-  default     what the resolver picks (quad forward inside the model's window + the lane backward schedule)
+  default     what the resolver picks (quad forward inside the model's window; chunked backward schedule, its walk pass on the quad
+              walker up to a few hundred trajectories, on the lane walker beyond)
   quad        group_lanes = 64: quad forward + quad backward (the fused walk of four trajectories per wavefront)
   quad-chunk  group_lanes = 64 + backward_mode = "chunked": the chunked schedule with the quad WALKER (four trajectories per wavefront
               and chunk; compose / stitch / reduce stay lane kernels)
-  lane-chunk  one lane per trajectory everywhere, chunked schedule
+  lane-chunk  quad forward sweep (LANES_QUAD) + the chunked schedule on the lane walker, asked for by name
   lane-fused  the lane kernels' fused walk behind the default forward sweep (same bytes as the quad walk, one trajectory per lane)
 `mpc`: the planar-quadrotor control step of bench.py (H = 50, two EM iterations per step) at B = 1024 / 8192, default vs quad."""
 import importlib
@@ -37,7 +38,7 @@ def engine(name, B, **kw):
 
 def sweeps(name, B, reps=20):
     rows = []
-    for tag, kw in (("default", {}), ("lane-chunk", dict(group_lanes=-1, backward_mode="chunked")), ("quad", dict(group_lanes=64)),
+    for tag, kw in (("default", {}), ("lane-chunk", dict(group_lanes=pkg._native.LANES_QUAD, backward_mode="chunked")), ("quad", dict(group_lanes=64)),
                     ("quad-chunk", dict(group_lanes=64, backward_mode="chunked")), ("lane-fused", dict(backward_mode="fused"))):
         eng = engine(name, B, **kw)
         eng.learn(3)
