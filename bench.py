@@ -517,7 +517,8 @@ def reference_shape_legs(pkg, device, lib=None, scale=1.0):
         out[tag] = {"facade_ms_per_em_iter": facade_ms, "em_iters_per_s": 1e3 / facade_ms, "kernel_ms": kernel_ms, "host_ms": facade_ms - kernel_ms,
                     "facade_over_engine_learn": facade_ms / kernel_ms, "reference_em_iters_per_s_1core": ref_its,
                     "vs_reference_1core": (1e3 / facade_ms) / ref_its, "iterations": n, "history_entries": n_lists,
-                    "forward_family": g.engine.forward_family, "backward": g.engine.backward_schedule, "failed_trajectories": len(g.engine.failures())}
+                    "forward_family": g.engine.forward_family, "backward_family": g.engine.backward_family, "backward": g.engine.backward_schedule,
+                    "failed_trajectories": len(g.engine.failures())}
 
     rs = np.random.RandomState(0)
     Qp = np.diag([1.0, 100.0, 1.0])
