@@ -493,12 +493,22 @@ class I2cGraph(GraphMetrics):
         if np.isnan(alpha_hat).any():
             raise ValueError("Alpha is NaN")
 
+    def _checked_iteration(self):
+        """The tail of an iteration: metric snapshots (device-side copies, i2c.py:1021-1027) enqueued BEFORE the one synchronisation
+        of _check_iteration() -- they run while the host waits instead of after it -- and taken back if the iteration raises."""
+        if self.record_metrics:
+            self._append_iteration_metrics()
+        try:
+            self._check_iteration()
+        except Exception:
+            if self.record_metrics:
+                self._drop_last_iteration_metrics()
+            raise
+
     def _maximize(self):
         self.engine.maximize(update_alpha=True)
-        self._check_iteration()
         self._invalidate()
-        if self.record_metrics:
-            self._append_iteration_metrics()  # entropies of the posterior policy, the state prior, the propagation (i2c.py:1021-1027)
+        self._checked_iteration()
 
     def compute_update_alpha(self, update_alpha):
         """i2c.py:921-963: alpha_hat, the clamp, and (with update_alpha) the new temperature in every cell -- nothing else:
@@ -509,9 +519,7 @@ class I2cGraph(GraphMetrics):
         self._sync_initial_state()
         self._invalidate()
         self.engine.learn_msgs()
-        self._check_iteration()
-        if self.record_metrics:
-            self._append_iteration_metrics()
+        self._checked_iteration()
 
     def update_models(self):
         pass

@@ -244,6 +244,19 @@ class GraphMetrics:
         if len(pend) * nbytes > _MAX_PENDING_BYTES:
             self._materialise_metrics()
 
+    def _drop_last_iteration_metrics(self):
+        """Take back what the last _append_iteration_metrics() added: the snapshots are enqueued BEFORE the iteration's one
+        synchronisation (they then run while the host waits), and an iteration that raises must leave no entry -- the reference
+        appends after its alpha check (i2c.py:1004-1027)."""
+        pend = self.__dict__.get("_pending_metrics")
+        if pend:
+            pend.pop()
+            return
+        for n in _LAZY_LISTS:  # (the snapshot was materialised on the spot: the pending buffer had reached its cap)
+            lst = self.__dict__.get("_m_" + n)
+            if lst and (n != "propagate_entropy" or (self._propagate and self.engine.prop is not None)):
+                lst.pop()
+
     def _materialise_metrics(self):
         pending = self.__dict__.get("_pending_metrics")
         if not pending:

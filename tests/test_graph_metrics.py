@@ -147,6 +147,15 @@ def test_iteration_entropy_lists_are_lazy():
         warnings.simplefilter("always")
         h = gm._sum_gaussian_entropy(np.array([[[[1.0, 0.0], [0.0, -1e-18]], [[1.0, 0.0], [0.0, 1.0]]]]), "probe")
     assert np.isnan(h[0]) and any("not positive definite" in str(x.message) for x in w)
+    # the snapshots are enqueued BEFORE the iteration's one synchronisation; an iteration that raises (the reference raises inside
+    # it, before its metric appends: i2c.py:1004-1027) leaves no entry behind
+    gr.learn_msgs()
+    n_pending, n_costs = len(gr._pending_metrics), len(gr.costs_m)
+    gr.engine.sig_x0[0, 0] = -1.0  # a negative variance: the first factorisation of the forward sweep fails
+    with pytest.raises(np.linalg.LinAlgError):
+        gr.learn_msgs()
+    assert len(gr._pending_metrics) == n_pending and len(gr.policy_entropy) == n_pending
+    del n_costs
 
 
 @pytest.mark.gpu
