@@ -7,7 +7,8 @@ round-5 judge did by hand, as a script. Needs /root/reference (this container on
    (new horizons, seeds, cost weights, temperatures, tolerances, cubature rules -- the generator of oracle/gen_golden.py, other
    arguments), writing the captures as .npz into a TEMPORARY directory;
 2. this process replays each of them through the product engine -- the host-simulation build of the same csrc/ cell code -- on
-   every kernel family that serves it (default, one lane per trajectory, quad sweeps incl. the round-6 backward walk, group), with
+   every kernel family that serves it (default, one lane per trajectory, quad sweeps incl. the round-6 backward walk and the quad walker
+   of the chunked schedule, group), with
    tests/parity.check_against_golden: every per-cell quantity and the EM summaries.
 Prints one line per (problem, family); exits non-zero on a mismatch."""
 import os
@@ -66,12 +67,13 @@ em("spot_quad12_T9_general", "Quadrotor12", m12, 9, G.QUAD12_Q, G.QUAD12_R, G.QU
    0.25 * m12.gravity * np.ones((9, 4)) + 1e-2 * rng.normal(size=(9, 4)), 1e-2 * np.eye(4), quad=(1.2, 0.44, 0.5), n_total=4)
 """
 
-CASES = [  # (name, tolerances, families to ask for: group_lanes values)
-    ("spot_pendulum_T57", (1e-8, 1e-7), (0, 64, True)),
+QC = (64, "chunked")  # the quad walker inside the chunked schedule, asked for by name (the default of the d >= 5 models at B = 1)
+CASES = [  # (name, tolerances, families to ask for: group_lanes values, or (group_lanes, backward_mode))
+    ("spot_pendulum_T57", (1e-8, 1e-7), (0, 64, True, QC)),
     ("spot_dcp_T33", (1e-6, 1e-5), (0, -1, 64, True)),
     ("spot_cartpole_T45_centre", (1e-6, 1e-5), (0, -1, 64)),
     ("spot_quadrotor_T17_general", (1e-6, 1e-5), (0, -1, 64, True)),
-    ("spot_covctrl_T37", (1e-7, 1e-6), (0, 64)),
+    ("spot_covctrl_T37", (1e-7, 1e-6), (0, 64, QC)),
     ("spot_quad12_T9_general", (1e-6, 1e-5), (0, 16)),
 ]
 
@@ -94,8 +96,9 @@ def main():
     bad = 0
     for name, (td, ts), fams in CASES:
         for lanes in fams:
+            kw = dict(group_lanes=lanes[0], backward_mode=lanes[1]) if isinstance(lanes, tuple) else dict(group_lanes=lanes)
             try:
-                eng = parity.check_against_golden(name, lib, "cpu", td, ts, group_lanes=lanes)
+                eng = parity.check_against_golden(name, lib, "cpu", td, ts, **kw)
                 print(f"{name:30s} group_lanes={str(lanes):5s} OK   forward {eng.forward_family:5s} backward {eng.backward_family:5s} ({eng.backward_schedule})")
             except AssertionError as e:
                 bad += 1
