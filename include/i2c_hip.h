@@ -103,7 +103,11 @@ enum {
  * quad FORWARD sweep only: the backward sweep resolves as group_lanes = 0 does (so I2C_LANES_QUAD with I2C_BWD_CHUNKED is the
  * quad forward sweep + the lane kernels' chunked schedule at any batch size). */
 #define I2C_LANES_QUAD 164
-enum { I2C_SWEEP_FORWARD = 0, I2C_SWEEP_BACKWARD = 1, I2C_SWEEP_PROPAGATE = 2, I2C_SWEEP_FILTER = 3 };
+enum { I2C_SWEEP_FORWARD = 0, I2C_SWEEP_BACKWARD = 1, I2C_SWEEP_PROPAGATE = 2, I2C_SWEEP_FILTER = 3,
+       /* the compose + stitch passes of the CHUNKED backward schedule (sigma-point rules): I2C_FAMILY_LANE, or I2C_FAMILY_QUAD inside
+        * the model's measured window / when group_lanes = 64 asks for the chunked schedule; I2C_ENOTSUP when the problem's backward
+        * sweep does not run that schedule. The walk pass is what I2C_SWEEP_BACKWARD reports. */
+       I2C_SWEEP_CHUNK_PASSES = 4 };
 /* hybrid default of a d >= 7 lane model WHOSE QUAD FORWARD KERNEL DOES NOT APPLY (none of the in-tree models since round 6: the quad
  * kernels take any cubature weights; an out-of-tree model with GROUP_FORWARD_AUTO and no quad form): its FORWARD sweep runs on the
  * group kernels while B * G stays within this many lanes (every group wave then has a SIMD of its own: 1024 SIMDs x 64 lanes).

@@ -529,7 +529,7 @@ static int launch_quad_backward(const Consts<M, R>& c, const A& a, void* stream)
 // the quad WALKER of the chunked schedule (d <= 8; backward_quad8_body<CHUNK>): grid = groups of four trajectories x chunks
 template <class M, typename R, typename S> static QChunk<R> quad_chunk_of(const Consts<M, R>& c, const ChunkArgs<R, S>& a, const int ch) {
   const int t_lo = ch * a.chunk_len, t_hi = (t_lo + a.chunk_len < c.T) ? t_lo + a.chunk_len : c.T;
-  return QChunk<R>{a.bnd, a.part, ch, t_lo, t_hi};
+  return QChunk<R>{a.bnd, a.part, ch, t_lo, t_hi, a.comp, a.n_chunks};
 }
 #ifdef I2C_HOST_SIM
 template <class M, typename R, typename S, bool GENERAL, bool LEANQ>
@@ -547,7 +547,7 @@ static int launch_quad_chunk_walk_g(const Consts<M, R>& c, const ChunkArgs<R, S>
           const int g = (l >> 2) & 3, b = b0 + g;
           const bool live = b < c.B;
           for (int ch = 0; ch < a.n_chunks; ++ch)
-            backward_quad8_body<M, R, S, GENERAL, LEANQ, true>(c, kc, a.cell, live ? b : c.B - 1, live,
+            backward_quad8_body<M, R, S, GENERAL, LEANQ, QB8_CHUNK_WALK>(c, kc, a.cell, live ? b : c.B - 1, live,
                                                                Quad<R>{l, l >> 4, g, l & 3, sh.data() + g * LSZ, &bar, xch.data()},
                                                                quad_chunk_of<M, R, S>(c, a, ch));
         });
@@ -557,7 +557,98 @@ static int launch_quad_chunk_walk_g(const Consts<M, R>& c, const ChunkArgs<R, S>
   }
   return I2C_ENOTSUP;
 }
+// the COMPOSE and STITCH passes in the quad form (compose_quad8_body, backward_quad8_body<QB8_STITCH>)
+template <class M, typename R, typename S>
+static int launch_quad_chunk_compose(const Consts<M, R>& c, const ChunkArgs<R, S>& a, void*) {
+  if constexpr (!QG<M>::WIDE) {
+    for (int b0 = 0; b0 < c.B; b0 += 4) {
+      std::vector<R> xch(128, R(0));
+      HostBarrier bar(64);
+      std::vector<std::thread> lanes;
+      for (int l = 0; l < 64; ++l)
+        lanes.emplace_back([&, l, b0] {
+          const int g = (l >> 2) & 3, b = b0 + g;
+          const bool live = b < c.B;
+          for (int ch = 0; ch < a.n_chunks; ++ch) {
+            const QChunk<R> qc = quad_chunk_of<M, R, S>(c, a, ch);
+            compose_quad8_body<M, R, S>(c, a.cell.fwd, a.comp, ch, qc.t_lo, qc.t_hi, live ? b : c.B - 1, live, Quad<R>{l, l >> 4, g, l & 3, nullptr, &bar, xch.data()});
+          }
+        });
+      for (auto& th : lanes) th.join();
+    }
+    return I2C_OK;
+  }
+  return I2C_ENOTSUP;
+}
+template <class M, typename R, typename S, bool GENERAL>
+static int launch_quad_chunk_stitch_g(const Consts<M, R>& c, const ChunkArgs<R, S>& a, void*) {
+  if constexpr (!QG<M>::WIDE) {
+    QBConst<M, R> kc;
+    qbconst_fill<M, R>(kc, &c, 0, 1);
+    constexpr int LSZ = quad_backward_lds<M>();
+    for (int b0 = 0; b0 < c.B; b0 += 4) {
+      std::vector<R> sh((size_t)4 * LSZ, R(0)), xch(128, R(0));
+      HostBarrier bar(64);
+      std::vector<std::thread> lanes;
+      for (int l = 0; l < 64; ++l)
+        lanes.emplace_back([&, l, b0] {
+          const int g = (l >> 2) & 3, b = b0 + g;
+          const bool live = b < c.B;
+          backward_quad8_body<M, R, S, GENERAL, true, QB8_STITCH>(c, kc, a.cell, live ? b : c.B - 1, live,
+                                                                  Quad<R>{l, l >> 4, g, l & 3, sh.data() + g * LSZ, &bar, xch.data()}, quad_chunk_of<M, R, S>(c, a, 0));
+        });
+      for (auto& th : lanes) th.join();
+    }
+    return I2C_OK;
+  }
+  return I2C_ENOTSUP;
+}
 #else
+template <class M, typename R, typename S>
+__global__ __launch_bounds__(64 * QB_WAVES_PER_BLOCK, 2) void k_quad_chunk_compose(const Consts<M, R> c, const ChunkArgs<R, S> a) {
+  constexpr int WPB = QB_WAVES_PER_BLOCK;
+  const int l = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6), g = (l >> 2) & 3;
+  const long b0 = 4L * ((long)blockIdx.x * WPB + wv);
+  if (b0 >= c.B) return;  // (wave-uniform: no trajectory in this wave)
+  const long b = b0 + g;
+  const bool live = b < c.B;
+  const Quad<R> q{l, l >> 4, g, l & 3, (lds_ptr<R>)nullptr};
+  const int ch = (int)blockIdx.y, t_lo = ch * a.chunk_len, t_hi = (t_lo + a.chunk_len < c.T) ? t_lo + a.chunk_len : c.T;
+  compose_quad8_body<M, R, S>(c, a.cell.fwd, a.comp, ch, t_lo, t_hi, (int)(live ? b : c.B - 1), live, q);
+}
+template <class M, typename R, typename S>
+static int launch_quad_chunk_compose(const Consts<M, R>& c, const ChunkArgs<R, S>& a, void* stream) {
+  if constexpr (!QG<M>::WIDE) {
+    constexpr int WPB = QB_WAVES_PER_BLOCK;
+    hipLaunchKernelGGL((k_quad_chunk_compose<M, R, S>), dim3((unsigned)(((long)c.B + 4 * WPB - 1) / (4 * WPB)), (unsigned)a.n_chunks), dim3(64 * WPB), 0, (hipStream_t)stream, c, a);
+    return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
+  }
+  return I2C_ENOTSUP;
+}
+template <class M, typename R, typename S, bool GENERAL = false>
+__global__ __launch_bounds__(64 * QB_WAVES_PER_BLOCK, 2) void k_quad_chunk_stitch(const Consts<M, R> c, const ChunkArgs<R, S> a) {
+  constexpr int WPB = QB_WAVES_PER_BLOCK, LSZ = quad_backward_lds<M>();
+  __shared__ QBConst<M, R> kc;
+  __shared__ R sh[WPB * 4 * LSZ];
+  qbconst_fill<M, R>(kc, (const Consts<M, R>*)__builtin_amdgcn_kernarg_segment_ptr(), (int)threadIdx.x, 64 * WPB);
+  __syncthreads();
+  const int l = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6), g = (l >> 2) & 3;
+  const long b0 = 4L * ((long)blockIdx.x * WPB + wv);
+  if (b0 >= c.B) return;  // (wave-uniform: no trajectory in this wave)
+  const long b = b0 + g;
+  const bool live = b < c.B;
+  const Quad<R> q{l, l >> 4, g, l & 3, (lds_ptr<R>)(sh + (wv * 4 + g) * LSZ)};
+  backward_quad8_body<M, R, S, GENERAL, true, QB8_STITCH>(c, kc, a.cell, (int)(live ? b : c.B - 1), live, q, QChunk<R>{a.bnd, a.part, 0, 0, c.T, a.comp, a.n_chunks});
+}
+template <class M, typename R, typename S, bool GENERAL>
+static int launch_quad_chunk_stitch_g(const Consts<M, R>& c, const ChunkArgs<R, S>& a, void* stream) {
+  if constexpr (!QG<M>::WIDE) {
+    constexpr int WPB = QB_WAVES_PER_BLOCK;
+    hipLaunchKernelGGL((k_quad_chunk_stitch<M, R, S, GENERAL>), dim3((unsigned)(((long)c.B + 4 * WPB - 1) / (4 * WPB))), dim3(64 * WPB), 0, (hipStream_t)stream, c, a);
+    return hipGetLastError() == hipSuccess ? I2C_OK : I2C_ELAUNCH;
+  }
+  return I2C_ENOTSUP;
+}
 template <class M, typename R, typename S, bool GENERAL = false, bool LEANQ = false>
 __global__ __launch_bounds__(64 * QB_WAVES_PER_BLOCK, 2) void k_quad_chunk_walk(const Consts<M, R> c, const ChunkArgs<R, S> a) {
   constexpr int WPB = QB_WAVES_PER_BLOCK, LSZ = quad_backward_lds<M>();
@@ -572,7 +663,7 @@ __global__ __launch_bounds__(64 * QB_WAVES_PER_BLOCK, 2) void k_quad_chunk_walk(
   const bool live = b < c.B;
   const Quad<R> q{l, l >> 4, g, l & 3, (lds_ptr<R>)(sh + (wv * 4 + g) * LSZ)};
   const int ch = (int)blockIdx.y, t_lo = ch * a.chunk_len, t_hi = (t_lo + a.chunk_len < c.T) ? t_lo + a.chunk_len : c.T;
-  backward_quad8_body<M, R, S, GENERAL, LEANQ, true>(c, kc, a.cell, (int)(live ? b : c.B - 1), live, q, QChunk<R>{a.bnd, a.part, ch, t_lo, t_hi});
+  backward_quad8_body<M, R, S, GENERAL, LEANQ, QB8_CHUNK_WALK>(c, kc, a.cell, (int)(live ? b : c.B - 1), live, q, QChunk<R>{a.bnd, a.part, ch, t_lo, t_hi, a.comp, a.n_chunks});
 }
 template <class M, typename R, typename S, bool GENERAL, bool LEANQ>
 static int launch_quad_chunk_walk_g(const Consts<M, R>& c, const ChunkArgs<R, S>& a, void* stream) {
@@ -585,6 +676,14 @@ static int launch_quad_chunk_walk_g(const Consts<M, R>& c, const ChunkArgs<R, S>
   return I2C_ENOTSUP;
 }
 #endif
+template <class M, typename R, typename S>
+static int launch_quad_chunk_stitch(const Consts<M, R>& c, const ChunkArgs<R, S>& a, void* stream) {
+  const bool unit = c.rule_xu.unit && c.rule_x.unit && c.rule_xu.w0 == R(0) && c.rule_x.w0 == R(0);
+  if constexpr (quad_general_exists<M>()) {
+    if (!unit) return launch_quad_chunk_stitch_g<M, R, S, true>(c, a, stream);
+  }
+  return unit ? launch_quad_chunk_stitch_g<M, R, S, false>(c, a, stream) : I2C_ENOTSUP;
+}
 template <class M, typename R, typename S>
 static int launch_quad_chunk_walk(const Consts<M, R>& c, const ChunkArgs<R, S>& a, void* stream) {
   const bool unit = c.rule_xu.unit && c.rule_x.unit && c.rule_xu.w0 == R(0) && c.rule_x.w0 == R(0);
@@ -842,6 +941,15 @@ template <class M> struct quad_chunk_walk_window<M, std::void_t<decltype(M::QUAD
   static constexpr int min_b = M::QUAD_CHUNK_WALK_MIN_B, max_b = M::QUAD_CHUNK_WALK_MAX_B;
 };
 
+// batch window in which the COMPOSE and STITCH passes of the chunked schedule run in the quad form by default (compose_quad8_body,
+// backward_quad8_body<QB8_STITCH>; measured per model, i2c_models.hpp: QUAD_CHUNK_PASSES_MIN_B / _MAX_B); whatever walker follows
+template <class M, class = void> struct quad_chunk_passes_window {
+  static constexpr int min_b = 0, max_b = -1;
+};
+template <class M> struct quad_chunk_passes_window<M, std::void_t<decltype(M::QUAD_CHUNK_PASSES_MAX_B)>> {
+  static constexpr int min_b = M::QUAD_CHUNK_PASSES_MIN_B, max_b = M::QUAD_CHUNK_PASSES_MAX_B;
+};
+
 // ---- per-(model, dtype) entry points ------------------------------------------------------
 // Which kernels serve a call:
 //   M::GROUP      lanes per trajectory of the model's group kernels (0: none compiled); fp64 only
@@ -932,6 +1040,23 @@ template <class M, typename R, typename S = R> struct Impl {
       return (p->group_lanes == 0 || p->group_lanes == I2C_LANES_QUAD) && p->backward_mode == I2C_BWD_AUTO && p->inference == I2C_INF_CUBATURE &&
              p->B >= quad_chunk_walk_window<M>::min_b && p->B <= quad_chunk_walk_window<M>::max_b && schedule(p->B, p->T, I2C_BWD_AUTO) == I2C_BWD_CHUNKED;
     return false;
+  }
+  // the compose / stitch passes of the chunked sigma-point schedule: I2C_FAMILY_QUAD when the quad walker was asked for by name
+  // (group_lanes = 64 with "chunked": the whole schedule on matrix instructions) or, by default, inside the model's
+  // quad_chunk_passes_window; I2C_FAMILY_LANE otherwise (i2c_kernel_family(problem, I2C_SWEEP_CHUNK_PASSES) reports it)
+  static int chunk_passes_family(const I2cProblem* p, const C& c) {
+    if constexpr (HAS_QUAD_BACKWARD && !QG<M>::WIDE && LANE) {
+      if (p->inference == I2C_INF_CUBATURE && quad_supported(p, c) == I2C_OK) {
+        if (p->group_lanes == 64 && p->backward_mode == I2C_BWD_CHUNKED) return I2C_FAMILY_QUAD;
+        static const int forced_max = [] {  // experiment knob (not part of the ABI): overrides the model's window
+          const char* e = getenv("I2C_QUAD_PASSES_MAX_B");
+          return e ? atoi(e) : -2;
+        }();
+        const int min_b = forced_max > -2 ? 1 : quad_chunk_passes_window<M>::min_b, max_b = forced_max > -2 ? forced_max : quad_chunk_passes_window<M>::max_b;
+        if ((p->group_lanes == 0 || p->group_lanes == I2C_LANES_QUAD) && p->B >= min_b && p->B <= max_b) return I2C_FAMILY_QUAD;
+      }
+    }
+    return I2C_FAMILY_LANE;
   }
   static constexpr bool HAS_QUAD_CKF = HAS_QUAD && !MIXED && quad_ckf_exists<M>();  // the filter step of the d = 16 form
   static constexpr bool HAS_QUAD_PROP = HAS_QUAD && !MIXED && quad_propagate_exists<M>();  // the closed-loop propagation of the d = 16 form
@@ -1026,6 +1151,12 @@ template <class M, typename R, typename S = R> struct Impl {
     I2cProblem q = sweep == I2C_SWEEP_FILTER ? filter_problem(p) : *p;
     if (sweep == I2C_SWEEP_PROPAGATE && p->inference == I2C_INF_LINEARIZE) q.quad_alpha = 1.0, q.quad_beta = 0.0, q.quad_kappa = 0.0;  // (as propagate())
     const C c = make_consts<M, R>(&q, 0.0, 0);
+    if (sweep == I2C_SWEEP_CHUNK_PASSES) {  // the compose / stitch passes: of a problem whose backward sweep runs the chunked sigma-point schedule
+      const int mode = plan(&q);
+      if (mode < 0) return mode;
+      if (mode != I2C_BWD_CHUNKED || q.inference != I2C_INF_CUBATURE) return I2C_ENOTSUP;
+      return chunk_passes_family(&q, c);
+    }
     return family(&q, c, sweep);
   }
 
@@ -1287,8 +1418,19 @@ template <class M, typename R, typename S = R> struct Impl {
       cr.T = ch.n_chunks;
       CellArgs<R, S> ared = a;
       ared.cell_stats = ch.part;
-      int rc = launch(k_chunk_compose<M, R, S>, p->B, ch.n_chunks, LANE_BLOCK, stream, c, ch);
-      if (rc == I2C_OK) rc = launch(k_chunk_stitch<M, R, S>, p->B, 1, LANE_BLOCK, stream, c, ch);
+      int rc;
+      bool lane_passes = true;
+      if constexpr (HAS_QUAD_BACKWARD && !QG<M>::WIDE) {
+        if (chunk_passes_family(p, c) == I2C_FAMILY_QUAD) {  // compose + stitch, four trajectories per wavefront
+          lane_passes = false;
+          rc = launch_quad_chunk_compose<M, R, S>(c, ch, stream);
+          if (rc == I2C_OK) rc = launch_quad_chunk_stitch<M, R, S>(c, ch, stream);
+        }
+      }
+      if (lane_passes) {
+        rc = launch(k_chunk_compose<M, R, S>, p->B, ch.n_chunks, LANE_BLOCK, stream, c, ch);
+        if (rc == I2C_OK) rc = launch(k_chunk_stitch<M, R, S>, p->B, 1, LANE_BLOCK, stream, c, ch);
+      }
       if (rc == I2C_OK) {
         if (quad_walk) {
           if constexpr (HAS_QUAD_BACKWARD && !QG<M>::WIDE) rc = launch_quad_chunk_walk<M, R, S>(c, ch, stream);

@@ -1891,14 +1891,22 @@ template <typename R, typename S> struct QIO8 {
 // pass's), cost sums into part[ch] for the reduction. Small batches are bound by the DEPTH of the chain: the lane walker needs
 // ~ 24 k clocks for a d = 8 cell of 64 trajectories, this one 4.2 k for a cell of four -- with chunks supplying the parallelism
 // over t, the walk of a batch that leaves most SIMDs idle is as long as its chunk, not as its lane cell.
+// MODE = QB8_STITCH: the STITCH pass of the chunked schedule in the same blocks -- end of the chain and terminal statistics (the code
+// of the fused walk), then chunk by chunk  bnd[ch] <- (m, S);  (m, S) <- (a + G m, C + G S G^T)  with the composites of the compose
+// pass (compose_quad8_body below, or the lane kernels': one format). A step is ~20 matrix + ~60 vector instructions where the lane
+// form needs 767 vector instructions (planar quadrotor), and the pass is a chain of NC dependent steps whatever the batch.
 template <typename R> struct QChunk {
-  const R* bnd;  // [NC][NX + sym(NX)][B]  smoothed state entering each chunk (chunk_stitch_body)
-  R* part;       // [NC][2][B]             per-chunk cost sums
+  R* bnd;         // [NC][NX + sym(NX)][B]  smoothed state entering each chunk (written by the stitch pass, read by the walkers)
+  R* part;        // [NC][2][B]             per-chunk cost sums
   int ch, t_lo, t_hi;
+  const R* comp;  // [NC][NX + NX*NX + sym(NX)][B]  composite maps (stitch pass)
+  int n_chunks;
 };
-template <class M, typename R, typename S, bool GENERAL = false, bool LEANQ = false, bool CHUNK = false, class KC>
+enum { QB8_FUSED = 0, QB8_CHUNK_WALK = 1, QB8_STITCH = 2 };
+template <class M, typename R, typename S, bool GENERAL = false, bool LEANQ = false, int MODE = QB8_FUSED, class KC>
 I2C_HD inline void backward_quad8_body(const Consts<M, R>& c, const KC& kc, const CellArgs<R, S>& a_in, const int b, const bool live, const Quad<R>& q,
-                                       const QChunk<R> qc = QChunk<R>{nullptr, nullptr, 0, 0, 0}) {
+                                       const QChunk<R> qc = QChunk<R>{nullptr, nullptr, 0, 0, 0, nullptr, 0}) {
+  constexpr bool CHUNK = MODE == QB8_CHUNK_WALK;
   CellArgs<R, S> a = a_in;
   if (LEANQ) a.xm = nullptr, a.zpost = nullptr, a.cell_stats = nullptr;
   using C = Consts<M, R>;
@@ -2118,6 +2126,84 @@ I2C_HD inline void backward_quad8_body(const Consts<M, R>& c, const KC& kc, cons
     if (lead) a.term_stats[b] = trT;
   }
 
+  if constexpr (MODE == QB8_STITCH) {
+    // ---- the stitch pass: the smoothed state entering every chunk, from the last chunk down ------------------------------------
+    constexpr int EC = NX + NX * NX + sym(NX);
+    const QIO8<R, R> ior{(unsigned)(B * sizeof(R)), (unsigned)b * (unsigned)sizeof(R)};
+    unsigned c_a[NBX], c_g[NBX * NBX], c_c[NBX * NBX], b_m[NBX], b_s[NBX * NBX];
+#pragma unroll
+    for (int j = 0; j < NBX; ++j) {
+      c_a[j] = ior.lane(in_col(j, NX), cc);
+      b_m[j] = ior.lane(live && r == 0 && in_col(j, NX), cc);
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) {
+        c_g[i * NBX + j] = ior.lane(in_n(i, j, NX), r * NX + cc);  // G[4 i + r][4 j + c], row-major
+        c_c[i * NBX + j] = ior.lane(i <= j && in_n(i, j, NX), sym_lane(i, j));
+        b_s[i * NBX + j] = ior.lane(live && i <= j && (i < j || up) && in_col(j, NX), sym_lane(i, j));
+      }
+    }
+    R ca[NBX], cg[NBX * NBX], ccv[NBX * NBX];  // the next composite, a step ahead
+    auto fetchc = [&](const int ch) {
+      const Window w = make_window(qc.comp + (unsigned long)(ch > 0 ? ch : 0) * EC * B, (unsigned long)EC * ior.rb);
+#pragma unroll
+      for (int j = 0; j < NBX; ++j) {
+        ca[j] = ior.ld(w, c_a[j], 4 * j);
+#pragma unroll
+        for (int i = 0; i < NBX; ++i) {
+          cg[i * NBX + j] = ior.ld(w, c_g[i * NBX + j], NX + 4 * i * NX + 4 * j);
+          if (i <= j) ccv[i * NBX + j] = ior.ld(w, c_c[i * NBX + j], NX + NX * NX + sym_k(i, j));
+        }
+      }
+    };
+    fetchc(qc.n_chunks - 1);
+    for (int ch = qc.n_chunks - 1; ch >= 0; --ch) {
+      R av[NBX], gt[NBX * NBX], cn[NBX * NBX];
+#pragma unroll
+      for (int j = 0; j < NBX; ++j) {
+        av[j] = ca[j];
+#pragma unroll
+        for (int i = 0; i < NBX; ++i) {
+          gt[i * NBX + j] = q_tr(q, cg[j * NBX + i]);  // the blocks of G^T
+          cn[i * NBX + j] = i <= j ? ccv[i * NBX + j] : R(0);
+        }
+      }
+      fetchc(ch - 1);
+      const Window wb = make_window(qc.bnd + (unsigned long)ch * C::E_XM * B, (unsigned long)C::E_XM * ior.rb);
+      R mr[NBX], sf[NBX * NBX], p1[NBX * NBX];
+#pragma unroll
+      for (int j = 0; j < NBX; ++j) {
+        ior.st(wb, b_m[j], 4 * j, m3m[j]);
+        mr[j] = q_tr(q, m3m[j]);  // row form
+#pragma unroll
+        for (int i = 0; i <= j; ++i) ior.st(wb, b_s[i * NBX + j], NX + sym_k(i, j), s3m[i * NBX + j]);
+      }
+#pragma unroll
+      for (int i = 0; i < NBX; ++i)
+#pragma unroll
+        for (int j = 0; j < NBX; ++j) {
+          sf[i * NBX + j] = j >= i ? s3m[i * NBX + j] : q_tr(q, s3m[j * NBX + i]);
+          p1[i * NBX + j] = R(0);
+        }
+#pragma unroll
+      for (int j = 0; j < NBX; ++j) {  // m <- a + G m
+        R ts = R(0);
+#pragma unroll
+        for (int i = 0; i < NBX; ++i) ts += gt[i * NBX + j] * mr[i];
+        m3m[j] = av[j] + q_colsum(q, ts);
+      }
+      q_tn<NBX, NBX, NBX>(q, sf, gt, p1);               // S G^T
+      q_tn<NBX, NBX, NBX, false, true>(q, gt, p1, cn);  // C + G (S G^T), upper blocks
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) {  // (the diagonal blocks exactly symmetric again: see the RTS update of the walk)
+        const R st = q_tr(q, cn[i * NBX + i]);
+        cn[i * NBX + i] = up ? cn[i * NBX + i] : st;
+      }
+#pragma unroll
+      for (int k = 0; k < NBX * NBX; ++k) s3m[k] = cn[k];
+    }
+    if (lead && fail != 0 && a.status[b] == 0) a.status[b] = fail;
+    return;
+  }
   R acc_m = R(0), acc_v = R(0);
   for (int t = t_hi - 1; t >= t_lo; --t) {
     const int kz = (int)opaque_uniform(0u);  // (see q_ldc)
@@ -2300,6 +2386,121 @@ I2C_HD inline void backward_quad8_body(const Consts<M, R>& c, const KC& kc, cons
       a.term_stats[2 * B + b] = sv;
     }
     if (fail != 0 && a.status[b] == 0) a.status[b] = fail;
+  }
+}
+
+// The COMPOSE pass of the chunked schedule in the same blocks (chunk_compose_body, i2c_cell.hpp: the x-marginal RTS recursion of one
+// chunk as an affine map of the smoothed state that enters it):  a <- mu1 + Jx (a - m3f),  C <- S1 + Jx (C - S3f) Jx^T,  G <- Jx G
+// from the chunk's last cell down, four trajectories per wavefront, rows fetched a cell ahead; the composite is stored in the lane
+// kernels' format ([a | G row-major | C packed][B]) so that either stitch pass reads it. ~25 matrix + ~50 vector instructions per
+// cell (NX = 6) where one lane needs 981 vector instructions.
+template <class M, typename R, typename S>
+I2C_HD inline void compose_quad8_body(const Consts<M, R>& c, const S* fwd, R* comp, const int ch, const int t_lo, const int t_hi, const int b, const bool live,
+                                      const Quad<R>& q) {
+  using C = Consts<M, R>;
+  constexpr int NX = C::NX, D = C::D, NBX = (NX + 3) / 4;
+  constexpr int O_MU3 = D + sym(D), O_S3 = O_MU3 + NX, O_J = O_S3 + sym(NX), EC = NX + NX * NX + sym(NX);
+  static_assert(quad_backward8_exists<M>(), "quad compose pass: the d <= 8 geometry");
+  const int r = q.r, cc = q.c;
+  const unsigned long B = c.B;
+  const bool up = r <= cc;
+  const int hi = r > cc ? r : cc, lo = r > cc ? cc : r;
+  const int tri_c = cc * (cc + 1) / 2 + r, tri_d = hi * (hi + 1) / 2 + lo;
+  auto sym_lane = [&](const int i, const int j) { return i == j ? tri_d + 4 * j * hi : tri_c + 4 * j * cc; };
+  auto sym_k = [&](const int i, const int j) { return i == j ? 8 * j * j + 6 * j : 8 * j * j + 2 * j + 4 * i; };
+  auto in_row = [&](const int i, const int N) { return 4 * i + 3 < N || 4 * i + r < N; };
+  auto in_col = [&](const int j, const int N) { return 4 * j + 3 < N || 4 * j + cc < N; };
+  auto in_n = [&](const int i, const int j, const int N) { return in_row(i, N) && in_col(j, N); };
+  const QIO8<R, S> io{(unsigned)(B * sizeof(S)), (unsigned)b * (unsigned)sizeof(S)};
+  const QIO8<R, R> ior{(unsigned)(B * sizeof(R)), (unsigned)b * (unsigned)sizeof(R)};
+  unsigned l_v[NBX], l_s[NBX * NBX], l_j[NBX * NBX], o_a[NBX], o_g[NBX * NBX], o_c[NBX * NBX];
+#pragma unroll
+  for (int j = 0; j < NBX; ++j) {
+    l_v[j] = io.lane(in_col(j, NX), cc);
+    o_a[j] = ior.lane(live && r == 0 && in_col(j, NX), cc);
+#pragma unroll
+    for (int i = 0; i < NBX; ++i) {
+      l_s[i * NBX + j] = io.lane(i <= j && in_n(i, j, NX), sym_lane(i, j));  // upper blocks (the diagonal ones as full symmetric blocks)
+      l_j[i * NBX + j] = io.lane(in_n(i, j, NX), cc * NX + r);               // Jx^T: J is stored [joint index][state]
+      o_g[i * NBX + j] = ior.lane(live && in_n(i, j, NX), r * NX + cc);
+      o_c[i * NBX + j] = ior.lane(live && i <= j && (i < j || up) && in_col(j, NX), sym_lane(i, j));
+    }
+  }
+  R n_mu[NBX], n_s1[NBX * NBX], n_m3[NBX], n_s3[NBX * NBX], n_jt[NBX * NBX];
+  auto fetch = [&](const int tc) {
+    const Window f = make_window(fwd + (unsigned long)tc * C::E_FWD * B, (unsigned long)C::E_FWD * io.rb);
+#pragma unroll
+    for (int j = 0; j < NBX; ++j) {
+      n_mu[j] = io.ld(f, l_v[j], 4 * j);
+      n_m3[j] = io.ld(f, l_v[j], O_MU3 + 4 * j);
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) {
+        if (i <= j) {
+          n_s1[i * NBX + j] = io.ld(f, l_s[i * NBX + j], D + sym_k(i, j));
+          n_s3[i * NBX + j] = io.ld(f, l_s[i * NBX + j], O_S3 + sym_k(i, j));
+        }
+        n_jt[i * NBX + j] = io.ld(f, l_j[i * NBX + j], O_J + 4 * j * NX + 4 * i);
+      }
+    }
+  };
+  fetch(t_hi - 1);
+  R av[NBX], g[NBX * NBX], cm[NBX * NBX];
+#pragma unroll
+  for (int j = 0; j < NBX; ++j) {
+    av[j] = R(0);
+#pragma unroll
+    for (int i = 0; i < NBX; ++i) {
+      g[i * NBX + j] = (i == j && r == cc && 4 * i + r < NX) ? R(1) : R(0);
+      cm[i * NBX + j] = R(0);
+    }
+  }
+  for (int t = t_hi - 1; t >= t_lo; --t) {
+    R mu1[NBX], s1[NBX * NBX], jt[NBX * NBX], drr[NBX], ds[NBX * NBX], p1[NBX * NBX], gn[NBX * NBX];
+#pragma unroll
+    for (int j = 0; j < NBX; ++j) {
+      mu1[j] = n_mu[j];
+      drr[j] = q_tr(q, av[j] - n_m3[j]);  // row form
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) {
+        s1[i * NBX + j] = i <= j ? n_s1[i * NBX + j] : R(0);
+        jt[i * NBX + j] = n_jt[i * NBX + j];
+        if (i <= j) ds[i * NBX + j] = cm[i * NBX + j] - n_s3[i * NBX + j];
+        p1[i * NBX + j] = R(0);
+        gn[i * NBX + j] = R(0);
+      }
+    }
+    fetch(t > t_lo ? t - 1 : t_lo);
+#pragma unroll
+    for (int i = 0; i < NBX; ++i)
+#pragma unroll
+      for (int j = 0; j < i; ++j) ds[i * NBX + j] = q_tr(q, ds[j * NBX + i]);
+#pragma unroll
+    for (int j = 0; j < NBX; ++j) {
+      R ts = R(0);
+#pragma unroll
+      for (int i = 0; i < NBX; ++i) ts += jt[i * NBX + j] * drr[i];
+      av[j] = mu1[j] + q_colsum(q, ts);
+    }
+    q_tn<NBX, NBX, NBX>(q, ds, jt, p1);               // (C - S3f) Jx^T
+    q_tn<NBX, NBX, NBX, false, true>(q, jt, p1, s1);  // S1 + Jx (...), upper blocks
+    q_tn<NBX, NBX, NBX>(q, jt, g, gn);                // Jx G
+#pragma unroll
+    for (int i = 0; i < NBX; ++i) {  // (the diagonal blocks exactly symmetric again: see the RTS update of the walk)
+      const R st = q_tr(q, s1[i * NBX + i]);
+      s1[i * NBX + i] = up ? s1[i * NBX + i] : st;
+    }
+#pragma unroll
+    for (int k = 0; k < NBX * NBX; ++k) cm[k] = s1[k], g[k] = gn[k];
+  }
+  const Window out = make_window(comp + (unsigned long)ch * EC * B, (unsigned long)EC * ior.rb);
+#pragma unroll
+  for (int j = 0; j < NBX; ++j) {
+    ior.st(out, o_a[j], 4 * j, av[j]);
+#pragma unroll
+    for (int i = 0; i < NBX; ++i) {
+      ior.st(out, o_g[i * NBX + j], NX + 4 * i * NX + 4 * j, g[i * NBX + j]);
+      if (i <= j) ior.st(out, o_c[i * NBX + j], NX + NX * NX + sym_k(i, j), cm[i * NBX + j]);
+    }
   }
 }
 

@@ -173,6 +173,9 @@ def test_hostsim_quad_backward_resolver(lib):
     assert fam(group_lanes=-1) == ("lane", "lane", "chunked")
     assert fam(deterministic_family=True) == ("lane", "lane", "fused")
     assert fam(storage_dtype=torch.float32) == ("quad", "quad", "chunked")  # fp32-stored messages
+    passes = lambda **kw: parity.engine_from_case(g, lib, "cpu", **kw).kernel_family("chunk_passes")  # noqa: E731
+    assert passes() == passes(group_lanes=64, backward_mode="chunked") == passes(group_lanes=Q, backward_mode="chunked") == "quad"
+    assert passes(group_lanes=-1) == "lane"
     N = parity.pkg._native  # the window's edge, asked of the resolver alone (no buffers)
     p = N.I2cProblem()
     p.abi_version, p.model_id, p.T, p.backward_mode, p.inference, p.dtype = N.ABI_VERSION, N.MODEL_IDS["DoubleCartpoleKnown"], 300, N.BWD_AUTO, N.INF_CUBATURE, 0
@@ -182,6 +185,15 @@ def test_hostsim_quad_backward_resolver(lib):
         p.B = B
         assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_BACKWARD)] == want
         assert lib.i2c_backward_schedule(ctypes.byref(p)) == N.BWD_CHUNKED
+    # the compose + stitch passes of that schedule (I2C_SWEEP_CHUNK_PASSES): quad up to 768 trajectories, whatever the walker
+    for B, want in ((1, "quad"), (512, "quad"), (768, "quad"), (769, "lane"), (4096, "lane")):
+        p.B = B
+        assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_CHUNK_PASSES)] == want
+    p.B, p.group_lanes = 4096, -1  # one lane per trajectory everywhere: lane passes; a fused walk has no such passes
+    assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_CHUNK_PASSES)] == "lane"
+    p.B, p.group_lanes = 32768, 0
+    assert lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_CHUNK_PASSES) == -2  # I2C_ENOTSUP
+    p.group_lanes = 0
     p.B, p.T = 1, 6  # too short to chunk: the lane kernels' two-pass schedule, as before
     assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_BACKWARD)] == "lane" and lib.i2c_backward_schedule(ctypes.byref(p)) == N.BWD_TWO_PASS
 

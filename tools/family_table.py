@@ -19,7 +19,7 @@ HORIZON = {"PendulumKnown": 200, "PendulumKnownActReg": 100, "CartpoleKnown": 50
            "LinearKnownMinimumEnergy": 60, "PlanarQuadrotor": 50, "Quadrotor12": 50}
 SCHED = {N.BWD_TWO_PASS: "two-pass", N.BWD_FUSED: "fused", N.BWD_CHUNKED: "chunked"}
 B_MAX = 1 << 18
-SEEDS = [1, 512, 1024, 1025, 2048, 2049, 4096, 4097, 8192, 8193, 12287, 12288, 16384, 20479, 20480, 32768, 65536, 131072, B_MAX]
+SEEDS = [1, 64, 65, 256, 257, 512, 768, 769, 1024, 1025, 2048, 2049, 4096, 4097, 8192, 8193, 12287, 12288, 16384, 20479, 20480, 32768, 65536, 131072, B_MAX]
 
 
 def shape(model_id, B, T, inference=N.INF_CUBATURE, post_layout=0):
@@ -34,6 +34,8 @@ def resolve(lib, model_id, B, T, layout):
     p = shape(model_id, B, T, post_layout=layout)
     fam = lambda sweep: N.FAMILY_NAMES.get(lib.i2c_kernel_family(ctypes.byref(p), sweep), "refused")  # noqa: E731
     sched = SCHED.get(lib.i2c_backward_schedule(ctypes.byref(p)), "refused")
+    if sched == "chunked" and fam(N.SWEEP_CHUNK_PASSES) == "quad":
+        sched += " (compose + stitch: quad)"
     return fam(N.SWEEP_FORWARD), f"{fam(N.SWEEP_BACKWARD)}, {sched}", fam(N.SWEEP_PROPAGATE), fam(N.SWEEP_FILTER)
 
 
