@@ -35,7 +35,7 @@ def resolve(lib, model_id, B, T, layout):
     fam = lambda sweep: N.FAMILY_NAMES.get(lib.i2c_kernel_family(ctypes.byref(p), sweep), "refused")  # noqa: E731
     sched = SCHED.get(lib.i2c_backward_schedule(ctypes.byref(p)), "refused")
     if sched == "chunked" and fam(N.SWEEP_CHUNK_PASSES) == "quad":
-        sched += " (compose + stitch: quad)"
+        sched += " (quad passes)"
     return fam(N.SWEEP_FORWARD), f"{fam(N.SWEEP_BACKWARD)}, {sched}", fam(N.SWEEP_PROPAGATE), fam(N.SWEEP_FILTER)
 
 
@@ -91,7 +91,7 @@ def table(lib=None):
 
 def block(lib=None):
     return (BEGIN + "\n" + table(lib) + "\n\n(cubature rule with `lam = 0`, fp64, `group_lanes = 0`, `backward_mode = \"auto\"`; generated from "
-            "`i2c_kernel_family` / `i2c_backward_schedule`; a request -- `group_lanes`, `backward_mode`, `deterministic_family` -- overrides it, "
+            "`i2c_kernel_family` / `i2c_backward_schedule`; \"quad passes\": compose + stitch in the quad form; a request -- `group_lanes`, `backward_mode`, `deterministic_family` -- overrides it, "
             "INTEGRATION.md section 1b)\n" + END)
 
 
