@@ -184,10 +184,12 @@ typedef struct I2cProblem {
                               trajectory, forward and backward sweeps), the quad kernels otherwise (I2cDims.quad: four trajectories per
                               wavefront) -- the forward sweep and, since round 6, the backward sweep of every d <= 8 model: the fused walk
                               (one pass over the forward messages, no chunk workspace) with backward_mode I2C_BWD_AUTO or
-                              I2C_BWD_FUSED, the chunked schedule with the quad WALKER (compose / stitch / reduce stay lane kernels;
-                              I2cProblem.work as for the lane schedule) with I2C_BWD_CHUNKED -- also the DEFAULT of the d >= 5 models up
-                              to a few hundred trajectories (cartpole 64, double cartpole / planar quadrotor 256: i2c_kernel_family
-                              answers I2C_FAMILY_QUAD, i2c_backward_schedule I2C_BWD_CHUNKED); I2C_BWD_TWO_PASS keeps the lane kernels;
+                              I2C_BWD_FUSED, the chunked schedule with compose, stitch and walk passes in the quad form (the reduction
+                              stays a lane kernel; I2cProblem.work as for the lane schedule) with I2C_BWD_CHUNKED. Parts of that are
+                              also DEFAULTS of the d >= 5 models at small batches: the quad WALKER up to 64 (cartpole) / 256 (double
+                              cartpole, planar quadrotor) trajectories (i2c_kernel_family(.., I2C_SWEEP_BACKWARD) answers
+                              I2C_FAMILY_QUAD, i2c_backward_schedule I2C_BWD_CHUNKED), the quad COMPOSE + STITCH passes up to
+                              256 / 768 / 1024 (I2C_SWEEP_CHUNK_PASSES); I2C_BWD_TWO_PASS keeps the lane kernels;
                               I2C_LANES_QUAD: the quad kernels of a model that also has wave kernels, at any batch size; on a d <= 8
                               model the quad forward sweep only (see the define);
                               (all of these: fp64 or I2C_F64_F32S; the wave kernels: cubature rule with lam = 0; the quad kernels: any
