@@ -127,13 +127,15 @@ def test_hip_quad_chunk_walk_vs_reference_golden(lib, name, tol_d, tol_s):
     assert (eng.forward_family, eng.backward_family, eng.backward_schedule) == ("quad", "quad", "chunked") and eng.work is not None
 
 
-@pytest.mark.parametrize("name,B,want", [("em_dcp_T60", 131, "quad"), ("em_dcp_T60", 259, "lane"), ("em_cartpole_T100", 61, "quad"), ("em_quadrotor_T20", 255, "quad"),
-                                         ("em_quadrotor_T20", 1027, "lane"), ("em_dcp_nondiag_T30", 3, "quad")])
-def test_hip_quad_chunk_walk_is_the_small_batch_default(lib, name, B, want):
-    """Nothing asked for: inside the model's measured window the chunked schedule walks on the quad walker, beyond it on the lane
-    walker -- ragged batches against the batched oracle either way. Asked for on a batch beyond the window: same answers."""
+@pytest.mark.parametrize("name,B,want,passes", [("em_dcp_T60", 131, "quad", "quad"), ("em_dcp_T60", 259, "lane", "quad"), ("em_dcp_T60", 771, "lane", "lane"),
+                                                ("em_cartpole_T100", 61, "quad", "quad"), ("em_cartpole_T100", 259, "lane", "lane"), ("em_quadrotor_T20", 255, "quad", "quad"),
+                                                ("em_quadrotor_T20", 1021, "lane", "quad"), ("em_quadrotor_T20", 1027, "lane", "lane"), ("em_dcp_nondiag_T30", 3, "quad", "quad")])
+def test_hip_quad_chunk_walk_is_the_small_batch_default(lib, name, B, want, passes):
+    """Nothing asked for: inside the model's measured windows the chunked schedule runs its walk pass on the quad walker and its
+    compose + stitch passes in the quad form (two windows: the passes keep their lead to larger batches), beyond them on the lane
+    kernels -- ragged batches against the batched oracle in every combination. Asked for on a batch beyond the windows: same answers."""
     eng, _ = parity.check_batch_against_oracle(name, lib, "cuda", B, 3, tol=1e-6)
-    assert (eng.forward_family, eng.backward_family, eng.backward_schedule) == ("quad", want, "chunked")
+    assert (eng.forward_family, eng.backward_family, eng.backward_schedule, eng.kernel_family("chunk_passes")) == ("quad", want, "chunked", passes)
     if want == "lane":
         eng, _ = parity.check_batch_against_oracle(name, lib, "cuda", B, 3, tol=1e-6, group_lanes=64, backward_mode="chunked")
         assert (eng.backward_family, eng.backward_schedule) == ("quad", "chunked")
@@ -444,20 +446,26 @@ def test_hip_linearize_chunked_backward_equals_sequential(lib, name):
     _linearize_chunked_equals_sequential(lib, "cuda", name, 1e-8)
 
 
-def test_hip_quad_backward_failure_is_per_trajectory(lib):
+@pytest.mark.parametrize("mode", ["auto", "chunked"])
+def test_hip_quad_backward_failure_is_per_trajectory(lib, mode):
     """A smoothed joint that is not positive definite in ONE cell of ONE trajectory (its filtered variance poisoned between the
     sweeps) is reported as that trajectory's failure -- reason 7 (the backward cell), that cell -- and leaves the other three
-    trajectories of its wavefront, and the rest of the batch, untouched."""
+    trajectories of its wavefront, and the rest of the batch, untouched: the fused quad walk, and the chunked schedule with its
+    compose, stitch and walk passes in the quad form."""
     g = load_case("em_dcp_T60")
     x0, mu_u = parity.batched_inputs(g, 6)
-    eng = parity.engine_from_case(g, lib, "cuda", x0=x0, mu_u=mu_u, group_lanes=64)
-    clean = parity.engine_from_case(g, lib, "cuda", x0=x0, mu_u=mu_u, group_lanes=64)
+    eng = parity.engine_from_case(g, lib, "cuda", x0=x0, mu_u=mu_u, group_lanes=64, backward_mode=mode)
+    clean = parity.engine_from_case(g, lib, "cuda", x0=x0, mu_u=mu_u, group_lanes=64, backward_mode=mode)
     for e in (eng, clean):
         e.forward_sweep()
     eng.fwd[17, eng.d, 2] = -1.0  # sig_xu1_f[0][0] of cell 17, trajectory 2
     for e in (eng, clean):
         e.backward_sweep()
-    assert eng.backward_family == "quad" and eng.failures() == [(2, 7, 17)] and clean.failures() == []
+    assert eng.backward_family == "quad" and clean.failures() == []
+    if mode == "auto":
+        assert eng.failures() == [(2, 7, 17)]
+    else:  # (the chunks walk concurrently: whichever cell of trajectory 2 noticed first is recorded)
+        assert eng.kernel_family("chunk_passes") == "quad" and [(b, r) for b, r, _ in eng.failures()] == [(2, 7)]
     ok = [0, 1, 3, 4, 5]
     for a, b in zip(eng.marginal_state_action() + eng.local_linear_policy(), clean.marginal_state_action() + clean.local_linear_policy()):
         assert torch.equal(a[ok], b[ok])

@@ -570,20 +570,27 @@ def test_hostsim_linearize_chunked_backward_equals_sequential(lib, name):
     _linearize_chunked_equals_sequential(lib, "cpu", name, 1e-9)
 
 
-def test_hostsim_quad_backward_failure_is_per_trajectory(lib):
+@pytest.mark.parametrize("mode", ["auto", "chunked"])
+def test_hostsim_quad_backward_failure_is_per_trajectory(lib, mode):
     """A smoothed joint that is not positive definite in ONE cell of ONE trajectory (its filtered variance poisoned between the
     sweeps) is reported as that trajectory's failure -- reason 7 (the backward cell), that cell -- and leaves the other three
-    trajectories of its wavefront, and the rest of the batch, untouched."""
+    trajectories of its wavefront, and the rest of the batch, untouched. The fused quad walk, and the chunked schedule with its
+    compose, stitch and walk passes in the quad form (the poisoned cell then also enters a composite: its chunk and the ones the
+    stitch pass reaches after it belong to that trajectory alone)."""
     g = load_case("em_dcp_T60")
     x0, mu_u = parity.batched_inputs(g, 6)
-    eng = parity.engine_from_case(g, lib, "cpu", x0=x0, mu_u=mu_u, group_lanes=64)
-    clean = parity.engine_from_case(g, lib, "cpu", x0=x0, mu_u=mu_u, group_lanes=64)
+    eng = parity.engine_from_case(g, lib, "cpu", x0=x0, mu_u=mu_u, group_lanes=64, backward_mode=mode)
+    clean = parity.engine_from_case(g, lib, "cpu", x0=x0, mu_u=mu_u, group_lanes=64, backward_mode=mode)
     for e in (eng, clean):
         e.forward_sweep()
     eng.fwd[17, eng.d, 2] = -1.0  # sig_xu1_f[0][0] of cell 17, trajectory 2
     for e in (eng, clean):
         e.backward_sweep()
-    assert eng.backward_family == "quad" and eng.failures() == [(2, 7, 17)] and clean.failures() == []
+    assert eng.backward_family == "quad" and clean.failures() == []
+    if mode == "auto":
+        assert eng.failures() == [(2, 7, 17)]
+    else:  # (the chunks walk concurrently: whichever cell of trajectory 2 noticed first is recorded)
+        assert eng.kernel_family("chunk_passes") == "quad" and [(b, r) for b, r, _ in eng.failures()] == [(2, 7)]
     ok = [0, 1, 3, 4, 5]
     for a, b in zip(eng.marginal_state_action() + eng.local_linear_policy(), clean.marginal_state_action() + clean.local_linear_policy()):
         assert torch.equal(a[ok], b[ok])
