@@ -136,7 +136,7 @@ def test_reference_covariance_control_scripts_run_unmodified(tmp_path, script, m
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "scripts")), reason="reference checkout not present")
 def test_reference_runner_accepts_every_working_shipped_config(tmp_path):
-    """scripts/i2c_run.py:run() over the shipped known-model experiment files (3 EM iterations each, evaluation rollouts,
+    """scripts/i2c_run.py:run() over the shipped known-model experiment files (2 EM iterations each, evaluation rollouts,
     plan files): cubature and Linearize configs of the linear system, pendulum, cartpole and double cartpole. The two
     remaining files (double_cartpole_known_quad / _gh) do not load in the reference either (`msg_iter`,
     `GaussHermiteCubatureQuadrature`)."""
@@ -158,7 +158,7 @@ def test_reference_runner_accepts_every_working_shipped_config(tmp_path):
         for name in {configs!r}:
             np.random.seed(0)
             ex = importlib.import_module("experiments." + name)
-            ex.N_INFERENCE, ex.N_ITERS_PER_PLOT = 3, 100
+            ex.N_INFERENCE, ex.N_ITERS_PER_PLOT = 2, 100
             with tempfile.TemporaryDirectory() as d:
                 runner.run(ex, d, None)
                 assert os.path.exists(os.path.join(d, "xu_plan.npy")), name
