@@ -128,7 +128,7 @@ def test_hip_quad_chunk_walk_vs_reference_golden(lib, name, tol_d, tol_s):
 
 
 @pytest.mark.parametrize("name,B,want,passes", [("em_dcp_T60", 131, "quad", "quad"), ("em_dcp_T60", 259, "lane", "quad"), ("em_dcp_T60", 771, "lane", "lane"),
-                                                ("em_cartpole_T100", 61, "quad", "quad"), ("em_cartpole_T100", 259, "lane", "lane"), ("em_quadrotor_T20", 255, "quad", "quad"),
+                                                ("em_cartpole_T100", 61, "quad", "quad"), ("em_cartpole_T100", 131, "lane", "quad"), ("em_cartpole_T100", 259, "lane", "lane"), ("em_quadrotor_T20", 255, "quad", "quad"),
                                                 ("em_quadrotor_T20", 1021, "lane", "quad"), ("em_quadrotor_T20", 1027, "lane", "lane"), ("em_dcp_nondiag_T30", 3, "quad", "quad")])
 def test_hip_quad_chunk_walk_is_the_small_batch_default(lib, name, B, want, passes):
     """Nothing asked for: inside the model's measured windows the chunked schedule runs its walk pass on the quad walker and its
