@@ -49,6 +49,15 @@ python3 tools/bench_mpc.py 1024 8192 > "$OUT/mpc_steps.txt" 2>&1
 python3 tools/bench_mpc12.py 1024 8192 >> "$OUT/mpc_steps.txt" 2>&1
 python3 tools/sweep_batch.py > "$OUT/batch_sweep.txt" 2>&1
 python3 tools/bench_reference_shapes.py > "$OUT/reference_shapes.txt" 2>&1
+# the quad passes of the chunked schedule at small batches (profiles/r6_quad_chunk_passes.txt; the A/B with the passes forced off:
+# I2C_QUAD_PASSES_MAX_B=0), and every backward form in one kernel trace at B = 64 (profiles/r6_{dcp,planar}_B64_walkers_kernel_stats.csv)
+python3 tools/bench_quad_backward8.py PlanarQuadrotor DoubleCartpoleKnown CartpoleKnown 1 64 128 256 512 768 1024 2048 4096 mpc > "$OUT/quad_chunk_passes.txt" 2>&1
+I2C_QUAD_PASSES_MAX_B=0 python3 tools/bench_quad_backward8.py PlanarQuadrotor DoubleCartpoleKnown CartpoleKnown 1 64 256 768 1024 > "$OUT/quad_chunk_passes_off.txt" 2>&1
+for M in DoubleCartpoleKnown:dcp PlanarQuadrotor:planar; do
+  N=${M%%:*}; S=${M##*:}
+  rocprofv3 --kernel-trace --stats $F -d "$OUT/kt_${S}_B64" -- python3 tools/bench_quad_backward8.py $N 64 > "$OUT/${S}_B64.txt" 2> "$OUT/log_kt_${S}_B64.txt"
+  f=$(find "$OUT/kt_${S}_B64" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/r6_${S}_B64_walkers_kernel_stats.csv"
+done
 for d in kt kt_dcp kt_planar kt_cartpole kt_q12_1024 kt_q12_8192 kt_q12_32768 kt_planar_mpc kt_q12_mpc; do
   f=$(find "$OUT/$d" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${d}_kernel_stats.csv"
 done
