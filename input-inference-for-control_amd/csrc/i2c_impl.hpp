@@ -1046,7 +1046,10 @@ template <class M, typename R, typename S = R> struct Impl {
   // quad_chunk_passes_window; I2C_FAMILY_LANE otherwise (i2c_kernel_family(problem, I2C_SWEEP_CHUNK_PASSES) reports it)
   static int chunk_passes_family(const I2cProblem* p, const C& c) {
     if constexpr (HAS_QUAD_BACKWARD && !QG<M>::WIDE && LANE) {
-      if (p->inference == I2C_INF_CUBATURE && quad_supported(p, c) == I2C_OK) {
+      // (the composites are addressed through 32-bit offsets of one window per chunk, masked lanes parked at 2 GiB: arithmetic-typed
+      //  rows, which quad_supported's storage-typed bound does not cover under fp32 storage)
+      constexpr long EC = M::NX + M::NX * M::NX + sym(M::NX);
+      if (p->inference == I2C_INF_CUBATURE && quad_supported(p, c) == I2C_OK && EC * (long)p->B * (long)sizeof(R) < (1L << 31)) {
         if (p->group_lanes == 64 && p->backward_mode == I2C_BWD_CHUNKED) return I2C_FAMILY_QUAD;
         static const int forced_max = [] {  // experiment knob (not part of the ABI): overrides the model's window
           const char* e = getenv("I2C_QUAD_PASSES_MAX_B");

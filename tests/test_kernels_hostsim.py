@@ -193,7 +193,14 @@ def test_hostsim_quad_backward_resolver(lib):
     assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_CHUNK_PASSES)] == "lane"
     p.B, p.group_lanes = 32768, 0
     assert lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_CHUNK_PASSES) == -2  # I2C_ENOTSUP
-    p.group_lanes = 0
+    # fp32-stored messages, 4.5 million trajectories, the whole schedule asked for in the quad form: the storage-typed cell windows
+    # still fit 2 GiB (the walker is served), the arithmetic-typed composites do not (compose + stitch stay lane kernels)
+    p.B, p.group_lanes, p.backward_mode, p.dtype = 4_500_000, 64, N.BWD_CHUNKED, N.F64_F32S
+    assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_BACKWARD)] == "quad"
+    assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_CHUNK_PASSES)] == "lane"
+    p.B = 1024
+    assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_CHUNK_PASSES)] == "quad"
+    p.group_lanes, p.backward_mode, p.dtype = 0, N.BWD_AUTO, 0
     p.B, p.T = 1, 6  # too short to chunk: the lane kernels' two-pass schedule, as before
     assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_BACKWARD)] == "lane" and lib.i2c_backward_schedule(ctypes.byref(p)) == N.BWD_TWO_PASS
 
