@@ -107,7 +107,10 @@ enum { I2C_SWEEP_FORWARD = 0, I2C_SWEEP_BACKWARD = 1, I2C_SWEEP_PROPAGATE = 2, I
        /* the compose + stitch passes of the CHUNKED backward schedule (sigma-point rules): I2C_FAMILY_LANE, or I2C_FAMILY_QUAD inside
         * the model's measured window / when group_lanes = 64 asks for the chunked schedule; I2C_ENOTSUP when the problem's backward
         * sweep does not run that schedule. The walk pass is what I2C_SWEEP_BACKWARD reports. */
-       I2C_SWEEP_CHUNK_PASSES = 4 };
+       I2C_SWEEP_CHUNK_PASSES = 4,
+       /* the stitch pass of that schedule alone: it keeps the quad form to larger batches than the compose pass (a chain of NC
+        * dependent steps on few wavefronts at any batch size) */
+       I2C_SWEEP_CHUNK_STITCH = 5 };
 /* hybrid default of a d >= 7 lane model WHOSE QUAD FORWARD KERNEL DOES NOT APPLY (none of the in-tree models since round 6: the quad
  * kernels take any cubature weights; an out-of-tree model with GROUP_FORWARD_AUTO and no quad form): its FORWARD sweep runs on the
  * group kernels while B * G stays within this many lanes (every group wave then has a SIMD of its own: 1024 SIMDs x 64 lanes).
@@ -189,7 +192,8 @@ typedef struct I2cProblem {
                               also DEFAULTS of the d >= 5 models at small batches: the quad WALKER up to 64 (cartpole) / 256 (double
                               cartpole, planar quadrotor) trajectories (i2c_kernel_family(.., I2C_SWEEP_BACKWARD) answers
                               I2C_FAMILY_QUAD, i2c_backward_schedule I2C_BWD_CHUNKED), the quad COMPOSE + STITCH passes up to
-                              256 / 768 / 1024 (I2C_SWEEP_CHUNK_PASSES); I2C_BWD_TWO_PASS keeps the lane kernels;
+                              256 / 768 / 1024 (I2C_SWEEP_CHUNK_PASSES), the stitch pass alone up to 2048 / 8192 / 4096
+                              (I2C_SWEEP_CHUNK_STITCH); I2C_BWD_TWO_PASS keeps the lane kernels;
                               I2C_LANES_QUAD: the quad kernels of a model that also has wave kernels, at any batch size; on a d <= 8
                               model the quad forward sweep only (see the define);
                               (all of these: fp64 or I2C_F64_F32S; the wave kernels: cubature rule with lam = 0; the quad kernels: any

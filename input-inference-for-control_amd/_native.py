@@ -23,7 +23,7 @@ BWD_AUTO, BWD_TWO_PASS, BWD_FUSED, BWD_CHUNKED = 0, 1, 2, 3
 INF_CUBATURE, INF_LINEARIZE, INF_GAUSS_HERMITE = 0, 1, 2
 FAMILY_LANE, FAMILY_GROUP, FAMILY_WAVE, FAMILY_QUAD = 1, 2, 3, 4  # i2c_kernel_family()
 FAMILY_NAMES = {FAMILY_LANE: "lane", FAMILY_GROUP: "group", FAMILY_WAVE: "wave", FAMILY_QUAD: "quad"}
-SWEEP_FORWARD, SWEEP_BACKWARD, SWEEP_PROPAGATE, SWEEP_FILTER, SWEEP_CHUNK_PASSES = 0, 1, 2, 3, 4
+SWEEP_FORWARD, SWEEP_BACKWARD, SWEEP_PROPAGATE, SWEEP_FILTER, SWEEP_CHUNK_PASSES, SWEEP_CHUNK_STITCH = 0, 1, 2, 3, 4, 5
 LANES_QUAD = 164  # I2cProblem.group_lanes: the quad kernels of a model that also has wave kernels; on a d <= 8 model the quad FORWARD sweep only (I2C_LANES_QUAD)
 
 PLUGIN_BASE = 64  # I2C_MODEL_PLUGIN_BASE: ids of out-of-tree models start here

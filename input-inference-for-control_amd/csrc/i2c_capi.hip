@@ -106,7 +106,7 @@ int i2c_backward_schedule(const I2cProblem* p) {
 }
 
 int i2c_kernel_family(const I2cProblem* p, int sweep) {
-  if (sweep < I2C_SWEEP_FORWARD || sweep > I2C_SWEEP_CHUNK_PASSES) return I2C_EINVAL;
+  if (sweep < I2C_SWEEP_FORWARD || sweep > I2C_SWEEP_CHUNK_STITCH) return I2C_EINVAL;
   I2C_DISPATCH_SHAPE(p, family(p, sweep));
 }
 

@@ -950,6 +950,14 @@ template <class M> struct quad_chunk_passes_window<M, std::void_t<decltype(M::QU
   static constexpr int min_b = M::QUAD_CHUNK_PASSES_MIN_B, max_b = M::QUAD_CHUNK_PASSES_MAX_B;
 };
 
+// ... and the batch size up to which the STITCH pass alone stays in the quad form (i2c_models.hpp: QUAD_CHUNK_STITCH_MAX_B)
+template <class M, class = void> struct quad_chunk_stitch_window {
+  static constexpr int max_b = -1;
+};
+template <class M> struct quad_chunk_stitch_window<M, std::void_t<decltype(M::QUAD_CHUNK_STITCH_MAX_B)>> {
+  static constexpr int max_b = M::QUAD_CHUNK_STITCH_MAX_B;
+};
+
 // ---- per-(model, dtype) entry points ------------------------------------------------------
 // Which kernels serve a call:
 //   M::GROUP      lanes per trajectory of the model's group kernels (0: none compiled); fp64 only
@@ -1061,6 +1069,21 @@ template <class M, typename R, typename S = R> struct Impl {
     }
     return I2C_FAMILY_LANE;
   }
+  // the STITCH pass alone in the quad form, beyond the window of the pair: the pass is a chain of NC dependent steps on B / 64 lane
+  // wavefronts whatever the batch -- 0.85 us per quad step against 1.6 - 2.5 us per lane step (experiment: I2C_QUAD_STITCH_MAX_B)
+  static bool quad_stitch_alone(const I2cProblem* p, const C& c) {
+    if constexpr (HAS_QUAD_BACKWARD && !QG<M>::WIDE && LANE) {
+      static const int forced_max = [] {
+        const char* e = getenv("I2C_QUAD_STITCH_MAX_B");
+        return e ? atoi(e) : -2;
+      }();
+      constexpr long EC = M::NX + M::NX * M::NX + sym(M::NX);
+      const int max_b = forced_max > -2 ? forced_max : quad_chunk_stitch_window<M>::max_b;
+      return p->inference == I2C_INF_CUBATURE && (p->group_lanes == 0 || p->group_lanes == I2C_LANES_QUAD) && p->B <= max_b && quad_supported(p, c) == I2C_OK &&
+             EC * (long)p->B * (long)sizeof(R) < (1L << 31);
+    }
+    return false;
+  }
   static constexpr bool HAS_QUAD_CKF = HAS_QUAD && !MIXED && quad_ckf_exists<M>();  // the filter step of the d = 16 form
   static constexpr bool HAS_QUAD_PROP = HAS_QUAD && !MIXED && quad_propagate_exists<M>();  // the closed-loop propagation of the d = 16 form
   static int family(const I2cProblem* p, const C& c, const int sweep) {
@@ -1159,6 +1182,12 @@ template <class M, typename R, typename S = R> struct Impl {
       if (mode < 0) return mode;
       if (mode != I2C_BWD_CHUNKED || q.inference != I2C_INF_CUBATURE) return I2C_ENOTSUP;
       return chunk_passes_family(&q, c);
+    }
+    if (sweep == I2C_SWEEP_CHUNK_STITCH) {  // the stitch pass of that schedule: with the compose pass, or alone inside its own window
+      const int mode = plan(&q);
+      if (mode < 0) return mode;
+      if (mode != I2C_BWD_CHUNKED || q.inference != I2C_INF_CUBATURE) return I2C_ENOTSUP;
+      return (chunk_passes_family(&q, c) == I2C_FAMILY_QUAD || quad_stitch_alone(&q, c)) ? I2C_FAMILY_QUAD : I2C_FAMILY_LANE;
     }
     return family(&q, c, sweep);
   }
@@ -1422,17 +1451,24 @@ template <class M, typename R, typename S = R> struct Impl {
       CellArgs<R, S> ared = a;
       ared.cell_stats = ch.part;
       int rc;
-      bool lane_passes = true;
+      bool quad_compose = false, quad_stitch = false;
       if constexpr (HAS_QUAD_BACKWARD && !QG<M>::WIDE) {
-        if (chunk_passes_family(p, c) == I2C_FAMILY_QUAD) {  // compose + stitch, four trajectories per wavefront
-          lane_passes = false;
-          rc = launch_quad_chunk_compose<M, R, S>(c, ch, stream);
-          if (rc == I2C_OK) rc = launch_quad_chunk_stitch<M, R, S>(c, ch, stream);
-        }
+        quad_compose = chunk_passes_family(p, c) == I2C_FAMILY_QUAD;  // compose + stitch, four trajectories per wavefront
+        quad_stitch = quad_compose || quad_stitch_alone(p, c);       // ... or the stitch pass alone (a chain of NC steps whatever the batch)
       }
-      if (lane_passes) {
+      if (quad_compose) {
+        if constexpr (HAS_QUAD_BACKWARD && !QG<M>::WIDE) rc = launch_quad_chunk_compose<M, R, S>(c, ch, stream);
+        else rc = I2C_ENOTSUP;
+      } else {
         rc = launch(k_chunk_compose<M, R, S>, p->B, ch.n_chunks, LANE_BLOCK, stream, c, ch);
-        if (rc == I2C_OK) rc = launch(k_chunk_stitch<M, R, S>, p->B, 1, LANE_BLOCK, stream, c, ch);
+      }
+      if (rc == I2C_OK) {
+        if (quad_stitch) {
+          if constexpr (HAS_QUAD_BACKWARD && !QG<M>::WIDE) rc = launch_quad_chunk_stitch<M, R, S>(c, ch, stream);
+          else rc = I2C_ENOTSUP;
+        } else {
+          rc = launch(k_chunk_stitch<M, R, S>, p->B, 1, LANE_BLOCK, stream, c, ch);
+        }
       }
       if (rc == I2C_OK) {
         if (quad_walk) {

@@ -376,9 +376,10 @@ class BatchedI2c:
     def kernel_family(self, sweep="forward"):
         """Which kernel family serves a sweep of THIS problem ("lane", "group", "wave" or "quad"): i2c_kernel_family(), the library's
         single resolver of group_lanes, model defaults and batch thresholds. The last bits of a result depend on it.
-        "chunk_passes": the compose + stitch passes of the chunked backward schedule (refused when another schedule runs)."""
+        "chunk_passes": the compose + stitch passes of the chunked backward schedule, "chunk_stitch": its stitch pass alone (refused
+        when another schedule runs)."""
         code = {"forward": _native.SWEEP_FORWARD, "backward": _native.SWEEP_BACKWARD, "propagate": _native.SWEEP_PROPAGATE,
-                "filter": _native.SWEEP_FILTER, "chunk_passes": _native.SWEEP_CHUNK_PASSES}[sweep]
+                "filter": _native.SWEEP_FILTER, "chunk_passes": _native.SWEEP_CHUNK_PASSES, "chunk_stitch": _native.SWEEP_CHUNK_STITCH}[sweep]
         rc = self.lib.i2c_kernel_family(C.byref(self._problem), code)
         self._check(0 if rc > 0 else (rc or -1), "i2c_kernel_family")
         return _native.FAMILY_NAMES[rc]

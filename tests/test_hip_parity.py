@@ -127,15 +127,19 @@ def test_hip_quad_chunk_walk_vs_reference_golden(lib, name, tol_d, tol_s):
     assert (eng.forward_family, eng.backward_family, eng.backward_schedule) == ("quad", "quad", "chunked") and eng.work is not None
 
 
-@pytest.mark.parametrize("name,B,want,passes", [("em_dcp_T60", 131, "quad", "quad"), ("em_dcp_T60", 259, "lane", "quad"), ("em_dcp_T60", 771, "lane", "lane"),
-                                                ("em_cartpole_T100", 61, "quad", "quad"), ("em_cartpole_T100", 131, "lane", "quad"), ("em_cartpole_T100", 259, "lane", "lane"), ("em_quadrotor_T20", 255, "quad", "quad"),
-                                                ("em_quadrotor_T20", 1021, "lane", "quad"), ("em_quadrotor_T20", 1027, "lane", "lane"), ("em_dcp_nondiag_T30", 3, "quad", "quad")])
-def test_hip_quad_chunk_walk_is_the_small_batch_default(lib, name, B, want, passes):
-    """Nothing asked for: inside the model's measured windows the chunked schedule runs its walk pass on the quad walker and its
-    compose + stitch passes in the quad form (two windows: the passes keep their lead to larger batches), beyond them on the lane
-    kernels -- ragged batches against the batched oracle in every combination. Asked for on a batch beyond the windows: same answers."""
+@pytest.mark.parametrize("name,B,want,passes,stitch", [
+    ("em_dcp_T60", 131, "quad", "quad", "quad"), ("em_dcp_T60", 259, "lane", "quad", "quad"), ("em_dcp_T60", 771, "lane", "lane", "quad"),
+    ("em_cartpole_T100", 61, "quad", "quad", "quad"), ("em_cartpole_T100", 131, "lane", "quad", "quad"), ("em_cartpole_T100", 259, "lane", "lane", "quad"),
+    ("em_cartpole_T100", 2051, "lane", "lane", "lane"), ("em_quadrotor_T20", 255, "quad", "quad", "quad"), ("em_quadrotor_T20", 1021, "lane", "quad", "quad"),
+    ("em_quadrotor_T20", 1027, "lane", "lane", "quad"), ("em_dcp_nondiag_T30", 3, "quad", "quad", "quad")])
+def test_hip_quad_chunk_walk_is_the_small_batch_default(lib, name, B, want, passes, stitch):
+    """Nothing asked for: inside the model's measured windows the chunked schedule runs its walk pass on the quad walker, its compose +
+    stitch passes in the quad form, its stitch pass alone in the quad form (three nested windows: walker < compose < stitch), beyond
+    them on the lane kernels -- ragged batches against the batched oracle in every combination. Asked for on a batch beyond the
+    windows: same answers."""
     eng, _ = parity.check_batch_against_oracle(name, lib, "cuda", B, 3, tol=1e-6)
-    assert (eng.forward_family, eng.backward_family, eng.backward_schedule, eng.kernel_family("chunk_passes")) == ("quad", want, "chunked", passes)
+    assert (eng.forward_family, eng.backward_family, eng.backward_schedule) == ("quad", want, "chunked")
+    assert (eng.kernel_family("chunk_passes"), eng.kernel_family("chunk_stitch")) == (passes, stitch)
     if want == "lane":
         eng, _ = parity.check_batch_against_oracle(name, lib, "cuda", B, 3, tol=1e-6, group_lanes=64, backward_mode="chunked")
         assert (eng.backward_family, eng.backward_schedule) == ("quad", "chunked")

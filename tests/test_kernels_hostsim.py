@@ -189,7 +189,12 @@ def test_hostsim_quad_backward_resolver(lib):
     for B, want in ((1, "quad"), (512, "quad"), (768, "quad"), (769, "lane"), (4096, "lane")):
         p.B = B
         assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_CHUNK_PASSES)] == want
+    # ... and the stitch pass ALONE keeps the quad form up to 8192 trajectories (I2C_SWEEP_CHUNK_STITCH)
+    for B, want in ((768, "quad"), (769, "quad"), (8192, "quad"), (8193, "lane")):
+        p.B = B
+        assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_CHUNK_STITCH)] == want
     p.B, p.group_lanes = 4096, -1  # one lane per trajectory everywhere: lane passes; a fused walk has no such passes
+    assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_CHUNK_STITCH)] == "lane"
     assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_CHUNK_PASSES)] == "lane"
     p.B, p.group_lanes = 32768, 0
     assert lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_CHUNK_PASSES) == -2  # I2C_ENOTSUP
@@ -203,6 +208,32 @@ def test_hostsim_quad_backward_resolver(lib):
     p.group_lanes, p.backward_mode, p.dtype = 0, N.BWD_AUTO, 0
     p.B, p.T = 1, 6  # too short to chunk: the lane kernels' two-pass schedule, as before
     assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_BACKWARD)] == "lane" and lib.i2c_backward_schedule(ctypes.byref(p)) == N.BWD_TWO_PASS
+
+
+def test_hostsim_quad_stitch_between_lane_compose_and_lane_walk():
+    """The pairing of the BASELINE batches of the d >= 5 models: lane compose pass, QUAD stitch pass, lane walker (one composite
+    format, one boundary format). The windows that select it start beyond what the host simulation can run, so a child process
+    forces them with the library's experiment knobs (read once per process) and checks two goldens end to end."""
+    import os
+    import subprocess
+    import sys as _sys
+    import textwrap
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = textwrap.dedent(f"""
+        import sys
+        sys.path[:0] = [{ROOT!r}, {os.path.join(ROOT, "input-inference-for-control_amd")!r}, {os.path.join(ROOT, "tests")!r}]
+        import hostsim, parity
+        lib = hostsim.load()
+        for name, td, ts in (("em_dcp_T60", 1e-7, 1e-6), ("em_quadrotor_T20", 1e-7, 1e-6), ("em_covctrl_qf_T40", 1e-8, 1e-7)):
+            eng = parity.check_against_golden(name, lib, "cpu", td, ts, backward_mode="chunked")
+            fams = (eng.backward_family, eng.backward_schedule, eng.kernel_family("chunk_passes"), eng.kernel_family("chunk_stitch"))
+            assert fams == ("lane", "chunked", "lane", "quad"), fams
+        print("ok")
+    """)
+    env = dict(os.environ, I2C_QUAD_PASSES_MAX_B="0", I2C_QUAD_STITCH_MAX_B="1000")
+    r = subprocess.run([_sys.executable, "-c", script], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
 def test_hostsim_quad_backward_optional_outputs_and_statistics(lib):

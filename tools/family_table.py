@@ -36,6 +36,8 @@ def resolve(lib, model_id, B, T, layout):
     sched = SCHED.get(lib.i2c_backward_schedule(ctypes.byref(p)), "refused")
     if sched == "chunked" and fam(N.SWEEP_CHUNK_PASSES) == "quad":
         sched += " (quad passes)"
+    elif sched == "chunked" and fam(N.SWEEP_CHUNK_STITCH) == "quad":
+        sched += " (quad stitch)"
     return fam(N.SWEEP_FORWARD), f"{fam(N.SWEEP_BACKWARD)}, {sched}", fam(N.SWEEP_PROPAGATE), fam(N.SWEEP_FILTER)
 
 
@@ -90,9 +92,8 @@ def table(lib=None):
 
 
 def block(lib=None):
-    return (BEGIN + "\n" + table(lib) + "\n\n(cubature rule with `lam = 0`, fp64, `group_lanes = 0`, `backward_mode = \"auto\"`; generated from "
-            "`i2c_kernel_family` / `i2c_backward_schedule`; \"quad passes\": compose + stitch in the quad form; a request -- `group_lanes`, `backward_mode`, `deterministic_family` -- overrides it, "
-            "INTEGRATION.md section 1b)\n" + END)
+    return (BEGIN + "\n" + table(lib) + "\n\n(`lam = 0`, fp64, nothing asked for; from `i2c_kernel_family` / `i2c_backward_schedule`; quad passes / quad stitch: "
+            "compose + stitch / the stitch pass alone in the quad form; requests override it: INTEGRATION.md section 1b)\n" + END)
 
 
 if __name__ == "__main__":
