@@ -192,7 +192,7 @@ typedef struct I2cProblem {
                               also DEFAULTS of the d >= 5 models at small batches: the quad WALKER up to 64 (cartpole) / 256 (double
                               cartpole, planar quadrotor) trajectories (i2c_kernel_family(.., I2C_SWEEP_BACKWARD) answers
                               I2C_FAMILY_QUAD, i2c_backward_schedule I2C_BWD_CHUNKED), the quad COMPOSE + STITCH passes up to
-                              256 / 768 / 1024 (I2C_SWEEP_CHUNK_PASSES), the stitch pass alone up to 2048 / 8192 / 4096
+                              128 / 256 / 384 (I2C_SWEEP_CHUNK_PASSES), the stitch pass alone up to 2048 / 8192 / 4096
                               (I2C_SWEEP_CHUNK_STITCH); I2C_BWD_TWO_PASS keeps the lane kernels;
                               I2C_LANES_QUAD: the quad kernels of a model that also has wave kernels, at any batch size; on a d <= 8
                               model the quad forward sweep only (see the define);

@@ -145,7 +145,7 @@ struct Cartpole {
   static constexpr int QUAD_FORWARD_MIN_B = 0;
   static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (d = 16 only; the d <= 8 quad backward walk has no default window: on request)
   static constexpr int QUAD_CHUNK_WALK_MIN_B = 1, QUAD_CHUNK_WALK_MAX_B = 64;  // the chunked schedule's walk pass on the quad walker by default (measured, profiles/r6_quad_chunk_walk.txt: B = 1 / 64: backward sweep 0.090 / 0.078 -> 0.069 / 0.074 ms; 256: 0.082 -> 0.091)
-  static constexpr int QUAD_CHUNK_PASSES_MIN_B = 1, QUAD_CHUNK_PASSES_MAX_B = 256;  // compose + stitch passes in the quad form by default (measured, profiles/r6_quad_chunk_passes.txt: backward sweep B = 1 / 128 / 256: 0.069 / 0.079 / 0.082 -> 0.044 / 0.068 / 0.078 ms; 512: 0.084 -> 0.099)
+  static constexpr int QUAD_CHUNK_PASSES_MIN_B = 1, QUAD_CHUNK_PASSES_MAX_B = 128;  // compose pass (+ stitch) in the quad form by default (measured with the quad stitch on, profiles/r6_quad_chunk_passes.txt: backward sweep B = 64 / 128: 0.066 / 0.072 -> 0.061 / 0.068 ms; 256: 0.074 -> 0.078)
   static constexpr int QUAD_CHUNK_STITCH_MAX_B = 2048;  // ... and the stitch pass alone up to here (backward sweep B = 1024 / 2048: 0.114 / 0.221 -> 0.107 / 0.213 ms; 4096: level)
   I2C_HD static constexpr int ang(int) { return 1; }
   // z = [x, sin th, cos th, xd, thd, u],  zT = [x, sin th, cos th, xd, thd]
@@ -204,7 +204,7 @@ struct DoubleCartpole {
   static constexpr int QUAD_FORWARD_MIN_B = 0;
   static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (d = 16 only; the d <= 8 quad backward walk has no default window: on request)
   static constexpr int QUAD_CHUNK_WALK_MIN_B = 1, QUAD_CHUNK_WALK_MAX_B = 256;  // the chunked schedule's walk pass on the quad walker by default (measured, profiles/r6_quad_chunk_walk.txt: B = 1 / 64 / 256: backward sweep 0.159 / 0.140 / 0.151 -> 0.119 / 0.123 / 0.145 ms; 512: 0.162 -> 0.188)
-  static constexpr int QUAD_CHUNK_PASSES_MIN_B = 1, QUAD_CHUNK_PASSES_MAX_B = 768;  // compose + stitch passes in the quad form by default (measured, profiles/r6_quad_chunk_passes.txt: backward sweep B = 1 / 256 / 768: 0.116 / 0.144 / 0.182 -> 0.046 / 0.102 / 0.177 ms; 1024: 0.205 -> 0.219)
+  static constexpr int QUAD_CHUNK_PASSES_MIN_B = 1, QUAD_CHUNK_PASSES_MAX_B = 256;  // compose pass (+ stitch) in the quad form by default (measured with the quad stitch on, profiles/r6_quad_chunk_passes.txt: backward sweep B = 64 / 128: 0.082 / 0.087 -> 0.071 / 0.075 ms; 256: level; 512: 0.123 -> 0.141)
   static constexpr int QUAD_CHUNK_STITCH_MAX_B = 8192;  // ... and the stitch pass alone up to here (backward sweep B = 1024 / 4096 / 8192: 0.205 / 0.474 / 0.925 -> 0.164 / 0.463 / 0.854 ms)
   static constexpr int BWD_FUSED_MIN_B = 20480;  // I2C_BWD_AUTO runs the fused backward walk from here up: its rows are the widest (104 doubles), the chunked form keeps its lead longer (measured: 16384: chunked 1.67 / fused 1.86 ms; 24576: 3.44 / 2.20)
   I2C_HD static constexpr int ang(int a) { return a == 0 ? 1 : 2; }
@@ -367,7 +367,7 @@ struct Quadrotor {
   static constexpr int QUAD_FORWARD_MIN_B = 0;
   static constexpr int QUAD_BACKWARD_MIN_B = 0;  // (d = 16 only; the d <= 8 quad backward walk has no default window: on request)
   static constexpr int QUAD_CHUNK_WALK_MIN_B = 1, QUAD_CHUNK_WALK_MAX_B = 256;  // the chunked schedule's walk pass on the quad walker by default (measured, profiles/r6_quad_chunk_walk.txt: B = 1 / 64 / 256: backward sweep 0.065 / 0.059 / 0.059 -> 0.047 / 0.051 / 0.051 ms; 512: 0.062 -> 0.065)
-  static constexpr int QUAD_CHUNK_PASSES_MIN_B = 1, QUAD_CHUNK_PASSES_MAX_B = 1024;  // compose + stitch passes in the quad form by default (measured, profiles/r6_quad_chunk_passes.txt: backward sweep B = 1 / 256 / 1024: 0.048 / 0.051 / 0.067 -> 0.022 / 0.036 / 0.063 ms; 2048: 0.078 -> 0.084)
+  static constexpr int QUAD_CHUNK_PASSES_MIN_B = 1, QUAD_CHUNK_PASSES_MAX_B = 384;  // compose pass (+ stitch) in the quad form by default (measured with the quad stitch on, profiles/r6_quad_chunk_passes.txt: backward sweep B = 64 / 256 / 384: 0.039 / 0.041 / 0.052 -> 0.035 / 0.035 / 0.047 ms; 512: 0.052 -> 0.054; 1024: 0.056 -> 0.063)
   static constexpr int QUAD_CHUNK_STITCH_MAX_B = 4096;  // ... and the stitch pass alone up to here (backward sweep B = 2048 / 4096: 0.078 / 0.110 -> 0.068 / 0.100 ms; 8192: level)
   I2C_HD static constexpr int ang(int) { return 2; }
   I2C_HD static constexpr int obs_lin(int k) { return k; }  // z = xu, zT = x

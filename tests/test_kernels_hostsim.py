@@ -185,8 +185,8 @@ def test_hostsim_quad_backward_resolver(lib):
         p.B = B
         assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_BACKWARD)] == want
         assert lib.i2c_backward_schedule(ctypes.byref(p)) == N.BWD_CHUNKED
-    # the compose + stitch passes of that schedule (I2C_SWEEP_CHUNK_PASSES): quad up to 768 trajectories, whatever the walker
-    for B, want in ((1, "quad"), (512, "quad"), (768, "quad"), (769, "lane"), (4096, "lane")):
+    # the compose (+ stitch) pass of that schedule (I2C_SWEEP_CHUNK_PASSES): quad up to 256 trajectories
+    for B, want in ((1, "quad"), (256, "quad"), (257, "lane"), (4096, "lane")):
         p.B = B
         assert N.FAMILY_NAMES[lib.i2c_kernel_family(ctypes.byref(p), N.SWEEP_CHUNK_PASSES)] == want
     # ... and the stitch pass ALONE keeps the quad form up to 8192 trajectories (I2C_SWEEP_CHUNK_STITCH)
