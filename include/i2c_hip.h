@@ -101,7 +101,8 @@ enum {
 /* I2cProblem.group_lanes = I2C_LANES_QUAD asks for the quad kernels of a model that also has wave kernels (64 = the
  * wave kernels there): the 12-state quadrotor -- forward and backward sweep, at any batch size. On a d <= 8 model it asks for the
  * quad FORWARD sweep only: the backward sweep resolves as group_lanes = 0 does (so I2C_LANES_QUAD with I2C_BWD_CHUNKED is the
- * quad forward sweep + the lane kernels' chunked schedule at any batch size). */
+ * quad forward sweep + the chunked schedule on the lane walker at any batch size; its compose / stitch passes follow the default
+ * windows, I2C_SWEEP_CHUNK_PASSES / _STITCH). */
 #define I2C_LANES_QUAD 164
 enum { I2C_SWEEP_FORWARD = 0, I2C_SWEEP_BACKWARD = 1, I2C_SWEEP_PROPAGATE = 2, I2C_SWEEP_FILTER = 3,
        /* the compose + stitch passes of the CHUNKED backward schedule (sigma-point rules): I2C_FAMILY_LANE, or I2C_FAMILY_QUAD inside
